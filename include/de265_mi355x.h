@@ -226,7 +226,7 @@ typedef struct m355_pic_params {
   uint16_t col_bd[M355_MAX_TILE_COLS + 1];       /* pps.colBd, in CTBs                      */
   uint16_t row_bd[M355_MAX_TILE_ROWS + 1];       /* pps.rowBd                               */
   uint16_t reserved;
-} m355_pic_params;                 /* 108 bytes */
+} m355_pic_params;                 /* 112 bytes */
 
 /* slice (segment) header fields the pixel path reads */
 enum {
@@ -314,7 +314,9 @@ enum {
                                       instead of adding it to the picture                         */
   M355_RBF_RDPCM_H   = 1 << 1,     /* rdpcmMode 1 */
   M355_RBF_RDPCM_V   = 1 << 2,     /* rdpcmMode 2 */
-  M355_RBF_ROTATE    = 1 << 3      /* transform_skip_rotation (transform.cc:400-402) */
+  M355_RBF_ROTATE    = 1 << 3,     /* transform_skip_rotation (transform.cc:400-402) */
+  M355_RBF_DEQUANTIZED = 1 << 4    /* coeffs[] levels are already scaled (what the table slots
+                                      transform_add / transform_skip_residual receive): skip dequant */
 };
 typedef struct m355_rb {
   uint16_t x, y;                   /* position in component samples */

@@ -660,7 +660,7 @@ static void do_residual(pic_state* s) {
       const int pos = e & 0xFFFF;
       const int lvl = (int16_t)(e >> 16);
       if (pos >= nT * nT) continue;
-      if (rb->kind == M355_RK_BYPASS) { coeff[pos] = (int16_t)lvl; continue; }
+      if (rb->kind == M355_RK_BYPASS || (rb->flags & M355_RBF_DEQUANTIZED)) { coeff[pos] = (int16_t)lvl; continue; }
       int bdShift = bd + rb->log2_size - 5;
       int64_t fact;
       if (!(pp->flags & M355_PF_SCALING_LIST)) { bdShift -= 4; fact = (int64_t)level_scale[rb->qp % 6] << (rb->qp / 6); }

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/girlshy*.m355gold.gz from the REAL reference (run in the build container,
+where /root/reference exists):
+
+    python tests/golden/make_girlshy_fixture.py
+
+It runs the reference decoder on testdata/girlshy.h265 through oracle/ref_recorder.cc (built into
+oracle/_ref/libde265_ref.so by `make -C oracle ref`), which records the per-picture work lists the
+pixel path consumes plus the reference's own final planes, and stores
+  * the work lists (decode order),
+  * the MD5 of each plane of each picture as the reference produced it,
+  * the display order + conformance crop, so that the whole-stream YUV MD5 can be re-derived and
+    compared with the reference CI's golden b81538fa33a67278e5263e231e43ca98 (scripts/ci-run.sh:91-92).
+Two variants: the full chain, and deblocking+SAO disabled (dec265 --disable-deblocking --disable-sao,
+golden 098a8f4d62bef69504174073879cd4ad measured with the reference in SURVEY.md 8c).
+"""
+import ctypes
+import gzip
+import hashlib
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from libde265_amd import worklist  # noqa: E402
+
+STREAM = "/root/reference/testdata/girlshy.h265"
+GOLDEN = {"full": "b81538fa33a67278e5263e231e43ca98", "nolf": "098a8f4d62bef69504174073879cd4ad"}
+
+
+def main():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-j8", "ref"], check=True)
+    ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libde265_ref.so"))
+    for variant, (nodeblk, nosao) in {"full": (0, 0), "nolf": (1, 1)}.items():
+        with tempfile.TemporaryDirectory() as td:
+            rec = os.path.join(td, "rec")
+            n = ref.ref_record_stream(STREAM.encode(), rec.encode(), nodeblk, nosao)
+            assert n > 0, n
+            raw = open(rec, "rb").read()
+            planes = open(rec + ".planes", "rb").read()
+            order = [[int(v) for v in l.split()] for l in open(rec + ".order")]
+        assert raw[:8] == b"M355REC1"
+        npic = struct.unpack_from("<i", raw, 8)[0]
+        o, po = 12, 0
+        pics, blobs = [], []
+        by_poc = {}
+        for i in range(npic):
+            poc, dpb, _, _ = struct.unpack_from("<4i", raw, o); o += 16
+            pic, o2 = worklist.Picture.loads(raw, o)
+            blobs.append(raw[o:o2]); o = o2
+            pp = pic.pp[0]
+            dims = worklist.plane_dims(int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]))
+            md5s, pl = [], []
+            for c, (w, h) in enumerate(dims):
+                bpp = 1 if (pp["bit_depth_luma"] if c == 0 else pp["bit_depth_chroma"]) <= 8 else 2
+                nb = w * h * bpp
+                md5s.append(hashlib.md5(planes[po:po + nb]).hexdigest()); pl.append((planes[po:po + nb], w, h, bpp)); po += nb
+            pics.append({"poc": poc, "dpb": dpb, "md5": md5s})
+            by_poc[poc] = pl
+        assert po == len(planes)
+        # re-derive the whole-stream MD5 exactly as `dec265 -o -` writes it (cropped planes, display order)
+        m = hashlib.md5()
+        for poc, w, h, cx, cy in order:
+            for c, (data, pw, ph, bpp) in enumerate(by_poc[poc]):
+                sx = 1 if c == 0 else by_poc[poc][0][1] // pw
+                sy = 1 if c == 0 else by_poc[poc][0][2] // ph
+                cw, ch, ox, oy = w // sx, h // sy, cx // sx, cy // sy
+                for y in range(ch):
+                    s = ((oy + y) * pw + ox) * bpp
+                    m.update(data[s:s + cw * bpp])
+        stream_md5 = m.hexdigest()
+        assert stream_md5 == GOLDEN[variant], (variant, stream_md5)
+        hdr = json.dumps({"stream": "testdata/girlshy.h265", "variant": variant, "stream_md5": stream_md5,
+                          "pictures": pics, "order": order}).encode()
+        out = os.path.join(HERE, "girlshy_%s.m355gold.gz" % variant)
+        with gzip.GzipFile(out, "wb", compresslevel=9, mtime=0) as f:
+            f.write(b"M355GOLD" + struct.pack("<I", len(hdr)) + hdr + b"".join(blobs))
+        print(variant, npic, "pictures, stream md5", stream_md5, "->", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()
