@@ -1,0 +1,156 @@
+"""ctypes binding of the C ABI declared in include/de265_mi355x.h (the product library
+libde265_mi355x.so, built by csrc/Makefile for gfx950).  There is NO fallback: if the library is
+missing or no HIP device is visible, loading / context creation raises."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import worklist
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libde265_mi355x.so")
+
+ERRORS = {1: "M355_ERR_NO_DEVICE", 2: "M355_ERR_HIP", 3: "M355_ERR_INVALID", 4: "M355_ERR_NOMEM", 5: "M355_ERR_TIMEOUT"}
+
+
+class M355Error(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("%s: %s" % (ERRORS.get(code, code), text))
+        self.code = code
+
+
+class Library:
+    """A loaded libde265_mi355x.so with typed entry points."""
+
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise RuntimeError("MI355X backend library not found: %s (build it: make -C libde265_amd/csrc; "
+                               "there is no CPU fallback)" % path)
+        self.path = path
+        L = self.lib = ctypes.CDLL(path)
+        vp, i, cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p
+        L.m355_last_error.restype = cp
+        L.m355_version.restype = cp
+        L.m355_device_count.restype = i
+        L.m355_create.argtypes = [i, ctypes.POINTER(vp)]
+        L.m355_destroy.argtypes = [vp]
+        L.m355_destroy.restype = None
+        L.m355_frame_create.argtypes = [vp, i, i, i, i, i]
+        L.m355_frame_destroy.argtypes = [vp, i]
+        L.m355_frame_upload.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
+        L.m355_frame_download.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
+        L.m355_frame_fill.argtypes = [vp, i, i, i]
+        L.m355_submit_picture.argtypes = [vp, vp]
+        L.m355_wait.argtypes = [vp]
+        L.m355_picture_upload.argtypes = [vp, vp]
+        L.m355_picture_release.argtypes = [vp, i]
+        L.m355_decode_resident.argtypes = [vp, i]
+        L.m355_set_stages.argtypes = [vp, i]
+        L.m355_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.m355_stream.argtypes = [vp]
+        L.m355_stream.restype = vp
+        L.init_acceleration_functions_mi355x.argtypes = [vp]
+
+    def error(self):
+        return (self.lib.m355_last_error() or b"").decode()
+
+    def check(self, rc):
+        if rc != 0:
+            raise M355Error(rc, self.error())
+
+    def device_count(self):
+        return self.lib.m355_device_count()
+
+
+class Context:
+    """One decoding context = one GPU, one HIP stream, a device-resident frame pool."""
+
+    def __init__(self, lib=None, device=0):
+        self.L = lib or Library()
+        h = ctypes.c_void_p()
+        self.L.check(self.L.lib.m355_create(device, ctypes.byref(h)))
+        self.h = h
+        self._geom = {}
+
+    def close(self):
+        if self.h:
+            self.L.lib.m355_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- frames ----
+    def frame_create(self, width, height, chroma_format_idc=1, bit_depth_luma=8, bit_depth_chroma=8):
+        f = self.L.lib.m355_frame_create(self.h, width, height, chroma_format_idc, bit_depth_luma, bit_depth_chroma)
+        if f < 0:
+            raise M355Error(-f, self.L.error())
+        self._geom[f] = (width, height, chroma_format_idc, bit_depth_luma, bit_depth_chroma)
+        return f
+
+    def frame_create_for(self, pp):
+        return self.frame_create(int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]),
+                                 int(pp["bit_depth_luma"]), int(pp["bit_depth_chroma"]))
+
+    def frame_destroy(self, f):
+        self.L.check(self.L.lib.m355_frame_destroy(self.h, f))
+        self._geom.pop(f, None)
+
+    def frame_upload(self, f, planes):
+        for c, a in enumerate(planes):
+            a = np.ascontiguousarray(a)
+            self.L.check(self.L.lib.m355_frame_upload(self.h, f, c, a.ctypes.data, a.shape[1]))
+
+    def frame_download(self, f):
+        w, h, cf, bdl, bdc = self._geom[f]
+        out = []
+        for c, (pw, ph) in enumerate(worklist.plane_dims(w, h, cf)):
+            if pw == 0:
+                continue
+            a = np.zeros((ph, pw), np.uint8 if (bdl if c == 0 else bdc) <= 8 else np.uint16)
+            self.L.check(self.L.lib.m355_frame_download(self.h, f, c, a.ctypes.data, pw))
+            out.append(a)
+        return out
+
+    def frame_fill(self, f, luma, chroma):
+        self.L.check(self.L.lib.m355_frame_fill(self.h, f, luma, chroma))
+
+    # ---- pictures ----
+    def submit(self, pic):
+        c, keep = pic.to_c()
+        self.L.check(self.L.lib.m355_submit_picture(self.h, ctypes.addressof(c)))
+        del keep
+
+    def wait(self):
+        self.L.check(self.L.lib.m355_wait(self.h))
+
+    def upload(self, pic):
+        c, keep = pic.to_c()
+        r = self.L.lib.m355_picture_upload(self.h, ctypes.addressof(c))
+        del keep
+        if r < 0:
+            raise M355Error(-r, self.L.error())
+        return r
+
+    def release(self, handle):
+        self.L.check(self.L.lib.m355_picture_release(self.h, handle))
+
+    def decode_resident(self, handle):
+        self.L.check(self.L.lib.m355_decode_resident(self.h, handle))
+
+    def set_stages(self, mask):
+        self.L.check(self.L.lib.m355_set_stages(self.h, mask))
+
+    def last_timing(self):
+        total = ctypes.c_float()
+        st = (ctypes.c_float * 5)()
+        self.L.check(self.L.lib.m355_last_timing(self.h, ctypes.byref(total), st))
+        return total.value, list(st)
+
+    def stream(self):
+        return self.L.lib.m355_stream(self.h)

@@ -1,0 +1,110 @@
+/*
+ * k_common.h — device-side picture descriptor, small device helpers and the launch entry points of
+ * the MI355X HEVC reconstruction kernels (one .hip file per stage).
+ *
+ * Data layout in HBM:
+ *   frames      : planar, one allocation per plane, element = uint8 (8 bit) / uint16 (9..16 bit),
+ *                 row pitch in SAMPLES padded to a multiple of 128 bytes;
+ *   work lists  : the PODs of include/de265_mi355x.h, uploaded verbatim (SoA per list);
+ *   metadata    : per-min-CB CU index plane, per-4x4 transform/prediction edge bytes and PB index
+ *                 plane — rasterised on the device from the CU / TU-leaf / PB lists (k_meta.hip);
+ *   residuals   : int16, one contiguous nT*nT tile per deferred (intra) block.
+ */
+#ifndef M355_K_COMMON_H
+#define M355_K_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "de265_mi355x.h"
+#include <k_asm.h> /* resolved through the include path (csrc/ for the product build) */
+
+struct DevRef {            /* one reference frame (indexed by m355_pb.ref_slot) */
+  const void* plane[3];
+  int stride[3];
+  int valid;
+  int pad;
+};
+struct DevRefTable { DevRef r[M355_MAX_REF_FRAMES]; };   /* passed by value (kernarg, 1.5 KB) */
+
+struct DevPic {
+  m355_pic_params pp;
+  int sw, sh;                       /* SubWidthC, SubHeightC */
+  int ctbW, ctbH, nCtb, w4, h4, wcb, hcb;
+  int pw[3], ph[3];                 /* plane dimensions */
+  void* plane[3];                   /* reconstruction / deblocking target */
+  int stride[3];
+  void* out_plane[3];               /* SAO output (the DPB frame) */
+  int out_stride[3];
+  /* work lists (device copies) */
+  const m355_slice* slices;
+  const m355_ctb* ctbs;
+  const m355_cu* cus;
+  const m355_tu* tus;
+  const m355_pb* pbs;
+  const m355_wt* wts;
+  const m355_rb* rbs;
+  const m355_ib* ibs;
+  const uint32_t* coeffs;
+  const uint16_t* pcm;
+  const uint8_t* scaling;
+  int n_cus, n_tus, n_pbs, n_ibs;
+  int rb_count[4];
+  /* derived tables / metadata planes */
+  const uint32_t* ctb_ts;           /* CtbAddrRStoTS */
+  const uint32_t* ts2rs;            /* CtbAddrTStoRS */
+  const uint16_t* tile_id;          /* TileIdRS */
+  uint32_t* cb_cu;                  /* per min CB: CU index + 1 */
+  uint8_t* cuf;                     /* per CU: bit0 filterLeftCbEdge, bit1 filterTopCbEdge, bit2 deblock on */
+  uint8_t* edge_tu;                 /* per 4x4: bit0 TU edge V, bit1 TU edge H, bit4 cbf_luma */
+  uint8_t* edge_pb;                 /* per 4x4: bit2 PB edge V, bit3 PB edge H */
+  uint32_t* pb_of;                  /* per 4x4: PB index + 1 */
+  int16_t* resbuf;
+  /* intra wavefront state */
+  uint32_t* ctb_done;               /* per CTB (raster) completion epoch */
+  uint32_t* ticket;                 /* work counter */
+  uint32_t* timeout;                /* set when a spin bound is exceeded */
+  uint32_t epoch;                   /* value meaning "done" for this submission */
+  const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks, decode order */
+  int n_intra_work;
+};
+
+enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
+
+/* ---- launchers (each in its stage's .hip); all asynchronous on `st` ---- */
+void m355_launch_meta(const DevPic& p, hipStream_t st);
+void m355_launch_inter(const DevPic& p, const DevRefTable& refs, bool hbd, hipStream_t st);
+void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st);
+
+/* ---- device helpers ---- */
+__device__ __forceinline__ int d_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int d_clip_bd(int v, int bd) { return d_clip3(0, (1 << bd) - 1, v); }
+__device__ __forceinline__ int d_abs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int d_sign(int v) { return (v > 0) - (v < 0); }
+
+/* lanes of one wave exchanging data through LDS: order the accesses (hardware executes a wave's DS
+ * operations in order; the fences keep the compiler from moving them) */
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int d_ctb_of(const DevPic& p, int xl, int yl)
+{
+  return (yl >> p.pp.log2_ctb_size) * p.ctbW + (xl >> p.pp.log2_ctb_size);
+}
+__device__ __forceinline__ const m355_slice& d_slice_at(const DevPic& p, int xl, int yl)
+{
+  return p.slices[p.ctbs[d_ctb_of(p, xl, yl)].slice_idx];
+}
+__device__ __forceinline__ uint32_t d_cu_index_at(const DevPic& p, int xl, int yl)
+{
+  return p.cb_cu[(yl >> p.pp.log2_min_cb_size) * p.wcb + (xl >> p.pp.log2_min_cb_size)];
+}
+
+#endif

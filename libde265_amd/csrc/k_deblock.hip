@@ -1,0 +1,190 @@
+/*
+ * k_deblock.hip — in-loop deblocking filter, one launch per edge direction.
+ *
+ * Replaces apply_deblocking_filter (deblock.cc:908-946): derive_boundaryStrength (:243-383),
+ * edge_filtering_luma_internal (:412-605) with deblock_luma_kernel (fallback-deblk.h:33-100) and
+ * edge_filtering_chroma_internal (:635-761) with deblock_chroma_kernel (fallback-deblk.h:104-124).
+ * (Edge flags come from k_meta.hip.)  As in the reference, ALL vertical edges of the picture are
+ * filtered before any horizontal edge — here a kernel boundary instead of the progress locks of
+ * deblock.cc:826-844.  Within one direction every 8x8-grid edge segment touches disjoint samples
+ * (<= 3 modified, 4 read, on each side of edges 8 apart), so the pass is embarrassingly parallel:
+ * one thread per 4-line edge segment, which derives bS, beta/tc and the filter decisions and filters
+ * the luma segment plus (every second segment, 4:2:0) the two chroma segments.
+ * Roofline: HBM-bound — picture read + write once per direction plus ~1.3 B of metadata per 4x4.
+ */
+#include "k_common.h"
+
+__constant__ uint8_t c_tab_beta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,
+                                       8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28, 30, 32,
+                                       34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+__constant__ uint8_t c_tab_tc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,
+                                     1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3,  3,  3,  3,  4,
+                                     4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+__constant__ int8_t c_qpc_420[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37}; /* transform.h:29-34 */
+
+struct CuInfo { int pred_mode, qp, pcm, bypass; };
+__device__ __forceinline__ CuInfo d_cu_info(const DevPic& p, int xl, int yl)
+{
+  CuInfo r = {0, 0, 0, 0};
+  const uint32_t ci = d_cu_index_at(p, xl, yl);
+  if (ci) {
+    const m355_cu cu = p.cus[ci - 1];
+    r.pred_mode = cu.pred_mode; r.qp = cu.qp_y;
+    r.pcm = (cu.flags & M355_CUF_PCM) != 0; r.bypass = (cu.flags & M355_CUF_TRANSQUANT_BYPASS) != 0;
+  }
+  return r;
+}
+
+/* derive_boundaryStrength for one edge unit (deblock.cc:243-383) */
+__device__ int d_boundary_strength(const DevPic& p, int x4, int y4, bool vertical, const CuInfo& P, const CuInfo& Q)
+{
+  const int u = y4 * p.w4 + x4;
+  const int ef = p.edge_tu[u] | p.edge_pb[u];
+  const int edgeMask = vertical ? (E_TU_V | E_PB_V) : (E_TU_H | E_PB_H);
+  if (!(ef & edgeMask)) return 0;
+  if (P.pred_mode == 0 || Q.pred_mode == 0) return 2;
+  const int uo = vertical ? u - 1 : u - p.w4;
+  if ((ef & (vertical ? E_TU_V : E_TU_H)) && ((ef & E_NONZERO) || (p.edge_tu[uo] & E_NONZERO))) return 1;
+  const uint32_t ip = p.pb_of[uo], iq = p.pb_of[u];
+  if (!ip || !iq) return 0;
+  const m355_pb A = p.pbs[ip - 1], B = p.pbs[iq - 1];
+  const bool pf0 = A.flags & M355_PBF_PRED_L0, pf1 = A.flags & M355_PBF_PRED_L1;
+  const bool qf0 = B.flags & M355_PBF_PRED_L0, qf1 = B.flags & M355_PBF_PRED_L1;
+  const int rP0 = pf0 ? A.ref_slot[0] : -1, rP1 = pf1 ? A.ref_slot[1] : -1;
+  const int rQ0 = qf0 ? B.ref_slot[0] : -1, rQ1 = qf1 ? B.ref_slot[1] : -1;
+  if (!((rP0 == rQ0 && rP1 == rQ1) || (rP0 == rQ1 && rP1 == rQ0))) return 1;
+  const int p0x = pf0 ? A.mv[0][0] : 0, p0y = pf0 ? A.mv[0][1] : 0, p1x = pf1 ? A.mv[1][0] : 0, p1y = pf1 ? A.mv[1][1] : 0;
+  const int q0x = qf0 ? B.mv[0][0] : 0, q0y = qf0 ? B.mv[0][1] : 0, q1x = qf1 ? B.mv[1][0] : 0, q1y = qf1 ? B.mv[1][1] : 0;
+#define FAR(ax, ay, bx, by) (d_abs((ax) - (bx)) >= 4 || d_abs((ay) - (by)) >= 4)
+  if (rP0 != rP1) {
+    if (rP0 == rQ0) return (FAR(p0x, p0y, q0x, q0y) || FAR(p1x, p1y, q1x, q1y)) ? 1 : 0;
+    return (FAR(p0x, p0y, q1x, q1y) || FAR(p1x, p1y, q0x, q0y)) ? 1 : 0;
+  }
+  return ((FAR(p0x, p0y, q0x, q0y) || FAR(p1x, p1y, q1x, q1y)) && (FAR(p0x, p0y, q1x, q1y) || FAR(p1x, p1y, q0x, q0y))) ? 1 : 0;
+#undef FAR
+}
+
+template <class PIX, bool VERTICAL>
+__global__ void __launch_bounds__(256) k_deblock(DevPic p)
+{
+  /* thread -> edge unit on the 8x8 luma grid: vertical edges at even x4, horizontal at even y4 */
+  const int nx = VERTICAL ? (p.w4 + 1) / 2 : p.w4;
+  const int ny = VERTICAL ? p.h4 : (p.h4 + 1) / 2;
+  const int tx = blockIdx.x * 64 + (threadIdx.x & 63), ty = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (tx >= nx || ty >= ny) return;
+  const int x4 = VERTICAL ? tx * 2 : tx, y4 = VERTICAL ? ty : ty * 2;
+  const int xDi = x4 << 2, yDi = y4 << 2;
+  if ((VERTICAL && x4 == 0) || (!VERTICAL && y4 == 0)) return; /* picture border: never flagged */
+  const int xp = VERTICAL ? xDi - 1 : xDi, yp = VERTICAL ? yDi : yDi - 1;
+  const CuInfo Q = d_cu_info(p, xDi, yDi), P = d_cu_info(p, xp, yp);
+  const int bS = d_boundary_strength(p, x4, y4, VERTICAL, P, Q);
+  if (bS == 0) return;
+
+  const m355_slice sh = d_slice_at(p, xDi, yDi);
+  const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
+  const bool filterP = !((plf && P.pcm) || P.bypass), filterQ = !((plf && Q.pcm) || Q.bypass);
+  const int qP_L = (Q.qp + P.qp + 1) >> 1;
+
+  /* ---- luma (deblock.cc:480-601, fallback-deblk.h:33-100) ---- */
+  {
+    const int bd = p.pp.bit_depth_luma;
+    const int stride = p.stride[0];
+    PIX* ptr = (PIX*)p.plane[0] + yDi * stride + xDi;
+    const int across = VERTICAL ? 1 : stride, along = VERTICAL ? stride : 1;
+    const int beta = c_tab_beta[d_clip3(0, 51, qP_L + sh.beta_offset)] * (1 << (bd - 8));
+    const int tc = c_tab_tc[d_clip3(0, 53, qP_L + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
+    int pv[4][4], qv[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) { qv[k][i] = ptr[k * along + i * across]; pv[k][i] = ptr[k * along - (i + 1) * across]; }
+    const int dp0 = d_abs(pv[0][2] - 2 * pv[0][1] + pv[0][0]), dp3 = d_abs(pv[3][2] - 2 * pv[3][1] + pv[3][0]);
+    const int dq0 = d_abs(qv[0][2] - 2 * qv[0][1] + qv[0][0]), dq3 = d_abs(qv[3][2] - 2 * qv[3][1] + qv[3][0]);
+    const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
+    if (d < beta) {
+      const bool dSam0 = 2 * dpq0 < (beta >> 2) && d_abs(pv[0][3] - pv[0][0]) + d_abs(qv[0][0] - qv[0][3]) < (beta >> 3) &&
+                         d_abs(pv[0][0] - qv[0][0]) < ((5 * tc + 1) >> 1);
+      const bool dSam3 = 2 * dpq3 < (beta >> 2) && d_abs(pv[3][3] - pv[3][0]) + d_abs(qv[3][0] - qv[3][3]) < (beta >> 3) &&
+                         d_abs(pv[3][0] - qv[3][0]) < ((5 * tc + 1) >> 1);
+      const bool strong = dSam0 && dSam3;
+      const bool dEp = dp < ((beta + (beta >> 1)) >> 3), dEq = dq < ((beta + (beta >> 1)) >> 3);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int p0 = pv[k][0], p1 = pv[k][1], p2 = pv[k][2], p3 = pv[k][3];
+        const int q0 = qv[k][0], q1 = qv[k][1], q2 = qv[k][2], q3 = qv[k][3];
+        PIX* o = ptr + k * along;
+        if (strong) {
+          if (filterP) {
+            o[-1 * across] = (PIX)d_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            o[-2 * across] = (PIX)d_clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+            o[-3 * across] = (PIX)d_clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+          }
+          if (filterQ) {
+            o[0] = (PIX)d_clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+            o[across] = (PIX)d_clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+            o[2 * across] = (PIX)d_clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+          }
+        } else {
+          int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+          if (d_abs(delta) < tc * 10) {
+            delta = d_clip3(-tc, tc, delta);
+            if (filterP) o[-across] = (PIX)d_clip_bd(p0 + delta, bd);
+            if (filterQ) o[0] = (PIX)d_clip_bd(q0 - delta, bd);
+            if (dEp && filterP) o[-2 * across] = (PIX)d_clip_bd(p1 + d_clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1), bd);
+            if (dEq && filterQ) o[across] = (PIX)d_clip_bd(q1 + d_clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1), bd);
+          }
+        }
+      }
+    }
+  }
+
+  /* ---- chroma (deblock.cc:635-761): bS == 2 only, on the 8-sample chroma grid ---- */
+  if (bS > 1 && p.pp.chroma_format_idc != 0) {
+    const int SW = p.sw, SH = p.sh;
+    /* the reference visits x4 = 0, 2*SW, ... (vertical) resp. y4 = 0, 2*SH, ... and, along the edge,
+       every SH-th (resp. SW-th) 4-luma unit */
+    const bool on_grid = VERTICAL ? ((x4 % (2 * SW)) == 0 && (y4 % SH) == 0) : ((y4 % (2 * SH)) == 0 && (x4 % SW) == 0);
+    if (on_grid) {
+      const int bd = p.pp.bit_depth_chroma;
+      const int xc = xDi / SW, yc = yDi / SH;
+      const int stride = p.stride[1];
+      const int across = VERTICAL ? 1 : stride, along = VERTICAL ? stride : 1;
+#pragma unroll
+      for (int cp = 0; cp < 2; cp++) {
+        const int qP_i = qP_L + (cp == 0 ? p.pp.pic_cb_qp_offset : p.pp.pic_cr_qp_offset);
+        int QP_C;
+        if (p.pp.chroma_format_idc == 1) QP_C = qP_i < 30 ? qP_i : (qP_i >= 43 ? qP_i - 6 : c_qpc_420[qP_i - 30]);
+        else QP_C = min(qP_i, 51);
+        const int tc = c_tab_tc[d_clip3(0, 53, QP_C + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
+        PIX* ptr = (PIX*)p.plane[cp + 1] + yc * stride + xc;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          PIX* o = ptr + k * along;
+          const int p0 = o[-across], p1 = o[-2 * across], q0 = o[0], q1 = o[across];
+          const int delta = d_clip3(-tc, tc, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
+          if (filterP) o[-across] = (PIX)d_clip_bd(p0 + delta, bd);
+          if (filterQ) o[0] = (PIX)d_clip_bd(q0 - delta, bd);
+        }
+      }
+    }
+  }
+}
+
+template <class PIX>
+static void launch_both(const DevPic& p, hipStream_t st)
+{
+  {
+    const int nx = (p.w4 + 1) / 2, ny = p.h4;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deblock<PIX, true>), dim3((nx + 63) / 64, (ny + 3) / 4), dim3(256), 0, st, p);
+  }
+  {
+    const int nx = p.w4, ny = (p.h4 + 1) / 2;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deblock<PIX, false>), dim3((nx + 63) / 64, (ny + 3) / 4), dim3(256), 0, st, p);
+  }
+}
+
+void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st)
+{
+  if (hbd) launch_both<uint16_t>(p, st);
+  else launch_both<uint8_t>(p, st);
+}

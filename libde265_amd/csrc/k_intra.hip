@@ -1,0 +1,339 @@
+/*
+ * k_intra.hip — intra prediction + deferred residual add, as a dependency-driven CTB wavefront.
+ *
+ * Replaces decode_intra_prediction (intrapred.cc:277-369): intra_border_computer::preproc /
+ * fill_from_image / reference_sample_substitution (intrapred.h:436-674),
+ * intra_prediction_sample_filtering (intrapred.h:185-258), intra_prediction_planar / _DC / _angular
+ * (intrapred.h:261-433), the residual add of decode_TU (slice.cc:3460-3524) for intra blocks, and
+ * read_pcm_samples (slice.cc:4211-4255) as a raw block.
+ *
+ * Why it looks like this: intra prediction of a block reads the reconstructed samples of its
+ * left / above / above-right neighbours, so the blocks of one CTB form a serial chain and CTBs form
+ * the classic WPP wavefront (needs CTB (x+1,y-1)).  This is the reference's ctb_progress protocol
+ * (image.h:76-80, slice.cc:4789-4795) moved onto the device:
+ *   - one workgroup per CTB that contains intra blocks; CTBs are claimed from an atomic ticket in
+ *     DECODE (tile-scan) order, so a workgroup only ever waits on CTBs claimed before it — no
+ *     residency assumption, no deadlock;
+ *   - completion is published per CTB with an agent-scope release + flag; consumers poll relaxed,
+ *     then take ONE agent-scope acquire (MI355X guide, guideline 16);
+ *   - inside the workgroup, one 64-lane wavefront per colour component walks that component's
+ *     blocks in decode order with the CTB (plus top-row / left-column halo) resident in LDS; the
+ *     three component chains are independent, so there is no workgroup barrier inside the chain —
+ *     only wave-level LDS ordering;
+ *   - the inverse transforms were done up front, in parallel, by k_residual.
+ * This stage is dependency-bound, not bandwidth-bound: critical path ~ (W_ctb + 2 H_ctb) CTB steps.
+ */
+#include "k_common.h"
+
+#define MAXCTB 64
+#define BODY_PITCH (MAXCTB + 2)
+#define SPIN_LIMIT (1u << 24)
+
+__constant__ int8_t c_intra_angle[35] = {0,   0,   32,  26,  21,  17, 13, 9,  5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
+                                         -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9,  13, 17, 21,  26,  32};
+__constant__ int16_t c_intra_inv_angle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256,
+                                              -315,  -390,  -482, -630, -910, -1638, -4096};
+
+/* pps.cc:608-623 MinTbAddrZS, computed instead of tabulated */
+__device__ __forceinline__ uint32_t d_min_tb_addr_zs(const DevPic& p, int xl, int yl)
+{
+  const int shift = p.pp.log2_ctb_size - p.pp.log2_min_tb_size;
+  const unsigned x = (unsigned)xl >> p.pp.log2_min_tb_size, y = (unsigned)yl >> p.pp.log2_min_tb_size;
+  const uint32_t v = p.ctb_ts[d_ctb_of(p, xl, yl)] << (shift * 2);
+  uint32_t m = 0;
+  for (int i = 0; i < shift; i++) m |= (((x >> i) & 1u) << (2 * i)) | (((y >> i) & 1u) << (2 * i + 1));
+  return v + m;
+}
+
+__device__ __forceinline__ bool d_is_intra_at(const DevPic& p, int xl, int yl)
+{
+  const uint32_t ci = d_cu_index_at(p, xl, yl);
+  return ci == 0 || p.cus[ci - 1].pred_mode == 0; /* zero-initialised cb_info reads MODE_INTRA */
+}
+
+/* source entry for reference_sample_substitution (intrapred.h:637-665): nearest available entry
+ * below e in scan order, else the lowest available entry */
+__device__ __forceinline__ int d_subst_src(int e, unsigned long long m0, unsigned long long m1, unsigned long long m2)
+{
+  const int k = e >> 6, b = e & 63;
+  const unsigned long long cur = k == 0 ? m0 : (k == 1 ? m1 : m2);
+  const unsigned long long below = cur & ((1ull << b) - 1ull);
+  if (below) return k * 64 + 63 - __clzll(below);
+  if (k >= 2 && m1) return 64 + 63 - __clzll(m1);
+  if (k >= 1 && m0) return 63 - __clzll(m0);
+  if (m0) return __ffsll(m0) - 1;
+  if (m1) return 64 + __ffsll(m1) - 1;
+  return 128;
+}
+
+template <class PIX>
+__global__ void __launch_bounds__(192) k_intra(DevPic p)
+{
+  /* per component: top halo row (x = -1 .. 2*cw-1, index x+1) and body rows with a left halo column */
+  __shared__ uint16_t s_top[3][2 * MAXCTB + 2];
+  __shared__ uint16_t s_body[3][MAXCTB * BODY_PITCH];
+  __shared__ uint16_t s_raw[3][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
+  __shared__ uint16_t s_p[3][4 * 32 + 8];        /* substituted border */
+  __shared__ uint16_t s_f[3][4 * 32 + 8];        /* filtered border */
+  __shared__ int s_ref[3][3 * 32 + 8];           /* angular ref[-nT..2nT], index +32 */
+  __shared__ uint32_t s_ticket;
+
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
+  __syncthreads();
+  if ((int)s_ticket >= p.n_intra_work) return;
+  const int ctb = (int)p.intra_work[s_ticket];
+  const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
+  const m355_ctb ctbinfo = p.ctbs[ctb];
+  const int l2c = p.pp.log2_ctb_size;
+
+  /* ---- wait for the neighbour CTBs this CTB may read (left, above-left, above, above-right) ---- */
+  if (threadIdx.x == 0) {
+    const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
+    for (int n = 0; n < 4; n++) {
+      const int nx = ctbX + dx[n], ny = ctbY + dy[n];
+      if (nx < 0 || ny < 0 || nx >= p.ctbW) continue;
+      const int nb = ny * p.ctbW + nx;
+      if (p.tile_id[nb] != p.tile_id[ctb]) continue;       /* never read across tiles; may be later in decode order */
+      if (p.ctbs[nb].ib_count == 0) continue;               /* finished by the preceding kernels (stream order) */
+      unsigned spins = 0;
+      while (__hip_atomic_load(&p.ctb_done[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > SPIN_LIMIT) { atomicExch(p.timeout, 1u); break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+
+  const int nc = p.pp.chroma_format_idc ? 3 : 1;
+  if (c < nc) {
+    const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
+    const int SubW = 1 << csw, SubH = 1 << csh;
+    const int cw = (1 << l2c) >> csw, ch = (1 << l2c) >> csh;
+    const int x0c = (ctbX << l2c) >> csw, y0c = (ctbY << l2c) >> csh;
+    const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+    PIX* plane = (PIX*)p.plane[c];
+    const int stride = p.stride[c], pw = p.pw[c], ph = p.ph[c];
+    uint16_t* top = s_top[c];
+    uint16_t* body = s_body[c];
+    uint16_t* raw = s_raw[c];
+    uint16_t* pp_ = s_p[c];
+    uint16_t* pf = s_f[c];
+    int* ref = s_ref[c] + 32;
+
+    /* ---- stage the CTB and its halo in LDS ---- */
+    for (int idx = lane; idx < cw * ch; idx += 64) {
+      const int y = idx / cw, x = idx - y * cw;
+      if (x0c + x < pw && y0c + y < ph) body[y * BODY_PITCH + x + 1] = plane[(y0c + y) * stride + x0c + x];
+    }
+    if (x0c > 0)
+      for (int y = lane; y < ch; y += 64)
+        if (y0c + y < ph) body[y * BODY_PITCH] = plane[(y0c + y) * stride + x0c - 1];
+    if (y0c > 0)
+      for (int x = lane; x < 2 * cw + 1; x += 64) {
+        const int xx = x0c - 1 + x;
+        if (xx >= 0 && xx < pw) top[x] = plane[(y0c - 1) * stride + xx];
+      }
+    wave_sync();
+
+#define SAMPLE(lx, ly) ((ly) < 0 ? top[(lx) + 1] : body[(ly) * BODY_PITCH + (lx) + 1])
+
+    for (uint32_t k = 0; k < ctbinfo.ib_count; k++) {
+      const m355_ib ib = p.ibs[ctbinfo.ib_start + k];
+      if (ib.cidx != c) continue;
+      const int nT = 1 << ib.log2_size;
+      const int xB = ib.x, yB = ib.y, lx = xB - x0c, ly = yB - y0c;
+
+      if (ib.flags & M355_IBF_PCM) { /* raw block */
+        for (int o = lane; o < nT * nT; o += 64) {
+          const int y = o >> ib.log2_size, x = o & (nT - 1);
+          body[(ly + y) * BODY_PITCH + lx + x + 1] = p.pcm[ib.res_ofs + o];
+        }
+        wave_sync();
+        continue;
+      }
+
+      /* ---- preproc (intrapred.h:436-531): CTB-level availability ---- */
+      const int xBL = xB * SubW, yBL = yB * SubH;
+      bool aL = xBL != 0, aT = yBL != 0, aTL = xBL != 0 && yBL != 0, aTR = yBL != 0;
+      if (xBL + nT * SubW >= p.pp.width) aTR = false;
+      {
+        const int xCurr = xBL >> l2c, yCurr = yBL >> l2c, xLeft = (xBL - 1) >> l2c, xRight = (xBL + nT * SubW) >> l2c,
+                  yTop = (yBL - 1) >> l2c;
+        const int cur = yCurr * p.ctbW + xCurr;
+        const int curS = p.slices[p.ctbs[cur].slice_idx].slice_addr_rs, curT = p.tile_id[cur];
+        if (aL) { const int n = yCurr * p.ctbW + xLeft; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aL = false; }
+        if (aT) { const int n = yTop * p.ctbW + xCurr; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aT = false; }
+        if (aTL) { const int n = yTop * p.ctbW + xLeft; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aTL = false; }
+        if (aTR) { const int n = yTop * p.ctbW + xRight; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aTR = false; }
+      }
+      int nBottom = p.pp.height - yB * SubH;
+      nBottom = (nBottom + SubH - 1) / SubH;
+      if (nBottom > 2 * nT) nBottom = 2 * nT;
+      int nRight = p.pp.width - xB * SubW;
+      nRight = (nRight + SubW - 1) / SubW;
+      if (nRight > 2 * nT) nRight = 2 * nT;
+      const uint32_t curAddr = d_min_tb_addr_zs(p, xBL, yBL);
+      const bool cip = (p.pp.flags & M355_PF_CONSTRAINED_INTRA_PRED) != 0;
+      const int nEnt = 4 * nT + 1;
+
+      /* ---- fill_from_image (intrapred.h:534-633): one border entry per lane and chunk ---- */
+      unsigned long long am[3] = {0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int e = lane + 64 * q;
+        bool av = false;
+        int val = 0;
+        if (e < nEnt) {
+          const int i = e - 2 * nT;
+          int xN, yN, sx, sy; /* test position (luma), sample position (local) */
+          if (i < 0) {
+            const int yy = -i - 1, g = yy & ~3;
+            av = aL && (g + 3 < nBottom);
+            xN = (xB - 1) * SubW; yN = (yB + g + 3) * SubH; sx = lx - 1; sy = ly + yy;
+          } else if (i == 0) {
+            av = aTL;
+            xN = (xB - 1) * SubW; yN = (yB - 1) * SubH; sx = lx - 1; sy = ly - 1;
+          } else {
+            const int xx = i - 1, g = xx & ~3;
+            av = (g < nT ? aT : aTR) && (g < nRight);
+            xN = (xB + g) * SubW; yN = (yB - 1) * SubH; sx = lx + xx; sy = ly - 1;
+          }
+          if (av) av = d_min_tb_addr_zs(p, xN, yN) <= curAddr;
+          if (av && cip) av = d_is_intra_at(p, xN, yN);
+          if (av) val = SAMPLE(sx, sy);
+          raw[e] = (uint16_t)val;
+        }
+        am[q] = __ballot(av);
+      }
+      wave_sync();
+      /* ---- reference_sample_substitution ---- */
+      const bool none = (am[0] | am[1] | am[2]) == 0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int e = lane + 64 * q;
+        if (e < nEnt) {
+          int v;
+          if (none) v = 1 << (bd - 1);
+          else if ((am[q] >> lane) & 1) v = raw[e];
+          else v = raw[d_subst_src(e, am[0], am[1], am[2])];
+          pp_[e] = (uint16_t)v;
+        }
+      }
+      wave_sync();
+      /* ---- intra_prediction_sample_filtering (intrapred.h:185-258) ---- */
+      const int mode = ib.mode;
+      uint16_t* P = pp_; /* border in use, entry index = i + 2nT */
+      const int Z = 2 * nT;
+      if (!(p.pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (c == 0 || p.pp.chroma_format_idc == 3) && mode != 1 && nT != 4) {
+        const int minDist = min(d_abs(mode - 26), d_abs(mode - 10));
+        const bool filt = nT == 8 ? minDist > 7 : (nT == 16 ? minDist > 1 : (nT == 32 ? minDist > 0 : false));
+        if (filt) {
+          const bool bi = (p.pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) && c == 0 && nT == 32 &&
+                          d_abs((int)pp_[Z] + pp_[Z + 64] - 2 * pp_[Z + 32]) < (1 << (p.pp.bit_depth_luma - 5)) &&
+                          d_abs((int)pp_[Z] + pp_[Z - 64] - 2 * pp_[Z - 32]) < (1 << (p.pp.bit_depth_luma - 5));
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const int e = lane + 64 * q;
+            if (e < nEnt) {
+              const int i = e - Z;
+              int v;
+              if (i == -Z || i == Z) v = pp_[e];
+              else if (bi) {
+                if (i == 0) v = pp_[Z];
+                else if (i < 0) v = pp_[Z] + (((-i) * ((int)pp_[Z - 64] - pp_[Z]) + 32) >> 6);
+                else v = pp_[Z] + ((i * ((int)pp_[Z + 64] - pp_[Z]) + 32) >> 6);
+              } else v = (pp_[e + 1] + 2 * pp_[e] + pp_[e - 1] + 2) >> 2;
+              pf[e] = (uint16_t)v;
+            }
+          }
+          wave_sync();
+          P = pf;
+        }
+      }
+#define BRD(i) ((int)P[(i) + Z])
+
+      /* ---- prediction (intrapred.h:261-433) ---- */
+      const int log2 = ib.log2_size;
+      int dcVal = 0;
+      if (mode == 1) {
+        int s = 0;
+        if (lane < nT) s = BRD(lane + 1) + BRD(-lane - 1);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        dcVal = (s + nT) >> (log2 + 1);
+      }
+      const int angle = c_intra_angle[mode];
+      if (mode >= 2) {
+        const int sgn = mode >= 18 ? 1 : -1;
+        const int inv = angle < 0 ? c_intra_inv_angle[mode - 11] : 0;
+        const int lo = (nT * angle) >> 5;
+        for (int t = lane; t < 3 * nT + 1; t += 64) {
+          const int x = t - nT;
+          int v = 0;
+          if (x >= 0 && x <= nT) v = BRD(sgn * x);
+          else if (x < 0) { if (angle < 0 && lo < -1 && x >= lo) v = BRD(-sgn * ((x * inv + 128) >> 8)); }
+          else if (angle >= 0) v = BRD(sgn * x);
+          ref[x] = v;
+        }
+        wave_sync();
+      }
+      const int16_t* res = (ib.flags & M355_IBF_HAS_RESIDUAL) ? p.resbuf + ib.res_ofs : nullptr;
+      const bool edge = (c == 0 && nT < 32);
+      const bool bfilt = edge && !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER);
+      for (int o = lane; o < nT * nT; o += 64) {
+        const int y = o >> log2, x = o & (nT - 1);
+        int v;
+        if (mode == 0) {
+          v = ((nT - 1 - x) * BRD(-1 - y) + (x + 1) * BRD(1 + nT) + (nT - 1 - y) * BRD(1 + x) + (y + 1) * BRD(-1 - nT) + nT) >> (log2 + 1);
+        } else if (mode == 1) {
+          v = dcVal;
+          if (edge) {
+            if (x == 0 && y == 0) v = (BRD(-1) + 2 * dcVal + BRD(1) + 2) >> 2;
+            else if (y == 0) v = (BRD(x + 1) + 3 * dcVal + 2) >> 2;
+            else if (x == 0) v = (BRD(-y - 1) + 3 * dcVal + 2) >> 2;
+          }
+        } else {
+          const int a = mode >= 18 ? y : x, b = mode >= 18 ? x : y;
+          const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
+          v = iFact ? ((32 - iFact) * ref[b + iIdx + 1] + iFact * ref[b + iIdx + 2] + 16) >> 5 : ref[b + iIdx + 1];
+          if (bfilt) {
+            if (mode == 26 && x == 0) v = d_clip_bd(BRD(1) + ((BRD(-1 - y) - BRD(0)) >> 1), bd);
+            if (mode == 10 && y == 0) v = d_clip_bd(BRD(-1) + ((BRD(1 + x) - BRD(0)) >> 1), bd);
+          }
+        }
+        if (res) v = d_clip_bd(v + res[o], bd);
+        body[(ly + y) * BODY_PITCH + lx + x + 1] = (uint16_t)v;
+      }
+      wave_sync();
+    }
+#undef BRD
+#undef SAMPLE
+
+    /* ---- write the CTB back ---- */
+    for (int idx = lane; idx < cw * ch; idx += 64) {
+      const int y = idx / cw, x = idx - y * cw;
+      if (x0c + x < pw && y0c + y < ph) plane[(y0c + y) * stride + x0c + x] = (PIX)body[y * BODY_PITCH + x + 1];
+    }
+  }
+
+  /* ---- publish (guideline 16: stores -> barrier -> one-lane agent release -> drain -> flag) ---- */
+  d_drain_vmem();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    d_drain_vmem();
+    __hip_atomic_store(&p.ctb_done[ctb], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)
+{
+  if (!p.n_intra_work) return;
+  hipMemsetAsync(p.ticket, 0, 4, st);
+  const dim3 grid(p.n_intra_work), block(192);
+  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<uint16_t>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<uint8_t>), grid, block, 0, st, p);
+}

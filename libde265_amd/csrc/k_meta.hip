@@ -1,0 +1,121 @@
+/*
+ * k_meta.hip — rasterise the CU / transform-leaf / PB lists into the metadata planes the in-loop
+ * filters and the intra availability tests read.  This replaces, on the device, what the reference
+ * keeps incrementally in de265_image::cb_info / tu_info / pb_info / deblk_info (image.h:389-395)
+ * and derive_edgeFlags_CTBRow + markTransformBlockBoundary + markPredictionBlockBoundary
+ * (deblock.cc:33-227).  Pure scatter kernels: HBM-write bound, a few bytes per 4x4 unit.
+ */
+#include "k_common.h"
+
+/* one thread per CU: CU-index plane, per-CU edge decisions (deblock.cc:172-210), PB edges */
+__global__ void __launch_bounds__(256) k_meta_cu(DevPic p)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_cus) return;
+  const m355_cu cu = p.cus[i];
+  const int x0 = cu.x, y0 = cu.y;
+  const int l2m = p.pp.log2_min_cb_size;
+  const int n = 1 << (cu.log2_size - l2m);
+  const int cx = x0 >> l2m, cy = y0 >> l2m;
+  for (int y = cy; y < cy + n && y < p.hcb; y++)
+    for (int x = cx; x < cx + n && x < p.wcb; x++) p.cb_cu[y * p.wcb + x] = (uint32_t)i + 1;
+
+  const int ctb_mask = (1 << p.pp.log2_ctb_size) - 1;
+  const m355_slice sh = d_slice_at(p, x0, y0);
+  int left = x0 != 0, top = y0 != 0;
+  if (x0 && (x0 & ctb_mask) == 0) {
+    if (!(sh.flags & M355_SF_LF_ACROSS_SLICES) && sh.slice_addr_rs != d_slice_at(p, x0 - 1, y0).slice_addr_rs) left = 0;
+    else if (!(p.pp.flags & M355_PF_LF_ACROSS_TILES) && p.tile_id[d_ctb_of(p, x0, y0)] != p.tile_id[d_ctb_of(p, x0 - 1, y0)]) left = 0;
+  }
+  if (y0 && (y0 & ctb_mask) == 0) {
+    if (!(sh.flags & M355_SF_LF_ACROSS_SLICES) && sh.slice_addr_rs != d_slice_at(p, x0, y0 - 1).slice_addr_rs) top = 0;
+    else if (!(p.pp.flags & M355_PF_LF_ACROSS_TILES) && p.tile_id[d_ctb_of(p, x0, y0)] != p.tile_id[d_ctb_of(p, x0, y0 - 1)]) top = 0;
+  }
+  const int en = !(sh.flags & M355_SF_DEBLOCK_DISABLED);
+  p.cuf[i] = (uint8_t)(left | (top << 1) | (en << 2));
+  if (!en) return;
+
+  /* markPredictionBlockBoundary (deblock.cc:68-129) */
+  const int cb = 1 << cu.log2_size, h2 = cb >> 1, q4 = cb >> 2;
+  int vx = -1, hy = -1;
+  switch (cu.part_mode) {
+    case 3: vx = h2; hy = h2; break;
+    case 2: vx = h2; break;
+    case 1: hy = h2; break;
+    case 6: vx = q4; break;
+    case 7: vx = h2 + q4; break;
+    case 4: hy = q4; break;
+    case 5: hy = h2 + q4; break;
+    default: break;
+  }
+  /* a unit may receive both bits (NxN centre): the vertical pass writes first, the horizontal ORs */
+  if (vx >= 0) {
+    const int ux = (x0 + vx) >> 2;
+    if (ux < p.w4)
+      for (int k = 0; k < cb; k += 4) {
+        const int uy = (y0 + k) >> 2;
+        if (uy < p.h4) p.edge_pb[uy * p.w4 + ux] = E_PB_V;
+      }
+  }
+  if (hy >= 0) {
+    const int uy = (y0 + hy) >> 2;
+    if (uy < p.h4)
+      for (int k = 0; k < cb; k += 4) {
+        const int ux = (x0 + k) >> 2;
+        if (ux < p.w4) p.edge_pb[uy * p.w4 + ux] |= E_PB_H;
+      }
+  }
+}
+
+/* one thread per transform-tree leaf: transform edges + cbf_luma (deblock.cc:33-63, slice.cc:2958) */
+__global__ void __launch_bounds__(256) k_meta_tu(DevPic p)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_tus) return;
+  const m355_tu tu = p.tus[i];
+  const int n4 = (1 << tu.log2_size) >> 2;
+  const int ux0 = tu.x >> 2, uy0 = tu.y >> 2;
+  const uint32_t ci = d_cu_index_at(p, tu.x, tu.y);
+  int left = 0, top = 0;
+  if (ci) {
+    const m355_cu cu = p.cus[ci - 1];
+    const uint8_t f = p.cuf[ci - 1];
+    if (f & 4) {
+      left = (tu.x == cu.x) ? (f & 1) : 1;
+      top = (tu.y == cu.y) ? ((f >> 1) & 1) : 1;
+    }
+  }
+  const int nz = (tu.flags & M355_TUF_NONZERO_COEFF) ? E_NONZERO : 0;
+  if (nz) {
+    for (int y = 0; y < n4 && uy0 + y < p.h4; y++)
+      for (int x = 0; x < n4 && ux0 + x < p.w4; x++)
+        p.edge_tu[(uy0 + y) * p.w4 + ux0 + x] = (uint8_t)(nz | ((x == 0 && left) ? E_TU_V : 0) | ((y == 0 && top) ? E_TU_H : 0));
+  } else {
+    if (left)
+      for (int y = 0; y < n4 && uy0 + y < p.h4; y++)
+        p.edge_tu[(uy0 + y) * p.w4 + ux0] = (uint8_t)(E_TU_V | ((y == 0 && top) ? E_TU_H : 0));
+    if (top)
+      for (int x = (left ? 1 : 0); x < n4 && ux0 + x < p.w4; x++) p.edge_tu[uy0 * p.w4 + ux0 + x] = E_TU_H;
+  }
+}
+
+/* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) */
+__global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n_pbs) return;
+  const m355_pb pb = p.pbs[i];
+  for (int y = pb.y >> 2; y < ((pb.y + pb.h) >> 2) && y < p.h4; y++)
+    for (int x = pb.x >> 2; x < ((pb.x + pb.w) >> 2) && x < p.w4; x++) p.pb_of[y * p.w4 + x] = (uint32_t)i + 1;
+}
+
+void m355_launch_meta(const DevPic& p, hipStream_t st)
+{
+  hipMemsetAsync(p.cb_cu, 0, (size_t)p.wcb * p.hcb * 4, st);
+  hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4, st);
+  hipMemsetAsync(p.edge_pb, 0, (size_t)p.w4 * p.h4, st);
+  hipMemsetAsync(p.pb_of, 0, (size_t)p.w4 * p.h4 * 4, st);
+  if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
+  if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
+  if (p.n_pbs) hipLaunchKernelGGL(k_meta_pb, dim3((p.n_pbs + 255) / 256), dim3(256), 0, st, p);
+}

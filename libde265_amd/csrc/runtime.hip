@@ -1,0 +1,555 @@
+/*
+ * runtime.hip — host side of the picture layer: context, device-resident frames (the DPB lives in
+ * HBM), work-list validation/upload and the per-picture launch sequence.
+ *
+ * Per picture the executor enqueues, on the context's own HIP stream:
+ *   H2D (one pinned arena copy)  ->  k_meta_*  ->  k_inter  ->  k_residual<2..5>  ->  k_intra
+ *   ->  k_deblock<V>  ->  k_deblock<H>  ->  k_sao
+ * which is the deferred form of decode_TU / decode_prediction_unit / run_postprocessing_filters_*
+ * (slice.cc:3460, motion.cc:2190, decctx.cc:1783-1833).  Nothing here falls back to the CPU: if HIP
+ * is unavailable every entry point fails with M355_ERR_NO_DEVICE.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "k_common.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(M355_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+struct Frame {
+  bool used = false;
+  int w = 0, h = 0, cf = 0, bdl = 0, bdc = 0;
+  int pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0}, stride[3] = {0, 0, 0}, bpp[3] = {1, 1, 1};
+  void* plane[3] = {nullptr, nullptr, nullptr};
+};
+
+static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
+{
+  f.w = w; f.h = h; f.cf = cf; f.bdl = bdl; f.bdc = bdc;
+  const int sw = (cf == 1 || cf == 2) ? 2 : 1, sh = (cf == 1) ? 2 : 1;
+  for (int c = 0; c < 3; c++) {
+    f.bpp[c] = ((c ? bdc : bdl) <= 8) ? 1 : 2;
+    if (c && cf == 0) { f.pw[c] = f.ph[c] = f.stride[c] = 0; continue; }
+    f.pw[c] = c ? w / sw : w;
+    f.ph[c] = c ? h / sh : h;
+    const int pitch_bytes = (f.pw[c] * f.bpp[c] + 127) & ~127;
+    f.stride[c] = pitch_bytes / f.bpp[c];
+  }
+}
+static int frame_alloc(Frame& f)
+{
+  for (int c = 0; c < 3; c++) {
+    if (!f.pw[c]) continue;
+    const size_t bytes = (size_t)f.stride[c] * f.ph[c] * f.bpp[c] + 256;
+    HIPCHK(hipMalloc(&f.plane[c], bytes));
+    HIPCHK(hipMemset(f.plane[c], 0, bytes)); /* planes are zero at allocation (image.cc:164) */
+  }
+  f.used = true;
+  return M355_OK;
+}
+static void frame_free(Frame& f)
+{
+  for (int c = 0; c < 3; c++) { if (f.plane[c]) hipFree(f.plane[c]); f.plane[c] = nullptr; }
+  f.used = false;
+}
+
+/* one picture's lists resident in HBM */
+struct Resident {
+  bool used = false;
+  m355_picture hdr;            /* counts + params (pointers are NOT valid) */
+  char* dev = nullptr;         /* device arena */
+  char* host = nullptr;        /* pinned staging arena */
+  size_t cap = 0, bytes = 0;
+  DevPic dp;                   /* device pointers filled at upload; frame planes at decode */
+  int n_intra_work = 0;
+};
+
+struct m355_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Frame> frames;
+  std::vector<Resident> resident;
+  Resident transient;
+  Frame work;                  /* pre-SAO working planes */
+  /* scratch */
+  uint32_t *cb_cu = nullptr, *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
+  uint8_t *edge_tu = nullptr, *edge_pb = nullptr, *cuf = nullptr;
+  int16_t* resbuf = nullptr;
+  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0;
+  uint32_t epoch = 0;
+  int stages = M355_STAGE_ALL;
+  hipEvent_t ev[7] = {};
+  bool timed = false;
+};
+
+template <class T> static int grow(T** p, size_t* cap, size_t need, hipStream_t st, bool zero)
+{
+  if (need <= *cap) return M355_OK;
+  HIPCHK(hipStreamSynchronize(st));
+  if (*p) hipFree(*p);
+  *p = nullptr;
+  const size_t n = need + need / 4 + 64;
+  HIPCHK(hipMalloc(p, n * sizeof(T)));
+  if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+  *cap = n;
+  return M355_OK;
+}
+
+extern "C" {
+
+const char* m355_last_error(void) { return g_err.c_str(); }
+const char* m355_version(void) { return "libde265_mi355x 0.1 (gfx950)"; }
+int m355_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int m355_create(int device, m355_ctx** out)
+{
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(M355_ERR_NO_DEVICE, "no HIP device visible (the MI355X backend has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(M355_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  HIPCHK(hipSetDevice(device));
+  m355_ctx* c = new m355_ctx;
+  c->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 7; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+  HIPCHK(hipMalloc(&c->ticket, 64));
+  HIPCHK(hipMalloc(&c->timeout, 64));
+  HIPCHK(hipMemset(c->ticket, 0, 64));
+  HIPCHK(hipMemset(c->timeout, 0, 64));
+  *out = c;
+  return M355_OK;
+}
+
+static void resident_free(Resident& r)
+{
+  if (r.dev) hipFree(r.dev);
+  if (r.host) hipHostFree(r.host);
+  r = Resident();
+}
+
+void m355_destroy(m355_ctx* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto& f : c->frames) if (f.used) frame_free(f);
+  if (c->work.used) frame_free(c->work);
+  for (auto& r : c->resident) if (r.used) resident_free(r);
+  resident_free(c->transient);
+  void* bufs[] = {c->cb_cu, c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->edge_pb, c->cuf, c->resbuf};
+  for (void* b : bufs) if (b) hipFree(b);
+  for (int i = 0; i < 7; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+void* m355_stream(m355_ctx* c) { return (void*)c->stream; }
+
+/* ------------------------------------------------------------------------------ frames -------- */
+
+int m355_frame_create(m355_ctx* c, int width, int height, int cf, int bdl, int bdc)
+{
+  if (width <= 0 || height <= 0 || cf < 0 || cf > 3 || bdl < 8 || bdl > 16 || bdc < 8 || bdc > 16) return -fail(M355_ERR_INVALID, "bad frame geometry");
+  if ((bdl <= 8) != (bdc <= 8) && cf != 0) return -fail(M355_ERR_INVALID, "luma/chroma must both be 8-bit or both be 9..16-bit");
+  hipSetDevice(c->device);
+  int idx = -1;
+  for (size_t i = 0; i < c->frames.size(); i++) if (!c->frames[i].used) { idx = (int)i; break; }
+  if (idx < 0) { c->frames.push_back(Frame()); idx = (int)c->frames.size() - 1; }
+  Frame& f = c->frames[idx];
+  f = Frame();
+  frame_geometry(f, width, height, cf, bdl, bdc);
+  int rc = frame_alloc(f);
+  if (rc) { frame_free(f); return -rc; }
+  return idx;
+}
+static Frame* get_frame(m355_ctx* c, int h)
+{
+  if (h < 0 || h >= (int)c->frames.size() || !c->frames[h].used) return nullptr;
+  return &c->frames[h];
+}
+int m355_frame_destroy(m355_ctx* c, int h)
+{
+  Frame* f = get_frame(c, h);
+  if (!f) return fail(M355_ERR_INVALID, "bad frame handle %d", h);
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  frame_free(*f);
+  return M355_OK;
+}
+int m355_frame_upload(m355_ctx* c, int h, int cidx, const void* src, ptrdiff_t stride)
+{
+  Frame* f = get_frame(c, h);
+  if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
+  hipSetDevice(c->device);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy2D(f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx], src, (size_t)stride * f->bpp[cidx],
+                     (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyHostToDevice));
+  return M355_OK;
+}
+int m355_frame_download(m355_ctx* c, int h, int cidx, void* dst, ptrdiff_t stride)
+{
+  Frame* f = get_frame(c, h);
+  if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
+  hipSetDevice(c->device);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy2D(dst, (size_t)stride * f->bpp[cidx], f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx],
+                     (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyDeviceToHost));
+  return M355_OK;
+}
+int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
+{
+  Frame* f = get_frame(c, h);
+  if (!f) return fail(M355_ERR_INVALID, "bad frame handle %d", h);
+  hipSetDevice(c->device);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int cc = 0; cc < 3; cc++) {
+    if (!f->pw[cc]) continue;
+    const size_t n = (size_t)f->stride[cc] * f->ph[cc];
+    const int v = cc ? vc : vl;
+    if (f->bpp[cc] == 1) HIPCHK(hipMemset(f->plane[cc], v, n));
+    else {
+      std::vector<uint16_t> tmp(n, (uint16_t)v);
+      HIPCHK(hipMemcpy(f->plane[cc], tmp.data(), n * 2, hipMemcpyHostToDevice));
+    }
+  }
+  return M355_OK;
+}
+
+/* ----------------------------------------------------------------------- validation ----------- */
+
+static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
+{
+  const m355_pic_params& pp = pic->pp;
+  if (pp.width <= 0 || pp.height <= 0 || pp.chroma_format_idc > 3) return fail(M355_ERR_INVALID, "bad picture size / chroma format");
+  if (pp.log2_ctb_size < 4 || pp.log2_ctb_size > 6 || pp.log2_min_tb_size < 2 || pp.log2_min_tb_size > pp.log2_ctb_size ||
+      pp.log2_min_cb_size < 3 || pp.log2_min_cb_size > pp.log2_ctb_size)
+    return fail(M355_ERR_INVALID, "bad block-size parameters");
+  if (pp.bit_depth_luma < 8 || pp.bit_depth_luma > 16 || pp.bit_depth_chroma < 8 || pp.bit_depth_chroma > 16) return fail(M355_ERR_INVALID, "bad bit depth");
+  const int cs = 1 << pp.log2_ctb_size;
+  const int ctbW = (pp.width + cs - 1) / cs, ctbH = (pp.height + cs - 1) / cs;
+  if (pic->n_ctbs != ctbW * ctbH) return fail(M355_ERR_INVALID, "n_ctbs %d != %dx%d", pic->n_ctbs, ctbW, ctbH);
+  if (pp.num_tile_cols < 1 || pp.num_tile_cols > M355_MAX_TILE_COLS || pp.num_tile_rows < 1 || pp.num_tile_rows > M355_MAX_TILE_ROWS)
+    return fail(M355_ERR_INVALID, "bad tile counts");
+  if (pp.col_bd[0] != 0 || pp.row_bd[0] != 0 || pp.col_bd[pp.num_tile_cols] != ctbW || pp.row_bd[pp.num_tile_rows] != ctbH)
+    return fail(M355_ERR_INVALID, "tile boundaries do not cover the picture");
+  for (int i = 0; i < pp.num_tile_cols; i++) if (pp.col_bd[i + 1] <= pp.col_bd[i]) return fail(M355_ERR_INVALID, "tile columns not increasing");
+  for (int i = 0; i < pp.num_tile_rows; i++) if (pp.row_bd[i + 1] <= pp.row_bd[i]) return fail(M355_ERR_INVALID, "tile rows not increasing");
+  if (pic->n_slices < 1) return fail(M355_ERR_INVALID, "no slices");
+  if ((pp.flags & M355_PF_SCALING_LIST) && !pic->scaling_factors) return fail(M355_ERR_INVALID, "scaling list enabled but no factors");
+  const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
+  uint32_t ibsum = 0;
+  for (int i = 0; i < pic->n_ctbs; i++) {
+    const m355_ctb& c = pic->ctbs[i];
+    if (c.slice_idx >= pic->n_slices) return fail(M355_ERR_INVALID, "ctb %d: slice index out of range", i);
+    if ((uint64_t)c.ib_start + c.ib_count > (uint64_t)pic->n_ibs) return fail(M355_ERR_INVALID, "ctb %d: intra block range out of bounds", i);
+    ibsum += c.ib_count;
+  }
+  if ((int)ibsum != pic->n_ibs) return fail(M355_ERR_INVALID, "intra blocks not all owned by a CTB");
+  for (int i = 0; i < pic->n_cus; i++) {
+    const m355_cu& cu = pic->cus[i];
+    if (cu.log2_size < pp.log2_min_cb_size || cu.log2_size > pp.log2_ctb_size || cu.x >= pp.width || cu.y >= pp.height || cu.pred_mode > 2 || cu.part_mode > 7)
+      return fail(M355_ERR_INVALID, "cu %d malformed", i);
+  }
+  for (int i = 0; i < pic->n_tus; i++) {
+    const m355_tu& tu = pic->tus[i];
+    if (tu.log2_size < 2 || tu.log2_size > 6 || tu.x >= pp.width || tu.y >= pp.height) return fail(M355_ERR_INVALID, "tu %d malformed", i);
+  }
+  for (int i = 0; i < pic->n_pbs; i++) {
+    const m355_pb& pb = pic->pbs[i];
+    if (pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3) || pb.x + pb.w > pp.width || pb.y + pb.h > pp.height)
+      return fail(M355_ERR_INVALID, "pb %d geometry", i);
+    if (!(pb.flags & (M355_PBF_MC_L0 | M355_PBF_MC_L1))) return fail(M355_ERR_INVALID, "pb %d: no list selected", i);
+    for (int l = 0; l < 2; l++) {
+      if (!(pb.flags & (M355_PBF_MC_L0 << l))) continue;
+      if (!(pb.flags & (M355_PBF_FILL_L0 << l))) {
+        if (pb.ref_slot[l] < 0 || pb.ref_slot[l] >= M355_MAX_REF_FRAMES || pic->ref_frames[pb.ref_slot[l]] < 0) return fail(M355_ERR_INVALID, "pb %d: reference slot invalid", i);
+      }
+      if ((pb.flags & M355_PBF_WEIGHTED) && pb.wt_idx[l] >= pic->n_wts) return fail(M355_ERR_INVALID, "pb %d: weight index", i);
+    }
+  }
+  for (int i = 0; i < pic->n_wts; i++)
+    if (pic->wts[i].log2wd_luma < 1 || pic->wts[i].log2wd_luma > 31 || (pp.chroma_format_idc && (pic->wts[i].log2wd_chroma < 1 || pic->wts[i].log2wd_chroma > 31)))
+      return fail(M355_ERR_INVALID, "weight %d: log2WD out of range", i);
+  int nrb = 0;
+  for (int s = 0; s < 4; s++) { if (pic->rb_count[s] < 0) return fail(M355_ERR_INVALID, "negative rb_count"); nrb += pic->rb_count[s]; }
+  int k = 0;
+  for (int s = 0; s < 4; s++)
+    for (int j = 0; j < pic->rb_count[s]; j++, k++) {
+      const m355_rb& rb = pic->rbs[k];
+      const int n = 1 << (s + 2);
+      const int W = rb.cidx ? pp.width / sw : pp.width, H = rb.cidx ? pp.height / sh : pp.height;
+      if (rb.log2_size != s + 2 || rb.cidx > 2 || rb.kind > 3 || rb.x + n > W || rb.y + n > H) return fail(M355_ERR_INVALID, "rb %d malformed", k);
+      if ((uint64_t)rb.coeff_ofs + rb.ncoeff > pic->n_coeffs) return fail(M355_ERR_INVALID, "rb %d: coefficient range", k);
+      if ((rb.flags & M355_RBF_DEFERRED) && (uint64_t)rb.res_ofs + n * n > pic->res_len) return fail(M355_ERR_INVALID, "rb %d: residual range", k);
+      if ((pp.flags & M355_PF_SCALING_LIST) && rb.matrix_id > 5) return fail(M355_ERR_INVALID, "rb %d: matrix id", k);
+      if (rb.kind == M355_RK_DST && s != 0) return fail(M355_ERR_INVALID, "rb %d: DST only exists for 4x4", k);
+    }
+  for (int i = 0; i < pic->n_ibs; i++) {
+    const m355_ib& ib = pic->ibs[i];
+    const int n = 1 << ib.log2_size;
+    const int W = ib.cidx ? pp.width / sw : pp.width, H = ib.cidx ? pp.height / sh : pp.height;
+    if (ib.log2_size < 2 || ib.log2_size > 5 || ib.cidx > 2 || ib.mode > 34 || ib.x + n > W || ib.y + n > H) return fail(M355_ERR_INVALID, "ib %d malformed", i);
+    if ((ib.flags & M355_IBF_HAS_RESIDUAL) && (uint64_t)ib.res_ofs + n * n > pic->res_len) return fail(M355_ERR_INVALID, "ib %d: residual range", i);
+    if ((ib.flags & M355_IBF_PCM) && (uint64_t)ib.res_ofs + n * n > pic->n_pcm) return fail(M355_ERR_INVALID, "ib %d: pcm range", i);
+  }
+  *ctbW_out = ctbW; *ctbH_out = ctbH;
+  return M355_OK;
+}
+
+/* ----------------------------------------------------------------------- upload --------------- */
+
+static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
+{
+  int ctbW, ctbH;
+  int rc = validate(pic, &ctbW, &ctbH);
+  if (rc) return rc;
+  const m355_pic_params& pp = pic->pp;
+  const int nCtb = ctbW * ctbH;
+  const int nrb = pic->rb_count[0] + pic->rb_count[1] + pic->rb_count[2] + pic->rb_count[3];
+  struct Seg { const void* src; size_t bytes; size_t ofs; };
+  Seg seg[16];
+  int ns = 0;
+  size_t total = 0;
+  auto add = [&](const void* src, size_t bytes) { seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].ofs = total; total += al(bytes ? bytes : 1); return ns++; };
+  const int i_sl = add(pic->slices, sizeof(m355_slice) * pic->n_slices);
+  const int i_ct = add(pic->ctbs, sizeof(m355_ctb) * pic->n_ctbs);
+  const int i_cu = add(pic->cus, sizeof(m355_cu) * pic->n_cus);
+  const int i_tu = add(pic->tus, sizeof(m355_tu) * pic->n_tus);
+  const int i_pb = add(pic->pbs, sizeof(m355_pb) * pic->n_pbs);
+  const int i_wt = add(pic->wts, sizeof(m355_wt) * pic->n_wts);
+  const int i_rb = add(pic->rbs, sizeof(m355_rb) * nrb);
+  const int i_ib = add(pic->ibs, sizeof(m355_ib) * pic->n_ibs);
+  const int i_co = add(pic->coeffs, 4 * (size_t)pic->n_coeffs);
+  const int i_pc = add(pic->pcm, 2 * (size_t)pic->n_pcm);
+  const int i_sc = add(pic->scaling_factors, pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0);
+  const int i_ts = add(nullptr, 4 * (size_t)nCtb);   /* ctb_ts   */
+  const int i_rs = add(nullptr, 4 * (size_t)nCtb);   /* ts2rs    */
+  const int i_ti = add(nullptr, 2 * (size_t)nCtb);   /* tile_id  */
+  const int i_iw = add(nullptr, 4 * (size_t)nCtb);   /* intra_work */
+
+  hipSetDevice(c->device);
+  if (total > r.cap) {
+    if (r.dev || r.host) HIPCHK(hipStreamSynchronize(c->stream));
+    if (r.dev) hipFree(r.dev);
+    if (r.host) hipHostFree(r.host);
+    r.dev = r.host = nullptr;
+    r.cap = total + total / 4;
+    HIPCHK(hipMalloc(&r.dev, r.cap));
+    HIPCHK(hipHostMalloc(&r.host, r.cap, hipHostMallocDefault));
+  } else {
+    /* the staging arena may still be in flight from the previous submission */
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  for (int i = 0; i < ns; i++)
+    if (seg[i].src && seg[i].bytes) memcpy(r.host + seg[i].ofs, seg[i].src, seg[i].bytes);
+  /* derived scan tables (pps.cc:589-606) */
+  uint32_t* ctb_ts = (uint32_t*)(r.host + seg[i_ts].ofs);
+  uint32_t* ts2rs = (uint32_t*)(r.host + seg[i_rs].ofs);
+  uint16_t* tile_id = (uint16_t*)(r.host + seg[i_ti].ofs);
+  uint32_t* iw = (uint32_t*)(r.host + seg[i_iw].ofs);
+  uint32_t ts = 0; int tidx = 0;
+  for (int ty = 0; ty < pp.num_tile_rows; ty++)
+    for (int tx = 0; tx < pp.num_tile_cols; tx++) {
+      for (int y = pp.row_bd[ty]; y < pp.row_bd[ty + 1]; y++)
+        for (int x = pp.col_bd[tx]; x < pp.col_bd[tx + 1]; x++) {
+          ctb_ts[y * ctbW + x] = ts; ts2rs[ts] = (uint32_t)(y * ctbW + x); tile_id[y * ctbW + x] = (uint16_t)tidx; ts++;
+        }
+      tidx++;
+    }
+  int nw = 0;
+  for (int t = 0; t < nCtb; t++)
+    if (pic->ctbs[ts2rs[t]].ib_count) iw[nw++] = ts2rs[t];
+  r.n_intra_work = nw;
+  r.bytes = total;
+  HIPCHK(hipMemcpyAsync(r.dev, r.host, total, hipMemcpyHostToDevice, c->stream));
+
+  r.hdr = *pic;
+  DevPic& d = r.dp;
+  memset(&d, 0, sizeof(d));
+  d.pp = pp;
+  d.sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1;
+  d.sh = pp.chroma_format_idc == 1 ? 2 : 1;
+  d.ctbW = ctbW; d.ctbH = ctbH; d.nCtb = nCtb;
+  d.w4 = (pp.width + 3) / 4; d.h4 = (pp.height + 3) / 4;
+  d.wcb = (pp.width + (1 << pp.log2_min_cb_size) - 1) >> pp.log2_min_cb_size;
+  d.hcb = (pp.height + (1 << pp.log2_min_cb_size) - 1) >> pp.log2_min_cb_size;
+  d.slices = (const m355_slice*)(r.dev + seg[i_sl].ofs);
+  d.ctbs = (const m355_ctb*)(r.dev + seg[i_ct].ofs);
+  d.cus = (const m355_cu*)(r.dev + seg[i_cu].ofs);
+  d.tus = (const m355_tu*)(r.dev + seg[i_tu].ofs);
+  d.pbs = (const m355_pb*)(r.dev + seg[i_pb].ofs);
+  d.wts = (const m355_wt*)(r.dev + seg[i_wt].ofs);
+  d.rbs = (const m355_rb*)(r.dev + seg[i_rb].ofs);
+  d.ibs = (const m355_ib*)(r.dev + seg[i_ib].ofs);
+  d.coeffs = (const uint32_t*)(r.dev + seg[i_co].ofs);
+  d.pcm = (const uint16_t*)(r.dev + seg[i_pc].ofs);
+  d.scaling = pic->scaling_factors ? (const uint8_t*)(r.dev + seg[i_sc].ofs) : nullptr;
+  d.n_cus = pic->n_cus; d.n_tus = pic->n_tus; d.n_pbs = pic->n_pbs; d.n_ibs = pic->n_ibs;
+  for (int s = 0; s < 4; s++) d.rb_count[s] = pic->rb_count[s];
+  d.ctb_ts = (const uint32_t*)(r.dev + seg[i_ts].ofs);
+  d.ts2rs = (const uint32_t*)(r.dev + seg[i_rs].ofs);
+  d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
+  d.intra_work = (const uint32_t*)(r.dev + seg[i_iw].ofs);
+  d.n_intra_work = nw;
+  r.used = true;
+  return M355_OK;
+}
+
+/* ----------------------------------------------------------------------- decode --------------- */
+
+static int decode(m355_ctx* c, Resident& r)
+{
+  hipSetDevice(c->device);
+  const m355_picture& pic = r.hdr;
+  const m355_pic_params& pp = pic.pp;
+  Frame* dst = get_frame(c, pic.dst_frame);
+  if (!dst) return fail(M355_ERR_INVALID, "dst_frame %d is not a live frame", pic.dst_frame);
+  if (dst->w != pp.width || dst->h != pp.height || dst->cf != pp.chroma_format_idc || dst->bdl != pp.bit_depth_luma || dst->bdc != pp.bit_depth_chroma)
+    return fail(M355_ERR_INVALID, "dst frame geometry does not match the picture parameters");
+  const bool hbd = pp.bit_depth_luma > 8;
+  DevPic d = r.dp;
+  DevRefTable refs;
+  memset(&refs, 0, sizeof(refs));
+  for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+    if (pic.ref_frames[i] < 0) continue;
+    Frame* f = get_frame(c, pic.ref_frames[i]);
+    if (!f) return fail(M355_ERR_INVALID, "ref_frames[%d]=%d is not a live frame", i, pic.ref_frames[i]);
+    if (f->w != dst->w || f->h != dst->h || f->cf != dst->cf || f->bdl != dst->bdl || f->bdc != dst->bdc)
+      return fail(M355_ERR_INVALID, "reference frame %d geometry differs (motion.cc:377-398 would conceal; record FILL instead)", i);
+    if (f == dst) return fail(M355_ERR_INVALID, "a picture cannot reference itself");
+    for (int cc = 0; cc < 3; cc++) { refs.r[i].plane[cc] = f->plane[cc]; refs.r[i].stride[cc] = f->stride[cc]; }
+    refs.r[i].valid = 1;
+  }
+  /* scratch */
+  int rc;
+  if ((rc = grow(&c->cb_cu, &c->cap_cb, (size_t)d.wcb * d.hcb, c->stream, false))) return rc;
+  {
+    size_t cap = c->cap_u4;
+    if ((size_t)d.w4 * d.h4 > cap) {
+      size_t c1 = cap, c2 = cap, c3 = cap;
+      if ((rc = grow(&c->pb_of, &c1, (size_t)d.w4 * d.h4, c->stream, false))) return rc;
+      if ((rc = grow(&c->edge_tu, &c2, (size_t)d.w4 * d.h4, c->stream, false))) return rc;
+      if ((rc = grow(&c->edge_pb, &c3, (size_t)d.w4 * d.h4, c->stream, false))) return rc;
+      c->cap_u4 = c1 < c2 ? (c1 < c3 ? c1 : c3) : (c2 < c3 ? c2 : c3);
+    }
+  }
+  if ((rc = grow(&c->ctb_done, &c->cap_ctb, (size_t)d.nCtb, c->stream, true))) return rc;
+  if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + 1, c->stream, false))) return rc;
+  if ((rc = grow(&c->resbuf, &c->cap_res, (size_t)pic.res_len + 1, c->stream, false))) return rc;
+
+  const bool want_sao = (c->stages & M355_STAGE_SAO) && (pp.flags & M355_PF_SAO_ENABLED);
+  Frame* target = dst;
+  if (want_sao) {
+    if (!c->work.used || c->work.w != dst->w || c->work.h != dst->h || c->work.cf != dst->cf || c->work.bdl != dst->bdl || c->work.bdc != dst->bdc) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (c->work.used) frame_free(c->work);
+      frame_geometry(c->work, dst->w, dst->h, dst->cf, dst->bdl, dst->bdc);
+      if ((rc = frame_alloc(c->work))) return rc;
+    }
+    target = &c->work;
+  }
+  for (int cc = 0; cc < 3; cc++) {
+    d.pw[cc] = dst->pw[cc]; d.ph[cc] = dst->ph[cc];
+    d.plane[cc] = target->plane[cc]; d.stride[cc] = target->stride[cc];
+    d.out_plane[cc] = dst->plane[cc]; d.out_stride[cc] = dst->stride[cc];
+  }
+  d.cb_cu = c->cb_cu; d.cuf = c->cuf; d.edge_tu = c->edge_tu; d.edge_pb = c->edge_pb; d.pb_of = c->pb_of;
+  d.resbuf = c->resbuf; d.ctb_done = c->ctb_done; d.ticket = c->ticket; d.timeout = c->timeout;
+  d.epoch = ++c->epoch;
+  if (d.epoch == 0) d.epoch = ++c->epoch;
+
+  hipStream_t st = c->stream;
+  hipEventRecord(c->ev[0], st);
+  const bool need_meta = (c->stages & (M355_STAGE_INTRA | M355_STAGE_DEBLOCK | M355_STAGE_SAO)) != 0;
+  if (need_meta) m355_launch_meta(d, st);
+  if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, refs, hbd, st);
+  hipEventRecord(c->ev[1], st);
+  if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
+  hipEventRecord(c->ev[2], st);
+  if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
+  hipEventRecord(c->ev[3], st);
+  if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
+  hipEventRecord(c->ev[4], st);
+  if (want_sao) m355_launch_sao(d, hbd, st);
+  hipEventRecord(c->ev[5], st);
+  c->timed = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return M355_OK;
+}
+
+int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
+{
+  int rc = upload(c, c->transient, pic);
+  if (rc) return rc;
+  return decode(c, c->transient);
+}
+
+int m355_wait(m355_ctx* c)
+{
+  hipSetDevice(c->device);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint32_t t = 0;
+  HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
+  if (t) {
+    hipMemset(c->timeout, 0, 4);
+    return fail(M355_ERR_TIMEOUT, "intra wavefront spin bound exceeded");
+  }
+  return M355_OK;
+}
+
+int m355_picture_upload(m355_ctx* c, const m355_picture* pic)
+{
+  int idx = -1;
+  for (size_t i = 0; i < c->resident.size(); i++) if (!c->resident[i].used) { idx = (int)i; break; }
+  if (idx < 0) { c->resident.push_back(Resident()); idx = (int)c->resident.size() - 1; }
+  int rc = upload(c, c->resident[idx], pic);
+  if (rc) { resident_free(c->resident[idx]); return -rc; }
+  return idx;
+}
+int m355_picture_release(m355_ctx* c, int h)
+{
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  resident_free(c->resident[h]);
+  return M355_OK;
+}
+int m355_decode_resident(m355_ctx* c, int h)
+{
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");
+  return decode(c, c->resident[h]);
+}
+int m355_set_stages(m355_ctx* c, int mask) { c->stages = mask & M355_STAGE_ALL; return M355_OK; }
+
+int m355_last_timing(m355_ctx* c, float* total_ms, float stage_ms[5])
+{
+  if (!c->timed) return fail(M355_ERR_INVALID, "nothing decoded yet");
+  hipSetDevice(c->device);
+  HIPCHK(hipEventSynchronize(c->ev[5]));
+  if (total_ms) HIPCHK(hipEventElapsedTime(total_ms, c->ev[0], c->ev[5]));
+  if (stage_ms)
+    for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&stage_ms[i], c->ev[i], c->ev[i + 1]));
+  return M355_OK;
+}
+
+} /* extern "C" */
