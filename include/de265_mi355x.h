@@ -406,10 +406,11 @@ enum { M355_STAGE_INTER = 1, M355_STAGE_RESIDUAL = 2, M355_STAGE_INTRA = 4, M355
        M355_STAGE_SAO = 16, M355_STAGE_ALL = 31 };
 M355_API int m355_set_stages(m355_ctx* ctx, int stage_mask);
 
-/* Timing of the last m355_decode_resident()/submit on this context, from HIP events recorded on the
- * context's own stream: total milliseconds and per-stage milliseconds [inter,residual,intra,
- * deblock,sao]. */
-M355_API int m355_last_timing(m355_ctx* ctx, float* total_ms, float stage_ms[5]);
+/* Per-stage device timing from HIP events recorded on the context's OWN stream around every decode
+ * enqueued since m355_timing_reset(): averages in milliseconds, stage order
+ * [meta, inter, residual, intra, deblock, sao]. m355_timing_collect() waits for the work. */
+M355_API int m355_timing_reset(m355_ctx* ctx);
+M355_API int m355_timing_collect(m355_ctx* ctx, int* n_decodes, float* total_ms, float stage_ms[6]);
 M355_API void* m355_stream(m355_ctx* ctx);   /* hipStream_t of the context */
 
 #ifdef __cplusplus

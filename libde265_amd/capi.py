@@ -48,7 +48,8 @@ class Library:
         L.m355_picture_release.argtypes = [vp, i]
         L.m355_decode_resident.argtypes = [vp, i]
         L.m355_set_stages.argtypes = [vp, i]
-        L.m355_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.m355_timing_reset.argtypes = [vp]
+        L.m355_timing_collect.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.m355_stream.argtypes = [vp]
         L.m355_stream.restype = vp
         L.init_acceleration_functions_mi355x.argtypes = [vp]
@@ -146,11 +147,16 @@ class Context:
     def set_stages(self, mask):
         self.L.check(self.L.lib.m355_set_stages(self.h, mask))
 
-    def last_timing(self):
+    def timing_reset(self):
+        self.L.check(self.L.lib.m355_timing_reset(self.h))
+
+    def timing_collect(self):
+        """-> (n_decodes, avg_total_ms, {stage: avg_ms}) for all decodes since timing_reset()"""
+        n = ctypes.c_int()
         total = ctypes.c_float()
-        st = (ctypes.c_float * 5)()
-        self.L.check(self.L.lib.m355_last_timing(self.h, ctypes.byref(total), st))
-        return total.value, list(st)
+        st = (ctypes.c_float * 6)()
+        self.L.check(self.L.lib.m355_timing_collect(self.h, ctypes.byref(n), ctypes.byref(total), st))
+        return n.value, total.value, dict(zip(["meta", "inter", "residual", "intra", "deblock", "sao"], list(st)))
 
     def stream(self):
         return self.L.lib.m355_stream(self.h)

@@ -90,7 +90,8 @@ struct m355_ctx {
   size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0;
   uint32_t epoch = 0;
   int stages = M355_STAGE_ALL;
-  hipEvent_t ev[7] = {};
+  std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
+  int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
 };
 
@@ -128,7 +129,6 @@ int m355_create(int device, m355_ctx** out)
   m355_ctx* c = new m355_ctx;
   c->device = device;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int i = 0; i < 7; i++) HIPCHK(hipEventCreate(&c->ev[i]));
   HIPCHK(hipMalloc(&c->ticket, 64));
   HIPCHK(hipMalloc(&c->timeout, 64));
   HIPCHK(hipMemset(c->ticket, 0, 64));
@@ -155,7 +155,7 @@ void m355_destroy(m355_ctx* c)
   resident_free(c->transient);
   void* bufs[] = {c->cb_cu, c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->edge_pb, c->cuf, c->resbuf};
   for (void* b : bufs) if (b) hipFree(b);
-  for (int i = 0; i < 7; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+  for (hipEvent_t e : c->evs) hipEventDestroy(e);
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -478,19 +478,24 @@ static int decode(m355_ctx* c, Resident& r)
   if (d.epoch == 0) d.epoch = ++c->epoch;
 
   hipStream_t st = c->stream;
-  hipEventRecord(c->ev[0], st);
+  if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
+  while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
+  hipEvent_t* ev = &c->evs[c->ev_used * 7];
+  c->ev_used++;
+  hipEventRecord(ev[0], st);
   const bool need_meta = (c->stages & (M355_STAGE_INTRA | M355_STAGE_DEBLOCK | M355_STAGE_SAO)) != 0;
   if (need_meta) m355_launch_meta(d, st);
+  hipEventRecord(ev[1], st);
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, refs, hbd, st);
-  hipEventRecord(c->ev[1], st);
+  hipEventRecord(ev[2], st);
   if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
-  hipEventRecord(c->ev[2], st);
+  hipEventRecord(ev[3], st);
   if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
-  hipEventRecord(c->ev[3], st);
+  hipEventRecord(ev[4], st);
   if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
-  hipEventRecord(c->ev[4], st);
+  hipEventRecord(ev[5], st);
   if (want_sao) m355_launch_sao(d, hbd, st);
-  hipEventRecord(c->ev[5], st);
+  hipEventRecord(ev[6], st);
   c->timed = true;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -541,14 +546,24 @@ int m355_decode_resident(m355_ctx* c, int h)
 }
 int m355_set_stages(m355_ctx* c, int mask) { c->stages = mask & M355_STAGE_ALL; return M355_OK; }
 
-int m355_last_timing(m355_ctx* c, float* total_ms, float stage_ms[5])
+int m355_timing_reset(m355_ctx* c) { c->ev_used = 0; return M355_OK; }
+
+/* averages over every decode enqueued since m355_timing_reset(); waits for them to finish */
+int m355_timing_collect(m355_ctx* c, int* n_decodes, float* total_ms, float stage_ms[6])
 {
-  if (!c->timed) return fail(M355_ERR_INVALID, "nothing decoded yet");
+  if (c->ev_used == 0) return fail(M355_ERR_INVALID, "nothing decoded since the last timing reset");
   hipSetDevice(c->device);
-  HIPCHK(hipEventSynchronize(c->ev[5]));
-  if (total_ms) HIPCHK(hipEventElapsedTime(total_ms, c->ev[0], c->ev[5]));
-  if (stage_ms)
-    for (int i = 0; i < 5; i++) HIPCHK(hipEventElapsedTime(&stage_ms[i], c->ev[i], c->ev[i + 1]));
+  HIPCHK(hipEventSynchronize(c->evs[(c->ev_used - 1) * 7 + 6]));
+  double tot = 0, st[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < c->ev_used; k++) {
+    hipEvent_t* ev = &c->evs[k * 7];
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[6])); tot += ms;
+    for (int i = 0; i < 6; i++) { HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); st[i] += ms; }
+  }
+  if (n_decodes) *n_decodes = c->ev_used;
+  if (total_ms) *total_ms = (float)(tot / c->ev_used);
+  if (stage_ms) for (int i = 0; i < 6; i++) stage_ms[i] = (float)(st[i] / c->ev_used);
   return M355_OK;
 }
 
