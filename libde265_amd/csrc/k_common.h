@@ -67,6 +67,7 @@ struct DevPic {
   uint32_t epoch;                   /* value meaning "done" for this submission */
   const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks, decode order */
   int n_intra_work;
+  const uint8_t* ctb_dep;           /* per CTB: bit n = wait for neighbour n (0 L, 1 TL, 2 T, 3 TR); bit 4 = somebody waits for us */
 };
 
 enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };

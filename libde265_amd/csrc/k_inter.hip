@@ -57,7 +57,6 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
     for (int ty = 0; ty < H; ty += 16)
       for (int tx = 0; tx < W; tx += 16) {
         const int tw = min(16, W - tx), th = min(16, H - ty);
-        const int nout = tw * th;
         int pred[2][4];
 #pragma unroll
         for (int l = 0; l < 2; l++) {
@@ -75,41 +74,48 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
           int xf, yf, xi, yi;
           if (c == 0) { xf = mvx & 3; yf = mvy & 3; xi = xP + (mvx >> 2); yi = yP + (mvy >> 2); }
           else { mvx *= 2 / p.sw; mvy *= 2 / p.sh; xf = mvx & 7; yf = mvy & 7; xi = xP + (mvx >> 3); yi = yP + (mvy >> 3); }
-          /* 1. reference window -> LDS (coordinate clamp = picture-edge padding, motion.cc:141-159) */
+          /* 1. reference window -> LDS (coordinate clamp = picture-edge padding, motion.cc:141-159);
+                32 lanes per window row, two rows per step: no integer division anywhere */
           const int ww = tw + ntaps - 1, wh = th + ntaps - 1;
-          for (int idx = lane; idx < ww * wh; idx += 64) {
-            const int wy = idx / ww, wx = idx - wy * ww;
-            const int xa = d_clip3(0, pw - 1, xi + tx + wx - before), ya = d_clip3(0, ph - 1, yi + ty + wy - before);
-            win[wy * WIN_PITCH + wx] = rp[ya * rstride + xa];
-          }
-          wave_sync();
-          /* 2. horizontal taps -> int16 (fallback-motion.cc:512-565 / 350-375) */
-          for (int idx = lane; idx < wh * tw; idx += 64) {
-            const int r = idx / tw, x = idx - r * tw;
-            int v;
-            if (xf == 0) v = win[r * WIN_PITCH + x + before];
-            else {
-              int s = 0;
-              if (c == 0) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) s += c_qpel_taps[xf][k] * win[r * WIN_PITCH + x + k];
-              } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) s += c_epel_taps[xf][k] * win[r * WIN_PITCH + x + k];
+          {
+            const int wx = lane & 31, wy0 = lane >> 5;
+            const int xa = d_clip3(0, pw - 1, xi + tx + wx - before);
+            if (wx < ww)
+              for (int wy = wy0; wy < wh; wy += 2) {
+                const int ya = d_clip3(0, ph - 1, yi + ty + wy - before);
+                win[wy * WIN_PITCH + wx] = rp[ya * rstride + xa];
               }
-              v = s >> shift1;
-            }
-            tmp[r * 16 + x] = (int16_t)v;
           }
           wave_sync();
-          /* 3. vertical taps -> registers (fallback-motion.cc:573-626 / 381-404) */
+          /* 2. horizontal taps -> int16 (fallback-motion.cc:512-565 / 350-375); 16 lanes per row */
+          {
+            const int x = lane & 15, r0 = lane >> 4;
+            if (x < tw)
+              for (int r = r0; r < wh; r += 4) {
+                int v;
+                if (xf == 0) v = win[r * WIN_PITCH + x + before];
+                else {
+                  int s = 0;
+                  if (c == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) s += c_qpel_taps[xf][k] * win[r * WIN_PITCH + x + k];
+                  } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) s += c_epel_taps[xf][k] * win[r * WIN_PITCH + x + k];
+                  }
+                  v = s >> shift1;
+                }
+                tmp[r * 16 + x] = (int16_t)v;
+              }
+          }
+          wave_sync();
+          /* 3. vertical taps -> registers (fallback-motion.cc:573-626 / 381-404); output k = rows 4k.. */
           const int vshift = (xf == 0) ? shift1 : 6;
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const int o = lane + 64 * k;
+            const int x = lane & 15, y = 4 * k + (lane >> 4);
             int v = 0;
-            if (o < nout) {
-              const int y = o / tw, x = o - y * tw;
+            if (x < tw && y < th) {
               if (yf == 0) {
                 v = tmp[(y + before) * 16 + x];
                 if (xf == 0) v = (int)((unsigned)v & 0xFFFF) << shift3; /* full-pel: ref << shift3 */
@@ -132,9 +138,8 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
         /* 4. weighted write-back (fallback-motion.cc:33-256, selection motion.cc:493-688) */
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const int o = lane + 64 * k;
-          if (o >= nout) continue;
-          const int y = o / tw, x = o - y * tw;
+          const int x = lane & 15, y = 4 * k + (lane >> 4);
+          if (x >= tw || y >= th) continue;
           int v;
           if (mc0 && mc1) {
             if (weighted) {

@@ -88,15 +88,20 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
   const m355_ctb ctbinfo = p.ctbs[ctb];
   const int l2c = p.pp.log2_ctb_size;
 
-  /* ---- wait for the neighbour CTBs this CTB may read (left, above-left, above, above-right) ---- */
-  if (threadIdx.x == 0) {
+  /* ---- wait for the neighbour CTBs whose INTRA output this CTB reads (left, above-left, above,
+   * above-right).  The host derives the mask from the block lists (runtime.hip, intra_dependencies):
+   * a neighbour matters only if it is in the same tile, one of our intra blocks touches the shared
+   * border on our side, and one of its intra blocks touches it on its side.  Everything else next
+   * door was finished by the preceding kernels (stream order), so sparse intra CUs in inter
+   * pictures decode fully in parallel and only genuinely chained CTBs form a wavefront. ---- */
+  const uint8_t dep = p.ctb_dep[ctb];
+  if (threadIdx.x == 0 && (dep & 15)) {
     const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
     for (int n = 0; n < 4; n++) {
       const int nx = ctbX + dx[n], ny = ctbY + dy[n];
       if (nx < 0 || ny < 0 || nx >= p.ctbW) continue;
       const int nb = ny * p.ctbW + nx;
-      if (p.tile_id[nb] != p.tile_id[ctb]) continue;       /* never read across tiles; may be later in decode order */
-      if (p.ctbs[nb].ib_count == 0) continue;               /* finished by the preceding kernels (stream order) */
+      if (!((dep >> n) & 1)) continue;         /* that neighbour's intra output is never read here */
       unsigned spins = 0;
       while (__hip_atomic_load(&p.ctb_done[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
         __builtin_amdgcn_s_sleep(2);
@@ -320,6 +325,7 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
   }
 
   /* ---- publish (guideline 16: stores -> barrier -> one-lane agent release -> drain -> flag) ---- */
+  if (!(dep & 16)) return;            /* nobody waits for this CTB (host-derived): nothing to publish */
   d_drain_vmem();
   __syncthreads();
   if (threadIdx.x == 0) {

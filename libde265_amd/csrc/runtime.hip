@@ -315,6 +315,52 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
 
 /* ----------------------------------------------------------------------- upload --------------- */
 
+/* Which neighbour CTBs must the intra wavefront wait for?  (k_intra.hip reads this mask.)
+ * touch bits per CTB: an intra block reaches its right column (1), bottom row (2), both (4);
+ * need bits: an intra block reads across the left (L), top (T), top-left (TL), top-right (TR) border. */
+static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, const uint16_t* tile_id, uint8_t* dep)
+{
+  const m355_pic_params& pp = pic->pp;
+  const int nCtb = ctbW * ctbH;
+  std::vector<uint8_t> touch(nCtb, 0), need(nCtb, 0);
+  const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
+  for (int c = 0; c < nCtb; c++) {
+    const m355_ctb& ctb = pic->ctbs[c];
+    const int cx = c % ctbW, cy = c / ctbW;
+    for (uint32_t k = 0; k < ctb.ib_count; k++) {
+      const m355_ib& ib = pic->ibs[ctb.ib_start + k];
+      const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
+      const int cw = (1 << pp.log2_ctb_size) >> csw, ch = (1 << pp.log2_ctb_size) >> csh;
+      const int lx = ib.x - ((cx << pp.log2_ctb_size) >> csw), ly = ib.y - ((cy << pp.log2_ctb_size) >> csh);
+      const int n = 1 << ib.log2_size;
+      if (lx + n == cw) touch[c] |= 1;
+      if (ly + n == ch) touch[c] |= 2;
+      if (lx + n == cw && ly + n == ch) touch[c] |= 4;
+      if (ib.flags & M355_IBF_PCM) continue;              /* raw blocks read no neighbours */
+      if (lx == 0) need[c] |= 1;                           /* L  */
+      if (lx == 0 && ly == 0) need[c] |= 2;                /* TL */
+      if (ly == 0) need[c] |= 4;                           /* T  */
+      if (ly == 0 && lx + 2 * n > cw) need[c] |= 8;        /* TR */
+    }
+  }
+  for (int c = 0; c < nCtb; c++) dep[c] = 0;
+  for (int c = 0; c < nCtb; c++) {
+    const int cx = c % ctbW, cy = c / ctbW;
+    const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
+    const uint8_t tbit[4] = {1, 4, 2, 2};                   /* what the neighbour must touch on its side */
+    for (int n = 0; n < 4; n++) {
+      const int nx = cx + dx[n], ny = cy + dy[n];
+      if (nx < 0 || ny < 0 || nx >= ctbW) continue;
+      const int nb = ny * ctbW + nx;
+      if (tile_id[nb] != tile_id[c]) continue;             /* never read across tiles (intrapred.h:499-508) */
+      if (((need[c] >> n) & 1) && (touch[nb] & tbit[n])) {
+        dep[c] |= (uint8_t)(1 << n);
+        dep[nb] |= 16;                                     /* somebody waits for nb: it must publish */
+      }
+    }
+  }
+}
+
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
@@ -326,7 +372,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const int nCtb = ctbW * ctbH;
   const int nrb = pic->rb_count[0] + pic->rb_count[1] + pic->rb_count[2] + pic->rb_count[3];
   struct Seg { const void* src; size_t bytes; size_t ofs; };
-  Seg seg[16];
+  Seg seg[20];
   int ns = 0;
   size_t total = 0;
   auto add = [&](const void* src, size_t bytes) { seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].ofs = total; total += al(bytes ? bytes : 1); return ns++; };
@@ -345,6 +391,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const int i_rs = add(nullptr, 4 * (size_t)nCtb);   /* ts2rs    */
   const int i_ti = add(nullptr, 2 * (size_t)nCtb);   /* tile_id  */
   const int i_iw = add(nullptr, 4 * (size_t)nCtb);   /* intra_work */
+  const int i_dp = add(nullptr, (size_t)nCtb);       /* ctb_dep */
 
   hipSetDevice(c->device);
   if (total > r.cap) {
@@ -379,6 +426,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   for (int t = 0; t < nCtb; t++)
     if (pic->ctbs[ts2rs[t]].ib_count) iw[nw++] = ts2rs[t];
   r.n_intra_work = nw;
+  intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
   r.bytes = total;
   HIPCHK(hipMemcpyAsync(r.dev, r.host, total, hipMemcpyHostToDevice, c->stream));
 
@@ -410,6 +458,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
   d.intra_work = (const uint32_t*)(r.dev + seg[i_iw].ofs);
   d.n_intra_work = nw;
+  d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
   r.used = true;
   return M355_OK;
 }
