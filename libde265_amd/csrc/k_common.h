@@ -25,7 +25,6 @@ struct DevRef {            /* one reference frame (indexed by m355_pb.ref_slot) 
   int valid;
   int pad;
 };
-struct DevRefTable { DevRef r[M355_MAX_REF_FRAMES]; };   /* passed by value (kernarg, 1.5 KB) */
 
 struct DevPic {
   m355_pic_params pp;
@@ -36,6 +35,7 @@ struct DevPic {
   int stride[3];
   void* out_plane[3];               /* SAO output (the DPB frame) */
   int out_stride[3];
+  const DevRef* refs;               /* M355_MAX_REF_FRAMES entries in device memory */
   /* work lists (device copies) */
   const m355_slice* slices;
   const m355_ctb* ctbs;
@@ -74,7 +74,7 @@ enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
 
 /* ---- launchers (each in its stage's .hip); all asynchronous on `st` ---- */
 void m355_launch_meta(const DevPic& p, hipStream_t st);
-void m355_launch_inter(const DevPic& p, const DevRefTable& refs, bool hbd, hipStream_t st);
+void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);

@@ -29,12 +29,14 @@ __constant__ int8_t c_epel_taps[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4,
 #define WIN_ROWS 23
 
 template <class PIX>
-__global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
+__global__ void __launch_bounds__(256) k_inter(DevPic p)
 {
   __shared__ uint16_t s_win[4][WIN_ROWS * WIN_PITCH];
   __shared__ int16_t s_tmp[4][WIN_ROWS * 16];
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  /* everything derived from the PB record is wave-uniform: tell the compiler (readfirstlane) so the
+     record, the MV phases and the filter taps live in SGPRs and the loops use scalar branches */
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int pbi = blockIdx.x * 4 + wave;
   if (pbi >= p.n_pbs) return; /* wave-uniform */
   const m355_pb pb = p.pbs[pbi];
@@ -67,13 +69,19 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
             for (int k = 0; k < 4; k++) pred[l][k] = 1 << 13;
             continue;
           }
-          const DevRef ref = refs.r[pb.ref_slot[l]];
-          const PIX* rp = (const PIX*)ref.plane[c];
-          const int rstride = ref.stride[c];
+          const DevRef* ref = &p.refs[pb.ref_slot[l]];
+          const PIX* rp = (const PIX*)ref->plane[c];
+          const int rstride = ref->stride[c];
           int mvx = pb.mv[l][0], mvy = pb.mv[l][1];
           int xf, yf, xi, yi;
           if (c == 0) { xf = mvx & 3; yf = mvy & 3; xi = xP + (mvx >> 2); yi = yP + (mvy >> 2); }
           else { mvx *= 2 / p.sw; mvy *= 2 / p.sh; xf = mvx & 7; yf = mvy & 7; xi = xP + (mvx >> 3); yi = yP + (mvy >> 3); }
+          int tpx[8], tpy[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            tpx[t] = c == 0 ? c_qpel_taps[xf][t] : (t < 4 ? c_epel_taps[xf][t] : 0);
+            tpy[t] = c == 0 ? c_qpel_taps[yf][t] : (t < 4 ? c_epel_taps[yf][t] : 0);
+          }
           /* 1. reference window -> LDS (coordinate clamp = picture-edge padding, motion.cc:141-159);
                 32 lanes per window row, two rows per step: no integer division anywhere */
           const int ww = tw + ntaps - 1, wh = th + ntaps - 1;
@@ -98,10 +106,10 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
                   int s = 0;
                   if (c == 0) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) s += c_qpel_taps[xf][k] * win[r * WIN_PITCH + x + k];
+                    for (int k = 0; k < 8; k++) s += tpx[k] * win[r * WIN_PITCH + x + k];
                   } else {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) s += c_epel_taps[xf][k] * win[r * WIN_PITCH + x + k];
+                    for (int k = 0; k < 4; k++) s += tpx[k] * win[r * WIN_PITCH + x + k];
                   }
                   v = s >> shift1;
                 }
@@ -123,10 +131,10 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
                 int s = 0;
                 if (c == 0) {
 #pragma unroll
-                  for (int t = 0; t < 8; t++) s += c_qpel_taps[yf][t] * tmp[(y + t) * 16 + x];
+                  for (int t = 0; t < 8; t++) s += tpy[t] * tmp[(y + t) * 16 + x];
                 } else {
 #pragma unroll
-                  for (int t = 0; t < 4; t++) s += c_epel_taps[yf][t] * tmp[(y + t) * 16 + x];
+                  for (int t = 0; t < 4; t++) s += tpy[t] * tmp[(y + t) * 16 + x];
                 }
                 v = s >> vshift;
               }
@@ -167,10 +175,10 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p, DevRefTable refs)
   }
 }
 
-void m355_launch_inter(const DevPic& p, const DevRefTable& refs, bool hbd, hipStream_t st)
+void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
 {
   if (!p.n_pbs) return;
   const dim3 grid((p.n_pbs + 3) / 4), block(256);
-  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter<uint16_t>), grid, block, 0, st, p, refs);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter<uint8_t>), grid, block, 0, st, p, refs);
+  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter<uint16_t>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter<uint8_t>), grid, block, 0, st, p);
 }

@@ -73,6 +73,9 @@ struct Resident {
   char* host = nullptr;        /* pinned staging arena */
   size_t cap = 0, bytes = 0;
   DevPic dp;                   /* device pointers filled at upload; frame planes at decode */
+  DevRef* refs_dev = nullptr;  /* reference-frame table (device) */
+  DevRef* refs_host = nullptr; /* pinned staging + last uploaded contents */
+  bool refs_valid = false;
   int n_intra_work = 0;
 };
 
@@ -141,6 +144,8 @@ static void resident_free(Resident& r)
 {
   if (r.dev) hipFree(r.dev);
   if (r.host) hipHostFree(r.host);
+  if (r.refs_dev) hipFree(r.refs_dev);
+  if (r.refs_host) hipHostFree(r.refs_host);
   r = Resident();
 }
 
@@ -476,8 +481,8 @@ static int decode(m355_ctx* c, Resident& r)
     return fail(M355_ERR_INVALID, "dst frame geometry does not match the picture parameters");
   const bool hbd = pp.bit_depth_luma > 8;
   DevPic d = r.dp;
-  DevRefTable refs;
-  memset(&refs, 0, sizeof(refs));
+  DevRef refs[M355_MAX_REF_FRAMES];
+  memset(refs, 0, sizeof(refs));
   for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
     if (pic.ref_frames[i] < 0) continue;
     Frame* f = get_frame(c, pic.ref_frames[i]);
@@ -485,9 +490,21 @@ static int decode(m355_ctx* c, Resident& r)
     if (f->w != dst->w || f->h != dst->h || f->cf != dst->cf || f->bdl != dst->bdl || f->bdc != dst->bdc)
       return fail(M355_ERR_INVALID, "reference frame %d geometry differs (motion.cc:377-398 would conceal; record FILL instead)", i);
     if (f == dst) return fail(M355_ERR_INVALID, "a picture cannot reference itself");
-    for (int cc = 0; cc < 3; cc++) { refs.r[i].plane[cc] = f->plane[cc]; refs.r[i].stride[cc] = f->stride[cc]; }
-    refs.r[i].valid = 1;
+    for (int cc = 0; cc < 3; cc++) { refs[i].plane[cc] = f->plane[cc]; refs[i].stride[cc] = f->stride[cc]; }
+    refs[i].valid = 1;
   }
+  if (!r.refs_dev) {
+    HIPCHK(hipMalloc(&r.refs_dev, sizeof(refs)));
+    HIPCHK(hipHostMalloc(&r.refs_host, sizeof(refs), hipHostMallocDefault));
+    r.refs_valid = false;
+  }
+  if (!r.refs_valid || memcmp(r.refs_host, refs, sizeof(refs)) != 0) {
+    HIPCHK(hipStreamSynchronize(c->stream));       /* the staging copy may still be in flight */
+    memcpy(r.refs_host, refs, sizeof(refs));
+    HIPCHK(hipMemcpyAsync(r.refs_dev, r.refs_host, sizeof(refs), hipMemcpyHostToDevice, c->stream));
+    r.refs_valid = true;
+  }
+  d.refs = r.refs_dev;
   /* scratch */
   int rc;
   if ((rc = grow(&c->cb_cu, &c->cap_cb, (size_t)d.wcb * d.hcb, c->stream, false))) return rc;
@@ -535,7 +552,7 @@ static int decode(m355_ctx* c, Resident& r)
   const bool need_meta = (c->stages & (M355_STAGE_INTRA | M355_STAGE_DEBLOCK | M355_STAGE_SAO)) != 0;
   if (need_meta) m355_launch_meta(d, st);
   hipEventRecord(ev[1], st);
-  if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, refs, hbd, st);
+  if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   hipEventRecord(ev[2], st);
   if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
   hipEventRecord(ev[3], st);
