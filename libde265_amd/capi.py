@@ -53,6 +53,7 @@ class Library:
         L.m355_stream.argtypes = [vp]
         L.m355_stream.restype = vp
         L.init_acceleration_functions_mi355x.argtypes = [vp]
+        L.m355_transform_add_batch.argtypes = [i, i, i, i, vp, ctypes.c_size_t, vp, ctypes.c_ssize_t, vp]
 
     def error(self):
         return (self.lib.m355_last_error() or b"").decode()
@@ -160,3 +161,63 @@ class Context:
 
     def stream(self):
         return self.L.lib.m355_stream(self.h)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Slot layer: ctypes mirror of `struct m355_acceleration_functions` (= the reference's
+# `struct acceleration_functions`, libde265/acceleration.h:29-231), member for member.
+# ---------------------------------------------------------------------------------------------------
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_ssize_t
+_F = lambda *a: ctypes.CFUNCTYPE(None, *a)  # noqa: E731  (all slots return void)
+_WAVG8, _UNW8 = _F(_vp, _sz, _vp, _vp, _sz, _i, _i), _F(_vp, _sz, _vp, _sz, _i, _i)
+_W8, _WB8 = _F(_vp, _sz, _vp, _sz, _i, _i, _i, _i, _i), _F(_vp, _sz, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i)
+_WAVG16, _UNW16 = _F(_vp, _sz, _vp, _vp, _sz, _i, _i, _i), _F(_vp, _sz, _vp, _sz, _i, _i, _i)
+_W16, _WB16 = _F(_vp, _sz, _vp, _sz, _i, _i, _i, _i, _i, _i), _F(_vp, _sz, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i)
+_EPEL8 = _F(_vp, _sz, _vp, _sz, _i, _i, _i, _i, _vp)
+_EPEL = _F(_vp, _sz, _vp, _sz, _i, _i, _i, _i, _vp, _i)
+_QPEL8, _QPEL16 = _F(_vp, _sz, _vp, _sz, _i, _i, _vp), _F(_vp, _sz, _vp, _sz, _i, _i, _vp, _i)
+_BYP, _TS8, _TSR8, _TA8 = _F(_vp, _vp, _i), _F(_vp, _vp, _sz), _F(_vp, _vp, _i, _sz), _F(_vp, _vp, _sz)
+_TA16, _ROT, _IDCT = _F(_vp, _vp, _sz, _i), _F(_vp, _i), _F(_vp, _vp, _i, _i)
+_ADDR, _DEQ = _F(_vp, _sz, _vp, _i, _i), _F(_vp, _vp, _vp, _i, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32)
+_DBL, _DBC, _RDP = _F(_vp, _sz, _i, _i, _i, _i, _i, _i, _i), _F(_vp, _sz, _i, _i, _i, _i), _F(_vp, _vp, _i, _i, _i)
+_IP, _IA = _F(_vp, _sz, _i, _i, _vp), _F(_vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp)
+_FWD = _F(_vp, _vp, _sz)
+
+
+class AccelerationFunctions(ctypes.Structure):
+    _fields_ = [
+        ("put_weighted_pred_avg_8", _WAVG8), ("put_unweighted_pred_8", _UNW8), ("put_weighted_pred_8", _W8),
+        ("put_weighted_bipred_8", _WB8),
+        ("put_weighted_pred_avg_16", _WAVG16), ("put_unweighted_pred_16", _UNW16), ("put_weighted_pred_16", _W16),
+        ("put_weighted_bipred_16", _WB16),
+        ("put_hevc_epel_8", _EPEL8), ("put_hevc_epel_h_8", _EPEL), ("put_hevc_epel_v_8", _EPEL), ("put_hevc_epel_hv_8", _EPEL),
+        ("put_hevc_qpel_8", (_QPEL8 * 4) * 4),
+        ("put_hevc_epel_16", _EPEL), ("put_hevc_epel_h_16", _EPEL), ("put_hevc_epel_v_16", _EPEL), ("put_hevc_epel_hv_16", _EPEL),
+        ("put_hevc_qpel_16", (_QPEL16 * 4) * 4),
+        ("transform_bypass", _BYP), ("transform_bypass_rdpcm_v", _BYP), ("transform_bypass_rdpcm_h", _BYP),
+        ("transform_skip_8", _TS8), ("transform_skip_rdpcm_v_8", _TSR8), ("transform_skip_rdpcm_h_8", _TSR8),
+        ("transform_4x4_dst_add_8", _TA8), ("transform_add_8", _TA8 * 4),
+        ("transform_skip_16", _TA16), ("transform_4x4_dst_add_16", _TA16), ("transform_add_16", _TA16 * 4),
+        ("rotate_coefficients", _ROT), ("transform_idst_4x4", _IDCT), ("transform_idct_4x4", _IDCT),
+        ("transform_idct_8x8", _IDCT), ("transform_idct_16x16", _IDCT), ("transform_idct_32x32", _IDCT),
+        ("add_residual_8", _ADDR), ("add_residual_16", _ADDR),
+        ("dequant_coeff_block", _DEQ),
+        ("deblock_luma_8", _DBL), ("deblock_chroma_8", _DBC),
+        ("rdpcm_v", _RDP), ("rdpcm_h", _RDP), ("transform_skip_residual", _RDP),
+        ("intra_pred_dc_8", _IP), ("intra_pred_dc_16", _IP), ("intra_pred_planar_8", _IP), ("intra_pred_planar_16", _IP),
+        ("intra_pred_angular_8", _IA), ("intra_pred_angular_16", _IA),
+        ("fwd_transform_4x4_dst_8", _FWD), ("fwd_transform_8", _FWD * 4), ("hadamard_transform_8", _FWD * 4),
+    ]
+
+
+assert ctypes.sizeof(AccelerationFunctions) == 94 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def acceleration_functions(lib=None):
+    """A table filled by init_acceleration_functions_mi355x() (raises when no device is visible)."""
+    lib = lib or Library()
+    t = AccelerationFunctions()
+    rc = lib.lib.init_acceleration_functions_mi355x(ctypes.byref(t))
+    if rc != 0:
+        raise M355Error(rc, "init_acceleration_functions_mi355x: no HIP device (there is no CPU fallback)")
+    return t
