@@ -10,4 +10,28 @@
  * zero, letting the flag store overtake the L2 write-back (MI355X guide, "Compiler hazard"). */
 __device__ __forceinline__ void d_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+/* pointers loaded from device tables: tell hipcc they are global (else it emits flat_load) */
+#define M355_GLOBAL __attribute__((address_space(1)))
+
+/* unaligned (2-byte / 1-byte aligned) vector loads from global memory: gfx950 executes them as single
+ * global_load_dwordx4/x3/x2 (checked on hardware, tools/ubench/ub_inter.hip) */
+typedef unsigned m355_u4 __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned m355_u3 __attribute__((ext_vector_type(3), aligned(1)));
+typedef unsigned m355_u2 __attribute__((ext_vector_type(2), aligned(1)));
+typedef unsigned m355_u1 __attribute__((aligned(1)));
+typedef unsigned short m355_h1 __attribute__((aligned(1)));
+__device__ __forceinline__ void d_ldg16(const M355_GLOBAL void* p, unsigned* o) { const m355_u4 v = *(const M355_GLOBAL m355_u4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+__device__ __forceinline__ void d_ldg12(const M355_GLOBAL void* p, unsigned* o) { const m355_u3 v = *(const M355_GLOBAL m355_u3*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+__device__ __forceinline__ void d_ldg8(const M355_GLOBAL void* p, unsigned* o) { const m355_u2 v = *(const M355_GLOBAL m355_u2*)p; o[0] = v.x; o[1] = v.y; }
+__device__ __forceinline__ unsigned d_ldg4(const M355_GLOBAL void* p) { return *(const M355_GLOBAL m355_u1*)p; }
+__device__ __forceinline__ unsigned d_ldg2(const M355_GLOBAL void* p) { return *(const M355_GLOBAL m355_h1*)p; }
+
+/* v_dot2c_i32_i16: c + a.lo*b.lo + a.hi*b.hi on packed signed 16-bit pairs — two filter taps per VALU
+ * issue (measured on MI355X: same issue rate as v_mad_i32_i24, tools/ubench/ub_inter.hip). */
+typedef short m355_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int d_dot2(unsigned a, unsigned b, int c)
+{
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(m355_short2, a), __builtin_bit_cast(m355_short2, b), c, false);
+}
+
 #endif

@@ -60,6 +60,10 @@ struct DevPic {
   uint8_t* edge_pb;                 /* per 4x4: bit2 PB edge V, bit3 PB edge H */
   uint32_t* pb_of;                  /* per 4x4: PB index + 1 */
   int16_t* resbuf;
+  uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
+  uint32_t* job_count;              /* device cursor used while the job list is built */
+  int n_jobs;                       /* sum over PBs of (w/4) * ceil(h/8), computed at upload */
+  int n_jobs_main;                  /* jobs [0, n_jobs_main): windows inside the picture; [n_jobs_main, n_jobs): EDGE */
   /* intra wavefront state */
   uint32_t* ctb_done;               /* per CTB (raster) completion epoch */
   uint32_t* ticket;                 /* work counter */
@@ -69,6 +73,24 @@ struct DevPic {
   int n_intra_work;
   const uint8_t* ctb_dep;           /* per CTB: bit n = wait for neighbour n (0 L, 1 TL, 2 T, 3 TR); bit 4 = somebody waits for us */
 };
+
+/* Does any reference window of this PB cross the left/right picture border (so its jobs need the
+ * per-sample clamped loads of motion.cc:141-159)?  Shared by the host (job counts at upload) and
+ * k_meta_pb (job sorting): both must agree.  Luma span of a 4-column job: [x-3, x+7] (+1 pad sample),
+ * chroma span of its 2 columns: [xc-1, xc+3].  Vertical clamping is done per row everywhere. */
+__host__ __device__ inline bool m355_pb_is_edge(const m355_pb& pb, int width, int chroma_format_idc)
+{
+  for (int l = 0; l < 2; l++) {
+    if (!(pb.flags & (M355_PBF_MC_L0 << l)) || (pb.flags & (M355_PBF_FILL_L0 << l))) continue;
+    const int xl = pb.x + (pb.mv[l][0] >> 2);
+    if (xl - 3 < 0 || xl + pb.w + 3 > width - 1) return true;
+    if (chroma_format_idc == 1) {
+      const int xc = (pb.x >> 1) + (pb.mv[l][0] >> 3);
+      if (xc - 1 < 0 || xc + (pb.w >> 1) + 1 > (width >> 1) - 1) return true;
+    }
+  }
+  return false;
+}
 
 enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
 

@@ -7,12 +7,23 @@
  *   put_unweighted_pred / put_weighted_pred_avg / put_weighted_pred / put_weighted_bipred
  *   (fallback-motion.cc:33-256).
  *
- * Mapping: one 64-lane wavefront per prediction block, walking the block in 16x16 (per component)
- * tiles.  Per tile and list the wave stages the (tw+7)x(th+7) reference window in LDS with clamped,
- * row-coalesced loads, runs the horizontal taps into an int16 LDS tile (the reference's mcbuffer,
- * same truncation), then the vertical taps into registers, and finally the weighted combination
- * straight to the picture — the 14-bit intermediates never touch HBM.  No workgroup barrier: the
- * four waves of a workgroup are independent (wave-level LDS ordering only).
+ * Main kernel (4:2:0 and monochrome), k_inter_jobs — register-resident, no LDS data staging:
+ *   k_meta_pb expands every PB into JOBS of 4 luma columns x 8 rows (+ the matching 2x4 Cb and Cr
+ *   samples); one LANE owns one job, consecutive lanes own horizontally adjacent jobs of the same
+ *   PB, so a wave's loads and stores are row-contiguous wherever a PB is >= 8 wide.  Per window row
+ *   a lane loads the 12 samples it needs with one unaligned 16-byte + one 8-byte load (overlap with
+ *   the neighbour lane is served by the L1), keeps them as packed 16-bit pairs and evaluates the
+ *   8-tap (4-tap) horizontal filter with v_dot2c_i32_i16 — two taps per issue, "odd" output columns
+ *   use a tap set shifted by one sample — truncating to int16 exactly where the reference stores
+ *   its mcbuffer.  The 16-bit intermediates of the 15 (7) window rows stay in registers as
+ *   (row 2k, row 2k+1) pairs, the vertical filter is the same dot2 scheme, and the weighted
+ *   combination writes 8-byte row segments straight to the picture.  Every lane carries its own
+ *   MV phases / taps / weights (VGPRs): PBs of any size and mix share a wave with no divergence
+ *   except the rare picture-edge path (per-sample clamped loads, motion.cc:141-159).
+ *   16-bit planes with bit depth 16 use the identity sum(t*s) = sum(t*(s-32768)) + 32768*64 so
+ *   samples fit the signed dot2 operands.
+ * Generic kernel (4:2:2 / 4:4:4), k_inter_generic: one wavefront per PB, 16x16 tiles through LDS.
+ *
  * Roofline: HBM/L2-bound; algorithmic bytes per PB and list = [(w+7)(h+7)+2(w/2+3)(h/2+3)]*B read,
  * w*h*1.5*B written.
  */
@@ -29,7 +40,7 @@ __constant__ int8_t c_epel_taps[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4,
 #define WIN_ROWS 23
 
 template <class PIX>
-__global__ void __launch_bounds__(256) k_inter(DevPic p)
+__global__ void __launch_bounds__(256) k_inter_generic(DevPic p)
 {
   __shared__ uint16_t s_win[4][WIN_ROWS * WIN_PITCH];
   __shared__ int16_t s_tmp[4][WIN_ROWS * 16];
@@ -175,10 +186,371 @@ __global__ void __launch_bounds__(256) k_inter(DevPic p)
   }
 }
 
+
+/* ================================================================================================
+ * job kernel
+ * ============================================================================================== */
+
+/* packed tap tables, built once per workgroup in LDS.
+ *   qpel[f] : E0..E3 = (t0,t1)(t2,t3)(t4,t5)(t6,t7) ; O0..O4 = (0,t0)(t1,t2)(t3,t4)(t5,t6)(t7,0)
+ *   epel[f] : E0..E1 = (c0,c1)(c2,c3)               ; O0..O2 = (0,c0)(c1,c2)(c3,0)            */
+#define QT_STRIDE 9
+#define ET_STRIDE 5
+__device__ __forceinline__ unsigned d_pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
+__device__ __forceinline__ int d_lo16s(unsigned v) { return (int)(int16_t)(v & 0xFFFFu); }
+__device__ __forceinline__ int d_hi16s(unsigned v) { return (int)v >> 16; }
+/* branch-free select on a per-lane all-ones / all-zeros mask (v_bfi_b32): keeps the filter arithmetic
+   unconditional — hipcc otherwise sinks the dot2 chains under per-lane branches on the MV phase */
+__device__ __forceinline__ unsigned d_sel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
+
+/* 12 consecutive samples starting at column xa of one row -> 6 packed 16-bit pairs.  FAST: the span
+ * lies inside the picture row (the 12th sample may be the first pad sample: never used with a
+ * non-zero tap); otherwise every column is clamped (motion.cc:84-91,147-155). */
+template <class PIX, bool FAST>
+__device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[6])
+{
+  if (FAST) {
+    if (sizeof(PIX) == 2) {
+      d_ldg16(row + xa, S);
+      d_ldg8(row + xa + 8, S + 4);
+    } else {
+      unsigned a[3];
+      d_ldg12(row + xa, a);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { S[2 * k] = (a[k] & 0xFFu) | ((a[k] & 0xFF00u) << 8); S[2 * k + 1] = ((a[k] >> 16) & 0xFFu) | ((a[k] >> 8) & 0xFF0000u); }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const unsigned lo = row[d_clip3(0, pw - 1, xa + 2 * k)], hi = row[d_clip3(0, pw - 1, xa + 2 * k + 1)];
+      S[k] = lo | (hi << 16);
+    }
+  }
+}
+/* 6 consecutive samples -> 3 pairs (chroma window row) */
+template <class PIX, bool FAST>
+__device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[3])
+{
+  if (FAST) {
+    if (sizeof(PIX) == 2) d_ldg12(row + xa, S);
+    else {
+      const unsigned a = d_ldg4(row + xa), b = d_ldg2(row + xa + 4);
+      S[0] = (a & 0xFFu) | ((a & 0xFF00u) << 8); S[1] = ((a >> 16) & 0xFFu) | ((a >> 8) & 0xFF0000u);
+      S[2] = (b & 0xFFu) | ((b & 0xFF00u) << 8);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const unsigned lo = row[d_clip3(0, pw - 1, xa + 2 * k)], hi = row[d_clip3(0, pw - 1, xa + 2 * k + 1)];
+      S[k] = lo | (hi << 16);
+    }
+  }
+}
+
+/* luma 4x8 block of one list -> packed 14-bit predictions (int16 pairs), fallback-motion.cc:492-636.
+ * (xi,yi) = integer position of the block's top-left sample in the reference plane. */
+template <class PIX, bool BIAS, bool FAST>
+__device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rstride, int pw, int ph, int xi, int yi, int xf, int yf, int bd,
+                                              const unsigned* qt, unsigned pred[8][2])
+{
+  const unsigned* tx = qt + xf * QT_STRIDE;
+  const unsigned* ty = qt + yf * QT_STRIDE;
+  const int shift1 = bd - 8, shift3 = max(2, 14 - bd);
+  const int xa = xi - 3;
+  const unsigned xmask = xf == 0 ? ~0u : 0u, ymask = yf == 0 ? ~0u : 0u, xymask = xmask & ymask;
+  unsigned Q[8][4];
+  {
+    unsigned XE[4], XO[5];
+#pragma unroll
+    for (int k = 0; k < 4; k++) XE[k] = tx[k];
+#pragma unroll
+    for (int k = 0; k < 5; k++) XO[k] = tx[4 + k];
+    const unsigned bias = BIAS ? 0x80008000u : 0u;
+    const int init = BIAS ? (1 << 21) : 0;
+    /* rows are fetched one pair ahead of the pair being filtered; the scheduling barriers keep hipcc
+       from hoisting all 15 rows of loads to the top (which spills) while still overlapping the next
+       pair's loads with this pair's arithmetic */
+    unsigned S[2][2][6];
+    d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi - 3) * rstride, xa, pw, S[0][0]);
+    d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi - 2) * rstride, xa, pw, S[0][1]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k < 7) {
+        d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi + 2 * k - 1) * rstride, xa, pw, S[(k + 1) & 1][0]);
+        if (k < 6) d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi + 2 * k) * rstride, xa, pw, S[(k + 1) & 1][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (2 * k + q >= 15) break;
+        const unsigned* R = S[k & 1][q];
+        unsigned B[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) B[i] = R[i] ^ bias;
+        int h[4];
+        h[0] = d_dot2(B[3], XE[3], d_dot2(B[2], XE[2], d_dot2(B[1], XE[1], d_dot2(B[0], XE[0], init))));
+        h[1] = d_dot2(B[4], XO[4], d_dot2(B[3], XO[3], d_dot2(B[2], XO[2], d_dot2(B[1], XO[1], d_dot2(B[0], XO[0], init)))));
+        h[2] = d_dot2(B[4], XE[3], d_dot2(B[3], XE[2], d_dot2(B[2], XE[1], d_dot2(B[1], XE[0], init))));
+        h[3] = d_dot2(B[5], XO[4], d_dot2(B[4], XO[3], d_dot2(B[3], XO[2], d_dot2(B[2], XO[1], d_dot2(B[1], XO[0], init)))));
+        const unsigned raw0 = R[1] >> 16, raw1 = R[2] & 0xFFFFu, raw2 = R[2] >> 16, raw3 = R[3] & 0xFFFFu;
+        /* int16 mcbuffer store (fallback-motion.cc:512-565); xFrac == 0 copies the sample unshifted */
+        const unsigned t0 = d_sel(xmask, raw0, (unsigned)(h[0] >> shift1) & 0xFFFFu), t1 = d_sel(xmask, raw1, (unsigned)(h[1] >> shift1) & 0xFFFFu);
+        const unsigned t2 = d_sel(xmask, raw2, (unsigned)(h[2] >> shift1) & 0xFFFFu), t3 = d_sel(xmask, raw3, (unsigned)(h[3] >> shift1) & 0xFFFFu);
+        if (q == 0) { Q[k][0] = t0; Q[k][1] = t1; Q[k][2] = t2; Q[k][3] = t3; }
+        else { Q[k][0] |= t0 << 16; Q[k][1] |= t1 << 16; Q[k][2] |= t2 << 16; Q[k][3] |= t3 << 16; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int vshift = xf == 0 ? shift1 : 6;
+  unsigned YE[4], YO[5];
+#pragma unroll
+  for (int k = 0; k < 4; k++) YE[k] = ty[k];
+#pragma unroll
+  for (int k = 0; k < 5; k++) YO[k] = ty[4 + k];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int ve = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0))));
+      const int vo = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)))));
+      /* yf == 0: row y+3 of the intermediates: y = 2m -> row 2m+3 = hi of pair m+1; y = 2m+1 -> row 2m+4 = lo of pair m+2 */
+      const unsigned ce = Q[m + 1][j] >> 16, co = Q[m + 2][j] & 0xFFFFu;   /* low 16 bits are all that is kept */
+      const unsigned pe = d_sel(ymask, d_sel(xymask, ce << shift3, ce), (unsigned)(ve >> vshift));
+      const unsigned po = d_sel(ymask, d_sel(xymask, co << shift3, co), (unsigned)(vo >> vshift));
+      /* the reference stores the prediction as int16 (predSamples, motion.cc:331) */
+      if ((j & 1) == 0) { pred[2 * m][j >> 1] = pe & 0xFFFFu; pred[2 * m + 1][j >> 1] = po & 0xFFFFu; }
+      else { pred[2 * m][j >> 1] |= pe << 16; pred[2 * m + 1][j >> 1] |= po << 16; }
+    }
+}
+
+/* chroma 2x4 block of one list and plane, fallback-motion.cc:305-415 / 262-302 */
+template <class PIX, bool BIAS, bool FAST>
+__device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int rstride, int pw, int ph, int xi, int yi, int xf, int yf, int bd,
+                                                const unsigned* et, unsigned pred[4])
+{
+  const unsigned* tx = et + xf * ET_STRIDE;
+  const unsigned* ty = et + yf * ET_STRIDE;
+  const int shift1 = bd - 8, shift3 = max(2, 14 - bd);
+  const int xa = xi - 1;
+  const unsigned xmask = xf == 0 ? ~0u : 0u, ymask = yf == 0 ? ~0u : 0u, xymask = xmask & ymask;
+  unsigned Q[4][2];
+  {
+    unsigned XE[2], XO[3];
+#pragma unroll
+    for (int k = 0; k < 2; k++) XE[k] = tx[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) XO[k] = tx[2 + k];
+    const unsigned bias = BIAS ? 0x80008000u : 0u;
+    const int init = BIAS ? (1 << 21) : 0;
+    unsigned S[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; r++) d_load6<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi + r - 1) * rstride, xa, pw, S[r]);
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const unsigned B0 = S[r][0] ^ bias, B1 = S[r][1] ^ bias, B2 = S[r][2] ^ bias;
+      const int h0 = d_dot2(B1, XE[1], d_dot2(B0, XE[0], init));
+      const int h1 = d_dot2(B2, XO[2], d_dot2(B1, XO[1], d_dot2(B0, XO[0], init)));
+      const unsigned t0 = d_sel(xmask, S[r][0] >> 16, (unsigned)(h0 >> shift1) & 0xFFFFu);
+      const unsigned t1 = d_sel(xmask, S[r][1] & 0xFFFFu, (unsigned)(h1 >> shift1) & 0xFFFFu);
+      if ((r & 1) == 0) { Q[r >> 1][0] = t0; Q[r >> 1][1] = t1; } else { Q[r >> 1][0] |= t0 << 16; Q[r >> 1][1] |= t1 << 16; }
+    }
+  }
+  unsigned YE[2], YO[3];
+#pragma unroll
+  for (int k = 0; k < 2; k++) YE[k] = ty[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) YO[k] = ty[2 + k];
+  const int vshift = xf == 0 ? shift1 : 6;
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int ve = d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0));
+      const int vo = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)));
+      /* yf == 0: row y+1: y = 2m -> row 2m+1 = hi of pair m ; y = 2m+1 -> row 2m+2 = lo of pair m+1 */
+      const unsigned ce = Q[m][j] >> 16, co = Q[m + 1][j] & 0xFFFFu;
+      const unsigned pe = d_sel(ymask, d_sel(xymask, ce << shift3, ce), (unsigned)(ve >> vshift));
+      const unsigned po = d_sel(ymask, d_sel(xymask, co << shift3, co), (unsigned)(vo >> vshift));
+      if (j == 0) { pred[2 * m] = pe & 0xFFFFu; pred[2 * m + 1] = po & 0xFFFFu; }
+      else { pred[2 * m] |= pe << 16; pred[2 * m + 1] |= po << 16; }
+    }
+}
+
+/* weighted write-back of one sample (fallback-motion.cc:33-256, selection motion.cc:493-688).  All four
+ * reference formulas are instances of ((a*w0 + b*w1 + rnd) >> sh) + o with the same int32 arithmetic:
+ *   unweighted uni : w0 1, w1 0, rnd 1<<(shift3-1),        sh shift3,   o 0      (put_unweighted_pred)
+ *   average        : w0 1, w1 1, rnd 1<<(shift2-1),        sh shift2,   o 0      (put_weighted_pred_avg)
+ *   weighted uni   : w0,   w1 0, rnd 1<<(log2WD-1),        sh log2WD,   o o0     (put_weighted_pred)
+ *   weighted bi    : w0,   w1,   rnd (o0+o1+1)<<log2WD,    sh log2WD+1, o 0      (put_weighted_bipred)
+ * so the per-lane mode costs no branch. */
+struct WtSel { int w0, w1, rnd, sh, o; };
+__device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
+{
+  return d_clip_bd(((a * s.w0 + b * s.w1 + s.rnd) >> s.sh) + s.o, bd);
+}
+
+/* FAST: jobs of PBs whose reference windows lie inside the picture horizontally (k_meta_pb sorts the
+ * others into the EDGE job range, handled by the FAST=false instance with clamped per-sample loads) */
+template <class PIX, bool BIAS, bool FAST>
+__global__ void __launch_bounds__(256, 3) k_inter_jobs(DevPic p, int job_base, int job_n)
+{
+  __shared__ unsigned s_qt[4 * QT_STRIDE];
+  __shared__ unsigned s_et[8 * ET_STRIDE];
+  if (threadIdx.x < 4) {
+    const int8_t* t = c_qpel_taps[threadIdx.x];
+    unsigned* o = s_qt + threadIdx.x * QT_STRIDE;
+    for (int k = 0; k < 4; k++) o[k] = d_pack16(t[2 * k], t[2 * k + 1]);
+    o[4] = d_pack16(0, t[0]);
+    for (int k = 1; k < 4; k++) o[4 + k] = d_pack16(t[2 * k - 1], t[2 * k]);
+    o[8] = d_pack16(t[7], 0);
+  } else if (threadIdx.x >= 64 && threadIdx.x < 72) {
+    const int8_t* t = c_epel_taps[threadIdx.x - 64];
+    unsigned* o = s_et + (threadIdx.x - 64) * ET_STRIDE;
+    o[0] = d_pack16(t[0], t[1]); o[1] = d_pack16(t[2], t[3]);
+    o[2] = d_pack16(0, t[0]); o[3] = d_pack16(t[1], t[2]); o[4] = d_pack16(t[3], 0);
+  }
+  __syncthreads();
+
+  /* XCD-aware block order: block b runs on XCD b % 8; give every XCD one contiguous eighth of the job
+     list (= a compact region of the picture) so reference-window overlap hits that XCD's own L2 */
+  const int per = gridDim.x >> 3;
+  const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int ji = lb * 256 + threadIdx.x;
+  if (ji >= job_n) return;
+  const uint32_t job = p.jobs[job_base + ji];
+  const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
+  const int strip = (job >> 25) & 15, rblk = job >> 29;
+  const int x0 = pb.x + 4 * strip, y0 = pb.y + 8 * rblk;
+  const int rows = min(8, pb.h - 8 * rblk);          /* 4 or 8 */
+  const bool mc0 = pb.flags & M355_PBF_MC_L0, mc1 = pb.flags & M355_PBF_MC_L1;
+  const bool bi = mc0 && mc1;
+  const int npass = bi ? 2 : 1;
+  /* pass 0 = the first (or only) list, pass 1 = L1 of a bi-predicted block; selected without indexing
+     the record dynamically (that would push it out of registers) */
+  const bool a1 = !mc0;
+  const int refA = a1 ? pb.ref_slot[1] : pb.ref_slot[0], mvxA = a1 ? pb.mv[1][0] : pb.mv[0][0], mvyA = a1 ? pb.mv[1][1] : pb.mv[0][1];
+  const bool fillA = pb.flags & (a1 ? M355_PBF_FILL_L1 : M355_PBF_FILL_L0), fillB = pb.flags & M355_PBF_FILL_L1;
+  const bool weighted = (pb.flags & M355_PBF_WEIGHTED) != 0;
+  const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
+  const int nc = p.pp.chroma_format_idc ? 3 : 1;
+
+#pragma unroll 1
+  for (int c = 0; c < nc; c++) {
+    const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+    WtSel ws;
+    {
+      const int shift3 = max(2, 14 - bd), shift2 = max(3, 15 - bd);
+      ws.w0 = 1; ws.w1 = bi ? 1 : 0; ws.o = 0;
+      ws.sh = bi ? shift2 : shift3; ws.rnd = 1 << (ws.sh - 1);
+      if (weighted) {
+        const m355_wt wa = p.wts[wtA], wb = p.wts[wtB];
+        const int o0 = c == 0 ? wa.o[0] : (c == 1 ? wa.o[1] : wa.o[2]), o1 = c == 0 ? wb.o[0] : (c == 1 ? wb.o[1] : wb.o[2]);
+        const int log2WD = c ? wa.log2wd_chroma : wa.log2wd_luma;
+        ws.w0 = c == 0 ? wa.w[0] : (c == 1 ? wa.w[1] : wa.w[2]);
+        ws.w1 = bi ? (c == 0 ? wb.w[0] : (c == 1 ? wb.w[1] : wb.w[2])) : 0;
+        ws.rnd = bi ? (int)((unsigned)(o0 + o1 + 1) << log2WD) : (1 << (log2WD - 1));
+        ws.sh = bi ? log2WD + 1 : log2WD;
+        ws.o = bi ? 0 : o0;
+      }
+    }
+    const int pw = p.pw[c], ph = p.ph[c];
+    if (c == 0) {
+      unsigned pa[8][2];
+#pragma unroll
+      for (int y = 0; y < 8; y++) { pa[y][0] = 0; pa[y][1] = 0; }
+      PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
+#pragma unroll 1
+      for (int pass = 0; pass < npass; pass++) {
+        unsigned cur[8][2];
+        if (pass ? fillB : fillA) {        /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
+#pragma unroll
+          for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
+        } else {
+          const DevRef* ref = &p.refs[pass ? pb.ref_slot[1] : refA];
+          const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+          d_mc_luma_4x8<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], pw, ph, x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, bd, s_qt, cur);
+        }
+        if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
+#pragma unroll
+          for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
+          continue;
+        }
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          if (y >= rows) break;
+          unsigned o[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
+            o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
+          }
+          if (sizeof(PIX) == 2) *(uint2*)(d + (size_t)y * p.stride[0]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+          else *(unsigned*)(d + (size_t)y * p.stride[0]) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+        }
+      }
+    } else {
+      /* chroma (4:2:0): 2 columns x 4 rows per plane; chroma mv = luma mv in 1/8 pel (motion.cc:196-203) */
+      const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
+      unsigned pa[4];
+#pragma unroll
+      for (int y = 0; y < 4; y++) pa[y] = 0;
+      PIX* d = (PIX*)p.plane[c] + (size_t)yc * p.stride[c] + xc;
+#pragma unroll 1
+      for (int pass = 0; pass < npass; pass++) {
+        unsigned cur[4];
+        if (pass ? fillB : fillA) {
+#pragma unroll
+          for (int y = 0; y < 4; y++) cur[y] = 0x20002000u;
+        } else {
+          const DevRef* ref = &p.refs[pass ? pb.ref_slot[1] : refA];
+          const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+          const M355_GLOBAL PIX* rp = (const M355_GLOBAL PIX*)(c == 1 ? ref->plane[1] : ref->plane[2]);
+          d_mc_chroma_2x4<PIX, BIAS, FAST>(rp, c == 1 ? ref->stride[1] : ref->stride[2], pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur);
+        }
+        if (pass + 1 < npass) {
+#pragma unroll
+          for (int y = 0; y < 4; y++) pa[y] = cur[y];
+          continue;
+        }
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          if (y >= crows) break;
+          const unsigned a = bi ? pa[y] : cur[y], b = cur[y];
+          const unsigned o0 = (unsigned)d_wpred(ws, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws, d_hi16s(a), d_hi16s(b), bd);
+          if (sizeof(PIX) == 2) *(unsigned*)(d + (size_t)y * p.stride[c]) = o0 | (o1 << 16);
+          else *(unsigned short*)(d + (size_t)y * p.stride[c]) = (unsigned short)(o0 | (o1 << 8));
+        }
+      }
+    }
+  }
+}
+
+template <class PIX, bool BIAS>
+static void launch_jobs(const DevPic& p, hipStream_t st)
+{
+  /* grids padded to a multiple of 8 blocks for the XCD-contiguous block order */
+  const int n_edge = p.n_jobs - p.n_jobs_main;
+  if (p.n_jobs_main) {
+    const int nblk = (p.n_jobs_main + 255) / 256;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), 0, st, p, 0, p.n_jobs_main);
+  }
+  if (n_edge) {
+    const int nblk = (n_edge + 255) / 256;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS, false>), dim3(((nblk + 7) / 8) * 8), dim3(256), 0, st, p, p.n_jobs_main, n_edge);
+  }
+}
+
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
 {
   if (!p.n_pbs) return;
+  if (p.pp.chroma_format_idc <= 1) {
+    if (!hbd) launch_jobs<uint8_t, false>(p, st);
+    else if (p.pp.bit_depth_luma == 16 || p.pp.bit_depth_chroma == 16) launch_jobs<uint16_t, true>(p, st);
+    else launch_jobs<uint16_t, false>(p, st);
+    return;
+  }
   const dim3 grid((p.n_pbs + 3) / 4), block(256);
-  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter<uint16_t>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter<uint8_t>), grid, block, 0, st, p);
+  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_generic<uint16_t>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_generic<uint8_t>), grid, block, 0, st, p);
 }

@@ -99,12 +99,38 @@ __global__ void __launch_bounds__(256) k_meta_tu(DevPic p)
   }
 }
 
-/* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) */
+/* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) and the job list of
+ * k_inter_jobs: (w/4) x ceil(h/8) jobs per PB, row block major so consecutive jobs are horizontally
+ * adjacent.  A wave reserves one contiguous range with a single atomic (wave-level exclusive scan),
+ * so the list stays in PB order at 64-PB granularity = spatially coherent. */
 __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.n_pbs) return;
-  const m355_pb pb = p.pbs[i];
+  const int lane = threadIdx.x & 63;
+  const bool active = i < p.n_pbs;
+  m355_pb pb;
+  if (active) pb = p.pbs[i]; else { pb.x = pb.y = 0; pb.w = pb.h = 0; pb.flags = 0; }
+  const int ns = pb.w >> 2, nr = (pb.h + 7) >> 3;
+  const bool edge = active && m355_pb_is_edge(pb, p.pp.width, p.pp.chroma_format_idc);
+  const int njobs = active ? ns * nr : 0;
+  /* two ranges: [0, n_jobs_main) and [n_jobs_main, n_jobs) (edge); wave-level exclusive scans */
+  int incl_m = edge ? 0 : njobs, incl_e = edge ? njobs : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int tm = __shfl_up(incl_m, (unsigned)d, 64), te = __shfl_up(incl_e, (unsigned)d, 64);
+    if (lane >= d) { incl_m += tm; incl_e += te; }
+  }
+  const int tot_m = __shfl(incl_m, 63, 64), tot_e = __shfl(incl_e, 63, 64);
+  uint32_t base_m = 0, base_e = 0;
+  if (lane == 63) {
+    if (tot_m) base_m = atomicAdd(p.job_count, (uint32_t)tot_m);
+    if (tot_e) base_e = atomicAdd(p.job_count + 1, (uint32_t)tot_e);
+  }
+  base_m = __shfl(base_m, 63, 64); base_e = __shfl(base_e, 63, 64);
+  if (!active) return;
+  uint32_t o = edge ? (uint32_t)p.n_jobs_main + base_e + (uint32_t)(incl_e - njobs) : base_m + (uint32_t)(incl_m - njobs);
+  for (int r = 0; r < nr; r++)
+    for (int s = 0; s < ns; s++) p.jobs[o++] = (uint32_t)i | ((uint32_t)s << 25) | ((uint32_t)r << 29);
   for (int y = pb.y >> 2; y < ((pb.y + pb.h) >> 2) && y < p.h4; y++)
     for (int x = pb.x >> 2; x < ((pb.x + pb.w) >> 2) && x < p.w4; x++) p.pb_of[y * p.w4 + x] = (uint32_t)i + 1;
 }
@@ -115,6 +141,7 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
   hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4, st);
   hipMemsetAsync(p.edge_pb, 0, (size_t)p.w4 * p.h4, st);
   hipMemsetAsync(p.pb_of, 0, (size_t)p.w4 * p.h4 * 4, st);
+  hipMemsetAsync(p.job_count, 0, 8, st);
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_pbs) hipLaunchKernelGGL(k_meta_pb, dim3((p.n_pbs + 255) / 256), dim3(256), 0, st, p);

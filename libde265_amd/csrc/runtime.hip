@@ -77,6 +77,7 @@ struct Resident {
   DevRef* refs_host = nullptr; /* pinned staging + last uploaded contents */
   bool refs_valid = false;
   int n_intra_work = 0;
+  int n_jobs = 0, n_jobs_main = 0;   /* inter jobs (k_inter_jobs), from the PB geometry */
 };
 
 struct m355_ctx {
@@ -90,7 +91,8 @@ struct m355_ctx {
   uint32_t *cb_cu = nullptr, *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
   uint8_t *edge_tu = nullptr, *edge_pb = nullptr, *cuf = nullptr;
   int16_t* resbuf = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0;
+  uint32_t* jobs = nullptr;
+  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0;
   uint32_t epoch = 0;
   int stages = M355_STAGE_ALL;
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
@@ -158,7 +160,7 @@ void m355_destroy(m355_ctx* c)
   if (c->work.used) frame_free(c->work);
   for (auto& r : c->resident) if (r.used) resident_free(r);
   resident_free(c->transient);
-  void* bufs[] = {c->cb_cu, c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->edge_pb, c->cuf, c->resbuf};
+  void* bufs[] = {c->cb_cu, c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->edge_pb, c->cuf, c->resbuf, c->jobs};
   for (void* b : bufs) if (b) hipFree(b);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   hipStreamDestroy(c->stream);
@@ -431,6 +433,16 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   for (int t = 0; t < nCtb; t++)
     if (pic->ctbs[ts2rs[t]].ib_count) iw[nw++] = ts2rs[t];
   r.n_intra_work = nw;
+  {
+    long long nj = 0, nm = 0;
+    for (int i = 0; i < pic->n_pbs; i++) {
+      const long long n = (long long)(pic->pbs[i].w >> 2) * ((pic->pbs[i].h + 7) >> 3);
+      nj += n;
+      if (!m355_pb_is_edge(pic->pbs[i], pp.width, pp.chroma_format_idc)) nm += n;
+    }
+    if (pic->n_pbs > 0x1FFFFFF || nj > 0x7FFFFFFF) return fail(M355_ERR_INVALID, "too many prediction blocks");
+    r.n_jobs = (int)nj; r.n_jobs_main = (int)nm;
+  }
   intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
   r.bytes = total;
   HIPCHK(hipMemcpyAsync(r.dev, r.host, total, hipMemcpyHostToDevice, c->stream));
@@ -463,6 +475,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
   d.intra_work = (const uint32_t*)(r.dev + seg[i_iw].ofs);
   d.n_intra_work = nw;
+  d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
   r.used = true;
   return M355_OK;
@@ -521,6 +534,7 @@ static int decode(m355_ctx* c, Resident& r)
   if ((rc = grow(&c->ctb_done, &c->cap_ctb, (size_t)d.nCtb, c->stream, true))) return rc;
   if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->resbuf, &c->cap_res, (size_t)pic.res_len + 1, c->stream, false))) return rc;
+  if ((rc = grow(&c->jobs, &c->cap_jobs, (size_t)r.n_jobs + 1, c->stream, false))) return rc;
 
   const bool want_sao = (c->stages & M355_STAGE_SAO) && (pp.flags & M355_PF_SAO_ENABLED);
   Frame* target = dst;
@@ -539,6 +553,7 @@ static int decode(m355_ctx* c, Resident& r)
     d.out_plane[cc] = dst->plane[cc]; d.out_stride[cc] = dst->stride[cc];
   }
   d.cb_cu = c->cb_cu; d.cuf = c->cuf; d.edge_tu = c->edge_tu; d.edge_pb = c->edge_pb; d.pb_of = c->pb_of;
+  d.jobs = c->jobs; d.job_count = c->ticket + 4;
   d.resbuf = c->resbuf; d.ctb_done = c->ctb_done; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;
@@ -549,7 +564,7 @@ static int decode(m355_ctx* c, Resident& r)
   hipEvent_t* ev = &c->evs[c->ev_used * 7];
   c->ev_used++;
   hipEventRecord(ev[0], st);
-  const bool need_meta = (c->stages & (M355_STAGE_INTRA | M355_STAGE_DEBLOCK | M355_STAGE_SAO)) != 0;
+  const bool need_meta = true;   /* metadata planes for intra/deblock/SAO, job list for inter */
   if (need_meta) m355_launch_meta(d, st);
   hipEventRecord(ev[1], st);
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);

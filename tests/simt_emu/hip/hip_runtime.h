@@ -119,6 +119,7 @@ static inline void __syncthreads() { simt::sync_threads(); }
 static inline void __builtin_amdgcn_wave_barrier() { simt::wave_rendezvous(); }
 static inline void __builtin_amdgcn_s_barrier() { simt::sync_threads(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}

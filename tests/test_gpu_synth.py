@@ -30,6 +30,9 @@ SMALL = CASES + [
     dict(width=1280, height=720, bit_depth=8, seed=25, intra_pct=25, weighted_pct=50, oob_mv_pct=20),
     dict(width=8, height=8, bit_depth=8, seed=26, log2_ctb=4),
     dict(width=72, height=24, bit_depth=9, seed=27, log2_ctb=4, intra_pct=50),
+    dict(width=416, height=240, bit_depth=12, seed=28, weighted_pct=30, oob_mv_pct=10),
+    dict(width=416, height=240, bit_depth=16, seed=29, weighted_pct=30, oob_mv_pct=10, intra_pct=0, cbf_pct=0),
+    dict(width=64, height=64, bit_depth=8, seed=30, oob_mv_pct=100, intra_pct=0),
 ]
 
 
