@@ -60,6 +60,7 @@ struct DevPic {
   uint8_t* edge_pb;                 /* per 4x4: bit2 PB edge V, bit3 PB edge H */
   uint32_t* pb_of;                  /* per 4x4: PB index + 1 */
   int16_t* resbuf;
+  uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
   uint32_t* job_count;              /* device cursor used while the job list is built */
   int n_jobs;                       /* sum over PBs of (w/4) * ceil(h/8), computed at upload */

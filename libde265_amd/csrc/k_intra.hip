@@ -26,7 +26,8 @@
 #include "k_common.h"
 
 #define MAXCTB 64
-#define BODY_PITCH (MAXCTB + 2)
+#define BODY_PITCH (MAXCTB + 8)   /* 144 B rows: sample x lives at column x + 8 (16-byte aligned 8-sample vectors), left halo at column 7 */
+#define BODY_X0 8
 #define SPIN_LIMIT (1u << 24)
 
 __constant__ int8_t c_intra_angle[35] = {0,   0,   32,  26,  21,  17, 13, 9,  5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
@@ -34,16 +35,9 @@ __constant__ int8_t c_intra_angle[35] = {0,   0,   32,  26,  21,  17, 13, 9,  5,
 __constant__ int16_t c_intra_inv_angle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256,
                                               -315,  -390,  -482, -630, -910, -1638, -4096};
 
-/* pps.cc:608-623 MinTbAddrZS, computed instead of tabulated */
-__device__ __forceinline__ uint32_t d_min_tb_addr_zs(const DevPic& p, int xl, int yl)
-{
-  const int shift = p.pp.log2_ctb_size - p.pp.log2_min_tb_size;
-  const unsigned x = (unsigned)xl >> p.pp.log2_min_tb_size, y = (unsigned)yl >> p.pp.log2_min_tb_size;
-  const uint32_t v = p.ctb_ts[d_ctb_of(p, xl, yl)] << (shift * 2);
-  uint32_t m = 0;
-  for (int i = 0; i < shift; i++) m |= (((x >> i) & 1u) << (2 * i)) | (((y >> i) & 1u) << (2 * i + 1));
-  return v + m;
-}
+/* z-scan order inside a CTB (pps.cc:608-623 MinTbAddrZS, low bits): Morton code of the min-TB coordinates */
+__device__ __forceinline__ uint32_t d_spread4(uint32_t v) { v = (v | (v << 2)) & 0x33u; return (v | (v << 1)) & 0x55u; }
+__device__ __forceinline__ uint32_t d_morton(uint32_t x, uint32_t y) { return d_spread4(x) | (d_spread4(y) << 1); }
 
 __device__ __forceinline__ bool d_is_intra_at(const DevPic& p, int xl, int yl)
 {
@@ -71,12 +65,14 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
 {
   /* per component: top halo row (x = -1 .. 2*cw-1, index x+1) and body rows with a left halo column */
   __shared__ uint16_t s_top[3][2 * MAXCTB + 2];
-  __shared__ uint16_t s_body[3][MAXCTB * BODY_PITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t s_body[3][MAXCTB * BODY_PITCH];
   __shared__ uint16_t s_raw[3][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
   __shared__ uint16_t s_p[3][4 * 32 + 8];        /* substituted border */
   __shared__ uint16_t s_f[3][4 * 32 + 8];        /* filtered border */
   __shared__ int s_ref[3][3 * 32 + 8];           /* angular ref[-nT..2nT], index +32 */
   __shared__ uint32_t s_ticket;
+  __shared__ uint32_t s_nts[9];                  /* CtbAddrRStoTS of the 3x3 CTB neighbourhood (0xFFFFFFFF outside the picture) */
+  __shared__ uint8_t s_nsame[9];                 /* neighbour CTB in the picture, same slice (SliceAddrRS) and same tile */
 
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
@@ -110,6 +106,18 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
+  /* 3x3 CTB neighbourhood facts, once per CTB: every availability test of intrapred.h:486-508 / :534-633
+     (picture, slice, tile, z-scan order across CTBs) becomes an LDS lookup instead of dependent global loads */
+  if (threadIdx.x >= 64 && threadIdx.x < 73) {
+    const int i = threadIdx.x - 64, nx = ctbX + i % 3 - 1, ny = ctbY + i / 3 - 1;
+    uint32_t ts = 0xFFFFFFFFu; uint8_t same = 0;
+    if (nx >= 0 && ny >= 0 && nx < p.ctbW && ny < p.ctbH) {
+      const int n = ny * p.ctbW + nx;
+      ts = p.ctb_ts[n];
+      same = p.slices[p.ctbs[n].slice_idx].slice_addr_rs == p.slices[ctbinfo.slice_idx].slice_addr_rs && p.tile_id[n] == p.tile_id[ctb];
+    }
+    s_nts[i] = ts; s_nsame[i] = same;
+  }
   __syncthreads();
 
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
@@ -128,51 +136,88 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
     uint16_t* pf = s_f[c];
     int* ref = s_ref[c] + 32;
 
-    /* ---- stage the CTB and its halo in LDS ---- */
-    for (int idx = lane; idx < cw * ch; idx += 64) {
-      const int y = idx / cw, x = idx - y * cw;
-      if (x0c + x < pw && y0c + y < ph) body[y * BODY_PITCH + x + 1] = plane[(y0c + y) * stride + x0c + x];
+    /* ---- stage the CTB and its halo in LDS: 8-sample vectors, all loads of a lane in flight at once ---- */
+    {
+      const int l2v = (l2c - csw) - 3;                       /* log2(vectors per row); cw >= 8 */
+      const int nvec = ch << l2v;
+      for (int idx = lane; idx < nvec; idx += 64) {
+        const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
+        if (x0c + xv < pw && y0c + y < ph) {
+          const PIX* src = plane + (size_t)(y0c + y) * stride + x0c + xv;
+          uint4 v;
+          if (sizeof(PIX) == 2) v = *(const uint4*)src;
+          else {
+            const uint2 b = *(const uint2*)src;
+            v.x = (b.x & 0xFFu) | ((b.x & 0xFF00u) << 8); v.y = ((b.x >> 16) & 0xFFu) | ((b.x >> 8) & 0xFF0000u);
+            v.z = (b.y & 0xFFu) | ((b.y & 0xFF00u) << 8); v.w = ((b.y >> 16) & 0xFFu) | ((b.y >> 8) & 0xFF0000u);
+          }
+          *(uint4*)(body + y * BODY_PITCH + BODY_X0 + xv) = v;
+        }
+      }
     }
     if (x0c > 0)
       for (int y = lane; y < ch; y += 64)
-        if (y0c + y < ph) body[y * BODY_PITCH] = plane[(y0c + y) * stride + x0c - 1];
+        if (y0c + y < ph) body[y * BODY_PITCH + BODY_X0 - 1] = plane[(size_t)(y0c + y) * stride + x0c - 1];
     if (y0c > 0)
       for (int x = lane; x < 2 * cw + 1; x += 64) {
         const int xx = x0c - 1 + x;
-        if (xx >= 0 && xx < pw) top[x] = plane[(y0c - 1) * stride + xx];
+        if (xx >= 0 && xx < pw) top[x] = plane[(size_t)(y0c - 1) * stride + xx];
       }
     wave_sync();
 
-#define SAMPLE(lx, ly) ((ly) < 0 ? top[(lx) + 1] : body[(ly) * BODY_PITCH + (lx) + 1])
+#define SAMPLE(lx, ly) ((ly) < 0 ? top[(lx) + 1] : body[(ly) * BODY_PITCH + (lx) + BODY_X0])
 
-    for (uint32_t k = 0; k < ctbinfo.ib_count; k++) {
-      const m355_ib ib = p.ibs[ctbinfo.ib_start + k];
-      if (ib.cidx != c) continue;
+    /* the CTB's block records are fetched 64 at a time (one per lane, coalesced); the wave then walks the
+       records of ITS component in decode order by broadcasting them from the owning lane — one global
+       load latency per 64 records instead of one per record in the serial chain */
+    for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
+    uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
+    if (kbase + lane < ctbinfo.ib_count) {
+      const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
+      rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
+    }
+    unsigned long long mine = __ballot((int)((rw1 & 0xFFu) == (uint32_t)c));
+    while (mine) {
+      const int src = __ffsll(mine) - 1;
+      mine &= mine - 1;
+      m355_ib ib;
+      {
+        const uint32_t w0 = __shfl(rw0, src, 64), w1 = __shfl(rw1, src, 64), w2 = __shfl(rw2, src, 64);
+        ib.x = (uint16_t)(w0 & 0xFFFFu); ib.y = (uint16_t)(w0 >> 16);
+        ib.cidx = (uint8_t)(w1 & 0xFFu); ib.log2_size = (uint8_t)((w1 >> 8) & 0xFFu); ib.mode = (uint8_t)((w1 >> 16) & 0xFFu); ib.flags = (uint8_t)(w1 >> 24);
+        ib.res_ofs = w2;
+      }
       const int nT = 1 << ib.log2_size;
       const int xB = ib.x, yB = ib.y, lx = xB - x0c, ly = yB - y0c;
 
       if (ib.flags & M355_IBF_PCM) { /* raw block */
         for (int o = lane; o < nT * nT; o += 64) {
           const int y = o >> ib.log2_size, x = o & (nT - 1);
-          body[(ly + y) * BODY_PITCH + lx + x + 1] = p.pcm[ib.res_ofs + o];
+          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = p.pcm[ib.res_ofs + o];
         }
         wave_sync();
         continue;
       }
 
-      /* ---- preproc (intrapred.h:436-531): CTB-level availability ---- */
+      /* residual of this block (written by k_residual): issue the loads now, consume them after the
+         border/prediction chain — up to 16 samples per lane (32x32) */
+      int16_t rv[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int o = lane + 64 * q;
+        rv[q] = ((ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
+      }
+
+      /* ---- preproc (intrapred.h:436-531): CTB-level availability from the neighbourhood table ---- */
       const int xBL = xB * SubW, yBL = yB * SubH;
       bool aL = xBL != 0, aT = yBL != 0, aTL = xBL != 0 && yBL != 0, aTR = yBL != 0;
       if (xBL + nT * SubW >= p.pp.width) aTR = false;
       {
-        const int xCurr = xBL >> l2c, yCurr = yBL >> l2c, xLeft = (xBL - 1) >> l2c, xRight = (xBL + nT * SubW) >> l2c,
-                  yTop = (yBL - 1) >> l2c;
-        const int cur = yCurr * p.ctbW + xCurr;
-        const int curS = p.slices[p.ctbs[cur].slice_idx].slice_addr_rs, curT = p.tile_id[cur];
-        if (aL) { const int n = yCurr * p.ctbW + xLeft; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aL = false; }
-        if (aT) { const int n = yTop * p.ctbW + xCurr; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aT = false; }
-        if (aTL) { const int n = yTop * p.ctbW + xLeft; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aTL = false; }
-        if (aTR) { const int n = yTop * p.ctbW + xRight; if (p.slices[p.ctbs[n].slice_idx].slice_addr_rs != curS || p.tile_id[n] != curT) aTR = false; }
+        const int dxL = ((xBL - 1) >> l2c) - ctbX, dxR = ((xBL + nT * SubW) >> l2c) - ctbX, dyT = ((yBL - 1) >> l2c) - ctbY;
+        if (aL && !s_nsame[3 + dxL + 1]) aL = false;
+        if (aT && !s_nsame[(dyT + 1) * 3 + 1]) aT = false;
+        if (aTL && !s_nsame[(dyT + 1) * 3 + dxL + 1]) aTL = false;
+        if (aTR && !s_nsame[(dyT + 1) * 3 + dxR + 1]) aTR = false;
       }
       int nBottom = p.pp.height - yB * SubH;
       nBottom = (nBottom + SubH - 1) / SubH;
@@ -180,7 +225,8 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
       int nRight = p.pp.width - xB * SubW;
       nRight = (nRight + SubW - 1) / SubW;
       if (nRight > 2 * nT) nRight = 2 * nT;
-      const uint32_t curAddr = d_min_tb_addr_zs(p, xBL, yBL);
+      const int l2tb = p.pp.log2_min_tb_size, cmask = (1 << l2c) - 1;
+      const uint32_t curTs = s_nts[4], curZ = d_morton((uint32_t)(xBL & cmask) >> l2tb, (uint32_t)(yBL & cmask) >> l2tb);
       const bool cip = (p.pp.flags & M355_PF_CONSTRAINED_INTRA_PRED) != 0;
       const int nEnt = 4 * nT + 1;
 
@@ -206,7 +252,11 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
             av = (g < nT ? aT : aTR) && (g < nRight);
             xN = (xB + g) * SubW; yN = (yB - 1) * SubH; sx = lx + xx; sy = ly - 1;
           }
-          if (av) av = d_min_tb_addr_zs(p, xN, yN) <= curAddr;
+          if (av) {     /* MinTbAddrZS[neighbour] <= MinTbAddrZS[current] (intrapred.h:560-566) */
+            const int dcx = (xN >> l2c) - ctbX, dcy = (yN >> l2c) - ctbY;
+            if (dcx == 0 && dcy == 0) av = d_morton((uint32_t)(xN & cmask) >> l2tb, (uint32_t)(yN & cmask) >> l2tb) <= curZ;
+            else av = s_nts[(dcy + 1) * 3 + dcx + 1] < curTs;
+          }
           if (av && cip) av = d_is_intra_at(p, xN, yN);
           if (av) val = SAMPLE(sx, sy);
           raw[e] = (uint16_t)val;
@@ -285,10 +335,13 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
         }
         wave_sync();
       }
-      const int16_t* res = (ib.flags & M355_IBF_HAS_RESIDUAL) ? p.resbuf + ib.res_ofs : nullptr;
+      const bool has_res = (ib.flags & M355_IBF_HAS_RESIDUAL) != 0;
       const bool edge = (c == 0 && nT < 32);
       const bool bfilt = edge && !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER);
-      for (int o = lane; o < nT * nT; o += 64) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int o = lane + 64 * q;
+        if (o >= nT * nT) break;
         const int y = o >> log2, x = o & (nT - 1);
         int v;
         if (mode == 0) {
@@ -309,18 +362,33 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
             if (mode == 10 && y == 0) v = d_clip_bd(BRD(-1) + ((BRD(1 + x) - BRD(0)) >> 1), bd);
           }
         }
-        if (res) v = d_clip_bd(v + res[o], bd);
-        body[(ly + y) * BODY_PITCH + lx + x + 1] = (uint16_t)v;
+        if (has_res) v = d_clip_bd(v + rv[q], bd);
+        body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;
       }
       wave_sync();
-    }
+    }   /* records of this component */
+    }   /* 64-record batches */
 #undef BRD
 #undef SAMPLE
 
-    /* ---- write the CTB back ---- */
-    for (int idx = lane; idx < cw * ch; idx += 64) {
-      const int y = idx / cw, x = idx - y * cw;
-      if (x0c + x < pw && y0c + y < ph) plane[(y0c + y) * stride + x0c + x] = (PIX)body[y * BODY_PITCH + x + 1];
+    /* ---- write the CTB back (same vector mapping) ---- */
+    {
+      const int l2v = (l2c - csw) - 3;
+      const int nvec = ch << l2v;
+      for (int idx = lane; idx < nvec; idx += 64) {
+        const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
+        if (x0c + xv < pw && y0c + y < ph) {
+          const uint4 v = *(const uint4*)(body + y * BODY_PITCH + BODY_X0 + xv);
+          PIX* dstp = plane + (size_t)(y0c + y) * stride + x0c + xv;
+          if (sizeof(PIX) == 2) *(uint4*)dstp = v;
+          else {
+            uint2 b;
+            b.x = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y << 8) & 0xFF000000u);
+            b.y = (v.z & 0xFFu) | ((v.z >> 8) & 0xFF00u) | ((v.w & 0xFFu) << 16) | ((v.w << 8) & 0xFF000000u);
+            *(uint2*)dstp = b;
+          }
+        }
+      }
     }
   }
 

@@ -135,6 +135,40 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
     for (int x = pb.x >> 2; x < ((pb.x + pb.w) >> 2) && x < p.w4; x++) p.pb_of[y * p.w4 + x] = (uint32_t)i + 1;
 }
 
+/* one thread per (CTB, component): which of the 3x3 neighbouring CTBs may NOT contribute SAO edge
+ * neighbours (sao.cc:122-164): outside the picture, another slice with filtering across it disabled, or
+ * another tile with loop_filter_across_tiles off.  Reproduces the reference's quirk of looking up the
+ * CTB's own slice address with COMPONENT coordinates used as luma coordinates (sao.cc:56), which is
+ * why the centre CTB has a bit too.  k_sao then needs no dependent global loads per border sample. */
+__global__ void __launch_bounds__(256) k_meta_sao(DevPic p)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nc = p.pp.chroma_format_idc ? 3 : 1;
+  if (i >= p.nCtb * nc) return;
+  const int c = i / p.nCtb, ctb = i - c * p.nCtb;
+  const int xCtb = ctb % p.ctbW, yCtb = ctb / p.ctbW;
+  const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
+  const int l2w = p.pp.log2_ctb_size - csw, l2h = p.pp.log2_ctb_size - csh;
+  const int xC = xCtb << l2w, yC = yCtb << l2h;
+  const int ctbSliceAddrRS = d_slice_at(p, min(xC, p.pp.width - 1), min(yC, p.pp.height - 1)).slice_addr_rs;
+  const int curFlags = p.slices[p.ctbs[ctb].slice_idx].flags;
+  const bool across_tiles = (p.pp.flags & M355_PF_LF_ACROSS_TILES) != 0;
+  uint32_t mask = 0;
+  for (int k = 0; k < 9; k++) {
+    const int nx = xCtb + k % 3 - 1, ny = yCtb + k / 3 - 1;
+    bool blocked = true;
+    if (nx >= 0 && ny >= 0 && nx < p.ctbW && ny < p.ctbH) {
+      const int n = ny * p.ctbW + nx;
+      const m355_slice shN = p.slices[p.ctbs[n].slice_idx];
+      blocked = (shN.slice_addr_rs < ctbSliceAddrRS && !(curFlags & M355_SF_LF_ACROSS_SLICES)) ||
+                (shN.slice_addr_rs > ctbSliceAddrRS && !(shN.flags & M355_SF_LF_ACROSS_SLICES)) ||
+                (!across_tiles && p.tile_id[n] != p.tile_id[ctb]);
+    }
+    if (blocked) mask |= 1u << k;
+  }
+  p.sao_nb[i] = (uint16_t)mask;
+}
+
 void m355_launch_meta(const DevPic& p, hipStream_t st)
 {
   hipMemsetAsync(p.cb_cu, 0, (size_t)p.wcb * p.hcb * 4, st);
@@ -144,5 +178,6 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
   hipMemsetAsync(p.job_count, 0, 8, st);
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
+  if (p.pp.flags & M355_PF_SAO_ENABLED) hipLaunchKernelGGL(k_meta_sao, dim3((p.nCtb * 3 + 255) / 256), dim3(256), 0, st, p);
   if (p.n_pbs) hipLaunchKernelGGL(k_meta_pb, dim3((p.n_pbs + 255) / 256), dim3(256), 0, st, p);
 }

@@ -92,7 +92,8 @@ struct m355_ctx {
   uint8_t *edge_tu = nullptr, *edge_pb = nullptr, *cuf = nullptr;
   int16_t* resbuf = nullptr;
   uint32_t* jobs = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0;
+  uint16_t* sao_nb = nullptr;
+  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
   uint32_t epoch = 0;
   int stages = M355_STAGE_ALL;
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
@@ -160,7 +161,7 @@ void m355_destroy(m355_ctx* c)
   if (c->work.used) frame_free(c->work);
   for (auto& r : c->resident) if (r.used) resident_free(r);
   resident_free(c->transient);
-  void* bufs[] = {c->cb_cu, c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->edge_pb, c->cuf, c->resbuf, c->jobs};
+  void* bufs[] = {c->cb_cu, c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->edge_pb, c->cuf, c->resbuf, c->jobs, c->sao_nb};
   for (void* b : bufs) if (b) hipFree(b);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   hipStreamDestroy(c->stream);
@@ -534,6 +535,7 @@ static int decode(m355_ctx* c, Resident& r)
   if ((rc = grow(&c->ctb_done, &c->cap_ctb, (size_t)d.nCtb, c->stream, true))) return rc;
   if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->resbuf, &c->cap_res, (size_t)pic.res_len + 1, c->stream, false))) return rc;
+  if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
   if ((rc = grow(&c->jobs, &c->cap_jobs, (size_t)r.n_jobs + 1, c->stream, false))) return rc;
 
   const bool want_sao = (c->stages & M355_STAGE_SAO) && (pp.flags & M355_PF_SAO_ENABLED);
@@ -553,7 +555,7 @@ static int decode(m355_ctx* c, Resident& r)
     d.out_plane[cc] = dst->plane[cc]; d.out_stride[cc] = dst->stride[cc];
   }
   d.cb_cu = c->cb_cu; d.cuf = c->cuf; d.edge_tu = c->edge_tu; d.edge_pb = c->edge_pb; d.pb_of = c->pb_of;
-  d.jobs = c->jobs; d.job_count = c->ticket + 4;
+  d.jobs = c->jobs; d.job_count = c->ticket + 4; d.sao_nb = c->sao_nb;
   d.resbuf = c->resbuf; d.ctb_done = c->ctb_done; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;
