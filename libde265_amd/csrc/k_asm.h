@@ -26,6 +26,21 @@ __device__ __forceinline__ void d_ldg8(const M355_GLOBAL void* p, unsigned* o) {
 __device__ __forceinline__ unsigned d_ldg4(const M355_GLOBAL void* p) { return *(const M355_GLOBAL m355_u1*)p; }
 __device__ __forceinline__ unsigned d_ldg2(const M355_GLOBAL void* p) { return *(const M355_GLOBAL m355_h1*)p; }
 
+/* v_perm_b32: byte permute of {hi:lo}; the two selectors used here gather the LOW resp. HIGH 16-bit halves
+ * of two registers into one packed pair (lo -> bits 0..15, hi -> bits 16..31) in a single VALU issue */
+__device__ __forceinline__ unsigned d_pack_lo16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
+__device__ __forceinline__ unsigned d_pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+/* v_perm_b32 as an 8-entry byte table lookup: byte idx (0..7) of {hi:lo} */
+__device__ __forceinline__ unsigned d_byte_lookup(unsigned hi, unsigned lo, unsigned idx) { return __builtin_amdgcn_perm(hi, lo, idx) & 0xFFu; }
+/* v_pk_lshlrev_b16: both 16-bit halves shifted left by s */
+typedef unsigned short m355_ushort2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned d_pk_shl16(unsigned v, int s)
+{
+  m355_ushort2 t = __builtin_bit_cast(m355_ushort2, v);
+  t = t << (m355_ushort2)(unsigned short)s;
+  return __builtin_bit_cast(unsigned, t);
+}
+
 /* v_dot2c_i32_i16: c + a.lo*b.lo + a.hi*b.hi on packed signed 16-bit pairs — two filter taps per VALU
  * issue (measured on MI355X: same issue rate as v_mad_i32_i24, tools/ubench/ub_inter.hip). */
 typedef short m355_short2 __attribute__((ext_vector_type(2)));

@@ -64,7 +64,7 @@ struct DevPic {
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
   uint32_t* job_count;              /* device cursor used while the job list is built */
   int n_jobs;                       /* sum over PBs of (w/4) * ceil(h/8), computed at upload */
-  int n_jobs_main;                  /* jobs [0, n_jobs_main): windows inside the picture; [n_jobs_main, n_jobs): EDGE */
+  int n_jobs_uni, n_jobs_main;      /* jobs [0, n_jobs_uni): one list; [n_jobs_uni, n_jobs_main): bi-predicted; [n_jobs_main, n_jobs): EDGE (clamped loads) */
   /* intra wavefront state */
   uint32_t* ctb_done;               /* per CTB (raster) completion epoch */
   uint32_t* ticket;                 /* work counter */
@@ -104,7 +104,8 @@ void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st);
 
 /* ---- device helpers ---- */
-__device__ __forceinline__ int d_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+/* lo <= hi at every call site: min(max()) lets hipcc emit v_med3_i32 / v_max+v_min instead of compare+select chains */
+__device__ __forceinline__ int d_clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 __device__ __forceinline__ int d_clip_bd(int v, int bd) { return d_clip3(0, (1 << bd) - 1, v); }
 __device__ __forceinline__ int d_abs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int d_sign(int v) { return (v > 0) - (v < 0); }

@@ -271,33 +271,48 @@ __device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rst
        from hoisting all 15 rows of loads to the top (which spills) while still overlapping the next
        pair's loads with this pair's arithmetic */
     unsigned S[2][2][6];
-    d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi - 3) * rstride, xa, pw, S[0][0]);
-    d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi - 2) * rstride, xa, pw, S[0][1]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) S[1][1][i] = 0;
+    d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi - 3), rstride), xa, pw, S[0][0]);
+    d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi - 2), rstride), xa, pw, S[0][1]);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      if (k < 7) {
-        d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi + 2 * k - 1) * rstride, xa, pw, S[(k + 1) & 1][0]);
-        if (k < 6) d_load12<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi + 2 * k) * rstride, xa, pw, S[(k + 1) & 1][1]);
+      if (FAST) {
+        if (k < 7) {
+          d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k - 1), rstride), xa, pw, S[(k + 1) & 1][0]);
+          if (k < 6) d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k), rstride), xa, pw, S[(k + 1) & 1][1]);
+        }
+      } else if (k > 0) {   /* edge jobs: 24 clamped sample loads per pair, no prefetch (register pressure) */
+        d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k - 3), rstride), xa, pw, S[k & 1][0]);
+        if (k < 7) d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k - 2), rstride), xa, pw, S[k & 1][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      /* both rows of the pair, then one v_perm per column packs the (row 2k, row 2k+1) int16 pair —
+         the int16 mcbuffer store of fallback-motion.cc:512-565; xFrac == 0 copies the sample unshifted */
+      int h[2][4];
 #pragma unroll
       for (int q = 0; q < 2; q++) {
-        if (2 * k + q >= 15) break;
         const unsigned* R = S[k & 1][q];
         unsigned B[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) B[i] = R[i] ^ bias;
-        int h[4];
-        h[0] = d_dot2(B[3], XE[3], d_dot2(B[2], XE[2], d_dot2(B[1], XE[1], d_dot2(B[0], XE[0], init))));
-        h[1] = d_dot2(B[4], XO[4], d_dot2(B[3], XO[3], d_dot2(B[2], XO[2], d_dot2(B[1], XO[1], d_dot2(B[0], XO[0], init)))));
-        h[2] = d_dot2(B[4], XE[3], d_dot2(B[3], XE[2], d_dot2(B[2], XE[1], d_dot2(B[1], XE[0], init))));
-        h[3] = d_dot2(B[5], XO[4], d_dot2(B[4], XO[3], d_dot2(B[3], XO[2], d_dot2(B[2], XO[1], d_dot2(B[1], XO[0], init)))));
-        const unsigned raw0 = R[1] >> 16, raw1 = R[2] & 0xFFFFu, raw2 = R[2] >> 16, raw3 = R[3] & 0xFFFFu;
-        /* int16 mcbuffer store (fallback-motion.cc:512-565); xFrac == 0 copies the sample unshifted */
-        const unsigned t0 = d_sel(xmask, raw0, (unsigned)(h[0] >> shift1) & 0xFFFFu), t1 = d_sel(xmask, raw1, (unsigned)(h[1] >> shift1) & 0xFFFFu);
-        const unsigned t2 = d_sel(xmask, raw2, (unsigned)(h[2] >> shift1) & 0xFFFFu), t3 = d_sel(xmask, raw3, (unsigned)(h[3] >> shift1) & 0xFFFFu);
-        if (q == 0) { Q[k][0] = t0; Q[k][1] = t1; Q[k][2] = t2; Q[k][3] = t3; }
-        else { Q[k][0] |= t0 << 16; Q[k][1] |= t1 << 16; Q[k][2] |= t2 << 16; Q[k][3] |= t3 << 16; }
+        h[q][0] = d_dot2(B[3], XE[3], d_dot2(B[2], XE[2], d_dot2(B[1], XE[1], d_dot2(B[0], XE[0], init)))) >> shift1;
+        h[q][1] = d_dot2(B[4], XO[4], d_dot2(B[3], XO[3], d_dot2(B[2], XO[2], d_dot2(B[1], XO[1], d_dot2(B[0], XO[0], init))))) >> shift1;
+        h[q][2] = d_dot2(B[4], XE[3], d_dot2(B[3], XE[2], d_dot2(B[2], XE[1], d_dot2(B[1], XE[0], init)))) >> shift1;
+        h[q][3] = d_dot2(B[5], XO[4], d_dot2(B[4], XO[3], d_dot2(B[3], XO[2], d_dot2(B[2], XO[1], d_dot2(B[1], XO[0], init))))) >> shift1;
+      }
+      const unsigned* Re = S[k & 1][0];
+      const unsigned* Ro = S[k & 1][1];
+      if (k < 7) {
+        Q[k][0] = d_sel(xmask, d_pack_hi16(Re[1], Ro[1]), d_pack_lo16((unsigned)h[0][0], (unsigned)h[1][0]));
+        Q[k][1] = d_sel(xmask, d_pack_lo16(Re[2], Ro[2]), d_pack_lo16((unsigned)h[0][1], (unsigned)h[1][1]));
+        Q[k][2] = d_sel(xmask, d_pack_hi16(Re[2], Ro[2]), d_pack_lo16((unsigned)h[0][2], (unsigned)h[1][2]));
+        Q[k][3] = d_sel(xmask, d_pack_lo16(Re[3], Ro[3]), d_pack_lo16((unsigned)h[0][3], (unsigned)h[1][3]));
+      } else {   /* row 14 only: the odd half (row 15) is never read with a non-zero tap */
+        Q[k][0] = d_sel(xmask, Re[1] >> 16, (unsigned)h[0][0] & 0xFFFFu);
+        Q[k][1] = d_sel(xmask, Re[2] & 0xFFFFu, (unsigned)h[0][1] & 0xFFFFu);
+        Q[k][2] = d_sel(xmask, Re[2] >> 16, (unsigned)h[0][2] & 0xFFFFu);
+        Q[k][3] = d_sel(xmask, Re[3] & 0xFFFFu, (unsigned)h[0][3] & 0xFFFFu);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -309,19 +324,23 @@ __device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rst
 #pragma unroll
   for (int k = 0; k < 5; k++) YO[k] = ty[4 + k];
 #pragma unroll
-  for (int m = 0; m < 4; m++)
+  for (int m = 0; m < 4; m++) {
+    int ve[4], vo[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int ve = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0))));
-      const int vo = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)))));
-      /* yf == 0: row y+3 of the intermediates: y = 2m -> row 2m+3 = hi of pair m+1; y = 2m+1 -> row 2m+4 = lo of pair m+2 */
-      const unsigned ce = Q[m + 1][j] >> 16, co = Q[m + 2][j] & 0xFFFFu;   /* low 16 bits are all that is kept */
-      const unsigned pe = d_sel(ymask, d_sel(xymask, ce << shift3, ce), (unsigned)(ve >> vshift));
-      const unsigned po = d_sel(ymask, d_sel(xymask, co << shift3, co), (unsigned)(vo >> vshift));
-      /* the reference stores the prediction as int16 (predSamples, motion.cc:331) */
-      if ((j & 1) == 0) { pred[2 * m][j >> 1] = pe & 0xFFFFu; pred[2 * m + 1][j >> 1] = po & 0xFFFFu; }
-      else { pred[2 * m][j >> 1] |= pe << 16; pred[2 * m + 1][j >> 1] |= po << 16; }
+      ve[j] = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0)))) >> vshift;
+      vo[j] = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0))))) >> vshift;
     }
+    /* packed per column pair; the reference stores the prediction as int16 (predSamples, motion.cc:331).
+       yf == 0 copies row y+3 of the intermediates (y = 2m -> hi half of pair m+1, y = 2m+1 -> lo half of
+       pair m+2), and a full-pel block is the sample << shift3 */
+#pragma unroll
+    for (int jp = 0; jp < 2; jp++) {
+      const unsigned ce = d_pack_hi16(Q[m + 1][2 * jp], Q[m + 1][2 * jp + 1]), co = d_pack_lo16(Q[m + 2][2 * jp], Q[m + 2][2 * jp + 1]);
+      pred[2 * m][jp] = d_sel(ymask, d_sel(xymask, d_pk_shl16(ce, shift3), ce), d_pack_lo16((unsigned)ve[2 * jp], (unsigned)ve[2 * jp + 1]));
+      pred[2 * m + 1][jp] = d_sel(ymask, d_sel(xymask, d_pk_shl16(co, shift3), co), d_pack_lo16((unsigned)vo[2 * jp], (unsigned)vo[2 * jp + 1]));
+    }
+  }
 }
 
 /* chroma 2x4 block of one list and plane, fallback-motion.cc:305-415 / 262-302 */
@@ -344,17 +363,28 @@ __device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int r
     const unsigned bias = BIAS ? 0x80008000u : 0u;
     const int init = BIAS ? (1 << 21) : 0;
     unsigned S[7][3];
+    if (FAST) {   /* all seven rows in flight at once; the edge path loads row by row (register pressure) */
 #pragma unroll
-    for (int r = 0; r < 7; r++) d_load6<PIX, FAST>(rp + (size_t)d_clip3(0, ph - 1, yi + r - 1) * rstride, xa, pw, S[r]);
+      for (int r = 0; r < 7; r++) d_load6<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + r - 1), rstride), xa, pw, S[r]);
+    }
+    int h[8][2];
 #pragma unroll
     for (int r = 0; r < 7; r++) {
+      if (!FAST) {
+        d_load6<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + r - 1), rstride), xa, pw, S[r]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const unsigned B0 = S[r][0] ^ bias, B1 = S[r][1] ^ bias, B2 = S[r][2] ^ bias;
-      const int h0 = d_dot2(B1, XE[1], d_dot2(B0, XE[0], init));
-      const int h1 = d_dot2(B2, XO[2], d_dot2(B1, XO[1], d_dot2(B0, XO[0], init)));
-      const unsigned t0 = d_sel(xmask, S[r][0] >> 16, (unsigned)(h0 >> shift1) & 0xFFFFu);
-      const unsigned t1 = d_sel(xmask, S[r][1] & 0xFFFFu, (unsigned)(h1 >> shift1) & 0xFFFFu);
-      if ((r & 1) == 0) { Q[r >> 1][0] = t0; Q[r >> 1][1] = t1; } else { Q[r >> 1][0] |= t0 << 16; Q[r >> 1][1] |= t1 << 16; }
+      h[r][0] = d_dot2(B1, XE[1], d_dot2(B0, XE[0], init)) >> shift1;
+      h[r][1] = d_dot2(B2, XO[2], d_dot2(B1, XO[1], d_dot2(B0, XO[0], init))) >> shift1;
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      Q[k][0] = d_sel(xmask, d_pack_hi16(S[2 * k][0], S[2 * k + 1][0]), d_pack_lo16((unsigned)h[2 * k][0], (unsigned)h[2 * k + 1][0]));
+      Q[k][1] = d_sel(xmask, d_pack_lo16(S[2 * k][1], S[2 * k + 1][1]), d_pack_lo16((unsigned)h[2 * k][1], (unsigned)h[2 * k + 1][1]));
+    }
+    Q[3][0] = d_sel(xmask, S[6][0] >> 16, (unsigned)h[6][0] & 0xFFFFu);
+    Q[3][1] = d_sel(xmask, S[6][1] & 0xFFFFu, (unsigned)h[6][1] & 0xFFFFu);
   }
   unsigned YE[2], YO[3];
 #pragma unroll
@@ -363,18 +393,18 @@ __device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int r
   for (int k = 0; k < 3; k++) YO[k] = ty[2 + k];
   const int vshift = xf == 0 ? shift1 : 6;
 #pragma unroll
-  for (int m = 0; m < 2; m++)
+  for (int m = 0; m < 2; m++) {
+    int ve[2], vo[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      const int ve = d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0));
-      const int vo = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)));
-      /* yf == 0: row y+1: y = 2m -> row 2m+1 = hi of pair m ; y = 2m+1 -> row 2m+2 = lo of pair m+1 */
-      const unsigned ce = Q[m][j] >> 16, co = Q[m + 1][j] & 0xFFFFu;
-      const unsigned pe = d_sel(ymask, d_sel(xymask, ce << shift3, ce), (unsigned)(ve >> vshift));
-      const unsigned po = d_sel(ymask, d_sel(xymask, co << shift3, co), (unsigned)(vo >> vshift));
-      if (j == 0) { pred[2 * m] = pe & 0xFFFFu; pred[2 * m + 1] = po & 0xFFFFu; }
-      else { pred[2 * m] |= pe << 16; pred[2 * m + 1] |= po << 16; }
+      ve[j] = d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0)) >> vshift;
+      vo[j] = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0))) >> vshift;
     }
+    /* yf == 0: row y+1: y = 2m -> hi half of pair m ; y = 2m+1 -> lo half of pair m+1 */
+    const unsigned ce = d_pack_hi16(Q[m][0], Q[m][1]), co = d_pack_lo16(Q[m + 1][0], Q[m + 1][1]);
+    pred[2 * m] = d_sel(ymask, d_sel(xymask, d_pk_shl16(ce, shift3), ce), d_pack_lo16((unsigned)ve[0], (unsigned)ve[1]));
+    pred[2 * m + 1] = d_sel(ymask, d_sel(xymask, d_pk_shl16(co, shift3), co), d_pack_lo16((unsigned)vo[0], (unsigned)vo[1]));
+  }
 }
 
 /* weighted write-back of one sample (fallback-motion.cc:33-256, selection motion.cc:493-688).  All four
@@ -387,13 +417,18 @@ __device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int r
 struct WtSel { int w0, w1, rnd, sh, o; };
 __device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
 {
-  return d_clip_bd(((a * s.w0 + b * s.w1 + s.rnd) >> s.sh) + s.o, bd);
+  /* a, b are int16 and the weights int16: 24-bit multiplies are exact (v_mad_i32_i24, full rate) */
+  return d_clip_bd(((__mul24(a, s.w0) + __mul24(b, s.w1) + s.rnd) >> s.sh) + s.o, bd);
 }
 
-/* FAST: jobs of PBs whose reference windows lie inside the picture horizontally (k_meta_pb sorts the
- * others into the EDGE job range, handled by the FAST=false instance with clamped per-sample loads) */
+/* One job.  FAST: the PB's reference windows lie inside the picture horizontally (k_meta_pb sorts the
+ * others into the EDGE job range, handled with clamped per-sample loads). */
 template <class PIX, bool BIAS, bool FAST>
-__global__ void __launch_bounds__(256, 3) k_inter_jobs(DevPic p, int job_base, int job_n)
+__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et);
+
+/* one launch for the main and the edge job range: blocks [0, nblk_edge8) take edge jobs */
+template <class PIX, bool BIAS>
+__global__ void __launch_bounds__(256, 3) k_inter_jobs(DevPic p, int nblk_edge8, int nblk_bi8)
 {
   __shared__ unsigned s_qt[4 * QT_STRIDE];
   __shared__ unsigned s_et[8 * ET_STRIDE];
@@ -412,13 +447,31 @@ __global__ void __launch_bounds__(256, 3) k_inter_jobs(DevPic p, int job_base, i
   }
   __syncthreads();
 
-  /* XCD-aware block order: block b runs on XCD b % 8; give every XCD one contiguous eighth of the job
-     list (= a compact region of the picture) so reference-window overlap hits that XCD's own L2 */
-  const int per = gridDim.x >> 3;
-  const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int ji = lb * 256 + threadIdx.x;
-  if (ji >= job_n) return;
-  const uint32_t job = p.jobs[job_base + ji];
+  /* Dispatch order = expected cost, longest first: edge blocks (per-sample clamped loads make them
+     latency-bound; started early they overlap with everything else), then bi-predicted blocks (two
+     passes), then one-list blocks.  Edge blocks are spread round-robin over the XCDs.  The other two
+     ranges use an XCD-aware order: block b runs on XCD b % 8, and every XCD gets one contiguous eighth of
+     each range (= compact regions of the picture) so reference-window overlap hits that XCD's own L2. */
+  const int b = blockIdx.x;
+  if (b < nblk_edge8) {
+    const int ji = p.n_jobs_main + b * 256 + threadIdx.x;
+    if (ji < p.n_jobs) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et);
+    return;
+  }
+  const int bm = b - nblk_edge8, xcd = bm & 7, slot = bm >> 3;
+  const int per_bi = nblk_bi8 >> 3, per_uni = (gridDim.x - nblk_edge8 - nblk_bi8) >> 3;
+  if (slot < per_bi) {
+    const int ji = p.n_jobs_uni + (xcd * per_bi + slot) * 256 + threadIdx.x;
+    if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et);
+  } else {
+    const int ji = (xcd * per_uni + slot - per_bi) * 256 + threadIdx.x;
+    if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et);
+  }
+}
+
+template <class PIX, bool BIAS, bool FAST>
+__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et)
+{
   const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
   const int strip = (job >> 25) & 15, rblk = job >> 29;
   const int x0 = pb.x + 4 * strip, y0 = pb.y + 8 * rblk;
@@ -529,16 +582,11 @@ __global__ void __launch_bounds__(256, 3) k_inter_jobs(DevPic p, int job_base, i
 template <class PIX, bool BIAS>
 static void launch_jobs(const DevPic& p, hipStream_t st)
 {
-  /* grids padded to a multiple of 8 blocks for the XCD-contiguous block order */
-  const int n_edge = p.n_jobs - p.n_jobs_main;
-  if (p.n_jobs_main) {
-    const int nblk = (p.n_jobs_main + 255) / 256;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS, true>), dim3(((nblk + 7) / 8) * 8), dim3(256), 0, st, p, 0, p.n_jobs_main);
-  }
-  if (n_edge) {
-    const int nblk = (n_edge + 255) / 256;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS, false>), dim3(((nblk + 7) / 8) * 8), dim3(256), 0, st, p, p.n_jobs_main, n_edge);
-  }
+  /* grid padded to a multiple of 8 blocks for the XCD-contiguous block order */
+  auto blocks8 = [](int jobs) { return (((jobs + 255) / 256 + 7) / 8) * 8; };
+  const int nblk_uni8 = blocks8(p.n_jobs_uni), nblk_bi8 = blocks8(p.n_jobs_main - p.n_jobs_uni), nblk_edge8 = blocks8(p.n_jobs - p.n_jobs_main);
+  if (!(nblk_uni8 + nblk_bi8 + nblk_edge8)) return;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(nblk_edge8 + nblk_bi8 + nblk_uni8), dim3(256), 0, st, p, nblk_edge8, nblk_bi8);
 }
 
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)

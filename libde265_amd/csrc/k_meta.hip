@@ -111,24 +111,28 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   m355_pb pb;
   if (active) pb = p.pbs[i]; else { pb.x = pb.y = 0; pb.w = pb.h = 0; pb.flags = 0; }
   const int ns = pb.w >> 2, nr = (pb.h + 7) >> 3;
-  const bool edge = active && m355_pb_is_edge(pb, p.pp.width, p.pp.chroma_format_idc);
   const int njobs = active ? ns * nr : 0;
-  /* two ranges: [0, n_jobs_main) and [n_jobs_main, n_jobs) (edge); wave-level exclusive scans */
-  int incl_m = edge ? 0 : njobs, incl_e = edge ? njobs : 0;
+  /* three ranges: one-list jobs, bi-predicted jobs (so a wave never idles through a second pass it does
+     not need), edge jobs; wave-level exclusive scans, one atomic per wave and range */
+  const bool edge = active && m355_pb_is_edge(pb, p.pp.width, p.pp.chroma_format_idc);
+  const bool bi = (pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1);
+  const int cls = !active ? 3 : (edge ? 2 : (bi ? 1 : 0));
+  int incl[3] = {cls == 0 ? njobs : 0, cls == 1 ? njobs : 0, cls == 2 ? njobs : 0};
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const int tm = __shfl_up(incl_m, (unsigned)d, 64), te = __shfl_up(incl_e, (unsigned)d, 64);
-    if (lane >= d) { incl_m += tm; incl_e += te; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int t = __shfl_up(incl[k], (unsigned)d, 64); if (lane >= d) incl[k] += t; }
   }
-  const int tot_m = __shfl(incl_m, 63, 64), tot_e = __shfl(incl_e, 63, 64);
-  uint32_t base_m = 0, base_e = 0;
-  if (lane == 63) {
-    if (tot_m) base_m = atomicAdd(p.job_count, (uint32_t)tot_m);
-    if (tot_e) base_e = atomicAdd(p.job_count + 1, (uint32_t)tot_e);
+  uint32_t base[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int tot = __shfl(incl[k], 63, 64);
+    if (lane == 63 && tot) base[k] = atomicAdd(p.job_count + k, (uint32_t)tot);
+    base[k] = __shfl(base[k], 63, 64);
   }
-  base_m = __shfl(base_m, 63, 64); base_e = __shfl(base_e, 63, 64);
   if (!active) return;
-  uint32_t o = edge ? (uint32_t)p.n_jobs_main + base_e + (uint32_t)(incl_e - njobs) : base_m + (uint32_t)(incl_m - njobs);
+  uint32_t o = cls == 0 ? base[0] + (uint32_t)(incl[0] - njobs)
+             : (cls == 1 ? (uint32_t)p.n_jobs_uni + base[1] + (uint32_t)(incl[1] - njobs) : (uint32_t)p.n_jobs_main + base[2] + (uint32_t)(incl[2] - njobs));
   for (int r = 0; r < nr; r++)
     for (int s = 0; s < ns; s++) p.jobs[o++] = (uint32_t)i | ((uint32_t)s << 25) | ((uint32_t)r << 29);
   for (int y = pb.y >> 2; y < ((pb.y + pb.h) >> 2) && y < p.h4; y++)
@@ -175,7 +179,7 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
   hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4, st);
   hipMemsetAsync(p.edge_pb, 0, (size_t)p.w4 * p.h4, st);
   hipMemsetAsync(p.pb_of, 0, (size_t)p.w4 * p.h4 * 4, st);
-  hipMemsetAsync(p.job_count, 0, 8, st);
+  hipMemsetAsync(p.job_count, 0, 12, st);
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
   if (p.pp.flags & M355_PF_SAO_ENABLED) hipLaunchKernelGGL(k_meta_sao, dim3((p.nCtb * 3 + 255) / 256), dim3(256), 0, st, p);

@@ -19,44 +19,52 @@ template <class PIX> struct Vec4;
 template <> struct Vec4<uint8_t> { typedef uint32_t T; };
 template <> struct Vec4<uint16_t> { typedef uint2 T; };
 
-/* offsets of the two neighbours per edge class (sao.cc:83-88) */
+/* four horizontally adjacent samples as raw words / one sample out of them */
+template <class PIX> __device__ __forceinline__ void d_sao_load4(const PIX* q, uint32_t* w)
+{
+  if (sizeof(PIX) == 2) { const uint2 v = *(const uint2*)q; w[0] = v.x; w[1] = v.y; }
+  else w[0] = *(const uint32_t*)q;
+}
+template <class PIX> __device__ __forceinline__ int d_sao_sample(const uint32_t* w, int k)
+{
+  if (sizeof(PIX) == 2) return (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+  return (int)((w[0] >> (8 * k)) & 0xFFu);
+}
+
+/* Edge offset for one 4x4 block, class given by the first neighbour offset (H0,V0) (sao.cc:83-88; the
+ * second neighbour is its mirror).  Branch-free per sample: which samples are on the CTB ring and which
+ * neighbour CTB a ring sample looks into are compile-time functions of (s,j,H0,V0) combined with the
+ * thread's four position flags; availability is one bit of the k_meta_sao mask; skipped samples
+ * (pcm/bypass, sao.cc:103-120) arrive as a 16-bit per-sample mask.
+ * nb[r][k]: sample at (x0 - 1 + k, y0 - 1 + r). */
 template <int H0, int V0, class PIX>
-__device__ __forceinline__ void d_sao_edge_block(const DevPic& p, int o0, int o1, int o2, int o3, const int nb[6][6], bool extended, bool plf, int x0, int y0,
-                                                 int xC, int yC, int ctbW_, int ctbH_, int width, int height, int csw, int csh, int l2w, int l2h,
+__device__ __forceinline__ void d_sao_edge_block(int o0, int o1, int o2, int o3, const int nb[6][6], uint32_t skipmask, bool L, bool R, bool T, bool Bt,
                                                  uint32_t nbmask, int maxv, int rows, PIX res[4][4])
 {
-  /* nb[r][k]: sample at (x0 - 1 + k, y0 - 1 + r); class offsets: a = (+H0,+V0), b = (-H0,-V0) */
+  const unsigned tab_lo = ((unsigned)o0 & 0xFFu) | (((unsigned)o1 & 0xFFu) << 8) | (((unsigned)o2 & 0xFFu) << 24), tab_hi = (unsigned)o3 & 0xFFu;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    if (j >= rows) break;
-    const int y = y0 + j, jj = y - yC, yl = y << csh;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-      const int x = x0 + s, i = x - xC, xl = x << csw;
-      if (extended) {
-        const uint32_t ci = d_cu_index_at(p, xl, yl);
-        if (ci) {
-          const m355_cu cu = p.cus[ci - 1];
-          if ((plf && (cu.flags & M355_CUF_PCM)) || (cu.flags & M355_CUF_TRANSQUANT_BYPASS)) continue;
-        }
-      }
-      bool zero = false;
-      if (i == 0 || jj == 0 || i == ctbW_ - 1 || jj == ctbH_ - 1) {
-        /* CTB-border sample (sao.cc:122-164): both neighbours must lie in usable CTBs (k_meta_sao mask) */
+      const bool lastrow = j == rows - 1;
+      /* on the CTB ring? (the reference tests availability only there, sao.cc:122) */
+      const bool ring = (s == 0 && L) || (s == 3 && R) || (j == 0 && T) || (lastrow && Bt);
+      bool blocked = false;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const int xS = x + (k ? -H0 : H0), yS = y + (k ? -V0 : V0);
-          const int dx = (xS >> l2w) - (xC >> l2w), dy = (yS >> l2h) - (yC >> l2h);
-          if (xS < 0 || yS < 0 || xS >= width || yS >= height || ((nbmask >> ((dy + 1) * 3 + dx + 1)) & 1u)) zero = true;
-        }
+      for (int k = 0; k < 2; k++) {
+        const int sx = s + (k ? -H0 : H0), sy = j + (k ? -V0 : V0);
+        const int dx = sx < 0 ? (L ? -1 : 0) : (sx > 3 ? (R ? 1 : 0) : 0);
+        const int dy = sy < 0 ? (T ? -1 : 0) : ((sy > 3 || (V0 != 0 && lastrow && sy > j)) ? (Bt ? 1 : 0) : 0);
+        blocked = blocked || ((nbmask >> ((dy + 1) * 3 + dx + 1)) & 1u);
       }
-      if (zero) continue;
+      const bool apply = !(ring && blocked) && !((skipmask >> (j * 4 + s)) & 1u);
       const int cv = nb[1 + j][1 + s];
       const int a = nb[1 + j + V0][1 + s + H0], b = nb[1 + j - V0][1 + s - H0];
-      const int edgeIdx = d_sign(cv - a) + d_sign(cv - b);
-      /* offsets in the order of sao.cc:95-100: edgeIdx -2,-1,+1,+2 -> saoOffsetVal 0..3 */
-      const int off = edgeIdx == -2 ? o0 : (edgeIdx == -1 ? o1 : (edgeIdx == 1 ? o2 : (edgeIdx == 2 ? o3 : 0)));
-      res[j][s] = (PIX)d_clip3(0, maxv, cv + off);
+      /* edgeIdx = Sign(c-a) + Sign(c-b); Sign(x) = med3(x,-1,1); offsets in the order of sao.cc:95-100 */
+      const int edgeIdx = d_clip3(-1, 1, cv - a) + d_clip3(-1, 1, cv - b);
+      const int off = (int)(int8_t)d_byte_lookup(tab_hi, tab_lo, (unsigned)(edgeIdx + 2));   /* [o0, o1, 0, o2, o3] */
+      const int m = -(int)apply;
+      res[j][s] = (PIX)((d_clip3(0, maxv, cv + off) & m) | (cv & ~m));
     }
   }
 }
@@ -64,26 +72,28 @@ __device__ __forceinline__ void d_sao_edge_block(const DevPic& p, int o0, int o1
 template <class PIX>
 __global__ void __launch_bounds__(256) k_sao(DevPic p)
 {
-  /* one thread = a 4x4 sample block (always inside one CTB: component CTB sizes are >= 8, plane sizes
-     multiples of 4... heights multiples of 2: the row count is clipped); a wave covers 256 x 4 samples.
-     Rows y0-1 .. y0+4 are loaded once as aligned 4-sample vectors; the columns x0-1 and x0+4 come from
-     the neighbouring lanes' vectors (cross-lane shuffle), from memory only at the wave's two ends. */
+  /* one thread = a 4x4 sample block (always inside one CTB: component CTB sizes are >= 8 and planes are
+     multiples of 4 wide; the row count is clipped at the picture bottom).  A wave covers 64 x 16 samples
+     = 16 x 4 threads, i.e. it stays inside ONE 64x64 luma CTB, so the SAO type / edge class branches
+     are wave-uniform.  Every thread loads only its own four rows as aligned 4-sample vectors; the rows
+     above/below come from the lanes 16 up/down and the columns left/right from the neighbouring lanes
+     (cross-lane shuffles) — memory is touched again only on the wave tile's rim. */
   typedef typename Vec4<PIX>::T V4;
   const int c = blockIdx.z;
-  const int lane = threadIdx.x & 63;
-  const int x0 = (blockIdx.x * 64 + lane) * 4, y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+  const int lane = threadIdx.x & 63, lx = lane & 15, ly = lane >> 4;
   const int width = p.pw[c], height = p.ph[c];
-  if (y0 >= height || (int)blockIdx.x * 256 >= width) return;   /* wave-uniform (chroma planes are smaller than the grid) */
-  const bool valid = x0 < width;
-  const int rows = min(4, height - y0);
+  const int xt = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 64, yt = (int)blockIdx.y * 16;
+  if (yt >= height || xt >= width) return;        /* wave-uniform (chroma planes are smaller than the grid) */
+  const int x0 = xt + lx * 4, y0 = yt + ly * 4;
+  const bool valid = x0 < width && y0 < height;
+  const int rows = valid ? min(4, height - y0) : 0;
   const PIX* in = (const PIX*)p.plane[c];
   PIX* out = (PIX*)p.out_plane[c];
   const int is = p.stride[c], os = p.out_stride[c];
 
   const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
   const int l2w = p.pp.log2_ctb_size - csw, l2h = p.pp.log2_ctb_size - csh;
-  const int xq = valid ? x0 : 0;
-  const int xCtb = xq >> l2w, yCtb = y0 >> l2h;
+  const int xCtb = (valid ? x0 : xt) >> l2w, yCtb = (valid ? y0 : yt) >> l2h;
   const m355_ctb ctb = p.ctbs[yCtb * p.ctbW + xCtb];
   const m355_slice csl = p.slices[ctb.slice_idx];
   /* this component's parameters, selected without indexing the record dynamically */
@@ -96,30 +106,40 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
   const int type = (enabled && valid) ? ((ctb.sao_type >> (2 * c)) & 3) : 0;
   const bool edge = type == 2;
 
-  /* ---- load the 6x6 neighbourhood ---- */
+  /* ---- the 6x6 neighbourhood; rows are kept as raw 32-bit words (NW per 4 samples) ---- */
+  constexpr int NW = (int)sizeof(V4) / 4;
   int nb[6][6];
-  union { V4 v; PIX s[4]; } row[6];
-  const bool any_edge = __any(edge);               /* a neighbour lane may need this lane's rows y0-1 / y0+4 */
+  uint32_t rw[6][NW];
 #pragma unroll
-  for (int r = 0; r < 6; r++) {
-    const int yy = y0 - 1 + r;
-    const bool need = valid && yy >= 0 && yy < height && (any_edge || (r >= 1 && r <= 4));
-    if (need) row[r].v = *(const V4*)(in + (size_t)yy * is + x0);
-    else { for (int k = 0; k < 4; k++) row[r].s[k] = 0; }
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < NW; k++) rw[r][k] = 0;
+#pragma unroll
+  for (int r = 1; r <= 4; r++)
+    if (r - 1 < rows) d_sao_load4<PIX>(in + (size_t)(y0 + r - 1) * is + x0, rw[r]);
+  const bool any_edge = __any(edge);
+  if (any_edge) {
+    /* rows y0-1 and y0+4: the lanes 16 up / down hold them as their last / first own row */
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      const uint32_t up = __shfl_up(rw[4][k], 16, 64), dn = __shfl_down(rw[1][k], 16, 64);
+      if (ly > 0) rw[0][k] = up;
+      if (ly < 3) rw[5][k] = dn;
+    }
+    if (valid && ly == 0 && y0 > 0) d_sao_load4<PIX>(in + (size_t)(y0 - 1) * is + x0, rw[0]);
+    if (valid && ly == 3 && y0 + 4 < height) d_sao_load4<PIX>(in + (size_t)(y0 + 4) * is + x0, rw[5]);
   }
 #pragma unroll
   for (int r = 0; r < 6; r++) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) nb[r][1 + k] = row[r].s[k];
+    for (int k = 0; k < 4; k++) nb[r][1 + k] = d_sao_sample<PIX>(rw[r], k);
     nb[r][0] = nb[r][5] = 0;
     if (any_edge) {
       const int yy = y0 - 1 + r;
-      const bool yok = yy >= 0 && yy < height;
-      int l = __shfl_up((int)row[r].s[3], 1, 64), rg = __shfl_down((int)row[r].s[0], 1, 64);
-      if (edge && yok) {
-        if (lane == 0 && x0 > 0) l = in[(size_t)yy * is + x0 - 1];
-        if (lane == 63 && x0 + 4 < width) rg = in[(size_t)yy * is + x0 + 4];
-      }
+      const bool yok = valid && yy >= 0 && yy < height;
+      int l = __shfl_up(nb[r][4], 1, 64), rg = __shfl_down(nb[r][1], 1, 64);
+      if (lx == 0) l = (edge && yok && x0 > 0) ? (int)in[(size_t)yy * is + x0 - 1] : 0;
+      if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? (int)in[(size_t)yy * is + x0 + 4] : 0;
       nb[r][0] = l; nb[r][5] = rg;
     }
   }
@@ -129,51 +149,56 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
 #pragma unroll
   for (int j = 0; j < 4; j++)
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) res[j][s2] = row[1 + j].s[s2];
+    for (int s2 = 0; s2 < 4; s2++) res[j][s2] = (PIX)nb[1 + j][1 + s2];
 
   if (type != 0) {
     const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma, maxv = (1 << bd) - 1;
-    const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
-    const bool extended = ctb.flags & M355_CTBF_HAS_PCM_OR_BYPASS;
+    /* samples of pcm (with pcm_loop_filter_disable) / transquant-bypass CUs are left alone (sao.cc:103-120): rare */
+    uint32_t skipmask = 0;
+    if (ctb.flags & M355_CTBF_HAS_PCM_OR_BYPASS) {
+      const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
+      for (int j = 0; j < 4; j++)
+        for (int s2 = 0; s2 < 4; s2++) {
+          const uint32_t ci = d_cu_index_at(p, min((x0 + s2) << csw, p.pp.width - 1), min((y0 + j) << csh, p.pp.height - 1));
+          if (ci) {
+            const m355_cu cu = p.cus[ci - 1];
+            if ((plf && (cu.flags & M355_CUF_PCM)) || (cu.flags & M355_CUF_TRANSQUANT_BYPASS)) skipmask |= 1u << (j * 4 + s2);
+          }
+        }
+    }
     if (edge) {
       const int cls = (ctb.sao_eo_class >> (2 * c)) & 3;
       const int xC = xCtb << l2w, yC = yCtb << l2h;
       const int nSW = 1 << l2w, nSH = 1 << l2h;
       const int ctbW_ = (xC + nSW > width) ? width - xC : nSW, ctbH_ = (yC + nSH > height) ? height - yC : nSH;
+      const bool L = x0 == xC, R = x0 + 4 == xC + ctbW_, T = y0 == yC, Bt = y0 + rows == yC + ctbH_;
       const uint32_t nbmask = p.sao_nb[c * p.nCtb + yCtb * p.ctbW + xCtb];
-      /* class -> first neighbour offset (sao.cc:83-88): 0:(-1,0) 1:(0,-1) 2:(-1,-1) 3:(+1,-1); the second is its mirror */
-      if (cls == 0) d_sao_edge_block<-1, 0, PIX>(p, so0, so1, so2, so3, nb, extended, plf, x0, y0, xC, yC, ctbW_, ctbH_, width, height, csw, csh, l2w, l2h, nbmask, maxv, rows, res);
-      else if (cls == 1) d_sao_edge_block<0, -1, PIX>(p, so0, so1, so2, so3, nb, extended, plf, x0, y0, xC, yC, ctbW_, ctbH_, width, height, csw, csh, l2w, l2h, nbmask, maxv, rows, res);
-      else if (cls == 2) d_sao_edge_block<-1, -1, PIX>(p, so0, so1, so2, so3, nb, extended, plf, x0, y0, xC, yC, ctbW_, ctbH_, width, height, csw, csh, l2w, l2h, nbmask, maxv, rows, res);
-      else d_sao_edge_block<1, -1, PIX>(p, so0, so1, so2, so3, nb, extended, plf, x0, y0, xC, yC, ctbW_, ctbH_, width, height, csw, csh, l2w, l2h, nbmask, maxv, rows, res);
+      /* class -> first neighbour offset (sao.cc:83-88): 0:(-1,0) 1:(0,-1) 2:(-1,-1) 3:(+1,-1); wave-uniform for luma */
+      if (cls == 0) d_sao_edge_block<-1, 0, PIX>(so0, so1, so2, so3, nb, skipmask, L, R, T, Bt, nbmask, maxv, rows, res);
+      else if (cls == 1) d_sao_edge_block<0, -1, PIX>(so0, so1, so2, so3, nb, skipmask, L, R, T, Bt, nbmask, maxv, rows, res);
+      else if (cls == 2) d_sao_edge_block<-1, -1, PIX>(so0, so1, so2, so3, nb, skipmask, L, R, T, Bt, nbmask, maxv, rows, res);
+      else d_sao_edge_block<1, -1, PIX>(so0, so1, so2, so3, nb, skipmask, L, R, T, Bt, nbmask, maxv, rows, res);
     } else {
+      const unsigned btab = ((unsigned)so0 & 0xFFu) | (((unsigned)so1 & 0xFFu) << 8) | (((unsigned)so2 & 0xFFu) << 16) | (((unsigned)so3 & 0xFFu) << 24);
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (j >= rows) break;
+      for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) {
-          if (extended) {
-            const uint32_t ci = d_cu_index_at(p, (x0 + s2) << csw, (y0 + j) << csh);
-            if (ci) {
-              const m355_cu cu = p.cus[ci - 1];
-              if ((plf && (cu.flags & M355_CUF_PCM)) || (cu.flags & M355_CUF_TRANSQUANT_BYPASS)) continue;
-            }
-          }
           const int cv = nb[1 + j][1 + s2];
           const int band = d_clip3(0, maxv, cv) >> (bd - 5);
           const int k = (band - band_pos) & 31;
-          if (k < 4) res[j][s2] = (PIX)d_clip3(0, maxv, cv + (k == 0 ? so0 : (k == 1 ? so1 : (k == 2 ? so2 : so3))));
+          const int off = (int)(int8_t)d_byte_lookup(0u, btab, (unsigned)k & 3u);
+          const int m = -(int)(k < 4 && !((skipmask >> (j * 4 + s2)) & 1u));
+          res[j][s2] = (PIX)((d_clip3(0, maxv, cv + off) & m) | (cv & ~m));
         }
-      }
     }
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (j >= rows) break;
-    union { V4 v; PIX s[4]; } o;
-#pragma unroll
-    for (int s2 = 0; s2 < 4; s2++) o.s[s2] = res[j][s2];
-    *(V4*)(out + (size_t)(y0 + j) * os + x0) = o.v;
+    PIX* q = out + (size_t)(y0 + j) * os + x0;
+    if (sizeof(PIX) == 2) *(uint2*)q = make_uint2((uint32_t)res[j][0] | ((uint32_t)res[j][1] << 16), (uint32_t)res[j][2] | ((uint32_t)res[j][3] << 16));
+    else *(uint32_t*)q = (uint32_t)res[j][0] | ((uint32_t)res[j][1] << 8) | ((uint32_t)res[j][2] << 16) | ((uint32_t)res[j][3] << 24);
   }
 }
 
@@ -181,7 +206,7 @@ void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st)
 {
   /* one launch for all components: grid.z = component; chroma blocks beyond the chroma plane exit at once */
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
-  const dim3 grid((p.pw[0] + 255) / 256, (p.ph[0] + 15) / 16, nc), block(256);
+  const dim3 grid((p.pw[0] + 255) / 256, (p.ph[0] + 15) / 16, nc), block(256);   /* 4 waves side by side: 256 x 16 samples */
   if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t>), grid, block, 0, st, p);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t>), grid, block, 0, st, p);
 }

@@ -77,7 +77,7 @@ struct Resident {
   DevRef* refs_host = nullptr; /* pinned staging + last uploaded contents */
   bool refs_valid = false;
   int n_intra_work = 0;
-  int n_jobs = 0, n_jobs_main = 0;   /* inter jobs (k_inter_jobs), from the PB geometry */
+  int n_jobs = 0, n_jobs_main = 0, n_jobs_uni = 0;   /* inter jobs (k_inter_jobs), from the PB geometry */
 };
 
 struct m355_ctx {
@@ -435,14 +435,18 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     if (pic->ctbs[ts2rs[t]].ib_count) iw[nw++] = ts2rs[t];
   r.n_intra_work = nw;
   {
-    long long nj = 0, nm = 0;
+    long long nj = 0, nm = 0, nu = 0;
     for (int i = 0; i < pic->n_pbs; i++) {
-      const long long n = (long long)(pic->pbs[i].w >> 2) * ((pic->pbs[i].h + 7) >> 3);
+      const m355_pb& pb = pic->pbs[i];
+      const long long n = (long long)(pb.w >> 2) * ((pb.h + 7) >> 3);
       nj += n;
-      if (!m355_pb_is_edge(pic->pbs[i], pp.width, pp.chroma_format_idc)) nm += n;
+      if (!m355_pb_is_edge(pb, pp.width, pp.chroma_format_idc)) {
+        nm += n;
+        if (!((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1))) nu += n;
+      }
     }
     if (pic->n_pbs > 0x1FFFFFF || nj > 0x7FFFFFFF) return fail(M355_ERR_INVALID, "too many prediction blocks");
-    r.n_jobs = (int)nj; r.n_jobs_main = (int)nm;
+    r.n_jobs = (int)nj; r.n_jobs_main = (int)nm; r.n_jobs_uni = (int)nu;
   }
   intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
   r.bytes = total;
@@ -476,7 +480,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
   d.intra_work = (const uint32_t*)(r.dev + seg[i_iw].ofs);
   d.n_intra_work = nw;
-  d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main;
+  d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main; d.n_jobs_uni = r.n_jobs_uni;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
   r.used = true;
   return M355_OK;
