@@ -8,57 +8,75 @@
  * 269-407), transform_skip_residual / rdpcm_* / transform_bypass* / rotate_coefficients
  * (fallback-dct.cc:81-256) and add_residual (fallback-dct.h:65-73).
  *
- * Mapping: blocks are binned by size on the host (m355_picture.rb_count).  A wavefront owns
- * 64/min(64,nT^2) blocks; the sparse (pos,level) pairs are dequantised and scattered into an LDS
- * tile, the separable transform runs column pass -> LDS -> row pass with the reference's exact
- * intermediate clip (int16 after the first stage, none after the second), pruned to the occupied
- * rows/columns (the reference's lastCol pruning, fallback-dct.cc:614-617, only skips zero terms).
- * Inter blocks are added to the picture in place; intra blocks go to the int16 residual buffer that
- * the intra wavefront consumes, so the serial intra chain never waits for a transform.
- * Roofline: HBM-bound (4 B per nonzero coefficient in, nT^2 samples read-modify-write); the matrix
- * work is VALU int MACs out of LDS, far below the integer roof at the sparsities of real streams.
+ * Mapping: blocks are binned by size on the host (m355_picture.rb_count); ONE launch covers all four
+ * sizes (largest first), a workgroup handles 4 * 64/nT blocks of one size.  Within a wave, lane =
+ * (column c, block b): the sparse (pos,level) pairs are dequantised and scattered into an LDS tile
+ * stored as vertical int16 PAIRS, so the column pass is v_dot2c_i32_i16 over (row 2q, row 2q+1) with
+ * the matrix pair coming from a compile-time table in constant memory — the matrix entry depends only
+ * on (q, output row), not on the lane, so it is a SCALAR operand (s_load) and each LDS read feeds nT
+ * dot2 issues.  The first-stage output is clipped to int16 exactly like the reference and written as
+ * horizontal pairs; the row pass is the same scheme with lane = (row, block) and produces nT
+ * horizontally adjacent samples per lane, which are added to the picture (inter) or stored to the
+ * deferred-residual buffer (intra) with 16-byte vector accesses.  Both passes are pruned to the
+ * occupied rows/columns (the reference's lastCol pruning, fallback-dct.cc:614-617, only skips zeros).
+ * Roofline: HBM-bound on paper (4 B per nonzero coefficient in, nT^2 samples read-modify-write); in
+ * practice VALU/latency-bound on dense blocks, see DESIGN.md.
  */
 #include "k_common.h"
 
-/* M[k][n] = c(k(2n+1)), c = quarter wave of the HEVC core transform (fallback-dct.cc:512-545) */
-__constant__ int8_t c_dct_qw[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
-                                    61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
-__constant__ int8_t c_dst4[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
 __constant__ int8_t c_level_scale[6] = {40, 45, 51, 57, 64, 72};
 
-__device__ __forceinline__ int dct_wave(int m)
+/* ---- compile-time tables: M[k][n] = c(k(2n+1)), c = quarter wave of the HEVC core transform
+ * (the matrix of fallback-dct.cc:512-545), stored as int16 pairs (M[F*2q][i], M[F*(2q+1)][i]), F = 32/nT ---- */
+struct ResTables {
+  uint32_t dct[4][16 * 32];   /* [log2-2][q * nT + i] */
+  uint32_t dst[2 * 4];        /* DST-VII 4x4 (fallback-dct.cc:260-265), same pairing */
+};
+constexpr int res_qw(int m)
 {
+  constexpr int qw[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                          61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
   m &= 127;
-  if (m <= 32) return c_dct_qw[m];
-  if (m <= 64) return -c_dct_qw[64 - m];
-  if (m < 96) return -c_dct_qw[m - 64];
-  return c_dct_qw[128 - m];
+  return m <= 32 ? qw[m] : (m <= 64 ? -qw[64 - m] : (m < 96 ? -qw[m - 64] : qw[128 - m]));
 }
+constexpr uint32_t res_pack(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+constexpr ResTables make_res_tables()
+{
+  ResTables t{};
+  for (int s = 0; s < 4; s++) {
+    const int nT = 4 << s, F = 32 / nT;
+    for (int q = 0; q < nT / 2; q++)
+      for (int i = 0; i < nT; i++) t.dct[s][q * nT + i] = res_pack(res_qw((F * 2 * q) * (2 * i + 1)), res_qw((F * (2 * q + 1)) * (2 * i + 1)));
+  }
+  constexpr int d4[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
+  for (int q = 0; q < 2; q++)
+    for (int i = 0; i < 4; i++) t.dst[q * 4 + i] = res_pack(d4[(2 * q) * 4 + i], d4[(2 * q + 1) * 4 + i]);
+  return t;
+}
+__constant__ ResTables c_res = make_res_tables();
+
+__device__ __forceinline__ uint32_t d_sel_u(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+#define RES_LDS_DWORDS (8 * (1024 + 32))   /* 32x32: 8 blocks per workgroup, nT^2/2 coefficient pairs + nT * (nT/2+1) first-stage pairs each */
 
 template <int LOG2, class PIX>
-__global__ void __launch_bounds__(256) k_residual(DevPic p, int rb_base, int rb_n)
+__device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, int rb_n, int group, uint32_t* smem)
 {
   constexpr int NT = 1 << LOG2, N2 = NT * NT;
-  constexpr int G = N2 < 64 ? N2 : 64;   /* lanes per block */
-  constexpr int TPW = 64 / G;            /* blocks per wave */
-  constexpr int S = N2 / G;              /* samples per lane */
-  constexpr int FACT = 32 / NT;
-
-  __shared__ int8_t s_mat[32 * 32];
-  __shared__ int16_t s_c[4 * TPW][N2];   /* dense coefficients */
-  __shared__ int16_t s_g[4 * TPW][N2];   /* first-stage output */
-  __shared__ int s_r[4 * TPW][N2];       /* residual of the skip / bypass paths (prefix sums need int32) */
-
-  for (int i = threadIdx.x; i < 1024; i += 256) s_mat[i] = (int8_t)dct_wave((i >> 5) * (2 * (i & 31) + 1));
-  __syncthreads();
+  constexpr int BPW = 64 / NT;           /* blocks per wave */
+  constexpr int QN = NT / 2;             /* int16 pairs per column / row */
+  constexpr int GP = QN + 1;             /* first-stage row pitch in dwords (padded: conflict-free row reads) */
+  constexpr int BLK_DW = QN * NT + NT * GP;
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sub = lane / G, sl = lane % G;
-  const int tbi = (blockIdx.x * 4 + wave) * TPW + sub;
+  const int c = lane & (NT - 1), b = lane >> LOG2;
+  const int tbi = (group * 4 + wave) * BPW + b;
   const bool active = tbi < rb_n;
-  int16_t* cf = s_c[wave * TPW + sub];
-  int16_t* gg = s_g[wave * TPW + sub];
-  int* rr = s_r[wave * TPW + sub];
+  uint32_t* cfp = smem + (wave * BPW + b) * BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
+  uint32_t* gp = cfp + QN * NT;                        /* gp[row * GP + q]  = (g[row][2q], g[row][2q+1])       */
+  int16_t* cf16 = (int16_t*)cfp;
+  int16_t* g16 = (int16_t*)gp;
+  int* rr = (int*)cfp;                                 /* skip / bypass residual (int32, N2 <= BLK_DW) */
 
   m355_rb rb;
   if (active) rb = p.rbs[rb_base + tbi];
@@ -67,7 +85,7 @@ __global__ void __launch_bounds__(256) k_residual(DevPic p, int rb_base, int rb_
 
   /* ---- dequantise + scatter (transform.cc:408-525) ---- */
 #pragma unroll
-  for (int k = 0; k < S; k++) cf[sl + G * k] = 0;
+  for (int k = 0; k < QN; k++) cfp[k * NT + c] = 0;
   wave_sync();
   int maxrow = -1, maxcol = -1;
   {
@@ -82,7 +100,7 @@ __global__ void __launch_bounds__(256) k_residual(DevPic p, int rb_base, int rb_
       const int sz_ofs = LOG2 == 2 ? 0 : LOG2 == 3 ? 6 * 16 : LOG2 == 4 ? 6 * 16 + 6 * 64 : 6 * 16 + 6 * 64 + 6 * 256;
       scl = p.scaling + sz_ofs + rb.matrix_id * N2;
     }
-    for (int k = sl; k < rb.ncoeff; k += G) {
+    for (int k = c; k < rb.ncoeff; k += NT) {
       const uint32_t e = p.coeffs[rb.coeff_ofs + k];
       int pos = e & 0xFFFF;
       const int lvl = (int16_t)(e >> 16);
@@ -95,102 +113,141 @@ __global__ void __launch_bounds__(256) k_residual(DevPic p, int rb_base, int rb_
         v = t < -32768 ? -32768 : (t > 32767 ? 32767 : (int)t);
       }
       if (rb.flags & M355_RBF_ROTATE) pos = N2 - 1 - pos;
-      cf[pos] = (int16_t)v;
-      if (v != 0) { maxrow = max(maxrow, pos >> LOG2); maxcol = max(maxcol, pos & (NT - 1)); }
+      const int row = pos >> LOG2, col = pos & (NT - 1);
+      cf16[((row >> 1) * NT + col) * 2 + (row & 1)] = (int16_t)v;
+      if (v != 0) { maxrow = max(maxrow, row); maxcol = max(maxcol, col); }
     }
   }
-  /* reduce the occupied extent over the block's lanes */
+  /* occupied extent: over the block's lanes for the skip/bypass test below, over the WAVE for the loop
+     bounds (uniform bounds keep the matrix operands scalar; extra iterations only add zeros) */
 #pragma unroll
-  for (int m = G >> 1; m >= 1; m >>= 1) {
-    maxrow = max(maxrow, __shfl_xor(maxrow, m, G));
-    maxcol = max(maxcol, __shfl_xor(maxcol, m, G));
+  for (int m = 32; m >= 1; m >>= 1) {
+    maxrow = max(maxrow, __shfl_xor(maxrow, m, 64));
+    maxcol = max(maxcol, __shfl_xor(maxcol, m, 64));
   }
   wave_sync();
 
-  int res[S];
-  if (rb.kind == M355_RK_DCT || rb.kind == M355_RK_DST) {
-    const bool dst = (LOG2 == 2) && rb.kind == M355_RK_DST;
-    /* column pass: g[i][c] = clip16((sum_j M[j][i] * coef[j][c] + 64) >> 7) */
+  const bool is_tr = rb.kind == M355_RK_DCT || rb.kind == M355_RK_DST;
+  const bool any_tr = __any(is_tr), any_other = __any(!is_tr && active);
+  int res[NT];      /* one row (lane's `c` is the row index here), NT adjacent samples */
 #pragma unroll
-    for (int k = 0; k < S; k++) {
-      const int o = sl + G * k, c = o & (NT - 1), i = o >> LOG2;
-      int sum = 0;
-      if (c <= maxcol)
-        for (int j = 0; j <= maxrow; j++) {
-          const int m = dst ? c_dst4[j * 4 + i] : s_mat[(FACT * j) * 32 + i];
-          sum += m * cf[c + j * NT];
-        }
-      gg[o] = (int16_t)d_clip3(-32768, 32767, (sum + 64) >> 7);
-    }
-    wave_sync();
-    /* row pass: r[y][i] = (sum_j M[j][i] * g[y][j] + rnd) >> (20-bd), not clipped */
-    const int postShift = 20 - bd, rnd2 = 1 << (postShift - 1);
+  for (int i = 0; i < NT; i++) res[i] = 0;
+
+  if (any_tr) {
+    const uint32_t dstmask = ((LOG2 == 2) && rb.kind == M355_RK_DST) ? ~0u : 0u;
+    const uint32_t* mt = c_res.dct[LOG2 - 2];
+    /* column pass: g[i][col] = clip16((sum_j M[j][i] * coef[j][col] + 64) >> 7), lane = (col, block) */
+    int acc[NT];
 #pragma unroll
-    for (int k = 0; k < S; k++) {
-      const int o = sl + G * k, i = o & (NT - 1), y = o >> LOG2;
-      int sum = 0;
-      for (int j = 0; j <= maxcol; j++) {
-        const int m = dst ? c_dst4[j * 4 + i] : s_mat[(FACT * j) * 32 + i];
-        sum += m * gg[y * NT + j];
+    for (int i = 0; i < NT; i++) acc[i] = 64;
+    const int q1 = __builtin_amdgcn_readfirstlane((maxrow >> 1) + 1);   /* wave-uniform (tell hipcc: scalar loop, scalar matrix loads); maxrow = -1 -> 0 iterations */
+    for (int q = 0; q < q1; q++) {
+      const uint32_t v = cfp[q * NT + c];
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        uint32_t m = mt[q * NT + i];
+        if (LOG2 == 2) { const uint32_t md = c_res.dst[q * 4 + i]; m = d_sel_u(dstmask, md, m); }   /* both scalar loads, per-lane select */
+        acc[i] = d_dot2(v, m, acc[i]);
       }
-      res[k] = (sum + rnd2) >> postShift;
     }
-  } else {
-    /* transform skip / bypass, optional RDPCM (fallback-dct.cc:81-91, 161-225) */
+#pragma unroll
+    for (int i = 0; i < NT; i++) g16[(i * GP) * 2 + c] = (int16_t)d_clip3(-32768, 32767, acc[i] >> 7);
+    wave_sync();
+    /* row pass: r[y][i] = (sum_j M[j][i] * g[y][j] + rnd) >> (20-bd), not clipped; lane = (row y, block) */
+    const int postShift = 20 - bd;
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] = 1 << (postShift - 1);
+    const int q2 = __builtin_amdgcn_readfirstlane((maxcol >> 1) + 1);
+    for (int q = 0; q < q2; q++) {
+      const uint32_t v = gp[c * GP + q];
+#pragma unroll
+      for (int i = 0; i < NT; i++) {
+        uint32_t m = mt[q * NT + i];
+        if (LOG2 == 2) { const uint32_t md = c_res.dst[q * 4 + i]; m = d_sel_u(dstmask, md, m); }   /* both scalar loads, per-lane select */
+        acc[i] = d_dot2(v, m, acc[i]);
+      }
+    }
+    if (is_tr) {
+#pragma unroll
+      for (int i = 0; i < NT; i++) res[i] = acc[i] >> postShift;
+    }
+    wave_sync();   /* gp/cfp are reused below (rr) only after everybody has read them */
+  }
+  if (any_other) {
+    /* transform skip / bypass, optional RDPCM (fallback-dct.cc:81-91, 161-225); rare */
     const bool skip = rb.kind == M355_RK_SKIP;
     const int bdShift2 = 20 - bd, tsShift = 5 + LOG2, rnd = skip ? (1 << (bdShift2 - 1)) : 0;
+    int col[NT];    /* column c of the block */
 #pragma unroll
-    for (int k = 0; k < S; k++) {
-      const int o = sl + G * k;
-      int c = cf[o];
-      if (skip) c = ((int)((unsigned)c << tsShift) + rnd) >> bdShift2;
-      rr[o] = c;
+    for (int j = 0; j < NT; j++) {
+      int v = cf16[((j >> 1) * NT + c) * 2 + (j & 1)];
+      if (skip) v = ((int)((unsigned)v << tsShift) + rnd) >> bdShift2;
+      col[j] = v;
+    }
+    wave_sync();   /* all reads of cf16 done before rr (same storage) is written */
+    if (!is_tr) {
+      if (rb.flags & M355_RBF_RDPCM_V) {
+#pragma unroll
+        for (int j = 1; j < NT; j++) col[j] += col[j - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < NT; j++) rr[j * NT + c] = col[j];
     }
     wave_sync();
-    if (rb.flags & (M355_RBF_RDPCM_V | M355_RBF_RDPCM_H)) {
-      if (sl < NT) {
-        int sum = 0;
-        if (rb.flags & M355_RBF_RDPCM_V) for (int y = 0; y < NT; y++) { sum += rr[y * NT + sl]; rr[y * NT + sl] = sum; }
-        else for (int x = 0; x < NT; x++) { sum += rr[sl * NT + x]; rr[sl * NT + x] = sum; }
-      }
-      wave_sync();
-    }
+    if (!is_tr) {
 #pragma unroll
-    for (int k = 0; k < S; k++) res[k] = rr[sl + G * k];
+      for (int i = 0; i < NT; i++) res[i] = rr[c * NT + i];   /* row c */
+      if (rb.flags & M355_RBF_RDPCM_H) {
+#pragma unroll
+        for (int i = 1; i < NT; i++) res[i] += res[i - 1];
+      }
+    }
   }
 
   if (!active) return;
+  const int y = c;
   if (rb.flags & M355_RBF_DEFERRED) {
-    int16_t* out = p.resbuf + rb.res_ofs;
+    int16_t* out = p.resbuf + rb.res_ofs + y * NT;
 #pragma unroll
-    for (int k = 0; k < S; k++) out[sl + G * k] = (int16_t)d_clip3(-32768, 32767, res[k]);
+    for (int i = 0; i < NT; i += 2) *(uint32_t*)(out + i) = res_pack(d_clip3(-32768, 32767, res[i]), d_clip3(-32768, 32767, res[i + 1]));
   } else {
-    PIX* d = (PIX*)p.plane[rb.cidx];
-    const int stride = p.stride[rb.cidx];
+    PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + y) * p.stride[rb.cidx] + rb.x;
+    if (sizeof(PIX) == 2) {
 #pragma unroll
-    for (int k = 0; k < S; k++) {
-      const int o = sl + G * k, x = o & (NT - 1), y = o >> LOG2;
-      PIX* q = d + (rb.y + y) * stride + rb.x + x;
-      *q = (PIX)d_clip_bd((int)*q + res[k], bd);
+      for (int i = 0; i < NT; i += 2) {
+        const uint32_t w = *(const uint32_t*)(d + i);
+        *(uint32_t*)(d + i) = (uint32_t)d_clip_bd((int)(w & 0xFFFFu) + res[i], bd) | ((uint32_t)d_clip_bd((int)(w >> 16) + res[i + 1], bd) << 16);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; i += 4) {
+        const uint32_t w = *(const uint32_t*)(d + i);
+        *(uint32_t*)(d + i) = (uint32_t)d_clip_bd((int)(w & 0xFFu) + res[i], bd) | ((uint32_t)d_clip_bd((int)((w >> 8) & 0xFFu) + res[i + 1], bd) << 8) |
+                              ((uint32_t)d_clip_bd((int)((w >> 16) & 0xFFu) + res[i + 2], bd) << 16) | ((uint32_t)d_clip_bd((int)(w >> 24) + res[i + 3], bd) << 24);
+      }
     }
   }
 }
 
+/* groups of 32x32 blocks first (longest), then 16x16, 8x8, 4x4: ng5/ng4/ng3 = group counts of the larger sizes */
 template <class PIX>
-static void launch_sizes(const DevPic& p, hipStream_t st)
+__global__ void __launch_bounds__(256) k_residual(DevPic p, int ng5, int ng4, int ng3)
 {
-  int base = 0;
-  if (p.rb_count[0]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<2, PIX>), dim3((p.rb_count[0] + 15) / 16), dim3(256), 0, st, p, base, p.rb_count[0]);
-  base += p.rb_count[0];
-  if (p.rb_count[1]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<3, PIX>), dim3((p.rb_count[1] + 3) / 4), dim3(256), 0, st, p, base, p.rb_count[1]);
-  base += p.rb_count[1];
-  if (p.rb_count[2]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<4, PIX>), dim3((p.rb_count[2] + 3) / 4), dim3(256), 0, st, p, base, p.rb_count[2]);
-  base += p.rb_count[2];
-  if (p.rb_count[3]) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<5, PIX>), dim3((p.rb_count[3] + 3) / 4), dim3(256), 0, st, p, base, p.rb_count[3]);
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[RES_LDS_DWORDS];
+  const int g = blockIdx.x;
+  const int base3 = p.rb_count[0], base4 = base3 + p.rb_count[1], base5 = base4 + p.rb_count[2];
+  if (g < ng5) d_residual_group<5, PIX>(p, base5, p.rb_count[3], g, s_buf);
+  else if (g < ng5 + ng4) d_residual_group<4, PIX>(p, base4, p.rb_count[2], g - ng5, s_buf);
+  else if (g < ng5 + ng4 + ng3) d_residual_group<3, PIX>(p, base3, p.rb_count[1], g - ng5 - ng4, s_buf);
+  else d_residual_group<2, PIX>(p, 0, p.rb_count[0], g - ng5 - ng4 - ng3, s_buf);
 }
 
 void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st)
 {
-  if (hbd) launch_sizes<uint16_t>(p, st);
-  else launch_sizes<uint8_t>(p, st);
+  /* blocks per workgroup: 4 waves * 64/nT */
+  const int ng2 = (p.rb_count[0] + 63) / 64, ng3 = (p.rb_count[1] + 31) / 32, ng4 = (p.rb_count[2] + 15) / 16, ng5 = (p.rb_count[3] + 7) / 8;
+  const int n = ng2 + ng3 + ng4 + ng5;
+  if (!n) return;
+  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint16_t>), dim3(n), dim3(256), 0, st, p, ng5, ng4, ng3);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint8_t>), dim3(n), dim3(256), 0, st, p, ng5, ng4, ng3);
 }
