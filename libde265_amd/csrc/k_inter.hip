@@ -476,6 +476,12 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
   const int strip = (job >> 25) & 15, rblk = job >> 29;
   const int x0 = pb.x + 4 * strip, y0 = pb.y + 8 * rblk;
   const int rows = min(8, pb.h - 8 * rblk);          /* 4 or 8 */
+  /* PB index plane for the deblocking filter's motion comparison (pb_info): this job's two 4x4 units */
+  {
+    uint32_t* po = p.pb_of + (size_t)(y0 >> 2) * p.w4 + (x0 >> 2);
+    po[0] = (job & 0x1FFFFFFu) + 1;
+    if (rows > 4) po[p.w4] = (job & 0x1FFFFFFu) + 1;
+  }
   const bool mc0 = pb.flags & M355_PBF_MC_L0, mc1 = pb.flags & M355_PBF_MC_L1;
   const bool bi = mc0 && mc1;
   const int npass = bi ? 2 : 1;

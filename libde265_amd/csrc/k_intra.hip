@@ -91,21 +91,6 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
    * door was finished by the preceding kernels (stream order), so sparse intra CUs in inter
    * pictures decode fully in parallel and only genuinely chained CTBs form a wavefront. ---- */
   const uint8_t dep = p.ctb_dep[ctb];
-  if (threadIdx.x == 0 && (dep & 15)) {
-    const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
-    for (int n = 0; n < 4; n++) {
-      const int nx = ctbX + dx[n], ny = ctbY + dy[n];
-      if (nx < 0 || ny < 0 || nx >= p.ctbW) continue;
-      const int nb = ny * p.ctbW + nx;
-      if (!((dep >> n) & 1)) continue;         /* that neighbour's intra output is never read here */
-      unsigned spins = 0;
-      while (__hip_atomic_load(&p.ctb_done[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > SPIN_LIMIT) { atomicExch(p.timeout, 1u); break; }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
   /* 3x3 CTB neighbourhood facts, once per CTB: every availability test of intrapred.h:486-508 / :534-633
      (picture, slice, tile, z-scan order across CTBs) becomes an LDS lookup instead of dependent global loads */
   if (threadIdx.x >= 64 && threadIdx.x < 73) {
@@ -118,24 +103,25 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
     }
     s_nts[i] = ts; s_nsame[i] = same;
   }
-  __syncthreads();
 
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
-  if (c < nc) {
-    const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
-    const int SubW = 1 << csw, SubH = 1 << csh;
-    const int cw = (1 << l2c) >> csw, ch = (1 << l2c) >> csh;
-    const int x0c = (ctbX << l2c) >> csw, y0c = (ctbY << l2c) >> csh;
-    const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
-    PIX* plane = (PIX*)p.plane[c];
-    const int stride = p.stride[c], pw = p.pw[c], ph = p.ph[c];
-    uint16_t* top = s_top[c];
-    uint16_t* body = s_body[c];
-    uint16_t* raw = s_raw[c];
-    uint16_t* pp_ = s_p[c];
-    uint16_t* pf = s_f[c];
-    int* ref = s_ref[c] + 32;
+  const bool comp = c < nc;
+  const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
+  const int SubW = 1 << csw, SubH = 1 << csh;
+  const int cw = (1 << l2c) >> csw, ch = (1 << l2c) >> csh;
+  const int x0c = (ctbX << l2c) >> csw, y0c = (ctbY << l2c) >> csh;
+  const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+  const int cs = comp ? c : 0;
+  PIX* plane = (PIX*)p.plane[cs];
+  const int stride = p.stride[cs], pw = p.pw[cs], ph = p.ph[cs];
+  uint16_t* top = s_top[cs];
+  uint16_t* body = s_body[cs];
+  uint16_t* raw = s_raw[cs];
+  uint16_t* pp_ = s_p[cs];
+  uint16_t* pf = s_f[cs];
+  int* ref = s_ref[cs] + 32;
 
+  if (comp) {
     /* ---- stage the CTB and its halo in LDS: 8-sample vectors, all loads of a lane in flight at once ---- */
     {
       const int l2v = (l2c - csw) - 3;                       /* log2(vectors per row); cw >= 8 */
@@ -155,6 +141,28 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
         }
       }
     }
+  }
+
+  /* ---- only now wait for the neighbour CTBs: everything above (own samples, finished by the preceding
+     kernels) overlapped with their work; what follows — the halo — is what they produce ---- */
+  if (threadIdx.x == 0 && (dep & 15)) {
+    const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
+    for (int n = 0; n < 4; n++) {
+      const int nx = ctbX + dx[n], ny = ctbY + dy[n];
+      if (nx < 0 || ny < 0 || nx >= p.ctbW) continue;
+      const int nb = ny * p.ctbW + nx;
+      if (!((dep >> n) & 1)) continue;         /* that neighbour's intra output is never read here */
+      unsigned spins = 0;
+      while (__hip_atomic_load(&p.ctb_done[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > SPIN_LIMIT) { atomicExch(p.timeout, 1u); break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+
+  if (comp) {
     if (x0c > 0)
       for (int y = lane; y < ch; y += 64)
         if (y0c + y < ph) body[y * BODY_PITCH + BODY_X0 - 1] = plane[(size_t)(y0c + y) * stride + x0c - 1];
@@ -193,7 +201,9 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
       if (ib.flags & M355_IBF_PCM) { /* raw block */
         for (int o = lane; o < nT * nT; o += 64) {
           const int y = o >> ib.log2_size, x = o & (nT - 1);
-          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = p.pcm[ib.res_ofs + o];
+          const uint16_t v = p.pcm[ib.res_ofs + o];
+          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = v;
+          plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;
         }
         wave_sync();
         continue;
@@ -363,7 +373,8 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
           }
         }
         if (has_res) v = d_clip_bd(v + rv[q], bd);
-        body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;
+        body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders */
+        plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;                /* the picture: only intra samples are (re)written */
       }
       wave_sync();
     }   /* records of this component */
@@ -371,25 +382,6 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
 #undef BRD
 #undef SAMPLE
 
-    /* ---- write the CTB back (same vector mapping) ---- */
-    {
-      const int l2v = (l2c - csw) - 3;
-      const int nvec = ch << l2v;
-      for (int idx = lane; idx < nvec; idx += 64) {
-        const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
-        if (x0c + xv < pw && y0c + y < ph) {
-          const uint4 v = *(const uint4*)(body + y * BODY_PITCH + BODY_X0 + xv);
-          PIX* dstp = plane + (size_t)(y0c + y) * stride + x0c + xv;
-          if (sizeof(PIX) == 2) *(uint4*)dstp = v;
-          else {
-            uint2 b;
-            b.x = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y << 8) & 0xFF000000u);
-            b.y = (v.z & 0xFFu) | ((v.z >> 8) & 0xFF00u) | ((v.w & 0xFFu) << 16) | ((v.w << 8) & 0xFF000000u);
-            *(uint2*)dstp = b;
-          }
-        }
-      }
-    }
   }
 
   /* ---- publish (guideline 16: stores -> barrier -> one-lane agent release -> drain -> flag) ---- */

@@ -130,11 +130,35 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
     if (lane == 63 && tot) base[k] = atomicAdd(p.job_count + k, (uint32_t)tot);
     base[k] = __shfl(base[k], 63, 64);
   }
-  if (!active) return;
-  uint32_t o = cls == 0 ? base[0] + (uint32_t)(incl[0] - njobs)
-             : (cls == 1 ? (uint32_t)p.n_jobs_uni + base[1] + (uint32_t)(incl[1] - njobs) : (uint32_t)p.n_jobs_main + base[2] + (uint32_t)(incl[2] - njobs));
-  for (int r = 0; r < nr; r++)
-    for (int s = 0; s < ns; s++) p.jobs[o++] = (uint32_t)i | ((uint32_t)s << 25) | ((uint32_t)r << 29);
+  /* emit the wave's jobs cooperatively: slot t of the wave's total belongs to the PB found by a binary
+     search over the wave's exclusive scan (shuffles), so a 64x64 PB (128 jobs) costs the wave two
+     iterations instead of stalling 63 lanes for 128 */
+  int incl_all = njobs;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl_all, (unsigned)d, 64); if (lane >= d) incl_all += t; }
+  const int total = __shfl(incl_all, 63, 64);
+  const int excl_all = incl_all - njobs;
+  const uint32_t dst0 = cls == 0 ? base[0] + (uint32_t)(incl[0] - njobs)
+                      : (cls == 1 ? (uint32_t)p.n_jobs_uni + base[1] + (uint32_t)(incl[1] - njobs) : (uint32_t)p.n_jobs_main + base[2] + (uint32_t)(incl[2] - njobs));
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int t = t0 + lane;
+    int k = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+      const int cand = k + step;
+      const int e = __shfl(excl_all, cand & 63, 64);
+      if (cand < 64 && e <= t) k = cand;
+    }
+    const int local = t - __shfl(excl_all, k, 64);
+    const int ns_k = __shfl(ns, k, 64);
+    const uint32_t dst = __shfl(dst0, k, 64) + (uint32_t)local;
+    const uint32_t pbi = (uint32_t)__shfl(i, k, 64);
+    if (t < total) {
+      const int r = local / ns_k, s = local - r * ns_k;
+      p.jobs[dst] = pbi | ((uint32_t)s << 25) | ((uint32_t)r << 29);
+    }
+  }
+  if (!active || !p.fill_pb_of_in_meta) return;
   for (int y = pb.y >> 2; y < ((pb.y + pb.h) >> 2) && y < p.h4; y++)
     for (int x = pb.x >> 2; x < ((pb.x + pb.w) >> 2) && x < p.w4; x++) p.pb_of[y * p.w4 + x] = (uint32_t)i + 1;
 }
@@ -175,10 +199,9 @@ __global__ void __launch_bounds__(256) k_meta_sao(DevPic p)
 
 void m355_launch_meta(const DevPic& p, hipStream_t st)
 {
-  hipMemsetAsync(p.cb_cu, 0, (size_t)p.wcb * p.hcb * 4, st);
-  hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4, st);
-  hipMemsetAsync(p.edge_pb, 0, (size_t)p.w4 * p.h4, st);
-  hipMemsetAsync(p.pb_of, 0, (size_t)p.w4 * p.h4 * 4, st);
+  /* edge_tu, edge_pb (sparse writers) and cb_cu (robustness against uncovered areas) live in ONE allocation: one
+     fill.  pb_of needs none: it is only read where both sides are inter-coded, i.e. covered by a PB. */
+  hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4 * 2 + (size_t)p.wcb * p.hcb * 4 + 64, st);
   hipMemsetAsync(p.job_count, 0, 12, st);
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);

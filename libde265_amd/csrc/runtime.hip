@@ -88,8 +88,8 @@ struct m355_ctx {
   Resident transient;
   Frame work;                  /* pre-SAO working planes */
   /* scratch */
-  uint32_t *cb_cu = nullptr, *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
-  uint8_t *edge_tu = nullptr, *edge_pb = nullptr, *cuf = nullptr;
+  uint32_t *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
+  uint8_t *edge_tu = nullptr, *cuf = nullptr;   /* edge_tu also holds edge_pb and cb_cu (one allocation) */
   int16_t* resbuf = nullptr;
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
@@ -161,7 +161,7 @@ void m355_destroy(m355_ctx* c)
   if (c->work.used) frame_free(c->work);
   for (auto& r : c->resident) if (r.used) resident_free(r);
   resident_free(c->transient);
-  void* bufs[] = {c->cb_cu, c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->edge_pb, c->cuf, c->resbuf, c->jobs, c->sao_nb};
+  void* bufs[] = {c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->cuf, c->resbuf, c->jobs, c->sao_nb};
   for (void* b : bufs) if (b) hipFree(b);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   hipStreamDestroy(c->stream);
@@ -525,16 +525,12 @@ static int decode(m355_ctx* c, Resident& r)
   d.refs = r.refs_dev;
   /* scratch */
   int rc;
-  if ((rc = grow(&c->cb_cu, &c->cap_cb, (size_t)d.wcb * d.hcb, c->stream, false))) return rc;
   {
-    size_t cap = c->cap_u4;
-    if ((size_t)d.w4 * d.h4 > cap) {
-      size_t c1 = cap, c2 = cap, c3 = cap;
-      if ((rc = grow(&c->pb_of, &c1, (size_t)d.w4 * d.h4, c->stream, false))) return rc;
-      if ((rc = grow(&c->edge_tu, &c2, (size_t)d.w4 * d.h4, c->stream, false))) return rc;
-      if ((rc = grow(&c->edge_pb, &c3, (size_t)d.w4 * d.h4, c->stream, false))) return rc;
-      c->cap_u4 = c1 < c2 ? (c1 < c3 ? c1 : c3) : (c2 < c3 ? c2 : c3);
-    }
+    /* edge_tu | edge_pb | cb_cu in one allocation (one memset per picture, k_meta.hip); pb_of separate */
+    const size_t u4 = (size_t)d.w4 * d.h4, ncb = (size_t)d.wcb * d.hcb;
+    const size_t need = ((2 * u4 + 63) & ~(size_t)63) + ncb * 4 + 64;
+    if ((rc = grow(&c->edge_tu, &c->cap_u4, need, c->stream, false))) return rc;
+    if ((rc = grow(&c->pb_of, &c->cap_cb, u4, c->stream, true))) return rc;
   }
   if ((rc = grow(&c->ctb_done, &c->cap_ctb, (size_t)d.nCtb, c->stream, true))) return rc;
   if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + 1, c->stream, false))) return rc;
@@ -558,7 +554,10 @@ static int decode(m355_ctx* c, Resident& r)
     d.plane[cc] = target->plane[cc]; d.stride[cc] = target->stride[cc];
     d.out_plane[cc] = dst->plane[cc]; d.out_stride[cc] = dst->stride[cc];
   }
-  d.cb_cu = c->cb_cu; d.cuf = c->cuf; d.edge_tu = c->edge_tu; d.edge_pb = c->edge_pb; d.pb_of = c->pb_of;
+  d.edge_tu = c->edge_tu; d.edge_pb = c->edge_tu + (size_t)d.w4 * d.h4;
+  d.cb_cu = (uint32_t*)(c->edge_tu + (((size_t)2 * d.w4 * d.h4 + 63) & ~(size_t)63));
+  d.cuf = c->cuf; d.pb_of = c->pb_of;
+  d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && pp.chroma_format_idc <= 1) ? 0 : 1;   /* else k_inter_jobs writes it */
   d.jobs = c->jobs; d.job_count = c->ticket + 4; d.sao_nb = c->sao_nb;
   d.resbuf = c->resbuf; d.ctb_done = c->ctb_done; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
