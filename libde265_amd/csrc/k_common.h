@@ -62,7 +62,7 @@ struct DevPic {
   int16_t* resbuf;
   uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
-  uint32_t* job_count;              /* device cursor used while the job list is built */
+  const uint32_t* job_base;         /* [256-PB chunk][3]: first job index of the chunk per range (uni, bi, edge), from the host's upload pass */
   int fill_pb_of_in_meta;           /* 1: k_meta_pb fills pb_of (inter stage off); 0: k_inter_jobs does, two units per job */
   int n_jobs;                       /* sum over PBs of (w/4) * ceil(h/8), computed at upload */
   int n_jobs_uni, n_jobs_main;      /* jobs [0, n_jobs_uni): one list; [n_jobs_uni, n_jobs_main): bi-predicted; [n_jobs_main, n_jobs): EDGE (clamped loads) */

@@ -101,8 +101,7 @@ __global__ void __launch_bounds__(256) k_meta_tu(DevPic p)
 
 /* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) and the job list of
  * k_inter_jobs: (w/4) x ceil(h/8) jobs per PB, row block major so consecutive jobs are horizontally
- * adjacent.  A wave reserves one contiguous range with a single atomic (wave-level exclusive scan),
- * so the list stays in PB order at 64-PB granularity = spatially coherent. */
+ * adjacent; three ranges (one-list, bi-predicted, picture-edge jobs), each in PB order. */
 __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,12 +122,19 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
 #pragma unroll
     for (int k = 0; k < 3; k++) { const int t = __shfl_up(incl[k], (unsigned)d, 64); if (lane >= d) incl[k] += t; }
   }
-  uint32_t base[3] = {0, 0, 0};
+  /* first job of this wave per range = the chunk's base (prefix sums computed by the host while it
+     validates the PB list — no atomics, and the job list is in PB order: deterministic and spatially
+     coherent) + the totals of the workgroup's earlier waves */
+  __shared__ int s_wtot[4][3];
+  const int wave = threadIdx.x >> 6;
+  if (lane == 63) { s_wtot[wave][0] = incl[0]; s_wtot[wave][1] = incl[1]; s_wtot[wave][2] = incl[2]; }
+  __syncthreads();
+  uint32_t base[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const int tot = __shfl(incl[k], 63, 64);
-    if (lane == 63 && tot) base[k] = atomicAdd(p.job_count + k, (uint32_t)tot);
-    base[k] = __shfl(base[k], 63, 64);
+    uint32_t bsum = p.job_base[blockIdx.x * 3 + k];
+    for (int w = 0; w < wave; w++) bsum += (uint32_t)s_wtot[w][k];
+    base[k] = bsum;
   }
   /* emit the wave's jobs cooperatively: slot t of the wave's total belongs to the PB found by a binary
      search over the wave's exclusive scan (shuffles), so a 64x64 PB (128 jobs) costs the wave two
@@ -139,7 +145,7 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   const int total = __shfl(incl_all, 63, 64);
   const int excl_all = incl_all - njobs;
   const uint32_t dst0 = cls == 0 ? base[0] + (uint32_t)(incl[0] - njobs)
-                      : (cls == 1 ? (uint32_t)p.n_jobs_uni + base[1] + (uint32_t)(incl[1] - njobs) : (uint32_t)p.n_jobs_main + base[2] + (uint32_t)(incl[2] - njobs));
+                      : (cls == 1 ? base[1] + (uint32_t)(incl[1] - njobs) : base[2] + (uint32_t)(incl[2] - njobs));
   for (int t0 = 0; t0 < total; t0 += 64) {
     const int t = t0 + lane;
     int k = 0;
@@ -202,7 +208,6 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
   /* edge_tu, edge_pb (sparse writers) and cb_cu (robustness against uncovered areas) live in ONE allocation: one
      fill.  pb_of needs none: it is only read where both sides are inter-coded, i.e. covered by a PB. */
   hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4 * 2 + (size_t)p.wcb * p.hcb * 4 + 64, st);
-  hipMemsetAsync(p.job_count, 0, 12, st);
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
   if (p.pp.flags & M355_PF_SAO_ENABLED) hipLaunchKernelGGL(k_meta_sao, dim3((p.nCtb * 3 + 255) / 256), dim3(256), 0, st, p);

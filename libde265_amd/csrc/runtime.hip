@@ -380,7 +380,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const int nCtb = ctbW * ctbH;
   const int nrb = pic->rb_count[0] + pic->rb_count[1] + pic->rb_count[2] + pic->rb_count[3];
   struct Seg { const void* src; size_t bytes; size_t ofs; };
-  Seg seg[20];
+  Seg seg[24];
   int ns = 0;
   size_t total = 0;
   auto add = [&](const void* src, size_t bytes) { seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].ofs = total; total += al(bytes ? bytes : 1); return ns++; };
@@ -400,6 +400,8 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const int i_ti = add(nullptr, 2 * (size_t)nCtb);   /* tile_id  */
   const int i_iw = add(nullptr, 4 * (size_t)nCtb);   /* intra_work */
   const int i_dp = add(nullptr, (size_t)nCtb);       /* ctb_dep */
+  const int n_chunks = (pic->n_pbs + 255) / 256;
+  const int i_jb = add(nullptr, 12 * (size_t)(n_chunks ? n_chunks : 1));   /* job_base */
 
   hipSetDevice(c->device);
   if (total > r.cap) {
@@ -435,17 +437,28 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     if (pic->ctbs[ts2rs[t]].ib_count) iw[nw++] = ts2rs[t];
   r.n_intra_work = nw;
   {
+    /* job counts per range (k_inter_jobs) and, per 256-PB chunk (= one k_meta_pb workgroup), the first job
+       index of the chunk in each range */
     long long nj = 0, nm = 0, nu = 0;
+    uint32_t* jb = (uint32_t*)(r.host + seg[i_jb].ofs);
+    std::vector<uint32_t> cnt((size_t)n_chunks * 3 + 3, 0);
     for (int i = 0; i < pic->n_pbs; i++) {
       const m355_pb& pb = pic->pbs[i];
       const long long n = (long long)(pb.w >> 2) * ((pb.h + 7) >> 3);
       nj += n;
+      int cls = 2;
       if (!m355_pb_is_edge(pb, pp.width, pp.chroma_format_idc)) {
         nm += n;
-        if (!((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1))) nu += n;
+        cls = 1;
+        if (!((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1))) { nu += n; cls = 0; }
       }
+      cnt[(size_t)(i >> 8) * 3 + cls] += (uint32_t)n;
     }
-    if (pic->n_pbs > 0x1FFFFFF || nj > 0x7FFFFFFF) return fail(M355_ERR_INVALID, "too many prediction blocks");
+    {
+      uint32_t run[3] = {0, (uint32_t)nu, (uint32_t)nm};
+      for (int k = 0; k < n_chunks; k++)
+        for (int q = 0; q < 3; q++) { jb[k * 3 + q] = run[q]; run[q] += cnt[(size_t)k * 3 + q]; }
+    }
     r.n_jobs = (int)nj; r.n_jobs_main = (int)nm; r.n_jobs_uni = (int)nu;
   }
   intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
@@ -482,6 +495,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.n_intra_work = nw;
   d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main; d.n_jobs_uni = r.n_jobs_uni;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
+  d.job_base = (const uint32_t*)(r.dev + seg[i_jb].ofs);
   r.used = true;
   return M355_OK;
 }
@@ -558,7 +572,7 @@ static int decode(m355_ctx* c, Resident& r)
   d.cb_cu = (uint32_t*)(c->edge_tu + (((size_t)2 * d.w4 * d.h4 + 63) & ~(size_t)63));
   d.cuf = c->cuf; d.pb_of = c->pb_of;
   d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && pp.chroma_format_idc <= 1) ? 0 : 1;   /* else k_inter_jobs writes it */
-  d.jobs = c->jobs; d.job_count = c->ticket + 4; d.sao_nb = c->sao_nb;
+  d.jobs = c->jobs; d.sao_nb = c->sao_nb;
   d.resbuf = c->resbuf; d.ctb_done = c->ctb_done; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;
