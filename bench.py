@@ -36,13 +36,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c5_8k10_8tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
+    ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):   # launched by torch.distributed.run
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -89,9 +91,13 @@ def main():
         dist.barrier()
     n_dec, avg_total_ms, stage_ms = ctx.timing_collect()
 
+    sharded = None
+    if dist and not args.no_tile_shard and (world > 1 or args.force_tile_shard):
+        sharded = tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist)
+
     if rank == 0:
         ab = synth.algorithmic_bytes(pic)
-        launches = {"inter": 1, "residual": sum(1 for c in pic.rb_count if c), "intra": 1, "deblock": 2, "sao": 3}
+        launches = {"inter": 1, "residual": 1, "intra": 1, "deblock": 2, "sao": 1}   # kernel launches per stage and picture
         dom = max(("inter", "residual", "intra", "deblock", "sao"), key=lambda s: stage_ms[s])
         per_launch_ms = stage_ms[dom] / max(1, launches[dom])
         achieved = (ab[dom] / max(1, launches[dom])) / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
@@ -108,15 +114,85 @@ def main():
             "pipeline_GBps": ab["total"] * args.steps / dt / 1e9,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "k_" + dom),
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": ab[dom] / max(1, launches[dom])},
         }
-        if not args.no_cpu_baseline:
+        if sharded is not None:
+            out["tile_sharded"] = sharded
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, synth, worklist)
         print(json.dumps(out))
     ctx.close()
     if dist:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot
+    run the profiler around itself): FETCH_SIZE x2 (the gfx950 correction of MI355X_MICROARCH.md, HBM section)
+    + WRITE_SIZE, both reported in KiB by rocprofv3; null when no profile of this workload is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t[workload][kernel]
+        return {"bytes_per_launch": e["fetch_bytes"] + e["write_bytes"], "fetch_bytes": e["fetch_bytes"], "write_bytes": e["write_bytes"],
+                "source": t[workload].get("_source")}
+    except Exception:
+        return None
+
+
+def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
+    """N>1 only: ONE picture of the workload sharded by tiles over all ranks — every rank
+    reconstructs its tiles, three halo exchanges feed deblocking / SAO across the tile boundaries, an all-gather
+    completes the picture on every GPU (it is the reference for later pictures).  Strong scaling of one picture,
+    reported next to the replica throughput; a failure here never costs the main line."""
+    try:
+        from libde265_amd import capi, shard
+        rank, world = dist.get_rank(), dist.get_world_size()
+        cfg = dict(synth.CONFIGS[args.workload])
+        pic = synth.picture(**cfg)                                 # the SAME picture on every rank
+        pp = pic.pp[0]
+        ctx = capi.Context(lib, local_rank)
+        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(), device="cuda:%d" % local_rank)
+        refs = []
+        for i in range(cfg["n_refs"]):
+            f = ctx.frame_create_for(pp)
+            ctx.frame_upload(f, synth.ref_planes(cfg["seed"] + 17 * i, int(pp["width"]), int(pp["height"]),
+                                                 int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
+            refs.append(f)
+        sp = shard.shard_picture(pic, rank, world)
+        sp.dst_frame = ctx.frame_create_for(pp)
+        sp.ref_frames = [refs[i] if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
+        h = dec.upload(sp)
+        for _ in range(args.warmup):
+            dec.decode(h)
+        ctx.wait()
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dec.decode(h)
+        ctx.wait()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # every rank must now hold the identical, complete picture: compare a checksum of the frames
+        planes = ctx.frame_download(sp.dst_frame)
+        import zlib
+        crc = zlib.crc32(b"".join(p.tobytes() for p in planes))
+        c = torch.tensor([crc, -crc], device="cuda", dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.MAX)
+        same = int(c[0].item()) == crc and int(c[1].item()) == -crc
+        xb = [int(ctx.shard_xbuf_bytes(h, k)) for k in range(4)]
+        dist.barrier()
+        ctx.close()
+        return {"value": args.steps * len(pic.ctbs) / dt, "unit": "CTB64/s", "ms_per_picture": 1e3 * dt / args.steps, "scaling": "strong",
+                "tiles_per_rank": (cfg["tile_cols"] * cfg["tile_rows"]) / world, "frames_identical_on_all_ranks": bool(same),
+                "exchange": {"halo_allreduce_bytes": xb[:3], "tile_allgather_bytes": xb[3]}}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
 def cpu_baseline(cfg, synth, worklist):

@@ -406,6 +406,43 @@ enum { M355_STAGE_INTER = 1, M355_STAGE_RESIDUAL = 2, M355_STAGE_INTRA = 4, M355
        M355_STAGE_SAO = 16, M355_STAGE_ALL = 31 };
 M355_API int m355_set_stages(m355_ctx* ctx, int stage_mask);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tile sharding across GPUs (one process per GPU).  Tiles are independent for
+ * prediction (intrapred.h:499-508 stops availability at tile borders) but coupled by the in-loop
+ * filters when pps.loop_filter_across_tiles_enabled_flag is set (deblock.cc:191-209, sao.cc:158-163)
+ * and by motion vectors that reach into other tiles of the reference pictures.  A sharded context
+ * owns the tiles t (tile-scan order) with  t * nranks / n_tiles == rank  and is given work lists
+ * that hold ONLY its tiles' CUs / TUs / PBs / residual / intra blocks (slices[] and ctbs[] stay
+ * picture-wide: the filters read the neighbours' slice flags).  One picture then runs as five phases
+ * with an exchange between them; the exchange buffers are CALLER-owned device memory (so the host
+ * layer can hand them to RCCL / torch.distributed), all 32-bit-word arrays in a canonical,
+ * rank-independent layout in which every element is produced by exactly one rank and is ZERO on all
+ * others — an integer SUM all-reduce (or any owner -> neighbour point-to-point copy) completes them:
+ *
+ *   phase 0  k_meta, k_inter, k_residual, k_intra on the own tiles;
+ *            pack X0 = border-unit metadata (QP_Y, PredMode, pcm/bypass, PBMotion, edge + cbf flags of
+ *            every 4x4 unit next to an interior tile boundary) + the 4-luma / 2-chroma-sample column
+ *            strips either side of every vertical tile boundary, PRE-deblock        -> exchange X0
+ *   phase 1  unpack X0 (foreign units appear as local metadata), deblock vertical edges (a boundary edge
+ *            is computed by both owners, each writes only its own side); pack X1 = row strips either
+ *            side of every horizontal tile boundary, post-vertical-pass             -> exchange X1
+ *   phase 2  unpack X1, deblock horizontal edges; pack X2 = column + row strips, deblocked (the
+ *            1-sample ring incl. corners that SAO edge classes read)                -> exchange X2
+ *   phase 3  unpack X2, SAO into the destination frame (own tiles); pack X3[rank] = own tiles of the
+ *            destination frame                                                      -> all-gather X3
+ *   phase 4  unpack X3: the destination frame is complete on every rank (reference for later pictures).
+ * ---------------------------------------------------------------------------------------------- */
+M355_API int m355_shard_set(m355_ctx* ctx, int rank, int nranks);      /* nranks == 0: sharding off (default) */
+/* rank owning tile t (tile-scan order) — pure function, the partition rule above */
+M355_API int m355_shard_owner_of_tile(int tile, int n_tiles, int nranks);
+/* byte size of exchange buffer `which` (0..3) for a resident picture; X3 = nranks equal slots
+ * (this rank's slot is [rank*bytes/nranks, (rank+1)*bytes/nranks)).  Multiples of 4. */
+M355_API int64_t m355_shard_xbuf_bytes(m355_ctx* ctx, int handle, int which);
+/* run one phase (0..4) of a resident picture; xbuf = the buffer the phase packs into (phases 0..3) —
+ * the buffer it unpacks is the one passed to the previous phase, which must still be valid and hold
+ * the exchanged contents.  Asynchronous on the context's stream (m355_stream()). */
+M355_API int m355_decode_phase(m355_ctx* ctx, int handle, int phase, void* xbuf);
+
 /* Per-stage device timing from HIP events recorded on the context's OWN stream around every decode
  * enqueued since m355_timing_reset(): averages in milliseconds, stage order
  * [meta, inter, residual, intra, deblock, sao]. m355_timing_collect() waits for the work. */

@@ -52,6 +52,11 @@ class Library:
         L.m355_timing_collect.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.m355_stream.argtypes = [vp]
         L.m355_stream.restype = vp
+        L.m355_shard_set.argtypes = [vp, i, i]
+        L.m355_shard_owner_of_tile.argtypes = [i, i, i]
+        L.m355_shard_xbuf_bytes.argtypes = [vp, i, i]
+        L.m355_shard_xbuf_bytes.restype = ctypes.c_int64
+        L.m355_decode_phase.argtypes = [vp, i, i, vp]
         L.init_acceleration_functions_mi355x.argtypes = [vp]
         L.m355_transform_add_batch.argtypes = [i, i, i, i, vp, ctypes.c_size_t, vp, ctypes.c_ssize_t, vp]
 
@@ -161,6 +166,19 @@ class Context:
 
     def stream(self):
         return self.L.lib.m355_stream(self.h)
+
+    # ---- tile sharding (see libde265_amd/shard.py for the multi-GPU driver) ----
+    def shard_set(self, rank, nranks):
+        self.L.check(self.L.lib.m355_shard_set(self.h, rank, nranks))
+
+    def shard_xbuf_bytes(self, handle, which):
+        n = self.L.lib.m355_shard_xbuf_bytes(self.h, handle, which)
+        if n < 0:
+            raise M355Error(-n, self.L.error())
+        return n
+
+    def decode_phase(self, handle, phase, xbuf_ptr):
+        self.L.check(self.L.lib.m355_decode_phase(self.h, handle, phase, xbuf_ptr))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -74,6 +74,22 @@ struct DevPic {
   const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks, decode order */
   int n_intra_work;
   const uint8_t* ctb_dep;           /* per CTB: bit n = wait for neighbour n (0 L, 1 TL, 2 T, 3 TR); bit 4 = somebody waits for us */
+  /* tile sharding (k_shard.hip): NULL = this context owns the whole picture */
+  const uint8_t* ctb_owner;         /* per CTB (raster): 1 = a tile of this rank */
+  int halo_cu_base, halo_pb_base;   /* first entry of the foreign border records appended to cus[] / pbs[] */
+};
+
+/* Canonical (rank-independent) layout of the tile-boundary exchange buffers (de265_mi355x.h, "Tile
+ * sharding"): per component the column strips of all interior vertical boundaries, then the row strips
+ * of all interior horizontal boundaries.  Column strip element (b, y, k): sample (xb_b - hw + k, y);
+ * row strip element (b, k, x): sample (x, yb_b - hh + k). */
+struct HaloLayout {
+  int n_vb, n_hb;                   /* interior vertical / horizontal tile boundaries */
+  int hw[3], hh[3];                 /* half strip width / height per component (0: component absent) */
+  int xb[3][M355_MAX_TILE_COLS];    /* boundary positions in component samples */
+  int yb[3][M355_MAX_TILE_ROWS];
+  int col_ofs[4], row_ofs[4];       /* first sample of each component's segment (entry 3 = total) */
+  int n_units;                      /* border 4x4 units: 2*n_vb*h4 + 2*n_hb*w4 */
 };
 
 /* Does any reference window of this PB cross the left/right picture border (so its jobs need the
@@ -102,7 +118,11 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st);   /* one direction (tile sharding) */
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st);
+/* tile sharding: `which` bit 0 = column strips, bit 1 = row strips; meta = border-unit records (16 B each) */
+void m355_launch_halo_pack(const DevPic& p, const HaloLayout& h, bool hbd, int which, void* samples, uint32_t* meta, hipStream_t st);
+void m355_launch_halo_unpack(const DevPic& p, const HaloLayout& h, bool hbd, int which, const void* samples, const uint32_t* meta, hipStream_t st);
 
 /* ---- device helpers ---- */
 /* lo <= hi at every call site: min(max()) lets hipcc emit v_med3_i32 / v_max+v_min instead of compare+select chains */

@@ -76,13 +76,19 @@ __global__ void __launch_bounds__(256) k_deblock(DevPic p)
   const int xDi = x4 << 2, yDi = y4 << 2;
   if ((VERTICAL && x4 == 0) || (!VERTICAL && y4 == 0)) return; /* picture border: never flagged */
   const int xp = VERTICAL ? xDi - 1 : xDi, yp = VERTICAL ? yDi : yDi - 1;
+  /* tile sharding: an edge is computed by the owner(s) of its two sides, each writes only its own side */
+  bool ownP = true, ownQ = true;
+  if (p.ctb_owner) {
+    ownQ = p.ctb_owner[d_ctb_of(p, xDi, yDi)] != 0; ownP = p.ctb_owner[d_ctb_of(p, xp, yp)] != 0;
+    if (!ownP && !ownQ) return;
+  }
   const CuInfo Q = d_cu_info(p, xDi, yDi), P = d_cu_info(p, xp, yp);
   const int bS = d_boundary_strength(p, x4, y4, VERTICAL, P, Q);
   if (bS == 0) return;
 
   const m355_slice sh = d_slice_at(p, xDi, yDi);
   const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
-  const bool filterP = !((plf && P.pcm) || P.bypass), filterQ = !((plf && Q.pcm) || Q.bypass);
+  const bool filterP = ownP && !((plf && P.pcm) || P.bypass), filterQ = ownQ && !((plf && Q.pcm) || Q.bypass);
   const int qP_L = (Q.qp + P.qp + 1) >> 1;
 
   /* ---- luma (deblock.cc:480-601, fallback-deblk.h:33-100) ---- */
@@ -171,20 +177,25 @@ __global__ void __launch_bounds__(256) k_deblock(DevPic p)
 }
 
 template <class PIX>
-static void launch_both(const DevPic& p, hipStream_t st)
+static void launch_pass(const DevPic& p, bool vertical, hipStream_t st)
 {
-  {
+  if (vertical) {
     const int nx = (p.w4 + 1) / 2, ny = p.h4;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deblock<PIX, true>), dim3((nx + 63) / 64, (ny + 3) / 4), dim3(256), 0, st, p);
-  }
-  {
+  } else {
     const int nx = p.w4, ny = (p.h4 + 1) / 2;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deblock<PIX, false>), dim3((nx + 63) / 64, (ny + 3) / 4), dim3(256), 0, st, p);
   }
 }
 
+void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st)
+{
+  if (hbd) launch_pass<uint16_t>(p, vertical, st);
+  else launch_pass<uint8_t>(p, vertical, st);
+}
+
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st)
 {
-  if (hbd) launch_both<uint16_t>(p, st);
-  else launch_both<uint8_t>(p, st);
+  m355_launch_deblock_pass(p, hbd, true, st);
+  m355_launch_deblock_pass(p, hbd, false, st);
 }

@@ -94,6 +94,9 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
   const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
   const int l2w = p.pp.log2_ctb_size - csw, l2h = p.pp.log2_ctb_size - csh;
   const int xCtb = (valid ? x0 : xt) >> l2w, yCtb = (valid ? y0 : yt) >> l2h;
+  /* tile sharding: only own CTBs are filtered / written; waves without any own sample leave at once */
+  const bool owned = !p.ctb_owner || p.ctb_owner[yCtb * p.ctbW + xCtb] != 0;
+  if (!__any(owned)) return;
   const m355_ctb ctb = p.ctbs[yCtb * p.ctbW + xCtb];
   const m355_slice csl = p.slices[ctb.slice_idx];
   /* this component's parameters, selected without indexing the record dynamically */
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
       nb[r][0] = l; nb[r][5] = rg;
     }
   }
-  if (!valid) return;
+  if (!valid || !owned) return;
 
   PIX res[4][4];
 #pragma unroll

@@ -48,13 +48,17 @@ static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
     f.stride[c] = pitch_bytes / f.bpp[c];
   }
 }
-static int frame_alloc(Frame& f)
+/* NOTE on memsets: hipMemset() on the null stream may return before the fill has run, and the context's
+ * stream is non-blocking (it does not order against the null stream) — a fill issued that way can land AFTER
+ * kernels launched later on the context's stream (seen with 8 contexts sharing one GPU).  Every fill is
+ * therefore enqueued on the context's own stream. */
+static int frame_alloc(Frame& f, hipStream_t st)
 {
   for (int c = 0; c < 3; c++) {
     if (!f.pw[c]) continue;
     const size_t bytes = (size_t)f.stride[c] * f.ph[c] * f.bpp[c] + 256;
     HIPCHK(hipMalloc(&f.plane[c], bytes));
-    HIPCHK(hipMemset(f.plane[c], 0, bytes)); /* planes are zero at allocation (image.cc:164) */
+    HIPCHK(hipMemsetAsync(f.plane[c], 0, bytes, st)); /* planes are zero at allocation (image.cc:164) */
   }
   f.used = true;
   return M355_OK;
@@ -78,6 +82,13 @@ struct Resident {
   bool refs_valid = false;
   int n_intra_work = 0;
   int n_jobs = 0, n_jobs_main = 0, n_jobs_uni = 0;   /* inter jobs (k_inter_jobs), from the PB geometry */
+  /* tile sharding (m355_decode_phase) */
+  bool sharded = false;
+  int shard_rank = 0, shard_n = 1;
+  HaloLayout halo;
+  DevPic live;                 /* the descriptor prepared by phase 0, reused by phases 1..4 */
+  bool live_sao = false, live_valid = false;
+  void* xprev = nullptr;       /* exchange buffer handed to the previous phase */
 };
 
 struct m355_ctx {
@@ -96,6 +107,7 @@ struct m355_ctx {
   size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
   uint32_t epoch = 0;
   int stages = M355_STAGE_ALL;
+  int shard_rank = 0, shard_n = 0;   /* shard_n == 0: sharding off */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
@@ -109,8 +121,63 @@ template <class T> static int grow(T** p, size_t* cap, size_t need, hipStream_t 
   *p = nullptr;
   const size_t n = need + need / 4 + 64;
   HIPCHK(hipMalloc(p, n * sizeof(T)));
-  if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), st));
   *cap = n;
+  return M355_OK;
+}
+
+struct TileRect { int x0, y0, x1, y1; };   /* luma samples */
+static std::vector<TileRect> rank_tiles(const m355_pic_params& pp, int rank, int nranks)
+{
+  std::vector<TileRect> v;
+  const int cs = 1 << pp.log2_ctb_size, n_tiles = pp.num_tile_cols * pp.num_tile_rows;
+  for (int ty = 0, t = 0; ty < pp.num_tile_rows; ty++)
+    for (int tx = 0; tx < pp.num_tile_cols; tx++, t++) {
+      if (m355_shard_owner_of_tile(t, n_tiles, nranks) != rank) continue;
+      TileRect r = {pp.col_bd[tx] * cs, pp.row_bd[ty] * cs, pp.col_bd[tx + 1] * cs, pp.row_bd[ty + 1] * cs};
+      if (r.x1 > pp.width) r.x1 = pp.width;
+      if (r.y1 > pp.height) r.y1 = pp.height;
+      v.push_back(r);
+    }
+  return v;
+}
+static size_t tiles_bytes(const m355_pic_params& pp, const std::vector<TileRect>& v)
+{
+  const int cf = pp.chroma_format_idc;
+  const int sw = (cf == 1 || cf == 2) ? 2 : 1, sh = cf == 1 ? 2 : 1;
+  const size_t bl = pp.bit_depth_luma <= 8 ? 1 : 2, bc = pp.bit_depth_chroma <= 8 ? 1 : 2;
+  size_t n = 0;
+  for (const TileRect& r : v) {
+    n += (size_t)(r.x1 - r.x0) * (r.y1 - r.y0) * bl;
+    if (cf) n += 2 * (size_t)((r.x1 - r.x0) / sw) * ((r.y1 - r.y0) / sh) * bc;
+  }
+  return (n + 255) & ~(size_t)255;
+}
+static size_t slot_bytes(const m355_pic_params& pp, int nranks)
+{
+  size_t m = 0;
+  for (int k = 0; k < nranks; k++) { const size_t b = tiles_bytes(pp, rank_tiles(pp, k, nranks)); if (b > m) m = b; }
+  return m;
+}
+/* copy the tiles of `rank` between the frame planes and its slot (to_slot) or back */
+static int copy_tiles(m355_ctx* c, const m355_pic_params& pp, Frame* f, int rank, int nranks, char* slot, bool to_slot)
+{
+  const int cf = pp.chroma_format_idc;
+  const int sw = (cf == 1 || cf == 2) ? 2 : 1, sh = cf == 1 ? 2 : 1;
+  size_t o = 0;
+  for (const TileRect& r : rank_tiles(pp, rank, nranks))
+    for (int cc = 0; cc < 3; cc++) {
+      if (cc && !cf) continue;
+      const int x = cc ? r.x0 / sw : r.x0, y = cc ? r.y0 / sh : r.y0;
+      const int w = cc ? (r.x1 - r.x0) / sw : r.x1 - r.x0, h = cc ? (r.y1 - r.y0) / sh : r.y1 - r.y0;
+      const size_t bpp = f->bpp[cc], pitch = (size_t)f->stride[cc] * bpp, wb = (size_t)w * bpp;
+      char* fp = (char*)f->plane[cc] + (size_t)y * pitch + (size_t)x * bpp;
+      if (w > 0 && h > 0) {
+        if (to_slot) HIPCHK(hipMemcpy2DAsync(slot + o, wb, fp, pitch, wb, h, hipMemcpyDeviceToDevice, c->stream));
+        else HIPCHK(hipMemcpy2DAsync(fp, pitch, slot + o, wb, wb, h, hipMemcpyDeviceToDevice, c->stream));
+      }
+      o += wb * h;
+    }
   return M355_OK;
 }
 
@@ -137,8 +204,9 @@ int m355_create(int device, m355_ctx** out)
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&c->ticket, 64));
   HIPCHK(hipMalloc(&c->timeout, 64));
-  HIPCHK(hipMemset(c->ticket, 0, 64));
-  HIPCHK(hipMemset(c->timeout, 0, 64));
+  HIPCHK(hipMemsetAsync(c->ticket, 0, 64, c->stream));
+  HIPCHK(hipMemsetAsync(c->timeout, 0, 64, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   *out = c;
   return M355_OK;
 }
@@ -183,7 +251,7 @@ int m355_frame_create(m355_ctx* c, int width, int height, int cf, int bdl, int b
   Frame& f = c->frames[idx];
   f = Frame();
   frame_geometry(f, width, height, cf, bdl, bdc);
-  int rc = frame_alloc(f);
+  int rc = frame_alloc(f, c->stream);
   if (rc) { frame_free(f); return -rc; }
   return idx;
 }
@@ -231,7 +299,7 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
     if (!f->pw[cc]) continue;
     const size_t n = (size_t)f->stride[cc] * f->ph[cc];
     const int v = cc ? vc : vl;
-    if (f->bpp[cc] == 1) HIPCHK(hipMemset(f->plane[cc], v, n));
+    if (f->bpp[cc] == 1) { HIPCHK(hipMemsetAsync(f->plane[cc], v, n, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     else {
       std::vector<uint16_t> tmp(n, (uint16_t)v);
       HIPCHK(hipMemcpy(f->plane[cc], tmp.data(), n * 2, hipMemcpyHostToDevice));
@@ -371,6 +439,30 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
+/* canonical exchange-buffer layout of a picture (k_common.h HaloLayout); depends on the picture parameters only */
+static void halo_layout(const m355_pic_params& pp, HaloLayout& h)
+{
+  memset(&h, 0, sizeof(h));
+  const int cf = pp.chroma_format_idc;
+  const int sw = (cf == 1 || cf == 2) ? 2 : 1, sh = cf == 1 ? 2 : 1;
+  const int cs = 1 << pp.log2_ctb_size;
+  h.n_vb = pp.num_tile_cols - 1; h.n_hb = pp.num_tile_rows - 1;
+  int col = 0, row = 0;
+  for (int c = 0; c < 3; c++) {
+    h.col_ofs[c] = col; h.row_ofs[c] = row;
+    if (c && cf == 0) continue;
+    const int pw = c ? pp.width / sw : pp.width, ph = c ? pp.height / sh : pp.height;
+    h.hw[c] = c ? 4 / sw : 4; h.hh[c] = c ? 4 / sh : 4;
+    for (int b = 0; b < h.n_vb; b++) h.xb[c][b] = (pp.col_bd[b + 1] * cs) / (c ? sw : 1);
+    for (int b = 0; b < h.n_hb; b++) h.yb[c][b] = (pp.row_bd[b + 1] * cs) / (c ? sh : 1);
+    col += h.n_vb * ph * 2 * h.hw[c];
+    row += h.n_hb * 2 * h.hh[c] * pw;
+  }
+  h.col_ofs[3] = col; h.row_ofs[3] = row;
+  const int w4 = (pp.width + 3) / 4, h4 = (pp.height + 3) / 4;
+  h.n_units = 2 * h.n_vb * h4 + 2 * h.n_hb * w4;
+}
+
 static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
 {
   int ctbW, ctbH;
@@ -383,12 +475,17 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   Seg seg[24];
   int ns = 0;
   size_t total = 0;
-  auto add = [&](const void* src, size_t bytes) { seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].ofs = total; total += al(bytes ? bytes : 1); return ns++; };
+  auto add = [&](const void* src, size_t bytes, size_t room = 0) { seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].ofs = total; total += al(bytes + room ? bytes + room : 1); return ns++; };
+  /* tile sharding: foreign border units are appended to cus[] / pbs[] by k_halo_unpack_meta */
+  const bool sharded = c->shard_n >= 1;
+  HaloLayout halo;
+  memset(&halo, 0, sizeof(halo));
+  if (sharded) halo_layout(pp, halo);
   const int i_sl = add(pic->slices, sizeof(m355_slice) * pic->n_slices);
   const int i_ct = add(pic->ctbs, sizeof(m355_ctb) * pic->n_ctbs);
-  const int i_cu = add(pic->cus, sizeof(m355_cu) * pic->n_cus);
+  const int i_cu = add(pic->cus, sizeof(m355_cu) * pic->n_cus, sizeof(m355_cu) * (size_t)halo.n_units);
   const int i_tu = add(pic->tus, sizeof(m355_tu) * pic->n_tus);
-  const int i_pb = add(pic->pbs, sizeof(m355_pb) * pic->n_pbs);
+  const int i_pb = add(pic->pbs, sizeof(m355_pb) * pic->n_pbs, sizeof(m355_pb) * (size_t)halo.n_units);
   const int i_wt = add(pic->wts, sizeof(m355_wt) * pic->n_wts);
   const int i_rb = add(pic->rbs, sizeof(m355_rb) * nrb);
   const int i_ib = add(pic->ibs, sizeof(m355_ib) * pic->n_ibs);
@@ -402,6 +499,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const int i_dp = add(nullptr, (size_t)nCtb);       /* ctb_dep */
   const int n_chunks = (pic->n_pbs + 255) / 256;
   const int i_jb = add(nullptr, 12 * (size_t)(n_chunks ? n_chunks : 1));   /* job_base */
+  const int i_ow = add(nullptr, sharded ? (size_t)nCtb : 0);               /* ctb_owner */
 
   hipSetDevice(c->device);
   if (total > r.cap) {
@@ -462,6 +560,18 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     r.n_jobs = (int)nj; r.n_jobs_main = (int)nm; r.n_jobs_uni = (int)nu;
   }
   intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
+  if (sharded) {
+    uint8_t* ow = (uint8_t*)(r.host + seg[i_ow].ofs);
+    const int n_tiles = pp.num_tile_cols * pp.num_tile_rows;
+    for (int i = 0; i < nCtb; i++) ow[i] = m355_shard_owner_of_tile(tile_id[i], n_tiles, c->shard_n) == c->shard_rank;
+    /* a sharded picture must hold only this rank's blocks (the lists drive the reconstruction kernels) */
+    for (int i = 0; i < pic->n_cus; i++)
+      if (!ow[(pic->cus[i].y >> pp.log2_ctb_size) * ctbW + (pic->cus[i].x >> pp.log2_ctb_size)])
+        return fail(M355_ERR_INVALID, "sharded picture: cu %d lies in a tile of another rank", i);
+    for (int i = 0; i < nCtb; i++)
+      if (!ow[i] && pic->ctbs[i].ib_count) return fail(M355_ERR_INVALID, "sharded picture: ctb %d of another rank has intra blocks", i);
+  }
+  r.sharded = sharded; r.shard_rank = c->shard_rank; r.shard_n = c->shard_n; r.halo = halo; r.live_valid = false; r.xprev = nullptr;
   r.bytes = total;
   HIPCHK(hipMemcpyAsync(r.dev, r.host, total, hipMemcpyHostToDevice, c->stream));
 
@@ -496,13 +606,16 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main; d.n_jobs_uni = r.n_jobs_uni;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
   d.job_base = (const uint32_t*)(r.dev + seg[i_jb].ofs);
+  d.ctb_owner = sharded ? (const uint8_t*)(r.dev + seg[i_ow].ofs) : nullptr;
+  d.halo_cu_base = pic->n_cus; d.halo_pb_base = pic->n_pbs;
   r.used = true;
   return M355_OK;
 }
 
 /* ----------------------------------------------------------------------- decode --------------- */
 
-static int decode(m355_ctx* c, Resident& r)
+/* frames, scratch and the device descriptor of one decode of `r` */
+static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
 {
   hipSetDevice(c->device);
   const m355_picture& pic = r.hdr;
@@ -511,7 +624,6 @@ static int decode(m355_ctx* c, Resident& r)
   if (!dst) return fail(M355_ERR_INVALID, "dst_frame %d is not a live frame", pic.dst_frame);
   if (dst->w != pp.width || dst->h != pp.height || dst->cf != pp.chroma_format_idc || dst->bdl != pp.bit_depth_luma || dst->bdc != pp.bit_depth_chroma)
     return fail(M355_ERR_INVALID, "dst frame geometry does not match the picture parameters");
-  const bool hbd = pp.bit_depth_luma > 8;
   DevPic d = r.dp;
   DevRef refs[M355_MAX_REF_FRAMES];
   memset(refs, 0, sizeof(refs));
@@ -547,7 +659,7 @@ static int decode(m355_ctx* c, Resident& r)
     if ((rc = grow(&c->pb_of, &c->cap_cb, u4, c->stream, true))) return rc;
   }
   if ((rc = grow(&c->ctb_done, &c->cap_ctb, (size_t)d.nCtb, c->stream, true))) return rc;
-  if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + 1, c->stream, false))) return rc;
+  if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + (size_t)r.halo.n_units + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->resbuf, &c->cap_res, (size_t)pic.res_len + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
   if ((rc = grow(&c->jobs, &c->cap_jobs, (size_t)r.n_jobs + 1, c->stream, false))) return rc;
@@ -559,7 +671,7 @@ static int decode(m355_ctx* c, Resident& r)
       HIPCHK(hipStreamSynchronize(c->stream));
       if (c->work.used) frame_free(c->work);
       frame_geometry(c->work, dst->w, dst->h, dst->cf, dst->bdl, dst->bdc);
-      if ((rc = frame_alloc(c->work))) return rc;
+      if ((rc = frame_alloc(c->work, c->stream))) return rc;
     }
     target = &c->work;
   }
@@ -576,7 +688,19 @@ static int decode(m355_ctx* c, Resident& r)
   d.resbuf = c->resbuf; d.ctb_done = c->ctb_done; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;
+  d_out = d; want_sao_out = want_sao;
+  return M355_OK;
+}
 
+static int decode(m355_ctx* c, Resident& r)
+{
+  if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
+  DevPic d;
+  bool want_sao;
+  int rc = prepare(c, r, d, want_sao);
+  if (rc) return rc;
+  const m355_pic_params& pp = r.hdr.pp;
+  const bool hbd = pp.bit_depth_luma > 8;
   hipStream_t st = c->stream;
   if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
   while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
@@ -602,6 +726,106 @@ static int decode(m355_ctx* c, Resident& r)
   return M355_OK;
 }
 
+/* ------------------------------------------------------------------ tile-sharded decode -------- */
+
+int m355_shard_owner_of_tile(int tile, int n_tiles, int nranks)
+{
+  if (nranks <= 1 || n_tiles <= 0) return 0;
+  return (int)(((long long)tile * nranks) / n_tiles);
+}
+
+int m355_shard_set(m355_ctx* c, int rank, int nranks)
+{
+  if (nranks == 0) { c->shard_rank = 0; c->shard_n = 0; return M355_OK; }
+  if (nranks < 0 || rank < 0 || rank >= nranks) return fail(M355_ERR_INVALID, "bad shard rank %d of %d", rank, nranks);
+  c->shard_rank = rank; c->shard_n = nranks;
+  return M355_OK;
+}
+
+static size_t halo_sample_bytes(const Resident& r, int which)
+{
+  const HaloLayout& h = r.halo;
+  const size_t n = ((which & 1) ? (size_t)h.col_ofs[3] : 0) + ((which & 2) ? (size_t)h.row_ofs[3] : 0);
+  const size_t b = n * (r.hdr.pp.bit_depth_luma <= 8 ? 1 : 2);
+  return (b + 3) & ~(size_t)3;
+}
+
+int64_t m355_shard_xbuf_bytes(m355_ctx* c, int h, int which)
+{
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded) return -(int64_t)fail(M355_ERR_INVALID, "not a sharded picture handle");
+  const Resident& r = c->resident[h];
+  switch (which) {
+    case 0: return (int64_t)((size_t)r.halo.n_units * 16 + halo_sample_bytes(r, 1));
+    case 1: return (int64_t)halo_sample_bytes(r, 2);
+    case 2: return (int64_t)halo_sample_bytes(r, 3);
+    case 3: return (int64_t)(slot_bytes(r.hdr.pp, r.shard_n) * (size_t)r.shard_n);
+    default: return -(int64_t)fail(M355_ERR_INVALID, "exchange buffer index %d", which);
+  }
+}
+
+int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
+{
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded) return fail(M355_ERR_INVALID, "not a sharded picture handle");
+  Resident& r = c->resident[h];
+  if (phase < 0 || phase > 4 || (phase < 4 && !xbuf)) return fail(M355_ERR_INVALID, "bad phase / buffer");
+  if (phase > 0 && !r.live_valid) return fail(M355_ERR_INVALID, "phase %d before phase 0", phase);
+  hipSetDevice(c->device);
+  hipStream_t st = c->stream;
+  const m355_pic_params& pp = r.hdr.pp;
+  const bool hbd = pp.bit_depth_luma > 8;
+  const size_t meta_bytes = (size_t)r.halo.n_units * 16;
+  if (phase == 0) {
+    int rc = prepare(c, r, r.live, r.live_sao);
+    if (rc) return rc;
+    r.live_valid = true;
+  }
+  const DevPic& d = r.live;
+  const bool deblock = (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED);
+  switch (phase) {
+    case 0:
+      m355_launch_meta(d, st);
+      if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
+      if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
+      if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
+      m355_launch_halo_pack(d, r.halo, hbd, 1, (char*)xbuf + meta_bytes, (uint32_t*)xbuf, st);
+      break;
+    case 1:
+      m355_launch_halo_unpack(d, r.halo, hbd, 1, (const char*)r.xprev + meta_bytes, (const uint32_t*)r.xprev, st);
+      if (deblock) m355_launch_deblock_pass(d, hbd, true, st);
+      m355_launch_halo_pack(d, r.halo, hbd, 2, xbuf, nullptr, st);
+      break;
+    case 2:
+      m355_launch_halo_unpack(d, r.halo, hbd, 2, r.xprev, nullptr, st);
+      if (deblock) m355_launch_deblock_pass(d, hbd, false, st);
+      m355_launch_halo_pack(d, r.halo, hbd, 3, xbuf, nullptr, st);
+      break;
+    case 3: {
+      m355_launch_halo_unpack(d, r.halo, hbd, 3, r.xprev, nullptr, st);
+      if (r.live_sao) m355_launch_sao(d, hbd, st);
+      Frame* dst = get_frame(c, r.hdr.dst_frame);
+      const size_t slot = slot_bytes(pp, r.shard_n);
+      int rc = copy_tiles(c, pp, dst, r.shard_rank, r.shard_n, (char*)xbuf + slot * (size_t)r.shard_rank, true);
+      if (rc) return rc;
+      break;
+    }
+    case 4: {
+      Frame* dst = get_frame(c, r.hdr.dst_frame);
+      const size_t slot = slot_bytes(pp, r.shard_n);
+      for (int k = 0; k < r.shard_n; k++) {
+        if (k == r.shard_rank) continue;
+        int rc = copy_tiles(c, pp, dst, k, r.shard_n, (char*)r.xprev + slot * (size_t)k, false);
+        if (rc) return rc;
+      }
+      r.live_valid = false;
+      break;
+    }
+  }
+  r.xprev = xbuf;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return M355_OK;
+}
+
 int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
 {
   int rc = upload(c, c->transient, pic);
@@ -616,7 +840,8 @@ int m355_wait(m355_ctx* c)
   uint32_t t = 0;
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
   if (t) {
-    hipMemset(c->timeout, 0, 4);
+    hipMemsetAsync(c->timeout, 0, 4, c->stream);
+    hipStreamSynchronize(c->stream);
     return fail(M355_ERR_TIMEOUT, "intra wavefront spin bound exceeded");
   }
   return M355_OK;

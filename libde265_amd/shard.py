@@ -1,0 +1,161 @@
+"""Tile-sharded decoding of one picture across GPUs — host side of SURVEY.md §8(e) over the C ABI
+(`m355_shard_set`, `m355_decode_phase`, include/de265_mi355x.h "Tile sharding").
+
+One process per GPU.  Rank r owns the tiles t (tile-scan order) with t*nranks//n_tiles == r, parses /
+receives only those tiles' work lists (`shard_picture` cuts a whole-picture list down to that, for tests
+and the benchmark; a real host parses just its tiles), and runs the five phases of a picture with an
+exchange after each of the first four:
+
+    X0  border-unit metadata + pre-deblock column strips   -> SUM all-reduce  (deblock.cc:191-209, :243-383)
+    X1  post-vertical-pass row strips                       -> SUM all-reduce  (deblock.cc:919-939)
+    X2  deblocked column + row strips (SAO ring)            -> SUM all-reduce  (sao.cc:83-88, :158-163)
+    X3  finished tiles of the destination frame             -> all-gather      (reference for later pictures)
+
+The buffers are torch tensors (device memory handed to RCCL through torch.distributed; CPU tensors when
+the kernel-logic emulator of the test tier is the library).  Every element of X0..X2 is produced by
+exactly one rank and zero elsewhere, so an integer SUM all-reduce completes them whatever the tile ->
+rank map is; traffic is a few hundred kB per picture, i.e. latency-bound on xGMI.  X3 is the real
+volume (one picture per reference picture, 1/nranks of it sent by each rank).
+"""
+import numpy as np
+
+from . import worklist
+
+
+def owner_of_tile(t, n_tiles, nranks):
+    """m355_shard_owner_of_tile: contiguous blocks of tiles in tile-scan order."""
+    return 0 if nranks <= 1 else (t * nranks) // n_tiles
+
+
+def ctb_owner_map(pp, nranks):
+    """rank owning each CTB (raster order) for picture parameters `pp` (PIC_PARAMS record)."""
+    cs = 1 << int(pp["log2_ctb_size"])
+    w, h = (int(pp["width"]) + cs - 1) // cs, (int(pp["height"]) + cs - 1) // cs
+    ntc, ntr = int(pp["num_tile_cols"]), int(pp["num_tile_rows"])
+    out = np.zeros((h, w), np.int32)
+    for ty in range(ntr):
+        for tx in range(ntc):
+            out[int(pp["row_bd"][ty]):int(pp["row_bd"][ty + 1]), int(pp["col_bd"][tx]):int(pp["col_bd"][tx + 1])] = \
+                owner_of_tile(ty * ntc + tx, ntc * ntr, nranks)
+    return out.reshape(-1), w
+
+
+def shard_picture(pic, rank, nranks):
+    """The part of a whole-picture work list that rank `rank` of `nranks` reconstructs: CUs, transform
+    leaves, PBs, residual and intra blocks of its tiles (with their coefficients); slices[], ctbs[] (SAO
+    parameters, slice indices), weights, PCM samples and the residual-buffer numbering stay picture-wide."""
+    pp = pic.pp[0]
+    owner, ctbw = ctb_owner_map(pp, nranks)
+    l2 = int(pp["log2_ctb_size"])
+    cf = int(pp["chroma_format_idc"])
+    sw = 2 if cf in (1, 2) else 1
+    sh = 2 if cf == 1 else 1
+
+    def mine(x, y, cidx=None):
+        x = x.astype(np.int64); y = y.astype(np.int64)
+        if cidx is not None:
+            x = np.where(cidx > 0, x * sw, x); y = np.where(cidx > 0, y * sh, y)
+        return owner[(y >> l2) * ctbw + (x >> l2)] == rank
+
+    out = worklist.Picture()
+    out.pp = pic.pp.copy()
+    out.dst_frame, out.ref_frames = pic.dst_frame, list(pic.ref_frames)
+    out.slices, out.wts, out.pcm = pic.slices.copy(), pic.wts.copy(), pic.pcm.copy()
+    out.scaling_factors, out.res_len, out.meta = pic.scaling_factors, pic.res_len, dict(pic.meta)
+    out.cus = pic.cus[mine(pic.cus["x"], pic.cus["y"])] if len(pic.cus) else pic.cus.copy()
+    out.tus = pic.tus[mine(pic.tus["x"], pic.tus["y"])] if len(pic.tus) else pic.tus.copy()
+    out.pbs = pic.pbs[mine(pic.pbs["x"], pic.pbs["y"])] if len(pic.pbs) else pic.pbs.copy()
+    # residual blocks: keep the size binning; compact the coefficient array
+    if len(pic.rbs):
+        keep = mine(pic.rbs["x"], pic.rbs["y"], pic.rbs["cidx"])
+        bins = np.repeat(np.arange(4), pic.rb_count)
+        out.rb_count = [int(np.count_nonzero(keep & (bins == s))) for s in range(4)]
+        rbs = pic.rbs[keep].copy()
+        n = rbs["ncoeff"].astype(np.int64)
+        new_ofs = np.concatenate([[0], np.cumsum(n)[:-1]]) if len(rbs) else np.zeros(0, np.int64)
+        idx = np.repeat(rbs["coeff_ofs"].astype(np.int64) - new_ofs, n) + np.arange(int(n.sum()))
+        out.coeffs = pic.coeffs[idx] if len(idx) else np.zeros(0, np.dtype("<u4"))
+        rbs["coeff_ofs"] = new_ofs.astype(np.uint32)
+        out.rbs = rbs
+    # intra blocks: whole CTBs are kept or dropped; renumber the CTBs' ranges
+    ctbs = pic.ctbs.copy()
+    keep_ctb = owner == rank
+    if len(pic.ibs):
+        order = np.argsort(ctbs["ib_start"], kind="stable")          # CTBs in decode (tile-scan) order own consecutive ranges
+        ctb_of_ib = np.repeat(order, ctbs["ib_count"][order].astype(np.int64))
+        keep_ib = keep_ctb[ctb_of_ib]
+        out.ibs = pic.ibs[keep_ib]
+        dropped_before = np.concatenate([[0], np.cumsum(~keep_ib)])[ctbs["ib_start"].astype(np.int64)]
+        ctbs["ib_start"] = np.where(keep_ctb, ctbs["ib_start"].astype(np.int64) - dropped_before, 0).astype(np.uint32)
+    ctbs["ib_count"] = np.where(keep_ctb, ctbs["ib_count"], 0)
+    out.ctbs = ctbs
+    return out
+
+
+class DistComm:
+    """Exchanges over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.nranks = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather_slots(self, t):
+        n = t.numel() // self.nranks
+        self.dist.all_gather_into_tensor(t, t[self.rank * n:(self.rank + 1) * n].clone(), group=self.group)
+
+
+class ShardedDecoder:
+    """One rank's executor: context + exchange buffers + the phase loop."""
+
+    def __init__(self, ctx, rank, nranks, comm=None, device="cuda"):
+        import torch
+        self.torch = torch
+        self.ctx, self.rank, self.nranks, self.comm = ctx, rank, nranks, comm
+        self.device = torch.device(device)
+        self.ctx.shard_set(rank, nranks)
+        self.xbufs = {}
+        self.stream = None
+        if self.device.type == "cuda":
+            # (torch's HIP runtime must have been initialised before the library's first HIP call in this
+            # process — torch.cuda.init() / set_device() first — or torch finds no device.)
+            # collectives are ordered against the library's own HIP stream
+            self.stream = torch.cuda.ExternalStream(int(ctx.stream()), device=self.device)
+
+    def upload(self, pic_shard):
+        h = self.ctx.upload(pic_shard)
+        self.xbufs[h] = [self.torch.zeros(max(1, self.ctx.shard_xbuf_bytes(h, k) // 4), dtype=self.torch.int32, device=self.device)
+                         for k in range(4)]
+        return h
+
+    def release(self, h):
+        self.ctx.release(h)
+        self.xbufs.pop(h, None)
+
+    def run_phase(self, h, k):
+        self.ctx.decode_phase(h, k, self.xbufs[h][k].data_ptr() if k < 4 else None)
+
+    def exchange(self, h, k):
+        buf = self.xbufs[h][k]
+        if self.stream is not None:
+            with self.torch.cuda.stream(self.stream):
+                self._exchange(buf, k)
+        else:
+            self.ctx.wait()                  # emulator: the "device" work is synchronous anyway
+            self._exchange(buf, k)
+
+    def _exchange(self, buf, k):
+        if k < 3:
+            self.comm.all_reduce_sum(buf)
+        else:
+            self.comm.all_gather_slots(buf)
+
+    def decode(self, h):
+        """All five phases of one picture; asynchronous on the context's stream (GPU)."""
+        for k in range(5):
+            self.run_phase(h, k)
+            if k < 4:
+                self.exchange(h, k)

@@ -22,6 +22,17 @@ REFERENCE_ROOT = "/root/reference"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # GPU tier: the tile-sharding tests hand torch tensors to the library.  torch ships its own HIP runtime;
+    # when it initialises AFTER the library's (system) runtime in the same process it finds no device, the
+    # other order works — so bring torch's up first (bench.py does the same for N > 1).
+    expr = config.getoption("-m") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
 
 
 def _make(target):

@@ -1,0 +1,72 @@
+"""Drivers for tile-sharded decoding in the tests: `local_sharded_decode` runs N virtual ranks in ONE
+process in lockstep (one context per rank on the same device / emulator) and performs the exchanges by
+hand — the same phase calls, buffers and pack/unpack kernels as the multi-process path, without a
+process group; `dist_sharded_decode` is the real torch.distributed path (gloo on CPU with the emulator
+library, RCCL on GPUs)."""
+import numpy as np
+
+from libde265_amd import capi, shard, worklist
+
+
+def _setup_rank(ctx, pic, refs, rank, nranks, device):
+    pp = pic.pp[0]
+    handles = []
+    for planes in refs:
+        f = ctx.frame_create_for(pp)
+        ctx.frame_upload(f, planes)
+        handles.append(f)
+    dst = ctx.frame_create_for(pp)
+    sp = shard.shard_picture(pic, rank, nranks)
+    sp.dst_frame = dst
+    sp.ref_frames = [handles[i] if i < len(handles) else -1 for i in range(worklist.MAX_REF_FRAMES)]
+    return sp, dst
+
+
+def local_sharded_decode(lib, pic, refs, nranks, device="cpu", stages=worklist.STAGE_ALL, repeat=1):
+    """-> list (per rank) of the downloaded destination planes; every rank must hold the whole picture."""
+    ctxs = [capi.Context(lib, 0) for _ in range(nranks)]
+    try:
+        decs, hs, dsts = [], [], []
+        for r, ctx in enumerate(ctxs):
+            ctx.set_stages(stages)
+            d = shard.ShardedDecoder(ctx, r, nranks, comm=None, device=device)
+            sp, dst = _setup_rank(ctx, pic, refs, r, nranks, device)
+            decs.append(d); hs.append(d.upload(sp)); dsts.append(dst)
+        for _ in range(repeat):
+            for k in range(5):
+                for d, h in zip(decs, hs):
+                    d.run_phase(h, k)
+                for ctx in ctxs:
+                    ctx.wait()
+                if k < 3:       # SUM all-reduce
+                    total = sum(d.xbufs[h][k] for d, h in zip(decs, hs))
+                    for d, h in zip(decs, hs):
+                        d.xbufs[h][k].copy_(total)
+                elif k == 3:    # all-gather of the rank slots
+                    n = decs[0].xbufs[hs[0]][3].numel() // nranks
+                    for r in range(nranks):
+                        for d, h in zip(decs, hs):
+                            d.xbufs[h][3][r * n:(r + 1) * n].copy_(decs[r].xbufs[hs[r]][3][r * n:(r + 1) * n])
+                if device != "cpu":
+                    import torch
+                    torch.cuda.synchronize()
+        return [ctx.frame_download(dst) for ctx, dst in zip(ctxs, dsts)]
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+
+
+def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL, local_device=0):
+    """inside an initialised torch.distributed process group: this rank's destination planes"""
+    comm = shard.DistComm()
+    ctx = capi.Context(lib, local_device)
+    try:
+        ctx.set_stages(stages)
+        d = shard.ShardedDecoder(ctx, comm.rank, comm.nranks, comm=comm, device=device)
+        sp, dst = _setup_rank(ctx, pic, refs, comm.rank, comm.nranks, device)
+        h = d.upload(sp)
+        d.decode(h)
+        ctx.wait()
+        return ctx.frame_download(dst)
+    finally:
+        ctx.close()

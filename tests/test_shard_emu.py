@@ -1,0 +1,40 @@
+"""Tile sharding on the CPU tier: the product kernels under the SIMT interpreter, N virtual
+ranks in one process, against the oracle's whole-picture decode.  Covers deblocking and SAO across
+tile boundaries (halo exchange), boundaries with filtering across tiles disabled, more tiles than
+ranks, ranks without tiles, 10-bit and all-intra pictures."""
+import pytest
+
+from oracle_py import Oracle
+from shard_util import local_sharded_decode
+from synth_util import assert_planes_equal, make_case, oracle_decode
+from test_emu_picture import emu_lib  # noqa: F401  (fixture)
+from libde265_amd import worklist
+
+CASES = [
+    (dict(width=256, height=128, bit_depth=8, seed=41, tile_cols=2, tile_rows=1), 2),
+    (dict(width=256, height=192, bit_depth=8, seed=42, tile_cols=2, tile_rows=2), 4),
+    (dict(width=256, height=192, bit_depth=10, seed=43, tile_cols=2, tile_rows=2), 2),
+    (dict(width=320, height=128, bit_depth=8, seed=44, tile_cols=3, tile_rows=1, lf_across_tiles=0), 3),
+    (dict(width=192, height=192, bit_depth=8, seed=45, tile_cols=1, tile_rows=3, intra_pct=100, n_refs=0), 2),
+    (dict(width=200, height=136, bit_depth=8, seed=46, tile_cols=2, tile_rows=2, log2_ctb=4), 3),
+    (dict(width=128, height=128, bit_depth=8, seed=47, tile_cols=2, tile_rows=1), 4),          # ranks 1 and 3 own nothing
+]
+
+
+@pytest.mark.parametrize("case,nranks", CASES, ids=lambda v: ("%dx%d_seed%d" % (v["width"], v["height"], v["seed"])) if isinstance(v, dict) else "r%d" % v)
+def test_sharded_matches_oracle(emu_lib, oracle, case, nranks):  # noqa: F811
+    o = Oracle(oracle)
+    pic, refs = make_case(**case)
+    want = oracle_decode(o, pic, refs)
+    for r, got in enumerate(local_sharded_decode(emu_lib, pic, refs, nranks)):
+        assert_planes_equal(got, want, "rank %d of %d" % (r, nranks))
+
+
+def test_sharded_stage_isolation(emu_lib, oracle):  # noqa: F811
+    o = Oracle(oracle)
+    pic, refs = make_case(width=256, height=128, bit_depth=8, seed=48, tile_cols=2, tile_rows=2)
+    for st in (worklist.STAGE_INTER | worklist.STAGE_RESIDUAL | worklist.STAGE_INTRA,
+               worklist.STAGE_ALL & ~worklist.STAGE_SAO):
+        want = oracle_decode(o, pic, refs, st)
+        for r, got in enumerate(local_sharded_decode(emu_lib, pic, refs, 2, stages=st)):
+            assert_planes_equal(got, want, "stages %d rank %d" % (st, r))
