@@ -153,9 +153,10 @@ class ShardedDecoder:
         else:
             self.comm.all_gather_slots(buf)
 
-    def decode(self, h):
-        """All five phases of one picture; asynchronous on the context's stream (GPU)."""
-        for k in range(5):
+    def decode(self, h, gather=True):
+        """All phases of one picture; asynchronous on the context's stream (GPU).  gather=False: a NON-reference
+        picture — the finished tiles stay where they were decoded (each rank outputs its own tiles), no X3."""
+        for k in range(5 if gather else 4):
             self.run_phase(h, k)
-            if k < 4:
+            if k < (4 if gather else 3):
                 self.exchange(h, k)
