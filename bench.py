@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c5_8k10_8tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-upload", action="store_true", help="also time m355_submit_picture per step (host lists -> pinned arena -> H2D -> decode): the PCIe-inclusive rate")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
     args = ap.parse_args()
@@ -91,6 +92,20 @@ def main():
         dist.barrier()
     n_dec, avg_total_ms, stage_ms = ctx.timing_collect()
 
+    with_upload = None
+    if args.with_upload and rank == 0:
+        for _ in range(2):
+            ctx.submit(pic)
+        ctx.wait()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.submit(pic)
+        ctx.wait()
+        dtu = time.perf_counter() - t0
+        c_pic, keep = pic.to_c()
+        nbytes = sum(a.nbytes for a in keep)
+        with_upload = {"value": args.steps * n_ctbs / dtu, "unit": "CTB64/s", "ms_per_step": 1e3 * dtu / args.steps,
+                       "list_bytes_per_picture": int(nbytes), "note": "python marshalling + memcpy into the pinned arena + H2D + decode, one stream, no overlap"}
     sharded = None
     if dist and not args.no_tile_shard and (world > 1 or args.force_tile_shard):
         sharded = tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist)
@@ -119,6 +134,8 @@ def main():
         }
         if sharded is not None:
             out["tile_sharded"] = sharded
+        if with_upload is not None:
+            out["with_upload"] = with_upload
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, synth, worklist)
         print(json.dumps(out))

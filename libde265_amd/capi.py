@@ -24,7 +24,8 @@ class Library:
     """A loaded libde265_mi355x.so with typed entry points."""
 
     def __init__(self, path=None):
-        path = path or DEFAULT_LIB
+        # M355_LIB: an alternative BUILD of the same HIP library (kernel-variant experiments, tools/variants.sh)
+        path = path or os.environ.get("M355_LIB") or DEFAULT_LIB
         if not os.path.exists(path):
             raise RuntimeError("MI355X backend library not found: %s (build it: make -C libde265_amd/csrc; "
                                "there is no CPU fallback)" % path)

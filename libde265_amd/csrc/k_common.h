@@ -114,6 +114,8 @@ enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
 
 /* ---- launchers (each in its stage's .hip); all asynchronous on `st` ---- */
 void m355_launch_meta(const DevPic& p, hipStream_t st);
+void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for k_inter */
+void m355_launch_meta_planes(const DevPic& p, hipStream_t st);   /* planes for intra / deblock / SAO */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);

@@ -210,6 +210,10 @@ template <class PIX, bool FAST>
 __device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[6])
 {
   if (FAST) {
+#ifdef M355_X_NOLOAD   /* experiment: no reference loads at all (timing only, results wrong) */
+    for (int k = 0; k < 6; k++) S[k] = (unsigned)xa * 0x10001u + k;
+    return;
+#endif
     if (sizeof(PIX) == 2) {
       d_ldg16(row + xa, S);
       d_ldg8(row + xa + 8, S + 4);
@@ -232,6 +236,10 @@ template <class PIX, bool FAST>
 __device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[3])
 {
   if (FAST) {
+#ifdef M355_X_NOLOAD
+    for (int k = 0; k < 3; k++) S[k] = (unsigned)xa * 0x10001u + k;
+    return;
+#endif
     if (sizeof(PIX) == 2) d_ldg12(row + xa, S);
     else {
       const unsigned a = d_ldg4(row + xa), b = d_ldg2(row + xa + 4);
@@ -424,14 +432,26 @@ __device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
 /* One job.  FAST: the PB's reference windows lie inside the picture horizontally (k_meta_pb sorts the
  * others into the EDGE job range, handled with clamped per-sample loads). */
 template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et);
+__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et, const DevRef* s_refs);
 
 /* one launch for the main and the edge job range: blocks [0, nblk_edge8) take edge jobs */
+#ifndef M355_INTER_WAVES
+#define M355_INTER_WAVES 3   /* waves per SIMD the register budget is sized for (tools/variants.sh sweeps it) */
+#endif
 template <class PIX, bool BIAS>
-__global__ void __launch_bounds__(256, 3) k_inter_jobs(DevPic p, int nblk_edge8, int nblk_bi8)
+__global__ void __launch_bounds__(256, M355_INTER_WAVES) k_inter_jobs(DevPic p, int nblk_edge8, int nblk_bi8)
 {
   __shared__ unsigned s_qt[4 * QT_STRIDE];
   __shared__ unsigned s_et[8 * ET_STRIDE];
+  /* the reference-frame table (plane pointers / pitches per DPB slot) in LDS: a job looks its references up
+     with ds_reads instead of a dependent global load per list and component (each one a full memory
+     latency on the wave's critical path) */
+  __shared__ DevRef s_refs[M355_MAX_REF_FRAMES];
+  {
+    const unsigned* src = (const unsigned*)p.refs;
+    unsigned* dst = (unsigned*)s_refs;
+    for (int i = threadIdx.x; i < (int)(sizeof(s_refs) / 4); i += 256) dst[i] = src[i];
+  }
   if (threadIdx.x < 4) {
     const int8_t* t = c_qpel_taps[threadIdx.x];
     unsigned* o = s_qt + threadIdx.x * QT_STRIDE;
@@ -455,22 +475,38 @@ __global__ void __launch_bounds__(256, 3) k_inter_jobs(DevPic p, int nblk_edge8,
   const int b = blockIdx.x;
   if (b < nblk_edge8) {
     const int ji = p.n_jobs_main + b * 256 + threadIdx.x;
-    if (ji < p.n_jobs) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et);
+    if (ji < p.n_jobs) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et, s_refs);
     return;
   }
   const int bm = b - nblk_edge8, xcd = bm & 7, slot = bm >> 3;
   const int per_bi = nblk_bi8 >> 3, per_uni = (gridDim.x - nblk_edge8 - nblk_bi8) >> 3;
+#ifndef M355_INTER_NO_INTERLEAVE
+  /* Within an XCD the bi-predicted and the one-list blocks are interleaved in proportion (both lists are in
+     PB order, so block i/per_bi of one and block i/per_uni of the other cover the same part of the picture):
+     the two classes then read the same reference region while it is still in that XCD's L2 — run one class
+     after the other and every region is fetched twice, far apart in time. */
+  const int per = per_bi + per_uni;
+  const int bi_before = (int)(((long long)slot * per_bi) / per), bi_after = (int)(((long long)(slot + 1) * per_bi) / per);
+  if (bi_after != bi_before) {
+    const int ji = p.n_jobs_uni + (xcd * per_bi + bi_before) * 256 + threadIdx.x;
+    if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
+  } else {
+    const int ji = (xcd * per_uni + slot - bi_before) * 256 + threadIdx.x;
+    if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
+  }
+#else
   if (slot < per_bi) {
     const int ji = p.n_jobs_uni + (xcd * per_bi + slot) * 256 + threadIdx.x;
-    if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et);
+    if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   } else {
     const int ji = (xcd * per_uni + slot - per_bi) * 256 + threadIdx.x;
-    if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et);
+    if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   }
+#endif
 }
 
 template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et)
+__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et, const DevRef* s_refs)
 {
   const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
   const int strip = (job >> 25) & 15, rblk = job >> 29;
@@ -494,91 +530,117 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
   const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
 
-#pragma unroll 1
-  for (int c = 0; c < nc; c++) {
-    const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+  /* weights of the job's component c (WtSel above); the two records are fetched once per job */
+  m355_wt wa, wb;
+  if (weighted) { wa = p.wts[wtA]; wb = p.wts[wtB]; }
+  auto make_ws = [&](int c, int bd) {
     WtSel ws;
-    {
-      const int shift3 = max(2, 14 - bd), shift2 = max(3, 15 - bd);
-      ws.w0 = 1; ws.w1 = bi ? 1 : 0; ws.o = 0;
-      ws.sh = bi ? shift2 : shift3; ws.rnd = 1 << (ws.sh - 1);
-      if (weighted) {
-        const m355_wt wa = p.wts[wtA], wb = p.wts[wtB];
-        const int o0 = c == 0 ? wa.o[0] : (c == 1 ? wa.o[1] : wa.o[2]), o1 = c == 0 ? wb.o[0] : (c == 1 ? wb.o[1] : wb.o[2]);
-        const int log2WD = c ? wa.log2wd_chroma : wa.log2wd_luma;
-        ws.w0 = c == 0 ? wa.w[0] : (c == 1 ? wa.w[1] : wa.w[2]);
-        ws.w1 = bi ? (c == 0 ? wb.w[0] : (c == 1 ? wb.w[1] : wb.w[2])) : 0;
-        ws.rnd = bi ? (int)((unsigned)(o0 + o1 + 1) << log2WD) : (1 << (log2WD - 1));
-        ws.sh = bi ? log2WD + 1 : log2WD;
-        ws.o = bi ? 0 : o0;
+    const int shift3 = max(2, 14 - bd), shift2 = max(3, 15 - bd);
+    ws.w0 = 1; ws.w1 = bi ? 1 : 0; ws.o = 0;
+    ws.sh = bi ? shift2 : shift3; ws.rnd = 1 << (ws.sh - 1);
+    if (weighted) {
+      const int o0 = c == 0 ? wa.o[0] : (c == 1 ? wa.o[1] : wa.o[2]), o1 = c == 0 ? wb.o[0] : (c == 1 ? wb.o[1] : wb.o[2]);
+      const int log2WD = c ? wa.log2wd_chroma : wa.log2wd_luma;
+      ws.w0 = c == 0 ? wa.w[0] : (c == 1 ? wa.w[1] : wa.w[2]);
+      ws.w1 = bi ? (c == 0 ? wb.w[0] : (c == 1 ? wb.w[1] : wb.w[2])) : 0;
+      ws.rnd = bi ? (int)((unsigned)(o0 + o1 + 1) << log2WD) : (1 << (log2WD - 1));
+      ws.sh = bi ? log2WD + 1 : log2WD;
+      ws.o = bi ? 0 : o0;
+    }
+    return ws;
+  };
+
+  /* ---- luma ---- */
+  {
+    const int bd = p.pp.bit_depth_luma;
+    const WtSel ws = make_ws(0, bd);
+    const int pw = p.pw[0], ph = p.ph[0];
+    unsigned pa[8][2];
+#pragma unroll
+    for (int y = 0; y < 8; y++) { pa[y][0] = 0; pa[y][1] = 0; }
+    PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; pass++) {
+      unsigned cur[8][2];
+      if (pass ? fillB : fillA) {        /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
+#pragma unroll
+        for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
+      } else {
+        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+        d_mc_luma_4x8<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], pw, ph, x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, bd, s_qt, cur);
+      }
+      if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
+#pragma unroll
+        for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
+        continue;
+      }
+#pragma unroll
+      for (int y = 0; y < 8; y++) {
+        if (y >= rows) break;
+        unsigned o[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
+          o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
+        }
+#ifdef M355_X_NOSTORE   /* experiment: results are computed but (never true at run time) not stored */
+        if (p.pp.width >= 0) continue;
+#endif
+        if (sizeof(PIX) == 2) *(uint2*)(d + (size_t)y * p.stride[0]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+        else *(unsigned*)(d + (size_t)y * p.stride[0]) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
       }
     }
-    const int pw = p.pw[c], ph = p.ph[c];
-    if (c == 0) {
-      unsigned pa[8][2];
+  }
+  if (nc == 1) return;
+
+  /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are
+     in flight together (one memory latency per list instead of two); chroma mv = luma mv in 1/8 pel
+     (motion.cc:196-203) ---- */
+  {
+    const int bd = p.pp.bit_depth_chroma;
+    const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
+    const int pw = p.pw[1], ph = p.ph[1];
+    const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
+    unsigned pa1[4], pa2[4];
 #pragma unroll
-      for (int y = 0; y < 8; y++) { pa[y][0] = 0; pa[y][1] = 0; }
-      PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
+    for (int y = 0; y < 4; y++) { pa1[y] = 0; pa2[y] = 0; }
+    PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
+    PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
 #pragma unroll 1
-      for (int pass = 0; pass < npass; pass++) {
-        unsigned cur[8][2];
-        if (pass ? fillB : fillA) {        /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
+    for (int pass = 0; pass < npass; pass++) {
+      unsigned cur1[4], cur2[4];
+      if (pass ? fillB : fillA) {
 #pragma unroll
-          for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
-        } else {
-          const DevRef* ref = &p.refs[pass ? pb.ref_slot[1] : refA];
-          const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-          d_mc_luma_4x8<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], pw, ph, x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, bd, s_qt, cur);
-        }
-        if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
-#pragma unroll
-          for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
-          continue;
-        }
-#pragma unroll
-        for (int y = 0; y < 8; y++) {
-          if (y >= rows) break;
-          unsigned o[4];
-#pragma unroll
-          for (int x = 0; x < 4; x++) {
-            const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
-            o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
-          }
-          if (sizeof(PIX) == 2) *(uint2*)(d + (size_t)y * p.stride[0]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-          else *(unsigned*)(d + (size_t)y * p.stride[0]) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-        }
+        for (int y = 0; y < 4; y++) { cur1[y] = 0x20002000u; cur2[y] = 0x20002000u; }
+      } else {
+        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur1);
+        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur2);
       }
-    } else {
-      /* chroma (4:2:0): 2 columns x 4 rows per plane; chroma mv = luma mv in 1/8 pel (motion.cc:196-203) */
-      const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
-      unsigned pa[4];
+      if (pass + 1 < npass) {
 #pragma unroll
-      for (int y = 0; y < 4; y++) pa[y] = 0;
-      PIX* d = (PIX*)p.plane[c] + (size_t)yc * p.stride[c] + xc;
-#pragma unroll 1
-      for (int pass = 0; pass < npass; pass++) {
-        unsigned cur[4];
-        if (pass ? fillB : fillA) {
+        for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
+        continue;
+      }
 #pragma unroll
-          for (int y = 0; y < 4; y++) cur[y] = 0x20002000u;
-        } else {
-          const DevRef* ref = &p.refs[pass ? pb.ref_slot[1] : refA];
-          const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-          const M355_GLOBAL PIX* rp = (const M355_GLOBAL PIX*)(c == 1 ? ref->plane[1] : ref->plane[2]);
-          d_mc_chroma_2x4<PIX, BIAS, FAST>(rp, c == 1 ? ref->stride[1] : ref->stride[2], pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur);
+      for (int y = 0; y < 4; y++) {
+        if (y >= crows) break;
+#ifdef M355_X_NOSTORE
+        if (p.pp.width >= 0) continue;
+#endif
+        {
+          const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
+          const unsigned o0 = (unsigned)d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd);
+          if (sizeof(PIX) == 2) *(unsigned*)(d1 + (size_t)y * p.stride[1]) = o0 | (o1 << 16);
+          else *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)(o0 | (o1 << 8));
         }
-        if (pass + 1 < npass) {
-#pragma unroll
-          for (int y = 0; y < 4; y++) pa[y] = cur[y];
-          continue;
-        }
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-          if (y >= crows) break;
-          const unsigned a = bi ? pa[y] : cur[y], b = cur[y];
-          const unsigned o0 = (unsigned)d_wpred(ws, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws, d_hi16s(a), d_hi16s(b), bd);
-          if (sizeof(PIX) == 2) *(unsigned*)(d + (size_t)y * p.stride[c]) = o0 | (o1 << 16);
-          else *(unsigned short*)(d + (size_t)y * p.stride[c]) = (unsigned short)(o0 | (o1 << 8));
+        {
+          const unsigned a = bi ? pa2[y] : cur2[y], b = cur2[y];
+          const unsigned o0 = (unsigned)d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd);
+          if (sizeof(PIX) == 2) *(unsigned*)(d2 + (size_t)y * p.stride[2]) = o0 | (o1 << 16);
+          else *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)(o0 | (o1 << 8));
         }
       }
     }

@@ -203,7 +203,14 @@ __global__ void __launch_bounds__(256) k_meta_sao(DevPic p)
   p.sao_nb[i] = (uint16_t)mask;
 }
 
-void m355_launch_meta(const DevPic& p, hipStream_t st)
+/* the inter stage needs only the job list (+ pb_of when the inter stage is off) */
+void m355_launch_meta_jobs(const DevPic& p, hipStream_t st)
+{
+  if (p.n_pbs) hipLaunchKernelGGL(k_meta_pb, dim3((p.n_pbs + 255) / 256), dim3(256), 0, st, p);
+}
+
+/* metadata planes for intra availability, deblocking and SAO (not read by k_inter / k_residual) */
+void m355_launch_meta_planes(const DevPic& p, hipStream_t st)
 {
   /* edge_tu, edge_pb (sparse writers) and cb_cu (robustness against uncovered areas) live in ONE allocation: one
      fill.  pb_of needs none: it is only read where both sides are inter-coded, i.e. covered by a PB. */
@@ -211,5 +218,10 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
   if (p.pp.flags & M355_PF_SAO_ENABLED) hipLaunchKernelGGL(k_meta_sao, dim3((p.nCtb * 3 + 255) / 256), dim3(256), 0, st, p);
-  if (p.n_pbs) hipLaunchKernelGGL(k_meta_pb, dim3((p.n_pbs + 255) / 256), dim3(256), 0, st, p);
+}
+
+void m355_launch_meta(const DevPic& p, hipStream_t st)
+{
+  m355_launch_meta_planes(p, st);
+  m355_launch_meta_jobs(p, st);
 }

@@ -94,6 +94,8 @@ struct Resident {
 struct m355_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<Frame> frames;
   std::vector<Resident> resident;
   Resident transient;
@@ -202,6 +204,9 @@ int m355_create(int device, m355_ctx** out)
   m355_ctx* c = new m355_ctx;
   c->device = device;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIPCHK(hipMalloc(&c->ticket, 64));
   HIPCHK(hipMalloc(&c->timeout, 64));
   HIPCHK(hipMemsetAsync(c->ticket, 0, 64, c->stream));
@@ -233,6 +238,9 @@ void m355_destroy(m355_ctx* c)
   for (void* b : bufs) if (b) hipFree(b);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   hipStreamDestroy(c->stream);
+  if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -707,12 +715,18 @@ static int decode(m355_ctx* c, Resident& r)
   hipEvent_t* ev = &c->evs[c->ev_used * 7];
   c->ev_used++;
   hipEventRecord(ev[0], st);
-  const bool need_meta = true;   /* metadata planes for intra/deblock/SAO, job list for inter */
-  if (need_meta) m355_launch_meta(d, st);
+  /* fork: the metadata planes (read first by k_intra) are rasterised on the side stream while the main
+     stream runs job list -> inter prediction -> residual, which do not read them */
+  hipEventRecord(c->ev_fork, st);
+  hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+  m355_launch_meta_planes(d, c->stream2);
+  hipEventRecord(c->ev_join, c->stream2);
+  m355_launch_meta_jobs(d, st);
   hipEventRecord(ev[1], st);
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   hipEventRecord(ev[2], st);
   if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
+  hipStreamWaitEvent(st, c->ev_join, 0);     /* join */
   hipEventRecord(ev[3], st);
   if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
   hipEventRecord(ev[4], st);

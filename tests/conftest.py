@@ -26,7 +26,7 @@ def pytest_configure(config):
     # when it initialises AFTER the library's (system) runtime in the same process it finds no device, the
     # other order works — so bring torch's up first (bench.py does the same for N > 1).
     expr = config.getoption("-m") or ""
-    if "gpu" in expr and "not gpu" not in expr:
+    if ("gpu" in expr and "not gpu" not in expr) or any("test_gpu" in str(a) for a in config.args):
         try:
             import torch
             if torch.cuda.is_available():
