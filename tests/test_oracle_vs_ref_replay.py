@@ -1,0 +1,48 @@
+"""Second pin of the CPU oracle: whole synthetic pictures replayed through the REAL reference functions
+(oracle/ref_replay.cc -> generate_inter_prediction_samples, scale_coefficients, decode_intra_prediction,
+apply_deblocking_filter, apply_sample_adaptive_offset_sequential of /root/reference, scalar AND SSE/AVX tables)
+must equal oracle/hevc_oracle.c bit for bit — tiles with and without filtering across them, 8/10/12-bit, CTB
+16/32/64, every CU/TU size, explicit weights, MVs far outside the picture, transform skip, intra-only pictures.
+(The first pin is the recorded girlshy stream, tests/test_girlshy_oracle.py.)  Needs oracle/_ref (built from
+/root/reference by oracle/Makefile); skipped where that is unavailable."""
+import pytest
+
+from oracle_py import Oracle
+from ref_replay_py import ref_replay
+from synth_util import assert_planes_equal, make_case, oracle_decode
+from libde265_amd import synth, worklist as W
+
+CASES = [
+    dict(width=192, height=128, bit_depth=8, seed=11),
+    dict(width=200, height=136, bit_depth=8, seed=12, tile_cols=2, tile_rows=2, lf_across_tiles=0),
+    dict(width=192, height=128, bit_depth=10, seed=13, tile_cols=3, tile_rows=1),
+    dict(width=128, height=128, bit_depth=8, seed=14, intra_pct=100, n_refs=0, tile_cols=2, tile_rows=1),
+    dict(width=136, height=72, bit_depth=12, seed=15, log2_ctb=5, intra_pct=40),
+    dict(width=128, height=64, bit_depth=8, seed=16, log2_ctb=4, fixed_cu_log2=3, cbf_pct=100),
+    dict(width=416, height=240, bit_depth=8, seed=21),
+    dict(width=832, height=480, bit_depth=10, seed=22, tile_cols=3, tile_rows=2),
+    dict(width=640, height=368, bit_depth=10, seed=24, intra_pct=100, n_refs=0, tile_cols=2, tile_rows=2),
+    dict(width=1280, height=720, bit_depth=8, seed=25, intra_pct=25, weighted_pct=50, oob_mv_pct=20),
+    dict(width=416, height=240, bit_depth=12, seed=28, weighted_pct=30, oob_mv_pct=10),
+    dict(width=64, height=64, bit_depth=8, seed=30, oob_mv_pct=100, intra_pct=0),
+    dict(width=72, height=24, bit_depth=9, seed=27, log2_ctb=4, intra_pct=50),
+]
+STAGES = [W.STAGE_ALL, W.STAGE_INTER | W.STAGE_RESIDUAL | W.STAGE_INTRA, W.STAGE_ALL & ~W.STAGE_SAO, W.STAGE_INTER]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d_%dbit_seed%d" % (c["width"], c["height"], c["bit_depth"], c["seed"]))
+def test_oracle_equals_reference_replay(oracle, ref, case):
+    o = Oracle(oracle)
+    pic, refs = make_case(**case)
+    for st in STAGES:
+        want = ref_replay(ref, pic, refs, st, accel=0)
+        assert_planes_equal(oracle_decode(o, pic, refs, st), want, "oracle vs scalar reference, stages %d" % st)
+    # the reference's SIMD tables give the same picture as its scalar ones (and hence as the oracle)
+    assert_planes_equal(ref_replay(ref, pic, refs, W.STAGE_ALL, accel=1), ref_replay(ref, pic, refs, W.STAGE_ALL, accel=0), "SSE vs scalar reference")
+
+
+@pytest.mark.parametrize("name", ["c2_1080p_intra", "c4_4k_4tiles"])
+def test_oracle_equals_reference_replay_baseline_configs(oracle, ref, name):
+    o = Oracle(oracle)
+    pic, refs = make_case(**synth.CONFIGS[name])
+    assert_planes_equal(oracle_decode(o, pic, refs), ref_replay(ref, pic, refs, accel=1), name)
