@@ -31,16 +31,23 @@ typedef struct m355_synth_cfg {
   int32_t lf_across_tiles;
   uint32_t seed;
   int32_t fixed_cu_log2;    /* 0 = random per CTB, else force this CU size (3..6) */
-  int32_t reserved[3];
+  int32_t n_slices;         /* 0/1 = one slice; else that many slices with random filter flags / offsets (whole tiles per
+                               slice when the picture has tiles, arbitrary CTB runs otherwise) */
+  int32_t features;         /* M355_SYN_* bits */
+  int32_t reserved[1];
 } m355_synth_cfg;
+enum { M355_SYN_CONSTRAINED_INTRA = 1, M355_SYN_TRANSQUANT_BYPASS = 2, M355_SYN_SCALING_LIST = 4, M355_SYN_PCM = 8,
+       M355_SYN_PCM_LOOP_FILTER_DISABLE = 16 };
 
 typedef struct { void* p; size_t n, cap, esz; } vec;
 typedef struct gen {
   const m355_synth_cfg* cfg;
   uint32_t s;
-  vec slices, ctbs, cus, tus, pbs, wts, rbs[4], ibs, coeffs;
+  vec slices, ctbs, cus, tus, pbs, wts, rbs[4], ibs, coeffs, pcm;
   uint32_t res_len;
   int ctbW, ctbH;
+  int ctb_has_bypass;       /* a CU of the CTB being generated uses cu_transquant_bypass */
+  int cu_bypass;            /* the CU being generated */
 } gen;
 
 static uint32_t rnd(gen* g) { uint32_t s = g->s; s ^= s << 13; s ^= s >> 17; s ^= s << 5; g->s = s; return s; }
@@ -105,6 +112,23 @@ static int gen_tb(gen* g, int cidx, int x, int y, int log2, int intra, int mode,
   rb->qp = (uint8_t)(cidx ? (qp > 3 ? qp - 3 : qp) : qp);
   rb->kind = (intra && cidx == 0 && log2 == 2) ? M355_RK_DST : M355_RK_DCT;
   if (log2 == 2 && rbelow(g, 20) == 0) rb->kind = M355_RK_SKIP;   /* transform_skip is Main profile for 4x4 */
+  if (g->cfg->features & M355_SYN_SCALING_LIST) {                  /* matrixID rule of transform.cc:493-502 */
+    int m = log2 == 5 ? 0 : cidx;
+    if (!intra) m += (log2 < 5) ? 3 : 1;
+    rb->matrix_id = (uint8_t)m;
+  }
+  if (g->cu_bypass) {                                              /* cu_transquant_bypass: the levels ARE the residual */
+    rb->kind = M355_RK_BYPASS;
+    rb->coeff_ofs = (uint32_t)g->coeffs.n;
+    int cnt = 0;
+    for (int pos = 0; pos < n; pos++) {
+      if (rbelow(g, 3)) continue;
+      int v = rrange(g, -40, 40); if (v == 0) v = 1;
+      *(uint32_t*)vpush(&g->coeffs, 4) = (uint32_t)pos | ((uint32_t)(uint16_t)(int16_t)v << 16);
+      cnt++;
+    }
+    rb->ncoeff = (uint16_t)cnt;
+  } else
   gen_coeffs(g, rb, n);
   if (intra) {
     rb->flags |= M355_RBF_DEFERRED; rb->res_ofs = g->res_len;
@@ -186,7 +210,22 @@ static void gen_cu(gen* g, int x, int y, int log2)
   const int qp = rrange(g, 22, 37);
   const int size = 1 << log2;
   cu->x = (uint16_t)x; cu->y = (uint16_t)y; cu->log2_size = (uint8_t)log2; cu->qp_y = (int8_t)qp;
-  if (intra) {
+  g->cu_bypass = (c->features & M355_SYN_TRANSQUANT_BYPASS) && rbelow(g, 12) == 0;
+  if (g->cu_bypass) { cu->flags |= M355_CUF_TRANSQUANT_BYPASS; g->ctb_has_bypass = 1; }
+  if (intra && !g->cu_bypass && log2 <= 5 && (c->features & M355_SYN_PCM) && rbelow(g, 10) == 0) {
+    /* PCM coding unit (slice.cc:4211-4255): raw samples, no prediction, no transform tree */
+    cu->pred_mode = 0; cu->part_mode = 0; cu->flags |= M355_CUF_PCM; g->ctb_has_bypass = 1;
+    for (int cidx = 0; cidx < 3; cidx++) {
+      const int l2 = cidx ? log2 - 1 : log2, n = 1 << (2 * l2);
+      m355_ib* ib = (m355_ib*)vpush(&g->ibs, sizeof(m355_ib));
+      ib->x = (uint16_t)(cidx ? x / 2 : x); ib->y = (uint16_t)(cidx ? y / 2 : y); ib->cidx = (uint8_t)cidx; ib->log2_size = (uint8_t)l2;
+      ib->mode = 1; ib->flags = M355_IBF_PCM; ib->res_ofs = (uint32_t)g->pcm.n;
+      const int pcm_bits = c->bit_depth - rbelow(g, 3);           /* PcmBitDepth <= BitDepth: samples << (BitDepth - PcmBitDepth) */
+      for (int i = 0; i < n; i++) *(uint16_t*)vpush(&g->pcm, 2) = (uint16_t)(rbelow(g, 1 << pcm_bits) << (c->bit_depth - pcm_bits));
+    }
+    m355_tu* tu = (m355_tu*)vpush(&g->tus, sizeof(m355_tu));
+    tu->x = (uint16_t)x; tu->y = (uint16_t)y; tu->log2_size = (uint8_t)log2;
+  } else if (intra) {
     cu->pred_mode = 0;
     const int nxn = (log2 == 3) && rbelow(g, 2);
     cu->part_mode = nxn ? 3 : 0;
@@ -258,7 +297,10 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
   pp->log2_ctb_size = (uint8_t)cfg->log2_ctb; pp->log2_min_tb_size = 2; pp->log2_min_cb_size = 3;
   pp->pic_cb_qp_offset = 1; pp->pic_cr_qp_offset = -1;
   pp->flags = M355_PF_STRONG_INTRA_SMOOTHING | (cfg->sao ? M355_PF_SAO_ENABLED : 0) | (cfg->deblock ? M355_PF_DEBLOCK_ENABLED : 0) |
-              (cfg->lf_across_tiles ? M355_PF_LF_ACROSS_TILES : 0);
+              (cfg->lf_across_tiles ? M355_PF_LF_ACROSS_TILES : 0) |
+              ((cfg->features & M355_SYN_CONSTRAINED_INTRA) ? M355_PF_CONSTRAINED_INTRA_PRED : 0) |
+              ((cfg->features & M355_SYN_SCALING_LIST) ? M355_PF_SCALING_LIST : 0) |
+              ((cfg->features & M355_SYN_PCM_LOOP_FILTER_DISABLE) ? M355_PF_PCM_LOOP_FILTER_DISABLE : 0);
   pp->num_tile_cols = (uint8_t)cfg->tile_cols; pp->num_tile_rows = (uint8_t)cfg->tile_rows;
   for (int i = 0; i <= cfg->tile_cols; i++) pp->col_bd[i] = (uint16_t)((i * g.ctbW) / cfg->tile_cols);   /* uniform spacing (pps.cc) */
   for (int i = 0; i <= cfg->tile_rows; i++) pp->row_bd[i] = (uint16_t)((i * g.ctbH) / cfg->tile_rows);
@@ -268,6 +310,22 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
   m355_slice* sl = (m355_slice*)vpush(&g.slices, sizeof(m355_slice));
   sl->slice_addr_rs = 0; sl->beta_offset = (int8_t)(2 * rrange(&g, -2, 2)); sl->tc_offset = (int8_t)(2 * rrange(&g, -2, 2));
   sl->flags = M355_SF_LF_ACROSS_SLICES | M355_SF_SAO_LUMA | M355_SF_SAO_CHROMA;
+  /* more slices: start points in tile-scan order (tile starts when the picture has tiles), random per-slice flags */
+  const int nctb = g.ctbW * g.ctbH, ntiles = cfg->tile_cols * cfg->tile_rows;
+  uint8_t* slice_start = (uint8_t*)calloc((size_t)nctb + 1, 1);
+  if (cfg->n_slices > 1) {
+    if (ntiles > 1) {
+      int ts = 0;
+      for (int ty = 0; ty < cfg->tile_rows; ty++)
+        for (int tx = 0; tx < cfg->tile_cols; tx++) {
+          if (ts && rbelow(&g, ntiles) < cfg->n_slices) slice_start[ts] = 1;
+          ts += (pp->row_bd[ty + 1] - pp->row_bd[ty]) * (pp->col_bd[tx + 1] - pp->col_bd[tx]);
+        }
+    } else {
+      for (int k = 1; k < cfg->n_slices; k++) slice_start[1 + rbelow(&g, nctb - 1 > 0 ? nctb - 1 : 1)] = nctb > 1;
+    }
+  }
+  int ts_run = 0, cur_slice = 0;
 
   g.ctbs.p = calloc((size_t)g.ctbW * g.ctbH, sizeof(m355_ctb)); g.ctbs.n = g.ctbs.cap = (size_t)g.ctbW * g.ctbH; g.ctbs.esz = sizeof(m355_ctb);
   m355_ctb* ctbs = (m355_ctb*)g.ctbs.p;
@@ -276,11 +334,22 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
       for (int cy = pp->row_bd[ty]; cy < pp->row_bd[ty + 1]; cy++)
         for (int cx = pp->col_bd[tx]; cx < pp->col_bd[tx + 1]; cx++) {
           m355_ctb* ctb = &ctbs[cy * g.ctbW + cx];
-          ctb->slice_idx = 0;
+          if (slice_start[ts_run]) {
+            m355_slice* ns = (m355_slice*)vpush(&g.slices, sizeof(m355_slice));
+            ns->slice_addr_rs = cy * g.ctbW + cx;
+            ns->beta_offset = (int8_t)(2 * rrange(&g, -3, 3)); ns->tc_offset = (int8_t)(2 * rrange(&g, -3, 3));
+            ns->flags = (uint8_t)((rbelow(&g, 4) == 0 ? M355_SF_DEBLOCK_DISABLED : 0) | (rbelow(&g, 2) ? M355_SF_LF_ACROSS_SLICES : 0) |
+                                  (rbelow(&g, 5) ? M355_SF_SAO_LUMA : 0) | (rbelow(&g, 5) ? M355_SF_SAO_CHROMA : 0));
+            cur_slice = (int)g.slices.n - 1;
+          }
+          ts_run++;
+          ctb->slice_idx = (uint16_t)cur_slice;
           ctb->ib_start = (uint32_t)g.ibs.n;
+          g.ctb_has_bypass = 0;
           const int target = cfg->fixed_cu_log2 ? cfg->fixed_cu_log2 : 3 + rbelow(&g, cfg->log2_ctb - 2);
           gen_cq(&g, cx * cs, cy * cs, cfg->log2_ctb, target > cfg->log2_ctb ? cfg->log2_ctb : target);
           ctb->ib_count = (uint32_t)g.ibs.n - ctb->ib_start;
+          if (g.ctb_has_bypass) ctb->flags |= M355_CTBF_HAS_PCM_OR_BYPASS;
           if (cfg->sao) {
             const int tl = rbelow(&g, 6), tc = rbelow(&g, 6); /* off, band, edge x4 */
             const int typ_l = tl == 0 ? 0 : (tl == 1 ? 1 : 2), typ_c = tc == 0 ? 0 : (tc == 1 ? 1 : 2);
@@ -304,12 +373,20 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
 
   pic->n_slices = (int32_t)g.slices.n; pic->n_ctbs = (int32_t)g.ctbs.n; pic->n_cus = (int32_t)g.cus.n; pic->n_tus = (int32_t)g.tus.n;
   pic->n_pbs = (int32_t)g.pbs.n; pic->n_wts = (int32_t)g.wts.n; pic->n_ibs = (int32_t)g.ibs.n;
-  pic->n_coeffs = (uint32_t)g.coeffs.n; pic->n_pcm = 0; pic->res_len = g.res_len;
+  pic->n_coeffs = (uint32_t)g.coeffs.n; pic->n_pcm = (uint32_t)g.pcm.n; pic->res_len = g.res_len;
   pic->slices = (const m355_slice*)g.slices.p; pic->ctbs = ctbs; pic->cus = (const m355_cu*)g.cus.p; pic->tus = (const m355_tu*)g.tus.p;
   pic->pbs = (const m355_pb*)g.pbs.p; pic->wts = (const m355_wt*)g.wts.p; pic->rbs = rbs; pic->ibs = (const m355_ib*)g.ibs.p;
-  pic->coeffs = (const uint32_t*)g.coeffs.p; pic->pcm = NULL; pic->scaling_factors = NULL;
-  void* own[] = {g.slices.p, g.ctbs.p, g.cus.p, g.tus.p, g.pbs.p, g.wts.p, rbs, g.ibs.p, g.coeffs.p};
-  for (int i = 0; i < 9; i++) out->owned[i] = own[i];
+  pic->coeffs = (const uint32_t*)g.coeffs.p; pic->pcm = (const uint16_t*)g.pcm.p; pic->scaling_factors = NULL;
+  uint8_t* sf = NULL;
+  if (cfg->features & M355_SYN_SCALING_LIST) {   /* ScalingFactor tables [sizeId][matrixID][y][x] (sps.h:58-65): flat 16 with random relief */
+    const int nsf = 6 * (16 + 64 + 256 + 1024);
+    sf = (uint8_t*)malloc((size_t)nsf);
+    for (int i = 0; i < nsf; i++) sf[i] = (uint8_t)(rbelow(&g, 4) == 0 ? rrange(&g, 1, 255) : rrange(&g, 8, 40));
+    pic->scaling_factors = sf;
+  }
+  free(slice_start);
+  void* own[] = {g.slices.p, g.ctbs.p, g.cus.p, g.tus.p, g.pbs.p, g.wts.p, rbs, g.ibs.p, g.coeffs.p, sf, g.pcm.p};
+  for (int i = 0; i < 11; i++) out->owned[i] = own[i];
   return M355_OK;
 }
 

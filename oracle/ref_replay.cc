@@ -15,8 +15,8 @@
  * not exercise — tiles, 10/12-bit, explicit weights, out-of-picture MVs, transform skip, every CU/TU size —
  * on the synthetic pictures the GPU parity tests use.  It is also the "reference" CPU baseline of bench.py.
  *
- * Not replayed (no such blocks in the synthetic lists; the oracle keeps its slot-level pin for them): PCM
- * blocks (read_pcm_samples consumes the bitstream), missing-reference fills.
+ * Not replayed: missing-reference fills (no such blocks in the synthetic lists).  PCM blocks: the sample store is
+ * done here (read_pcm_samples consumes the bitstream), the filters' treatment of PCM units is the reference's.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -78,7 +78,6 @@ __attribute__((visibility("default")))
 int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int stages, int accel, void* const* out_planes)
 {
   const m355_pic_params& pp = pic->pp;
-  if (pic->n_pcm) return -1;
 
   decoder_context dctx;                          /* img->decctx: acceleration table for intra / deblock / transforms */
   ReplayContext rctx;                            /* the base_context motion compensation sees */
@@ -133,6 +132,7 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
     for (int i = 0; i < pp.num_tile_rows; i++) q.rowHeight[i] = pp.row_bd[i + 1] - pp.row_bd[i];
     q.loop_filter_across_tiles_enabled_flag = (pp.flags & M355_PF_LF_ACROSS_TILES) ? 1 : 0;
     q.deblocking_filter_control_present_flag = 1;
+    q.scaling_list = sps->scaling_list;          /* transform.cc:505-508 reads the PPS copy (pps.cc copies the SPS list when it has none) */
     q.set_derived_values(sps.get());
     q.pps_read = true;
   }
@@ -292,7 +292,20 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
       const m355_ctb& cb = pic->ctbs[q.scan->CtbAddrTStoRS[ts]];
       for (uint32_t k = 0; k < cb.ib_count; k++) {
         const m355_ib& ib = pic->ibs[cb.ib_start + k];
-        if (ib.flags & M355_IBF_PCM) return -1;
+        if (ib.flags & M355_IBF_PCM) {
+          /* read_pcm_samples (slice.cc:4211-4255) consumes the bitstream and stores sample << (BitDepth - PcmBitDepth);
+             the lists carry the stored values, so the store is all that is left to do here — what this pins is the
+             REFERENCE's treatment of PCM units in the filters (pcm_loop_filter_disable, deblock.cc:576-592, sao.cc:103-120) */
+          const int n = 1 << ib.log2_size, bpp = img->get_bytes_per_pixel(ib.cidx);
+          const ptrdiff_t st = img->get_image_stride(ib.cidx);
+          for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++) {
+              const uint16_t v = pic->pcm[ib.res_ofs + y * n + x];
+              uint8_t* q = img->get_image_plane(ib.cidx) + ((size_t)(ib.y + y) * st + ib.x + x) * bpp;
+              if (bpp == 1) *q = (uint8_t)v; else *(uint16_t*)q = v;
+            }
+          continue;
+        }
         decode_intra_prediction(img, ib.x, ib.y, (IntraPredMode)ib.mode, 1 << ib.log2_size, ib.cidx);
         if ((ib.flags & M355_IBF_HAS_RESIDUAL) && (stages & M355_STAGE_RESIDUAL)) {
           auto it = deferred.find(ib.res_ofs);

@@ -14,6 +14,9 @@ CASES = [
     dict(width=128, height=128, bit_depth=8, seed=14, intra_pct=100, n_refs=0, tile_cols=2, tile_rows=1),
     dict(width=136, height=72, bit_depth=12, seed=15, log2_ctb=5, intra_pct=40),
     dict(width=128, height=64, bit_depth=8, seed=16, log2_ctb=4, fixed_cu_log2=3, cbf_pct=100),
+    dict(width=192, height=128, bit_depth=8, seed=17, n_slices=4, features=7, intra_pct=30),
+    dict(width=192, height=128, bit_depth=10, seed=18, n_slices=3, tile_cols=2, tile_rows=2, features=7),
+    dict(width=192, height=128, bit_depth=8, seed=19, features=31, intra_pct=60, n_slices=2),
 ]
 
 

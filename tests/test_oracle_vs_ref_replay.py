@@ -2,7 +2,8 @@
 (oracle/ref_replay.cc -> generate_inter_prediction_samples, scale_coefficients, decode_intra_prediction,
 apply_deblocking_filter, apply_sample_adaptive_offset_sequential of /root/reference, scalar AND SSE/AVX tables)
 must equal oracle/hevc_oracle.c bit for bit — tiles with and without filtering across them, 8/10/12-bit, CTB
-16/32/64, every CU/TU size, explicit weights, MVs far outside the picture, transform skip, intra-only pictures.
+16/32/64, every CU/TU size, explicit weights, MVs far outside the picture, transform skip, intra-only pictures,
+several slices with their own filter flags, constrained intra prediction, cu_transquant_bypass, scaling lists.
 (The first pin is the recorded girlshy stream, tests/test_girlshy_oracle.py.)  Needs oracle/_ref (built from
 /root/reference by oracle/Makefile); skipped where that is unavailable."""
 import pytest
@@ -26,6 +27,20 @@ CASES = [
     dict(width=416, height=240, bit_depth=12, seed=28, weighted_pct=30, oob_mv_pct=10),
     dict(width=64, height=64, bit_depth=8, seed=30, oob_mv_pct=100, intra_pct=0),
     dict(width=72, height=24, bit_depth=9, seed=27, log2_ctb=4, intra_pct=50),
+    # several slices (random deblock-disable / filter-across-slices / SAO flags, beta / tc offsets)
+    dict(width=256, height=192, bit_depth=8, seed=71, n_slices=4),
+    dict(width=256, height=192, bit_depth=10, seed=72, n_slices=3, tile_cols=2, tile_rows=2),
+    dict(width=384, height=256, bit_depth=8, seed=77, n_slices=6, tile_cols=3, tile_rows=2, lf_across_tiles=0, intra_pct=30),
+    # constrained_intra_pred, cu_transquant_bypass CUs, scaling lists; and all of it together
+    dict(width=256, height=192, bit_depth=8, seed=73, features=1, intra_pct=40),
+    dict(width=256, height=192, bit_depth=8, seed=74, features=2),
+    dict(width=256, height=192, bit_depth=10, seed=75, features=4),
+    dict(width=320, height=192, bit_depth=8, seed=76, features=7, n_slices=5, intra_pct=30),
+    dict(width=320, height=192, bit_depth=12, seed=78, features=7, n_slices=3, intra_pct=100, n_refs=0, log2_ctb=5),
+    # PCM coding units, with and without pcm_loop_filter_disable
+    dict(width=256, height=192, bit_depth=8, seed=81, features=8, intra_pct=50),
+    dict(width=256, height=192, bit_depth=10, seed=82, features=8 + 16 + 2, intra_pct=50, n_slices=3),
+    dict(width=256, height=192, bit_depth=8, seed=83, features=31, intra_pct=100, n_refs=0),
 ]
 STAGES = [W.STAGE_ALL, W.STAGE_INTER | W.STAGE_RESIDUAL | W.STAGE_INTRA, W.STAGE_ALL & ~W.STAGE_SAO, W.STAGE_INTER]
 
