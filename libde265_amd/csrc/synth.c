@@ -34,7 +34,7 @@ typedef struct m355_synth_cfg {
   int32_t n_slices;         /* 0/1 = one slice; else that many slices with random filter flags / offsets (whole tiles per
                                slice when the picture has tiles, arbitrary CTB runs otherwise) */
   int32_t features;         /* M355_SYN_* bits */
-  int32_t reserved[1];
+  int32_t chroma_format;    /* 0 or 1 = 4:2:0 (default), 2 = 4:2:2, 3 = 4:4:4, 4 = monochrome */
 } m355_synth_cfg;
 enum { M355_SYN_CONSTRAINED_INTRA = 1, M355_SYN_TRANSQUANT_BYPASS = 2, M355_SYN_SCALING_LIST = 4, M355_SYN_PCM = 8,
        M355_SYN_PCM_LOOP_FILTER_DISABLE = 16 };
@@ -46,6 +46,7 @@ typedef struct gen {
   vec slices, ctbs, cus, tus, pbs, wts, rbs[4], ibs, coeffs, pcm;
   uint32_t res_len;
   int ctbW, ctbH;
+  int cf;                   /* chroma_format_idc of the picture */
   int ctb_has_bypass;       /* a CU of the CTB being generated uses cu_transquant_bypass */
   int cu_bypass;            /* the CU being generated */
 } gen;
@@ -145,12 +146,30 @@ static void gen_tu(gen* g, int x, int y, int log2, int intra, int lmode, int cmo
   const int nz = gen_tb(g, 0, x, y, log2, intra, lmode, qp, NULL);
   m355_tu* tu = (m355_tu*)vpush(&g->tus, sizeof(m355_tu));
   tu->x = (uint16_t)x; tu->y = (uint16_t)y; tu->log2_size = (uint8_t)log2; tu->flags = nz ? M355_TUF_NONZERO_COEFF : 0;
-  if (log2 > 2) {
-    gen_tb(g, 1, x / 2, y / 2, log2 - 1, intra, cmode, qp, NULL);
-    gen_tb(g, 2, x / 2, y / 2, log2 - 1, intra, cmode, qp, NULL);
-  } else if (blk_idx == 3) {
-    gen_tb(g, 1, xbase / 2, ybase / 2, 2, intra, cmode, qp, NULL);
-    gen_tb(g, 2, xbase / 2, ybase / 2, 2, intra, cmode, qp, NULL);
+  /* chroma blocks of the transform unit (slice.cc:3706-3847): 4:2:0 halves both dimensions (the chroma of four 4x4
+     luma blocks is one 4x4 pair emitted after the 4th); 4:2:2 halves the width only — two square blocks stacked
+     per component; 4:4:4 follows luma down to 4x4 */
+  if (g->cf == 1) {
+    if (log2 > 2) {
+      gen_tb(g, 1, x / 2, y / 2, log2 - 1, intra, cmode, qp, NULL);
+      gen_tb(g, 2, x / 2, y / 2, log2 - 1, intra, cmode, qp, NULL);
+    } else if (blk_idx == 3) {
+      gen_tb(g, 1, xbase / 2, ybase / 2, 2, intra, cmode, qp, NULL);
+      gen_tb(g, 2, xbase / 2, ybase / 2, 2, intra, cmode, qp, NULL);
+    }
+  } else if (g->cf == 2) {
+    for (int c = 1; c <= 2; c++) {
+      if (log2 > 2) {
+        gen_tb(g, c, x / 2, y, log2 - 1, intra, cmode, qp, NULL);
+        gen_tb(g, c, x / 2, y + (1 << (log2 - 1)), log2 - 1, intra, cmode, qp, NULL);
+      } else if (blk_idx == 3) {
+        gen_tb(g, c, xbase / 2, ybase, 2, intra, cmode, qp, NULL);
+        gen_tb(g, c, xbase / 2, ybase + 4, 2, intra, cmode, qp, NULL);
+      }
+    }
+  } else if (g->cf == 3) {
+    gen_tb(g, 1, x, y, log2, intra, cmode, qp, NULL);
+    gen_tb(g, 2, x, y, log2, intra, cmode, qp, NULL);
   }
 }
 
@@ -215,13 +234,18 @@ static void gen_cu(gen* g, int x, int y, int log2)
   if (intra && !g->cu_bypass && log2 <= 5 && (c->features & M355_SYN_PCM) && rbelow(g, 10) == 0) {
     /* PCM coding unit (slice.cc:4211-4255): raw samples, no prediction, no transform tree */
     cu->pred_mode = 0; cu->part_mode = 0; cu->flags |= M355_CUF_PCM; g->ctb_has_bypass = 1;
-    for (int cidx = 0; cidx < 3; cidx++) {
-      const int l2 = cidx ? log2 - 1 : log2, n = 1 << (2 * l2);
-      m355_ib* ib = (m355_ib*)vpush(&g->ibs, sizeof(m355_ib));
-      ib->x = (uint16_t)(cidx ? x / 2 : x); ib->y = (uint16_t)(cidx ? y / 2 : y); ib->cidx = (uint8_t)cidx; ib->log2_size = (uint8_t)l2;
-      ib->mode = 1; ib->flags = M355_IBF_PCM; ib->res_ofs = (uint32_t)g->pcm.n;
+    const int ncomp = g->cf ? 3 : 1;
+    for (int cidx = 0; cidx < ncomp; cidx++) {
+      /* square raw blocks: 4:2:2 chroma (half width, full height) is two stacked squares */
+      const int subw = (cidx && (g->cf == 1 || g->cf == 2)) ? 1 : 0, subh = (cidx && g->cf == 1) ? 1 : 0;
+      const int l2 = log2 - subw, nblk = (subw && !subh) ? 2 : 1, n = 1 << (2 * l2);
       const int pcm_bits = c->bit_depth - rbelow(g, 3);           /* PcmBitDepth <= BitDepth: samples << (BitDepth - PcmBitDepth) */
-      for (int i = 0; i < n; i++) *(uint16_t*)vpush(&g->pcm, 2) = (uint16_t)(rbelow(g, 1 << pcm_bits) << (c->bit_depth - pcm_bits));
+      for (int b = 0; b < nblk; b++) {
+        m355_ib* ib = (m355_ib*)vpush(&g->ibs, sizeof(m355_ib));
+        ib->x = (uint16_t)(x >> subw); ib->y = (uint16_t)((y >> subh) + b * (1 << l2)); ib->cidx = (uint8_t)cidx; ib->log2_size = (uint8_t)l2;
+        ib->mode = 1; ib->flags = M355_IBF_PCM; ib->res_ofs = (uint32_t)g->pcm.n;
+        for (int i = 0; i < n; i++) *(uint16_t*)vpush(&g->pcm, 2) = (uint16_t)(rbelow(g, 1 << pcm_bits) << (c->bit_depth - pcm_bits));
+      }
     }
     m355_tu* tu = (m355_tu*)vpush(&g->tus, sizeof(m355_tu));
     tu->x = (uint16_t)x; tu->y = (uint16_t)y; tu->log2_size = (uint8_t)log2;
@@ -292,7 +316,8 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
   memset(out, 0, sizeof(*out));
   m355_picture* pic = &out->pic;
   m355_pic_params* pp = &pic->pp;
-  pp->width = cfg->width; pp->height = cfg->height; pp->chroma_format_idc = 1;
+  g.cf = cfg->chroma_format == 0 ? 1 : (cfg->chroma_format == 4 ? 0 : cfg->chroma_format);
+  pp->width = cfg->width; pp->height = cfg->height; pp->chroma_format_idc = (uint8_t)g.cf;
   pp->bit_depth_luma = pp->bit_depth_chroma = (uint8_t)cfg->bit_depth;
   pp->log2_ctb_size = (uint8_t)cfg->log2_ctb; pp->log2_min_tb_size = 2; pp->log2_min_cb_size = 3;
   pp->pic_cb_qp_offset = 1; pp->pic_cr_qp_offset = -1;

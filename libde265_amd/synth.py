@@ -16,7 +16,7 @@ class SynthCfg(ctypes.Structure):
                 ("width", "height", "bit_depth", "log2_ctb", "tile_cols", "tile_rows", "intra_pct", "bipred_pct",
                  "weighted_pct", "oob_mv_pct", "cbf_pct", "deblock", "sao", "n_refs", "lf_across_tiles")] + \
                [("seed", ctypes.c_uint32), ("fixed_cu_log2", ctypes.c_int32), ("n_slices", ctypes.c_int32),
-                ("features", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("features", ctypes.c_int32), ("chroma_format", ctypes.c_int32)]
 
 SYN_CONSTRAINED_INTRA, SYN_TRANSQUANT_BYPASS, SYN_SCALING_LIST, SYN_PCM, SYN_PCM_LOOP_FILTER_DISABLE = 1, 2, 4, 8, 16   # SynthCfg.features bits (csrc/synth.c)
 
@@ -54,7 +54,7 @@ CONFIGS = {
 def make_cfg(**kw):
     d = dict(width=416, height=240, bit_depth=8, log2_ctb=6, tile_cols=1, tile_rows=1, intra_pct=10, bipred_pct=50,
              weighted_pct=10, oob_mv_pct=2, cbf_pct=60, deblock=1, sao=1, n_refs=2, lf_across_tiles=1, seed=1,
-             fixed_cu_log2=0, n_slices=0, features=0)
+             fixed_cu_log2=0, n_slices=0, features=0, chroma_format=0)
     d.update(kw)
     c = SynthCfg()
     for k, v in d.items():

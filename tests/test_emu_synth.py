@@ -17,6 +17,9 @@ CASES = [
     dict(width=192, height=128, bit_depth=8, seed=17, n_slices=4, features=7, intra_pct=30),
     dict(width=192, height=128, bit_depth=10, seed=18, n_slices=3, tile_cols=2, tile_rows=2, features=7),
     dict(width=192, height=128, bit_depth=8, seed=19, features=31, intra_pct=60, n_slices=2),
+    dict(width=128, height=128, bit_depth=8, seed=31, chroma_format=4),
+    dict(width=128, height=128, bit_depth=8, seed=32, chroma_format=3, intra_pct=30, features=31),
+    dict(width=128, height=128, bit_depth=10, seed=33, chroma_format=2, intra_pct=30, features=31, tile_cols=2),
 ]
 
 

@@ -41,6 +41,12 @@ CASES = [
     dict(width=256, height=192, bit_depth=8, seed=81, features=8, intra_pct=50),
     dict(width=256, height=192, bit_depth=10, seed=82, features=8 + 16 + 2, intra_pct=50, n_slices=3),
     dict(width=256, height=192, bit_depth=8, seed=83, features=31, intra_pct=100, n_refs=0),
+    # monochrome, 4:4:4, 4:2:2 (range extensions), alone and with everything above
+    dict(width=256, height=192, bit_depth=8, seed=91, chroma_format=4),
+    dict(width=256, height=192, bit_depth=8, seed=92, chroma_format=3, intra_pct=30),
+    dict(width=256, height=192, bit_depth=10, seed=93, chroma_format=2, intra_pct=30),
+    dict(width=256, height=192, bit_depth=8, seed=94, chroma_format=3, features=31, n_slices=3, tile_cols=2, intra_pct=50),
+    dict(width=256, height=192, bit_depth=10, seed=95, chroma_format=2, features=31, n_slices=3, tile_rows=2, intra_pct=50),
 ]
 STAGES = [W.STAGE_ALL, W.STAGE_INTER | W.STAGE_RESIDUAL | W.STAGE_INTRA, W.STAGE_ALL & ~W.STAGE_SAO, W.STAGE_INTER]
 
