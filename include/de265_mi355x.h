@@ -210,7 +210,10 @@ enum {
   M355_PF_INTRA_SMOOTHING_DISABLED = 1 << 5,  /* sps.range_extension.intra_smoothing_disabled_flag       */
   M355_PF_IMPLICIT_RDPCM           = 1 << 6,  /* sps.range_extension.implicit_rdpcm_enabled_flag         */
   M355_PF_SCALING_LIST             = 1 << 7,  /* sps.scaling_list_enable_flag (transform.cc:461)         */
-  M355_PF_DEBLOCK_ENABLED          = 1 << 8   /* !DE265_DECODER_PARAM_DISABLE_DEBLOCKING (de265.h:409)   */
+  M355_PF_DEBLOCK_ENABLED          = 1 << 8,  /* !DE265_DECODER_PARAM_DISABLE_DEBLOCKING (de265.h:409)   */
+  M355_PF_CROSS_COMPONENT_PRED     = 1 << 9   /* pps.range_extension.cross_component_prediction_enabled_flag
+                                                 (4:4:4 only, transform.cc:244-260): chroma blocks may carry a
+                                                 ResScaleVal in m355_rb.matrix_id (see there)            */
 };
 
 typedef struct m355_pic_params {
@@ -325,7 +328,13 @@ typedef struct m355_rb {
   uint8_t  kind;                   /* M355_RK_* */
   uint8_t  flags;                  /* M355_RBF_* */
   uint8_t  qp;                     /* qPYPrime / qPCbPrime / qPCrPrime (transform.cc:371-377) */
-  uint8_t  matrix_id;              /* scaling-list matrixID (transform.cc:493-502); unused if no list */
+  uint8_t  matrix_id;              /* bits 0-2: scaling-list matrixID (transform.cc:493-502), unused if no list.
+                                      Cross-component prediction (M355_PF_CROSS_COMPONENT_PRED, chroma blocks): bits 4-6 =
+                                      log2_res_scale_abs_plus1 (0 = none), bit 7 = sign -> ResScaleVal = +-(1 << (v-1))
+                                      (slice.cc:3721-3760); bit 3 = the TU's luma block is rbs[i-2] (else rbs[i-1]): the
+                                      three blocks of a 4:4:4 transform unit have one size, so they sit next to each other
+                                      in their size bin.  A chroma block with cbf 0 but ResScaleVal != 0 is listed with
+                                      ncoeff 0 (slice.cc:3512-3523). */
   uint16_t ncoeff;
   uint32_t coeff_ofs;              /* first entry in coeffs[] */
   uint32_t res_ofs;                /* int16 offset in the residual buffer (DEFERRED) */

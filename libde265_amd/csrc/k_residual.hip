@@ -59,31 +59,22 @@ __device__ __forceinline__ uint32_t d_sel_u(uint32_t mask, uint32_t a, uint32_t 
 
 #define RES_LDS_DWORDS (8 * (1024 + 32))   /* 32x32: 8 blocks per workgroup, nT^2/2 coefficient pairs + nT * (nT/2+1) first-stage pairs each */
 
-template <int LOG2, class PIX>
-__device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, int rb_n, int group, uint32_t* smem)
+/* Residual of one block per lane group (all lanes of the wave call this together): res[] = row `c` of the block,
+ * NT adjacent samples, before it is added to the picture / stored.  smem pointers are the lane group's tile. */
+template <int LOG2>
+__device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb, bool active, int c, uint32_t* cfp, int* res)
 {
   constexpr int NT = 1 << LOG2, N2 = NT * NT;
-  constexpr int BPW = 64 / NT;           /* blocks per wave */
   constexpr int QN = NT / 2;             /* int16 pairs per column / row */
   constexpr int GP = QN + 1;             /* first-stage row pitch in dwords (padded: conflict-free row reads) */
-  constexpr int BLK_DW = QN * NT + NT * GP;
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = lane & (NT - 1), b = lane >> LOG2;
-  const int tbi = (group * 4 + wave) * BPW + b;
-  const bool active = tbi < rb_n;
-  uint32_t* cfp = smem + (wave * BPW + b) * BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
   uint32_t* gp = cfp + QN * NT;                        /* gp[row * GP + q]  = (g[row][2q], g[row][2q+1])       */
   int16_t* cf16 = (int16_t*)cfp;
   int16_t* g16 = (int16_t*)gp;
   int* rr = (int*)cfp;                                 /* skip / bypass residual (int32, N2 <= BLK_DW) */
-
-  m355_rb rb;
-  if (active) rb = p.rbs[rb_base + tbi];
-  else { rb.ncoeff = 0; rb.kind = M355_RK_DCT; rb.flags = 0; rb.cidx = 0; rb.qp = 0; rb.x = rb.y = 0; rb.coeff_ofs = rb.res_ofs = 0; rb.matrix_id = 0; rb.log2_size = LOG2; }
   const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
 
   /* ---- dequantise + scatter (transform.cc:408-525) ---- */
+  wave_sync();                                         /* a previous use of the tile is over */
 #pragma unroll
   for (int k = 0; k < QN; k++) cfp[k * NT + c] = 0;
   wave_sync();
@@ -98,7 +89,7 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
     const uint8_t* scl = nullptr;
     if (sclist && p.scaling) {
       const int sz_ofs = LOG2 == 2 ? 0 : LOG2 == 3 ? 6 * 16 : LOG2 == 4 ? 6 * 16 + 6 * 64 : 6 * 16 + 6 * 64 + 6 * 256;
-      scl = p.scaling + sz_ofs + rb.matrix_id * N2;
+      scl = p.scaling + sz_ofs + (rb.matrix_id & 7) * N2;
     }
     for (int k = c; k < rb.ncoeff; k += NT) {
       const uint32_t e = p.coeffs[rb.coeff_ofs + k];
@@ -129,7 +120,6 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
 
   const bool is_tr = rb.kind == M355_RK_DCT || rb.kind == M355_RK_DST;
   const bool any_tr = __any(is_tr), any_other = __any(!is_tr && active);
-  int res[NT];      /* one row (lane's `c` is the row index here), NT adjacent samples */
 #pragma unroll
   for (int i = 0; i < NT; i++) res[i] = 0;
 
@@ -200,6 +190,61 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
       if (rb.flags & M355_RBF_RDPCM_H) {
 #pragma unroll
         for (int i = 1; i < NT; i++) res[i] += res[i - 1];
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ m355_rb d_rb_idle(int log2)
+{
+  m355_rb rb;
+  rb.ncoeff = 0; rb.kind = M355_RK_DCT; rb.flags = 0; rb.cidx = 0; rb.qp = 0; rb.x = rb.y = 0; rb.coeff_ofs = rb.res_ofs = 0; rb.matrix_id = 0; rb.log2_size = (uint8_t)log2;
+  return rb;
+}
+
+template <int LOG2, class PIX>
+__device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, int rb_n, int group, uint32_t* smem)
+{
+  constexpr int NT = 1 << LOG2;
+  constexpr int BPW = 64 / NT;           /* blocks per wave */
+  constexpr int QN = NT / 2;
+  constexpr int GP = QN + 1;
+  constexpr int BLK_DW = QN * NT + NT * GP;
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & (NT - 1), b = lane >> LOG2;
+  const int tbi = (group * 4 + wave) * BPW + b;
+  const bool active = tbi < rb_n;
+  uint32_t* cfp = smem + (wave * BPW + b) * BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
+
+  m355_rb rb = d_rb_idle(LOG2);
+  if (active) rb = p.rbs[rb_base + tbi];
+  const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+
+  int res[NT];      /* one row (lane's `c` is the row index here), NT adjacent samples */
+  d_rb_compute<LOG2>(p, rb, active, c, cfp, res);
+
+  /* cross-component prediction (4:4:4 range extension; transform.cc:244-260, slice.cc:3721-3760): the chroma block
+     adds (ResScaleVal * ((rY << BitDepthC) >> BitDepthY)) >> 3 of its transform unit's LUMA residual, which this lane
+     group recomputes from the luma block's own coefficients (rbs[i-1] or rbs[i-2], see m355_rb.matrix_id) — no
+     ordering between blocks, no side buffer.  Both shifts act on the value as uint32_t, as in the reference. */
+  if (p.pp.flags & M355_PF_CROSS_COMPONENT_PRED) {
+    const int v = (active && rb.cidx) ? ((rb.matrix_id >> 4) & 7) : 0;
+    const int back = (rb.matrix_id & 8) ? 2 : 1;
+    bool ccp = v != 0 && tbi - back >= 0;
+    m355_rb rl = d_rb_idle(LOG2);
+    if (ccp) {
+      rl = p.rbs[rb_base + tbi - back];
+      if (rl.cidx != 0) { ccp = false; rl = d_rb_idle(LOG2); }
+    }
+    if (__any(ccp)) {
+      int resl[NT];
+      d_rb_compute<LOG2>(p, rl, ccp, c, cfp, resl);
+      if (ccp) {
+        const int scale = (rb.matrix_id & 0x80) ? -(1 << (v - 1)) : (1 << (v - 1));
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+          res[i] += (scale * (int)(((unsigned)resl[i] << p.pp.bit_depth_chroma) >> p.pp.bit_depth_luma)) >> 3;
       }
     }
   }

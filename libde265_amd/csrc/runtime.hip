@@ -382,7 +382,7 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
       if (rb.log2_size != s + 2 || rb.cidx > 2 || rb.kind > 3 || rb.x + n > W || rb.y + n > H) return fail(M355_ERR_INVALID, "rb %d malformed", k);
       if ((uint64_t)rb.coeff_ofs + rb.ncoeff > pic->n_coeffs) return fail(M355_ERR_INVALID, "rb %d: coefficient range", k);
       if ((rb.flags & M355_RBF_DEFERRED) && (uint64_t)rb.res_ofs + n * n > pic->res_len) return fail(M355_ERR_INVALID, "rb %d: residual range", k);
-      if ((pp.flags & M355_PF_SCALING_LIST) && rb.matrix_id > 5) return fail(M355_ERR_INVALID, "rb %d: matrix id", k);
+      if ((pp.flags & M355_PF_SCALING_LIST) && (rb.matrix_id & 7) > 5) return fail(M355_ERR_INVALID, "rb %d: matrix id", k);
       if (rb.kind == M355_RK_DST && s != 0) return fail(M355_ERR_INVALID, "rb %d: DST only exists for 4x4", k);
     }
   for (int i = 0; i < pic->n_ibs; i++) {

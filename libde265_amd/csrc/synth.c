@@ -37,7 +37,7 @@ typedef struct m355_synth_cfg {
   int32_t chroma_format;    /* 0 or 1 = 4:2:0 (default), 2 = 4:2:2, 3 = 4:4:4, 4 = monochrome */
 } m355_synth_cfg;
 enum { M355_SYN_CONSTRAINED_INTRA = 1, M355_SYN_TRANSQUANT_BYPASS = 2, M355_SYN_SCALING_LIST = 4, M355_SYN_PCM = 8,
-       M355_SYN_PCM_LOOP_FILTER_DISABLE = 16 };
+       M355_SYN_PCM_LOOP_FILTER_DISABLE = 16, M355_SYN_CROSS_COMPONENT = 32 /* 4:4:4 only */ };
 
 typedef struct { void* p; size_t n, cap, esz; } vec;
 typedef struct gen {
@@ -168,8 +168,35 @@ static void gen_tu(gen* g, int x, int y, int log2, int intra, int lmode, int cmo
       }
     }
   } else if (g->cf == 3) {
-    gen_tb(g, 1, x, y, log2, intra, cmode, qp, NULL);
-    gen_tb(g, 2, x, y, log2, intra, cmode, qp, NULL);
+    /* cross-component prediction (slice.cc:3721-3760): only with cbf_luma; a chroma block with cbf 0 but a
+       ResScaleVal is still listed (ncoeff 0); matrix_id bits 3..7 carry distance-to-luma / magnitude / sign */
+    const int ccp_ok = (g->cfg->features & M355_SYN_CROSS_COMPONENT) && nz;
+    int emitted = 0;
+    for (int c = 1; c <= 2; c++) {
+      const int v = (ccp_ok && rbelow(g, 2)) ? 1 + rbelow(g, 4) : 0, neg = v ? rbelow(g, 2) : 0;
+      const size_t before = g->rbs[log2 - 2].n;
+      const int had = gen_tb(g, c, x, y, log2, intra, cmode, qp, NULL);
+      if (!had && v) {
+        /* gen_tb pushed no block (cbf 0): list an empty one.  For intra blocks gen_tb has pushed the ib already. */
+        m355_rb* rb = (m355_rb*)vpush(&g->rbs[log2 - 2], sizeof(m355_rb));
+        rb->x = (uint16_t)x; rb->y = (uint16_t)y; rb->cidx = (uint8_t)c; rb->log2_size = (uint8_t)log2;
+        rb->qp = (uint8_t)(qp > 3 ? qp - 3 : qp); rb->kind = g->cu_bypass ? M355_RK_BYPASS : M355_RK_DCT;
+        rb->coeff_ofs = (uint32_t)g->coeffs.n; rb->ncoeff = 0;
+        if (g->cfg->features & M355_SYN_SCALING_LIST) rb->matrix_id = (uint8_t)((log2 == 5 ? 0 : c) + (intra ? 0 : (log2 < 5 ? 3 : 1)));
+        if (intra) {
+          m355_ib* ib = (m355_ib*)g->ibs.p + (g->ibs.n - 1);
+          const uint32_t n2 = 1u << (2 * log2);
+          rb->flags |= M355_RBF_DEFERRED; rb->res_ofs = g->res_len;
+          ib->flags |= M355_IBF_HAS_RESIDUAL; ib->res_ofs = g->res_len;
+          g->res_len += n2;
+        }
+      }
+      if (g->rbs[log2 - 2].n > before) {
+        m355_rb* rb = (m355_rb*)g->rbs[log2 - 2].p + (g->rbs[log2 - 2].n - 1);
+        if (v) rb->matrix_id |= (uint8_t)((v << 4) | (neg << 7) | (emitted ? 8 : 0));
+        emitted++;
+      }
+    }
   }
 }
 
@@ -325,7 +352,8 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
               (cfg->lf_across_tiles ? M355_PF_LF_ACROSS_TILES : 0) |
               ((cfg->features & M355_SYN_CONSTRAINED_INTRA) ? M355_PF_CONSTRAINED_INTRA_PRED : 0) |
               ((cfg->features & M355_SYN_SCALING_LIST) ? M355_PF_SCALING_LIST : 0) |
-              ((cfg->features & M355_SYN_PCM_LOOP_FILTER_DISABLE) ? M355_PF_PCM_LOOP_FILTER_DISABLE : 0);
+              ((cfg->features & M355_SYN_PCM_LOOP_FILTER_DISABLE) ? M355_PF_PCM_LOOP_FILTER_DISABLE : 0) |
+              (((cfg->features & M355_SYN_CROSS_COMPONENT) && g.cf == 3) ? M355_PF_CROSS_COMPONENT_PRED : 0);
   pp->num_tile_cols = (uint8_t)cfg->tile_cols; pp->num_tile_rows = (uint8_t)cfg->tile_rows;
   for (int i = 0; i <= cfg->tile_cols; i++) pp->col_bd[i] = (uint16_t)((i * g.ctbW) / cfg->tile_cols);   /* uniform spacing (pps.cc) */
   for (int i = 0; i <= cfg->tile_rows; i++) pp->row_bd[i] = (uint16_t)((i * g.ctbH) / cfg->tile_rows);

@@ -18,7 +18,7 @@ class SynthCfg(ctypes.Structure):
                [("seed", ctypes.c_uint32), ("fixed_cu_log2", ctypes.c_int32), ("n_slices", ctypes.c_int32),
                 ("features", ctypes.c_int32), ("chroma_format", ctypes.c_int32)]
 
-SYN_CONSTRAINED_INTRA, SYN_TRANSQUANT_BYPASS, SYN_SCALING_LIST, SYN_PCM, SYN_PCM_LOOP_FILTER_DISABLE = 1, 2, 4, 8, 16   # SynthCfg.features bits (csrc/synth.c)
+SYN_CONSTRAINED_INTRA, SYN_TRANSQUANT_BYPASS, SYN_SCALING_LIST, SYN_PCM, SYN_PCM_LOOP_FILTER_DISABLE, SYN_CROSS_COMPONENT = 1, 2, 4, 8, 16, 32   # SynthCfg.features bits (csrc/synth.c)
 
 
 class _SynthOut(ctypes.Structure):

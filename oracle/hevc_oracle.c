@@ -644,6 +644,50 @@ static void do_inter(pic_state* s) {
 
 static const int level_scale[6] = {40, 45, 51, 57, 64, 72}; /* transform.cc:358 */
 
+/* residual of one block before it is added / stored: dequant + transform / skip / bypass (transform.cc:361-607) */
+static void rb_residual(pic_state* s, const m355_rb* rb, int32_t* r) {
+  const m355_picture* pic = s->pic;
+  const m355_pic_params* pp = s->pp;
+  const int nT = 1 << rb->log2_size, bd = rb->cidx ? pp->bit_depth_chroma : pp->bit_depth_luma;
+  int16_t coeff[32 * 32];
+  memset(coeff, 0, sizeof(int16_t) * nT * nT);
+  /* --- inverse quantisation (transform.cc:408-525) --- */
+  for (int k = 0; k < rb->ncoeff; k++) {
+    const uint32_t e = pic->coeffs[rb->coeff_ofs + k];
+    const int pos = e & 0xFFFF;
+    const int lvl = (int16_t)(e >> 16);
+    if (pos >= nT * nT) continue;
+    if (rb->kind == M355_RK_BYPASS || (rb->flags & M355_RBF_DEQUANTIZED)) { coeff[pos] = (int16_t)lvl; continue; }
+    int bdShift = bd + rb->log2_size - 5;
+    int64_t fact;
+    if (!(pp->flags & M355_PF_SCALING_LIST)) { bdShift -= 4; fact = (int64_t)level_scale[rb->qp % 6] << (rb->qp / 6); }
+    else {
+      static const int sz_ofs[4] = {0, 6 * 16, 6 * 16 + 6 * 64, 6 * 16 + 6 * 64 + 6 * 256};
+      const uint8_t* scl = pic->scaling_factors + sz_ofs[rb->log2_size - 2] + (rb->matrix_id & 7) * nT * nT;
+      fact = (int64_t)(scl[pos] * level_scale[rb->qp % 6]) << (rb->qp / 6);
+    }
+    const int64_t offset = (int64_t)1 << (bdShift - 1);
+    int64_t v = ((int64_t)lvl * fact + offset) >> bdShift;
+    coeff[pos] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+  }
+  /* --- transform / skip / bypass (transform.cc:404-447, :530-607) --- */
+  if (rb->flags & M355_RBF_ROTATE) o_rotate_coefficients(coeff, nT);
+  if (rb->kind == M355_RK_BYPASS) {
+    if (rb->flags & M355_RBF_RDPCM_V) o_transform_bypass_rdpcm_v(r, coeff, nT);
+    else if (rb->flags & M355_RBF_RDPCM_H) o_transform_bypass_rdpcm_h(r, coeff, nT);
+    else o_transform_bypass(r, coeff, nT);
+  } else if (rb->kind == M355_RK_SKIP) {
+    const int bdShift2 = 20 - bd, tsShift = 5 + rb->log2_size; /* transform.cc:550-554 (no extended precision) */
+    if (rb->flags & M355_RBF_RDPCM_V) o_rdpcm_v(r, coeff, nT, tsShift, bdShift2);
+    else if (rb->flags & M355_RBF_RDPCM_H) o_rdpcm_h(r, coeff, nT, tsShift, bdShift2);
+    else o_transform_skip_residual(r, coeff, nT, tsShift, bdShift2);
+  } else {
+    /* with cross_component_prediction_enabled_flag the reference goes through transform_idct_NxN + add_residual
+       (transform.cc:611-616) with max_coeff_bits 15: the same arithmetic as the *_add slots */
+    inv_transform(r, coeff, nT, rb->kind == M355_RK_DST, 20 - bd, -32768, 32767);
+  }
+}
+
 static void do_residual(pic_state* s) {
   const m355_picture* pic = s->pic;
   const m355_pic_params* pp = s->pp;
@@ -651,41 +695,22 @@ static void do_residual(pic_state* s) {
   for (int i = 0; i < nrb; i++) {
     const m355_rb* rb = &pic->rbs[i];
     const int nT = 1 << rb->log2_size, bd = rb->cidx ? pp->bit_depth_chroma : pp->bit_depth_luma;
-    int16_t coeff[32 * 32];
     int32_t r[32 * 32];
-    memset(coeff, 0, sizeof(int16_t) * nT * nT);
-    /* --- inverse quantisation (transform.cc:408-525) --- */
-    for (int k = 0; k < rb->ncoeff; k++) {
-      const uint32_t e = pic->coeffs[rb->coeff_ofs + k];
-      const int pos = e & 0xFFFF;
-      const int lvl = (int16_t)(e >> 16);
-      if (pos >= nT * nT) continue;
-      if (rb->kind == M355_RK_BYPASS || (rb->flags & M355_RBF_DEQUANTIZED)) { coeff[pos] = (int16_t)lvl; continue; }
-      int bdShift = bd + rb->log2_size - 5;
-      int64_t fact;
-      if (!(pp->flags & M355_PF_SCALING_LIST)) { bdShift -= 4; fact = (int64_t)level_scale[rb->qp % 6] << (rb->qp / 6); }
-      else {
-        static const int sz_ofs[4] = {0, 6 * 16, 6 * 16 + 6 * 64, 6 * 16 + 6 * 64 + 6 * 256};
-        const uint8_t* scl = pic->scaling_factors + sz_ofs[rb->log2_size - 2] + rb->matrix_id * nT * nT;
-        fact = (int64_t)(scl[pos] * level_scale[rb->qp % 6]) << (rb->qp / 6);
+    rb_residual(s, rb, r);
+    /* cross-component prediction (transform.cc:244-260, slice.cc:3721-3760): chroma residual += (ResScaleVal *
+       ((rY << BitDepthC) >> BitDepthY)) >> 3 with the luma residual of the same transform unit.  The reference does
+       both shifts on the value cast to uint32_t, i.e. the right shift is LOGICAL (a negative rY loses its sign):
+       restated literally. */
+    if ((pp->flags & M355_PF_CROSS_COMPONENT_PRED) && rb->cidx && ((rb->matrix_id >> 4) & 7)) {
+      const int v = (rb->matrix_id >> 4) & 7;
+      const int res_scale = (rb->matrix_id & 0x80) ? -(1 << (v - 1)) : (1 << (v - 1));
+      const int back = (rb->matrix_id & 8) ? 2 : 1;
+      if (i - back >= 0 && pic->rbs[i - back].cidx == 0 && pic->rbs[i - back].log2_size == rb->log2_size) {
+        int32_t rl[32 * 32];
+        rb_residual(s, &pic->rbs[i - back], rl);
+        for (int k = 0; k < nT * nT; k++)
+          r[k] += (res_scale * (int32_t)(((uint32_t)rl[k] << pp->bit_depth_chroma) >> pp->bit_depth_luma)) >> 3;
       }
-      const int64_t offset = (int64_t)1 << (bdShift - 1);
-      int64_t v = ((int64_t)lvl * fact + offset) >> bdShift;
-      coeff[pos] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
-    }
-    /* --- transform / skip / bypass (transform.cc:404-447, :530-607) --- */
-    if (rb->flags & M355_RBF_ROTATE) o_rotate_coefficients(coeff, nT);
-    if (rb->kind == M355_RK_BYPASS) {
-      if (rb->flags & M355_RBF_RDPCM_V) o_transform_bypass_rdpcm_v(r, coeff, nT);
-      else if (rb->flags & M355_RBF_RDPCM_H) o_transform_bypass_rdpcm_h(r, coeff, nT);
-      else o_transform_bypass(r, coeff, nT);
-    } else if (rb->kind == M355_RK_SKIP) {
-      const int bdShift2 = 20 - bd, tsShift = 5 + rb->log2_size; /* transform.cc:550-554 (no extended precision) */
-      if (rb->flags & M355_RBF_RDPCM_V) o_rdpcm_v(r, coeff, nT, tsShift, bdShift2);
-      else if (rb->flags & M355_RBF_RDPCM_H) o_rdpcm_h(r, coeff, nT, tsShift, bdShift2);
-      else o_transform_skip_residual(r, coeff, nT, tsShift, bdShift2);
-    } else {
-      inv_transform(r, coeff, nT, rb->kind == M355_RK_DST, 20 - bd, -32768, 32767);
     }
     if (rb->flags & M355_RBF_DEFERRED) {
       for (int k = 0; k < nT * nT; k++) s->resbuf[rb->res_ofs + k] = (int16_t)clip3(-32768, 32767, r[k]);

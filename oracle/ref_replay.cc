@@ -132,6 +132,7 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
     for (int i = 0; i < pp.num_tile_rows; i++) q.rowHeight[i] = pp.row_bd[i + 1] - pp.row_bd[i];
     q.loop_filter_across_tiles_enabled_flag = (pp.flags & M355_PF_LF_ACROSS_TILES) ? 1 : 0;
     q.deblocking_filter_control_present_flag = 1;
+    q.range_extension.cross_component_prediction_enabled_flag = (pp.flags & M355_PF_CROSS_COMPONENT_PRED) != 0;
     q.scaling_list = sps->scaling_list;          /* transform.cc:505-508 reads the PPS copy (pps.cc copies the SPS list when it has none) */
     q.set_derived_values(sps.get());
     q.pps_read = true;
@@ -273,6 +274,11 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
     tctx->qPYPrime = tctx->qPCbPrime = tctx->qPCrPrime = rb.qp;
     tctx->cu_transquant_bypass_flag = rb.kind == M355_RK_BYPASS;
     tctx->ResScaleVal = 0;
+    if ((pp.flags & M355_PF_CROSS_COMPONENT_PRED) && c && ((rb.matrix_id >> 4) & 7)) {
+      /* the TU's luma block ran just before (list / decode order), so tctx->residual_luma is this TU's */
+      const int v = (rb.matrix_id >> 4) & 7;
+      tctx->ResScaleVal = (rb.matrix_id & 0x80) ? -(1 << (v - 1)) : (1 << (v - 1));
+    }
     const int rdpcm = (rb.flags & M355_RBF_RDPCM_H) ? 1 : ((rb.flags & M355_RBF_RDPCM_V) ? 2 : 0);
     const bool intra = img->get_pred_mode(xl, yl) == MODE_INTRA;
     scale_coefficients(tctx.get(), rb.x, rb.y, rb.x, rb.y, nT, c, rb.kind == M355_RK_SKIP, intra, rdpcm);

@@ -20,6 +20,8 @@ CASES = [
     dict(width=128, height=128, bit_depth=8, seed=31, chroma_format=4),
     dict(width=128, height=128, bit_depth=8, seed=32, chroma_format=3, intra_pct=30, features=31),
     dict(width=128, height=128, bit_depth=10, seed=33, chroma_format=2, intra_pct=30, features=31, tile_cols=2),
+    dict(width=128, height=128, bit_depth=8, seed=34, chroma_format=3, intra_pct=30, features=32),
+    dict(width=192, height=128, bit_depth=10, seed=35, chroma_format=3, intra_pct=40, features=63, log2_ctb=5),
 ]
 
 

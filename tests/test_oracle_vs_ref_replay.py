@@ -47,6 +47,9 @@ CASES = [
     dict(width=256, height=192, bit_depth=10, seed=93, chroma_format=2, intra_pct=30),
     dict(width=256, height=192, bit_depth=8, seed=94, chroma_format=3, features=31, n_slices=3, tile_cols=2, intra_pct=50),
     dict(width=256, height=192, bit_depth=10, seed=95, chroma_format=2, features=31, n_slices=3, tile_rows=2, intra_pct=50),
+    # cross-component prediction (4:4:4), incl. chroma blocks without coefficients and bypass / scaling-list CUs
+    dict(width=256, height=192, bit_depth=8, seed=101, chroma_format=3, features=32, intra_pct=30),
+    dict(width=256, height=192, bit_depth=10, seed=102, chroma_format=3, features=32 + 31, intra_pct=50, n_slices=2),
 ]
 STAGES = [W.STAGE_ALL, W.STAGE_INTER | W.STAGE_RESIDUAL | W.STAGE_INTRA, W.STAGE_ALL & ~W.STAGE_SAO, W.STAGE_INTER]
 
