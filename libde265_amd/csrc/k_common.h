@@ -71,8 +71,9 @@ struct DevPic {
   uint32_t* ticket;                 /* work counter */
   uint32_t* timeout;                /* set when a spin bound is exceeded */
   uint32_t epoch;                   /* value meaning "done" for this submission */
-  const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks, decode order */
-  int n_intra_work;
+  const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks: first the n_intra_free CTBs that wait
+                                       for nobody, then the others in decode order */
+  int n_intra_work, n_intra_free;
   const uint8_t* ctb_dep;           /* per CTB: bit n = wait for neighbour n (0 L, 1 TL, 2 T, 3 TR); bit 4 = somebody waits for us */
   /* tile sharding (k_shard.hip): NULL = this context owns the whole picture */
   const uint8_t* ctb_owner;         /* per CTB (raster): 1 = a tile of this rank */

@@ -26,7 +26,10 @@
 #include "k_common.h"
 
 #define MAXCTB 64
-#define BODY_PITCH (MAXCTB + 8)   /* 144 B rows: sample x lives at column x + 8 (16-byte aligned 8-sample vectors), left halo at column 7 */
+/* body rows of a component: CTB width + 8 samples — sample x lives at column x + 8 (16-byte aligned 8-sample vectors),
+   the left halo at column 7.  Chroma bodies are sized for the chroma format (template parameter CF): the LDS
+   footprint decides how many CTBs a CU works on at once, and this stage lives on concurrency. */
+#define BODY_PITCH_OF(cw) ((cw) + 8)
 #define BODY_X0 8
 #define SPIN_LIMIT (1u << 24)
 
@@ -60,12 +63,14 @@ __device__ __forceinline__ int d_subst_src(int e, unsigned long long m0, unsigne
   return 128;
 }
 
-template <class PIX>
-__global__ void __launch_bounds__(192) k_intra(DevPic p)
+template <class PIX, int CF>
+__global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work_n, int use_ticket)
 {
   /* per component: top halo row (x = -1 .. 2*cw-1, index x+1) and body rows with a left halo column */
+  constexpr int CW_C = (CF == 1 || CF == 2) ? MAXCTB / 2 : MAXCTB, CH_C = CF == 1 ? MAXCTB / 2 : MAXCTB;   /* chroma CTB size */
+  constexpr int BODY_L = MAXCTB * BODY_PITCH_OF(MAXCTB), BODY_C = CF == 0 ? 8 : CH_C * BODY_PITCH_OF(CW_C);
   __shared__ uint16_t s_top[3][2 * MAXCTB + 2];
-  __shared__ __attribute__((aligned(16))) uint16_t s_body[3][MAXCTB * BODY_PITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t s_body[BODY_L + 2 * BODY_C];
   __shared__ uint16_t s_raw[3][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
   __shared__ uint16_t s_p[3][4 * 32 + 8];        /* substituted border */
   __shared__ uint16_t s_f[3][4 * 32 + 8];        /* filtered border */
@@ -76,10 +81,10 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
 
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
-  if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
+  if (threadIdx.x == 0) s_ticket = use_ticket ? atomicAdd(p.ticket, 1u) : blockIdx.x;
   __syncthreads();
-  if ((int)s_ticket >= p.n_intra_work) return;
-  const int ctb = (int)p.intra_work[s_ticket];
+  if ((int)s_ticket >= work_n) return;
+  const int ctb = (int)p.intra_work[work_base + (int)s_ticket];
   const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
   const m355_ctb ctbinfo = p.ctbs[ctb];
   const int l2c = p.pp.log2_ctb_size;
@@ -115,7 +120,8 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
   PIX* plane = (PIX*)p.plane[cs];
   const int stride = p.stride[cs], pw = p.pw[cs], ph = p.ph[cs];
   uint16_t* top = s_top[cs];
-  uint16_t* body = s_body[cs];
+  uint16_t* body = s_body + (cs == 0 ? 0 : BODY_L + (cs - 1) * BODY_C);
+  const int BODY_PITCH = cs == 0 ? BODY_PITCH_OF(MAXCTB) : BODY_PITCH_OF(CW_C);
   uint16_t* raw = s_raw[cs];
   uint16_t* pp_ = s_p[cs];
   uint16_t* pf = s_f[cs];
@@ -395,11 +401,20 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p)
   }
 }
 
+template <class PIX, int CF>
+static void launch_intra_cf(const DevPic& p, hipStream_t st)
+{
+  hipMemsetAsync(p.ticket, 0, 4, st);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF>), dim3(p.n_intra_work), dim3(192), 0, st, p, 0, p.n_intra_work, 1);
+}
+
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)
 {
   if (!p.n_intra_work) return;
-  hipMemsetAsync(p.ticket, 0, 4, st);
-  const dim3 grid(p.n_intra_work), block(192);
-  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<uint16_t>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<uint8_t>), grid, block, 0, st, p);
+  switch (p.pp.chroma_format_idc) {
+    case 0: if (hbd) launch_intra_cf<uint16_t, 0>(p, st); else launch_intra_cf<uint8_t, 0>(p, st); break;
+    case 1: if (hbd) launch_intra_cf<uint16_t, 1>(p, st); else launch_intra_cf<uint8_t, 1>(p, st); break;
+    case 2: if (hbd) launch_intra_cf<uint16_t, 2>(p, st); else launch_intra_cf<uint8_t, 2>(p, st); break;
+    default: if (hbd) launch_intra_cf<uint16_t, 3>(p, st); else launch_intra_cf<uint8_t, 3>(p, st); break;
+  }
 }

@@ -13,7 +13,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "k_common.h"
@@ -538,9 +540,24 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
         }
       tidx++;
     }
-  int nw = 0;
-  for (int t = 0; t < nCtb; t++)
-    if (pic->ctbs[ts2rs[t]].ib_count) iw[nw++] = ts2rs[t];
+  /* intra work list (claimed in this order through k_intra's ticket): first the CTBs that wait for no neighbour,
+     LONGEST FIRST (a CTB's blocks are a serial chain, so the CTB with the most blocks is the stage's critical path:
+     it must start at once, not at a random point of the launch), then the dependent ones in decode order.  A
+     workgroup still only ever waits on lower tickets: free CTBs never wait, dependent ones wait on free ones (all
+     earlier) or on dependent ones earlier in decode order. */
+  intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
+  int nw = 0, n_free = 0;
+  {
+    const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
+    std::vector<std::pair<uint32_t, uint32_t>> freec;     /* (block count, raster address) */
+    for (int t = 0; t < nCtb; t++)
+      if (pic->ctbs[ts2rs[t]].ib_count && !(dep[ts2rs[t]] & 15)) freec.push_back(std::make_pair(pic->ctbs[ts2rs[t]].ib_count, ts2rs[t]));
+    std::stable_sort(freec.begin(), freec.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
+    for (const auto& e : freec) iw[nw++] = e.second;
+    n_free = nw;
+    for (int t = 0; t < nCtb; t++)
+      if (pic->ctbs[ts2rs[t]].ib_count && (dep[ts2rs[t]] & 15)) iw[nw++] = ts2rs[t];
+  }
   r.n_intra_work = nw;
   {
     /* job counts per range (k_inter_jobs) and, per 256-PB chunk (= one k_meta_pb workgroup), the first job
@@ -567,7 +584,6 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     }
     r.n_jobs = (int)nj; r.n_jobs_main = (int)nm; r.n_jobs_uni = (int)nu;
   }
-  intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
   if (sharded) {
     uint8_t* ow = (uint8_t*)(r.host + seg[i_ow].ofs);
     const int n_tiles = pp.num_tile_cols * pp.num_tile_rows;
@@ -610,7 +626,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.ts2rs = (const uint32_t*)(r.dev + seg[i_rs].ofs);
   d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
   d.intra_work = (const uint32_t*)(r.dev + seg[i_iw].ofs);
-  d.n_intra_work = nw;
+  d.n_intra_work = nw; d.n_intra_free = n_free;
   d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main; d.n_jobs_uni = r.n_jobs_uni;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
   d.job_base = (const uint32_t*)(r.dev + seg[i_jb].ofs);
