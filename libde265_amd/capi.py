@@ -49,6 +49,7 @@ class Library:
         L.m355_picture_release.argtypes = [vp, i]
         L.m355_decode_resident.argtypes = [vp, i]
         L.m355_set_stages.argtypes = [vp, i]
+        L.m355_set_pipeline_depth.argtypes = [vp, i]
         L.m355_timing_reset.argtypes = [vp]
         L.m355_timing_collect.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.m355_stream.argtypes = [vp]
@@ -153,6 +154,9 @@ class Context:
 
     def set_stages(self, mask):
         self.L.check(self.L.lib.m355_set_stages(self.h, mask))
+
+    def set_pipeline_depth(self, depth):
+        self.L.check(self.L.lib.m355_set_pipeline_depth(self.h, depth))
 
     def timing_reset(self):
         self.L.check(self.L.lib.m355_timing_reset(self.h))

@@ -35,6 +35,9 @@ struct Frame {
   int w = 0, h = 0, cf = 0, bdl = 0, bdc = 0;
   int pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0}, stride[3] = {0, 0, 0}, bpp[3] = {1, 1, 1};
   void* plane[3] = {nullptr, nullptr, nullptr};
+  /* pictures in flight on different lanes (m355_set_pipeline_depth): last writer / last readers per lane */
+  hipEvent_t ev_wr = nullptr, ev_rd[2] = {nullptr, nullptr};
+  bool wr_pending = false, rd_pending[2] = {false, false};
 };
 
 static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
@@ -68,6 +71,9 @@ static int frame_alloc(Frame& f, hipStream_t st)
 static void frame_free(Frame& f)
 {
   for (int c = 0; c < 3; c++) { if (f.plane[c]) hipFree(f.plane[c]); f.plane[c] = nullptr; }
+  if (f.ev_wr) hipEventDestroy(f.ev_wr);
+  for (int k = 0; k < 2; k++) if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]);
+  f.ev_wr = f.ev_rd[0] = f.ev_rd[1] = nullptr; f.wr_pending = f.rd_pending[0] = f.rd_pending[1] = false;
   f.used = false;
 }
 
@@ -91,10 +97,30 @@ struct Resident {
   DevPic live;                 /* the descriptor prepared by phase 0, reused by phases 1..4 */
   bool live_sao = false, live_valid = false;
   void* xprev = nullptr;       /* exchange buffer handed to the previous phase */
+  hipEvent_t ev_up = nullptr;  /* lists copied to the device (decodes on the other lane wait for it) */
+};
+
+/* Everything ONE picture in flight writes: streams, working planes, metadata / job / residual scratch.  The context's
+ * own fields of the same names are the ACTIVE lane; select_lane() swaps them with the parked copy, so all the code
+ * below keeps addressing c->stream, c->work, c->resbuf ... (m355_set_pipeline_depth(ctx, 2) decodes consecutive
+ * pictures alternately on two lanes: the dependency-bound tail of one picture's intra stage and its filters overlap
+ * the next picture's prediction; frame hazards are ordered with per-frame events). */
+struct Lane {
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  Frame work;
+  uint32_t *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
+  uint8_t *edge_tu = nullptr, *cuf = nullptr;
+  int16_t* resbuf = nullptr;
+  uint32_t* jobs = nullptr;
+  uint16_t* sao_nb = nullptr;
+  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
 };
 
 struct m355_ctx {
   int device = 0;
+  Lane parked;                 /* the lane that is not active (valid when depth == 2) */
+  int depth = 1, active = 0;   /* pipeline depth, index of the active lane */
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -116,6 +142,50 @@ struct m355_ctx {
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
 };
+
+#define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_join) X(work) X(pb_of) X(ctb_done) X(ticket) X(timeout) X(edge_tu) X(cuf) \
+  X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_ctb) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
+static void select_lane(m355_ctx* c, int lane)
+{
+  if (c->depth < 2 || lane == c->active) return;
+#define SWAP_FIELD(f) std::swap(c->f, c->parked.f);
+  LANE_FIELDS(SWAP_FIELD)
+#undef SWAP_FIELD
+  c->active = lane;
+}
+static int lane_create(m355_ctx* c, Lane& l)
+{
+  HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&l.stream2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming));
+  HIPCHK(hipMalloc(&l.ticket, 64));
+  HIPCHK(hipMalloc(&l.timeout, 64));
+  HIPCHK(hipMemsetAsync(l.ticket, 0, 64, l.stream));
+  HIPCHK(hipMemsetAsync(l.timeout, 0, 64, l.stream));
+  HIPCHK(hipStreamSynchronize(l.stream));
+  return M355_OK;
+}
+static void lane_destroy(Lane& l)
+{
+  if (l.stream) hipStreamSynchronize(l.stream);
+  if (l.stream2) hipStreamSynchronize(l.stream2);
+  if (l.work.used) frame_free(l.work);
+  void* bufs[] = {l.pb_of, l.ctb_done, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb};
+  for (void* b : bufs) if (b) hipFree(b);
+  if (l.ev_fork) hipEventDestroy(l.ev_fork);
+  if (l.ev_join) hipEventDestroy(l.ev_join);
+  if (l.stream2) hipStreamDestroy(l.stream2);
+  if (l.stream) hipStreamDestroy(l.stream);
+  l = Lane();
+}
+/* all work of the context, on every lane */
+static hipError_t sync_all(m355_ctx* c)
+{
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (c->depth >= 2 && c->parked.stream) { hipError_t e2 = hipStreamSynchronize(c->parked.stream); if (e == hipSuccess) e = e2; }
+  return e;
+}
 
 template <class T> static int grow(T** p, size_t* cap, size_t need, hipStream_t st, bool zero)
 {
@@ -205,15 +275,13 @@ int m355_create(int device, m355_ctx** out)
   HIPCHK(hipSetDevice(device));
   m355_ctx* c = new m355_ctx;
   c->device = device;
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  HIPCHK(hipMalloc(&c->ticket, 64));
-  HIPCHK(hipMalloc(&c->timeout, 64));
-  HIPCHK(hipMemsetAsync(c->ticket, 0, 64, c->stream));
-  HIPCHK(hipMemsetAsync(c->timeout, 0, 64, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  {
+    Lane l;
+    int rc = lane_create(c, l);
+    if (rc) { lane_destroy(l); delete c; return rc; }
+    c->parked = l; c->depth = 2; c->active = 1; select_lane(c, 0); c->depth = 1;   /* move it into the active fields */
+    c->parked = Lane();
+  }
   *out = c;
   return M355_OK;
 }
@@ -224,6 +292,7 @@ static void resident_free(Resident& r)
   if (r.host) hipHostFree(r.host);
   if (r.refs_dev) hipFree(r.refs_dev);
   if (r.refs_host) hipHostFree(r.refs_host);
+  if (r.ev_up) hipEventDestroy(r.ev_up);
   r = Resident();
 }
 
@@ -231,19 +300,39 @@ void m355_destroy(m355_ctx* c)
 {
   if (!c) return;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  sync_all(c);
   for (auto& f : c->frames) if (f.used) frame_free(f);
-  if (c->work.used) frame_free(c->work);
   for (auto& r : c->resident) if (r.used) resident_free(r);
   resident_free(c->transient);
-  void* bufs[] = {c->pb_of, c->ctb_done, c->ticket, c->timeout, c->edge_tu, c->cuf, c->resbuf, c->jobs, c->sao_nb};
-  for (void* b : bufs) if (b) hipFree(b);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
-  hipStreamDestroy(c->stream);
-  if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
-  if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  if (c->ev_join) hipEventDestroy(c->ev_join);
+  {
+    /* the active lane lives in the context's own fields: collect it into a Lane and destroy both */
+    Lane a;
+#define MOVE_FIELD(f) a.f = c->f;
+    LANE_FIELDS(MOVE_FIELD)
+#undef MOVE_FIELD
+    lane_destroy(a);
+    lane_destroy(c->parked);
+  }
   delete c;
+}
+
+/* 1: pictures run one after the other on the context's stream (default).  2: consecutive decodes alternate between two
+ * lanes (own streams, working planes and scratch) and overlap wherever the frames they touch allow it: a decode waits
+ * for the last writer of every reference frame it reads, and — only right before its first write — for the last writer
+ * and the readers of its destination frame. */
+int m355_set_pipeline_depth(m355_ctx* c, int depth)
+{
+  if (depth < 1 || depth > 2) return fail(M355_ERR_INVALID, "pipeline depth must be 1 or 2");
+  hipSetDevice(c->device);
+  HIPCHK(sync_all(c));
+  if (depth == 2 && !c->parked.stream) {
+    int rc = lane_create(c, c->parked);
+    if (rc) return rc;
+  }
+  if (depth == 1) select_lane(c, 0);
+  c->depth = depth;
+  return M355_OK;
 }
 
 void* m355_stream(m355_ctx* c) { return (void*)c->stream; }
@@ -275,7 +364,7 @@ int m355_frame_destroy(m355_ctx* c, int h)
   Frame* f = get_frame(c, h);
   if (!f) return fail(M355_ERR_INVALID, "bad frame handle %d", h);
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  sync_all(c);
   frame_free(*f);
   return M355_OK;
 }
@@ -284,7 +373,7 @@ int m355_frame_upload(m355_ctx* c, int h, int cidx, const void* src, ptrdiff_t s
   Frame* f = get_frame(c, h);
   if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
   hipSetDevice(c->device);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(sync_all(c));
   HIPCHK(hipMemcpy2D(f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx], src, (size_t)stride * f->bpp[cidx],
                      (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyHostToDevice));
   return M355_OK;
@@ -294,7 +383,7 @@ int m355_frame_download(m355_ctx* c, int h, int cidx, void* dst, ptrdiff_t strid
   Frame* f = get_frame(c, h);
   if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
   hipSetDevice(c->device);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(sync_all(c));
   HIPCHK(hipMemcpy2D(dst, (size_t)stride * f->bpp[cidx], f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx],
                      (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyDeviceToHost));
   return M355_OK;
@@ -304,12 +393,12 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
   Frame* f = get_frame(c, h);
   if (!f) return fail(M355_ERR_INVALID, "bad frame handle %d", h);
   hipSetDevice(c->device);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(sync_all(c));
   for (int cc = 0; cc < 3; cc++) {
     if (!f->pw[cc]) continue;
     const size_t n = (size_t)f->stride[cc] * f->ph[cc];
     const int v = cc ? vc : vl;
-    if (f->bpp[cc] == 1) { HIPCHK(hipMemsetAsync(f->plane[cc], v, n, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
+    if (f->bpp[cc] == 1) { HIPCHK(hipMemsetAsync(f->plane[cc], v, n, c->stream)); HIPCHK(sync_all(c)); }
     else {
       std::vector<uint16_t> tmp(n, (uint16_t)v);
       HIPCHK(hipMemcpy(f->plane[cc], tmp.data(), n * 2, hipMemcpyHostToDevice));
@@ -513,7 +602,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
 
   hipSetDevice(c->device);
   if (total > r.cap) {
-    if (r.dev || r.host) HIPCHK(hipStreamSynchronize(c->stream));
+    if (r.dev || r.host) HIPCHK(sync_all(c));
     if (r.dev) hipFree(r.dev);
     if (r.host) hipHostFree(r.host);
     r.dev = r.host = nullptr;
@@ -522,7 +611,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     HIPCHK(hipHostMalloc(&r.host, r.cap, hipHostMallocDefault));
   } else {
     /* the staging arena may still be in flight from the previous submission */
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
   }
   for (int i = 0; i < ns; i++)
     if (seg[i].src && seg[i].bytes) memcpy(r.host + seg[i].ofs, seg[i].src, seg[i].bytes);
@@ -598,6 +687,8 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   r.sharded = sharded; r.shard_rank = c->shard_rank; r.shard_n = c->shard_n; r.halo = halo; r.live_valid = false; r.xprev = nullptr;
   r.bytes = total;
   HIPCHK(hipMemcpyAsync(r.dev, r.host, total, hipMemcpyHostToDevice, c->stream));
+  if (!r.ev_up) HIPCHK(hipEventCreateWithFlags(&r.ev_up, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(r.ev_up, c->stream));      /* a decode on the other lane waits for the lists */
 
   r.hdr = *pic;
   DevPic& d = r.dp;
@@ -667,7 +758,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
     r.refs_valid = false;
   }
   if (!r.refs_valid || memcmp(r.refs_host, refs, sizeof(refs)) != 0) {
-    HIPCHK(hipStreamSynchronize(c->stream));       /* the staging copy may still be in flight */
+    HIPCHK(sync_all(c));       /* the staging copy may still be in flight */
     memcpy(r.refs_host, refs, sizeof(refs));
     HIPCHK(hipMemcpyAsync(r.refs_dev, r.refs_host, sizeof(refs), hipMemcpyHostToDevice, c->stream));
     r.refs_valid = true;
@@ -692,7 +783,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   Frame* target = dst;
   if (want_sao) {
     if (!c->work.used || c->work.w != dst->w || c->work.h != dst->h || c->work.cf != dst->cf || c->work.bdl != dst->bdl || c->work.bdc != dst->bdc) {
-      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(sync_all(c));
       if (c->work.used) frame_free(c->work);
       frame_geometry(c->work, dst->w, dst->h, dst->cf, dst->bdl, dst->bdc);
       if ((rc = frame_alloc(c->work, c->stream))) return rc;
@@ -716,21 +807,46 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   return M355_OK;
 }
 
+static hipError_t frame_event(hipEvent_t* e)
+{
+  if (*e) return hipSuccess;
+  return hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+
 static int decode(m355_ctx* c, Resident& r)
 {
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
+  if (c->depth == 2) select_lane(c, c->active ^ 1);          /* consecutive pictures alternate between the lanes */
   DevPic d;
   bool want_sao;
   int rc = prepare(c, r, d, want_sao);
   if (rc) return rc;
   const m355_pic_params& pp = r.hdr.pp;
   const bool hbd = pp.bit_depth_luma > 8;
+  const bool piped = c->depth == 2;
+  Frame* dstf = get_frame(c, r.hdr.dst_frame);
+  if (piped) {
+    /* read-after-write: the lists (uploaded on whichever lane was active) and every reference frame's last writer */
+    if (r.ev_up) hipStreamWaitEvent(c->stream, r.ev_up, 0);
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+      if (f && f->wr_pending) hipStreamWaitEvent(c->stream, f->ev_wr, 0);
+    }
+  }
+  /* write-after-write / write-after-read on the destination: waited for right before the first kernel that writes
+     it — the SAO stage when SAO runs (everything before writes this lane's working planes), else the first stage */
+  auto dst_hazards = [&]() {
+    if (!piped) return;
+    if (dstf->wr_pending) hipStreamWaitEvent(c->stream, dstf->ev_wr, 0);
+    for (int k = 0; k < 2; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(c->stream, dstf->ev_rd[k], 0);
+  };
   hipStream_t st = c->stream;
   if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
   while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
   hipEvent_t* ev = &c->evs[c->ev_used * 7];
   c->ev_used++;
   hipEventRecord(ev[0], st);
+  if (!want_sao) dst_hazards();
   /* fork: the metadata planes (read first by k_intra) are rasterised on the side stream while the main
      stream runs job list -> inter prediction -> residual, which do not read them */
   hipEventRecord(c->ev_fork, st);
@@ -748,8 +864,18 @@ static int decode(m355_ctx* c, Resident& r)
   hipEventRecord(ev[4], st);
   if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
   hipEventRecord(ev[5], st);
-  if (want_sao) m355_launch_sao(d, hbd, st);
+  if (want_sao) { dst_hazards(); m355_launch_sao(d, hbd, st); }
   hipEventRecord(ev[6], st);
+  if (piped) {
+    if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+    hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+      if (!f) continue;
+      if (frame_event(&f->ev_rd[c->active]) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+      hipEventRecord(f->ev_rd[c->active], st); f->rd_pending[c->active] = true;
+    }
+  }
   c->timed = true;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -866,12 +992,15 @@ int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
 int m355_wait(m355_ctx* c)
 {
   hipSetDevice(c->device);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  uint32_t t = 0;
+  HIPCHK(sync_all(c));
+  for (auto& f : c->frames) { f.wr_pending = false; f.rd_pending[0] = f.rd_pending[1] = false; }   /* everything is complete */
+  uint32_t t = 0, t2 = 0;
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
-  if (t) {
+  if (c->parked.timeout) HIPCHK(hipMemcpy(&t2, c->parked.timeout, 4, hipMemcpyDeviceToHost));
+  if (t | t2) {
     hipMemsetAsync(c->timeout, 0, 4, c->stream);
-    hipStreamSynchronize(c->stream);
+    if (c->parked.timeout) hipMemsetAsync(c->parked.timeout, 0, 4, c->parked.stream);
+    sync_all(c);
     return fail(M355_ERR_TIMEOUT, "intra wavefront spin bound exceeded");
   }
   return M355_OK;
@@ -890,7 +1019,7 @@ int m355_picture_release(m355_ctx* c, int h)
 {
   if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  sync_all(c);
   resident_free(c->resident[h]);
   return M355_OK;
 }
@@ -908,7 +1037,7 @@ int m355_timing_collect(m355_ctx* c, int* n_decodes, float* total_ms, float stag
 {
   if (c->ev_used == 0) return fail(M355_ERR_INVALID, "nothing decoded since the last timing reset");
   hipSetDevice(c->device);
-  HIPCHK(hipEventSynchronize(c->evs[(c->ev_used - 1) * 7 + 6]));
+  HIPCHK(sync_all(c));
   double tot = 0, st[6] = {0, 0, 0, 0, 0, 0};
   for (int k = 0; k < c->ev_used; k++) {
     hipEvent_t* ev = &c->evs[k * 7];

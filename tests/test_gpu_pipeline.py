@@ -1,0 +1,70 @@
+"""Two pictures in flight (m355_set_pipeline_depth(ctx, 2)): consecutive decodes alternate between two lanes and
+overlap; frame hazards are ordered by events.  A chain of pictures in which every picture references the PREVIOUS
+output (read-after-write across lanes) and frames are recycled (write-after-read / write-after-write) must still
+equal the oracle's sequential decode, with no host synchronisation between the submissions."""
+import numpy as np
+import pytest
+
+from oracle_py import Oracle
+from synth_util import assert_planes_equal
+from libde265_amd import capi, synth, worklist
+
+pytestmark = pytest.mark.gpu
+
+
+def chain_case(n, **cfg):
+    pics = [synth.picture(**dict(cfg, seed=cfg["seed"] + 101 * k)) for k in range(n)]
+    pp = pics[0].pp[0]
+    ref0 = synth.ref_planes(cfg["seed"], int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"]))
+    return pics, ref0
+
+
+@pytest.mark.parametrize("cfg", [dict(width=416, height=240, bit_depth=8, seed=201, n_refs=2),
+                                 dict(width=832, height=480, bit_depth=10, seed=202, n_refs=2, tile_cols=2, tile_rows=2),
+                                 dict(width=640, height=368, bit_depth=8, seed=203, n_refs=2, sao=0)],
+                         ids=lambda c: "%dx%d_seed%d" % (c["width"], c["height"], c["seed"]))
+def test_dependent_pictures_pipelined(oracle, cfg):
+    o = Oracle(oracle)
+    n = 6
+    pics, ref0 = chain_case(n, **cfg)
+    pp = pics[0].pp[0]
+    # oracle: picture k references slot 0 = the fixed frame, slot 1 = output of picture k-1 (k = 0: the fixed frame again)
+    of0 = o.frame_new(pp); o.frame_set_planes(of0, ref0)
+    oprev, want = of0, []
+    for pic in pics:
+        od = o.frame_new(pp)
+        pic.ref_frames = [0, 1] + [-1] * (worklist.MAX_REF_FRAMES - 2)
+        assert o.decode(pic, od, {0: of0, 1: oprev}) == 0
+        want.append(o.frame_planes(od))
+        oprev = od
+    lib = capi.Library()
+    ctx = capi.Context(lib, 0)
+    try:
+        ctx.set_pipeline_depth(2)
+        g0 = ctx.frame_create_for(pp); ctx.frame_upload(g0, ref0)
+        pool = [ctx.frame_create_for(pp) for _ in range(3)]        # recycled destination frames
+        handles, prev = [], g0
+        for k, pic in enumerate(pics):
+            pic.dst_frame = pool[k % 3]
+            pic.ref_frames = [g0, prev] + [-1] * (worklist.MAX_REF_FRAMES - 2)
+            handles.append(ctx.upload(pic))
+            prev = pic.dst_frame
+        got = []
+        # pictures 0..2 go out back to back; their frames are then recycled by 3..5, so download in between
+        for k in range(3):
+            ctx.decode_resident(handles[k])
+        ctx.wait()
+        got += [ctx.frame_download(pool[k]) for k in range(3)]
+        for k in range(3, n):
+            ctx.decode_resident(handles[k])
+        ctx.wait()
+        got += [ctx.frame_download(pool[k % 3]) for k in range(3, n)]
+        for k in range(n):
+            assert_planes_equal(got[k], want[k], "picture %d" % k)
+        # replaying one resident picture many times (the benchmark's pattern: same destination every time)
+        for _ in range(8):
+            ctx.decode_resident(handles[n - 1])
+        ctx.wait()
+        assert_planes_equal(ctx.frame_download(pool[(n - 1) % 3]), want[n - 1], "replayed")
+    finally:
+        ctx.close()
