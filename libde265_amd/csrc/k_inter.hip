@@ -206,6 +206,11 @@ __device__ __forceinline__ unsigned d_sel(unsigned mask, unsigned a, unsigned b)
 /* 12 consecutive samples starting at column xa of one row -> 6 packed 16-bit pairs.  FAST: the span
  * lies inside the picture row (the 12th sample may be the first pad sample: never used with a
  * non-zero tap); otherwise every column is clamped (motion.cc:84-91,147-155). */
+/* Vector loads must start on a DWORD boundary: measured on MI355X (tools/ubench/ub_l1.hip), a global_load_dwordx4 whose
+ * address is only 2-byte aligned is processed one dword per pass — 64 cycles per wave instruction instead of 16 (x2: 32
+ * vs 16, x3: 48 vs 16) — and the texture addresser is what bounds this kernel.  So the window rows are fetched from the
+ * dword-aligned address at or below the first sample and funnel-shifted into place (v_alignbit / v_alignbyte, per-lane
+ * shift): a few VALU issues per row buy back up to 3/4 of the addresser time of a misaligned row. */
 template <class PIX, bool FAST>
 __device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[6])
 {
@@ -215,11 +220,22 @@ __device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int
     return;
 #endif
     if (sizeof(PIX) == 2) {
-      d_ldg16(row + xa, S);
-      d_ldg8(row + xa + 8, S + 4);
+      /* 11 samples xa..xa+10 are needed: the 12 loaded ones start at xa or xa-1 (the spare slot moves to the front) */
+      const unsigned sh = ((unsigned)xa & 1u) << 4;
+      unsigned E[6];
+      const M355_GLOBAL PIX* q = row + (xa & ~1);
+      d_ldg16(q, E);
+      d_ldg8(q + 8, E + 4);
+#pragma unroll
+      for (int k = 0; k < 5; k++) S[k] = __builtin_amdgcn_alignbit(E[k + 1], E[k], sh);
+      S[5] = E[5] >> sh;
     } else {
-      unsigned a[3];
-      d_ldg12(row + xa, a);
+      /* 11 bytes xa..xa+10 out of the 16 at the dword-aligned address below */
+      const unsigned sh = (unsigned)xa & 3u;
+      unsigned E[4], a[3];
+      d_ldg16(row + (xa & ~3), E);
+#pragma unroll
+      for (int k = 0; k < 3; k++) a[k] = __builtin_amdgcn_alignbyte(E[k + 1], E[k], sh);
 #pragma unroll
       for (int k = 0; k < 3; k++) { S[2 * k] = (a[k] & 0xFFu) | ((a[k] & 0xFF00u) << 8); S[2 * k + 1] = ((a[k] >> 16) & 0xFFu) | ((a[k] >> 8) & 0xFF0000u); }
     }
@@ -231,7 +247,7 @@ __device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int
     }
   }
 }
-/* 6 consecutive samples -> 3 pairs (chroma window row) */
+/* 6 consecutive samples -> 3 pairs (chroma window row; the last one is never used with a non-zero tap) */
 template <class PIX, bool FAST>
 __device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[3])
 {
@@ -240,9 +256,17 @@ __device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int 
     for (int k = 0; k < 3; k++) S[k] = (unsigned)xa * 0x10001u + k;
     return;
 #endif
-    if (sizeof(PIX) == 2) d_ldg12(row + xa, S);
-    else {
-      const unsigned a = d_ldg4(row + xa), b = d_ldg2(row + xa + 4);
+    if (sizeof(PIX) == 2) {
+      const unsigned sh = ((unsigned)xa & 1u) << 4;
+      unsigned E[3];
+      d_ldg12(row + (xa & ~1), E);
+      S[0] = __builtin_amdgcn_alignbit(E[1], E[0], sh); S[1] = __builtin_amdgcn_alignbit(E[2], E[1], sh); S[2] = E[2] >> sh;
+    } else {
+      /* 5 bytes xa..xa+4 out of the 8 at the dword-aligned address below */
+      const unsigned sh = (unsigned)xa & 3u;
+      unsigned E[2];
+      d_ldg8(row + (xa & ~3), E);
+      const unsigned a = __builtin_amdgcn_alignbyte(E[1], E[0], sh), b = E[1] >> (8 * sh);
       S[0] = (a & 0xFFu) | ((a & 0xFF00u) << 8); S[1] = ((a >> 16) & 0xFFu) | ((a >> 8) & 0xFF0000u);
       S[2] = (b & 0xFFu) | ((b & 0xFF00u) << 8);
     }

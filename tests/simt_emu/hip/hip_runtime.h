@@ -124,6 +124,9 @@ static inline void __builtin_amdgcn_s_barrier() { simt::sync_threads(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 static inline void __builtin_amdgcn_s_sleep(int) {}
+/* v_alignbit_b32 / v_alignbyte_b32: low 32 bits of {hi:lo} >> shift */
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned s) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> (s & 31)); }
+static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned s) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> ((s & 3) * 8)); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
