@@ -30,14 +30,16 @@ static int fail(int code, const char* fmt, ...)
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(M355_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
+#define M355_MAX_LANES 4   /* pictures in flight per context (m355_set_pipeline_depth) */
+
 struct Frame {
   bool used = false;
   int w = 0, h = 0, cf = 0, bdl = 0, bdc = 0;
   int pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0}, stride[3] = {0, 0, 0}, bpp[3] = {1, 1, 1};
   void* plane[3] = {nullptr, nullptr, nullptr};
   /* pictures in flight on different lanes (m355_set_pipeline_depth): last writer / last readers per lane */
-  hipEvent_t ev_wr = nullptr, ev_rd[2] = {nullptr, nullptr};
-  bool wr_pending = false, rd_pending[2] = {false, false};
+  hipEvent_t ev_wr = nullptr, ev_rd[M355_MAX_LANES] = {};
+  bool wr_pending = false, rd_pending[M355_MAX_LANES] = {};
 };
 
 static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
@@ -72,8 +74,8 @@ static void frame_free(Frame& f)
 {
   for (int c = 0; c < 3; c++) { if (f.plane[c]) hipFree(f.plane[c]); f.plane[c] = nullptr; }
   if (f.ev_wr) hipEventDestroy(f.ev_wr);
-  for (int k = 0; k < 2; k++) if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]);
-  f.ev_wr = f.ev_rd[0] = f.ev_rd[1] = nullptr; f.wr_pending = f.rd_pending[0] = f.rd_pending[1] = false;
+  for (int k = 0; k < M355_MAX_LANES; k++) { if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]); f.ev_rd[k] = nullptr; f.rd_pending[k] = false; }
+  f.ev_wr = nullptr; f.wr_pending = false;
   f.used = false;
 }
 
@@ -101,9 +103,9 @@ struct Resident {
 };
 
 /* Everything ONE picture in flight writes: streams, working planes, metadata / job / residual scratch.  The context's
- * own fields of the same names are the ACTIVE lane; select_lane() swaps them with the parked copy, so all the code
- * below keeps addressing c->stream, c->work, c->resbuf ... (m355_set_pipeline_depth(ctx, 2) decodes consecutive
- * pictures alternately on two lanes: the dependency-bound tail of one picture's intra stage and its filters overlap
+ * own fields of the same names are the ACTIVE lane; select_lane() exchanges them with a parked copy, so all the code
+ * below keeps addressing c->stream, c->work, c->resbuf ... (m355_set_pipeline_depth(ctx, n) decodes consecutive
+ * pictures round-robin on n lanes: the dependency-bound tail of one picture's intra stage and its filters overlap
  * the next picture's prediction; frame hazards are ordered with per-frame events). */
 struct Lane {
   hipStream_t stream = nullptr, stream2 = nullptr;
@@ -119,7 +121,7 @@ struct Lane {
 
 struct m355_ctx {
   int device = 0;
-  Lane parked;                 /* the lane that is not active (valid when depth == 2) */
+  Lane lanes[M355_MAX_LANES];  /* parked lanes; lanes[active] is stale: the active lane lives in the fields below */
   int depth = 1, active = 0;   /* pipeline depth, index of the active lane */
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
@@ -147,10 +149,13 @@ struct m355_ctx {
   X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_ctb) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
 static void select_lane(m355_ctx* c, int lane)
 {
-  if (c->depth < 2 || lane == c->active) return;
-#define SWAP_FIELD(f) std::swap(c->f, c->parked.f);
-  LANE_FIELDS(SWAP_FIELD)
-#undef SWAP_FIELD
+  if (lane == c->active) return;
+#define PARK_FIELD(f) c->lanes[c->active].f = c->f;
+#define LOAD_FIELD(f) c->f = c->lanes[lane].f;
+  LANE_FIELDS(PARK_FIELD)
+  LANE_FIELDS(LOAD_FIELD)
+#undef PARK_FIELD
+#undef LOAD_FIELD
   c->active = lane;
 }
 static int lane_create(m355_ctx* c, Lane& l)
@@ -183,7 +188,8 @@ static void lane_destroy(Lane& l)
 static hipError_t sync_all(m355_ctx* c)
 {
   hipError_t e = hipStreamSynchronize(c->stream);
-  if (c->depth >= 2 && c->parked.stream) { hipError_t e2 = hipStreamSynchronize(c->parked.stream); if (e == hipSuccess) e = e2; }
+  for (int k = 0; k < M355_MAX_LANES; k++)
+    if (k != c->active && c->lanes[k].stream) { hipError_t e2 = hipStreamSynchronize(c->lanes[k].stream); if (e == hipSuccess) e = e2; }
   return e;
 }
 
@@ -279,8 +285,9 @@ int m355_create(int device, m355_ctx** out)
     Lane l;
     int rc = lane_create(c, l);
     if (rc) { lane_destroy(l); delete c; return rc; }
-    c->parked = l; c->depth = 2; c->active = 1; select_lane(c, 0); c->depth = 1;   /* move it into the active fields */
-    c->parked = Lane();
+#define LOAD_FIELD(f) c->f = l.f;
+    LANE_FIELDS(LOAD_FIELD)                       /* lane 0 is the active one: it lives in the context's own fields */
+#undef LOAD_FIELD
   }
   *out = c;
   return M355_OK;
@@ -312,7 +319,7 @@ void m355_destroy(m355_ctx* c)
     LANE_FIELDS(MOVE_FIELD)
 #undef MOVE_FIELD
     lane_destroy(a);
-    lane_destroy(c->parked);
+    for (int k = 0; k < M355_MAX_LANES; k++) if (k != c->active) lane_destroy(c->lanes[k]);
   }
   delete c;
 }
@@ -323,14 +330,15 @@ void m355_destroy(m355_ctx* c)
  * and the readers of its destination frame. */
 int m355_set_pipeline_depth(m355_ctx* c, int depth)
 {
-  if (depth < 1 || depth > 2) return fail(M355_ERR_INVALID, "pipeline depth must be 1 or 2");
+  if (depth < 1 || depth > M355_MAX_LANES) return fail(M355_ERR_INVALID, "pipeline depth must be 1..%d", M355_MAX_LANES);
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-  if (depth == 2 && !c->parked.stream) {
-    int rc = lane_create(c, c->parked);
-    if (rc) return rc;
-  }
-  if (depth == 1) select_lane(c, 0);
+  select_lane(c, 0);
+  for (int k = 1; k < depth; k++)
+    if (!c->lanes[k].stream) {
+      int rc = lane_create(c, c->lanes[k]);
+      if (rc) return rc;
+    }
   c->depth = depth;
   return M355_OK;
 }
@@ -816,14 +824,14 @@ static hipError_t frame_event(hipEvent_t* e)
 static int decode(m355_ctx* c, Resident& r)
 {
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
-  if (c->depth == 2) select_lane(c, c->active ^ 1);          /* consecutive pictures alternate between the lanes */
+  if (c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);   /* consecutive pictures go round the lanes */
   DevPic d;
   bool want_sao;
   int rc = prepare(c, r, d, want_sao);
   if (rc) return rc;
   const m355_pic_params& pp = r.hdr.pp;
   const bool hbd = pp.bit_depth_luma > 8;
-  const bool piped = c->depth == 2;
+  const bool piped = c->depth >= 2;
   Frame* dstf = get_frame(c, r.hdr.dst_frame);
   if (piped) {
     /* read-after-write: the lists (uploaded on whichever lane was active) and every reference frame's last writer */
@@ -838,7 +846,7 @@ static int decode(m355_ctx* c, Resident& r)
   auto dst_hazards = [&]() {
     if (!piped) return;
     if (dstf->wr_pending) hipStreamWaitEvent(c->stream, dstf->ev_wr, 0);
-    for (int k = 0; k < 2; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(c->stream, dstf->ev_rd[k], 0);
+    for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(c->stream, dstf->ev_rd[k], 0);
   };
   hipStream_t st = c->stream;
   if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
@@ -993,13 +1001,15 @@ int m355_wait(m355_ctx* c)
 {
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-  for (auto& f : c->frames) { f.wr_pending = false; f.rd_pending[0] = f.rd_pending[1] = false; }   /* everything is complete */
-  uint32_t t = 0, t2 = 0;
+  for (auto& f : c->frames) { f.wr_pending = false; for (int k = 0; k < M355_MAX_LANES; k++) f.rd_pending[k] = false; }   /* everything is complete */
+  uint32_t t = 0;
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
-  if (c->parked.timeout) HIPCHK(hipMemcpy(&t2, c->parked.timeout, 4, hipMemcpyDeviceToHost));
-  if (t | t2) {
+  for (int k = 0; k < M355_MAX_LANES; k++)
+    if (k != c->active && c->lanes[k].timeout) { uint32_t t2 = 0; HIPCHK(hipMemcpy(&t2, c->lanes[k].timeout, 4, hipMemcpyDeviceToHost)); t |= t2; }
+  if (t) {
     hipMemsetAsync(c->timeout, 0, 4, c->stream);
-    if (c->parked.timeout) hipMemsetAsync(c->parked.timeout, 0, 4, c->parked.stream);
+    for (int k = 0; k < M355_MAX_LANES; k++)
+      if (k != c->active && c->lanes[k].timeout) hipMemsetAsync(c->lanes[k].timeout, 0, 4, c->lanes[k].stream);
     sync_all(c);
     return fail(M355_ERR_TIMEOUT, "intra wavefront spin bound exceeded");
   }

@@ -23,7 +23,8 @@ def chain_case(n, **cfg):
                                  dict(width=832, height=480, bit_depth=10, seed=202, n_refs=2, tile_cols=2, tile_rows=2),
                                  dict(width=640, height=368, bit_depth=8, seed=203, n_refs=2, sao=0)],
                          ids=lambda c: "%dx%d_seed%d" % (c["width"], c["height"], c["seed"]))
-def test_dependent_pictures_pipelined(oracle, cfg):
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_dependent_pictures_pipelined(oracle, cfg, depth):
     o = Oracle(oracle)
     n = 6
     pics, ref0 = chain_case(n, **cfg)
@@ -40,7 +41,7 @@ def test_dependent_pictures_pipelined(oracle, cfg):
     lib = capi.Library()
     ctx = capi.Context(lib, 0)
     try:
-        ctx.set_pipeline_depth(2)
+        ctx.set_pipeline_depth(depth)
         g0 = ctx.frame_create_for(pp); ctx.frame_upload(g0, ref0)
         pool = [ctx.frame_create_for(pp) for _ in range(3)]        # recycled destination frames
         handles, prev = [], g0
