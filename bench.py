@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c5_8k10_8tiles")
-    ap.add_argument("--pipeline-depth", type=int, default=2, help="pictures in flight per GPU in the timed region (1 or 2)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1 or 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-upload", action="store_true", help="also time m355_submit_picture per step (host lists -> pinned arena -> H2D -> decode): the PCIe-inclusive rate")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")

@@ -41,6 +41,19 @@ __device__ __forceinline__ unsigned d_pk_shl16(unsigned v, int s)
   return __builtin_bit_cast(unsigned, t);
 }
 
+/* packed 16-bit lane arithmetic (VOP3P: two samples per VALU issue) — k_sao's edge / band classification */
+__device__ __forceinline__ unsigned d_pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(m355_ushort2, a) - __builtin_bit_cast(m355_ushort2, b)); }
+__device__ __forceinline__ unsigned d_pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(m355_ushort2, a) + __builtin_bit_cast(m355_ushort2, b)); }
+__device__ __forceinline__ unsigned d_pk_lshr16(unsigned v, int s) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(m355_ushort2, v) >> (m355_ushort2)(unsigned short)s); }
+typedef short m355_short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned d_pk_min_i16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(m355_short2v, a), __builtin_bit_cast(m355_short2v, b))); }
+__device__ __forceinline__ unsigned d_pk_max_i16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(m355_short2v, a), __builtin_bit_cast(m355_short2v, b))); }
+__device__ __forceinline__ unsigned d_pk_min_u16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(m355_ushort2, a), __builtin_bit_cast(m355_ushort2, b))); }
+__device__ __forceinline__ unsigned d_pk_addsat_u16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(m355_ushort2, a), __builtin_bit_cast(m355_ushort2, b))); }
+__device__ __forceinline__ unsigned d_pk_subsat_u16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(m355_ushort2, a), __builtin_bit_cast(m355_ushort2, b))); }
+/* raw v_perm_b32: result byte i = byte sel[i] of {hi:lo} for selectors 0..7, 0x00 for 0x0c, 0xff for 0x0d..0x0f */
+__device__ __forceinline__ unsigned d_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
 /* v_dot2c_i32_i16: c + a.lo*b.lo + a.hi*b.hi on packed signed 16-bit pairs — two filter taps per VALU
  * issue (measured on MI355X: same issue rate as v_mad_i32_i24, tools/ubench/ub_inter.hip). */
 typedef short m355_short2 __attribute__((ext_vector_type(2)));

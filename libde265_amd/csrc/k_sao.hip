@@ -69,6 +69,33 @@ __device__ __forceinline__ void d_sao_edge_block(int o0, int o1, int o2, int o3,
   }
 }
 
+/* Packed path (bit depth <= 15): which of the 16 samples of a 4x4 block (bit j*4+s) sit on the CTB ring AND have one of
+ * their two edge-class neighbours (direction +-(H0,V0)) in a CTB that may not be used (sao.cc:122-164)?  The neighbour of
+ * sample (s,j) in direction (h,v) leaves the block in x iff s is on the matching block edge — the sample sets are
+ * compile-time masks; which neighbouring CTB that means depends on whether the block edge is also a CTB edge (L,R,T,Bt). */
+template <int h, int v>
+__device__ __forceinline__ uint32_t d_sao_dir_blocked(bool L, bool R, bool T, bool Bt, uint32_t nbmask)
+{
+  constexpr uint32_t MX = h < 0 ? 0x1111u : (h > 0 ? 0x8888u : 0u), MY = v < 0 ? 0x000Fu : (v > 0 ? 0xF000u : 0u);
+  constexpr uint32_t M_xy = MX & MY, M_x = MX & ~MY, M_y = MY & ~MX, M_in = 0xFFFFu & ~(MX | MY);
+  const int dx = h < 0 ? -(int)L : (h > 0 ? (int)R : 0), dy = v < 0 ? -(int)T : (v > 0 ? (int)Bt : 0);
+  const uint32_t b_in = (nbmask >> 4) & 1u, b_x = (nbmask >> (4 + dx)) & 1u, b_y = (nbmask >> (4 + 3 * dy)) & 1u, b_xy = (nbmask >> (4 + 3 * dy + dx)) & 1u;
+  return (b_in ? M_in : 0u) | (b_x ? M_x : 0u) | (b_y ? M_y : 0u) | (b_xy ? M_xy : 0u);
+}
+template <int H0, int V0>
+__device__ __forceinline__ uint32_t d_sao_bad(bool L, bool R, bool T, bool Bt, uint32_t nbmask)
+{
+  const uint32_t ring = (L ? 0x1111u : 0u) | (R ? 0x8888u : 0u) | (T ? 0x000Fu : 0u) | (Bt ? 0xF000u : 0u);
+  return ring & (d_sao_dir_blocked<H0, V0>(L, R, T, Bt, nbmask) | d_sao_dir_blocked<-H0, -V0>(L, R, T, Bt, nbmask));
+}
+/* table index (edgeIdx + 2, sao.cc:95-100) of two packed samples: Sign(c-a) + Sign(c-b) + 2 on 16-bit lanes */
+__device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint32_t b)
+{
+  const uint32_t one = 0x00010001u, m1 = 0xFFFFFFFFu;
+  const uint32_t s1 = d_pk_max_i16(d_pk_min_i16(d_pk_sub16(c, a), one), m1), s2 = d_pk_max_i16(d_pk_min_i16(d_pk_sub16(c, b), one), m1);
+  return d_pk_add16(d_pk_add16(s1, s2), 0x00020002u);
+}
+
 template <class PIX>
 __global__ void __launch_bounds__(256) k_sao(DevPic p)
 {
@@ -132,21 +159,142 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
     if (valid && ly == 0 && y0 > 0) d_sao_load4<PIX>(in + (size_t)(y0 - 1) * is + x0, rw[0]);
     if (valid && ly == 3 && y0 + 4 < height) d_sao_load4<PIX>(in + (size_t)(y0 + 4) * is + x0, rw[5]);
   }
+  const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma, maxv = (1 << bd) - 1;
+  const bool packed = bd <= 15;      /* uniform: 16-bit lane differences need |c - a| < 32768 */
+  /* rows as packed 16-bit pairs (s0,s1)(s2,s3) + the sample left / right of the block */
+  uint32_t P[6][2];
+  int Ls[6], Rs[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) nb[r][1 + k] = d_sao_sample<PIX>(rw[r], k);
-    nb[r][0] = nb[r][5] = 0;
+    if (sizeof(PIX) == 2) { P[r][0] = rw[r][0]; P[r][1] = rw[r][NW - 1]; }
+    else { P[r][0] = d_perm(0u, rw[r][0], 0x0c010c00u); P[r][1] = d_perm(0u, rw[r][0], 0x0c030c02u); }
+    Ls[r] = Rs[r] = 0;
+  }
+  if (packed) {
     if (any_edge) {
-      const int yy = y0 - 1 + r;
-      const bool yok = valid && yy >= 0 && yy < height;
-      int l = __shfl_up(nb[r][4], 1, 64), rg = __shfl_down(nb[r][1], 1, 64);
-      if (lx == 0) l = (edge && yok && x0 > 0) ? (int)in[(size_t)yy * is + x0 - 1] : 0;
-      if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? (int)in[(size_t)yy * is + x0 + 4] : 0;
-      nb[r][0] = l; nb[r][5] = rg;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const int yy = y0 - 1 + r;
+        const bool yok = valid && yy >= 0 && yy < height;
+        int l = __shfl_up((int)(P[r][1] >> 16), 1, 64), rg = __shfl_down((int)(P[r][0] & 0xFFFFu), 1, 64);
+        if (lx == 0) l = (edge && yok && x0 > 0) ? (int)in[(size_t)yy * is + x0 - 1] : 0;
+        if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? (int)in[(size_t)yy * is + x0 + 4] : 0;
+        Ls[r] = l; Rs[r] = rg;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) nb[r][1 + k] = d_sao_sample<PIX>(rw[r], k);
+      nb[r][0] = nb[r][5] = 0;
+      if (any_edge) {
+        const int yy = y0 - 1 + r;
+        const bool yok = valid && yy >= 0 && yy < height;
+        int l = __shfl_up(nb[r][4], 1, 64), rg = __shfl_down(nb[r][1], 1, 64);
+        if (lx == 0) l = (edge && yok && x0 > 0) ? (int)in[(size_t)yy * is + x0 - 1] : 0;
+        if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? (int)in[(size_t)yy * is + x0 + 4] : 0;
+        nb[r][0] = l; nb[r][5] = rg;
+      }
     }
   }
+  /* pcm (with pcm_loop_filter_disable) / transquant-bypass samples are left alone (sao.cc:103-120); and is any
+     neighbouring CTB unusable?  Both are rare: the wave takes the masked path only if some lane needs it */
+  uint32_t skipmask = 0;
+  if (valid && owned && type != 0 && (ctb.flags & M355_CTBF_HAS_PCM_OR_BYPASS)) {
+    const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
+    for (int j = 0; j < 4; j++)
+      for (int s2 = 0; s2 < 4; s2++) {
+        const uint32_t ci = d_cu_index_at(p, min((x0 + s2) << csw, p.pp.width - 1), min((y0 + j) << csh, p.pp.height - 1));
+        if (ci) {
+          const m355_cu cu = p.cus[ci - 1];
+          if ((plf && (cu.flags & M355_CUF_PCM)) || (cu.flags & M355_CUF_TRANSQUANT_BYPASS)) skipmask |= 1u << (j * 4 + s2);
+        }
+      }
+  }
+  const uint32_t nbmask = (valid && edge) ? p.sao_nb[c * p.nCtb + yCtb * p.ctbW + xCtb] : 0u;
+  const bool slow = __any(skipmask != 0 || nbmask != 0);
   if (!valid || !owned) return;
+
+  if (packed) {
+    uint32_t O[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { O[j][0] = P[1 + j][0]; O[j][1] = P[1 + j][1]; }
+    if (type != 0) {
+      /* 5-entry offset table split into its positive and negative parts (bytes; |offset| <= 124): the sample becomes
+         min(satsub(satadd(c, pos), neg), maxv) = Clip3(0, maxv, c + offset) on unsigned 16-bit lanes.
+         edge: index = edgeIdx + 2 -> [o0, o1, 0, o2, o3] (sao.cc:95-100); band: index = min(k, 4) -> [o0..o3, 0] */
+      const int t0 = so0, t1 = so1, t2 = edge ? 0 : so2, t3 = edge ? so2 : so3, t4 = edge ? so3 : 0;
+      const uint32_t tpos_lo = (uint32_t)max(t0, 0) | ((uint32_t)max(t1, 0) << 8) | ((uint32_t)max(t2, 0) << 16) | ((uint32_t)max(t3, 0) << 24), tpos_hi = (uint32_t)max(t4, 0);
+      const uint32_t tneg_lo = (uint32_t)max(-t0, 0) | ((uint32_t)max(-t1, 0) << 8) | ((uint32_t)max(-t2, 0) << 16) | ((uint32_t)max(-t3, 0) << 24), tneg_hi = (uint32_t)max(-t4, 0);
+      uint32_t IDX[4][2];
+      uint32_t bad = skipmask;
+      if (edge) {
+        const int cls = (ctb.sao_eo_class >> (2 * c)) & 3;
+        const int xC = xCtb << l2w, yC = yCtb << l2h;
+        const int nSW = 1 << l2w, nSH = 1 << l2h;
+        const int ctbW_ = (xC + nSW > width) ? width - xC : nSW, ctbH_ = (yC + nSH > height) ? height - yC : nSH;
+        const bool L = x0 == xC, R = x0 + 4 == xC + ctbW_, T = y0 == yC, Bt = y0 + 4 == yC + ctbH_;
+        /* per row: (L,s0) / (s1,s2) / (s3,R) = the row seen one sample to the left / right */
+        uint32_t Lp[6], Mp[6], Rp[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          Lp[r] = (P[r][0] << 16) | (uint32_t)Ls[r];
+          Mp[r] = __builtin_amdgcn_alignbit(P[r][1], P[r][0], 16);
+          Rp[r] = __builtin_amdgcn_alignbit((uint32_t)Rs[r], P[r][1], 16);
+        }
+        /* class -> first neighbour offset (sao.cc:83-88): 0:(-1,0) 1:(0,-1) 2:(-1,-1) 3:(+1,-1); wave-uniform for luma */
+        if (cls == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { IDX[j][0] = d_sao_edge_idx(O[j][0], Lp[1 + j], Mp[1 + j]); IDX[j][1] = d_sao_edge_idx(O[j][1], Mp[1 + j], Rp[1 + j]); }
+          if (slow) bad |= d_sao_bad<-1, 0>(L, R, T, Bt, nbmask);
+        } else if (cls == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { IDX[j][0] = d_sao_edge_idx(O[j][0], P[j][0], P[2 + j][0]); IDX[j][1] = d_sao_edge_idx(O[j][1], P[j][1], P[2 + j][1]); }
+          if (slow) bad |= d_sao_bad<0, -1>(L, R, T, Bt, nbmask);
+        } else if (cls == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { IDX[j][0] = d_sao_edge_idx(O[j][0], Lp[j], Mp[2 + j]); IDX[j][1] = d_sao_edge_idx(O[j][1], Mp[j], Rp[2 + j]); }
+          if (slow) bad |= d_sao_bad<-1, -1>(L, R, T, Bt, nbmask);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { IDX[j][0] = d_sao_edge_idx(O[j][0], Mp[j], Lp[2 + j]); IDX[j][1] = d_sao_edge_idx(O[j][1], Rp[j], Mp[2 + j]); }
+          if (slow) bad |= d_sao_bad<1, -1>(L, R, T, Bt, nbmask);
+        }
+      } else {
+        /* band offset (sao.cc:166-200): k = ((sample >> (bd-5)) - band_position) & 31 */
+        const uint32_t bp2 = (uint32_t)band_pos * 0x00010001u;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int q = 0; q < 2; q++) IDX[j][q] = d_pk_min_u16(d_pk_sub16(d_pk_lshr16(O[j][q], bd - 5), bp2) & 0x001F001Fu, 0x00040004u);
+      }
+      const uint32_t maxv2 = (uint32_t)maxv * 0x00010001u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t sel = d_perm(IDX[j][1], IDX[j][0], 0x06040200u);             /* the row's four table indices as bytes */
+        const uint32_t pos4 = d_perm(tpos_hi, tpos_lo, sel), neg4 = d_perm(tneg_hi, tneg_lo, sel);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const uint32_t usel = q ? 0x0c030c02u : 0x0c010c00u;                       /* two bytes -> two 16-bit lanes */
+          uint32_t vnew = d_pk_min_u16(d_pk_subsat_u16(d_pk_addsat_u16(O[j][q], d_perm(0u, pos4, usel)), d_perm(0u, neg4, usel)), maxv2);
+          if (slow) {
+            const uint32_t two = (bad >> (4 * j + 2 * q)) & 3u;
+            const uint32_t keep = (((two & 1u) - 1u) & 0xFFFFu) | (((two >> 1) - 1u) << 16);   /* lanes that may be modified */
+            vnew = (vnew & keep) | (O[j][q] & ~keep);
+          }
+          O[j][q] = vnew;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      PIX* q = out + (size_t)(y0 + j) * os + x0;
+      if (sizeof(PIX) == 2) *(uint2*)q = make_uint2(O[j][0], O[j][1]);
+      else *(uint32_t*)q = d_perm(O[j][1], O[j][0], 0x06040200u);
+    }
+    return;
+  }
 
   PIX res[4][4];
 #pragma unroll
@@ -154,28 +302,14 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
 #pragma unroll
     for (int s2 = 0; s2 < 4; s2++) res[j][s2] = (PIX)nb[1 + j][1 + s2];
 
+  /* ---- bit depth 16: one sample per lane-op (the original formulation) ---- */
   if (type != 0) {
-    const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma, maxv = (1 << bd) - 1;
-    /* samples of pcm (with pcm_loop_filter_disable) / transquant-bypass CUs are left alone (sao.cc:103-120): rare */
-    uint32_t skipmask = 0;
-    if (ctb.flags & M355_CTBF_HAS_PCM_OR_BYPASS) {
-      const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
-      for (int j = 0; j < 4; j++)
-        for (int s2 = 0; s2 < 4; s2++) {
-          const uint32_t ci = d_cu_index_at(p, min((x0 + s2) << csw, p.pp.width - 1), min((y0 + j) << csh, p.pp.height - 1));
-          if (ci) {
-            const m355_cu cu = p.cus[ci - 1];
-            if ((plf && (cu.flags & M355_CUF_PCM)) || (cu.flags & M355_CUF_TRANSQUANT_BYPASS)) skipmask |= 1u << (j * 4 + s2);
-          }
-        }
-    }
     if (edge) {
       const int cls = (ctb.sao_eo_class >> (2 * c)) & 3;
       const int xC = xCtb << l2w, yC = yCtb << l2h;
       const int nSW = 1 << l2w, nSH = 1 << l2h;
       const int ctbW_ = (xC + nSW > width) ? width - xC : nSW, ctbH_ = (yC + nSH > height) ? height - yC : nSH;
       const bool L = x0 == xC, R = x0 + 4 == xC + ctbW_, T = y0 == yC, Bt = y0 + rows == yC + ctbH_;
-      const uint32_t nbmask = p.sao_nb[c * p.nCtb + yCtb * p.ctbW + xCtb];
       /* class -> first neighbour offset (sao.cc:83-88): 0:(-1,0) 1:(0,-1) 2:(-1,-1) 3:(+1,-1); wave-uniform for luma */
       if (cls == 0) d_sao_edge_block<-1, 0, PIX>(so0, so1, so2, so3, nb, skipmask, L, R, T, Bt, nbmask, maxv, rows, res);
       else if (cls == 1) d_sao_edge_block<0, -1, PIX>(so0, so1, so2, so3, nb, skipmask, L, R, T, Bt, nbmask, maxv, rows, res);

@@ -13,6 +13,27 @@ static inline unsigned d_pack_lo16(unsigned lo, unsigned hi) { return (lo & 0xFF
 static inline unsigned d_pack_hi16(unsigned lo, unsigned hi) { return (lo >> 16) | (hi & 0xFFFF0000u); }
 static inline unsigned d_pk_shl16(unsigned v, int s) { return ((v << s) & 0xFFFFu) | ((((v >> 16) << s) & 0xFFFFu) << 16); }
 static inline unsigned d_byte_lookup(unsigned hi, unsigned lo, unsigned idx) { const unsigned long long t = ((unsigned long long)hi << 32) | lo; return (unsigned)(t >> (8 * (idx & 7))) & 0xFFu; }
+#define M355_PK2(expr_lo, expr_hi) ((unsigned)((expr_lo) & 0xFFFFu) | ((unsigned)((expr_hi) & 0xFFFFu) << 16))
+static inline unsigned d_pk_sub16(unsigned a, unsigned b) { return M355_PK2((a & 0xFFFF) - (b & 0xFFFF), (a >> 16) - (b >> 16)); }
+static inline unsigned d_pk_add16(unsigned a, unsigned b) { return M355_PK2((a & 0xFFFF) + (b & 0xFFFF), (a >> 16) + (b >> 16)); }
+static inline unsigned d_pk_lshr16(unsigned v, int s) { return M355_PK2((v & 0xFFFF) >> s, (v >> 16) >> s); }
+static inline int m355_s16(unsigned v) { return (int)(short)(v & 0xFFFF); }
+static inline unsigned d_pk_min_i16(unsigned a, unsigned b) { const int l = m355_s16(a) < m355_s16(b) ? m355_s16(a) : m355_s16(b), h = m355_s16(a >> 16) < m355_s16(b >> 16) ? m355_s16(a >> 16) : m355_s16(b >> 16); return M355_PK2((unsigned)l, (unsigned)h); }
+static inline unsigned d_pk_max_i16(unsigned a, unsigned b) { const int l = m355_s16(a) > m355_s16(b) ? m355_s16(a) : m355_s16(b), h = m355_s16(a >> 16) > m355_s16(b >> 16) ? m355_s16(a >> 16) : m355_s16(b >> 16); return M355_PK2((unsigned)l, (unsigned)h); }
+static inline unsigned d_pk_min_u16(unsigned a, unsigned b) { const unsigned l = (a & 0xFFFF) < (b & 0xFFFF) ? (a & 0xFFFF) : (b & 0xFFFF), h = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16); return M355_PK2(l, h); }
+static inline unsigned d_pk_addsat_u16(unsigned a, unsigned b) { unsigned l = (a & 0xFFFF) + (b & 0xFFFF), h = (a >> 16) + (b >> 16); if (l > 0xFFFF) l = 0xFFFF; if (h > 0xFFFF) h = 0xFFFF; return M355_PK2(l, h); }
+static inline unsigned d_pk_subsat_u16(unsigned a, unsigned b) { const unsigned l = (a & 0xFFFF) > (b & 0xFFFF) ? (a & 0xFFFF) - (b & 0xFFFF) : 0, h = (a >> 16) > (b >> 16) ? (a >> 16) - (b >> 16) : 0; return M355_PK2(l, h); }
+static inline unsigned d_perm(unsigned hi, unsigned lo, unsigned sel)
+{
+  const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+  unsigned r = 0;
+  for (int i = 0; i < 4; i++) {
+    const unsigned s = (sel >> (8 * i)) & 0xFF;
+    const unsigned b = s < 8 ? (unsigned)(t >> (8 * s)) & 0xFF : (s == 0x0c ? 0u : 0xFFu);
+    r |= b << (8 * i);
+  }
+  return r;
+}
 static inline int d_dot2(unsigned a, unsigned b, int c)
 {
   return c + (int)(int16_t)(a & 0xFFFF) * (int16_t)(b & 0xFFFF) + (int)(int16_t)(a >> 16) * (int16_t)(b >> 16);
