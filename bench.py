@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--workload", default="c5_8k10_8tiles")
     ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1 or 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", type=int, default=31, help="DIAGNOSTIC ONLY: M355_STAGE_* mask (anything but 31 is not a valid benchmark)")
     ap.add_argument("--with-upload", action="store_true", help="also time m355_submit_picture per step (host lists -> pinned arena -> H2D -> decode): the PCIe-inclusive rate")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
@@ -71,6 +72,8 @@ def main():
     pic.ref_frames = [refs[i] if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
     handle = ctx.upload(pic)
     ctx.wait()
+    if args.stages != 31:
+        ctx.set_stages(args.stages)
 
     # (1) one picture at a time (pipeline depth 1): clean per-stage device timings for the roofline figures
     for _ in range(args.warmup):
@@ -96,6 +99,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.decode_resident(handle)
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (launches are asynchronous)
     ctx.wait()
     if dist:
         torch.cuda.synchronize()
@@ -135,12 +139,13 @@ def main():
             "metric": "decoded CTBs/s", "value": world * args.steps * n_ctbs / dt, "unit": "CTB64/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "ms_per_step_one_in_flight": 1e3 * dt_serial / args.steps, "pictures_in_flight": args.pipeline_depth,
+            "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if pp["bit_depth_luma"] <= 8 else "u16", "data": "synthetic",
             "fps": world * args.steps / dt,
             "config": {"workload": args.workload, "width": int(pp["width"]), "height": int(pp["height"]),
                        "bit_depth": int(pp["bit_depth_luma"]), "tiles": "%dx%d" % (cfg["tile_cols"], cfg["tile_rows"]),
-                       "ctbs_per_picture": n_ctbs, "stages": "inter+residual+intra+deblock+sao", "parallelism": "pictures/%d" % world},
+                       "ctbs_per_picture": n_ctbs, "stages": "inter+residual+intra+deblock+sao" if args.stages == 31 else "DIAGNOSTIC mask %d" % args.stages, "parallelism": "pictures/%d" % world},
             "algorithmic_bytes_per_ctb": ab["total"] / n_ctbs,
             "pipeline_GBps": ab["total"] * args.steps / dt / 1e9,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
