@@ -44,7 +44,9 @@ struct DevPic {
   const m355_pb* pbs;
   const m355_wt* wts;
   const m355_rb* rbs;
-  const m355_ib* ibs;
+  const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime.hip intra_schedule) */
+  const uint16_t* ib_level;         /* level of ibs[i] inside its CTB */
+  int intra_waves;                  /* k_intra: waves per colour component (1 or 4) */
   const uint32_t* coeffs;
   const uint16_t* pcm;
   const uint8_t* scaling;

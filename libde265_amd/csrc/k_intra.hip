@@ -16,10 +16,12 @@
  *     residency assumption, no deadlock;
  *   - completion is published per CTB with an agent-scope release + flag; consumers poll relaxed,
  *     then take ONE agent-scope acquire (MI355X guide, guideline 16);
- *   - inside the workgroup, one 64-lane wavefront per colour component walks that component's
- *     blocks in decode order with the CTB (plus top-row / left-column halo) resident in LDS; the
- *     three component chains are independent, so there is no workgroup barrier inside the chain —
- *     only wave-level LDS ordering;
+ *   - inside the workgroup the CTB (plus top-row / left-column halo) is resident in LDS and its blocks run LEVEL BY
+ *     LEVEL: the host sorts each CTB's blocks by dependency level (runtime.hip intra_schedule: a block depends on the
+ *     earlier blocks that cover its left column / top row), blocks of one level are independent, and each colour
+ *     component has 1 (inter pictures: a handful of blocks per CTB) or 4 (intra pictures: up to 256 luma blocks per
+ *     CTB) wavefronts that share a level's blocks, with a workgroup barrier between levels — the serial chain per
+ *     CTB shrinks from the block count to the level count (about 46 instead of 256 for a CTB of 4x4 blocks);
  *   - the inverse transforms were done up front, in parallel, by k_residual.
  * This stage is dependency-bound, not bandwidth-bound: critical path ~ (W_ctb + 2 H_ctb) CTB steps.
  */
@@ -63,23 +65,36 @@ __device__ __forceinline__ int d_subst_src(int e, unsigned long long m0, unsigne
   return 128;
 }
 
-template <class PIX, int CF>
-__global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work_n, int use_ticket)
+#define INTRA_GMAX 4   /* waves per colour component */
+/* DENSE: intra pictures (many blocks per CTB): INTRA_GMAX waves per component share each level, residuals are fetched
+ * into LDS up front.  !DENSE: inter pictures (a handful of blocks per CTB): one wave per component, no workgroup
+ * barriers inside the chain, residuals fetched per block under its border phase. */
+template <class PIX, int CF, bool DENSE>
+__global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic p, int work_base, int work_n, int use_ticket)
 {
   /* per component: top halo row (x = -1 .. 2*cw-1, index x+1) and body rows with a left halo column */
   constexpr int CW_C = (CF == 1 || CF == 2) ? MAXCTB / 2 : MAXCTB, CH_C = CF == 1 ? MAXCTB / 2 : MAXCTB;   /* chroma CTB size */
   constexpr int BODY_L = MAXCTB * BODY_PITCH_OF(MAXCTB), BODY_C = CF == 0 ? 8 : CH_C * BODY_PITCH_OF(CW_C);
   __shared__ uint16_t s_top[3][2 * MAXCTB + 2];
   __shared__ __attribute__((aligned(16))) uint16_t s_body[BODY_L + 2 * BODY_C];
-  __shared__ uint16_t s_raw[3][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
-  __shared__ uint16_t s_p[3][4 * 32 + 8];        /* substituted border */
-  __shared__ uint16_t s_f[3][4 * 32 + 8];        /* filtered border */
-  __shared__ int s_ref[3][3 * 32 + 8];           /* angular ref[-nT..2nT], index +32 */
+  /* the CTB's deferred residuals in picture layout (pitch = component CTB width): fetched up front, all loads in flight
+     together, so that the per-block chain reads them from LDS instead of paying a global-memory latency per block */
+  constexpr int RES_L = DENSE ? MAXCTB * MAXCTB : 8, RES_C = (CF == 0 || !DENSE) ? 8 : CH_C * CW_C;
+  __shared__ __attribute__((aligned(16))) int16_t s_res[RES_L + 2 * RES_C];
+  /* per WAVE (a wave works on one block at a time): */
+  constexpr int NWV = 3 * (DENSE ? INTRA_GMAX : 1);
+  __shared__ uint16_t s_raw[NWV][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
+  __shared__ uint16_t s_p[NWV][4 * 32 + 8];        /* substituted border */
+  __shared__ uint16_t s_f[NWV][4 * 32 + 8];        /* filtered border */
+  __shared__ int s_ref[NWV][3 * 32 + 8];           /* angular ref[-nT..2nT], index +32 */
   __shared__ uint32_t s_ticket;
   __shared__ uint32_t s_nts[9];                  /* CtbAddrRStoTS of the 3x3 CTB neighbourhood (0xFFFFFFFF outside the picture) */
   __shared__ uint8_t s_nsame[9];                 /* neighbour CTB in the picture, same slice (SliceAddrRS) and same tile */
 
-  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  /* wave -> (colour component c, sub-wave g of G): blockDim.x = 192 * G */
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int G = DENSE ? INTRA_GMAX : 1;
+  const int c = wv / G, g = wv - c * G;
 
   if (threadIdx.x == 0) s_ticket = use_ticket ? atomicAdd(p.ticket, 1u) : blockIdx.x;
   __syncthreads();
@@ -122,17 +137,19 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
   uint16_t* top = s_top[cs];
   uint16_t* body = s_body + (cs == 0 ? 0 : BODY_L + (cs - 1) * BODY_C);
   const int BODY_PITCH = cs == 0 ? BODY_PITCH_OF(MAXCTB) : BODY_PITCH_OF(CW_C);
-  uint16_t* raw = s_raw[cs];
-  uint16_t* pp_ = s_p[cs];
-  uint16_t* pf = s_f[cs];
-  int* ref = s_ref[cs] + 32;
+  int16_t* resl = s_res + (cs == 0 ? 0 : RES_L + (cs - 1) * RES_C);
+  const int RES_PITCH = cs == 0 ? MAXCTB : CW_C;
+  uint16_t* raw = s_raw[wv];
+  uint16_t* pp_ = s_p[wv];
+  uint16_t* pf = s_f[wv];
+  int* ref = s_ref[wv] + 32;
 
   if (comp) {
     /* ---- stage the CTB and its halo in LDS: 8-sample vectors, all loads of a lane in flight at once ---- */
     {
       const int l2v = (l2c - csw) - 3;                       /* log2(vectors per row); cw >= 8 */
       const int nvec = ch << l2v;
-      for (int idx = lane; idx < nvec; idx += 64) {
+      for (int idx = lane + 64 * g; idx < nvec; idx += 64 * G) {
         const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
         if (x0c + xv < pw && y0c + y < ph) {
           const PIX* src = plane + (size_t)(y0c + y) * stride + x0c + xv;
@@ -144,6 +161,38 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
             v.z = (b.y & 0xFFu) | ((b.y & 0xFF00u) << 8); v.w = ((b.y >> 16) & 0xFFu) | ((b.y >> 8) & 0xFF0000u);
           }
           *(uint4*)(body + y * BODY_PITCH + BODY_X0 + xv) = v;
+        }
+      }
+    }
+  }
+
+  /* ---- residual pre-pass: every wave fetches the residuals of the blocks it will process (same selection as the
+     main loop below, so no other wave ever reads them) ---- */
+  constexpr bool res_in_lds = DENSE;
+  for (uint32_t kbase = 0; res_in_lds && kbase < ctbinfo.ib_count; kbase += 64) {
+    uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
+    int lv = -1;
+    const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
+    if (lane < nvalid) {
+      const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
+      rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
+      lv = p.ib_level[ctbinfo.ib_start + kbase + lane];
+    }
+    const int lv_first = __shfl(lv, 0, 64), lv_last = __shfl(lv, nvalid - 1, 64);
+    for (int L = lv_first; L <= lv_last; L++) {
+      unsigned long long mine = __ballot((int)(comp && lv == L && (rw1 & 0xFFu) == (uint32_t)c));
+      int rank = 0;
+      while (mine) {
+        const int src = __ffsll(mine) - 1;
+        mine &= mine - 1;
+        if ((rank++ % G) != g) continue;
+        const uint32_t w0 = __shfl(rw0, src, 64), w1 = __shfl(rw1, src, 64), w2 = __shfl(rw2, src, 64);
+        const int flags = (int)(w1 >> 24), log2 = (int)((w1 >> 8) & 0xFFu), nT = 1 << log2;
+        if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
+        const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
+        for (int o = lane * 4; o < nT * nT; o += 256) {        /* 4 samples (one row segment) per lane and step */
+          const uint2 v = *(const uint2*)(p.resbuf + w2 + o);
+          *(uint2*)(resl + (ly + (o >> log2)) * RES_PITCH + lx + (o & (nT - 1))) = v;
         }
       }
     }
@@ -168,7 +217,7 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
   }
   __syncthreads();
 
-  if (comp) {
+  if (comp && g == 0) {
     if (x0c > 0)
       for (int y = lane; y < ch; y += 64)
         if (y0c + y < ph) body[y * BODY_PITCH + BODY_X0 - 1] = plane[(size_t)(y0c + y) * stride + x0c - 1];
@@ -177,23 +226,33 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
         const int xx = x0c - 1 + x;
         if (xx >= 0 && xx < pw) top[x] = plane[(size_t)(y0c - 1) * stride + xx];
       }
-    wave_sync();
+  }
+  if (G > 1) __syncthreads(); else wave_sync();     /* CTB + halo staged by all waves of the component (G == 1: by this wave) */
 
 #define SAMPLE(lx, ly) ((ly) < 0 ? top[(lx) + 1] : body[(ly) * BODY_PITCH + (lx) + BODY_X0])
 
-    /* the CTB's block records are fetched 64 at a time (one per lane, coalesced); the wave then walks the
-       records of ITS component in decode order by broadcasting them from the owning lane — one global
-       load latency per 64 records instead of one per record in the serial chain */
-    for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
+  /* The CTB's block records (sorted by level, then component) are fetched 64 at a time (one per lane, coalesced) by
+     EVERY wave; for each level present in the batch, a wave takes the blocks of its component that fall to it
+     (every G-th) by broadcasting the record from the owning lane, then all waves meet at the workgroup barrier.  The
+     loop bounds come from the records alone, so all waves (also those of absent components) execute the same
+     barriers. */
+  for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
     uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
-    if (kbase + lane < ctbinfo.ib_count) {
+    int lv = -1;
+    const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
+    if (lane < nvalid) {
       const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
       rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
+      lv = p.ib_level[ctbinfo.ib_start + kbase + lane];
     }
-    unsigned long long mine = __ballot((int)((rw1 & 0xFFu) == (uint32_t)c));
+    const int lv_first = __shfl(lv, 0, 64), lv_last = __shfl(lv, nvalid - 1, 64);
+    for (int L = lv_first; L <= lv_last; L++) {
+    unsigned long long mine = __ballot((int)(comp && lv == L && (rw1 & 0xFFu) == (uint32_t)c));
+    int rank = 0;
     while (mine) {
       const int src = __ffsll(mine) - 1;
       mine &= mine - 1;
+      if ((rank++ % G) != g) continue;             /* another wave of this component takes it */
       m355_ib ib;
       {
         const uint32_t w0 = __shfl(rw0, src, 64), w1 = __shfl(rw1, src, 64), w2 = __shfl(rw2, src, 64);
@@ -215,13 +274,13 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
         continue;
       }
 
-      /* residual of this block (written by k_residual): issue the loads now, consume them after the
+      /* residual of this block (written by k_residual), sparse case: issue the loads now, consume them after the
          border/prediction chain — up to 16 samples per lane (32x32) */
       int16_t rv[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         const int o = lane + 64 * q;
-        rv[q] = ((ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
+        rv[q] = (!res_in_lds && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
       }
 
       /* ---- preproc (intrapred.h:436-531): CTB-level availability from the neighbourhood table ---- */
@@ -250,6 +309,7 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
       unsigned long long am[3] = {0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 3; q++) {
+        if (64 * q >= nEnt) continue;              /* wave-uniform: 4x4 / 8x8 blocks have 17 / 33 border entries */
         const int e = lane + 64 * q;
         bool av = false;
         int val = 0;
@@ -284,6 +344,7 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
       const bool none = (am[0] | am[1] | am[2]) == 0;
 #pragma unroll
       for (int q = 0; q < 3; q++) {
+        if (64 * q >= nEnt) continue;
         const int e = lane + 64 * q;
         if (e < nEnt) {
           int v;
@@ -307,6 +368,7 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
                           d_abs((int)pp_[Z] + pp_[Z - 64] - 2 * pp_[Z - 32]) < (1 << (p.pp.bit_depth_luma - 5));
 #pragma unroll
           for (int q = 0; q < 3; q++) {
+            if (64 * q >= nEnt) continue;
             const int e = lane + 64 * q;
             if (e < nEnt) {
               const int i = e - Z;
@@ -378,17 +440,18 @@ __global__ void __launch_bounds__(192) k_intra(DevPic p, int work_base, int work
             if (mode == 10 && y == 0) v = d_clip_bd(BRD(-1) + ((BRD(1 + x) - BRD(0)) >> 1), bd);
           }
         }
-        if (has_res) v = d_clip_bd(v + rv[q], bd);
+        if (has_res) v = d_clip_bd(v + (res_in_lds ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (int)rv[q]), bd);
         body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders */
         plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;                /* the picture: only intra samples are (re)written */
       }
       wave_sync();
-    }   /* records of this component */
-    }   /* 64-record batches */
+    }   /* this wave's blocks of the level */
+    if (G > 1) __syncthreads();   /* level done: its samples are in LDS for the next level's borders (G == 1: the wave's own
+                                     blocks are ordered by wave_sync above; components do not interact) */
+    }   /* levels in the batch */
+  }   /* 64-record batches */
 #undef BRD
 #undef SAMPLE
-
-  }
 
   /* ---- publish (guideline 16: stores -> barrier -> one-lane agent release -> drain -> flag) ---- */
   if (!(dep & 16)) return;            /* nobody waits for this CTB (host-derived): nothing to publish */
@@ -405,7 +468,8 @@ template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, hipStream_t st)
 {
   hipMemsetAsync(p.ticket, 0, 4, st);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF>), dim3(p.n_intra_work), dim3(192), 0, st, p, 0, p.n_intra_work, 1);
+  if (p.intra_waves >= INTRA_GMAX) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, true>), dim3(p.n_intra_work), dim3(192 * INTRA_GMAX), 0, st, p, 0, p.n_intra_work, 1);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, false>), dim3(p.n_intra_work), dim3(192), 0, st, p, 0, p.n_intra_work, 1);
 }
 
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)

@@ -445,6 +445,18 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
     ibsum += c.ib_count;
   }
   if ((int)ibsum != pic->n_ibs) return fail(M355_ERR_INVALID, "intra blocks not all owned by a CTB");
+  for (int i = 0; i < pic->n_ctbs; i++) {
+    const m355_ctb& c = pic->ctbs[i];
+    const int cx = i % ctbW, cy = i / ctbW;
+    for (uint32_t k = 0; k < c.ib_count; k++) {
+      const m355_ib& ib = pic->ibs[c.ib_start + k];
+      if (ib.cidx > 2 || ib.log2_size < 2 || ib.log2_size > 5) return fail(M355_ERR_INVALID, "ib %u malformed", c.ib_start + k);
+      const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0, n = 1 << ib.log2_size;
+      const int x0 = (cx << pp.log2_ctb_size) >> csw, y0 = (cy << pp.log2_ctb_size) >> csh;
+      if (ib.x < x0 || ib.y < y0 || ib.x + n > x0 + (cs >> csw) || ib.y + n > y0 + (cs >> csh))
+        return fail(M355_ERR_INVALID, "ib %u lies outside its CTB %d", c.ib_start + k, i);
+    }
+  }
   for (int i = 0; i < pic->n_cus; i++) {
     const m355_cu& cu = pic->cus[i];
     if (cu.log2_size < pp.log2_min_cb_size || cu.log2_size > pp.log2_ctb_size || cu.x >= pp.width || cu.y >= pp.height || cu.pred_mode > 2 || cu.part_mode > 7)
@@ -544,6 +556,53 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
   }
 }
 
+/* Dependency levels of the intra blocks inside each CTB (k_intra.hip): a block reads the column left of it and the row
+ * above it over 2*nT + 1 samples each, so it depends on every EARLIER block of its component and CTB that covers one
+ * of those samples (a superset of what the availability rules of intrapred.h:534-633 let it read); level = 1 + the
+ * highest level among them.  Blocks of one level are independent: k_intra runs them concurrently on several waves with
+ * a workgroup barrier between levels, instead of walking the CTB's blocks one by one.  `out` receives each CTB's blocks
+ * sorted by (level, component), decode order kept inside; `lvl` their levels.  *waves = waves per component worth
+ * launching (1 when CTBs hold few blocks, as in inter pictures). */
+static void intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint16_t* lvl, int* waves)
+{
+  const m355_pic_params& pp = pic->pp;
+  const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
+  std::vector<std::pair<uint32_t, uint32_t>> key;      /* (level << 2 | cidx, index) */
+  long long dense = 0, n_intra_ctbs = 0;
+  for (int c = 0; c < pic->n_ctbs; c++) {
+    const m355_ctb& ctb = pic->ctbs[c];
+    if (!ctb.ib_count) continue;
+    n_intra_ctbs++; dense += ctb.ib_count;
+    const int cx = c % ctbW, cy = c / ctbW;
+    int16_t grid[3][16][16];
+    memset(grid, 0xFF, sizeof(grid));                  /* -1: no intra block of this CTB there (yet) */
+    key.clear();
+    for (uint32_t k = 0; k < ctb.ib_count; k++) {
+      const m355_ib& ib = pic->ibs[ctb.ib_start + k];
+      const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
+      const int ux = (ib.x - ((cx << pp.log2_ctb_size) >> csw)) >> 2, uy = (ib.y - ((cy << pp.log2_ctb_size) >> csh)) >> 2;
+      const int n4 = (1 << ib.log2_size) >> 2;
+      int level = 0;
+      if (ux < 0 || uy < 0 || ux >= 16 || uy >= 16) { key.push_back(std::make_pair((uint32_t)ib.cidx, k)); continue; }   /* rejected by validate() */
+      if (!(ib.flags & M355_IBF_PCM)) {                /* raw blocks read nothing */
+        for (int t = -1; t < 2 * n4; t++) {
+          if (ux - 1 >= 0 && uy + t >= 0 && uy + t < 16) level = std::max(level, grid[ib.cidx][uy + t][ux - 1] + 1);
+          if (uy - 1 >= 0 && ux + t >= 0 && ux + t < 16) level = std::max(level, grid[ib.cidx][uy - 1][ux + t] + 1);
+        }
+      }
+      for (int y = uy; y < uy + n4 && y < 16; y++)
+        for (int x = ux; x < ux + n4 && x < 16; x++) if (x >= 0 && y >= 0) grid[ib.cidx][y][x] = (int16_t)level;
+      key.push_back(std::make_pair(((uint32_t)level << 2) | ib.cidx, k));
+    }
+    std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    for (uint32_t k = 0; k < ctb.ib_count; k++) {
+      out[ctb.ib_start + k] = pic->ibs[ctb.ib_start + key[k].second];
+      lvl[ctb.ib_start + k] = (uint16_t)(key[k].first >> 2);
+    }
+  }
+  *waves = (n_intra_ctbs && dense / n_intra_ctbs >= 24) ? 4 : 1;
+}
+
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 /* canonical exchange-buffer layout of a picture (k_common.h HaloLayout); depends on the picture parameters only */
@@ -595,7 +654,8 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const int i_pb = add(pic->pbs, sizeof(m355_pb) * pic->n_pbs, sizeof(m355_pb) * (size_t)halo.n_units);
   const int i_wt = add(pic->wts, sizeof(m355_wt) * pic->n_wts);
   const int i_rb = add(pic->rbs, sizeof(m355_rb) * nrb);
-  const int i_ib = add(pic->ibs, sizeof(m355_ib) * pic->n_ibs);
+  const int i_ib = add(nullptr, sizeof(m355_ib) * pic->n_ibs);   /* written below: each CTB's blocks sorted by dependency level */
+  const int i_il = add(nullptr, 2 * (size_t)pic->n_ibs);         /* ib_level */
   const int i_co = add(pic->coeffs, 4 * (size_t)pic->n_coeffs);
   const int i_pc = add(pic->pcm, 2 * (size_t)pic->n_pcm);
   const int i_sc = add(pic->scaling_factors, pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0);
@@ -623,6 +683,8 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   }
   for (int i = 0; i < ns; i++)
     if (seg[i].src && seg[i].bytes) memcpy(r.host + seg[i].ofs, seg[i].src, seg[i].bytes);
+  int intra_waves = 1;
+  intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint16_t*)(r.host + seg[i_il].ofs), &intra_waves);
   /* derived scan tables (pps.cc:589-606) */
   uint32_t* ctb_ts = (uint32_t*)(r.host + seg[i_ts].ofs);
   uint32_t* ts2rs = (uint32_t*)(r.host + seg[i_rs].ofs);
@@ -716,6 +778,8 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.wts = (const m355_wt*)(r.dev + seg[i_wt].ofs);
   d.rbs = (const m355_rb*)(r.dev + seg[i_rb].ofs);
   d.ibs = (const m355_ib*)(r.dev + seg[i_ib].ofs);
+  d.ib_level = (const uint16_t*)(r.dev + seg[i_il].ofs);
+  d.intra_waves = intra_waves;
   d.coeffs = (const uint32_t*)(r.dev + seg[i_co].ofs);
   d.pcm = (const uint16_t*)(r.dev + seg[i_pc].ofs);
   d.scaling = pic->scaling_factors ? (const uint8_t*)(r.dev + seg[i_sc].ofs) : nullptr;
