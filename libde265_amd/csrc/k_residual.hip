@@ -256,20 +256,40 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
 #pragma unroll
     for (int i = 0; i < NT; i += 2) *(uint32_t*)(out + i) = res_pack(d_clip3(-32768, 32767, res[i]), d_clip3(-32768, 32767, res[i + 1]));
   } else {
+    /* read-modify-write of the lane's row: NT samples, as 16-byte (NT >= 8) or 8-byte vectors — blocks are aligned to
+       their size, so the row segment is too */
     PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + y) * p.stride[rb.cidx] + rb.x;
     if (sizeof(PIX) == 2) {
+      constexpr int NV = NT / 2;                 /* dwords per row */
+      uint32_t w[NV];
+      if (NT >= 8) {
 #pragma unroll
-      for (int i = 0; i < NT; i += 2) {
-        const uint32_t w = *(const uint32_t*)(d + i);
-        *(uint32_t*)(d + i) = (uint32_t)d_clip_bd((int)(w & 0xFFFFu) + res[i], bd) | ((uint32_t)d_clip_bd((int)(w >> 16) + res[i + 1], bd) << 16);
-      }
+        for (int i = 0; i < NV; i += 4) { const uint4 v = *(const uint4*)(d + 2 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
+      } else { const uint2 v = *(const uint2*)d; w[0] = v.x; w[1] = v.y; }
+#pragma unroll
+      for (int i = 0; i < NV; i++)
+        w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFFFu) + res[2 * i], bd) | ((uint32_t)d_clip_bd((int)(w[i] >> 16) + res[2 * i + 1], bd) << 16);
+      if (NT >= 8) {
+#pragma unroll
+        for (int i = 0; i < NV; i += 4) *(uint4*)(d + 2 * i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
+      } else *(uint2*)d = make_uint2(w[0], w[1]);
     } else {
+      constexpr int NV = NT / 4;
+      uint32_t w[NV];
+      if (NT >= 16) {
 #pragma unroll
-      for (int i = 0; i < NT; i += 4) {
-        const uint32_t w = *(const uint32_t*)(d + i);
-        *(uint32_t*)(d + i) = (uint32_t)d_clip_bd((int)(w & 0xFFu) + res[i], bd) | ((uint32_t)d_clip_bd((int)((w >> 8) & 0xFFu) + res[i + 1], bd) << 8) |
-                              ((uint32_t)d_clip_bd((int)((w >> 16) & 0xFFu) + res[i + 2], bd) << 16) | ((uint32_t)d_clip_bd((int)(w >> 24) + res[i + 3], bd) << 24);
-      }
+        for (int i = 0; i < NV; i += 4) { const uint4 v = *(const uint4*)(d + 4 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
+      } else if (NT == 8) { const uint2 v = *(const uint2*)d; w[0] = v.x; w[NV - 1] = v.y; }
+      else w[0] = *(const uint32_t*)d;
+#pragma unroll
+      for (int i = 0; i < NV; i++)
+        w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFu) + res[4 * i], bd) | ((uint32_t)d_clip_bd((int)((w[i] >> 8) & 0xFFu) + res[4 * i + 1], bd) << 8) |
+               ((uint32_t)d_clip_bd((int)((w[i] >> 16) & 0xFFu) + res[4 * i + 2], bd) << 16) | ((uint32_t)d_clip_bd((int)(w[i] >> 24) + res[4 * i + 3], bd) << 24);
+      if (NT >= 16) {
+#pragma unroll
+        for (int i = 0; i < NV; i += 4) *(uint4*)(d + 4 * i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
+      } else if (NT == 8) *(uint2*)d = make_uint2(w[0], w[NV - 1]);
+      else *(uint32_t*)d = w[0];
     }
   }
 }
