@@ -14,6 +14,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -100,6 +104,9 @@ struct Resident {
   bool live_sao = false, live_valid = false;
   void* xprev = nullptr;       /* exchange buffer handed to the previous phase */
   hipEvent_t ev_up = nullptr;  /* lists copied to the device (decodes on the other lane wait for it) */
+  hipEvent_t ev_done = nullptr; /* last decode of these lists finished: the arenas may be overwritten */
+  bool done_pending = false;
+  bool fresh = false;          /* uploaded and not decoded since: nothing in flight reads its reference table */
 };
 
 /* Everything ONE picture in flight writes: streams, working planes, metadata / job / residual scratch.  The context's
@@ -128,7 +135,8 @@ struct m355_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<Frame> frames;
   std::vector<Resident> resident;
-  Resident transient;
+  Resident transient[3];       /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes */
+  int next_transient = 0;
   Frame work;                  /* pre-SAO working planes */
   /* scratch */
   uint32_t *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
@@ -300,6 +308,7 @@ static void resident_free(Resident& r)
   if (r.refs_dev) hipFree(r.refs_dev);
   if (r.refs_host) hipHostFree(r.refs_host);
   if (r.ev_up) hipEventDestroy(r.ev_up);
+  if (r.ev_done) hipEventDestroy(r.ev_done);
   r = Resident();
 }
 
@@ -310,7 +319,7 @@ void m355_destroy(m355_ctx* c)
   sync_all(c);
   for (auto& f : c->frames) if (f.used) frame_free(f);
   for (auto& r : c->resident) if (r.used) resident_free(r);
-  resident_free(c->transient);
+  for (auto& t : c->transient) resident_free(t);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   {
     /* the active lane lives in the context's own fields: collect it into a Lane and destroy both */
@@ -417,6 +426,47 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
 
 /* ----------------------------------------------------------------------- validation ----------- */
 
+extern "C++" {
+/* Host-side parallel helpers: an 8K picture's lists are > 1.5 million records and 30 MB — validating and copying them on
+ * one thread costs several milliseconds per picture, ten times the device time. */
+static int host_threads()
+{
+  static int n = 0;
+  if (!n) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 16 ? 8 : (hc >= 4 ? 4 : 1); }
+  return n;
+}
+template <class F> static void parallel_ranges(size_t n, size_t min_per_thread, F f)   /* f(begin, end) */
+{
+  int T = host_threads();
+  if (n < 2 * min_per_thread) T = 1;
+  else if (n / min_per_thread < (size_t)T) T = (int)(n / min_per_thread);
+  if (T <= 1) { f((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back([=]() { f(n * t / T, n * (t + 1) / T); });
+  f((size_t)0, n / T);
+  for (auto& x : th) x.join();
+}
+/* check(i) -> nullptr or a message; the LOWEST failing index is reported as "<what> <i>: <message>" */
+template <class F> static int check_all(const char* what, size_t n, F check)
+{
+  std::atomic<size_t> first(n);
+  std::atomic<const char*> msg(nullptr);
+  std::mutex mu;
+  parallel_ranges(n, 32768, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e && i < first.load(std::memory_order_relaxed); i++) {
+      const char* m = check(i);
+      if (m) { std::lock_guard<std::mutex> g(mu); if (i < first.load()) { first.store(i); msg.store(m); } return; }
+    }
+  });
+  if (first.load() < n) return fail(M355_ERR_INVALID, "%s %zu: %s", what, first.load(), msg.load());
+  return M355_OK;
+}
+static void parallel_memcpy(void* dst, const void* src, size_t bytes)
+{
+  parallel_ranges(bytes, (size_t)1 << 20, [=](size_t b, size_t e) { memcpy((char*)dst + b, (const char*)src + b, e - b); });
+}
+} /* extern "C++" */
+
 static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
 {
   const m355_pic_params& pp = pic->pp;
@@ -436,7 +486,9 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
   for (int i = 0; i < pp.num_tile_rows; i++) if (pp.row_bd[i + 1] <= pp.row_bd[i]) return fail(M355_ERR_INVALID, "tile rows not increasing");
   if (pic->n_slices < 1) return fail(M355_ERR_INVALID, "no slices");
   if ((pp.flags & M355_PF_SCALING_LIST) && !pic->scaling_factors) return fail(M355_ERR_INVALID, "scaling list enabled but no factors");
+  if (pic->n_cus < 0 || pic->n_tus < 0 || pic->n_pbs < 0 || pic->n_wts < 0 || pic->n_ibs < 0) return fail(M355_ERR_INVALID, "negative list length");
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
+  int rc;
   uint32_t ibsum = 0;
   for (int i = 0; i < pic->n_ctbs; i++) {
     const m355_ctb& c = pic->ctbs[i];
@@ -445,65 +497,87 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
     ibsum += c.ib_count;
   }
   if ((int)ibsum != pic->n_ibs) return fail(M355_ERR_INVALID, "intra blocks not all owned by a CTB");
-  for (int i = 0; i < pic->n_ctbs; i++) {
+  size_t nrb = 0, bin_end[4];
+  for (int s = 0; s < 4; s++) { if (pic->rb_count[s] < 0) return fail(M355_ERR_INVALID, "negative rb_count"); nrb += (size_t)pic->rb_count[s]; bin_end[s] = nrb; }
+  /* every record of every list, as ONE parallel sweep over their concatenation (one thread start-up per picture) */
+  auto chk_ctb = [&](size_t i) -> const char* {
     const m355_ctb& c = pic->ctbs[i];
-    const int cx = i % ctbW, cy = i / ctbW;
+    const int cx = (int)i % ctbW, cy = (int)i / ctbW;
     for (uint32_t k = 0; k < c.ib_count; k++) {
       const m355_ib& ib = pic->ibs[c.ib_start + k];
-      if (ib.cidx > 2 || ib.log2_size < 2 || ib.log2_size > 5) return fail(M355_ERR_INVALID, "ib %u malformed", c.ib_start + k);
+      if (ib.cidx > 2 || ib.log2_size < 2 || ib.log2_size > 5) return "an intra block is malformed";
       const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0, n = 1 << ib.log2_size;
       const int x0 = (cx << pp.log2_ctb_size) >> csw, y0 = (cy << pp.log2_ctb_size) >> csh;
-      if (ib.x < x0 || ib.y < y0 || ib.x + n > x0 + (cs >> csw) || ib.y + n > y0 + (cs >> csh))
-        return fail(M355_ERR_INVALID, "ib %u lies outside its CTB %d", c.ib_start + k, i);
+      if (ib.x < x0 || ib.y < y0 || ib.x + n > x0 + (cs >> csw) || ib.y + n > y0 + (cs >> csh)) return "an intra block lies outside the CTB";
     }
-  }
-  for (int i = 0; i < pic->n_cus; i++) {
+    return nullptr;
+  };
+  auto chk_cu = [&](size_t i) -> const char* {
     const m355_cu& cu = pic->cus[i];
-    if (cu.log2_size < pp.log2_min_cb_size || cu.log2_size > pp.log2_ctb_size || cu.x >= pp.width || cu.y >= pp.height || cu.pred_mode > 2 || cu.part_mode > 7)
-      return fail(M355_ERR_INVALID, "cu %d malformed", i);
-  }
-  for (int i = 0; i < pic->n_tus; i++) {
+    return (cu.log2_size < pp.log2_min_cb_size || cu.log2_size > pp.log2_ctb_size || cu.x >= pp.width || cu.y >= pp.height || cu.pred_mode > 2 || cu.part_mode > 7) ? "malformed" : nullptr;
+  };
+  auto chk_tu = [&](size_t i) -> const char* {
     const m355_tu& tu = pic->tus[i];
-    if (tu.log2_size < 2 || tu.log2_size > 6 || tu.x >= pp.width || tu.y >= pp.height) return fail(M355_ERR_INVALID, "tu %d malformed", i);
-  }
-  for (int i = 0; i < pic->n_pbs; i++) {
+    return (tu.log2_size < 2 || tu.log2_size > 6 || tu.x >= pp.width || tu.y >= pp.height) ? "malformed" : nullptr;
+  };
+  auto chk_pb = [&](size_t i) -> const char* {
     const m355_pb& pb = pic->pbs[i];
-    if (pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3) || pb.x + pb.w > pp.width || pb.y + pb.h > pp.height)
-      return fail(M355_ERR_INVALID, "pb %d geometry", i);
-    if (!(pb.flags & (M355_PBF_MC_L0 | M355_PBF_MC_L1))) return fail(M355_ERR_INVALID, "pb %d: no list selected", i);
+    if (pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3) || pb.x + pb.w > pp.width || pb.y + pb.h > pp.height) return "geometry";
+    if (!(pb.flags & (M355_PBF_MC_L0 | M355_PBF_MC_L1))) return "no list selected";
     for (int l = 0; l < 2; l++) {
       if (!(pb.flags & (M355_PBF_MC_L0 << l))) continue;
-      if (!(pb.flags & (M355_PBF_FILL_L0 << l))) {
-        if (pb.ref_slot[l] < 0 || pb.ref_slot[l] >= M355_MAX_REF_FRAMES || pic->ref_frames[pb.ref_slot[l]] < 0) return fail(M355_ERR_INVALID, "pb %d: reference slot invalid", i);
-      }
-      if ((pb.flags & M355_PBF_WEIGHTED) && pb.wt_idx[l] >= pic->n_wts) return fail(M355_ERR_INVALID, "pb %d: weight index", i);
+      if (!(pb.flags & (M355_PBF_FILL_L0 << l)) && (pb.ref_slot[l] < 0 || pb.ref_slot[l] >= M355_MAX_REF_FRAMES || pic->ref_frames[pb.ref_slot[l]] < 0)) return "reference slot invalid";
+      if ((pb.flags & M355_PBF_WEIGHTED) && pb.wt_idx[l] >= pic->n_wts) return "weight index";
     }
-  }
-  for (int i = 0; i < pic->n_wts; i++)
-    if (pic->wts[i].log2wd_luma < 1 || pic->wts[i].log2wd_luma > 31 || (pp.chroma_format_idc && (pic->wts[i].log2wd_chroma < 1 || pic->wts[i].log2wd_chroma > 31)))
-      return fail(M355_ERR_INVALID, "weight %d: log2WD out of range", i);
-  int nrb = 0;
-  for (int s = 0; s < 4; s++) { if (pic->rb_count[s] < 0) return fail(M355_ERR_INVALID, "negative rb_count"); nrb += pic->rb_count[s]; }
-  int k = 0;
-  for (int s = 0; s < 4; s++)
-    for (int j = 0; j < pic->rb_count[s]; j++, k++) {
-      const m355_rb& rb = pic->rbs[k];
-      const int n = 1 << (s + 2);
-      const int W = rb.cidx ? pp.width / sw : pp.width, H = rb.cidx ? pp.height / sh : pp.height;
-      if (rb.log2_size != s + 2 || rb.cidx > 2 || rb.kind > 3 || rb.x + n > W || rb.y + n > H) return fail(M355_ERR_INVALID, "rb %d malformed", k);
-      if ((uint64_t)rb.coeff_ofs + rb.ncoeff > pic->n_coeffs) return fail(M355_ERR_INVALID, "rb %d: coefficient range", k);
-      if ((rb.flags & M355_RBF_DEFERRED) && (uint64_t)rb.res_ofs + n * n > pic->res_len) return fail(M355_ERR_INVALID, "rb %d: residual range", k);
-      if ((pp.flags & M355_PF_SCALING_LIST) && (rb.matrix_id & 7) > 5) return fail(M355_ERR_INVALID, "rb %d: matrix id", k);
-      if (rb.kind == M355_RK_DST && s != 0) return fail(M355_ERR_INVALID, "rb %d: DST only exists for 4x4", k);
-    }
-  for (int i = 0; i < pic->n_ibs; i++) {
+    return nullptr;
+  };
+  auto chk_wt = [&](size_t i) -> const char* {
+    return (pic->wts[i].log2wd_luma < 1 || pic->wts[i].log2wd_luma > 31 || (pp.chroma_format_idc && (pic->wts[i].log2wd_chroma < 1 || pic->wts[i].log2wd_chroma > 31))) ? "log2WD out of range" : nullptr;
+  };
+  auto chk_rb = [&](size_t k) -> const char* {
+    const m355_rb& rb = pic->rbs[k];
+    const int s = k < bin_end[0] ? 0 : (k < bin_end[1] ? 1 : (k < bin_end[2] ? 2 : 3));
+    const int n = 1 << (s + 2);
+    const int W = rb.cidx ? pp.width / sw : pp.width, H = rb.cidx ? pp.height / sh : pp.height;
+    if (rb.log2_size != s + 2 || rb.cidx > 2 || rb.kind > 3 || rb.x + n > W || rb.y + n > H) return "malformed";
+    if ((uint64_t)rb.coeff_ofs + rb.ncoeff > pic->n_coeffs) return "coefficient range";
+    if ((rb.flags & M355_RBF_DEFERRED) && (uint64_t)rb.res_ofs + n * n > pic->res_len) return "residual range";
+    if ((pp.flags & M355_PF_SCALING_LIST) && (rb.matrix_id & 7) > 5) return "matrix id";
+    if (rb.kind == M355_RK_DST && s != 0) return "DST only exists for 4x4";
+    return nullptr;
+  };
+  auto chk_ib = [&](size_t i) -> const char* {
     const m355_ib& ib = pic->ibs[i];
     const int n = 1 << ib.log2_size;
     const int W = ib.cidx ? pp.width / sw : pp.width, H = ib.cidx ? pp.height / sh : pp.height;
-    if (ib.log2_size < 2 || ib.log2_size > 5 || ib.cidx > 2 || ib.mode > 34 || ib.x + n > W || ib.y + n > H) return fail(M355_ERR_INVALID, "ib %d malformed", i);
-    if ((ib.flags & M355_IBF_HAS_RESIDUAL) && (uint64_t)ib.res_ofs + n * n > pic->res_len) return fail(M355_ERR_INVALID, "ib %d: residual range", i);
-    if ((ib.flags & M355_IBF_PCM) && (uint64_t)ib.res_ofs + n * n > pic->n_pcm) return fail(M355_ERR_INVALID, "ib %d: pcm range", i);
+    if (ib.log2_size < 2 || ib.log2_size > 5 || ib.cidx > 2 || ib.mode > 34 || ib.x + n > W || ib.y + n > H) return "malformed";
+    if ((ib.flags & M355_IBF_HAS_RESIDUAL) && (uint64_t)ib.res_ofs + n * n > pic->res_len) return "residual range";
+    if ((ib.flags & M355_IBF_PCM) && (uint64_t)ib.res_ofs + n * n > pic->n_pcm) return "pcm range";
+    return nullptr;
+  };
+  const char* const names[7] = {"ctb", "cu", "tu", "pb", "weight", "rb", "ib"};
+  const size_t cnts[7] = {(size_t)pic->n_ctbs, (size_t)pic->n_cus, (size_t)pic->n_tus, (size_t)pic->n_pbs, (size_t)pic->n_wts, nrb, (size_t)pic->n_ibs};
+  size_t ofs[8];
+  ofs[0] = 0;
+  for (int q = 0; q < 7; q++) ofs[q + 1] = ofs[q] + cnts[q];
+  std::atomic<size_t> first(ofs[7]);
+  std::atomic<const char*> first_msg(nullptr);
+  std::mutex mu;
+  parallel_ranges(ofs[7], 65536, [&](size_t b, size_t e) {
+    for (size_t g = b; g < e && g < first.load(std::memory_order_relaxed); g++) {
+      int q = 0;
+      while (g >= ofs[q + 1]) q++;
+      const size_t i = g - ofs[q];
+      const char* m = q == 0 ? chk_ctb(i) : q == 1 ? chk_cu(i) : q == 2 ? chk_tu(i) : q == 3 ? chk_pb(i) : q == 4 ? chk_wt(i) : q == 5 ? chk_rb(i) : chk_ib(i);
+      if (m) { std::lock_guard<std::mutex> gd(mu); if (g < first.load()) { first.store(g); first_msg.store(m); } return; }
+    }
+  });
+  if (first.load() < ofs[7]) {
+    int q = 0;
+    while (first.load() >= ofs[q + 1]) q++;
+    return fail(M355_ERR_INVALID, "%s %zu: %s", names[q], first.load() - ofs[q], first_msg.load());
   }
+  (void)rc;
   *ctbW_out = ctbW; *ctbH_out = ctbH;
   return M355_OK;
 }
@@ -567,40 +641,44 @@ static void intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint
 {
   const m355_pic_params& pp = pic->pp;
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
-  std::vector<std::pair<uint32_t, uint32_t>> key;      /* (level << 2 | cidx, index) */
-  long long dense = 0, n_intra_ctbs = 0;
-  for (int c = 0; c < pic->n_ctbs; c++) {
-    const m355_ctb& ctb = pic->ctbs[c];
-    if (!ctb.ib_count) continue;
-    n_intra_ctbs++; dense += ctb.ib_count;
-    const int cx = c % ctbW, cy = c / ctbW;
-    int16_t grid[3][16][16];
-    memset(grid, 0xFF, sizeof(grid));                  /* -1: no intra block of this CTB there (yet) */
-    key.clear();
-    for (uint32_t k = 0; k < ctb.ib_count; k++) {
-      const m355_ib& ib = pic->ibs[ctb.ib_start + k];
-      const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
-      const int ux = (ib.x - ((cx << pp.log2_ctb_size) >> csw)) >> 2, uy = (ib.y - ((cy << pp.log2_ctb_size) >> csh)) >> 2;
-      const int n4 = (1 << ib.log2_size) >> 2;
-      int level = 0;
-      if (ux < 0 || uy < 0 || ux >= 16 || uy >= 16) { key.push_back(std::make_pair((uint32_t)ib.cidx, k)); continue; }   /* rejected by validate() */
-      if (!(ib.flags & M355_IBF_PCM)) {                /* raw blocks read nothing */
-        for (int t = -1; t < 2 * n4; t++) {
-          if (ux - 1 >= 0 && uy + t >= 0 && uy + t < 16) level = std::max(level, grid[ib.cidx][uy + t][ux - 1] + 1);
-          if (uy - 1 >= 0 && ux + t >= 0 && ux + t < 16) level = std::max(level, grid[ib.cidx][uy - 1][ux + t] + 1);
+  std::atomic<long long> dense(0), n_intra_ctbs(0);
+  parallel_ranges((size_t)pic->n_ctbs, 256, [&](size_t cb, size_t ce) {
+    std::vector<std::pair<uint32_t, uint32_t>> key;      /* (level << 2 | cidx, index) */
+    long long my_dense = 0, my_n = 0;
+    for (size_t c = cb; c < ce; c++) {
+      const m355_ctb& ctb = pic->ctbs[c];
+      if (!ctb.ib_count) continue;
+      my_n++; my_dense += ctb.ib_count;
+      const int cx = (int)c % ctbW, cy = (int)c / ctbW;
+      int16_t grid[3][16][16];
+      memset(grid, 0xFF, sizeof(grid));                  /* -1: no intra block of this CTB there (yet) */
+      key.clear();
+      for (uint32_t k = 0; k < ctb.ib_count; k++) {
+        const m355_ib& ib = pic->ibs[ctb.ib_start + k];
+        const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
+        const int ux = (ib.x - ((cx << pp.log2_ctb_size) >> csw)) >> 2, uy = (ib.y - ((cy << pp.log2_ctb_size) >> csh)) >> 2;
+        const int n4 = (1 << ib.log2_size) >> 2;
+        int level = 0;
+        if (ux < 0 || uy < 0 || ux >= 16 || uy >= 16) { key.push_back(std::make_pair((uint32_t)ib.cidx, k)); continue; }   /* rejected by validate() */
+        if (!(ib.flags & M355_IBF_PCM)) {                /* raw blocks read nothing */
+          for (int t = -1; t < 2 * n4; t++) {
+            if (ux - 1 >= 0 && uy + t >= 0 && uy + t < 16) level = std::max(level, grid[ib.cidx][uy + t][ux - 1] + 1);
+            if (uy - 1 >= 0 && ux + t >= 0 && ux + t < 16) level = std::max(level, grid[ib.cidx][uy - 1][ux + t] + 1);
+          }
         }
+        for (int y = uy; y < uy + n4 && y < 16; y++)
+          for (int x = ux; x < ux + n4 && x < 16; x++) grid[ib.cidx][y][x] = (int16_t)level;
+        key.push_back(std::make_pair(((uint32_t)level << 2) | ib.cidx, k));
       }
-      for (int y = uy; y < uy + n4 && y < 16; y++)
-        for (int x = ux; x < ux + n4 && x < 16; x++) if (x >= 0 && y >= 0) grid[ib.cidx][y][x] = (int16_t)level;
-      key.push_back(std::make_pair(((uint32_t)level << 2) | ib.cidx, k));
+      std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+      for (uint32_t k = 0; k < ctb.ib_count; k++) {
+        out[ctb.ib_start + k] = pic->ibs[ctb.ib_start + key[k].second];
+        lvl[ctb.ib_start + k] = (uint16_t)(key[k].first >> 2);
+      }
     }
-    std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
-    for (uint32_t k = 0; k < ctb.ib_count; k++) {
-      out[ctb.ib_start + k] = pic->ibs[ctb.ib_start + key[k].second];
-      lvl[ctb.ib_start + k] = (uint16_t)(key[k].first >> 2);
-    }
-  }
-  *waves = (n_intra_ctbs && dense / n_intra_ctbs >= 24) ? 4 : 1;
+    dense += my_dense; n_intra_ctbs += my_n;
+  });
+  *waves = (n_intra_ctbs.load() && dense.load() / n_intra_ctbs.load() >= 24) ? 4 : 1;
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -631,9 +709,14 @@ static void halo_layout(const m355_pic_params& pp, HaloLayout& h)
 
 static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
 {
+  static const bool prof = getenv("M355_PROFILE_UPLOAD") != nullptr;     /* phase times of this function on stderr */
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t_start = now();
   int ctbW, ctbH;
   int rc = validate(pic, &ctbW, &ctbH);
   if (rc) return rc;
+  const auto t_valid = now();
   const m355_pic_params& pp = pic->pp;
   const int nCtb = ctbW * ctbH;
   const int nrb = pic->rb_count[0] + pic->rb_count[1] + pic->rb_count[2] + pic->rb_count[3];
@@ -677,12 +760,15 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     r.cap = total + total / 4;
     HIPCHK(hipMalloc(&r.dev, r.cap));
     HIPCHK(hipHostMalloc(&r.host, r.cap, hipHostMallocDefault));
-  } else {
-    /* the staging arena may still be in flight from the previous submission */
-    HIPCHK(sync_all(c));
+  } else if (r.done_pending) {
+    /* the arenas may still be in use by the last decode of these lists */
+    HIPCHK(hipEventSynchronize(r.ev_done));
+    r.done_pending = false;
   }
+  const auto t_wait = now();
   for (int i = 0; i < ns; i++)
-    if (seg[i].src && seg[i].bytes) memcpy(r.host + seg[i].ofs, seg[i].src, seg[i].bytes);
+    if (seg[i].src && seg[i].bytes) parallel_memcpy(r.host + seg[i].ofs, seg[i].src, seg[i].bytes);
+  const auto t_copy = now();
   int intra_waves = 1;
   intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint16_t*)(r.host + seg[i_il].ofs), &intra_waves);
   /* derived scan tables (pps.cc:589-606) */
@@ -724,18 +810,17 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     long long nj = 0, nm = 0, nu = 0;
     uint32_t* jb = (uint32_t*)(r.host + seg[i_jb].ofs);
     std::vector<uint32_t> cnt((size_t)n_chunks * 3 + 3, 0);
-    for (int i = 0; i < pic->n_pbs; i++) {
-      const m355_pb& pb = pic->pbs[i];
-      const long long n = (long long)(pb.w >> 2) * ((pb.h + 7) >> 3);
-      nj += n;
-      int cls = 2;
-      if (!m355_pb_is_edge(pb, pp.width, pp.chroma_format_idc)) {
-        nm += n;
-        cls = 1;
-        if (!((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1))) { nu += n; cls = 0; }
-      }
-      cnt[(size_t)(i >> 8) * 3 + cls] += (uint32_t)n;
-    }
+    parallel_ranges((size_t)n_chunks, 64, [&](size_t kb, size_t ke) {
+      for (size_t k = kb; k < ke; k++)
+        for (int i = (int)k * 256; i < pic->n_pbs && i < (int)(k + 1) * 256; i++) {
+          const m355_pb& pb = pic->pbs[i];
+          const uint32_t n = (uint32_t)(pb.w >> 2) * ((pb.h + 7) >> 3);
+          int cls = 2;
+          if (!m355_pb_is_edge(pb, pp.width, pp.chroma_format_idc)) cls = ((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0;
+          cnt[k * 3 + cls] += n;
+        }
+    });
+    for (int k = 0; k < n_chunks; k++) { nu += cnt[(size_t)k * 3]; nm += (long long)cnt[(size_t)k * 3] + cnt[(size_t)k * 3 + 1]; nj += (long long)cnt[(size_t)k * 3] + cnt[(size_t)k * 3 + 1] + cnt[(size_t)k * 3 + 2]; }
     {
       uint32_t run[3] = {0, (uint32_t)nu, (uint32_t)nm};
       for (int k = 0; k < n_chunks; k++)
@@ -755,7 +840,9 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
       if (!ow[i] && pic->ctbs[i].ib_count) return fail(M355_ERR_INVALID, "sharded picture: ctb %d of another rank has intra blocks", i);
   }
   r.sharded = sharded; r.shard_rank = c->shard_rank; r.shard_n = c->shard_n; r.halo = halo; r.live_valid = false; r.xprev = nullptr;
-  r.bytes = total;
+  r.bytes = total; r.fresh = true; r.refs_valid = false;
+  if (prof) fprintf(stderr, "m355 upload: validate %.3f ms, wait/alloc %.3f, copy %.3f (%.1f MB), derive (schedule, jobs, dependencies) %.3f\n",
+                    ms(t_start, t_valid), ms(t_valid, t_wait), ms(t_wait, t_copy), total / 1e6, ms(t_copy, now()));
   HIPCHK(hipMemcpyAsync(r.dev, r.host, total, hipMemcpyHostToDevice, c->stream));
   if (!r.ev_up) HIPCHK(hipEventCreateWithFlags(&r.ev_up, hipEventDisableTiming));
   HIPCHK(hipEventRecord(r.ev_up, c->stream));      /* a decode on the other lane waits for the lists */
@@ -830,7 +917,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
     r.refs_valid = false;
   }
   if (!r.refs_valid || memcmp(r.refs_host, refs, sizeof(refs)) != 0) {
-    HIPCHK(sync_all(c));       /* the staging copy may still be in flight */
+    if (!r.fresh) HIPCHK(sync_all(c));       /* a decode in flight may still read the table / the staging copy */
     memcpy(r.refs_host, refs, sizeof(refs));
     HIPCHK(hipMemcpyAsync(r.refs_dev, r.refs_host, sizeof(refs), hipMemcpyHostToDevice, c->stream));
     r.refs_valid = true;
@@ -938,6 +1025,8 @@ static int decode(m355_ctx* c, Resident& r)
   hipEventRecord(ev[5], st);
   if (want_sao) { dst_hazards(); m355_launch_sao(d, hbd, st); }
   hipEventRecord(ev[6], st);
+  if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+  hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
   if (piped) {
     if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
@@ -1056,9 +1145,11 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
 
 int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
 {
-  int rc = upload(c, c->transient, pic);
+  Resident& t = c->transient[c->next_transient];
+  c->next_transient = (c->next_transient + 1) % 3;
+  int rc = upload(c, t, pic);
   if (rc) return rc;
-  return decode(c, c->transient);
+  return decode(c, t);
 }
 
 int m355_wait(m355_ctx* c)
