@@ -63,3 +63,28 @@ def test_girlshy_stream_md5_on_gpu(gpu_lib):
             sy = 1 if c == 0 else pl[0].shape[0] // p.shape[0]
             m.update(p[cy // sy:cy // sy + h // sy, cx // sx:cx // sx + w // sx].tobytes())
     assert m.hexdigest() == "b81538fa33a67278e5263e231e43ca98"
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_girlshy_pipelined(gpu_lib, depth):
+    """the real stream's dependency structure (I/P/B reference chains) with several pictures in flight: all 75 pictures are
+    submitted back to back (one frame each, no host synchronisation in between), then compared with the reference"""
+    hdr, pics = load_gold("girlshy_full.m355gold.gz")
+    ctx = capi.Context(gpu_lib, 0)
+    try:
+        ctx.set_pipeline_depth(depth)
+        frames, by_dpb = [], {}
+        for pic in pics:
+            dst = ctx.frame_create_for(pic.pp[0])
+            saved = (pic.dst_frame, pic.ref_frames)
+            pic.ref_frames = [by_dpb[s] if pic.ref_frames[s] >= 0 else -1 for s in range(worklist.MAX_REF_FRAMES)]
+            by_dpb[pic.dst_frame] = dst
+            pic.dst_frame = dst
+            ctx.submit(pic)
+            pic.dst_frame, pic.ref_frames = saved
+            frames.append(dst)
+        ctx.wait()
+        for i, (pic, f) in enumerate(zip(pics, frames)):
+            assert plane_md5s(ctx.frame_download(f)) == pic.meta["md5"], "picture %d (POC %d) differs from the reference" % (i, pic.meta["poc"])
+    finally:
+        ctx.close()
