@@ -6,7 +6,11 @@ intra wavefront, deblocking, SAO) over one synthetic picture of the named worklo
 lists and reference frames already resident in HBM when the timed region starts.  Default workload =
 BASELINE.json configs[4] at one GPU: 8K (7680x4320) 10-bit, 4x2 tiles, full in-loop filter chain
 ("c5_8k10_8tiles").  value = CTB64/s over all ranks; for N>1 every rank decodes its
-own picture stream (weak scaling, no data-path collective — see DESIGN.md §multi-GPU).
+own picture stream (weak scaling, no data-path collective — see DESIGN.md §multi-GPU); the barrier and the
+max-over-ranks clock of torch.distributed run over gloo (an idle RCCL communicator in the process costs the
+kernels ~13 % here), RCCL is created for the additional tile-sharded measurement, which does exchange data.
+The timed region runs with --pipeline-depth pictures in flight (default 3; the one-at-a-time time is reported
+beside it).
 
 Also reported:
   roofline      — the dominant kernel's algorithmic bytes per launch (SURVEY.md §8d accounting, computed
@@ -42,16 +46,30 @@ def main():
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
     args = ap.parse_args()
+    # stdout carries exactly ONE line (rank 0's JSON): the libraries underneath are chatty on fd 1 (RCCL's version banner at
+    # NCCL_DEBUG=VERSION, gloo's "[Gloo] Rank ... is connected" line), so fd 1 is pointed at stderr for the run and the
+    # result is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):   # launched by torch.distributed.run
+        # RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION and above; stdout carries exactly one JSON line here
+        if not os.environ.get("M355_KEEP_NCCL_DEBUG"):
+            os.environ.pop("NCCL_DEBUG", None)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # The replica data path has no collective; torch.distributed only provides the barrier and the max-over-ranks
+        # clock.  Those run over gloo: merely INITIALISING an RCCL communicator in the process slows every kernel of the
+        # library by ~13 % on this stack (measured: 0.535 vs 0.460 ms per picture with / without an idle RCCL group), which
+        # would be charged to multi-GPU scaling although nothing is exchanged.  RCCL is created afterwards, as a second
+        # group, for the part that does exchange data (the tile-sharded leg).
+        dist.init_process_group(os.environ.get("M355_BENCH_BACKEND", "gloo"))
 
     from libde265_amd import capi, synth, worklist
     lib = capi.Library()                      # raises if the HIP library is missing: no fallback
@@ -105,7 +123,7 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.barrier()
@@ -168,7 +186,8 @@ def main():
             out["with_upload"] = with_upload
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, synth, worklist)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist:
         dist.destroy_process_group()
@@ -197,11 +216,12 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
     try:
         from libde265_amd import capi, shard
         rank, world = dist.get_rank(), dist.get_world_size()
+        grp = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None     # RCCL over xGMI for the exchanges
         cfg = dict(synth.CONFIGS[args.workload])
         pic = synth.picture(**cfg)                                 # the SAME picture on every rank
         pp = pic.pp[0]
         ctx = capi.Context(lib, local_rank)
-        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(), device="cuda:%d" % local_rank)
+        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(grp), device="cuda:%d" % local_rank)
         refs = []
         for i in range(cfg["n_refs"]):
             f = ctx.frame_create_for(pp)
@@ -222,7 +242,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         ctx.wait()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # the same without the finished-tile all-gather (a non-reference picture)
@@ -232,7 +252,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
             dec.decode(h, gather=False)
         ctx.wait()
         torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_ng = float(t.item())
         dec.decode(h)                       # leave the complete picture behind for the check below
@@ -241,7 +261,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         planes = ctx.frame_download(sp.dst_frame)
         import zlib
         crc = zlib.crc32(b"".join(p.tobytes() for p in planes))
-        c = torch.tensor([crc, -crc], device="cuda", dtype=torch.int64)
+        c = torch.tensor([crc, -crc], dtype=torch.int64)
         dist.all_reduce(c, op=dist.ReduceOp.MAX)
         same = int(c[0].item()) == crc and int(c[1].item()) == -crc
         xb = [int(ctx.shard_xbuf_bytes(h, k)) for k in range(4)]
