@@ -33,54 +33,63 @@ STREAM = "/root/reference/testdata/girlshy.h265"
 GOLDEN = {"full": "b81538fa33a67278e5263e231e43ca98", "nolf": "098a8f4d62bef69504174073879cd4ad"}
 
 
+def record_fixture(ref, stream, out, nodeblk, nosao, meta, expect_md5=None):
+    """run the reference decoder on `stream` through ref_recorder and write the fixture `out`; returns the stream MD5"""
+    with tempfile.TemporaryDirectory() as td:
+        rec = os.path.join(td, "rec")
+        n = ref.ref_record_stream(stream.encode(), rec.encode(), nodeblk, nosao)
+        assert n > 0, n
+        raw = open(rec, "rb").read()
+        planes = open(rec + ".planes", "rb").read()
+        order = [[int(v) for v in l.split()] for l in open(rec + ".order")]
+    assert raw[:8] == b"M355REC1"
+    npic = struct.unpack_from("<i", raw, 8)[0]
+    o, po = 12, 0
+    pics, blobs = [], []
+    by_poc = {}
+    for i in range(npic):
+        poc, dpb, _, _ = struct.unpack_from("<4i", raw, o); o += 16
+        pic, o2 = worklist.Picture.loads(raw, o)
+        blobs.append(raw[o:o2]); o = o2
+        pp = pic.pp[0]
+        dims = worklist.plane_dims(int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]))
+        md5s, pl = [], []
+        for c, (w, h) in enumerate(dims):
+            bpp = 1 if (pp["bit_depth_luma"] if c == 0 else pp["bit_depth_chroma"]) <= 8 else 2
+            nb = w * h * bpp
+            md5s.append(hashlib.md5(planes[po:po + nb]).hexdigest()); pl.append((planes[po:po + nb], w, h, bpp)); po += nb
+        pics.append({"poc": poc, "dpb": dpb, "md5": md5s})
+        by_poc.setdefault(poc, []).append(pl)   # IDR-only streams repeat POC 0: first decoded is first output
+    assert po == len(planes)
+    # re-derive the whole-stream MD5 exactly as `dec265 -o -` writes it (cropped planes, display order)
+    m = hashlib.md5()
+    for poc, w, h, cx, cy in order:
+        cur = by_poc[poc].pop(0)
+        for c, (data, pw, ph, bpp) in enumerate(cur):
+            sx = 1 if c == 0 else cur[0][1] // pw
+            sy = 1 if c == 0 else cur[0][2] // ph
+            cw, ch, ox, oy = w // sx, h // sy, cx // sx, cy // sy
+            for y in range(ch):
+                s = ((oy + y) * pw + ox) * bpp
+                m.update(data[s:s + cw * bpp])
+    stream_md5 = m.hexdigest()
+    if expect_md5 is not None:
+        assert stream_md5 == expect_md5, (out, stream_md5)
+    hdr = dict(meta)
+    hdr.update({"stream_md5": stream_md5, "pictures": pics, "order": order})
+    hdr = json.dumps(hdr).encode()
+    with gzip.GzipFile(out, "wb", compresslevel=9, mtime=0) as f:
+        f.write(b"M355GOLD" + struct.pack("<I", len(hdr)) + hdr + b"".join(blobs))
+    print(os.path.basename(out), npic, "pictures, stream md5", stream_md5, os.path.getsize(out), "bytes")
+    return stream_md5
+
+
 def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-j8", "ref"], check=True)
     ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libde265_ref.so"))
     for variant, (nodeblk, nosao) in {"full": (0, 0), "nolf": (1, 1)}.items():
-        with tempfile.TemporaryDirectory() as td:
-            rec = os.path.join(td, "rec")
-            n = ref.ref_record_stream(STREAM.encode(), rec.encode(), nodeblk, nosao)
-            assert n > 0, n
-            raw = open(rec, "rb").read()
-            planes = open(rec + ".planes", "rb").read()
-            order = [[int(v) for v in l.split()] for l in open(rec + ".order")]
-        assert raw[:8] == b"M355REC1"
-        npic = struct.unpack_from("<i", raw, 8)[0]
-        o, po = 12, 0
-        pics, blobs = [], []
-        by_poc = {}
-        for i in range(npic):
-            poc, dpb, _, _ = struct.unpack_from("<4i", raw, o); o += 16
-            pic, o2 = worklist.Picture.loads(raw, o)
-            blobs.append(raw[o:o2]); o = o2
-            pp = pic.pp[0]
-            dims = worklist.plane_dims(int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]))
-            md5s, pl = [], []
-            for c, (w, h) in enumerate(dims):
-                bpp = 1 if (pp["bit_depth_luma"] if c == 0 else pp["bit_depth_chroma"]) <= 8 else 2
-                nb = w * h * bpp
-                md5s.append(hashlib.md5(planes[po:po + nb]).hexdigest()); pl.append((planes[po:po + nb], w, h, bpp)); po += nb
-            pics.append({"poc": poc, "dpb": dpb, "md5": md5s})
-            by_poc[poc] = pl
-        assert po == len(planes)
-        # re-derive the whole-stream MD5 exactly as `dec265 -o -` writes it (cropped planes, display order)
-        m = hashlib.md5()
-        for poc, w, h, cx, cy in order:
-            for c, (data, pw, ph, bpp) in enumerate(by_poc[poc]):
-                sx = 1 if c == 0 else by_poc[poc][0][1] // pw
-                sy = 1 if c == 0 else by_poc[poc][0][2] // ph
-                cw, ch, ox, oy = w // sx, h // sy, cx // sx, cy // sy
-                for y in range(ch):
-                    s = ((oy + y) * pw + ox) * bpp
-                    m.update(data[s:s + cw * bpp])
-        stream_md5 = m.hexdigest()
-        assert stream_md5 == GOLDEN[variant], (variant, stream_md5)
-        hdr = json.dumps({"stream": "testdata/girlshy.h265", "variant": variant, "stream_md5": stream_md5,
-                          "pictures": pics, "order": order}).encode()
-        out = os.path.join(HERE, "girlshy_%s.m355gold.gz" % variant)
-        with gzip.GzipFile(out, "wb", compresslevel=9, mtime=0) as f:
-            f.write(b"M355GOLD" + struct.pack("<I", len(hdr)) + hdr + b"".join(blobs))
-        print(variant, npic, "pictures, stream md5", stream_md5, "->", out, os.path.getsize(out), "bytes")
+        record_fixture(ref, STREAM, os.path.join(HERE, "girlshy_%s.m355gold.gz" % variant), nodeblk, nosao,
+                       {"stream": "testdata/girlshy.h265", "variant": variant}, GOLDEN[variant])
 
 
 if __name__ == "__main__":
