@@ -398,6 +398,22 @@ M355_API int m355_frame_upload(m355_ctx* ctx, int frame, int cidx, const void* s
 M355_API int m355_frame_download(m355_ctx* ctx, int frame, int cidx, void* dst, ptrdiff_t stride);
 M355_API int m355_frame_fill(m355_ctx* ctx, int frame, int value_luma, int value_chroma);
 
+/* SEI decoded picture hash of a device frame, computed where the frame lives.
+ * Replaces compute_MD5 / compute_CRC_8bit_fast / compute_checksum (sei.cc:161-258) as called by
+ * process_sei_decoded_picture_hash (sei.cc:276-356); hash_type and the result fields are those of
+ * sei_decoded_picture_hash (sei.h:57-70).  Only the field of the requested type is written, for plane 0 (monochrome)
+ * or planes 0..2.  Synchronous: waits for the pictures in flight.  CRC and checksum run on the device (the frame is not
+ * copied back); MD5 is one serial chain per plane, so the planes are downloaded and hashed on host threads. */
+#define M355_HASH_MD5      0
+#define M355_HASH_CRC      1
+#define M355_HASH_CHECKSUM 2
+typedef struct m355_picture_hash {
+  uint8_t  md5[3][16];
+  uint16_t crc[3];
+  uint32_t checksum[3];
+} m355_picture_hash;
+M355_API int m355_frame_hash(m355_ctx* ctx, int frame, int hash_type, m355_picture_hash* out);
+
 /* Replaces (deferred): decode_TU (slice.cc:3460), decode_prediction_unit (motion.cc:2190) and
  * run_postprocessing_filters_sequential/_parallel (decctx.cc:1783/1811) for one picture. Asynchronous:
  * returns after the work is enqueued on the context's stream. */

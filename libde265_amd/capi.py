@@ -20,6 +20,14 @@ class M355Error(RuntimeError):
         self.code = code
 
 
+HASH_MD5, HASH_CRC, HASH_CHECKSUM = 0, 1, 2
+
+
+class PictureHash(ctypes.Structure):
+    """m355_picture_hash (include/de265_mi355x.h), the fields of sei_decoded_picture_hash (sei.h:64-69)"""
+    _fields_ = [("md5", (ctypes.c_uint8 * 16) * 3), ("crc", ctypes.c_uint16 * 3), ("checksum", ctypes.c_uint32 * 3)]
+
+
 class Library:
     """A loaded libde265_mi355x.so with typed entry points."""
 
@@ -43,6 +51,7 @@ class Library:
         L.m355_frame_upload.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_download.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_fill.argtypes = [vp, i, i, i]
+        L.m355_frame_hash.argtypes = [vp, i, i, vp]
         L.m355_submit_picture.argtypes = [vp, vp]
         L.m355_wait.argtypes = [vp]
         L.m355_picture_upload.argtypes = [vp, vp]
@@ -128,6 +137,16 @@ class Context:
 
     def frame_fill(self, f, luma, chroma):
         self.L.check(self.L.lib.m355_frame_fill(self.h, f, luma, chroma))
+
+    def frame_hash(self, f, hash_type):
+        """SEI decoded picture hash (m355_frame_hash): list of per-plane values — bytes (MD5) or int (CRC, checksum)"""
+        out = PictureHash()
+        self.L.check(self.L.lib.m355_frame_hash(self.h, f, hash_type, ctypes.addressof(out)))
+        w, h, cf, bdl, bdc = self._geom[f]
+        n = 3 if cf else 1
+        if hash_type == HASH_MD5:
+            return [bytes(out.md5[c]) for c in range(n)]
+        return [int((out.crc if hash_type == HASH_CRC else out.checksum)[c]) for c in range(n)]
 
     # ---- pictures ----
     def submit(self, pic):

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "k_common.h"
+#include "k_hash.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...)
@@ -151,6 +152,7 @@ struct m355_ctx {
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
+  uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
 };
 
 #define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_join) X(work) X(pb_of) X(ctb_done) X(ticket) X(timeout) X(edge_tu) X(cuf) \
@@ -321,6 +323,7 @@ void m355_destroy(m355_ctx* c)
   for (auto& r : c->resident) if (r.used) resident_free(r);
   for (auto& t : c->transient) resident_free(t);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
+  if (c->hash_acc) hipFree(c->hash_acc);
   {
     /* the active lane lives in the context's own fields: collect it into a Lane and destroy both */
     Lane a;
@@ -420,6 +423,55 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
       std::vector<uint16_t> tmp(n, (uint16_t)v);
       HIPCHK(hipMemcpy(f->plane[cc], tmp.data(), n * 2, hipMemcpyHostToDevice));
     }
+  }
+  return M355_OK;
+}
+
+int m355_frame_hash(m355_ctx* c, int h, int type, m355_picture_hash* out)
+{
+  Frame* f = get_frame(c, h);
+  if (!f || !out) return fail(M355_ERR_INVALID, "bad frame handle %d / null result", h);
+  if (type != M355_HASH_MD5 && type != M355_HASH_CRC && type != M355_HASH_CHECKSUM) return fail(M355_ERR_INVALID, "bad hash type %d", type);
+  hipSetDevice(c->device);
+  HIPCHK(sync_all(c));
+  const int np = f->pw[1] ? 3 : 1;
+  if (type == M355_HASH_MD5) {
+    std::vector<uint8_t> host[3];
+    std::vector<std::thread> th;
+    for (int cc = 0; cc < np; cc++) {
+      const size_t rb = (size_t)f->pw[cc] * f->bpp[cc];
+      host[cc].resize(rb * f->ph[cc]);
+      HIPCHK(hipMemcpy2D(host[cc].data(), rb, f->plane[cc], (size_t)f->stride[cc] * f->bpp[cc], rb, f->ph[cc], hipMemcpyDeviceToHost));
+      th.emplace_back([&, cc, rb] { m355_md5_rows(host[cc].data(), rb, (int)rb, f->ph[cc], out->md5[cc]); });
+    }
+    for (auto& t : th) t.join();
+    return M355_OK;
+  }
+  if (!c->hash_acc) HIPCHK(hipMalloc(&c->hash_acc, 4 * sizeof(uint32_t)));
+  HashArgs a = {};
+  a.rows_per_wave = 8;
+  a.out = c->hash_acc;
+  int nw = 0;
+  for (int cc = 0; cc < 3; cc++) {
+    a.first[cc] = nw;
+    if (cc >= np) continue;
+    a.pl[cc].base = (const uint8_t*)f->plane[cc];
+    a.pl[cc].pitch = (size_t)f->stride[cc] * f->bpp[cc];
+    a.pl[cc].row_bytes = f->pw[cc] * f->bpp[cc];
+    a.pl[cc].h = f->ph[cc];
+    a.pl[cc].bpp = f->bpp[cc];
+    nw += (f->ph[cc] + a.rows_per_wave - 1) / a.rows_per_wave;
+  }
+  a.first[3] = nw;
+  uint32_t acc[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemsetAsync(c->hash_acc, 0, 4 * sizeof(uint32_t), c->stream));
+  m355_launch_frame_hash(a, type, c->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(acc, c->hash_acc, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int cc = 0; cc < np; cc++) {
+    if (type == M355_HASH_CRC) out->crc[cc] = (uint16_t)(acc[cc] ^ m355_crc_init_term((uint64_t)a.pl[cc].row_bytes * a.pl[cc].h));
+    else out->checksum[cc] = acc[cc];
   }
   return M355_OK;
 }

@@ -1183,3 +1183,94 @@ int o_decode_picture(const m355_picture* pic, o_frame* dst, o_frame* const* refs
   free_state(&s);
   return 0;
 }
+
+/* ================================================================================================
+ * SEI decoded picture hash (sei.cc:161-257).  The hashed message is the plane row by row; samples of more than 8 bits
+ * contribute two bytes, low byte first (raw_hash_data::prepare_16bit, sei.cc:141-158).
+ * ================================================================================================ */
+
+/* compute_checksum, sei.cc:161-186.  For bit_depth > 8 the reference indexes rows with stride/2 although its strides are
+ * in samples (image.h:276-283), i.e. it reads the wrong rows; this restatement follows H.265 D.3.19 (and the reference's
+ * 8-bit branch), which is what a stream's SEI carries. */
+uint32_t o_hash_checksum(const void* data, int w, int h, ptrdiff_t stride, int bit_depth) {
+  uint32_t sum = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const uint8_t xorMask = (uint8_t)((x & 0xFF) ^ (y & 0xFF) ^ (x >> 8) ^ (y >> 8));
+      if (bit_depth <= 8) sum += ((const uint8_t*)data)[y * stride + x] ^ xorMask;
+      else {
+        const uint16_t v = ((const uint16_t*)data)[y * stride + x];
+        sum += (v & 0xFF) ^ xorMask;
+        sum += (v >> 8) ^ xorMask;
+      }
+    }
+  return sum;
+}
+
+/* crc_process_byte_parallel, sei.cc:198-207 */
+static uint16_t crc_byte(uint16_t crc, uint8_t byte) {
+  const uint16_t s = (uint16_t)(byte ^ (crc >> 8));
+  const uint16_t t = (uint16_t)(s ^ (s >> 4));
+  return (uint16_t)((crc << 8) ^ t ^ (t << 5) ^ (t << 12));
+}
+/* compute_CRC_8bit_fast, sei.cc:209-233 */
+uint32_t o_hash_crc(const void* data, int w, int h, ptrdiff_t stride, int bit_depth) {
+  uint16_t crc = 0xFFFF;
+  crc = crc_byte(crc, 0);
+  crc = crc_byte(crc, 0);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      if (bit_depth <= 8) crc = crc_byte(crc, ((const uint8_t*)data)[y * stride + x]);
+      else {
+        const uint16_t v = ((const uint16_t*)data)[y * stride + x];
+        crc = crc_byte(crc, (uint8_t)(v & 0xFF));
+        crc = crc_byte(crc, (uint8_t)(v >> 8));
+      }
+    }
+  return crc;
+}
+
+/* compute_MD5, sei.cc:236-257, over RFC 1321 (the reference bundles its own md5.cc) */
+typedef struct { uint32_t s[4]; uint64_t n; uint8_t buf[64]; } o_md5;
+static uint32_t md5_rol(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+static void md5_block(o_md5* m, const uint8_t* p) {
+  static const int R[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+  uint32_t w[16], a = m->s[0], b = m->s[1], c = m->s[2], d = m->s[3];
+  for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+  for (int i = 0; i < 64; i++) {
+    /* K[i] = floor(2^32 * |sin(i + 1)|) */
+    const uint32_t K = (uint32_t)(int64_t)(4294967296.0 * __builtin_fabs(__builtin_sin((double)(i + 1))));
+    uint32_t f; int g;
+    switch (i >> 4) {
+      case 0: f = (b & c) | (~b & d); g = i; break;
+      case 1: f = (d & b) | (~d & c); g = (5 * i + 1) & 15; break;
+      case 2: f = b ^ c ^ d; g = (3 * i + 5) & 15; break;
+      default: f = c ^ (b | ~d); g = (7 * i) & 15; break;
+    }
+    const uint32_t t = d;
+    d = c; c = b;
+    b = b + md5_rol(a + f + K + w[g], R[i >> 4][i & 3]);
+    a = t;
+  }
+  m->s[0] += a; m->s[1] += b; m->s[2] += c; m->s[3] += d;
+}
+static void md5_update(o_md5* m, const uint8_t* p, size_t len) {
+  for (size_t i = 0; i < len; i++) {
+    m->buf[m->n++ & 63] = p[i];
+    if ((m->n & 63) == 0) md5_block(m, m->buf);
+  }
+}
+void o_hash_md5(const void* data, int w, int h, ptrdiff_t stride, int bit_depth, uint8_t out[16]) {
+  o_md5 m = {{0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u}, 0, {0}};
+  const int bpp = bit_depth <= 8 ? 1 : 2;
+  for (int y = 0; y < h; y++) md5_update(&m, (const uint8_t*)data + (size_t)y * stride * bpp, (size_t)w * bpp);   /* little-endian host = low byte first */
+  const uint64_t bits = m.n * 8;
+  const uint8_t pad = 0x80, zero = 0;
+  md5_update(&m, &pad, 1);
+  while ((m.n & 63) != 56) md5_update(&m, &zero, 1);
+  uint8_t lenb[8];
+  for (int i = 0; i < 8; i++) lenb[i] = (uint8_t)(bits >> (8 * i));
+  md5_update(&m, lenb, 8);
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 4; k++) out[4 * i + k] = (uint8_t)(m.s[i] >> (8 * k));
+}

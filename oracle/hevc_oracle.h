@@ -98,6 +98,12 @@ void o_frame_export(const o_frame* f, int cidx, void* dst, ptrdiff_t stride, int
  * is indexed by m355_pb.ref_slot). stages = M355_STAGE_* mask. Returns 0 or M355_ERR_INVALID. */
 int o_decode_picture(const m355_picture* pic, o_frame* dst, o_frame* const* refs, int stages);
 
+/* ---- SEI decoded picture hash of one plane (sei.cc:161-257); data = w x h samples (uint8_t for bit_depth <= 8,
+ * else uint16_t), stride in samples ---- */
+uint32_t o_hash_checksum(const void* data, int w, int h, ptrdiff_t stride, int bit_depth);
+uint32_t o_hash_crc(const void* data, int w, int h, ptrdiff_t stride, int bit_depth);
+void o_hash_md5(const void* data, int w, int h, ptrdiff_t stride, int bit_depth, uint8_t out[16]);
+
 #ifdef __cplusplus
 }
 #endif

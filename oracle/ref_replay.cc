@@ -331,4 +331,49 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
   return 0;
 }
 
+
+/* Pin for the SEI picture-hash path: builds a de265_image from tight planes and lets the reference's own
+ * process_sei (sei.cc:441 -> process_sei_decoded_picture_hash, sei.cc:276-356) judge the candidate hash.
+ * hash_type as sei.h:57-61.  Returns the reference's de265_error (0 = hash accepted, DE265_ERROR_CHECKSUM_MISMATCH
+ * otherwise) or a negative code for setup errors. */
+__attribute__((visibility("default")))
+int m355_ref_check_hash(int width, int height, int chroma_format_idc, int bit_depth_luma, int bit_depth_chroma,
+                        const void* const* planes, int hash_type, const uint8_t* md5 /* [3][16] */, const uint16_t* crc, const uint32_t* checksum)
+{
+  std::shared_ptr<seq_parameter_set> sps = std::make_shared<seq_parameter_set>();
+  sps->set_defaults();
+  sps->chroma_format_idc = chroma_format_idc;
+  sps->pic_width_in_luma_samples = width; sps->pic_height_in_luma_samples = height;
+  sps->bit_depth_luma = bit_depth_luma; sps->bit_depth_chroma = bit_depth_chroma;
+  sps->log2_min_luma_coding_block_size = 3;
+  sps->log2_diff_max_min_luma_coding_block_size = 0;
+  sps->log2_min_transform_block_size = 2;
+  sps->log2_diff_max_min_transform_block_size = 1;
+  if (sps->compute_derived_values(false) != DE265_OK) return -2;
+  sps->sps_read = true;
+  std::shared_ptr<pic_parameter_set> pps = std::make_shared<pic_parameter_set>();
+  pps->set_defaults();
+  pps->sps = sps;
+  pps->set_derived_values(sps.get());
+  pps->pps_read = true;
+
+  decoder_context dctx;
+  dctx.param_sei_check_hash = true;              /* DE265_DECODER_PARAM_BOOL_SEI_CHECK_HASH (de265.cc:522); process_sei skips the check otherwise */
+  de265_image img;
+  if (img.alloc_image(width, height, (de265_chroma)chroma_format_idc, sps, false, &dctx, 0, nullptr, false) != DE265_OK) return -2;
+  img.set_headers(nullptr, sps, pps);
+  const int nc = chroma_format_idc ? 3 : 1;
+  for (int c = 0; c < nc; c++) import_plane(&img, c, planes[c]);
+  img.PicOutputFlag = true;
+
+  sei_message sei;
+  memset(&sei, 0, sizeof(sei));
+  sei.payload_type = sei_payload_type_decoded_picture_hash;
+  sei.data.decoded_picture_hash.hash_type = (sei_decoded_picture_hash_type)hash_type;
+  if (md5) memcpy(sei.data.decoded_picture_hash.md5, md5, 48);
+  if (crc) memcpy(sei.data.decoded_picture_hash.crc, crc, 6);
+  if (checksum) memcpy(sei.data.decoded_picture_hash.checksum, checksum, 12);
+  return (int)process_sei(&sei, &img);
+}
+
 } /* extern "C" */

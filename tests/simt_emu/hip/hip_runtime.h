@@ -199,6 +199,7 @@ template <class T> static inline T __builtin_amdgcn_readfirstlane(T v)
 /* atomics: one OS thread, fibers switch only at rendezvous points */
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
