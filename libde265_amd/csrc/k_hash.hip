@@ -56,16 +56,25 @@ uint32_t m355_crc_init_term(uint64_t nbytes)
 }
 
 #define HASH_BLOCK 1024   /* bytes per wave step: 64 lanes x 16 */
-struct HashTables { uint16_t after[64]; uint16_t blk; };
+struct HashTables { uint16_t after[64]; uint16_t blk; uint16_t sq[40]; };   /* sq[k] = x^(8 * 2^k) */
 constexpr HashTables make_hash_tables()
 {
   HashTables t{};
   for (int l = 0; l < 64; l++) t.after[l] = (uint16_t)gf_pow_x8((uint64_t)(63 - l) * 16);
   t.blk = (uint16_t)gf_pow_x8(HASH_BLOCK);
+  for (int k = 0; k < 40; k++) t.sq[k] = (uint16_t)gf_pow_x8((uint64_t)1 << k);
   return t;
 }
 __constant__ HashTables c_hash = make_hash_tables();
 
+/* x^(8 * nbytes) on the device: one multiplication per set bit of nbytes (nbytes < 2^40) */
+__device__ __forceinline__ uint32_t d_pow_x8(uint64_t nbytes)
+{
+  uint32_t res = 1u;
+  for (int k = 0; nbytes; k++, nbytes >>= 1)
+    if (nbytes & 1u) res = gf_mul(res, c_hash.sq[k]);
+  return res;
+}
 __device__ __forceinline__ uint32_t d_crc_byte(uint32_t crc, uint32_t byte)
 {
   const uint32_t s = byte ^ (crc >> 8);
@@ -120,13 +129,13 @@ __global__ void __launch_bounds__(256) k_frame_hash(HashArgs a)
           if (k < n) crc = d_crc_byte(crc, (w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
         uint32_t mult, step;
         if (len == HASH_BLOCK) { mult = c_hash.after[lane]; step = c_hash.blk; }
-        else { mult = gf_pow_x8((uint64_t)max(len - lo - n, 0)); step = gf_pow_x8((uint64_t)len); }   /* last block of a row */
+        else { mult = d_pow_x8((uint64_t)max(len - lo - n, 0)); step = d_pow_x8((uint64_t)len); }   /* last block of a row */
         const uint32_t blk = d_wave_xor(n > 0 ? gf_mul(crc, mult) : 0u);
         acc = gf_mul(acc, step) ^ blk;
       }
     }
     const uint64_t after = (uint64_t)(pl.h - y1) * (uint64_t)pl.row_bytes;
-    const uint32_t v = gf_mul(acc, gf_pow_x8(after));
+    const uint32_t v = gf_mul(acc, d_pow_x8(after));
     if (lane == 0 && y1 > y0) atomicXor(&a.out[c], v);
   } else {
     uint32_t sum = 0;

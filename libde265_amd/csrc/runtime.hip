@@ -449,8 +449,13 @@ int m355_frame_hash(m355_ctx* c, int h, int type, m355_picture_hash* out)
   }
   if (!c->hash_acc) HIPCHK(hipMalloc(&c->hash_acc, 4 * sizeof(uint32_t)));
   HashArgs a = {};
-  a.rows_per_wave = 8;
   a.out = c->hash_acc;
+  {
+    /* enough waves to fill 1024 SIMDs a few times over, each still covering >= 1 row */
+    int rows = 0;
+    for (int cc = 0; cc < np; cc++) rows += f->ph[cc];
+    a.rows_per_wave = std::max(1, rows / 4096);
+  }
   int nw = 0;
   for (int cc = 0; cc < 3; cc++) {
     a.first[cc] = nw;

@@ -1237,9 +1237,11 @@ static void md5_block(o_md5* m, const uint8_t* p) {
   static const int R[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
   uint32_t w[16], a = m->s[0], b = m->s[1], c = m->s[2], d = m->s[3];
   for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+  static uint32_t Kt[64];
+  if (!Kt[0])   /* K[i] = floor(2^32 * |sin(i + 1)|) */
+    for (int i = 63; i >= 0; i--) Kt[i] = (uint32_t)(int64_t)(4294967296.0 * __builtin_fabs(__builtin_sin((double)(i + 1))));
   for (int i = 0; i < 64; i++) {
-    /* K[i] = floor(2^32 * |sin(i + 1)|) */
-    const uint32_t K = (uint32_t)(int64_t)(4294967296.0 * __builtin_fabs(__builtin_sin((double)(i + 1))));
+    const uint32_t K = Kt[i];
     uint32_t f; int g;
     switch (i >> 4) {
       case 0: f = (b & c) | (~b & d); g = i; break;
