@@ -11,7 +11,7 @@ pixel path consumes plus the reference's own final planes, and stores
   * the MD5 of each plane of each picture as the reference produced it,
   * the display order + conformance crop, so that the whole-stream YUV MD5 can be re-derived and
     compared with the reference CI's golden b81538fa33a67278e5263e231e43ca98 (scripts/ci-run.sh:91-92).
-Two variants: the full chain, and deblocking+SAO disabled (dec265 --disable-deblocking --disable-sao,
+Four variants: the full chain, SAO disabled, deblocking disabled, and deblocking+SAO disabled (dec265 --disable-deblocking --disable-sao,
 golden 098a8f4d62bef69504174073879cd4ad measured with the reference in SURVEY.md 8c).
 """
 import ctypes
@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 from libde265_amd import worklist  # noqa: E402
 
 STREAM = "/root/reference/testdata/girlshy.h265"
-GOLDEN = {"full": "b81538fa33a67278e5263e231e43ca98", "nolf": "098a8f4d62bef69504174073879cd4ad"}
+GOLDEN = {"full": "b81538fa33a67278e5263e231e43ca98", "nolf": "098a8f4d62bef69504174073879cd4ad",
+          # stage-isolated goldens measured with the reference CLI: dec265 --disable-sao / --disable-deblocking
+          "nosao": "f0647c472db1a58c4a5f8b605da7513b", "nodeblk": "6983e435cf17979b90b721555a45493b"}
 
 
 def record_fixture(ref, stream, out, nodeblk, nosao, meta, expect_md5=None):
@@ -87,7 +89,7 @@ def record_fixture(ref, stream, out, nodeblk, nosao, meta, expect_md5=None):
 def main():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-j8", "ref"], check=True)
     ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libde265_ref.so"))
-    for variant, (nodeblk, nosao) in {"full": (0, 0), "nolf": (1, 1)}.items():
+    for variant, (nodeblk, nosao) in {"full": (0, 0), "nolf": (1, 1), "nosao": (0, 1), "nodeblk": (1, 0)}.items():
         record_fixture(ref, STREAM, os.path.join(HERE, "girlshy_%s.m355gold.gz" % variant), nodeblk, nosao,
                        {"stream": "testdata/girlshy.h265", "variant": variant}, GOLDEN[variant])
 

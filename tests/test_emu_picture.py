@@ -46,7 +46,7 @@ def run_stream(ctx, pics, n, stages=worklist.STAGE_ALL):
         assert plane_md5s(planes) == pic.meta["md5"], "picture %d (POC %d) differs from the reference" % (i, pic.meta["poc"])
 
 
-@pytest.mark.parametrize("variant,n", [("full", 75), ("nolf", 20)])
+@pytest.mark.parametrize("variant,n", [("full", 75), ("nolf", 20), ("nosao", 12), ("nodeblk", 12)])
 def test_emulated_kernels_match_reference_on_girlshy(emu_lib, variant, n):
     hdr, pics = load_gold("girlshy_%s.m355gold.gz" % variant)
     ctx = capi.Context(emu_lib, 0)

@@ -27,11 +27,15 @@ def replay(decode_fn, new_frame, free_frame, get_planes, pics):
         free_frame(f)
 
 
-@pytest.mark.parametrize("variant", ["full", "nolf"])
+GOLDEN = {"full": "b81538fa33a67278e5263e231e43ca98", "nolf": "098a8f4d62bef69504174073879cd4ad",
+          # stage-isolated (dec265 --disable-sao / --disable-deblocking)
+          "nosao": "f0647c472db1a58c4a5f8b605da7513b", "nodeblk": "6983e435cf17979b90b721555a45493b"}
+
+
+@pytest.mark.parametrize("variant", sorted(GOLDEN))
 def test_girlshy_oracle_matches_reference(oracle, variant):
     hdr, pics = load_gold("girlshy_%s.m355gold.gz" % variant)
-    assert hdr["stream_md5"] == {"full": "b81538fa33a67278e5263e231e43ca98",
-                                 "nolf": "098a8f4d62bef69504174073879cd4ad"}[variant]
+    assert hdr["stream_md5"] == GOLDEN[variant]
     o = Oracle(oracle)
     by_poc = {}
     for i, pic, planes in replay(o.decode, o.frame_new, o.frame_free, o.frame_planes, pics):

@@ -23,7 +23,7 @@ def gpu_lib():
     return lib
 
 
-@pytest.mark.parametrize("variant", ["full", "nolf"])
+@pytest.mark.parametrize("variant", ["full", "nolf", "nosao", "nodeblk"])
 def test_girlshy_bit_exact_on_gpu(gpu_lib, variant):
     hdr, pics = load_gold("girlshy_%s.m355gold.gz" % variant)
     ctx = capi.Context(gpu_lib, 0)
