@@ -21,6 +21,7 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libde265_ref.so")
 GEOMS = [  # w, h, chroma_format_idc, bit depth luma / chroma
     (64, 48, 1, 8, 8), (200, 120, 1, 8, 8), (416, 240, 1, 10, 10), (1928, 24, 1, 8, 8), (72, 40, 0, 8, 8),
     (136, 72, 2, 10, 9), (264, 16, 3, 12, 12), (8, 8, 1, 8, 8), (1096, 16, 3, 16, 16), (600, 304, 1, 9, 10),
+    (8, 4104, 1, 8, 8), (16, 8200, 0, 10, 10),     # > 4096 plane rows: several rows per wavefront in the device kernels
 ]
 
 
