@@ -63,6 +63,8 @@ def main():
             os.environ.pop("NCCL_DEBUG", None)
         import torch
         import torch.distributed as dist
+        if os.environ.get("M355_BENCH_SHARE_GPU"):   # plumbing check of the N>1 path on a box with fewer GPUs than ranks
+            local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         # The replica data path has no collective; torch.distributed only provides the barrier and the max-over-ranks
         # clock.  Those run over gloo: merely INITIALISING an RCCL communicator in the process slows every kernel of the
