@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
   __shared__ uint16_t s_f[NWV][4 * 32 + 8];        /* filtered border */
   __shared__ int s_ref[NWV][3 * 32 + 8];           /* angular ref[-nT..2nT], index +32 */
   __shared__ uint32_t s_ticket;
+  __shared__ uint32_t s_need[3][MAXCTB];         /* !DENSE: per component and CTB row, which 8-sample vectors some block's border reads */
   __shared__ uint32_t s_nts[9];                  /* CtbAddrRStoTS of the 3x3 CTB neighbourhood (0xFFFFFFFF outside the picture) */
   __shared__ uint8_t s_nsame[9];                 /* neighbour CTB in the picture, same slice (SliceAddrRS) and same tile */
 
@@ -145,12 +146,39 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
   int* ref = s_ref[wv] + 32;
 
   if (comp) {
+    /* Inter pictures (!DENSE: a handful of intra blocks per CTB, one wave per component): only the samples some block's
+       border gathers — the row above it (x-1 .. x+2nT-1) and the column left of it (y .. y+2nT-1), intrapred.h:436-674 —
+       are read at all, so only the vectors holding them are staged (a 64x64 CTB with two 8x8 intra blocks: ~6 of its 512
+       luma vectors) instead of the whole CTB.  Blocks written later land in the same LDS tile as before. */
+    if (!DENSE) {
+      for (int y = lane; y < ch; y += 64) s_need[cs][y] = 0;
+      wave_sync();
+      const int nvr = cw >> 3;                                /* vectors per row */
+      for (uint32_t k = lane; k < ctbinfo.ib_count; k += 64) {
+        const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + k];
+        const uint32_t w0 = r[0], w1 = r[1];
+        if ((w1 & 0xFFu) != (uint32_t)c) continue;
+        const int nT = 1 << ((w1 >> 8) & 0xFFu);
+        const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
+        if (ly >= 1) {
+          const int v0 = max(lx - 1, 0) >> 3, v1 = min((lx + 2 * nT - 1) >> 3, nvr - 1);
+          if (v1 >= v0) atomicOr(&s_need[cs][ly - 1], ((2u << v1) - 1u) & ~((1u << v0) - 1u));
+        }
+        if (lx >= 1) {
+          const uint32_t bit = 1u << ((lx - 1) >> 3);
+          const int y1 = min(ly + 2 * nT, ch);
+          for (int y = max(ly, 0); y < y1; y++) atomicOr(&s_need[cs][y], bit);
+        }
+      }
+      wave_sync();
+    }
     /* ---- stage the CTB and its halo in LDS: 8-sample vectors, all loads of a lane in flight at once ---- */
     {
       const int l2v = (l2c - csw) - 3;                       /* log2(vectors per row); cw >= 8 */
       const int nvec = ch << l2v;
       for (int idx = lane + 64 * g; idx < nvec; idx += 64 * G) {
         const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
+        if (!DENSE && !((s_need[cs][y] >> (xv >> 3)) & 1u)) continue;
         if (x0c + xv < pw && y0c + y < ph) {
           const PIX* src = plane + (size_t)(y0c + y) * stride + x0c + xv;
           uint4 v;
