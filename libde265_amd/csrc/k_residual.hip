@@ -91,22 +91,34 @@ __device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb,
       const int sz_ofs = LOG2 == 2 ? 0 : LOG2 == 3 ? 6 * 16 : LOG2 == 4 ? 6 * 16 + 6 * 64 : 6 * 16 + 6 * 64 + 6 * 256;
       scl = p.scaling + sz_ofs + (rb.matrix_id & 7) * N2;
     }
-    for (int k = c; k < rb.ncoeff; k += NT) {
-      const uint32_t e = p.coeffs[rb.coeff_ofs + k];
-      int pos = e & 0xFFFF;
-      const int lvl = (int16_t)(e >> 16);
-      if (pos >= N2) continue;
-      int v;
-      if (raw) v = lvl;
-      else {
-        const long long fact = (long long)(scl ? scl[pos] * ls : ls) << qs;
-        long long t = ((long long)lvl * fact + offset) >> bdShift;
-        v = t < -32768 ? -32768 : (t > 32767 ? 32767 : (int)t);
+    /* the (pos, level) pairs are fetched eight per lane at a time: a dense 32x32 block holds 1024 of them, and one
+       dependent load -> scatter step per pair (32 memory round trips per lane) was what the whole launch waited for */
+    constexpr int GB = 8;
+    for (int k0 = c; k0 < rb.ncoeff; k0 += NT * GB) {
+      uint32_t eb[GB];
+#pragma unroll
+      for (int j = 0; j < GB; j++) {
+        const int k = k0 + j * NT;
+        eb[j] = k < rb.ncoeff ? p.coeffs[rb.coeff_ofs + k] : 0xFFFFFFFFu;   /* pos 65535: skipped below */
       }
-      if (rb.flags & M355_RBF_ROTATE) pos = N2 - 1 - pos;
-      const int row = pos >> LOG2, col = pos & (NT - 1);
-      cf16[((row >> 1) * NT + col) * 2 + (row & 1)] = (int16_t)v;
-      if (v != 0) { maxrow = max(maxrow, row); maxcol = max(maxcol, col); }
+#pragma unroll
+      for (int j = 0; j < GB; j++) {
+        const uint32_t e = eb[j];
+        int pos = e & 0xFFFF;
+        const int lvl = (int16_t)(e >> 16);
+        if (pos >= N2) continue;
+        int v;
+        if (raw) v = lvl;
+        else {
+          const long long fact = (long long)(scl ? scl[pos] * ls : ls) << qs;
+          long long t = ((long long)lvl * fact + offset) >> bdShift;
+          v = t < -32768 ? -32768 : (t > 32767 ? 32767 : (int)t);
+        }
+        if (rb.flags & M355_RBF_ROTATE) pos = N2 - 1 - pos;
+        const int row = pos >> LOG2, col = pos & (NT - 1);
+        cf16[((row >> 1) * NT + col) * 2 + (row & 1)] = (int16_t)v;
+        if (v != 0) { maxrow = max(maxrow, row); maxcol = max(maxcol, col); }
+      }
     }
   }
   /* occupied extent: over the block's lanes for the skip/bypass test below, over the WAVE for the loop
@@ -221,6 +233,30 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
   if (active) rb = p.rbs[rb_base + tbi];
   const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
 
+  /* the lane's destination row (prediction samples the residual is added to) is requested BEFORE the transform: its
+     memory round trip then overlaps the coefficient fetch and the two filter passes instead of following them (the
+     launch is a chain of dependent round trips per workgroup, not bandwidth: 0.03-0.045 ms for any ONE block size alone) */
+  constexpr int NVP = sizeof(PIX) == 2 ? NT / 2 : (NT >= 4 ? NT / 4 : 1);
+  uint32_t w[NVP];
+#pragma unroll
+  for (int i = 0; i < NVP; i++) w[i] = 0;
+  const bool rmw = active && !(rb.flags & M355_RBF_DEFERRED);
+  PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
+  if (rmw) {
+    if (sizeof(PIX) == 2) {
+      if (NT >= 8) {
+#pragma unroll
+        for (int i = 0; i < NVP; i += 4) { const uint4 v = *(const uint4*)(d + 2 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
+      } else { const uint2 v = *(const uint2*)d; w[0] = v.x; w[1] = v.y; }
+    } else {
+      if (NT >= 16) {
+#pragma unroll
+        for (int i = 0; i < NVP; i += 4) { const uint4 v = *(const uint4*)(d + 4 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
+      } else if (NT == 8) { const uint2 v = *(const uint2*)d; w[0] = v.x; w[NVP - 1] = v.y; }
+      else w[0] = *(const uint32_t*)d;
+    }
+  }
+
   int res[NT];      /* one row (lane's `c` is the row index here), NT adjacent samples */
   d_rb_compute<LOG2>(p, rb, active, c, cfp, res);
 
@@ -256,16 +292,10 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
 #pragma unroll
     for (int i = 0; i < NT; i += 2) *(uint32_t*)(out + i) = res_pack(d_clip3(-32768, 32767, res[i]), d_clip3(-32768, 32767, res[i + 1]));
   } else {
-    /* read-modify-write of the lane's row: NT samples, as 16-byte (NT >= 8) or 8-byte vectors — blocks are aligned to
-       their size, so the row segment is too */
-    PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + y) * p.stride[rb.cidx] + rb.x;
+    /* add to the lane's row (read above) and write it back: NT samples as 16-byte (NT >= 8) or 8-byte vectors — blocks are
+       aligned to their size, so the row segment is too */
     if (sizeof(PIX) == 2) {
       constexpr int NV = NT / 2;                 /* dwords per row */
-      uint32_t w[NV];
-      if (NT >= 8) {
-#pragma unroll
-        for (int i = 0; i < NV; i += 4) { const uint4 v = *(const uint4*)(d + 2 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
-      } else { const uint2 v = *(const uint2*)d; w[0] = v.x; w[1] = v.y; }
 #pragma unroll
       for (int i = 0; i < NV; i++)
         w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFFFu) + res[2 * i], bd) | ((uint32_t)d_clip_bd((int)(w[i] >> 16) + res[2 * i + 1], bd) << 16);
@@ -275,12 +305,6 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
       } else *(uint2*)d = make_uint2(w[0], w[1]);
     } else {
       constexpr int NV = NT / 4;
-      uint32_t w[NV];
-      if (NT >= 16) {
-#pragma unroll
-        for (int i = 0; i < NV; i += 4) { const uint4 v = *(const uint4*)(d + 4 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
-      } else if (NT == 8) { const uint2 v = *(const uint2*)d; w[0] = v.x; w[NV - 1] = v.y; }
-      else w[0] = *(const uint32_t*)d;
 #pragma unroll
       for (int i = 0; i < NV; i++)
         w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFu) + res[4 * i], bd) | ((uint32_t)d_clip_bd((int)((w[i] >> 8) & 0xFFu) + res[4 * i + 1], bd) << 8) |
