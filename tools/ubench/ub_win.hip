@@ -95,13 +95,16 @@ int main()
       const double bytes = (double)nregions * 390 * 16 * 10;
       if (rep == 2) printf("layout %s: %.3f ms per launch, %.2f TB/s requested (%.0f MB per launch)\n", layout ? "tiled 32x8 " : "linear     ", ms / 10, bytes / ms / 1e9, bytes / 10 / 1e6);
     }
+  // the same at limited occupancy: dynamic LDS caps the workgroups per CU (160 KB / lds) — k_inter runs 2-3 workgroups per CU
+  const int ldss[5] = {0, 20 * 1024, 40 * 1024, 52 * 1024, 80 * 1024};
+  for (int li = 0; li < 5; li++)
   for (int rep = 0; rep < 3; rep++) {
     float ms;
     CHK(hipEventRecord(e0));
-    for (int k = 0; k < 10; k++) hipLaunchKernelGGL(k_win_jobs, dim3(blocks), dim3(256), 0, 0, out, f0, f1, nregions, 1234u + k);
+    for (int k = 0; k < 10; k++) hipLaunchKernelGGL(k_win_jobs, dim3(blocks), dim3(256), ldss[li], 0, out, f0, f1, nregions, 1234u + k);
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
     const double uniq = (double)nregions * 390 * 16 * 10, req = (double)nregions * 64 * 15 * 24 * 10;
-    if (rep == 2) printf("job-shaped requests (k_inter): %.3f ms per launch = %.2f TB/s of distinct window bytes (%.2f TB/s requested by the lanes)\n", ms / 10, uniq / ms / 1e9, req / ms / 1e9);
+    if (rep == 2) printf("job-shaped requests (k_inter), %d workgroups/CU: %.3f ms per launch = %.2f TB/s of distinct window bytes (%.2f TB/s requested by the lanes)\n", ldss[li] ? 160 * 1024 / ldss[li] : 8, ms / 10, uniq / ms / 1e9, req / ms / 1e9);
   }
   return 0;
 }
