@@ -11,6 +11,7 @@
  */
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -489,7 +490,11 @@ extern "C++" {
 static int host_threads()
 {
   static int n = 0;
-  if (!n) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 16 ? 8 : (hc >= 4 ? 4 : 1); }
+  if (!n) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    n = hc >= 16 ? 8 : (hc >= 4 ? 4 : 1);
+    if (const char* e = getenv("M355_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n = v; }   /* validation / staging threads per submit */
+  }
   return n;
 }
 template <class F> static void parallel_ranges(size_t n, size_t min_per_thread, F f)   /* f(begin, end) */
