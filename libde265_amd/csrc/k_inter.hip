@@ -203,6 +203,30 @@ __device__ __forceinline__ int d_hi16s(unsigned v) { return (int)v >> 16; }
    unconditional — hipcc otherwise sinks the dot2 chains under per-lane branches on the MV phase */
 __device__ __forceinline__ unsigned d_sel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
 
+/* Picture-edge rows (motion.cc:84-91,141-159: every sample coordinate clamped to the row): instead of one clamped load per
+ * sample, the row segment nearest to the wanted span is fetched with the vector loads of the fast path and the clamp becomes a
+ * SATURATING SHIFT of it.  P = NP packed pairs = loaded samples X[0 .. 2NP-1]; result pair m = (X[c(2m+d)], X[c(2m+1+d)]),
+ * c = clamp to [0, 2NP-1].  The segment is chosen so that X[0] / X[2NP-1] are the row's first / last sample whenever the span
+ * sticks out on that side. */
+template <int NP, int NOUT>
+__device__ __forceinline__ void d_shift_sat(const unsigned (&P)[NP], int d, unsigned* S)
+{
+  const unsigned L = (P[0] & 0xFFFFu) * 0x10001u, R = (P[NP - 1] >> 16) * 0x10001u;
+  const int q = d >> 1;
+  const unsigned sh = ((unsigned)d & 1u) << 4;
+  unsigned V[NOUT + 1];
+#pragma unroll
+  for (int m = 0; m <= NOUT; m++) {
+    const int i = m + q;
+    unsigned v = L;
+#pragma unroll
+    for (int j = 0; j < NP; j++) v = i == j ? P[j] : v;
+    V[m] = i >= NP ? R : v;
+  }
+#pragma unroll
+  for (int m = 0; m < NOUT; m++) S[m] = __builtin_amdgcn_alignbit(V[m + 1], V[m], sh);
+}
+
 /* 12 consecutive samples starting at column xa of one row -> 6 packed 16-bit pairs.  FAST: the span
  * lies inside the picture row (the 12th sample may be the first pad sample: never used with a
  * non-zero tap); otherwise every column is clamped (motion.cc:84-91,147-155). */
@@ -239,7 +263,20 @@ __device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int
 #pragma unroll
       for (int k = 0; k < 3; k++) { S[2 * k] = (a[k] & 0xFFu) | ((a[k] & 0xFF00u) << 8); S[2 * k + 1] = ((a[k] >> 16) & 0xFFu) | ((a[k] >> 8) & 0xFF0000u); }
     }
-  } else {
+  } else if (sizeof(PIX) == 2 && pw >= 12) {
+    const int xb = d_clip3(0, pw - 12, xa);
+    unsigned E[6];
+    d_ldg16(row + xb, E);
+    d_ldg8(row + xb + 8, E + 4);
+    d_shift_sat<6, 6>(E, xa - xb, S);
+  } else if (sizeof(PIX) == 1 && pw >= 16) {
+    const int xb = d_clip3(0, pw - 16, xa);
+    unsigned E[4], P[8];
+    d_ldg16(row + xb, E);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { P[2 * k] = (E[k] & 0xFFu) | ((E[k] & 0xFF00u) << 8); P[2 * k + 1] = ((E[k] >> 16) & 0xFFu) | ((E[k] >> 8) & 0xFF0000u); }
+    d_shift_sat<8, 6>(P, xa - xb, S);
+  } else {      /* rows shorter than one vector */
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       const unsigned lo = row[d_clip3(0, pw - 1, xa + 2 * k)], hi = row[d_clip3(0, pw - 1, xa + 2 * k + 1)];
@@ -270,7 +307,19 @@ __device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int 
       S[0] = (a & 0xFFu) | ((a & 0xFF00u) << 8); S[1] = ((a >> 16) & 0xFFu) | ((a >> 8) & 0xFF0000u);
       S[2] = (b & 0xFFu) | ((b & 0xFF00u) << 8);
     }
-  } else {
+  } else if (sizeof(PIX) == 2 && pw >= 6) {
+    const int xb = d_clip3(0, pw - 6, xa);
+    unsigned E[3];
+    d_ldg12(row + xb, E);
+    d_shift_sat<3, 3>(E, xa - xb, S);
+  } else if (sizeof(PIX) == 1 && pw >= 8) {
+    const int xb = d_clip3(0, pw - 8, xa);
+    unsigned E[2], P[4];
+    d_ldg8(row + xb, E);
+#pragma unroll
+    for (int k = 0; k < 2; k++) { P[2 * k] = (E[k] & 0xFFu) | ((E[k] & 0xFF00u) << 8); P[2 * k + 1] = ((E[k] >> 16) & 0xFFu) | ((E[k] >> 8) & 0xFF0000u); }
+    d_shift_sat<4, 3>(P, xa - xb, S);
+  } else {      /* rows shorter than one vector */
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const unsigned lo = row[d_clip3(0, pw - 1, xa + 2 * k)], hi = row[d_clip3(0, pw - 1, xa + 2 * k + 1)];

@@ -48,6 +48,13 @@ CONFIGS = {
                          deblock=1, sao=1, seed=0xC4C4C4C4),
     "c5_8k10_8tiles": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2,
                            deblock=1, sao=1, seed=0xC5C5C5C5),
+    # diagnostics (not BASELINE configs): C5 with one CU size only / without out-of-picture motion vectors — what the block mix costs
+    "c5x_cu64": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
+                     seed=0xC5C5C5C5, fixed_cu_log2=6, oob_mv_pct=0),
+    "c5x_cu16": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
+                     seed=0xC5C5C5C5, fixed_cu_log2=4, oob_mv_pct=0),
+    "c5x_noedge": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
+                       seed=0xC5C5C5C5, oob_mv_pct=0),
 }
 
 
