@@ -16,8 +16,8 @@ Also reported:
   roofline      — the dominant kernel's algorithmic bytes per launch (SURVEY.md §8d accounting, computed
                   from the actual lists) / its average duration from HIP events on the library's stream,
                   against the 8 TB/s HBM3E peak;
-  cpu_baseline  — the CPU restatement (oracle, scalar port, 1 core) timed on a bounded sample of the
-                  same recipe on this box's host cores.
+  cpu_baseline  — the REAL reference functions (oracle/_ref, SSE/AVX tables where the reference has them) replaying a
+                  bounded sample of the same recipe on this box's host cores, one picture stream per thread.
 """
 import argparse
 import ctypes
@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c5_8k10_8tiles")
-    ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1 or 2)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", type=int, default=31, help="DIAGNOSTIC ONLY: M355_STAGE_* mask (anything but 31 is not a valid benchmark)")
     ap.add_argument("--with-upload", action="store_true", help="also time m355_submit_picture per step (host lists -> pinned arena -> H2D -> decode): the PCIe-inclusive rate")

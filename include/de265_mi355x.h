@@ -211,9 +211,11 @@ enum {
   M355_PF_IMPLICIT_RDPCM           = 1 << 6,  /* sps.range_extension.implicit_rdpcm_enabled_flag         */
   M355_PF_SCALING_LIST             = 1 << 7,  /* sps.scaling_list_enable_flag (transform.cc:461)         */
   M355_PF_DEBLOCK_ENABLED          = 1 << 8,  /* !DE265_DECODER_PARAM_DISABLE_DEBLOCKING (de265.h:409)   */
-  M355_PF_CROSS_COMPONENT_PRED     = 1 << 9   /* pps.range_extension.cross_component_prediction_enabled_flag
+  M355_PF_CROSS_COMPONENT_PRED     = 1 << 9,  /* pps.range_extension.cross_component_prediction_enabled_flag
                                                  (4:4:4 only, transform.cc:244-260): chroma blocks may carry a
                                                  ResScaleVal in m355_rb.matrix_id (see there)            */
+  M355_PF_TRANSFORM_SKIP_ROTATION  = 1 << 10  /* sps.range_extension.transform_skip_rotation_enabled_flag (transform.cc:400-402);
+                                                 informative: the kernels follow the per-block M355_RBF_ROTATE */
 };
 
 typedef struct m355_pic_params {

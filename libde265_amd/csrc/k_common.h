@@ -80,6 +80,7 @@ struct DevPic {
   /* tile sharding (k_shard.hip): NULL = this context owns the whole picture */
   const uint8_t* ctb_owner;         /* per CTB (raster): 1 = a tile of this rank */
   int halo_cu_base, halo_pb_base;   /* first entry of the foreign border records appended to cus[] / pbs[] */
+  int n_pb_records;                 /* n_pbs + the foreign border records: the highest PB index + 1 that pb_of may legitimately hold */
 };
 
 /* Canonical (rank-independent) layout of the tile-boundary exchange buffers (de265_mi355x.h, "Tile

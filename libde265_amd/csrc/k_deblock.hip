@@ -47,6 +47,9 @@ __device__ int d_boundary_strength(const DevPic& p, int x4, int y4, bool vertica
   if ((ef & (vertical ? E_TU_V : E_TU_H)) && ((ef & E_NONZERO) || (p.edge_tu[uo] & E_NONZERO))) return 1;
   const uint32_t ip = p.pb_of[uo], iq = p.pb_of[u];
   if (!ip || !iq) return 0;
+  /* pb_of is not cleared between pictures (k_meta.hip): an inter CU whose units no PB of THIS picture covers (a list that
+     validation cannot fully check) leaves a stale index — never follow it past this picture's records */
+  if (ip > (uint32_t)p.n_pb_records || iq > (uint32_t)p.n_pb_records) return 0;
   const m355_pb A = p.pbs[ip - 1], B = p.pbs[iq - 1];
   const bool pf0 = A.flags & M355_PBF_PRED_L0, pf1 = A.flags & M355_PBF_PRED_L1;
   const bool qf0 = B.flags & M355_PBF_PRED_L0, qf1 = B.flags & M355_PBF_PRED_L1;

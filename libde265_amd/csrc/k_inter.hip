@@ -239,10 +239,6 @@ template <class PIX, bool FAST>
 __device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[6])
 {
   if (FAST) {
-#ifdef M355_X_NOLOAD   /* experiment: no reference loads at all (timing only, results wrong) */
-    for (int k = 0; k < 6; k++) S[k] = (unsigned)xa * 0x10001u + k;
-    return;
-#endif
     if (sizeof(PIX) == 2) {
       /* 11 samples xa..xa+10 are needed: the 12 loaded ones start at xa or xa-1 (the spare slot moves to the front) */
       const unsigned sh = ((unsigned)xa & 1u) << 4;
@@ -289,10 +285,6 @@ template <class PIX, bool FAST>
 __device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[3])
 {
   if (FAST) {
-#ifdef M355_X_NOLOAD
-    for (int k = 0; k < 3; k++) S[k] = (unsigned)xa * 0x10001u + k;
-    return;
-#endif
     if (sizeof(PIX) == 2) {
       const unsigned sh = ((unsigned)xa & 1u) << 4;
       unsigned E[3];
@@ -657,9 +649,6 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
           const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
           o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
         }
-#ifdef M355_X_NOSTORE   /* experiment: results are computed but (never true at run time) not stored */
-        if (p.pp.width >= 0) continue;
-#endif
         if (sizeof(PIX) == 2) *(uint2*)(d + (size_t)y * p.stride[0]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
         else *(unsigned*)(d + (size_t)y * p.stride[0]) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
       }
@@ -700,9 +689,6 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
 #pragma unroll
       for (int y = 0; y < 4; y++) {
         if (y >= crows) break;
-#ifdef M355_X_NOSTORE
-        if (p.pp.width >= 0) continue;
-#endif
         {
           const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
           const unsigned o0 = (unsigned)d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd);

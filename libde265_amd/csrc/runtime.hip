@@ -363,6 +363,7 @@ void* m355_stream(m355_ctx* c) { return (void*)c->stream; }
 int m355_frame_create(m355_ctx* c, int width, int height, int cf, int bdl, int bdc)
 {
   if (width <= 0 || height <= 0 || cf < 0 || cf > 3 || bdl < 8 || bdl > 16 || bdc < 8 || bdc > 16) return -fail(M355_ERR_INVALID, "bad frame geometry");
+  if ((width & 7) || (height & 7)) return -fail(M355_ERR_INVALID, "frame size %dx%d: HEVC pictures are multiples of the minimum coding block size (>= 8)", width, height);
   if ((bdl <= 8) != (bdc <= 8) && cf != 0) return -fail(M355_ERR_INVALID, "luma/chroma must both be 8-bit or both be 9..16-bit");
   hipSetDevice(c->device);
   int idx = -1;
@@ -537,6 +538,12 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
       pp.log2_min_cb_size < 3 || pp.log2_min_cb_size > pp.log2_ctb_size)
     return fail(M355_ERR_INVALID, "bad block-size parameters");
   if (pp.bit_depth_luma < 8 || pp.bit_depth_luma > 16 || pp.bit_depth_chroma < 8 || pp.bit_depth_chroma > 16) return fail(M355_ERR_INVALID, "bad bit depth");
+  /* pic_width/height_in_luma_samples are multiples of MinCbSizeY (>= 8) in every conforming SPS (sps.cc:428-437 rejects others);
+     the filter kernels rely on it: they work in whole 4x4 units of every plane (k_deblock, k_sao) */
+  if ((pp.width & ((1 << pp.log2_min_cb_size) - 1)) || (pp.height & ((1 << pp.log2_min_cb_size) - 1)))
+    return fail(M355_ERR_INVALID, "picture size %dx%d is not a multiple of the minimum coding block size %d", pp.width, pp.height, 1 << pp.log2_min_cb_size);
+  if (pp.width > 65535 - 64 || pp.height > 65535 - 64) return fail(M355_ERR_INVALID, "picture larger than the 16-bit block coordinates allow");
+  if (pic->n_pbs >= (1 << 25)) return fail(M355_ERR_INVALID, "too many prediction blocks (job words hold 25 index bits)");
   const int cs = 1 << pp.log2_ctb_size;
   const int ctbW = (pp.width + cs - 1) / cs, ctbH = (pp.height + cs - 1) / cs;
   if (pic->n_ctbs != ctbW * ctbH) return fail(M355_ERR_INVALID, "n_ctbs %d != %dx%d", pic->n_ctbs, ctbW, ctbH);
@@ -944,6 +951,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.job_base = (const uint32_t*)(r.dev + seg[i_jb].ofs);
   d.ctb_owner = sharded ? (const uint8_t*)(r.dev + seg[i_ow].ofs) : nullptr;
   d.halo_cu_base = pic->n_cus; d.halo_pb_base = pic->n_pbs;
+  d.n_pb_records = pic->n_pbs + halo.n_units;
   r.used = true;
   return M355_OK;
 }

@@ -37,7 +37,12 @@ typedef struct m355_synth_cfg {
   int32_t chroma_format;    /* 0 or 1 = 4:2:0 (default), 2 = 4:2:2, 3 = 4:4:4, 4 = monochrome */
 } m355_synth_cfg;
 enum { M355_SYN_CONSTRAINED_INTRA = 1, M355_SYN_TRANSQUANT_BYPASS = 2, M355_SYN_SCALING_LIST = 4, M355_SYN_PCM = 8,
-       M355_SYN_PCM_LOOP_FILTER_DISABLE = 16, M355_SYN_CROSS_COMPONENT = 32 /* 4:4:4 only */ };
+       M355_SYN_PCM_LOOP_FILTER_DISABLE = 16, M355_SYN_CROSS_COMPONENT = 32 /* 4:4:4 only */,
+       M355_SYN_RDPCM = 64,          /* RExt: transform skip up to 32x32, implicit (intra, modes 10 / 26) and explicit (inter) RDPCM on
+                                        skip and bypass blocks (slice.cc:3491-3503, fallback-dct.cc:161-256) */
+       M355_SYN_ROTATE = 128,        /* RExt transform_skip_rotation_enabled_flag: 4x4 skip / bypass blocks of intra CUs (transform.cc:400-402) */
+       M355_SYN_MISSING_REF = 256,   /* some PBs reference a DPB slot that holds no picture: predSamples = 1 << 13 (motion.cc:362-376) */
+       M355_SYN_DEQUANTIZED = 512    /* some blocks carry already-scaled levels (what the table slots receive) */ };
 
 typedef struct { void* p; size_t n, cap, esz; } vec;
 typedef struct gen {
@@ -113,6 +118,7 @@ static int gen_tb(gen* g, int cidx, int x, int y, int log2, int intra, int mode,
   rb->qp = (uint8_t)(cidx ? (qp > 3 ? qp - 3 : qp) : qp);
   rb->kind = (intra && cidx == 0 && log2 == 2) ? M355_RK_DST : M355_RK_DCT;
   if (log2 == 2 && rbelow(g, 20) == 0) rb->kind = M355_RK_SKIP;   /* transform_skip is Main profile for 4x4 */
+  if ((g->cfg->features & M355_SYN_RDPCM) && rbelow(g, 4) == 0) rb->kind = M355_RK_SKIP;   /* log2_max_transform_skip_block_size up to 5 (RExt) */
   if (g->cfg->features & M355_SYN_SCALING_LIST) {                  /* matrixID rule of transform.cc:493-502 */
     int m = log2 == 5 ? 0 : cidx;
     if (!intra) m += (log2 < 5) ? 3 : 1;
@@ -131,6 +137,12 @@ static int gen_tb(gen* g, int cidx, int x, int y, int log2, int intra, int mode,
     rb->ncoeff = (uint16_t)cnt;
   } else
   gen_coeffs(g, rb, n);
+  if ((g->cfg->features & M355_SYN_RDPCM) && (rb->kind == M355_RK_SKIP || rb->kind == M355_RK_BYPASS)) {
+    /* intra: implicit_rdpcm_enabled_flag && mode 10 (horizontal) / 26 (vertical); inter: explicit_rdpcm_flag + dir (slice.cc:3491-3503) */
+    if (intra) rb->flags |= (uint8_t)(mode == 10 ? M355_RBF_RDPCM_H : (mode == 26 ? M355_RBF_RDPCM_V : 0));
+    else { const int r3 = rbelow(g, 3); rb->flags |= (uint8_t)(r3 == 1 ? M355_RBF_RDPCM_H : (r3 == 2 ? M355_RBF_RDPCM_V : 0)); }
+  }
+  if ((g->cfg->features & M355_SYN_DEQUANTIZED) && rb->kind != M355_RK_BYPASS && rbelow(g, 3) == 0) rb->flags |= M355_RBF_DEQUANTIZED;
   if (intra) {
     rb->flags |= M355_RBF_DEFERRED; rb->res_ofs = g->res_len;
     ib->flags |= M355_IBF_HAS_RESIDUAL; ib->res_ofs = g->res_len;
@@ -230,6 +242,10 @@ static void gen_pb(gen* g, int x, int y, int w, int h)
     int mvx = rrange(g, -64, 64), mvy = rrange(g, -64, 64);
     if (pct(g, c->oob_mv_pct)) { mvx = rrange(g, -4 * c->width, 4 * c->width); mvy = rrange(g, -4 * c->height, 4 * c->height); if (mvx > 32000) mvx = 32000; if (mvx < -32000) mvx = -32000; if (mvy > 32000) mvy = 32000; if (mvy < -32000) mvy = -32000; }
     pb->mv[l][0] = (int16_t)mvx; pb->mv[l][1] = (int16_t)mvy;
+    if ((c->features & M355_SYN_MISSING_REF) && rbelow(g, 8) == 0) {   /* RefPicList entry without a usable picture */
+      pb->flags |= (uint8_t)(M355_PBF_FILL_L0 << l);
+      pb->ref_slot[l] = (int8_t)c->n_refs;
+    }
   }
   if (pct(g, c->weighted_pct)) {
     pb->flags |= M355_PBF_WEIGHTED;
@@ -282,7 +298,12 @@ static void gen_cu(gen* g, int x, int y, int log2)
     cu->part_mode = nxn ? 3 : 0;
     int lmodes[4];
     for (int i = 0; i < 4; i++) lmodes[i] = rbelow(g, 35);
-    gen_tt(g, x, y, log2, 0, 1, lmodes, rbelow(g, 35), qp, nxn);
+    int cmode = rbelow(g, 35);
+    if (c->features & M355_SYN_RDPCM) {                                /* implicit RDPCM needs modes 10 / 26: make them common */
+      for (int i = 0; i < 4; i++) if (rbelow(g, 2)) lmodes[i] = rbelow(g, 2) ? 10 : 26;
+      if (rbelow(g, 2)) cmode = rbelow(g, 2) ? 10 : 26;
+    }
+    gen_tt(g, x, y, log2, 0, 1, lmodes, cmode, qp, nxn);
   } else {
     const int skip = rbelow(g, 4) == 0;
     cu->pred_mode = skip ? 2 : 1;
@@ -353,7 +374,9 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
               ((cfg->features & M355_SYN_CONSTRAINED_INTRA) ? M355_PF_CONSTRAINED_INTRA_PRED : 0) |
               ((cfg->features & M355_SYN_SCALING_LIST) ? M355_PF_SCALING_LIST : 0) |
               ((cfg->features & M355_SYN_PCM_LOOP_FILTER_DISABLE) ? M355_PF_PCM_LOOP_FILTER_DISABLE : 0) |
-              (((cfg->features & M355_SYN_CROSS_COMPONENT) && g.cf == 3) ? M355_PF_CROSS_COMPONENT_PRED : 0);
+              (((cfg->features & M355_SYN_CROSS_COMPONENT) && g.cf == 3) ? M355_PF_CROSS_COMPONENT_PRED : 0) |
+              ((cfg->features & M355_SYN_RDPCM) ? M355_PF_IMPLICIT_RDPCM : 0) |
+              ((cfg->features & M355_SYN_ROTATE) ? M355_PF_TRANSFORM_SKIP_ROTATION : 0);
   pp->num_tile_cols = (uint8_t)cfg->tile_cols; pp->num_tile_rows = (uint8_t)cfg->tile_rows;
   for (int i = 0; i <= cfg->tile_cols; i++) pp->col_bd[i] = (uint16_t)((i * g.ctbW) / cfg->tile_cols);   /* uniform spacing (pps.cc) */
   for (int i = 0; i <= cfg->tile_rows; i++) pp->row_bd[i] = (uint16_t)((i * g.ctbH) / cfg->tile_rows);
@@ -416,6 +439,41 @@ __attribute__((visibility("default"))) int m355_synth_picture(const m355_synth_c
             }
           }
         }
+
+  if (cfg->features & M355_SYN_ROTATE) {
+    /* transform_skip_rotation (transform.cc:400-402): every 4x4 skip / bypass block whose CU is intra — where the reference
+       looks the prediction mode up at the block's (xT,yT) in COMPONENT samples read as a luma position, which for subsampled
+       chroma is another CU; restated literally, so the lists carry what the reference would do */
+    const int wcb = (cfg->width + 7) >> 3, hcb = (cfg->height + 7) >> 3;
+    uint8_t* is_intra = (uint8_t*)calloc((size_t)wcb * hcb, 1);
+    const m355_cu* cus = (const m355_cu*)g.cus.p;
+    for (size_t i = 0; i < g.cus.n; i++) {
+      if (cus[i].pred_mode != 0) continue;
+      const int n8 = 1 << (cus[i].log2_size - 3);
+      for (int yy = 0; yy < n8; yy++) memset(is_intra + (size_t)((cus[i].y >> 3) + yy) * wcb + (cus[i].x >> 3), 1, (size_t)n8);
+    }
+    m355_rb* r4 = (m355_rb*)g.rbs[0].p;
+    for (size_t i = 0; i < g.rbs[0].n; i++)
+      if ((r4[i].kind == M355_RK_SKIP || r4[i].kind == M355_RK_BYPASS) && is_intra[(size_t)(r4[i].y >> 3) * wcb + (r4[i].x >> 3)]) r4[i].flags |= M355_RBF_ROTATE;
+    free(is_intra);
+  }
+
+  if (cfg->features & M355_SYN_RDPCM) {
+    /* implicit_rdpcm_enabled_flag: angular prediction inside cu_transquant_bypass CUs runs without the boundary filter
+       (intrapred.cc:306-308) — the bypass flag is looked up at the block's position in COMPONENT samples, as the reference does */
+    const int wcb = (cfg->width + 7) >> 3, hcb = (cfg->height + 7) >> 3;
+    uint8_t* is_bypass = (uint8_t*)calloc((size_t)wcb * hcb, 1);
+    const m355_cu* cus = (const m355_cu*)g.cus.p;
+    for (size_t i = 0; i < g.cus.n; i++) {
+      if (!(cus[i].flags & M355_CUF_TRANSQUANT_BYPASS)) continue;
+      const int n8 = 1 << (cus[i].log2_size - 3);
+      for (int yy = 0; yy < n8; yy++) memset(is_bypass + (size_t)((cus[i].y >> 3) + yy) * wcb + (cus[i].x >> 3), 1, (size_t)n8);
+    }
+    m355_ib* ibs = (m355_ib*)g.ibs.p;
+    for (size_t i = 0; i < g.ibs.n; i++)
+      if (!(ibs[i].flags & M355_IBF_PCM) && is_bypass[(size_t)(ibs[i].y >> 3) * wcb + (ibs[i].x >> 3)]) ibs[i].flags |= M355_IBF_DISABLE_BOUNDARY_FILTER;
+    free(is_bypass);
+  }
 
   /* concatenate the four size bins */
   size_t nrb = 0;

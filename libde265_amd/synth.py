@@ -19,6 +19,7 @@ class SynthCfg(ctypes.Structure):
                 ("features", ctypes.c_int32), ("chroma_format", ctypes.c_int32)]
 
 SYN_CONSTRAINED_INTRA, SYN_TRANSQUANT_BYPASS, SYN_SCALING_LIST, SYN_PCM, SYN_PCM_LOOP_FILTER_DISABLE, SYN_CROSS_COMPONENT = 1, 2, 4, 8, 16, 32   # SynthCfg.features bits (csrc/synth.c)
+SYN_RDPCM, SYN_ROTATE, SYN_MISSING_REF, SYN_DEQUANTIZED = 64, 128, 256, 512
 
 
 class _SynthOut(ctypes.Structure):

@@ -15,8 +15,12 @@
  * not exercise — tiles, 10/12-bit, explicit weights, out-of-picture MVs, transform skip, every CU/TU size —
  * on the synthetic pictures the GPU parity tests use.  It is also the "reference" CPU baseline of bench.py.
  *
- * Not replayed: missing-reference fills (no such blocks in the synthetic lists).  PCM blocks: the sample store is
- * done here (read_pcm_samples consumes the bitstream), the filters' treatment of PCM units is the reference's.
+ * Missing-reference fills (M355_PBF_FILL_*): the block's DPB slot holds no image here either, so the reference's own
+ * error path (motion.cc:362-376) produces the 1 << 13 prediction.  Blocks that carry already-scaled levels
+ * (M355_RBF_DEQUANTIZED, what the table slots receive) enter the reference below its dequantiser: the levels go into
+ * coeffBuf and the reference's own slots (transform_add / transform_skip_residual / rdpcm_* + add_residual) run on them,
+ * as scale_coefficients_internal calls them (transform.cc:530-625).  PCM blocks: the sample store is done here
+ * (read_pcm_samples consumes the bitstream), the filters' treatment of PCM units is the reference's.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -102,6 +106,7 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
   sps->strong_intra_smoothing_enable_flag = (pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) ? 1 : 0;
   sps->range_extension.intra_smoothing_disabled_flag = (pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) ? 1 : 0;
   sps->range_extension.implicit_rdpcm_enabled_flag = (pp.flags & M355_PF_IMPLICIT_RDPCM) ? 1 : 0;
+  sps->range_extension.transform_skip_rotation_enabled_flag = (pp.flags & M355_PF_TRANSFORM_SKIP_ROTATION) ? 1 : 0;
   if (pp.flags & M355_PF_SCALING_LIST) {
     /* ScalingFactor tables as the lists carry them: [sizeId][matrixID][y][x] (sps.h:58-65) */
     sps->scaling_list_enable_flag = 1;
@@ -215,13 +220,13 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
   }
   for (int i = 0; i < pic->n_pbs; i++) {
     const m355_pb& pb = pic->pbs[i];
-    if (pb.flags & (M355_PBF_FILL_L0 | M355_PBF_FILL_L1)) return -1;
     PBMotion mv;
     memset(&mv, 0, sizeof(mv));
     for (int l = 0; l < 2; l++) {
       mv.predFlag[l] = (pb.flags & (M355_PBF_PRED_L0 << l)) ? 1 : 0;
       if (mv.predFlag[l]) {
         if (pb.ref_slot[l] < 0 || pb.ref_slot[l] >= MAX_NUM_REF_PICS) return -1;
+        if ((pb.flags & (M355_PBF_FILL_L0 << l)) && rctx.frames[pb.ref_slot[l]]) return -1;   /* a fill must name a slot without a picture */
         mv.refIdx[l] = (uint8_t)pb.ref_slot[l];
         mv.mv[l].x = pb.mv[l][0]; mv.mv[l].y = pb.mv[l][1];
       }
@@ -262,7 +267,7 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
   tctx->decctx = &dctx; tctx->img = img;
   memset(tctx->coeffBuf, 0, 32 * 32 * sizeof(int16_t));
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh_ = pp.chroma_format_idc == 1 ? 2 : 1;
-  auto run_rb = [&](const m355_rb& rb) {
+  auto run_rb = [&](const m355_rb& rb) -> bool {
     const int nT = 1 << rb.log2_size, c = rb.cidx;
     const int xl = c ? rb.x * sw : rb.x, yl = c ? rb.y * sh_ : rb.y;
     tctx->shdr = img->get_SliceHeader(xl, yl);
@@ -281,15 +286,40 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
     }
     const int rdpcm = (rb.flags & M355_RBF_RDPCM_H) ? 1 : ((rb.flags & M355_RBF_RDPCM_V) ? 2 : 0);
     const bool intra = img->get_pred_mode(xl, yl) == MODE_INTRA;
+    if ((rb.flags & M355_RBF_DEQUANTIZED) && rb.kind != M355_RK_BYPASS) {
+      /* below the dequantiser: the calls of transform.cc:530-625 on the block's levels as they are */
+      if (pp.flags & M355_PF_CROSS_COMPONENT_PRED) return false;
+      acceleration_functions& acc = dctx.acceleration;
+      const int bd = c ? pp.bit_depth_chroma : pp.bit_depth_luma;
+      int16_t* coeff = tctx->coeffBuf;
+      for (int k = 0; k < rb.ncoeff; k++) coeff[tctx->coeffPos[c][k]] = tctx->coeffList[c][k];
+      uint8_t* pred = img->get_image_plane(c) + ((size_t)rb.y * img->get_image_stride(c) + rb.x) * img->get_bytes_per_pixel(c);
+      const int stride = img->get_image_stride(c);
+      if (rb.kind == M355_RK_SKIP) {
+        const int bdShift = 20 - bd, tsShift = 5 + rb.log2_size;
+        if (rb.flags & M355_RBF_ROTATE) acc.rotate_coefficients(coeff, nT);
+        int32_t residual[32 * 32];
+        if (rdpcm == 2) acc.rdpcm_v(residual, coeff, nT, tsShift, bdShift);
+        else if (rdpcm == 1) acc.rdpcm_h(residual, coeff, nT, tsShift, bdShift);
+        else acc.transform_skip_residual(residual, coeff, nT, tsShift, bdShift);
+        if (bd > 8) acc.add_residual<uint16_t>((uint16_t*)pred, stride, residual, nT, bd); else acc.add_residual<uint8_t>(pred, stride, residual, nT, bd);
+      } else if (rb.kind == M355_RK_DST) {
+        if (bd > 8) acc.transform_4x4_dst_add<uint16_t>((uint16_t*)pred, coeff, stride, bd); else acc.transform_4x4_dst_add<uint8_t>(pred, coeff, stride, bd);
+      } else {
+        if (bd > 8) acc.transform_add<uint16_t>(rb.log2_size - 2, (uint16_t*)pred, coeff, stride, bd); else acc.transform_add<uint8_t>(rb.log2_size - 2, pred, coeff, stride, bd);
+      }
+      memset(coeff, 0, 32 * 32 * sizeof(int16_t));
+      return true;
+    }
     scale_coefficients(tctx.get(), rb.x, rb.y, rb.x, rb.y, nT, c, rb.kind == M355_RK_SKIP, intra, rdpcm);
+    return true;
   };
   const int nrb = pic->rb_count[0] + pic->rb_count[1] + pic->rb_count[2] + pic->rb_count[3];
   std::unordered_map<uint32_t, int> deferred;    /* res_ofs -> rb index */
   for (int i = 0; i < nrb; i++) {
     const m355_rb& rb = pic->rbs[i];
-    if (rb.flags & M355_RBF_DEQUANTIZED) return -1;
     if (rb.flags & M355_RBF_DEFERRED) deferred[rb.res_ofs] = i;
-    else if (stages & M355_STAGE_RESIDUAL) run_rb(rb);
+    else if (stages & M355_STAGE_RESIDUAL) { if (!run_rb(rb)) return -1; }
   }
   if (stages & M355_STAGE_INTRA) {
     /* decode order = tile scan over the CTBs, each CTB's blocks as listed */
@@ -316,7 +346,7 @@ int m355_ref_replay(const m355_picture* pic, const void* const* ref_planes, int 
         if ((ib.flags & M355_IBF_HAS_RESIDUAL) && (stages & M355_STAGE_RESIDUAL)) {
           auto it = deferred.find(ib.res_ofs);
           if (it == deferred.end()) return -1;
-          run_rb(pic->rbs[it->second]);
+          if (!run_rb(pic->rbs[it->second])) return -1;
         }
       }
     }

@@ -12,6 +12,18 @@ from libde265_amd import capi, worklist
 
 def corrupt(pic, rng):
     """one random field of one random record set to a random (often out-of-range) value"""
+    if rng.integers(8) == 0:
+        # picture parameters: geometry / block sizes / bit depths / tile grid
+        pp = pic.pp.copy()
+        fields = [f for f in pp.dtype.names if not f.startswith("reserved")]
+        f = fields[rng.integers(len(fields))]
+        col = pp[f]
+        info = np.iinfo(col.dtype)
+        val = [info.max, info.min, int(rng.integers(info.min, int(info.max) + 1)), 0, 1, int(col.flat[0]) + 1, int(col.flat[0]) + 4][rng.integers(7)]
+        val = min(max(val, info.min), info.max)
+        col.flat[rng.integers(col.size)] = val
+        pic.pp = pp
+        return "pp.%s=%d" % (f, val)
     lists = [n for n in ("ctbs", "cus", "tus", "pbs", "rbs", "ibs", "slices", "wts") if len(getattr(pic, n))]
     name = lists[rng.integers(len(lists))]
     arr = getattr(pic, name).copy()
@@ -29,7 +41,7 @@ def corrupt(pic, rng):
     return "%s[%d].%s=%d" % (name, i, f, val)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(8))
 def test_corrupted_lists_never_crash(emu_lib, seed):  # noqa: F811
     rng = np.random.default_rng(1000 + seed)
     cfg = [dict(width=128, height=64, bit_depth=8, seed=301, tile_cols=2), dict(width=96, height=96, bit_depth=10, seed=302, intra_pct=60, features=31),
@@ -39,7 +51,7 @@ def test_corrupted_lists_never_crash(emu_lib, seed):  # noqa: F811
         accepted = rejected = 0
         for _ in range(25):
             pic, refs = make_case(**cfg)
-            pp = pic.pp[0]
+            pp = pic.pp[0].copy()
             what = [corrupt(pic, rng) for _ in range(1 + rng.integers(3))]
             handles = [ctx.frame_create_for(pp) for _ in refs]
             for h, planes in zip(handles, refs):

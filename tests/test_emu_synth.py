@@ -22,6 +22,11 @@ CASES = [
     dict(width=128, height=128, bit_depth=10, seed=33, chroma_format=2, intra_pct=30, features=31, tile_cols=2),
     dict(width=128, height=128, bit_depth=8, seed=34, chroma_format=3, intra_pct=30, features=32),
     dict(width=192, height=128, bit_depth=10, seed=35, chroma_format=3, intra_pct=40, features=63, log2_ctb=5),
+    # RDPCM (64) / rotation (128) on skip + bypass blocks, missing references (256), pre-scaled levels (512)
+    dict(width=192, height=128, bit_depth=8, seed=41, features=64 + 128 + 2, intra_pct=50, cbf_pct=90),
+    dict(width=128, height=128, bit_depth=10, seed=42, features=64 + 128 + 2, chroma_format=3, intra_pct=50, cbf_pct=90, fixed_cu_log2=3),
+    dict(width=192, height=128, bit_depth=8, seed=43, features=256, intra_pct=5, weighted_pct=30),
+    dict(width=128, height=128, bit_depth=10, seed=44, features=512 + 64 + 128, intra_pct=40, cbf_pct=90, chroma_format=2),
 ]
 
 

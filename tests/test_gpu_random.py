@@ -36,11 +36,13 @@ def random_case(seed):
     tr = int(rng.integers(1, min(3, ctbs_y) + 1)) if rng.random() < 0.5 else 1
     feats = 0
     for bit, pr in ((synth.SYN_CONSTRAINED_INTRA, .3), (synth.SYN_TRANSQUANT_BYPASS, .3), (synth.SYN_SCALING_LIST, .3), (synth.SYN_PCM, .3),
-                    (synth.SYN_PCM_LOOP_FILTER_DISABLE, .2)):
+                    (synth.SYN_PCM_LOOP_FILTER_DISABLE, .2), (synth.SYN_RDPCM, .25), (synth.SYN_ROTATE, .25), (synth.SYN_MISSING_REF, .25),
+                    (synth.SYN_DEQUANTIZED, .15)):
         if rng.random() < pr:
             feats |= bit
     if cf == 3 and rng.random() < 0.5:
         feats |= synth.SYN_CROSS_COMPONENT
+        feats &= ~synth.SYN_DEQUANTIZED                    # pre-scaled levels come from the table slots, which cross-component pictures bypass
     intra = int(rng.choice([0, 5, 30, 100]))
     return dict(width=w, height=h, bit_depth=bd, log2_ctb=log2_ctb, tile_cols=tc, tile_rows=tr, intra_pct=intra,
                 n_refs=0 if intra == 100 else 2, bipred_pct=int(rng.choice([0, 50, 100])), weighted_pct=int(rng.choice([0, 10, 60])),

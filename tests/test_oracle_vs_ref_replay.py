@@ -50,6 +50,20 @@ CASES = [
     # cross-component prediction (4:4:4), incl. chroma blocks without coefficients and bypass / scaling-list CUs
     dict(width=256, height=192, bit_depth=8, seed=101, chroma_format=3, features=32, intra_pct=30),
     dict(width=256, height=192, bit_depth=10, seed=102, chroma_format=3, features=32 + 31, intra_pct=50, n_slices=2),
+    # range-extension residual tools: transform skip up to 32x32 with implicit (intra 10 / 26) and explicit (inter) RDPCM on skip
+    # and bypass blocks (64), transform_skip_rotation of 4x4 blocks (128); both, with bypass CUs, in 4:2:0, 4:4:4 and 4:2:2
+    dict(width=256, height=192, bit_depth=8, seed=111, features=64, intra_pct=40, cbf_pct=90),
+    dict(width=256, height=192, bit_depth=10, seed=112, features=64 + 2, intra_pct=50, cbf_pct=90, fixed_cu_log2=3),
+    dict(width=256, height=192, bit_depth=8, seed=113, features=128 + 2, intra_pct=60, cbf_pct=100, fixed_cu_log2=3),
+    dict(width=256, height=192, bit_depth=12, seed=114, features=64 + 128 + 2, chroma_format=3, intra_pct=50, cbf_pct=90),
+    dict(width=256, height=192, bit_depth=8, seed=115, features=64 + 128 + 2 + 4, chroma_format=2, intra_pct=50, cbf_pct=90, n_slices=2),
+    # prediction blocks whose reference picture is missing (motion.cc:362-376): uni, bi (one or both lists), weighted
+    dict(width=256, height=192, bit_depth=8, seed=121, features=256, intra_pct=5, weighted_pct=30),
+    dict(width=256, height=192, bit_depth=10, seed=122, features=256, intra_pct=0, bipred_pct=100, weighted_pct=0, tile_cols=2),
+    dict(width=256, height=192, bit_depth=8, seed=123, features=256, intra_pct=0, chroma_format=3, bipred_pct=50),
+    # blocks that carry already-scaled levels (M355_RBF_DEQUANTIZED): the reference entered below its dequantiser
+    dict(width=256, height=192, bit_depth=8, seed=131, features=512, intra_pct=30, cbf_pct=90),
+    dict(width=256, height=192, bit_depth=10, seed=132, features=512 + 64 + 128, intra_pct=50, cbf_pct=90),
 ]
 STAGES = [W.STAGE_ALL, W.STAGE_INTER | W.STAGE_RESIDUAL | W.STAGE_INTRA, W.STAGE_ALL & ~W.STAGE_SAO, W.STAGE_INTER]
 
