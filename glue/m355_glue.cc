@@ -1,0 +1,912 @@
+/*
+ * m355_glue.cc — the reference-side binding of the MI355X backend (what a libde265 maintainer adds).
+ *
+ * Linked with the reference's OWN objects (compiled from /root/reference where it lies, see glue/Makefile)
+ * into glue/_build/libde265.so: a libde265 with the unchanged public de265.h ABI whose pixel path runs on the
+ * GPU.  Nothing of the reference is copied or edited; the reference functions below are REPLACED at link time
+ * (their definitions in the reference objects are weakened with objcopy, ours win):
+ *
+ *   scale_coefficients                  transform.cc:645   -> record one m355_rb + the parser's sparse levels
+ *   decode_intra_prediction             intrapred.cc:321   -> record one m355_ib (decode order)
+ *   generate_inter_prediction_samples   motion.cc:288      -> record one m355_pb with the host-side decisions
+ *   decoder_context::run_postprocessing_filters_sequential / _parallel   decctx.cc:1783 / 1811
+ *                                                          -> walk the picture's metadata, m355_submit_picture()
+ *   de265_new_decoder / de265_free_decoder / de265_peek_next_picture / de265_get_next_picture   de265.cc:254-449
+ *                                                          -> backend context; download a picture when it is output
+ * deblock.cc and sao.cc are not linked at all (their four entry points exist here only as traps).
+ *
+ * The host keeps doing everything it did before — NAL / CABAC parsing, MV and QP derivation, DPB management,
+ * output order — and NO pixel arithmetic: every slot of the decoder's acceleration table is replaced by a trap
+ * that counts (m355_glue_cpu_pixel_calls(), 0 in the tests).  Pictures live on the device keyed by DPB index
+ * (dpb.cc:194-281); the host planes, handed out from a pinned pool through de265_set_image_allocation_functions
+ * (de265.h:350-368), are written only when a picture is output (or when the stream carries a picture hash SEI to check).
+ *
+ * Threading: the recording hooks run on the decoder's worker threads (threads.h); every thread appends to its own
+ * lists, which the submit step (single-threaded, after img->wait_for_completion) concatenates.
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "libde265/de265.h"
+#include "libde265/decctx.h"
+#include "libde265/image.h"
+#include "libde265/intrapred.h"
+#include "libde265/motion.h"
+#include "libde265/pps.h"
+#include "libde265/slice.h"
+#include "libde265/sps.h"
+#include "libde265/transform.h"
+#include "libde265/deblock.h"
+#include "libde265/sao.h"
+
+#include "de265_mi355x.h"
+
+/* the reference's own entry points, renamed in de265.o by glue/Makefile (objcopy --redefine-sym) */
+extern "C" {
+de265_decoder_context* m355ref_de265_new_decoder(void);
+de265_error m355ref_de265_free_decoder(de265_decoder_context*);
+}
+
+namespace {
+
+/* ------------------------------------------------------------------ backend library (C ABI) ------ */
+
+#define M355_FUNCS(X) \
+  X(m355_last_error) X(m355_device_count) X(m355_create) X(m355_destroy) X(m355_frame_create) X(m355_frame_destroy) \
+  X(m355_frame_upload) X(m355_frame_download) X(m355_submit_picture) X(m355_wait) X(m355_set_pipeline_depth) \
+  X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash)
+
+struct Api {
+  void* handle = nullptr;
+  std::string path;
+#define DECL(n) decltype(&::n) n = nullptr;
+  M355_FUNCS(DECL)
+#undef DECL
+};
+
+Api* api()
+{
+  static Api a;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::string path;
+    if (const char* e = getenv("M355_LIB")) path = e;
+    else {
+      Dl_info info;
+      if (dladdr((void*)&api, &info) && info.dli_fname) {
+        path = info.dli_fname;                                   /* <repo>/glue/_build/libde265.so */
+        for (int up = 0; up < 3; up++) { size_t k = path.rfind('/'); path = k == std::string::npos ? "." : path.substr(0, k); }
+        path += "/libde265_amd/libde265_mi355x.so";
+      }
+    }
+    a.path = path;
+    a.handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!a.handle) { fprintf(stderr, "libde265 (MI355X glue): cannot load the backend %s: %s\n", path.c_str(), dlerror()); return; }
+#define LOAD(n) a.n = (decltype(a.n))dlsym(a.handle, #n); if (!a.n) { fprintf(stderr, "libde265 (MI355X glue): backend lacks %s\n", #n); a.handle = nullptr; return; }
+    M355_FUNCS(LOAD)
+#undef LOAD
+  });
+  return a.handle ? &a : nullptr;
+}
+
+std::atomic<long long> g_cpu_pixel_calls(0);
+
+/* ------------------------------------------------------------------ per-thread recording --------- */
+
+struct Run { uint32_t ctb, start, count; };
+
+struct ThreadRec {
+  const decoder_context* owner = nullptr;
+  uint32_t img_id = 0xFFFFFFFFu;
+  std::vector<m355_pb> pbs;
+  std::vector<m355_rb> rbs[4];
+  std::vector<m355_ib> ibs;
+  std::vector<uint32_t> coeffs;
+  std::vector<Run> runs;
+  uint32_t res_len = 0;
+  int last_ib = -1;                 /* the intra block just predicted: its residual (if any) comes next (slice.cc:3489-3508) */
+  int luma_rb = -1;                 /* cross-component prediction: the transform unit's luma block in its size bin */
+  int skipped_pbs = 0;              /* prediction units the reference leaves unwritten (motion.cc warnings) */
+  void clear()
+  {
+    pbs.clear(); for (auto& v : rbs) v.clear(); ibs.clear(); coeffs.clear(); runs.clear();
+    res_len = 0; last_ib = -1; luma_rb = -1; skipped_pbs = 0; img_id = 0xFFFFFFFFu; owner = nullptr;
+  }
+};
+
+/* pinned plane pool (get_buffer / release_buffer run once per picture: dpb.cc:271 -> image.cc:211) */
+struct PlanePool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_;
+  std::map<void*, size_t> size_of;
+  void* get(size_t bytes)
+  {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = free_.find(bytes);
+      if (it != free_.end()) { void* p = it->second; free_.erase(it); return p; }
+    }
+    void* p = api()->m355_host_alloc(bytes);
+    if (p) { std::lock_guard<std::mutex> g(mu); size_of[p] = bytes; }
+    return p;
+  }
+  void put(void* p)
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = size_of.find(p);
+    if (it != size_of.end()) free_.insert(std::make_pair(it->second, p));
+  }
+  void drain()
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& kv : size_of) api()->m355_host_free(kv.first);
+    size_of.clear(); free_.clear();
+  }
+};
+
+struct Glue {
+  decoder_context* dctx = nullptr;
+  m355_ctx* mctx = nullptr;
+  std::mutex mu;
+  uint32_t cur_id = 0xFFFFFFFFu;            /* image the thread lists belong to */
+  std::vector<ThreadRec*> recs;             /* the lists of the picture being parsed */
+  std::vector<ThreadRec*> pool;             /* idle */
+  int frame_of_slot[M355_MAX_REF_FRAMES];
+  uint32_t dev_id[M355_MAX_REF_FRAMES];     /* image ID whose pixels the slot's device frame holds */
+  uint32_t host_id[M355_MAX_REF_FRAMES];    /* image ID whose pixels the host planes hold (downloaded) */
+  int geom[M355_MAX_REF_FRAMES][5];
+  PlanePool planes;
+  /* statistics (m355_glue_stats) */
+  long long n_pictures = 0, n_uploads = 0, n_downloads = 0;
+  double ms_walk = 0, ms_submit = 0, ms_download = 0;
+  std::string error;
+  Glue()
+  {
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) { frame_of_slot[i] = -1; dev_id[i] = host_id[i] = 0xFFFFFFFFu; }
+  }
+};
+
+std::mutex g_reg_mu;
+std::vector<Glue*> g_glues;
+
+std::atomic<unsigned> g_reg_gen(1);         /* bumped whenever a decoder is created or freed: invalidates the per-thread caches */
+
+Glue* glue_of(const decoder_context* d)
+{
+  static thread_local const decoder_context* t_d = nullptr;
+  static thread_local Glue* t_g = nullptr;
+  static thread_local unsigned t_gen = 0;
+  if (t_d == d && t_g && t_gen == g_reg_gen.load(std::memory_order_acquire)) return t_g;
+  std::lock_guard<std::mutex> g(g_reg_mu);
+  for (Glue* x : g_glues) if (x->dctx == d) { t_d = d; t_g = x; t_gen = g_reg_gen.load(); return x; }
+  return nullptr;
+}
+
+void install_traps(acceleration_functions& a);
+
+/* the calling thread's lists for the picture `img` */
+ThreadRec* rec_for(de265_image* img)
+{
+  static thread_local ThreadRec* t_rec = nullptr;
+  const decoder_context* d = img->decctx;
+  if (t_rec && t_rec->owner == d && t_rec->img_id == img->get_ID()) return t_rec;
+  Glue* g = glue_of(d);
+  if (!g) return nullptr;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->cur_id != img->get_ID()) {
+    /* first block of a new picture; lists of a picture that was never completed (dropped by the decoder) are discarded */
+    for (ThreadRec* r : g->recs) { r->clear(); g->pool.push_back(r); }
+    g->recs.clear();
+    g->cur_id = img->get_ID();
+    /* de265_set_parameter_int(.., DE265_DECODER_PARAM_ACCELERATION_CODE, ..) refills the table (decctx.cc:239-270): keep
+       the traps in place, so that "no CPU pixel work" stays a checked property, whatever the application selects */
+    install_traps(g->dctx->acceleration);
+  }
+  ThreadRec* r;
+  if (!g->pool.empty()) { r = g->pool.back(); g->pool.pop_back(); }
+  else r = new ThreadRec;           /* never freed before process exit: other threads may still hold the pointer */
+  r->owner = d; r->img_id = img->get_ID();
+  g->recs.push_back(r);
+  t_rec = r;
+  return r;
+}
+
+inline int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+
+/* ------------------------------------------------------------------ slot traps -------------------- */
+/* Every slot of the decoder's table is replaced by one of these: the reference's pixel functions are not reachable
+ * any more (their callers are the replaced functions), so a call here would mean CPU pixel work went unnoticed. */
+template <class R, class... A> R trap(A...) { g_cpu_pixel_calls++; return R(); }
+template <class R, class... A> void set_trap(R (*&slot)(A...)) { slot = &trap<R, A...>; }
+
+void install_traps(acceleration_functions& a)
+{
+  set_trap(a.put_weighted_pred_avg_8); set_trap(a.put_unweighted_pred_8); set_trap(a.put_weighted_pred_8); set_trap(a.put_weighted_bipred_8);
+  set_trap(a.put_weighted_pred_avg_16); set_trap(a.put_unweighted_pred_16); set_trap(a.put_weighted_pred_16); set_trap(a.put_weighted_bipred_16);
+  set_trap(a.put_hevc_epel_8); set_trap(a.put_hevc_epel_h_8); set_trap(a.put_hevc_epel_v_8); set_trap(a.put_hevc_epel_hv_8);
+  set_trap(a.put_hevc_epel_16); set_trap(a.put_hevc_epel_h_16); set_trap(a.put_hevc_epel_v_16); set_trap(a.put_hevc_epel_hv_16);
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { set_trap(a.put_hevc_qpel_8[i][j]); set_trap(a.put_hevc_qpel_16[i][j]); }
+  set_trap(a.transform_bypass); set_trap(a.transform_bypass_rdpcm_v); set_trap(a.transform_bypass_rdpcm_h);
+  set_trap(a.transform_skip_8); set_trap(a.transform_skip_rdpcm_v_8); set_trap(a.transform_skip_rdpcm_h_8);
+  set_trap(a.transform_4x4_dst_add_8); set_trap(a.transform_skip_16); set_trap(a.transform_4x4_dst_add_16);
+  for (int i = 0; i < 4; i++) { set_trap(a.transform_add_8[i]); set_trap(a.transform_add_16[i]); }
+  set_trap(a.rotate_coefficients);
+  set_trap(a.transform_idst_4x4); set_trap(a.transform_idct_4x4); set_trap(a.transform_idct_8x8); set_trap(a.transform_idct_16x16); set_trap(a.transform_idct_32x32);
+  set_trap(a.add_residual_8); set_trap(a.add_residual_16);
+  set_trap(a.dequant_coeff_block);
+  set_trap(a.deblock_luma_8); set_trap(a.deblock_chroma_8);
+  set_trap(a.rdpcm_v); set_trap(a.rdpcm_h); set_trap(a.transform_skip_residual);
+  set_trap(a.intra_pred_dc_8); set_trap(a.intra_pred_dc_16); set_trap(a.intra_pred_planar_8); set_trap(a.intra_pred_planar_16);
+  set_trap(a.intra_pred_angular_8); set_trap(a.intra_pred_angular_16);
+}
+
+/* ------------------------------------------------------------------ image allocation hook --------- */
+
+int glue_get_buffer(de265_decoder_context* ctx, de265_image_spec* spec, de265_image* img, void* userdata)
+{
+  /* same plane geometry as the default allocator (image.cc:110-160), from the pinned pool, NOT zero-filled: the host
+     planes are only ever written by PCM sample reads, reference concealment (fill_image) and picture downloads */
+  Glue* g = (Glue*)userdata;
+  const int subw = (img->get_chroma_format() == de265_chroma_420 || img->get_chroma_format() == de265_chroma_422) ? 2 : 1;
+  const int subh = img->get_chroma_format() == de265_chroma_420 ? 2 : 1;
+  const uint32_t cw = spec->width / subw, ch = spec->height / subh;
+  const uint32_t ls = (spec->width + spec->alignment - 1) / spec->alignment * spec->alignment;
+  uint32_t cs = (cw + spec->alignment - 1) / spec->alignment * spec->alignment;
+  const size_t lb = (size_t)ls * ((img->get_bit_depth(0) + 7) / 8) * spec->height + 64;
+  const size_t cb = (size_t)cs * ((img->get_bit_depth(1) + 7) / 8) * ch + 64;
+  void* p[3] = {g->planes.get(lb), nullptr, nullptr};
+  bool ok = p[0] != nullptr;
+  if (img->get_chroma_format() != de265_chroma_mono) {
+    p[1] = g->planes.get(cb); p[2] = g->planes.get(cb);
+    ok = ok && p[1] && p[2];
+  } else cs = 0;
+  if (!ok) { for (void* q : p) if (q) g->planes.put(q); return 0; }
+  de265_set_image_plane(img, 0, p[0], (int)ls, nullptr);
+  de265_set_image_plane(img, 1, p[1], (int)cs, nullptr);
+  de265_set_image_plane(img, 2, p[2], (int)cs, nullptr);
+  (void)ctx;
+  return 1;
+}
+void glue_release_buffer(de265_decoder_context* ctx, de265_image* img, void* userdata)
+{
+  Glue* g = (Glue*)userdata;
+  for (int c = 0; c < 3; c++) {
+    void* p = (void*)img->get_image_plane(c);
+    if (p) g->planes.put(p);
+  }
+  (void)ctx;
+}
+
+/* ------------------------------------------------------------------ device frames ---------------- */
+
+int slot_of(decoder_context* d, const de265_image* img)
+{
+  for (int i = 0; i < M355_MAX_REF_FRAMES && d->has_image(i); i++)
+    if (d->get_image(i) == img) return i;
+  return -1;
+}
+
+bool ensure_frame(Glue* g, int slot, const de265_image* img)
+{
+  const seq_parameter_set& sps = img->get_sps();
+  const int geo[5] = {sps.pic_width_in_luma_samples, sps.pic_height_in_luma_samples, sps.chroma_format_idc, sps.BitDepth_Y, sps.BitDepth_C};
+  if (g->frame_of_slot[slot] >= 0 && memcmp(geo, g->geom[slot], sizeof(geo)) == 0) return true;
+  if (g->frame_of_slot[slot] >= 0) api()->m355_frame_destroy(g->mctx, g->frame_of_slot[slot]);
+  g->frame_of_slot[slot] = api()->m355_frame_create(g->mctx, geo[0], geo[1], geo[2], geo[3], geo[4]);
+  g->dev_id[slot] = 0xFFFFFFFFu;
+  if (g->frame_of_slot[slot] < 0) { g->error = api()->m355_last_error(); return false; }
+  memcpy(g->geom[slot], geo, sizeof(geo));
+  return true;
+}
+
+/* a DPB picture the backend did not produce (the decoder's concealment pictures, decctx.cc:1294-1321): host -> device */
+bool upload_host_planes(Glue* g, int slot, const de265_image* img)
+{
+  if (!ensure_frame(g, slot, img)) return false;
+  const int nc = img->get_chroma_format() == de265_chroma_mono ? 1 : 3;
+  for (int c = 0; c < nc; c++)
+    if (api()->m355_frame_upload(g->mctx, g->frame_of_slot[slot], c, img->get_image_plane(c), img->get_image_stride(c)) != M355_OK) { g->error = api()->m355_last_error(); return false; }
+  g->dev_id[slot] = img->get_ID();
+  g->host_id[slot] = img->get_ID();
+  g->n_uploads++;
+  return true;
+}
+
+void download_if_needed(Glue* g, de265_image* img)
+{
+  const int slot = slot_of(g->dctx, img);
+  if (slot < 0 || g->frame_of_slot[slot] < 0) return;
+  if (g->dev_id[slot] != img->get_ID() || g->host_id[slot] == img->get_ID()) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int nc = img->get_chroma_format() == de265_chroma_mono ? 1 : 3;
+  for (int c = 0; c < nc; c++)
+    if (api()->m355_frame_download(g->mctx, g->frame_of_slot[slot], c, img->get_image_plane(c), img->get_image_stride(c)) != M355_OK) {
+      g->error = api()->m355_last_error();
+      fprintf(stderr, "libde265 (MI355X glue): download failed: %s\n", g->error.c_str());
+      return;
+    }
+  g->host_id[slot] = img->get_ID();
+  g->n_downloads++;
+  g->ms_download += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+/* ------------------------------------------------------------------ picture submission ----------- */
+
+void walk_tu(const de265_image* img, int x0, int y0, int log2, int depth, std::vector<m355_tu>& out)
+{
+  /* the recursion of markTransformBlockBoundary (deblock.cc:33-63) */
+  if (img->get_split_transform_flag(x0, y0, depth)) {
+    const int h = 1 << (log2 - 1);
+    walk_tu(img, x0, y0, log2 - 1, depth + 1, out);
+    walk_tu(img, x0 + h, y0, log2 - 1, depth + 1, out);
+    walk_tu(img, x0, y0 + h, log2 - 1, depth + 1, out);
+    walk_tu(img, x0 + h, y0 + h, log2 - 1, depth + 1, out);
+  } else {
+    m355_tu tu; memset(&tu, 0, sizeof(tu));
+    tu.x = (uint16_t)x0; tu.y = (uint16_t)y0; tu.log2_size = (uint8_t)log2;
+    tu.flags = img->get_nonzero_coefficient(x0, y0) ? M355_TUF_NONZERO_COEFF : 0;
+    out.push_back(tu);
+  }
+}
+
+/* z-scan rank of a luma position inside its CTB at 8x8 granularity: the decode order of coding units */
+inline uint32_t z_rank(int x, int y)
+{
+  uint32_t r = 0;
+  for (int b = 0; b < 4; b++) r |= (uint32_t)(((x >> (3 + b)) & 1) << (2 * b)) | (uint32_t)(((y >> (3 + b)) & 1) << (2 * b + 1));
+  return r;
+}
+
+bool submit_picture(Glue* g, de265_image* img)
+{
+  Api* A = api();
+  decoder_context* d = g->dctx;
+  const auto t0 = std::chrono::steady_clock::now();
+  const seq_parameter_set& sps = img->get_sps();
+  const pic_parameter_set& pps = img->get_pps();
+
+  m355_picture pic; memset(&pic, 0, sizeof(pic));
+  m355_pic_params& pp = pic.pp;
+  pp.width = sps.pic_width_in_luma_samples; pp.height = sps.pic_height_in_luma_samples;
+  pp.chroma_format_idc = (uint8_t)sps.chroma_format_idc;
+  pp.bit_depth_luma = (uint8_t)sps.BitDepth_Y; pp.bit_depth_chroma = (uint8_t)sps.BitDepth_C;
+  pp.log2_ctb_size = (uint8_t)sps.Log2CtbSizeY; pp.log2_min_tb_size = (uint8_t)sps.Log2MinTrafoSize;
+  pp.log2_min_cb_size = (uint8_t)sps.Log2MinCbSizeY;
+  pp.pic_cb_qp_offset = (int8_t)pps.pic_cb_qp_offset; pp.pic_cr_qp_offset = (int8_t)pps.pic_cr_qp_offset;
+  if (pps.constrained_intra_pred_flag) pp.flags |= M355_PF_CONSTRAINED_INTRA_PRED;
+  if (sps.strong_intra_smoothing_enable_flag) pp.flags |= M355_PF_STRONG_INTRA_SMOOTHING;
+  if (sps.pcm_loop_filter_disable_flag) pp.flags |= M355_PF_PCM_LOOP_FILTER_DISABLE;
+  if (pps.loop_filter_across_tiles_enabled_flag) pp.flags |= M355_PF_LF_ACROSS_TILES;
+  if (sps.sample_adaptive_offset_enabled_flag && !d->param_disable_sao) pp.flags |= M355_PF_SAO_ENABLED;
+  if (sps.range_extension.intra_smoothing_disabled_flag) pp.flags |= M355_PF_INTRA_SMOOTHING_DISABLED;
+  if (sps.range_extension.implicit_rdpcm_enabled_flag) pp.flags |= M355_PF_IMPLICIT_RDPCM;
+  if (sps.range_extension.transform_skip_rotation_enabled_flag) pp.flags |= M355_PF_TRANSFORM_SKIP_ROTATION;
+  if (sps.scaling_list_enable_flag) pp.flags |= M355_PF_SCALING_LIST;
+  if (!d->param_disable_deblocking) pp.flags |= M355_PF_DEBLOCK_ENABLED;
+  if (pps.range_extension.cross_component_prediction_enabled_flag) pp.flags |= M355_PF_CROSS_COMPONENT_PRED;
+  pp.num_tile_cols = (uint8_t)pps.num_tile_columns; pp.num_tile_rows = (uint8_t)pps.num_tile_rows;
+  if (pps.num_tile_columns > M355_MAX_TILE_COLS || pps.num_tile_rows > M355_MAX_TILE_ROWS) { g->error = "tile grid larger than the backend's tables"; return false; }
+  for (int i = 0; i <= pps.num_tile_columns; i++) pp.col_bd[i] = (uint16_t)pps.colBd[i];
+  for (int i = 0; i <= pps.num_tile_rows; i++) pp.row_bd[i] = (uint16_t)pps.rowBd[i];
+
+  /* ---- slice headers (what deblocking / SAO read of them) ---- */
+  std::vector<m355_slice> slices;
+  for (size_t i = 0; i < img->slices.size(); i++) {
+    const slice_segment_header* sh = img->slices[i];
+    m355_slice s; memset(&s, 0, sizeof(s));
+    s.slice_addr_rs = (int32_t)sh->SliceAddrRS;
+    s.beta_offset = (int8_t)sh->slice_beta_offset; s.tc_offset = (int8_t)sh->slice_tc_offset;
+    if (sh->slice_deblocking_filter_disabled_flag) s.flags |= M355_SF_DEBLOCK_DISABLED;
+    if (sh->slice_loop_filter_across_slices_enabled_flag) s.flags |= M355_SF_LF_ACROSS_SLICES;
+    if (sh->slice_sao_luma_flag) s.flags |= M355_SF_SAO_LUMA;
+    if (sh->slice_sao_chroma_flag) s.flags |= M355_SF_SAO_CHROMA;
+    slices.push_back(s);
+  }
+  if (slices.empty()) { g->error = "picture without slices"; return false; }
+
+  /* ---- CTBs: slice index, SAO parameters (image.h:160-170, slice.h:268-276) ---- */
+  const int ctbW = sps.PicWidthInCtbsY, ctbH = sps.PicHeightInCtbsY;
+  std::vector<m355_ctb> ctbs((size_t)ctbW * ctbH);
+  bool any_pcm = false;
+  for (int y = 0; y < ctbH; y++)
+    for (int x = 0; x < ctbW; x++) {
+      m355_ctb& c = ctbs[(size_t)y * ctbW + x]; memset(&c, 0, sizeof(c));
+      const unsigned si = img->get_SliceHeaderIndexCtb(x, y);
+      c.slice_idx = (uint16_t)(si < slices.size() ? si : 0);
+      const sao_info* sao = img->get_sao_info(x, y);
+      c.sao_type = sao->SaoTypeIdx; c.sao_eo_class = sao->SaoEoClass;
+      memcpy(c.sao_band_pos, sao->sao_band_position, 3);
+      memcpy(c.sao_offset, sao->saoOffsetVal, 12);
+      if (img->get_CTB_has_pcm_or_cu_transquant_bypass(x, y)) c.flags |= M355_CTBF_HAS_PCM_OR_BYPASS;
+    }
+
+  /* ---- coding units + transform-tree leaves (image.h:173-195, deblock.cc:33-63) ---- */
+  std::vector<m355_cu> cus;
+  std::vector<m355_tu> tus;
+  std::vector<uint32_t> pcm_cus;
+  const int minCb = sps.MinCbSizeY;
+  long long covered = 0;
+  for (int cy = 0; cy < sps.PicHeightInMinCbsY; cy++)
+    for (int cx = 0; cx < sps.PicWidthInMinCbsY; cx++) {
+      const int l2 = img->get_log2CbSize_cbUnits(cx, cy);
+      if (l2 == 0) continue;
+      const int x0 = cx * minCb, y0 = cy * minCb;
+      m355_cu cu; memset(&cu, 0, sizeof(cu));
+      cu.x = (uint16_t)x0; cu.y = (uint16_t)y0; cu.log2_size = (uint8_t)l2;
+      cu.pred_mode = (uint8_t)img->get_pred_mode(x0, y0);
+      cu.part_mode = (uint8_t)img->get_PartMode(x0, y0);
+      cu.qp_y = (int8_t)img->get_QPY(x0, y0);
+      if (img->get_pcm_flag(x0, y0)) { cu.flags |= M355_CUF_PCM; pcm_cus.push_back((uint32_t)cus.size()); any_pcm = true; }
+      if (img->get_cu_transquant_bypass(x0, y0)) cu.flags |= M355_CUF_TRANSQUANT_BYPASS;
+      cus.push_back(cu);
+      covered += 1ll << (2 * l2);
+      walk_tu(img, x0, y0, l2, 0, tus);
+    }
+
+  /* ---- concatenate the threads' lists ---- */
+  std::vector<ThreadRec*> recs;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->cur_id == img->get_ID()) recs = g->recs;         /* else: a picture without a single coded block */
+  }
+  size_t n_pb = 0, n_ib = 0, n_co = 0, n_rb[4] = {0, 0, 0, 0};
+  int skipped = 0;
+  std::vector<uint32_t> co_base(recs.size()), res_base(recs.size());
+  uint32_t res_len = 0;
+  for (size_t t = 0; t < recs.size(); t++) {
+    co_base[t] = (uint32_t)n_co; res_base[t] = res_len;
+    n_pb += recs[t]->pbs.size(); n_ib += recs[t]->ibs.size(); n_co += recs[t]->coeffs.size(); res_len += recs[t]->res_len;
+    for (int s = 0; s < 4; s++) n_rb[s] += recs[t]->rbs[s].size();
+    skipped += recs[t]->skipped_pbs;
+  }
+  std::vector<m355_pb> pbs; pbs.reserve(n_pb);
+  std::vector<uint32_t> coeffs; coeffs.reserve(n_co);
+  std::vector<m355_rb> rbs; rbs.reserve(n_rb[0] + n_rb[1] + n_rb[2] + n_rb[3]);
+  for (ThreadRec* r : recs) { pbs.insert(pbs.end(), r->pbs.begin(), r->pbs.end()); coeffs.insert(coeffs.end(), r->coeffs.begin(), r->coeffs.end()); }
+  for (int s = 0; s < 4; s++)
+    for (size_t t = 0; t < recs.size(); t++)
+      for (m355_rb rb : recs[t]->rbs[s]) {
+        rb.coeff_ofs += co_base[t];
+        if (rb.flags & M355_RBF_DEFERRED) rb.res_ofs += res_base[t];
+        rbs.push_back(rb);
+      }
+  for (int s = 0; s < 4; s++) pic.rb_count[s] = (int32_t)n_rb[s];
+
+  /* intra blocks: each CTB's run (one thread decodes a whole CTB), CTBs in raster order */
+  std::vector<m355_ib> ibs; ibs.reserve(n_ib);
+  std::vector<uint16_t> pcm;
+  {
+    struct Ref { uint32_t ctb; uint16_t t; uint32_t start, count; };
+    std::vector<Ref> order;
+    for (size_t t = 0; t < recs.size(); t++)
+      for (const Run& rn : recs[t]->runs) order.push_back(Ref{rn.ctb, (uint16_t)t, rn.start, rn.count});
+    std::stable_sort(order.begin(), order.end(), [](const Ref& a, const Ref& b) { return a.ctb < b.ctb; });
+    for (size_t k = 0; k < order.size(); k++) {
+      if (k + 1 < order.size() && order[k + 1].ctb == order[k].ctb) continue;     /* a CTB coded twice (damaged stream): the last one stands */
+      const Ref& o = order[k];
+      if (o.ctb >= ctbs.size()) continue;
+      m355_ctb& c = ctbs[o.ctb];
+      c.ib_start = (uint32_t)ibs.size(); c.ib_count = o.count;
+      for (uint32_t i = 0; i < o.count; i++) {
+        m355_ib ib = recs[o.t]->ibs[o.start + i];
+        if (ib.flags & M355_IBF_HAS_RESIDUAL) ib.res_ofs += res_base[o.t];
+        ibs.push_back(ib);
+      }
+    }
+  }
+  if (any_pcm) {
+    /* PCM coding units (slice.cc:4211-4255): the parser has stored the raw samples in the host planes (bitstream reading,
+       not arithmetic); lift them into pcm[] and list one raw block per component at the unit's place in decode order */
+    const int sw = sps.SubWidthC, sh = sps.SubHeightC, nc = sps.chroma_format_idc ? 3 : 1;
+    std::vector<std::vector<std::pair<uint32_t, m355_ib>>> extra(ctbs.size());   /* per CTB: (z rank of the CU, block) */
+    for (uint32_t ci : pcm_cus) {
+      const m355_cu& cu = cus[ci];
+      const uint32_t ctb = (uint32_t)((cu.y >> sps.Log2CtbSizeY) * ctbW + (cu.x >> sps.Log2CtbSizeY));
+      for (int c = 0; c < nc; c++) {
+        const int subw = c ? (sw == 2) : 0, subh = c ? (sh == 2) : 0;
+        const int l2 = cu.log2_size - subw, nblk = (subw && !subh) ? 2 : 1, n = 1 << l2;    /* 4:2:2 chroma: two stacked squares */
+        if (l2 < 2) continue;
+        for (int b = 0; b < nblk; b++) {
+          m355_ib ib; memset(&ib, 0, sizeof(ib));
+          ib.x = (uint16_t)(cu.x >> subw); ib.y = (uint16_t)((cu.y >> subh) + b * n); ib.cidx = (uint8_t)c; ib.log2_size = (uint8_t)l2;
+          ib.mode = 1; ib.flags = M355_IBF_PCM; ib.res_ofs = (uint32_t)pcm.size();
+          const int bpp = img->get_bytes_per_pixel(c);
+          const uint8_t* base = img->get_image_plane(c);
+          const ptrdiff_t st = img->get_image_stride(c);
+          for (int yy = 0; yy < n; yy++)
+            for (int xx = 0; xx < n; xx++) {
+              const uint8_t* q = base + ((size_t)(ib.y + yy) * st + ib.x + xx) * bpp;
+              pcm.push_back(bpp == 1 ? (uint16_t)*q : *(const uint16_t*)q);
+            }
+          extra[ctb].push_back(std::make_pair(z_rank(cu.x, cu.y), ib));
+        }
+      }
+    }
+    std::vector<m355_ib> merged; merged.reserve(ibs.size() + 3 * pcm_cus.size());
+    for (size_t ci = 0; ci < ctbs.size(); ci++) {
+      m355_ctb& c = ctbs[ci];
+      const uint32_t start = (uint32_t)merged.size();
+      if (extra[ci].empty()) { merged.insert(merged.end(), ibs.begin() + c.ib_start, ibs.begin() + c.ib_start + c.ib_count); }
+      else {
+        /* recorded blocks are in decode order; key = z rank of their coding unit */
+        std::vector<std::pair<uint32_t, m355_ib>> all;
+        for (uint32_t i = 0; i < c.ib_count; i++) {
+          const m355_ib& ib = ibs[c.ib_start + i];
+          const int xl = ib.cidx ? ib.x * (sw == 2 ? 2 : 1) : ib.x, yl = ib.cidx ? ib.y * (sh == 2 ? 2 : 1) : ib.y;
+          const int cl2 = img->get_log2CbSize(xl, yl);
+          all.push_back(std::make_pair(z_rank((xl >> cl2) << cl2, (yl >> cl2) << cl2), ib));
+        }
+        all.insert(all.end(), extra[ci].begin(), extra[ci].end());
+        std::stable_sort(all.begin(), all.end(), [](const std::pair<uint32_t, m355_ib>& a, const std::pair<uint32_t, m355_ib>& b) { return a.first < b.first; });
+        for (auto& e : all) merged.push_back(e.second);
+      }
+      c.ib_start = start; c.ib_count = (uint32_t)merged.size() - start;
+    }
+    ibs.swap(merged);
+  }
+
+  /* ---- explicit weights: one entry per (slice, list, refIdx) (motion.cc:508-529, 571-598, 633-652) ---- */
+  std::vector<m355_wt> wts;
+  bool any_weighted = false;
+  for (const m355_pb& pb : pbs) if (pb.flags & M355_PBF_WEIGHTED) { any_weighted = true; break; }
+  if (any_weighted) {
+    if (img->slices.size() * 32 > 65535) { g->error = "too many slices for the weight table index"; return false; }
+    const int shift1_L = std::max(2, 14 - sps.BitDepth_Y), shift1_C = std::max(2, 14 - sps.BitDepth_C);
+    wts.resize(img->slices.size() * 32);
+    for (size_t si = 0; si < img->slices.size(); si++) {
+      const slice_segment_header* sh = img->slices[si];
+      for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 16; r++) {
+          m355_wt& w = wts[si * 32 + l * 16 + r]; memset(&w, 0, sizeof(w));
+          w.w[0] = sh->LumaWeight[l][r]; w.o[0] = (int16_t)(sh->luma_offset[l][r] * (1 << sps.WpOffsetBdShiftY));
+          for (int k = 0; k < 2; k++) { w.w[1 + k] = sh->ChromaWeight[l][r][k]; w.o[1 + k] = (int16_t)(sh->ChromaOffset[l][r][k] * (1 << sps.WpOffsetBdShiftC)); }
+          w.log2wd_luma = (uint8_t)(sh->luma_log2_weight_denom + shift1_L);
+          w.log2wd_chroma = (uint8_t)(sh->ChromaLog2WeightDenom + shift1_C);
+        }
+    }
+  }
+
+  /* ---- frames: destination + every DPB slot a prediction block reads ---- */
+  const int dslot = slot_of(d, img);
+  if (dslot < 0) { g->error = "picture is not in the DPB"; return false; }
+  if (!ensure_frame(g, dslot, img)) return false;
+  pic.dst_frame = g->frame_of_slot[dslot];
+  for (int i = 0; i < M355_MAX_REF_FRAMES; i++) pic.ref_frames[i] = -1;
+  bool used[M355_MAX_REF_FRAMES] = {};
+  for (const m355_pb& pb : pbs)
+    for (int l = 0; l < 2; l++)
+      if ((pb.flags & (M355_PBF_MC_L0 << l)) && !(pb.flags & (M355_PBF_FILL_L0 << l))) used[pb.ref_slot[l]] = true;
+  for (int s = 0; s < M355_MAX_REF_FRAMES; s++) {
+    if (!used[s]) continue;
+    const de265_image* rp = d->get_image(s);
+    if (s == dslot || !rp) { g->error = "prediction block references its own picture / an empty slot"; return false; }
+    if (g->frame_of_slot[s] < 0 || g->dev_id[s] != rp->get_ID()) {
+      if (!upload_host_planes(g, s, rp)) return false;
+    }
+    pic.ref_frames[s] = g->frame_of_slot[s];
+  }
+
+  long long area = 0;
+  for (int y = 0; y < sps.PicHeightInMinCbsY; y++) area += (long long)sps.PicWidthInMinCbsY;
+  area *= (long long)minCb * minCb;
+  if (covered != area || skipped) pp.flags |= M355_PF_CLEAR_DST;
+
+  uint8_t sf[6 * (16 + 64 + 256 + 1024)];
+  if (sps.scaling_list_enable_flag) {
+    /* [sizeId][matrixID][y][x] as transform.cc:505-508 reads them from the PPS */
+    uint8_t* f = sf;
+    memcpy(f, pps.scaling_list.ScalingFactor_Size0, 6 * 16); f += 6 * 16;
+    memcpy(f, pps.scaling_list.ScalingFactor_Size1, 6 * 64); f += 6 * 64;
+    memcpy(f, pps.scaling_list.ScalingFactor_Size2, 6 * 256); f += 6 * 256;
+    memcpy(f, pps.scaling_list.ScalingFactor_Size3, 6 * 1024);
+    pic.scaling_factors = sf;
+  }
+
+  pic.n_slices = (int32_t)slices.size(); pic.n_ctbs = (int32_t)ctbs.size(); pic.n_cus = (int32_t)cus.size(); pic.n_tus = (int32_t)tus.size();
+  pic.n_pbs = (int32_t)pbs.size(); pic.n_wts = (int32_t)wts.size(); pic.n_ibs = (int32_t)ibs.size();
+  pic.n_coeffs = (uint32_t)coeffs.size(); pic.n_pcm = (uint32_t)pcm.size(); pic.res_len = res_len;
+  pic.slices = slices.data(); pic.ctbs = ctbs.data(); pic.cus = cus.data(); pic.tus = tus.data(); pic.pbs = pbs.data();
+  pic.wts = wts.data(); pic.rbs = rbs.data(); pic.ibs = ibs.data(); pic.coeffs = coeffs.data(); pic.pcm = pcm.data();
+
+  const auto t1 = std::chrono::steady_clock::now();
+  const int rc = A->m355_submit_picture(g->mctx, &pic);
+  const auto t2 = std::chrono::steady_clock::now();
+  g->ms_walk += std::chrono::duration<double, std::milli>(t1 - t0).count();
+  g->ms_submit += std::chrono::duration<double, std::milli>(t2 - t1).count();
+  if (rc != M355_OK) { g->error = A->m355_last_error(); return false; }
+  g->dev_id[dslot] = img->get_ID();
+  g->host_id[dslot] = 0xFFFFFFFFu;
+  g->n_pictures++;
+  return true;
+}
+
+/* picture complete (decode_some, decctx.cc:605-630): hand it to the device */
+void picture_complete(decoder_context* d, de265_image* img)
+{
+  Glue* g = glue_of(d);
+  if (!g) { fprintf(stderr, "libde265 (MI355X glue): decoder without a backend context\n"); abort(); }
+  if (!submit_picture(g, img)) {
+    fprintf(stderr, "libde265 (MI355X glue): picture POC %d not decoded: %s\n", img->PicOrderCntVal, g->error.c_str());
+    img->integrity = INTEGRITY_DECODING_ERRORS;
+    d->add_warning(DE265_WARNING_INCORRECT_ENTRY_POINT_OFFSET, false);   /* there is no backend-specific warning code in de265.h */
+  }
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->cur_id == img->get_ID()) {
+      for (ThreadRec* r : g->recs) { r->clear(); g->pool.push_back(r); }
+      g->recs.clear();
+      g->cur_id = 0xFFFFFFFFu;
+    }
+  }
+  /* a decoded-picture-hash SEI is checked by the reference on the host planes right after this call (decctx.cc:634-641,
+     sei.cc:276-356): bring the picture back for it */
+  if (d->param_sei_check_hash) download_if_needed(g, img);
+}
+
+} // namespace
+
+/* =============================================================== replaced reference functions ===== */
+
+/* transform.cc:645 — one coded transform block.  What scale_coefficients_internal (transform.cc:361-642) decides on the
+ * host is recorded; its arithmetic is k_residual's. */
+void scale_coefficients(thread_context* tctx, int xT, int yT, int x0, int y0, int nT, int cIdx, bool transform_skip_flag, bool intra, int rdpcmMode)
+{
+  (void)x0; (void)y0;
+  de265_image* img = tctx->img;
+  ThreadRec* r = rec_for(img);
+  if (!r) return;
+  const seq_parameter_set& sps = img->get_sps();
+  const pic_parameter_set& pps = img->get_pps();
+  const int log2 = ilog2(nT);
+  m355_rb rb; memset(&rb, 0, sizeof(rb));
+  rb.x = (uint16_t)xT; rb.y = (uint16_t)yT; rb.cidx = (uint8_t)cIdx; rb.log2_size = (uint8_t)log2;
+  rb.qp = (uint8_t)(cIdx == 0 ? tctx->qPYPrime : (cIdx == 1 ? tctx->qPCbPrime : tctx->qPCrPrime));       /* transform.cc:371-377 */
+  const bool cuIntra = img->get_pred_mode(xT, yT) == MODE_INTRA;      /* transform.cc:398: looked up at (xT,yT) as given — restated literally */
+  const bool rotate = sps.range_extension.transform_skip_rotation_enabled_flag && nT == 4 && cuIntra;   /* :400-402 */
+  if (tctx->cu_transquant_bypass_flag) {
+    rb.kind = M355_RK_BYPASS;
+    if (rotate) rb.flags |= M355_RBF_ROTATE;
+  } else if (transform_skip_flag) {
+    rb.kind = M355_RK_SKIP;
+    if (rotate) rb.flags |= M355_RBF_ROTATE;
+  } else rb.kind = (nT == 4 && cIdx == 0 && cuIntra) ? M355_RK_DST : M355_RK_DCT;                          /* :601-606 */
+  if (rb.kind == M355_RK_BYPASS || rb.kind == M355_RK_SKIP) {
+    if (rdpcmMode == 1) rb.flags |= M355_RBF_RDPCM_H; else if (rdpcmMode == 2) rb.flags |= M355_RBF_RDPCM_V;
+  }
+  if (sps.scaling_list_enable_flag) {                                 /* matrixID, transform.cc:493-502 */
+    int m = nT == 32 ? 0 : cIdx;
+    if (!intra) m += nT < 32 ? 3 : 1;
+    rb.matrix_id = (uint8_t)m;
+  }
+  std::vector<m355_rb>& bin = r->rbs[log2 - 2];
+  if (pps.range_extension.cross_component_prediction_enabled_flag) {
+    /* slice.cc:3721-3760: ResScaleVal of a chroma block, and where its transform unit's luma block sits in the size bin */
+    if (cIdx == 0) r->luma_rb = (int)bin.size();
+    else if (tctx->ResScaleVal != 0 && r->luma_rb >= 0) {
+      const int a = tctx->ResScaleVal < 0 ? -tctx->ResScaleVal : tctx->ResScaleVal;
+      const int back = (int)bin.size() - r->luma_rb;                  /* 1 or 2 */
+      if (back == 1 || back == 2)
+        rb.matrix_id |= (uint8_t)(((ilog2(a) + 1) << 4) | (tctx->ResScaleVal < 0 ? 0x80 : 0) | (back == 2 ? 8 : 0));
+    }
+  }
+  const int n = tctx->nCoeff[cIdx];
+  rb.coeff_ofs = (uint32_t)r->coeffs.size();
+  rb.ncoeff = (uint16_t)n;
+  const int16_t* lvl = tctx->coeffList[cIdx];
+  const int16_t* pos = tctx->coeffPos[cIdx];
+  for (int i = 0; i < n; i++) r->coeffs.push_back((uint32_t)(uint16_t)pos[i] | ((uint32_t)(uint16_t)lvl[i] << 16));
+  if (intra && r->last_ib >= 0) {
+    m355_ib& ib = r->ibs[r->last_ib];
+    if (ib.cidx == rb.cidx && ib.x == rb.x && ib.y == rb.y && ib.log2_size == rb.log2_size && !(ib.flags & M355_IBF_HAS_RESIDUAL)) {
+      /* an intra block's residual is added after its prediction, which needs its neighbours first: deferred */
+      ib.flags |= M355_IBF_HAS_RESIDUAL; ib.res_ofs = r->res_len;
+      rb.flags |= M355_RBF_DEFERRED; rb.res_ofs = r->res_len;
+      r->res_len += (uint32_t)nT * nT;
+    }
+  }
+  bin.push_back(rb);
+}
+
+/* intrapred.cc:321 — one intra-predicted block, in decode order */
+void decode_intra_prediction(de265_image* img, int xB0, int yB0, enum IntraPredMode intraPredMode, int nT, int cIdx)
+{
+  ThreadRec* r = rec_for(img);
+  if (!r) return;
+  const seq_parameter_set& sps = img->get_sps();
+  m355_ib ib; memset(&ib, 0, sizeof(ib));
+  ib.x = (uint16_t)xB0; ib.y = (uint16_t)yB0; ib.cidx = (uint8_t)cIdx; ib.log2_size = (uint8_t)ilog2(nT); ib.mode = (uint8_t)intraPredMode;
+  if (sps.range_extension.implicit_rdpcm_enabled_flag && img->get_cu_transquant_bypass(xB0, yB0)) ib.flags |= M355_IBF_DISABLE_BOUNDARY_FILTER;   /* intrapred.cc:306-308 */
+  const int xl = cIdx ? xB0 * sps.SubWidthC : xB0, yl = cIdx ? yB0 * sps.SubHeightC : yB0;
+  const uint32_t ctb = (uint32_t)((yl >> sps.Log2CtbSizeY) * sps.PicWidthInCtbsY + (xl >> sps.Log2CtbSizeY));
+  if (r->runs.empty() || r->runs.back().ctb != ctb) r->runs.push_back(Run{ctb, (uint32_t)r->ibs.size(), 0});
+  r->runs.back().count++;
+  r->last_ib = (int)r->ibs.size();
+  r->ibs.push_back(ib);
+}
+
+/* motion.cc:288 — one prediction block.  The decisions of motion.cc:340-688 (bi -> uni demotion, unusable reference ->
+ * 1 << 13 fill, which weighted-prediction branch) are taken here, on the host; the arithmetic is k_inter's. */
+void generate_inter_prediction_samples(base_context* ctx, const slice_segment_header* shdr, de265_image* img, int xC, int yC, int xB, int yB,
+                                       int nCS, int nPbW, int nPbH, const PBMotion* vi)
+{
+  (void)nCS;
+  ThreadRec* r = rec_for(img);
+  if (!r) return;
+  const pic_parameter_set* pps = shdr->pps.get();
+  const seq_parameter_set* sps = pps->sps.get();
+  if (sps->BitDepth_Y != img->get_bit_depth(0) || sps->BitDepth_C != img->get_bit_depth(1)) {           /* motion.cc:304-309 */
+    img->integrity = INTEGRITY_DECODING_ERRORS;
+    ctx->add_warning(DE265_WARNING_BIT_DEPTH_OF_CURRENT_IMAGE_DOES_NOT_MATCH_SPS, false);
+    r->skipped_pbs++;
+    return;
+  }
+  if (sps->chroma_format_idc != img->get_chroma_format()) {                                               /* :311-315 */
+    img->integrity = INTEGRITY_DECODING_ERRORS;
+    ctx->add_warning(DE265_WARNING_CHROMA_OF_CURRENT_IMAGE_DOES_NOT_MATCH_SPS, false);
+    r->skipped_pbs++;
+    return;
+  }
+  const int xP = xC + xB, yP = yC + yB;
+  int predFlag[2] = {vi->predFlag[0], vi->predFlag[1]};
+  if (pps->weighted_pred_flag == 0 && predFlag[0] && predFlag[1] && vi->mv[0].x == vi->mv[1].x && vi->mv[0].y == vi->mv[1].y &&
+      shdr->RefPicList[0][vi->refIdx[0]] == shdr->RefPicList[1][vi->refIdx[1]])
+    predFlag[1] = 0;                                                                                      /* :348-357 */
+
+  m355_pb pb; memset(&pb, 0, sizeof(pb));
+  pb.x = (uint16_t)xP; pb.y = (uint16_t)yP; pb.w = (uint8_t)nPbW; pb.h = (uint8_t)nPbH;
+  pb.ref_slot[0] = pb.ref_slot[1] = -1;
+  for (int l = 0; l < 2; l++) {
+    if (vi->predFlag[l]) {                       /* as stored: what boundary-strength derivation compares (deblock.cc:294-366) */
+      pb.flags |= (uint8_t)(M355_PBF_PRED_L0 << l);
+      const int idx = shdr->RefPicList[l][vi->refIdx[l]];
+      pb.ref_slot[l] = (int8_t)((idx >= 0 && idx < M355_MAX_REF_FRAMES) ? idx : -1);
+      pb.mv[l][0] = vi->mv[l].x; pb.mv[l][1] = vi->mv[l].y;
+    }
+    if (!predFlag[l]) continue;
+    const int idx = shdr->RefPicList[l][vi->refIdx[l]];
+    const de265_image* refPic = (idx >= 0 && idx < M355_MAX_REF_FRAMES) ? ctx->get_image((uint16_t)idx) : nullptr;
+    bool usable = true;
+    if (!refPic || refPic->PicState == UnusedForReference) { ctx->add_warning(DE265_WARNING_NONEXISTING_REFERENCE_PICTURE_ACCESSED, false); usable = false; }           /* :362-367 */
+    else if (refPic->get_width(0) != sps->pic_width_in_luma_samples || refPic->get_height(0) != sps->pic_height_in_luma_samples ||
+             img->get_chroma_format() != refPic->get_chroma_format()) { ctx->add_warning(DE265_WARNING_REFERENCE_IMAGE_SIZE_DOES_NOT_MATCH_SPS, false); usable = false; }   /* :368-374 */
+    else if (img->get_bit_depth(0) != refPic->get_bit_depth(0) || img->get_bit_depth(1) != refPic->get_bit_depth(1)) {
+      ctx->add_warning(DE265_WARNING_REFERENCE_IMAGE_BIT_DEPTH_DOES_NOT_MATCH, false); usable = false;                                                               /* :375-380 */
+    }
+    if (!usable) { img->integrity = INTEGRITY_DECODING_ERRORS; pb.flags |= (uint8_t)(M355_PBF_FILL_L0 << l); }
+  }
+  /* weighted sample prediction: which branch of motion.cc:493-688 */
+  bool weighted = false, write = true;
+  if (shdr->slice_type == SLICE_TYPE_P) {
+    if (predFlag[0] == 1 && predFlag[1] == 0) { pb.flags |= M355_PBF_MC_L0; weighted = pps->weighted_pred_flag != 0; }
+    else write = false;
+  } else {
+    if (predFlag[0] == 1 && predFlag[1] == 1) { pb.flags |= M355_PBF_MC_L0 | M355_PBF_MC_L1; weighted = pps->weighted_bipred_flag != 0; }
+    else if (predFlag[0] == 1 || predFlag[1] == 1) { pb.flags |= predFlag[0] ? M355_PBF_MC_L0 : M355_PBF_MC_L1; weighted = pps->weighted_bipred_flag != 0; }
+    else write = false;
+  }
+  if (!write) {
+    ctx->add_warning(DE265_WARNING_BOTH_PREDFLAGS_ZERO, false);
+    img->integrity = INTEGRITY_DECODING_ERRORS;
+    r->skipped_pbs++;
+    return;
+  }
+  /* a FILL of a list that is not interpolated has no meaning for the kernels */
+  for (int l = 0; l < 2; l++) if (!(pb.flags & (M355_PBF_MC_L0 << l))) pb.flags &= (uint8_t)~(M355_PBF_FILL_L0 << l);
+  if (weighted) {
+    pb.flags |= M355_PBF_WEIGHTED;
+    const unsigned si = img->get_SliceHeaderIndex(xP, yP);
+    for (int l = 0; l < 2; l++) pb.wt_idx[l] = (uint16_t)(si * 32 + l * 16 + (vi->refIdx[l] & 15));
+  }
+  r->pbs.push_back(pb);
+}
+
+/* decctx.cc:1783 / 1811 — the picture is parsed: instead of filtering it on the host, submit it */
+void decoder_context::run_postprocessing_filters_sequential(de265_image* img) { picture_complete(this, img); }
+void decoder_context::run_postprocessing_filters_parallel(image_unit* imgunit) { picture_complete(this, imgunit->img); }
+
+/* deblock.cc / sao.cc are not part of this build; their entry points only exist so that the (unreachable) weakened
+ * originals of the two functions above still link */
+static void pixel_path_trap(const char* what) { fprintf(stderr, "libde265 (MI355X glue): CPU pixel path reached: %s\n", what); abort(); }
+void apply_deblocking_filter(de265_image*) { pixel_path_trap("apply_deblocking_filter"); }
+void add_deblocking_tasks(image_unit*) { pixel_path_trap("add_deblocking_tasks"); }
+void apply_sample_adaptive_offset(de265_image*) { pixel_path_trap("apply_sample_adaptive_offset"); }
+void apply_sample_adaptive_offset_sequential(de265_image*) { pixel_path_trap("apply_sample_adaptive_offset_sequential"); }
+bool add_sao_tasks(image_unit*, int) { pixel_path_trap("add_sao_tasks"); return false; }
+
+/* =============================================================== public API wrappers (de265.h) ==== */
+
+extern "C" {
+
+LIBDE265_API de265_decoder_context* de265_new_decoder()
+{
+  Api* A = api();
+  if (!A) return nullptr;
+  if (A->m355_device_count() < 1) { fprintf(stderr, "libde265 (MI355X glue): no HIP device — this build has no CPU pixel path\n"); return nullptr; }
+  de265_decoder_context* c = m355ref_de265_new_decoder();
+  if (!c) return nullptr;
+  Glue* g = new Glue;
+  g->dctx = (decoder_context*)c;
+  int dev = 0;
+  if (const char* e = getenv("M355_DEVICE")) dev = atoi(e);
+  if (A->m355_create(dev, &g->mctx) != M355_OK) {
+    fprintf(stderr, "libde265 (MI355X glue): %s\n", A->m355_last_error());
+    delete g; m355ref_de265_free_decoder(c);
+    return nullptr;
+  }
+  int depth = 2;
+  if (const char* e = getenv("M355_PIPELINE_DEPTH")) depth = atoi(e);
+  if (depth >= 1 && depth <= 4) A->m355_set_pipeline_depth(g->mctx, depth);
+  install_traps(g->dctx->acceleration);
+  de265_image_allocation alloc = {glue_get_buffer, glue_release_buffer};
+  de265_set_image_allocation_functions(c, &alloc, g);
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  g_glues.push_back(g);
+  g_reg_gen++;
+  return c;
+}
+
+LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)
+{
+  Glue* g = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (size_t i = 0; i < g_glues.size(); i++)
+      if ((de265_decoder_context*)g_glues[i]->dctx == c) { g = g_glues[i]; g_glues.erase(g_glues.begin() + i); g_reg_gen++; break; }
+  }
+  if (g && getenv("M355_GLUE_STATS"))
+    fprintf(stderr, "m355 glue: %lld pictures submitted, %lld uploaded, %lld downloaded; host ms per picture: lists %.3f, submit %.3f; download %.3f ms each; cpu pixel calls %lld\n",
+            g->n_pictures, g->n_uploads, g->n_downloads, g->n_pictures ? g->ms_walk / g->n_pictures : 0.0, g->n_pictures ? g->ms_submit / g->n_pictures : 0.0,
+            g->n_downloads ? g->ms_download / g->n_downloads : 0.0, g_cpu_pixel_calls.load());
+  if (g) api()->m355_wait(g->mctx);
+  const de265_error e = m355ref_de265_free_decoder(c);      /* releases the images into the pool */
+  if (g) {
+    api()->m355_destroy(g->mctx);
+    g->planes.drain();
+    for (ThreadRec* r : g->recs) { r->clear(); }
+    delete g;                                                /* ThreadRecs stay allocated (see rec_for) */
+  }
+  return e;
+}
+
+LIBDE265_API const struct de265_image* de265_peek_next_picture(de265_decoder_context* c)
+{
+  decoder_context* ctx = (decoder_context*)c;
+  if (ctx->num_pictures_in_output_queue() <= 0) return nullptr;     /* de265.cc:437-449 */
+  de265_image* img = ctx->get_next_picture_in_output_queue();
+  Glue* g = glue_of(ctx);
+  if (g && img) download_if_needed(g, img);
+  return img;
+}
+
+LIBDE265_API const struct de265_image* de265_get_next_picture(de265_decoder_context* c)
+{
+  const struct de265_image* img = de265_peek_next_picture(c);      /* de265.cc:426-435 */
+  if (img) de265_release_next_picture(c);
+  return img;
+}
+
+/* test / diagnostics hooks of this build (not part of de265.h) */
+LIBDE265_API long long m355_glue_cpu_pixel_calls(void) { return g_cpu_pixel_calls.load(); }
+LIBDE265_API const char* m355_glue_backend_path(void) { Api* A = api(); return A ? A->path.c_str() : ""; }
+LIBDE265_API int m355_glue_stats(de265_decoder_context* c, long long* pictures, long long* uploads, long long* downloads)
+{
+  Glue* g = glue_of((decoder_context*)c);
+  if (!g) return -1;
+  if (pictures) *pictures = g->n_pictures;
+  if (uploads) *uploads = g->n_uploads;
+  if (downloads) *downloads = g->n_downloads;
+  return 0;
+}
+
+} /* extern "C" */

@@ -21,9 +21,10 @@
  *         deblock V → deblock H → SAO
  *      on the device, against reference frames that stay resident in HBM.
  *
- * All structs are plain little-endian PODs shared by the HIP library, the CPU oracle
- * (oracle/hevc_oracle.c), the recorder (m355_rec_*) and the Python host layer (numpy dtypes in
- * libde265_amd/worklist.py mirror them field by field; tests/test_abi_layout.py checks sizes).
+ * All structs are plain little-endian PODs shared by the HIP library, the reference-side glue that
+ * records them inside the reference's decoder (glue/m355_glue.cc), the CPU oracle
+ * (oracle/hevc_oracle.c) and the Python test layer (numpy dtypes in libde265_amd/worklist.py mirror
+ * them field by field; tests/test_abi_layout.py checks sizes).
  */
 #ifndef DE265_MI355X_H
 #define DE265_MI355X_H
@@ -214,8 +215,11 @@ enum {
   M355_PF_CROSS_COMPONENT_PRED     = 1 << 9,  /* pps.range_extension.cross_component_prediction_enabled_flag
                                                  (4:4:4 only, transform.cc:244-260): chroma blocks may carry a
                                                  ResScaleVal in m355_rb.matrix_id (see there)            */
-  M355_PF_TRANSFORM_SKIP_ROTATION  = 1 << 10  /* sps.range_extension.transform_skip_rotation_enabled_flag (transform.cc:400-402);
+  M355_PF_TRANSFORM_SKIP_ROTATION  = 1 << 10, /* sps.range_extension.transform_skip_rotation_enabled_flag (transform.cc:400-402);
                                                  informative: the kernels follow the per-block M355_RBF_ROTATE */
+  M355_PF_CLEAR_DST                = 1 << 11  /* zero the picture before reconstructing it, as the reference's allocator does for
+                                                 every new picture (image.cc:164): only matters when the lists do not cover the
+                                                 whole picture (damaged streams: missing slices, PBs without a usable list) */
 };
 
 typedef struct m355_pic_params {
@@ -399,6 +403,12 @@ M355_API int m355_frame_destroy(m355_ctx* ctx, int frame);
 M355_API int m355_frame_upload(m355_ctx* ctx, int frame, int cidx, const void* src, ptrdiff_t stride);
 M355_API int m355_frame_download(m355_ctx* ctx, int frame, int cidx, void* dst, ptrdiff_t stride);
 M355_API int m355_frame_fill(m355_ctx* ctx, int frame, int value_luma, int value_chroma);
+
+/* Pinned host memory for the planes an application reads decoded pictures from: what a get_buffer callback registered
+ * with de265_set_image_allocation_functions (de265.h:350-368; default allocator image.cc:110-184) hands out, so that
+ * m355_frame_download runs at full PCIe rate.  NULL on failure. */
+M355_API void* m355_host_alloc(size_t bytes);
+M355_API void  m355_host_free(void* p);
 
 /* SEI decoded picture hash of a device frame, computed where the frame lives.
  * Replaces compute_MD5 / compute_CRC_8bit_fast / compute_checksum (sei.cc:161-258) as called by

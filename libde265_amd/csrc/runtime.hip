@@ -429,6 +429,14 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
   return M355_OK;
 }
 
+void* m355_host_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(M355_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+void m355_host_free(void* p) { if (p) hipHostFree(p); }
+
 int m355_frame_hash(m355_ctx* c, int h, int type, m355_picture_hash* out)
 {
   Frame* f = get_frame(c, h);
@@ -1076,6 +1084,13 @@ static int decode(m355_ctx* c, Resident& r)
   c->ev_used++;
   hipEventRecord(ev[0], st);
   if (!want_sao) dst_hazards();
+  if (pp.flags & M355_PF_CLEAR_DST) {
+    /* a new picture starts from zero in the reference (image.cc:164); the planes being reconstructed are this lane's
+       working planes (SAO rewrites every sample of the destination) or the destination itself */
+    Frame* tgt = want_sao ? &c->work : dstf;
+    for (int cc = 0; cc < 3; cc++)
+      if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
+  }
   /* fork: the metadata planes (read first by k_intra) are rasterised on the side stream while the main
      stream runs job list -> inter prediction -> residual, which do not read them */
   hipEventRecord(c->ev_fork, st);

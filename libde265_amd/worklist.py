@@ -25,6 +25,7 @@ PF_SCALING_LIST = 1 << 7
 PF_DEBLOCK_ENABLED = 1 << 8
 PF_CROSS_COMPONENT_PRED = 1 << 9
 PF_TRANSFORM_SKIP_ROTATION = 1 << 10
+PF_CLEAR_DST = 1 << 11
 # slice flags
 SF_DEBLOCK_DISABLED, SF_LF_ACROSS_SLICES, SF_SAO_LUMA, SF_SAO_CHROMA = 1, 2, 4, 8
 CTBF_HAS_PCM_OR_BYPASS = 1

@@ -207,3 +207,15 @@ void ref_deblock_chroma(int simd, void* ptr, ptrdiff_t stride, int pb, int verti
 }
 
 } // extern "C"
+
+/* Layer a backend's table initialiser on a live decoder's acceleration table, exactly where the reference layers its own
+ * SSE / AVX / ARM tables (base_context::set_acceleration_functions, decctx.cc:239-270: fallback first, then the overrides).
+ * `init` has the signature of init_acceleration_functions_mi355x (include/de265_mi355x.h).  Test infrastructure. */
+#include "libde265/decctx.h"
+extern "C" __attribute__((visibility("default")))
+int ref_layer_acceleration(de265_decoder_context* c, int (*init)(void*))
+{
+  decoder_context* ctx = (decoder_context*)c;
+  ctx->set_acceleration_functions(de265_acceleration_SCALAR);
+  return init(&ctx->acceleration);
+}

@@ -1,0 +1,90 @@
+"""Minimal ctypes driver of the reference's public C API (libde265/de265.h) — the dec265 decode loop
+(dec265/dec265.cc:790-838) and its YUV writer (write_picture, dec265.cc:207-262) in Python, so that a test can decode a
+bitstream through ANY libde265 build (the reference build oracle/_ref/libde265_ref.so, or glue/_build/libde265.so whose
+pixel path is the MI355X backend) and hash what an application would see.  Test infrastructure."""
+import ctypes
+import hashlib
+
+DE265_OK = 0
+PARAM_BOOL_SEI_CHECK_HASH = 0
+PARAM_ACCELERATION_CODE = 5
+PARAM_DISABLE_DEBLOCKING = 7
+PARAM_DISABLE_SAO = 8
+ACCELERATION_SCALAR = 0
+
+
+def bind(lib):
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    lib.de265_new_decoder.restype = vp
+    lib.de265_free_decoder.argtypes = [vp]
+    lib.de265_start_worker_threads.argtypes = [vp, i]
+    lib.de265_push_data.argtypes = [vp, vp, i, ctypes.c_int64, vp]
+    lib.de265_flush_data.argtypes = [vp]
+    lib.de265_decode.argtypes = [vp, ctypes.POINTER(i)]
+    lib.de265_get_next_picture.argtypes = [vp]
+    lib.de265_get_next_picture.restype = vp
+    lib.de265_get_image_width.argtypes = [vp, i]
+    lib.de265_get_image_height.argtypes = [vp, i]
+    lib.de265_get_bits_per_pixel.argtypes = [vp, i]
+    lib.de265_get_chroma_format.argtypes = [vp]
+    lib.de265_get_image_plane.argtypes = [vp, i, ctypes.POINTER(i)]
+    lib.de265_get_image_plane.restype = vp
+    lib.de265_set_parameter_bool.argtypes = [vp, i, i]
+    lib.de265_set_parameter_int.argtypes = [vp, i, i]
+    lib.de265_get_warning.argtypes = [vp]
+    return lib
+
+
+def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=False, scalar=False, after_create=None, max_frames=None):
+    """-> (md5 hex of the output YUV, number of pictures, list of warnings).  The YUV is what `dec265 -o` writes: every
+    output picture, cropped to the conformance window, planes Y Cb Cr, 8-bit samples as bytes / deeper ones as 2 bytes LE."""
+    bind(lib)
+    ctx = lib.de265_new_decoder()
+    if not ctx:
+        raise RuntimeError("de265_new_decoder failed")
+    try:
+        if scalar:
+            lib.de265_set_parameter_int(ctx, PARAM_ACCELERATION_CODE, ACCELERATION_SCALAR)
+        lib.de265_set_parameter_bool(ctx, PARAM_DISABLE_DEBLOCKING, int(disable_deblocking))
+        lib.de265_set_parameter_bool(ctx, PARAM_DISABLE_SAO, int(disable_sao))
+        if after_create:
+            after_create(ctx)
+        if threads > 0:
+            assert lib.de265_start_worker_threads(ctx, threads) == DE265_OK
+        buf = ctypes.create_string_buffer(data, len(data))
+        assert lib.de265_push_data(ctx, buf, len(data), 0, None) == DE265_OK
+        assert lib.de265_flush_data(ctx) == DE265_OK
+        md5 = hashlib.md5()
+        n = 0
+        more = ctypes.c_int(1)
+        while more.value:
+            more.value = 0
+            err = lib.de265_decode(ctx, ctypes.byref(more))
+            if err != DE265_OK:
+                break
+            while True:
+                img = lib.de265_get_next_picture(ctx)
+                if not img:
+                    break
+                nc = 1 if lib.de265_get_chroma_format(img) == 0 else 3
+                for c in range(nc):
+                    stride = ctypes.c_int()
+                    p = lib.de265_get_image_plane(img, c, ctypes.byref(stride))
+                    w, h = lib.de265_get_image_width(img, c), lib.de265_get_image_height(img, c)
+                    bpp = (lib.de265_get_bits_per_pixel(img, c) + 7) // 8
+                    row = ctypes.c_char * (w * bpp)
+                    for y in range(h):
+                        md5.update(row.from_address(p + y * stride.value * bpp))
+                n += 1
+                if max_frames and n >= max_frames:
+                    more.value = 0
+                    break
+        warnings = []
+        while True:
+            wn = lib.de265_get_warning(ctx)
+            if wn == DE265_OK:
+                break
+            warnings.append(wn)
+        return md5.hexdigest(), n, warnings
+    finally:
+        lib.de265_free_decoder(ctx)
