@@ -109,6 +109,7 @@ struct Run { uint32_t ctb, start, count; };
 struct ThreadRec {
   const decoder_context* owner = nullptr;
   uint32_t img_id = 0xFFFFFFFFu;
+  const void* thread = nullptr;     /* the one thread that appends to these lists */
   std::vector<m355_pb> pbs;
   std::vector<m355_rb> rbs[4];
   std::vector<m355_ib> ibs;
@@ -121,7 +122,7 @@ struct ThreadRec {
   void clear()
   {
     pbs.clear(); for (auto& v : rbs) v.clear(); ibs.clear(); coeffs.clear(); runs.clear();
-    res_len = 0; last_ib = -1; luma_rb = -1; skipped_pbs = 0; img_id = 0xFFFFFFFFu; owner = nullptr;
+    res_len = 0; last_ib = -1; luma_rb = -1; skipped_pbs = 0; img_id = 0xFFFFFFFFu; owner = nullptr; thread = nullptr;
   }
 };
 
@@ -199,8 +200,11 @@ void install_traps(acceleration_functions& a);
 ThreadRec* rec_for(de265_image* img)
 {
   static thread_local ThreadRec* t_rec = nullptr;
+  static thread_local char t_token;          /* its address identifies the calling thread */
   const decoder_context* d = img->decctx;
-  if (t_rec && t_rec->owner == d && t_rec->img_id == img->get_ID()) return t_rec;
+  /* the cached lists are still this thread's own only if nobody recycled them since (a recycled ThreadRec may carry the
+     same decoder and the same picture again — for ANOTHER thread) */
+  if (t_rec && t_rec->thread == &t_token && t_rec->owner == d && t_rec->img_id == img->get_ID()) return t_rec;
   Glue* g = glue_of(d);
   if (!g) return nullptr;
   std::lock_guard<std::mutex> lk(g->mu);
@@ -216,7 +220,7 @@ ThreadRec* rec_for(de265_image* img)
   ThreadRec* r;
   if (!g->pool.empty()) { r = g->pool.back(); g->pool.pop_back(); }
   else r = new ThreadRec;           /* never freed before process exit: other threads may still hold the pointer */
-  r->owner = d; r->img_id = img->get_ID();
+  r->owner = d; r->img_id = img->get_ID(); r->thread = &t_token;
   g->recs.push_back(r);
   t_rec = r;
   return r;
