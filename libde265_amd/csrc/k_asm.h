@@ -10,6 +10,9 @@
  * zero, letting the flag store overtake the L2 write-back (MI355X guide, "Compiler hazard"). */
 __device__ __forceinline__ void d_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+/* spin bound of k_intra's granule polls: ~2^22 polls x (one L2 round trip + s_sleep) is seconds — far beyond any real wait */
+#define M355_SPIN_LIMIT (1u << 22)
+
 /* pointers loaded from device tables: tell hipcc they are global (else it emits flat_load) */
 #define M355_GLOBAL __attribute__((address_space(1)))
 

@@ -46,7 +46,7 @@ struct DevPic {
   const m355_rb* rbs;
   const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime.hip intra_schedule) */
   const uint16_t* ib_level;         /* level of ibs[i] inside its CTB */
-  int intra_waves;                  /* k_intra: waves per colour component (1 or 4) */
+  int intra_dense;                  /* k_intra variant: 1 = intra picture (12-wave workgroups, residuals in LDS), 0 = a handful of blocks per CTB */
   const uint32_t* coeffs;
   const uint16_t* pcm;
   const uint8_t* scaling;
@@ -69,14 +69,17 @@ struct DevPic {
   int n_jobs;                       /* sum over PBs of (w/4) * ceil(h/8), computed at upload */
   int n_jobs_uni, n_jobs_main;      /* jobs [0, n_jobs_uni): one list; [n_jobs_uni, n_jobs_main): bi-predicted; [n_jobs_main, n_jobs): EDGE (clamped loads) */
   /* intra wavefront state */
-  uint32_t* ctb_done;               /* per CTB (raster) completion epoch */
+  unsigned long long* edge;         /* k_intra's halo exchange: 8-byte granules (epoch << 32 | two samples), per component the right
+                                       columns of all CTB columns [ctbX][row >> 1], then the bottom rows of all CTB rows [ctbY][col >> 1] */
+  uint32_t edge_col_ofs[3], edge_row_ofs[3];   /* first granule of each component's column / row arrays */
   uint32_t* ticket;                 /* work counter */
   uint32_t* timeout;                /* set when a spin bound is exceeded */
   uint32_t epoch;                   /* value meaning "done" for this submission */
   const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks: first the n_intra_free CTBs that wait
                                        for nobody, then the others in decode order */
   int n_intra_work, n_intra_free;
-  const uint8_t* ctb_dep;           /* per CTB: bit n = wait for neighbour n (0 L, 1 TL, 2 T, 3 TR); bit 4 = somebody waits for us */
+  const uint8_t* ctb_dep;           /* per CTB: bit n = reads intra output of neighbour n (0 L, 1 TL, 2 T, 3 TR; orders the work list);
+                                       bit 4 = a neighbour reads ours; bits 5-6 = the CTB's widest level (0: 1 luma block, 1: 2, 2: 3-4, 3: more) -> waves in k_intra */
   /* tile sharding (k_shard.hip): NULL = this context owns the whole picture */
   const uint8_t* ctb_owner;         /* per CTB (raster): 1 = a tile of this rank */
   int halo_cu_base, halo_pb_base;   /* first entry of the foreign border records appended to cus[] / pbs[] */

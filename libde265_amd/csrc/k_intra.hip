@@ -14,17 +14,25 @@
  *   - one workgroup per CTB that contains intra blocks; CTBs are claimed from an atomic ticket in
  *     DECODE (tile-scan) order, so a workgroup only ever waits on CTBs claimed before it — no
  *     residency assumption, no deadlock;
- *   - completion is published per CTB with an agent-scope release + flag; consumers poll relaxed,
- *     then take ONE agent-scope acquire (MI355X guide, guideline 16);
- *   - inside the workgroup the CTB (plus top-row / left-column halo) is resident in LDS and its blocks run LEVEL BY
- *     LEVEL: the host sorts each CTB's blocks by dependency level (runtime.hip intra_schedule: a block depends on the
- *     earlier blocks that cover its left column / top row), blocks of one level are independent, and each colour
- *     component has 1 (inter pictures: a handful of blocks per CTB) or 4 (intra pictures: up to 256 luma blocks per
- *     CTB) wavefronts that share a level's blocks, with a workgroup barrier between levels — the serial chain per
- *     CTB shrinks from the block count to the level count (about 46 instead of 256 for a CTB of 4x4 blocks);
+ *   - dependencies between CTBs are tracked at the granularity of the SAMPLES ACTUALLY READ, not per CTB: a block that
+ *     finishes a piece of its CTB's right column or bottom row publishes those samples as 8-byte granules
+ *     {tag = this decode's epoch, two samples} with agent-scope (write-through) stores — "the data is the flag"
+ *     (MI355X guide, guideline 16, form R2: no fences, no write-back of the L2).  A consumer stages its halo from the
+ *     picture where the neighbouring samples come from the preceding kernels (inter prediction: final by stream order)
+ *     and from the granules where they come from an intra block of a neighbour CTB; a granule that is not there yet is
+ *     polled only by the block whose border gather needs it, when it needs it.  A CTB therefore starts at once, runs
+ *     beside its neighbours, and the critical path of an intra picture is the diagonal of BLOCKS (about 15 levels of
+ *     lag per CTB column and 30 per CTB row for a picture of 4x4 blocks), not (W_ctb + 2 H_ctb) whole-CTB steps;
+ *   - inside the workgroup the CTB is resident in LDS and its blocks run LEVEL BY LEVEL: the host sorts each CTB's
+ *     blocks by dependency level (runtime.hip intra_schedule: a block depends on the earlier blocks that cover its left
+ *     column / top row), blocks of one level are independent, and each colour component has 1, 2 or 4 wavefronts (per
+ *     CTB, from the widest level: a lone intra CU in an inter picture needs one, a CTB of 4x4 blocks four) that share a
+ *     level's blocks, with a workgroup barrier between levels when there is more than one wave per component — the
+ *     serial chain per CTB shrinks from the block count to the level count (about 46 instead of 256 for 4x4 blocks);
  *   - the inverse transforms were done up front, in parallel, by k_residual.
- * This stage is dependency-bound, not bandwidth-bound: critical path ~ (W_ctb + 2 H_ctb) CTB steps.
+ * This stage is dependency-bound, not bandwidth-bound.
  */
+#include <stdlib.h>
 #include "k_common.h"
 
 #define MAXCTB 64
@@ -33,7 +41,7 @@
    footprint decides how many CTBs a CU works on at once, and this stage lives on concurrency. */
 #define BODY_PITCH_OF(cw) ((cw) + 8)
 #define BODY_X0 8
-#define SPIN_LIMIT (1u << 24)
+#define SPIN_LIMIT M355_SPIN_LIMIT   /* k_asm.h: bound on the polls for one granule (a list that promises a sample nobody produces) */
 
 __constant__ int8_t c_intra_angle[35] = {0,   0,   32,  26,  21,  17, 13, 9,  5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
                                          -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9,  13, 17, 21,  26,  32};
@@ -65,57 +73,71 @@ __device__ __forceinline__ int d_subst_src(int e, unsigned long long m0, unsigne
   return 128;
 }
 
-#define INTRA_GMAX 4   /* waves per colour component */
-/* DENSE: intra pictures (many blocks per CTB): INTRA_GMAX waves per component share each level, residuals are fetched
- * into LDS up front.  !DENSE: inter pictures (a handful of blocks per CTB): one wave per component, no workgroup
- * barriers inside the chain, residuals fetched per block under its border phase. */
-template <class PIX, int CF, bool DENSE>
-__global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic p, int work_base, int work_n, int use_ticket)
+#define HALO_NOT_READY 0xFFFFFFFFu
+
+typedef unsigned long long m355_granule;   /* (epoch << 32) | sample1 << 16 | sample0 */
+
+/* right-column granules of CTB column `col` of component c: index (row of the picture) >> 1 */
+__device__ __forceinline__ m355_granule* d_edge_col(const DevPic& p, int c, int col, int y) { return p.edge + p.edge_col_ofs[c] + (size_t)col * (size_t)(p.ph[c] >> 1) + (size_t)(y >> 1); }
+/* bottom-row granules of CTB row `row`: index (column of the picture) >> 1 */
+__device__ __forceinline__ m355_granule* d_edge_row(const DevPic& p, int c, int row, int x) { return p.edge + p.edge_row_ofs[c] + (size_t)row * (size_t)(p.pw[c] >> 1) + (size_t)(x >> 1); }
+
+/* NW = waves per workgroup: 12 for intra pictures (CTBs with hundreds of blocks: up to 8 luma + 2 + 2 chroma waves share a
+ * level, the CTB's residuals are fetched into LDS up front), 6 for inter pictures (a handful of intra blocks per CTB: up to
+ * 4 + 1 + 1 waves, residuals fetched per block under its border phase; the smaller footprint keeps ~2.5x as many CTBs in
+ * flight).  The CTB's own wave counts come from ctb_dep bits 5-6 (runtime.hip intra_schedule). */
+template <class PIX, int CF, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p, int work_n)
 {
-  /* per component: top halo row (x = -1 .. 2*cw-1, index x+1) and body rows with a left halo column */
+  constexpr bool RES_LDS = NW >= 12;
+  /* per component: halo (top row x = -1 .. 2*cw-1 at index x+1; left column) as 32-bit words: a sample, or
+     HALO_NOT_READY while the neighbour CTB has not published it; body rows */
   constexpr int CW_C = (CF == 1 || CF == 2) ? MAXCTB / 2 : MAXCTB, CH_C = CF == 1 ? MAXCTB / 2 : MAXCTB;   /* chroma CTB size */
   constexpr int BODY_L = MAXCTB * BODY_PITCH_OF(MAXCTB), BODY_C = CF == 0 ? 8 : CH_C * BODY_PITCH_OF(CW_C);
-  __shared__ uint16_t s_top[3][2 * MAXCTB + 2];
+  __shared__ uint32_t s_top[3][2 * MAXCTB + 2];
+  __shared__ uint32_t s_left[3][MAXCTB];
   __shared__ __attribute__((aligned(16))) uint16_t s_body[BODY_L + 2 * BODY_C];
   /* the CTB's deferred residuals in picture layout (pitch = component CTB width): fetched up front, all loads in flight
      together, so that the per-block chain reads them from LDS instead of paying a global-memory latency per block */
-  constexpr int RES_L = DENSE ? MAXCTB * MAXCTB : 8, RES_C = (CF == 0 || !DENSE) ? 8 : CH_C * CW_C;
+  constexpr int RES_L = RES_LDS ? MAXCTB * MAXCTB : 8, RES_C = (CF == 0 || !RES_LDS) ? 8 : CH_C * CW_C;
   __shared__ __attribute__((aligned(16))) int16_t s_res[RES_L + 2 * RES_C];
   /* per WAVE (a wave works on one block at a time): */
-  constexpr int NWV = 3 * (DENSE ? INTRA_GMAX : 1);
+  constexpr int NWV = NW;
   __shared__ uint16_t s_raw[NWV][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
   __shared__ uint16_t s_p[NWV][4 * 32 + 8];        /* substituted border */
   __shared__ uint16_t s_f[NWV][4 * 32 + 8];        /* filtered border */
-  __shared__ int s_ref[NWV][3 * 32 + 8];           /* angular ref[-nT..2nT], index +32 */
   __shared__ uint32_t s_ticket;
-  __shared__ uint32_t s_need[3][MAXCTB];         /* !DENSE: per component and CTB row, which 8-sample vectors some block's border reads */
+  __shared__ uint32_t s_need[3][MAXCTB];         /* per component and CTB row, which 8-sample vectors some block's border reads */
   __shared__ uint32_t s_nts[9];                  /* CtbAddrRStoTS of the 3x3 CTB neighbourhood (0xFFFFFFFF outside the picture) */
   __shared__ uint8_t s_nsame[9];                 /* neighbour CTB in the picture, same slice (SliceAddrRS) and same tile */
 
-  /* wave -> (colour component c, sub-wave g of G): blockDim.x = 192 * G */
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int G = DENSE ? INTRA_GMAX : 1;
-  const int c = wv / G, g = wv - c * G;
 
-  if (threadIdx.x == 0) s_ticket = use_ticket ? atomicAdd(p.ticket, 1u) : blockIdx.x;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
   __syncthreads();
   if ((int)s_ticket >= work_n) return;
-  const int ctb = (int)p.intra_work[work_base + (int)s_ticket];
+  const int ctb = (int)p.intra_work[(int)s_ticket];
+  /* wave -> (colour component c, sub-wave g of G): GL luma waves, then GC for Cb, GC for Cr; the rest leave at once
+     (finished waves do not take part in later barriers) */
+  int GL, GC;
+  {
+    const int code = (p.ctb_dep[ctb] >> 5) & 3;          /* widest level of the CTB: luma 1 / 2 / 3-4 / more blocks */
+    GL = code == 0 ? 1 : (code == 1 ? 2 : (code == 2 || NW < 12 ? 4 : 8));
+    GC = (code == 3 && NW >= 12) ? 2 : 1;
+    if (GL > NW - 2) GL = NW - 2;
+  }
+  if (wv >= GL + 2 * GC) return;
+  const int c = wv < GL ? 0 : (wv < GL + GC ? 1 : 2);
+  const int G = c == 0 ? GL : GC, g = c == 0 ? wv : (wv - GL - (c - 1) * GC);
+  const bool multi = GL + GC > 2;                        /* more than one wave per component somewhere: levels end in a barrier */
   const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
   const m355_ctb ctbinfo = p.ctbs[ctb];
   const int l2c = p.pp.log2_ctb_size;
 
-  /* ---- wait for the neighbour CTBs whose INTRA output this CTB reads (left, above-left, above,
-   * above-right).  The host derives the mask from the block lists (runtime.hip, intra_dependencies):
-   * a neighbour matters only if it is in the same tile, one of our intra blocks touches the shared
-   * border on our side, and one of its intra blocks touches it on its side.  Everything else next
-   * door was finished by the preceding kernels (stream order), so sparse intra CUs in inter
-   * pictures decode fully in parallel and only genuinely chained CTBs form a wavefront. ---- */
-  const uint8_t dep = p.ctb_dep[ctb];
   /* 3x3 CTB neighbourhood facts, once per CTB: every availability test of intrapred.h:486-508 / :534-633
      (picture, slice, tile, z-scan order across CTBs) becomes an LDS lookup instead of dependent global loads */
-  if (threadIdx.x >= 64 && threadIdx.x < 73) {
-    const int i = threadIdx.x - 64, nx = ctbX + i % 3 - 1, ny = ctbY + i / 3 - 1;
+  if (threadIdx.x < 9) {
+    const int i = threadIdx.x, nx = ctbX + i % 3 - 1, ny = ctbY + i / 3 - 1;
     uint32_t ts = 0xFFFFFFFFu; uint8_t same = 0;
     if (nx >= 0 && ny >= 0 && nx < p.ctbW && ny < p.ctbH) {
       const int n = ny * p.ctbW + nx;
@@ -135,50 +157,51 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
   const int cs = comp ? c : 0;
   PIX* plane = (PIX*)p.plane[cs];
   const int stride = p.stride[cs], pw = p.pw[cs], ph = p.ph[cs];
-  uint16_t* top = s_top[cs];
+  uint32_t* top = s_top[cs];
+  uint32_t* left = s_left[cs];
   uint16_t* body = s_body + (cs == 0 ? 0 : BODY_L + (cs - 1) * BODY_C);
   const int BODY_PITCH = cs == 0 ? BODY_PITCH_OF(MAXCTB) : BODY_PITCH_OF(CW_C);
+  uint16_t* raw = s_raw[wv];
+  uint16_t* psub = s_p[wv];
+  uint16_t* pf = s_f[wv];
+  const uint32_t epoch = p.epoch;
+#define SYNC_CTB() do { if (multi) __syncthreads(); else wave_sync(); } while (0)
   int16_t* resl = s_res + (cs == 0 ? 0 : RES_L + (cs - 1) * RES_C);
   const int RES_PITCH = cs == 0 ? MAXCTB : CW_C;
-  uint16_t* raw = s_raw[wv];
-  uint16_t* pp_ = s_p[wv];
-  uint16_t* pf = s_f[wv];
-  int* ref = s_ref[wv] + 32;
 
-  if (comp) {
-    /* Inter pictures (!DENSE: a handful of intra blocks per CTB, one wave per component): only the samples some block's
-       border gathers — the row above it (x-1 .. x+2nT-1) and the column left of it (y .. y+2nT-1), intrapred.h:436-674 —
-       are read at all, so only the vectors holding them are staged (a 64x64 CTB with two 8x8 intra blocks: ~6 of its 512
-       luma vectors) instead of the whole CTB.  Blocks written later land in the same LDS tile as before. */
-    if (!DENSE) {
-      for (int y = lane; y < ch; y += 64) s_need[cs][y] = 0;
-      wave_sync();
-      const int nvr = cw >> 3;                                /* vectors per row */
-      for (uint32_t k = lane; k < ctbinfo.ib_count; k += 64) {
-        const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + k];
-        const uint32_t w0 = r[0], w1 = r[1];
-        if ((w1 & 0xFFu) != (uint32_t)c) continue;
-        const int nT = 1 << ((w1 >> 8) & 0xFFu);
-        const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
-        if (ly >= 1) {
-          const int v0 = max(lx - 1, 0) >> 3, v1 = min((lx + 2 * nT - 1) >> 3, nvr - 1);
-          if (v1 >= v0) atomicOr(&s_need[cs][ly - 1], ((2u << v1) - 1u) & ~((1u << v0) - 1u));
-        }
-        if (lx >= 1) {
-          const uint32_t bit = 1u << ((lx - 1) >> 3);
-          const int y1 = min(ly + 2 * nT, ch);
-          for (int y = max(ly, 0); y < y1; y++) atomicOr(&s_need[cs][y], bit);
-        }
+  /* ---- which body vectors does some block's border read?  Only those are staged: the row above a block
+     (x-1 .. x+2nT-1) and the column left of it (y .. y+2nT-1), intrapred.h:436-674 — a 64x64 CTB with two 8x8 intra
+     blocks: ~6 of its 512 luma vectors.  Samples that blocks of this CTB produce land in the same LDS tile later. ---- */
+  if (comp && g == 0) {
+    for (int y = lane; y < ch; y += 64) s_need[cs][y] = 0;
+    wave_sync();
+    const int nvr = cw >> 3;                                /* vectors per row */
+    for (uint32_t k = lane; k < ctbinfo.ib_count; k += 64) {
+      const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + k];
+      const uint32_t w0 = r[0], w1 = r[1];
+      if ((w1 & 0xFFu) != (uint32_t)c) continue;
+      const int nT = 1 << ((w1 >> 8) & 0xFFu);
+      const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
+      if (ly >= 1) {
+        const int v0 = max(lx - 1, 0) >> 3, v1 = min((lx + 2 * nT - 1) >> 3, nvr - 1);
+        if (v1 >= v0) atomicOr(&s_need[cs][ly - 1], ((2u << v1) - 1u) & ~((1u << v0) - 1u));
       }
-      wave_sync();
+      if (lx >= 1) {
+        const uint32_t bit = 1u << ((lx - 1) >> 3);
+        const int y1 = min(ly + 2 * nT, ch);
+        for (int y = max(ly, 0); y < y1; y++) atomicOr(&s_need[cs][y], bit);
+      }
     }
-    /* ---- stage the CTB and its halo in LDS: 8-sample vectors, all loads of a lane in flight at once ---- */
+  }
+  SYNC_CTB();
+  if (comp) {
+    /* ---- stage those vectors: 8 samples each, all loads of a lane in flight at once ---- */
     {
       const int l2v = (l2c - csw) - 3;                       /* log2(vectors per row); cw >= 8 */
       const int nvec = ch << l2v;
       for (int idx = lane + 64 * g; idx < nvec; idx += 64 * G) {
         const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
-        if (!DENSE && !((s_need[cs][y] >> (xv >> 3)) & 1u)) continue;
+        if (!((s_need[cs][y] >> (xv >> 3)) & 1u)) continue;
         if (x0c + xv < pw && y0c + y < ph) {
           const PIX* src = plane + (size_t)(y0c + y) * stride + x0c + xv;
           uint4 v;
@@ -192,28 +215,40 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
         }
       }
     }
-  }
-
-  /* ---- residual pre-pass: every wave fetches the residuals of the blocks it will process (same selection as the
-     main loop below, so no other wave ever reads them) ---- */
-  constexpr bool res_in_lds = DENSE;
-  for (uint32_t kbase = 0; res_in_lds && kbase < ctbinfo.ib_count; kbase += 64) {
-    uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
-    int lv = -1;
-    const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
-    if (lane < nvalid) {
-      const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
-      rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
-      lv = p.ib_level[ctbinfo.ib_start + kbase + lane];
+    /* ---- halo: the row above the CTB (x = -1 .. 2cw-1) and the column left of it.  A sample that an INTRA block of a
+       neighbour CTB produces comes from that CTB's granules — if it is there already; otherwise the entry stays
+       HALO_NOT_READY and the block that needs it polls for it.  Everything else was finished by the preceding kernels
+       (stream order) and is read from the picture. ---- */
+    const int nhalo = (2 * cw + 1) + ch;
+    for (int h = lane + 64 * g; h < nhalo; h += 64 * G) {
+      const bool is_top = h < 2 * cw + 1;
+      const int hx = is_top ? x0c - 1 + h : x0c - 1, hy = is_top ? y0c - 1 : y0c + (h - (2 * cw + 1));
+      uint32_t v = 0;
+      if (hx >= 0 && hy >= 0 && hx < pw && hy < ph) {
+        const uint32_t ci = d_cu_index_at(p, hx << csw, hy << csh);
+        if (ci != 0 && p.cus[ci - 1].pred_mode == 0) {
+          const m355_granule gr = __hip_atomic_load(is_top ? d_edge_row(p, cs, ctbY - 1, hx) : d_edge_col(p, cs, ctbX - 1, hy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = (uint32_t)(gr >> 32) == epoch ? (uint32_t)((gr >> (16 * ((is_top ? hx : hy) & 1))) & 0xFFFFu) : HALO_NOT_READY;
+        } else v = plane[(size_t)hy * stride + hx];
+      }
+      if (is_top) top[h] = v; else left[h - (2 * cw + 1)] = v;
     }
-    const int lv_first = __shfl(lv, 0, 64), lv_last = __shfl(lv, nvalid - 1, 64);
-    for (int L = lv_first; L <= lv_last; L++) {
-      unsigned long long mine = __ballot((int)(comp && lv == L && (rw1 & 0xFFu) == (uint32_t)c));
-      int rank = 0;
+  }
+  /* ---- residual pre-pass (intra pictures): the CTB's deferred residuals go to LDS, each component's waves taking its
+     blocks in turn ---- */
+  if (RES_LDS) {
+    int taken = 0;                                           /* blocks of this component seen so far (wave-uniform) */
+    for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
+      uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
+      if (kbase + lane < ctbinfo.ib_count) {
+        const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
+        rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
+      }
+      unsigned long long mine = __ballot((int)(comp && (rw1 & 0xFFu) == (uint32_t)c));
       while (mine) {
         const int src = __ffsll(mine) - 1;
         mine &= mine - 1;
-        if ((rank++ % G) != g) continue;
+        if ((taken++ & (G - 1)) != g) continue;
         const uint32_t w0 = __shfl(rw0, src, 64), w1 = __shfl(rw1, src, 64), w2 = __shfl(rw2, src, 64);
         const int flags = (int)(w1 >> 24), log2 = (int)((w1 >> 8) & 0xFFu), nT = 1 << log2;
         if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
@@ -225,45 +260,23 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
       }
     }
   }
-
-  /* ---- only now wait for the neighbour CTBs: everything above (own samples, finished by the preceding
-     kernels) overlapped with their work; what follows — the halo — is what they produce ---- */
-  if (threadIdx.x == 0 && (dep & 15)) {
-    const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
-    for (int n = 0; n < 4; n++) {
-      const int nx = ctbX + dx[n], ny = ctbY + dy[n];
-      if (nx < 0 || ny < 0 || nx >= p.ctbW) continue;
-      const int nb = ny * p.ctbW + nx;
-      if (!((dep >> n) & 1)) continue;         /* that neighbour's intra output is never read here */
-      unsigned spins = 0;
-      while (__hip_atomic_load(&p.ctb_done[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > SPIN_LIMIT) { atomicExch(p.timeout, 1u); break; }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-
-  if (comp && g == 0) {
-    if (x0c > 0)
-      for (int y = lane; y < ch; y += 64)
-        if (y0c + y < ph) body[y * BODY_PITCH + BODY_X0 - 1] = plane[(size_t)(y0c + y) * stride + x0c - 1];
-    if (y0c > 0)
-      for (int x = lane; x < 2 * cw + 1; x += 64) {
-        const int xx = x0c - 1 + x;
-        if (xx >= 0 && xx < pw) top[x] = plane[(size_t)(y0c - 1) * stride + xx];
-      }
-  }
-  if (G > 1) __syncthreads(); else wave_sync();     /* CTB + halo staged by all waves of the component (G == 1: by this wave) */
-
-#define SAMPLE(lx, ly) ((ly) < 0 ? top[(lx) + 1] : body[(ly) * BODY_PITCH + (lx) + BODY_X0])
+  __syncthreads();     /* neighbourhood table (wave 0), bodies, halos and residuals staged */
+  /* the 3x3 neighbourhood as two 9-bit masks in registers: same slice + tile / earlier in decode order than this CTB */
+  uint32_t nb_same = 0, nb_earlier = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { nb_same |= (uint32_t)(s_nsame[k] != 0) << k; nb_earlier |= (uint32_t)(s_nts[k] < s_nts[4]) << k; }
 
   /* The CTB's block records (sorted by level, then component) are fetched 64 at a time (one per lane, coalesced) by
      EVERY wave; for each level present in the batch, a wave takes the blocks of its component that fall to it
      (every G-th) by broadcasting the record from the owning lane, then all waves meet at the workgroup barrier.  The
      loop bounds come from the records alone, so all waves (also those of absent components) execute the same
      barriers. */
+#ifdef M355_X_TIMING
+  long long tT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = clock64();
+#define TMARK(i) do { const long long n_ = clock64(); tT[i] += n_ - tmark; tmark = n_; } while (0)
+#else
+#define TMARK(i)
+#endif
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
     uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
     int lv = -1;
@@ -280,7 +293,7 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
     while (mine) {
       const int src = __ffsll(mine) - 1;
       mine &= mine - 1;
-      if ((rank++ % G) != g) continue;             /* another wave of this component takes it */
+      if ((rank++ & (G - 1)) != g) continue;             /* another wave of this component takes it */
       m355_ib ib;
       {
         const uint32_t w0 = __shfl(rw0, src, 64), w1 = __shfl(rw1, src, 64), w2 = __shfl(rw2, src, 64);
@@ -290,25 +303,18 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
       }
       const int nT = 1 << ib.log2_size;
       const int xB = ib.x, yB = ib.y, lx = xB - x0c, ly = yB - y0c;
+      TMARK(0);
+      /* does the block complete a piece of the CTB's right column / bottom row that a neighbour CTB may read? */
+      const bool pub_col = lx + nT == cw && ctbX + 1 < p.ctbW, pub_row = ly + nT == ch && ctbY + 1 < p.ctbH;
 
-      if (ib.flags & M355_IBF_PCM) { /* raw block */
-        for (int o = lane; o < nT * nT; o += 64) {
-          const int y = o >> ib.log2_size, x = o & (nT - 1);
-          const uint16_t v = p.pcm[ib.res_ofs + o];
-          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = v;
-          plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;
-        }
-        wave_sync();
-        continue;
-      }
-
-      /* residual of this block (written by k_residual), sparse case: issue the loads now, consume them after the
+      if (!(ib.flags & M355_IBF_PCM)) {
+      /* residual of this block (written by k_residual): issue the loads now, consume them after the
          border/prediction chain — up to 16 samples per lane (32x32) */
       int16_t rv[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         const int o = lane + 64 * q;
-        rv[q] = (!res_in_lds && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
+        rv[q] = (!RES_LDS && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
       }
 
       /* ---- preproc (intrapred.h:436-531): CTB-level availability from the neighbourhood table ---- */
@@ -317,19 +323,19 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
       if (xBL + nT * SubW >= p.pp.width) aTR = false;
       {
         const int dxL = ((xBL - 1) >> l2c) - ctbX, dxR = ((xBL + nT * SubW) >> l2c) - ctbX, dyT = ((yBL - 1) >> l2c) - ctbY;
-        if (aL && !s_nsame[3 + dxL + 1]) aL = false;
-        if (aT && !s_nsame[(dyT + 1) * 3 + 1]) aT = false;
-        if (aTL && !s_nsame[(dyT + 1) * 3 + dxL + 1]) aTL = false;
-        if (aTR && !s_nsame[(dyT + 1) * 3 + dxR + 1]) aTR = false;
+        if (aL && !((nb_same >> (3 + dxL + 1)) & 1u)) aL = false;
+        if (aT && !((nb_same >> ((dyT + 1) * 3 + 1)) & 1u)) aT = false;
+        if (aTL && !((nb_same >> ((dyT + 1) * 3 + dxL + 1)) & 1u)) aTL = false;
+        if (aTR && !((nb_same >> ((dyT + 1) * 3 + dxR + 1)) & 1u)) aTR = false;
       }
       int nBottom = p.pp.height - yB * SubH;
-      nBottom = (nBottom + SubH - 1) / SubH;
+      nBottom = (nBottom + SubH - 1) >> csh;
       if (nBottom > 2 * nT) nBottom = 2 * nT;
       int nRight = p.pp.width - xB * SubW;
-      nRight = (nRight + SubW - 1) / SubW;
+      nRight = (nRight + SubW - 1) >> csw;
       if (nRight > 2 * nT) nRight = 2 * nT;
       const int l2tb = p.pp.log2_min_tb_size, cmask = (1 << l2c) - 1;
-      const uint32_t curTs = s_nts[4], curZ = d_morton((uint32_t)(xBL & cmask) >> l2tb, (uint32_t)(yBL & cmask) >> l2tb);
+      const uint32_t curZ = d_morton((uint32_t)(xBL & cmask) >> l2tb, (uint32_t)(yBL & cmask) >> l2tb);
       const bool cip = (p.pp.flags & M355_PF_CONSTRAINED_INTRA_PRED) != 0;
       const int nEnt = 4 * nT + 1;
 
@@ -340,49 +346,86 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
         if (64 * q >= nEnt) continue;              /* wave-uniform: 4x4 / 8x8 blocks have 17 / 33 border entries */
         const int e = lane + 64 * q;
         bool av = false;
-        int val = 0;
+        uint32_t val = 0;
+        uint32_t* hslot = nullptr;                 /* the halo word behind this entry, if it is one */
+        const m355_granule* gsrc = nullptr;
+        int ghalf = 0;
         if (e < nEnt) {
           const int i = e - 2 * nT;
           int xN, yN, sx, sy; /* test position (luma), sample position (local) */
           if (i < 0) {
-            const int yy = -i - 1, g = yy & ~3;
-            av = aL && (g + 3 < nBottom);
-            xN = (xB - 1) * SubW; yN = (yB + g + 3) * SubH; sx = lx - 1; sy = ly + yy;
+            const int yy = -i - 1, g4 = yy & ~3;
+            av = aL && (g4 + 3 < nBottom);
+            xN = (xB - 1) * SubW; yN = (yB + g4 + 3) * SubH; sx = lx - 1; sy = ly + yy;
           } else if (i == 0) {
             av = aTL;
             xN = (xB - 1) * SubW; yN = (yB - 1) * SubH; sx = lx - 1; sy = ly - 1;
           } else {
-            const int xx = i - 1, g = xx & ~3;
-            av = (g < nT ? aT : aTR) && (g < nRight);
-            xN = (xB + g) * SubW; yN = (yB - 1) * SubH; sx = lx + xx; sy = ly - 1;
+            const int xx = i - 1, g4 = xx & ~3;
+            av = (g4 < nT ? aT : aTR) && (g4 < nRight);
+            xN = (xB + g4) * SubW; yN = (yB - 1) * SubH; sx = lx + xx; sy = ly - 1;
           }
           if (av) {     /* MinTbAddrZS[neighbour] <= MinTbAddrZS[current] (intrapred.h:560-566) */
             const int dcx = (xN >> l2c) - ctbX, dcy = (yN >> l2c) - ctbY;
             if (dcx == 0 && dcy == 0) av = d_morton((uint32_t)(xN & cmask) >> l2tb, (uint32_t)(yN & cmask) >> l2tb) <= curZ;
-            else av = s_nts[(dcy + 1) * 3 + dcx + 1] < curTs;
+            else av = (nb_earlier >> ((dcy + 1) * 3 + dcx + 1)) & 1u;
           }
           if (av && cip) av = d_is_intra_at(p, xN, yN);
-          if (av) val = SAMPLE(sx, sy);
-          raw[e] = (uint16_t)val;
+          if (av) {
+            if (sy < 0) { hslot = &top[sx + 1]; val = *hslot; gsrc = d_edge_row(p, cs, ctbY - 1, x0c + sx); ghalf = (x0c + sx) & 1; }
+            else if (sx < 0) { hslot = &left[sy]; val = *hslot; gsrc = d_edge_col(p, cs, ctbX - 1, y0c + sy); ghalf = (y0c + sy) & 1; }
+            else val = body[sy * BODY_PITCH + sx + BODY_X0];
+          }
         }
+        /* a halo sample its CTB has not published yet: poll its granule (relaxed, agent scope: served by the L2 / fabric,
+           never by this CU's L1); every waiting lane has its own word, the wave leaves when all have arrived */
+        bool pending = av && hslot != nullptr && val == HALO_NOT_READY;
+        if (__any(pending)) {
+          unsigned spins = 0;
+          for (;;) {
+            if (pending) {
+              const m355_granule gr = __hip_atomic_load(gsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((uint32_t)(gr >> 32) == epoch) { val = (uint32_t)((gr >> (16 * ghalf)) & 0xFFFFu); *hslot = val; pending = false; }
+            }
+            if (!__any(pending)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { if (lane == 0) atomicExch(p.timeout, 1u); break; }
+          }
+        }
+        if (e < nEnt) raw[e] = (uint16_t)val;
         am[q] = __ballot(av);
       }
       wave_sync();
-      /* ---- reference_sample_substitution ---- */
+      TMARK(1);
+      /* ---- reference_sample_substitution (only when something is missing: the common interior block keeps its gathered
+         border as it is) ---- */
       const bool none = (am[0] | am[1] | am[2]) == 0;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        if (64 * q >= nEnt) continue;
-        const int e = lane + 64 * q;
-        if (e < nEnt) {
-          int v;
-          if (none) v = 1 << (bd - 1);
-          else if ((am[q] >> lane) & 1) v = raw[e];
-          else v = raw[d_subst_src(e, am[0], am[1], am[2])];
-          pp_[e] = (uint16_t)v;
-        }
+      bool all_av;
+      {
+        const unsigned long long full = ~0ull;
+        const int r1 = nEnt - 64, r2 = nEnt - 128;      /* entries in the 2nd / 3rd mask word */
+        all_av = am[0] == (nEnt >= 64 ? full : ((1ull << nEnt) - 1ull)) &&
+                 (r1 <= 0 || am[1] == (r1 >= 64 ? full : ((1ull << r1) - 1ull))) &&
+                 (r2 <= 0 || am[2] == ((1ull << r2) - 1ull));
       }
-      wave_sync();
+      uint16_t* pp_ = raw;
+      if (!all_av) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          if (64 * q >= nEnt) continue;
+          const int e = lane + 64 * q;
+          if (e < nEnt) {
+            int v;
+            if (none) v = 1 << (bd - 1);
+            else if ((am[q] >> lane) & 1) v = raw[e];
+            else v = raw[d_subst_src(e, am[0], am[1], am[2])];
+            psub[e] = (uint16_t)v;
+          }
+        }
+        wave_sync();
+        pp_ = psub;
+      }
+      TMARK(2);
       /* ---- intra_prediction_sample_filtering (intrapred.h:185-258) ---- */
       const int mode = ib.mode;
       uint16_t* P = pp_; /* border in use, entry index = i + 2nT */
@@ -416,6 +459,7 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
       }
 #define BRD(i) ((int)P[(i) + Z])
 
+      TMARK(3);
       /* ---- prediction (intrapred.h:261-433) ---- */
       const int log2 = ib.log2_size;
       int dcVal = 0;
@@ -426,21 +470,14 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
         dcVal = (s + nT) >> (log2 + 1);
       }
+      /* angular modes (intrapred.h:330-433): the projected reference array ref[] of the reference is not built — its entry x is
+         border entry sgn*x for x >= 0 and, left of the corner (negative angles only), -sgn*((x*invAngle+128)>>8): the two taps
+         of a sample are read straight from the border */
       const int angle = c_intra_angle[mode];
-      if (mode >= 2) {
-        const int sgn = mode >= 18 ? 1 : -1;
-        const int inv = angle < 0 ? c_intra_inv_angle[mode - 11] : 0;
-        const int lo = (nT * angle) >> 5;
-        for (int t = lane; t < 3 * nT + 1; t += 64) {
-          const int x = t - nT;
-          int v = 0;
-          if (x >= 0 && x <= nT) v = BRD(sgn * x);
-          else if (x < 0) { if (angle < 0 && lo < -1 && x >= lo) v = BRD(-sgn * ((x * inv + 128) >> 8)); }
-          else if (angle >= 0) v = BRD(sgn * x);
-          ref[x] = v;
-        }
-        wave_sync();
-      }
+      const int sgn = mode >= 18 ? 1 : -1;
+      const int inv = (mode >= 2 && angle < 0) ? c_intra_inv_angle[mode - 11] : 0;
+#define REFV(x_) ((x_) >= 0 ? BRD(sgn * (x_)) : BRD(-sgn * (((x_) * inv + 128) >> 8)))
+      TMARK(4);
       const bool has_res = (ib.flags & M355_IBF_HAS_RESIDUAL) != 0;
       const bool edge = (c == 0 && nT < 32);
       const bool bfilt = edge && !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER);
@@ -462,42 +499,62 @@ __global__ void __launch_bounds__(DENSE ? 192 * INTRA_GMAX : 192) k_intra(DevPic
         } else {
           const int a = mode >= 18 ? y : x, b = mode >= 18 ? x : y;
           const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
-          v = iFact ? ((32 - iFact) * ref[b + iIdx + 1] + iFact * ref[b + iIdx + 2] + 16) >> 5 : ref[b + iIdx + 1];
+          const int r1 = REFV(b + iIdx + 1);
+          v = iFact ? ((32 - iFact) * r1 + iFact * REFV(b + iIdx + 2) + 16) >> 5 : r1;
           if (bfilt) {
             if (mode == 26 && x == 0) v = d_clip_bd(BRD(1) + ((BRD(-1 - y) - BRD(0)) >> 1), bd);
             if (mode == 10 && y == 0) v = d_clip_bd(BRD(-1) + ((BRD(1 + x) - BRD(0)) >> 1), bd);
           }
         }
-        if (has_res) v = d_clip_bd(v + (res_in_lds ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (int)rv[q]), bd);
+        if (has_res) v = d_clip_bd(v + (RES_LDS ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (int)rv[q]), bd);
         body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders */
         plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;                /* the picture: only intra samples are (re)written */
       }
+#undef BRD
+#undef REFV
+      } else { /* raw block (slice.cc:4211-4255) */
+        for (int o = lane; o < nT * nT; o += 64) {
+          const int y = o >> ib.log2_size, x = o & (nT - 1);
+          const uint16_t v = p.pcm[ib.res_ofs + o];
+          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = v;
+          plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;
+        }
+      }
       wave_sync();
+      TMARK(5);
+      /* ---- publish: the block's share of the CTB's right column / bottom row, two samples per granule ---- */
+      if (pub_col && lane < (nT >> 1)) {
+        const int y = ly + 2 * lane;
+        const uint32_t s0 = body[y * BODY_PITCH + lx + nT - 1 + BODY_X0], s1 = body[(y + 1) * BODY_PITCH + lx + nT - 1 + BODY_X0];
+        __hip_atomic_store(d_edge_col(p, cs, ctbX, y0c + y), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (pub_row && lane >= 32 && lane < 32 + (nT >> 1)) {
+        const int x = lx + 2 * (lane - 32);
+        const uint32_t s0 = body[(ly + nT - 1) * BODY_PITCH + x + BODY_X0], s1 = body[(ly + nT - 1) * BODY_PITCH + x + 1 + BODY_X0];
+        __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + x), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      TMARK(6);
     }   /* this wave's blocks of the level */
-    if (G > 1) __syncthreads();   /* level done: its samples are in LDS for the next level's borders (G == 1: the wave's own
-                                     blocks are ordered by wave_sync above; components do not interact) */
+    if (multi) __syncthreads();
+    TMARK(7);   /* level done: its samples are in LDS for the next level's borders (one wave per component:
+                                     its own blocks are ordered by wave_sync above; components do not interact) */
     }   /* levels in the batch */
   }   /* 64-record batches */
-#undef BRD
-#undef SAMPLE
-
-  /* ---- publish (guideline 16: stores -> barrier -> one-lane agent release -> drain -> flag) ---- */
-  if (!(dep & 16)) return;            /* nobody waits for this CTB (host-derived): nothing to publish */
-  d_drain_vmem();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    d_drain_vmem();
-    __hip_atomic_store(&p.ctb_done[ctb], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+#ifdef M355_X_TIMING
+  if (lane == 0 && wv == 0) for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)(p.timeout + 2) + i, (unsigned long long)tT[i]);
+#endif
+#undef SYNC_CTB
 }
 
 template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, hipStream_t st)
 {
   hipMemsetAsync(p.ticket, 0, 4, st);
-  if (p.intra_waves >= INTRA_GMAX) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, true>), dim3(p.n_intra_work), dim3(192 * INTRA_GMAX), 0, st, p, 0, p.n_intra_work, 1);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, false>), dim3(p.n_intra_work), dim3(192), 0, st, p, 0, p.n_intra_work, 1);
+  static const int nw_sparse = getenv("M355_INTRA_NW") ? atoi(getenv("M355_INTRA_NW")) : 4;     /* experiment knob */
+  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 12>), dim3(p.n_intra_work), dim3(64 * 12), 0, st, p, p.n_intra_work);
+  else if (nw_sparse == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 3>), dim3(p.n_intra_work), dim3(64 * 3), 0, st, p, p.n_intra_work);
+  else if (nw_sparse == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 6>), dim3(p.n_intra_work), dim3(64 * 6), 0, st, p, p.n_intra_work);
 }
 
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)

@@ -120,12 +120,13 @@ struct Lane {
   hipStream_t stream = nullptr, stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   Frame work;
-  uint32_t *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
+  uint32_t *pb_of = nullptr, *ticket = nullptr, *timeout = nullptr;
+  unsigned long long* edge = nullptr;   /* k_intra halo granules */
   uint8_t *edge_tu = nullptr, *cuf = nullptr;
   int16_t* resbuf = nullptr;
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
 };
 
 struct m355_ctx {
@@ -141,12 +142,13 @@ struct m355_ctx {
   int next_transient = 0;
   Frame work;                  /* pre-SAO working planes */
   /* scratch */
-  uint32_t *pb_of = nullptr, *ctb_done = nullptr, *ticket = nullptr, *timeout = nullptr;
+  uint32_t *pb_of = nullptr, *ticket = nullptr, *timeout = nullptr;
+  unsigned long long* edge = nullptr;   /* k_intra halo granules */
   uint8_t *edge_tu = nullptr, *cuf = nullptr;   /* edge_tu also holds edge_pb and cb_cu (one allocation) */
   int16_t* resbuf = nullptr;
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_ctb = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
   uint32_t epoch = 0;
   int stages = M355_STAGE_ALL;
   int shard_rank = 0, shard_n = 0;   /* shard_n == 0: sharding off */
@@ -156,8 +158,8 @@ struct m355_ctx {
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
 };
 
-#define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_join) X(work) X(pb_of) X(ctb_done) X(ticket) X(timeout) X(edge_tu) X(cuf) \
-  X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_ctb) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
+#define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
+  X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
 static void select_lane(m355_ctx* c, int lane)
 {
   if (lane == c->active) return;
@@ -176,9 +178,9 @@ static int lane_create(m355_ctx* c, Lane& l)
   HIPCHK(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming));
   HIPCHK(hipMalloc(&l.ticket, 64));
-  HIPCHK(hipMalloc(&l.timeout, 64));
+  HIPCHK(hipMalloc(&l.timeout, 128));
   HIPCHK(hipMemsetAsync(l.ticket, 0, 64, l.stream));
-  HIPCHK(hipMemsetAsync(l.timeout, 0, 64, l.stream));
+  HIPCHK(hipMemsetAsync(l.timeout, 0, 128, l.stream));
   HIPCHK(hipStreamSynchronize(l.stream));
   return M355_OK;
 }
@@ -187,7 +189,7 @@ static void lane_destroy(Lane& l)
   if (l.stream) hipStreamSynchronize(l.stream);
   if (l.stream2) hipStreamSynchronize(l.stream2);
   if (l.work.used) frame_free(l.work);
-  void* bufs[] = {l.pb_of, l.ctb_done, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb};
+  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb};
   for (void* b : bufs) if (b) hipFree(b);
   if (l.ev_fork) hipEventDestroy(l.ev_fork);
   if (l.ev_join) hipEventDestroy(l.ev_join);
@@ -712,20 +714,22 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
  * of those samples (a superset of what the availability rules of intrapred.h:534-633 let it read); level = 1 + the
  * highest level among them.  Blocks of one level are independent: k_intra runs them concurrently on several waves with
  * a workgroup barrier between levels, instead of walking the CTB's blocks one by one.  `out` receives each CTB's blocks
- * sorted by (level, component), decode order kept inside; `lvl` their levels.  *waves = waves per component worth
- * launching (1 when CTBs hold few blocks, as in inter pictures). */
-static void intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint16_t* lvl, int* waves)
+ * sorted by (level, component), decode order kept inside; `lvl` their levels; log2_waves[ctb] = how wide the CTB's widest
+ * level is in luma blocks (0: 1, 1: 2, 2: 3-4, 3: more) -> how many waves k_intra runs on it; *dense = intra picture
+ * (24 or more blocks per intra CTB on average). */
+static void intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint16_t* lvl, uint8_t* log2_waves, int* dense)
 {
   const m355_pic_params& pp = pic->pp;
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
-  std::atomic<long long> dense(0), n_intra_ctbs(0);
+  std::atomic<long long> n_blocks(0), n_intra_ctbs(0);
   parallel_ranges((size_t)pic->n_ctbs, 256, [&](size_t cb, size_t ce) {
     std::vector<std::pair<uint32_t, uint32_t>> key;      /* (level << 2 | cidx, index) */
-    long long my_dense = 0, my_n = 0;
+    long long my_blocks = 0, my_ctbs = 0;
     for (size_t c = cb; c < ce; c++) {
       const m355_ctb& ctb = pic->ctbs[c];
+      log2_waves[c] = 0;
       if (!ctb.ib_count) continue;
-      my_n++; my_dense += ctb.ib_count;
+      my_ctbs++; my_blocks += ctb.ib_count;
       const int cx = (int)c % ctbW, cy = (int)c / ctbW;
       int16_t grid[3][16][16];
       memset(grid, 0xFF, sizeof(grid));                  /* -1: no intra block of this CTB there (yet) */
@@ -748,14 +752,18 @@ static void intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint
         key.push_back(std::make_pair(((uint32_t)level << 2) | ib.cidx, k));
       }
       std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+      uint32_t widest = 1, run = 0;
       for (uint32_t k = 0; k < ctb.ib_count; k++) {
         out[ctb.ib_start + k] = pic->ibs[ctb.ib_start + key[k].second];
         lvl[ctb.ib_start + k] = (uint16_t)(key[k].first >> 2);
+        run = (k && key[k].first == key[k - 1].first) ? run + 1 : 1;
+        if ((key[k].first & 3) == 0) widest = std::max(widest, run);      /* luma blocks of one level */
       }
+      log2_waves[c] = widest >= 5 ? 3 : (widest >= 3 ? 2 : (widest == 2 ? 1 : 0));
     }
-    dense += my_dense; n_intra_ctbs += my_n;
+    n_blocks += my_blocks; n_intra_ctbs += my_ctbs;
   });
-  *waves = (n_intra_ctbs.load() && dense.load() / n_intra_ctbs.load() >= 24) ? 4 : 1;
+  *dense = (n_intra_ctbs.load() && n_blocks.load() / n_intra_ctbs.load() >= 24) ? 1 : 0;
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -846,8 +854,9 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   for (int i = 0; i < ns; i++)
     if (seg[i].src && seg[i].bytes) parallel_memcpy(r.host + seg[i].ofs, seg[i].src, seg[i].bytes);
   const auto t_copy = now();
-  int intra_waves = 1;
-  intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint16_t*)(r.host + seg[i_il].ofs), &intra_waves);
+  std::vector<uint8_t> log2_waves((size_t)nCtb, 0);
+  int intra_dense = 0;
+  intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint16_t*)(r.host + seg[i_il].ofs), log2_waves.data(), &intra_dense);
   /* derived scan tables (pps.cc:589-606) */
   uint32_t* ctb_ts = (uint32_t*)(r.host + seg[i_ts].ofs);
   uint32_t* ts2rs = (uint32_t*)(r.host + seg[i_rs].ofs);
@@ -868,6 +877,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
      workgroup still only ever waits on lower tickets: free CTBs never wait, dependent ones wait on free ones (all
      earlier) or on dependent ones earlier in decode order. */
   intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
+  for (int i = 0; i < nCtb; i++) ((uint8_t*)(r.host + seg[i_dp].ofs))[i] |= (uint8_t)(log2_waves[i] << 5);
   int nw = 0, n_free = 0;
   {
     const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
@@ -943,7 +953,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.rbs = (const m355_rb*)(r.dev + seg[i_rb].ofs);
   d.ibs = (const m355_ib*)(r.dev + seg[i_ib].ofs);
   d.ib_level = (const uint16_t*)(r.dev + seg[i_il].ofs);
-  d.intra_waves = intra_waves;
+  d.intra_dense = intra_dense;
   d.coeffs = (const uint32_t*)(r.dev + seg[i_co].ofs);
   d.pcm = (const uint16_t*)(r.dev + seg[i_pc].ofs);
   d.scaling = pic->scaling_factors ? (const uint8_t*)(r.dev + seg[i_sc].ofs) : nullptr;
@@ -1010,7 +1020,16 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
     if ((rc = grow(&c->edge_tu, &c->cap_u4, need, c->stream, false))) return rc;
     if ((rc = grow(&c->pb_of, &c->cap_cb, u4, c->stream, true))) return rc;
   }
-  if ((rc = grow(&c->ctb_done, &c->cap_ctb, (size_t)d.nCtb, c->stream, true))) return rc;
+  {
+    /* k_intra's halo granules: per component ctbW right columns of ph / 2 granules and ctbH bottom rows of pw / 2; zero at
+       allocation, never cleared: a granule is valid when it carries the epoch of the decode that reads it */
+    size_t n = 0;
+    for (int cc = 0; cc < 3; cc++) {
+      d.edge_col_ofs[cc] = (uint32_t)n; n += (size_t)d.ctbW * (size_t)(dst->ph[cc] >> 1);
+      d.edge_row_ofs[cc] = (uint32_t)n; n += (size_t)d.ctbH * (size_t)(dst->pw[cc] >> 1);
+    }
+    if ((rc = grow(&c->edge, &c->cap_edge, n + 1, c->stream, true))) return rc;
+  }
   if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + (size_t)r.halo.n_units + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->resbuf, &c->cap_res, (size_t)pic.res_len + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
@@ -1037,7 +1056,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   d.cuf = c->cuf; d.pb_of = c->pb_of;
   d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && pp.chroma_format_idc <= 1) ? 0 : 1;   /* else k_inter_jobs writes it */
   d.jobs = c->jobs; d.sao_nb = c->sao_nb;
-  d.resbuf = c->resbuf; d.ctb_done = c->ctb_done; d.ticket = c->ticket; d.timeout = c->timeout;
+  d.resbuf = c->resbuf; d.edge = c->edge; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;
   d_out = d; want_sao_out = want_sao;
@@ -1244,6 +1263,12 @@ int m355_wait(m355_ctx* c)
   for (auto& f : c->frames) { f.wr_pending = false; for (int k = 0; k < M355_MAX_LANES; k++) f.rd_pending[k] = false; }   /* everything is complete */
   uint32_t t = 0;
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
+  if (getenv("M355_INTRA_TIMING")) {   /* kernels built with -DM355_X_TIMING: clock sums of wave 0 of every CTB, per phase */
+    unsigned long long tt[8];
+    HIPCHK(hipMemcpy(tt, c->timeout + 2, sizeof(tt), hipMemcpyDeviceToHost));
+    fprintf(stderr, "m355 intra timing (clocks): rec %llu gather %llu subst %llu filter %llu ref %llu predict %llu publish %llu barrier %llu\n", tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], tt[7]);
+    hipMemset(c->timeout + 2, 0, sizeof(tt));
+  }
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].timeout) { uint32_t t2 = 0; HIPCHK(hipMemcpy(&t2, c->lanes[k].timeout, 4, hipMemcpyDeviceToHost)); t |= t2; }
   if (t) {

@@ -3,6 +3,8 @@
 #define M355_K_ASM_H
 #include <string.h>
 #define M355_GLOBAL
+/* workgroups run one after the other here: a poll that is not satisfied at once never will be */
+#define M355_SPIN_LIMIT 4u
 static inline void d_drain_vmem() {}
 static inline void d_ldg16(const void* p, unsigned* o) { memcpy(o, p, 16); }
 static inline void d_ldg12(const void* p, unsigned* o) { memcpy(o, p, 12); }

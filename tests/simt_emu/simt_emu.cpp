@@ -85,7 +85,8 @@ void run_block(Block& b)
         if (b.fibers[i].state == AT_BLOCK_BARRIER) waiting++;
       }
       if (live && waiting == live) {
-        for (int i = 0; i < n; i++) b.fibers[i].state = RUNNABLE;
+        /* threads that have returned stay finished: like the hardware, a barrier only counts the waves still running */
+        for (int i = 0; i < n; i++) if (b.fibers[i].state == AT_BLOCK_BARRIER) b.fibers[i].state = RUNNABLE;
         progressed = true;
       }
     }
