@@ -36,13 +36,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=1200, help="steps of THE timed region (default: ~0.5 s of device time at the default workload)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c5_8k10_8tiles")
     ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", type=int, default=31, help="DIAGNOSTIC ONLY: M355_STAGE_* mask (anything but 31 is not a valid benchmark)")
-    ap.add_argument("--with-upload", action="store_true", help="also time m355_submit_picture per step (host lists -> pinned arena -> H2D -> decode): the PCIe-inclusive rate")
+    ap.add_argument("--no-with-upload", action="store_true", help="skip the PCIe-inclusive legs (lists recorded into the pinned arena -> validation -> H2D -> decode, per step)")
+    ap.add_argument("--no-dependent-chain", action="store_true", help="skip the leg in which every picture references the two decoded before it")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
     args = ap.parse_args()
@@ -99,12 +100,13 @@ def main():
     for _ in range(args.warmup):
         ctx.decode_resident(handle)
     ctx.wait()
+    side_steps = max(1, min(args.steps, 200))   # the legs beside the timed region run a bounded number of steps
     ctx.timing_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(side_steps):
         ctx.decode_resident(handle)
     ctx.wait()
-    dt_serial = time.perf_counter() - t0
+    dt_serial = (time.perf_counter() - t0) * args.steps / side_steps
     n_dec, avg_total_ms, stage_ms = ctx.timing_collect()
     # (2) THE timed region: the same K steps with two pictures in flight (m355_set_pipeline_depth: consecutive decodes
     # alternate between two lanes; every step still runs the whole chain for one picture — here each step's SAO, the only
@@ -131,29 +133,78 @@ def main():
         dist.barrier()
     ctx.set_pipeline_depth(1)
 
-    with_upload = None
-    if args.with_upload and rank == 0:
-        for _ in range(4):                   # the three rotating staging arenas are allocated on first use
-            ctx.submit(pic)
+    # (3) a dependent chain: picture k is predicted from the pictures k-1 and k-2 (the same lists, uploaded once per frame
+    # assignment; frames rotate), decoded with the same number of pictures in flight — every decode waits for the SAO of its
+    # references (per-frame events in the library).  What a real P/B chain sees, next to the independent-picture headline.
+    chain = None
+    if not args.no_dependent_chain and rank == 0 and cfg["n_refs"] >= 1:
+        nr = cfg["n_refs"]
+        frames = [ctx.frame_create_for(pp) for _ in range(nr + 1)]
+        for i in range(nr):
+            ctx.frame_upload(frames[i + 1], synth.ref_planes(cfg["seed"] + 17 * i, int(pp["width"]), int(pp["height"]),
+                                                             int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
+        hs = []
+        saved = (pic.dst_frame, pic.ref_frames)
+        for i in range(nr + 1):
+            pic.dst_frame = frames[i]
+            pic.ref_frames = [frames[(i + 1 + k) % (nr + 1)] if k < nr else -1 for k in range(worklist.MAX_REF_FRAMES)]
+            hs.append(ctx.upload(pic))
+        pic.dst_frame, pic.ref_frames = saved
+        ctx.wait()
+        ctx.set_pipeline_depth(args.pipeline_depth)
+        for k in range(2 * (nr + 1)):
+            ctx.decode_resident(hs[k % (nr + 1)])
         ctx.wait()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.submit(pic)
+        for k in range(side_steps):
+            ctx.decode_resident(hs[k % (nr + 1)])
+        ctx.wait()
+        dtc = time.perf_counter() - t0
+        ctx.set_pipeline_depth(1)
+        for h2 in hs:
+            ctx.release(h2)
+        for f in frames:
+            ctx.frame_destroy(f)
+        chain = {"value": side_steps * n_ctbs / dtc, "unit": "CTB64/s", "ms_per_step": 1e3 * dtc / side_steps, "steps": side_steps,
+                 "note": "each picture references the %d decoded before it (decode waits for their SAO), %d lanes" % (nr, args.pipeline_depth)}
+
+    # (4) PCIe-inclusive: the lists are written into the library's pinned arena (m355_arena_begin; libm355synth copies them
+    # there with 16 threads, standing in for the parser's recorder threads), then validated, scheduled, copied to the device
+    # and decoded, every step.  "submit_only": the same with the lists already lying in the arenas (three rotate).
+    with_upload = None
+    if not args.no_with_upload and rank == 0:
+        ctx.set_pipeline_depth(args.pipeline_depth)
+        st = {}
+        for _ in range(4):                   # the three rotating arenas are allocated on first use
+            ctx.submit_in_place(pic, state=st)
+        ctx.wait()
+        t0 = time.perf_counter()
+        for _ in range(side_steps):
+            ctx.submit_in_place(pic, state=st)
         ctx.wait()
         dtu = time.perf_counter() - t0
         t0 = time.perf_counter()
-        hs = [ctx.upload(pic) for _ in range(5)]
+        for _ in range(side_steps):
+            ctx.submit_in_place(pic, state=st, refill=False)
         ctx.wait()
-        up_ms = 1e3 * (time.perf_counter() - t0) / 5
-        for h2 in hs:
-            ctx.release(h2)
+        dts = time.perf_counter() - t0
+        for _ in range(3):
+            ctx.submit(pic)
+        ctx.wait()
+        n_copy = max(1, side_steps // 4)
         t0 = time.perf_counter()
-        for _ in range(5):
-            c_pic, keep = pic.to_c()
-        marshal_ms = 1e3 * (time.perf_counter() - t0) / 5
+        for _ in range(n_copy):
+            ctx.submit(pic)                   # the copying entry (lists anywhere in host memory): marshals in Python every step
+        ctx.wait()
+        dtcopy = time.perf_counter() - t0
+        ctx.set_pipeline_depth(1)
+        c_pic, keep = pic.to_c()
         nbytes = sum(a.nbytes for a in keep)
-        with_upload = {"value": args.steps * n_ctbs / dtu, "unit": "CTB64/s", "ms_per_step": 1e3 * dtu / args.steps,
-                       "list_bytes_per_picture": int(nbytes), "upload_only_ms": up_ms, "python_marshal_ms": marshal_ms, "note": "per step: list validation + copy into a pinned staging arena (3 rotating, host work overlaps the previous picture on the GPU) + H2D + decode"}
+        with_upload = {"value": side_steps * n_ctbs / dtu, "unit": "CTB64/s", "ms_per_step": 1e3 * dtu / side_steps, "steps": side_steps,
+                       "list_bytes_per_picture": int(nbytes),
+                       "submit_only": {"value": side_steps * n_ctbs / dts, "ms_per_step": 1e3 * dts / side_steps},
+                       "copying_submit": {"value": n_copy * n_ctbs / dtcopy, "ms_per_step": 1e3 * dtcopy / n_copy},
+                       "note": "per step: lists written into the pinned arena (16 host threads) + validation + schedules + H2D + decode, %d pictures in flight; submit_only = without the writing; copying_submit = m355_submit_picture on lists elsewhere in host memory (incl. the Python marshalling of this harness)" % args.pipeline_depth}
     emitted = []
 
     def emit(sharded):
@@ -188,6 +239,8 @@ def main():
             out["tile_sharded"] = sharded
         if with_upload is not None:
             out["with_upload"] = with_upload
+        if chain is not None:
+            out["dependent_chain"] = chain
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, synth, worklist)
         sys.stdout.flush()
@@ -338,25 +391,31 @@ def cpu_baseline(cfg, synth, worklist):
         while time.perf_counter() - t0 < 2.5:
             fn(pic); n1 += 1
         rates[name] = n1 * len(pic.ctbs) / (time.perf_counter() - t0)
-    T = max(1, min(32, (os.cpu_count() or 1)))
-    counts = [0] * T
-    stop = time.perf_counter() + 8.0
+    def run_threads(T, seconds):
+        counts = [0] * T
+        stop = time.perf_counter() + seconds
 
-    def worker(i):
-        mypic = copy.copy(pic)                        # the drivers set ref_frames on the picture object
-        while time.perf_counter() < stop:
-            decode_once(mypic)
-            counts[i] += 1
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(T)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    out = {"value": sum(counts) * len(pic.ctbs) / dt, "unit": "CTB64/s", "cores": T, "kind": kind,
+        def worker(i):
+            mypic = copy.copy(pic)                        # the drivers set ref_frames on the picture object
+            while time.perf_counter() < stop:
+                decode_once(mypic)
+                counts[i] += 1
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(T)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return sum(counts), time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
+    T = max(1, min(32, ncpu))
+    n32, dt = run_threads(T, 8.0)
+    out = {"value": n32 * len(pic.ctbs) / dt, "unit": "CTB64/s", "cores": T, "kind": kind,
            "sample": "%d x (1920x1088 %d-bit picture of the same recipe, %d CTB64) through %s on %d threads" %
-                     (sum(counts), small["bit_depth"], len(pic.ctbs), what, T), "host_cores_available": os.cpu_count()}
+                     (n32, small["bit_depth"], len(pic.ctbs), what, T), "host_cores_available": ncpu}
+    if ncpu > T:
+        nall, dta = run_threads(ncpu, 8.0)                # the whole box: one picture stream per hardware thread
+        out["all_cores"] = {"value": nall * len(pic.ctbs) / dta, "cores": ncpu, "pictures": nall}
     out.update(rates)
     return out
 

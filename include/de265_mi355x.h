@@ -430,6 +430,21 @@ M355_API int m355_frame_hash(m355_ctx* ctx, int frame, int hash_type, m355_pictu
  * run_postprocessing_filters_sequential/_parallel (decctx.cc:1783/1811) for one picture. Asynchronous:
  * returns after the work is enqueued on the context's stream. */
 M355_API int m355_submit_picture(m355_ctx* ctx, const m355_picture* pic);
+/* Lists recorded IN PLACE: m355_arena_begin hands out, for the NEXT m355_submit_picture on this context, host pointers into
+ * the context's pinned staging arena with room for `caps` entries per list (the caller sizes them from the previous
+ * picture, say).  The parser's recorder threads write the lists there; the submitted m355_picture carries exactly those
+ * pointers (pic->rbs = the 4x4 bin's region; the four size bins live in their own regions caps->rb_bin[0..3], filled in by
+ * the call) and its real counts (<= the capacities): the submit then validates, derives its schedules and starts the
+ * host-to-device copy without copying a byte on the host.  It waits for the picture that used this arena last (three arenas
+ * rotate).  dst_frame / ref_frames / pp / counts are the caller's to fill in. */
+typedef struct m355_arena_caps {
+  int32_t n_slices, n_ctbs, n_cus, n_tus, n_pbs, n_wts, n_ibs;
+  int32_t n_rbs[4];
+  uint32_t n_coeffs, n_pcm;
+  int32_t scaling;                 /* 1: room for the scaling-factor tables */
+  m355_rb* rb_bin[4];              /* out: where the residual blocks of each size go */
+} m355_arena_caps;
+M355_API int m355_arena_begin(m355_ctx* ctx, m355_arena_caps* caps, m355_picture* pic);
 /* Blocks until all submitted work finished; returns M355_ERR_TIMEOUT if a device spin bound hit. */
 M355_API int m355_wait(m355_ctx* ctx);
 

@@ -28,6 +28,13 @@ class PictureHash(ctypes.Structure):
     _fields_ = [("md5", (ctypes.c_uint8 * 16) * 3), ("crc", ctypes.c_uint16 * 3), ("checksum", ctypes.c_uint32 * 3)]
 
 
+class ArenaCaps(ctypes.Structure):
+    """m355_arena_caps (include/de265_mi355x.h)"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_slices", "n_ctbs", "n_cus", "n_tus", "n_pbs", "n_wts", "n_ibs")] + \
+               [("n_rbs", ctypes.c_int32 * 4), ("n_coeffs", ctypes.c_uint32), ("n_pcm", ctypes.c_uint32), ("scaling", ctypes.c_int32),
+                ("rb_bin", ctypes.c_void_p * 4)]
+
+
 class Library:
     """A loaded libde265_mi355x.so with typed entry points."""
 
@@ -51,6 +58,10 @@ class Library:
         L.m355_frame_upload.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_download.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_fill.argtypes = [vp, i, i, i]
+        L.m355_arena_begin.argtypes = [vp, vp, vp]
+        L.m355_host_alloc.argtypes = [ctypes.c_size_t]
+        L.m355_host_alloc.restype = vp
+        L.m355_host_free.argtypes = [vp]
         L.m355_frame_hash.argtypes = [vp, i, i, vp]
         L.m355_submit_picture.argtypes = [vp, vp]
         L.m355_wait.argtypes = [vp]
@@ -153,6 +164,43 @@ class Context:
         c, keep = pic.to_c()
         self.L.check(self.L.lib.m355_submit_picture(self.h, ctypes.addressof(c)))
         del keep
+
+    def submit_in_place(self, src_pic, slack=1.0, fill_threads=16, refill=True, state=None):
+        """The in-place path: m355_arena_begin (capacities = the picture's counts x slack) -> the lists are written into the
+        pinned arena by libm355synth's m355_synth_fill_arena (standing in for recorder threads) -> m355_submit_picture on
+        those pointers (no host copy inside the library).  refill=False re-submits what the arena still holds from an
+        earlier call with the same capacities (the three arenas rotate): the library's own share of the work alone.
+        `state` caches the marshalled source picture between calls."""
+        from . import synth
+        state = state if state is not None else {}
+        if "src" not in state:
+            src, state["keep"] = src_pic.to_c()
+            caps = ArenaCaps()
+            for n in ("n_slices", "n_ctbs", "n_cus", "n_tus", "n_pbs", "n_wts", "n_ibs"):
+                setattr(caps, n, int(getattr(src, n)) if n in ("n_slices", "n_ctbs") else int(getattr(src, n) * slack) + 1)
+            for b in range(4):
+                caps.n_rbs[b] = int(src.rb_count[b] * slack) + 1
+            caps.n_coeffs = int(src.n_coeffs * slack) + 1
+            caps.n_pcm = int(src.n_pcm * slack) + 1
+            caps.scaling = 1 if src.scaling_factors else 0
+            state.update(src=src, caps=caps, dst=worklist.CPicture(), lib=synth._lib(), a_src=ctypes.addressof(src))
+            state["a_caps"], state["a_dst"] = ctypes.addressof(caps), ctypes.addressof(state["dst"])
+        src, dst, lib = state["src"], state["dst"], state["lib"]
+        src.dst_frame = src_pic.dst_frame
+        rc = self.L.lib.m355_arena_begin(self.h, state["a_caps"], state["a_dst"])
+        if rc:
+            self.L.check(rc)
+        if refill or not state.get("filled", 0) >= 3:
+            lib.m355_synth_fill_arena(state["a_src"], state["a_caps"], state["a_dst"], fill_threads)
+            state["filled"] = state.get("filled", 0) + 1
+        else:
+            lib.m355_synth_fill_arena_header(state["a_src"], state["a_dst"])
+        dst.dst_frame = src.dst_frame
+        ctypes.memmove(dst.ref_frames, src.ref_frames, 4 * worklist.MAX_REF_FRAMES)
+        rc = self.L.lib.m355_submit_picture(self.h, state["a_dst"])
+        if rc:
+            self.L.check(rc)
+        return state
 
     def wait(self):
         self.L.check(self.L.lib.m355_wait(self.h))

@@ -43,7 +43,7 @@ struct DevPic {
   const m355_tu* tus;
   const m355_pb* pbs;
   const m355_wt* wts;
-  const m355_rb* rbs;
+  const m355_rb* rb_bin[4];         /* residual blocks of 4x4, 8x8, 16x16, 32x32 (rb_count[] entries each) */
   const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime.hip intra_schedule) */
   const uint16_t* ib_level;         /* level of ibs[i] inside its CTB */
   int intra_dense;                  /* k_intra variant: 1 = intra picture (12-wave workgroups, residuals in LDS), 0 = a handful of blocks per CTB */
@@ -73,7 +73,12 @@ struct DevPic {
                                        columns of all CTB columns [ctbX][row >> 1], then the bottom rows of all CTB rows [ctbY][col >> 1] */
   uint32_t edge_col_ofs[3], edge_row_ofs[3];   /* first granule of each component's column / row arrays */
   uint32_t* ticket;                 /* work counter */
-  uint32_t* timeout;                /* set when a spin bound is exceeded */
+  uint32_t* timeout;                /* [0] set when a spin bound is exceeded; [1] this decode's lists were rejected by k_validate
+                                       (every kernel of the decode returns at once); [2] lowest rejected (list << 28 | record), sticky
+                                       until m355_wait reports it */
+  int device_validate;              /* lists recorded in place: checked on the device (k_validate) instead of on the host */
+  int n_wts;
+  uint32_t n_coeffs, n_pcm, res_len, ref_valid;   /* list lengths the records index into; bit s of ref_valid = ref_frames[s] is a frame */
   uint32_t epoch;                   /* value meaning "done" for this submission */
   const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks: first the n_intra_free CTBs that wait
                                        for nobody, then the others in decode order */
@@ -117,9 +122,13 @@ __host__ __device__ inline bool m355_pb_is_edge(const m355_pb& pb, int width, in
   return false;
 }
 
+/* first statement of every kernel of a decode: a picture whose lists k_validate rejected is never acted upon */
+#define M355_GATE(p) do { if ((p).timeout[1] != 0u) return; } while (0)
+
 enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
 
 /* ---- launchers (each in its stage's .hip); all asynchronous on `st` ---- */
+void m355_launch_validate(const DevPic& p, hipStream_t st);   /* device-side validation of the work lists (k_meta.hip) */
 void m355_launch_meta(const DevPic& p, hipStream_t st);
 void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for k_inter */
 void m355_launch_meta_planes(const DevPic& p, hipStream_t st);   /* planes for intra / deblock / SAO */

@@ -70,6 +70,7 @@ __device__ int d_boundary_strength(const DevPic& p, int x4, int y4, bool vertica
 template <class PIX, bool VERTICAL>
 __global__ void __launch_bounds__(256) k_deblock(DevPic p)
 {
+  M355_GATE(p);
   /* thread -> edge unit on the 8x8 luma grid: vertical edges at even x4, horizontal at even y4 */
   const int nx = VERTICAL ? (p.w4 + 1) / 2 : p.w4;
   const int ny = VERTICAL ? p.h4 : (p.h4 + 1) / 2;

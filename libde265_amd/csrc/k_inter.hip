@@ -42,6 +42,7 @@ __constant__ int8_t c_epel_taps[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4,
 template <class PIX>
 __global__ void __launch_bounds__(256) k_inter_generic(DevPic p)
 {
+  M355_GATE(p);
   __shared__ uint16_t s_win[4][WIN_ROWS * WIN_PITCH];
   __shared__ int16_t s_tmp[4][WIN_ROWS * 16];
 
@@ -506,6 +507,7 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
 template <class PIX, bool BIAS>
 __global__ void __launch_bounds__(256, M355_INTER_WAVES) k_inter_jobs(DevPic p, int nblk_edge8, int nblk_bi8)
 {
+  M355_GATE(p);
   __shared__ unsigned s_qt[4 * QT_STRIDE];
   __shared__ unsigned s_et[8 * ET_STRIDE];
   /* the reference-frame table (plane pointers / pitches per DPB slot) in LDS: a job looks its references up

@@ -89,6 +89,7 @@ __device__ __forceinline__ m355_granule* d_edge_row(const DevPic& p, int c, int 
 template <class PIX, int CF, int NW>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p, int work_n)
 {
+  M355_GATE(p);
   constexpr bool RES_LDS = NW >= 12;
   /* per component: halo (top row x = -1 .. 2*cw-1 at index x+1; left column) as 32-bit words: a sample, or
      HALO_NOT_READY while the neighbour CTB has not published it; body rows */
@@ -541,7 +542,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     }   /* levels in the batch */
   }   /* 64-record batches */
 #ifdef M355_X_TIMING
-  if (lane == 0 && wv == 0) for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)(p.timeout + 2) + i, (unsigned long long)tT[i]);
+  if (lane == 0 && wv == 0) for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)(p.timeout + 16) + i, (unsigned long long)tT[i]);
 #endif
 #undef SYNC_CTB
 }

@@ -10,6 +10,7 @@
 /* one thread per CU: CU-index plane, per-CU edge decisions (deblock.cc:172-210), PB edges */
 __global__ void __launch_bounds__(256) k_meta_cu(DevPic p)
 {
+  M355_GATE(p);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n_cus) return;
   const m355_cu cu = p.cus[i];
@@ -70,6 +71,7 @@ __global__ void __launch_bounds__(256) k_meta_cu(DevPic p)
 /* one thread per transform-tree leaf: transform edges + cbf_luma (deblock.cc:33-63, slice.cc:2958) */
 __global__ void __launch_bounds__(256) k_meta_tu(DevPic p)
 {
+  M355_GATE(p);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n_tus) return;
   const m355_tu tu = p.tus[i];
@@ -104,6 +106,7 @@ __global__ void __launch_bounds__(256) k_meta_tu(DevPic p)
  * adjacent; three ranges (one-list, bi-predicted, picture-edge jobs), each in PB order. */
 __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
 {
+  M355_GATE(p);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool active = i < p.n_pbs;
@@ -176,6 +179,7 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
  * why the centre CTB has a bit too.  k_sao then needs no dependent global loads per border sample. */
 __global__ void __launch_bounds__(256) k_meta_sao(DevPic p)
 {
+  M355_GATE(p);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
   if (i >= p.nCtb * nc) return;
@@ -224,4 +228,70 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
 {
   m355_launch_meta_planes(p, st);
   m355_launch_meta_jobs(p, st);
+}
+
+
+/* ---- device-side validation of work lists that were recorded in place (m355_arena_begin): the record checks of the host's
+ * validate() (runtime.hip), one thread per record over the concatenation cus | tus | pbs | wts | rbs (4 bins) | ibs.  A rejected
+ * record raises the decode's gate word (every later kernel of the decode returns at once: bad lists are never acted upon) and
+ * leaves (list << 28 | record) in the sticky word that m355_wait reports.  (The CTB table and each CTB's intra block geometry
+ * are checked on the host: its schedules index by them.) ---- */
+__global__ void __launch_bounds__(256) k_validate(DevPic p, uint32_t n_total)
+{
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= n_total) return;
+  const m355_pic_params& pp = p.pp;
+  const uint32_t cnt[9] = {(uint32_t)p.n_cus, (uint32_t)p.n_tus, (uint32_t)p.n_pbs, (uint32_t)p.n_wts, (uint32_t)p.rb_count[0], (uint32_t)p.rb_count[1],
+                           (uint32_t)p.rb_count[2], (uint32_t)p.rb_count[3], (uint32_t)p.n_ibs};
+  uint32_t i = g;
+  int q = 0;
+  while (q < 8 && i >= cnt[q]) { i -= cnt[q]; q++; }
+  bool bad = false;
+  const int W = pp.width, H = pp.height;
+  if (q == 0) {
+    const m355_cu cu = p.cus[i];
+    bad = cu.log2_size < pp.log2_min_cb_size || cu.log2_size > pp.log2_ctb_size || cu.x >= W || cu.y >= H || cu.pred_mode > 2 || cu.part_mode > 7;
+  } else if (q == 1) {
+    const m355_tu tu = p.tus[i];
+    bad = tu.log2_size < 2 || tu.log2_size > 6 || tu.x >= W || tu.y >= H;
+  } else if (q == 2) {
+    const m355_pb pb = p.pbs[i];
+    bad = pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3) || pb.x + pb.w > W || pb.y + pb.h > H || !(pb.flags & (M355_PBF_MC_L0 | M355_PBF_MC_L1));
+    for (int l = 0; l < 2 && !bad; l++) {
+      if (!(pb.flags & (M355_PBF_MC_L0 << l))) continue;
+      if (!(pb.flags & (M355_PBF_FILL_L0 << l)) && (pb.ref_slot[l] < 0 || pb.ref_slot[l] >= M355_MAX_REF_FRAMES || !((p.ref_valid >> pb.ref_slot[l]) & 1u))) bad = true;
+      if ((pb.flags & M355_PBF_WEIGHTED) && pb.wt_idx[l] >= p.n_wts) bad = true;
+    }
+  } else if (q == 3) {
+    const m355_wt wt = p.wts[i];
+    bad = wt.log2wd_luma < 1 || wt.log2wd_luma > 31 || (pp.chroma_format_idc && (wt.log2wd_chroma < 1 || wt.log2wd_chroma > 31));
+  } else if (q <= 7) {
+    const int sb = q - 4;
+    const m355_rb rb = p.rb_bin[sb][i];
+    const int n = 1 << (sb + 2);
+    const int Wc = rb.cidx ? W / p.sw : W, Hc = rb.cidx ? H / p.sh : H;
+    bad = rb.log2_size != sb + 2 || rb.cidx > 2 || rb.kind > 3 || rb.x + n > Wc || rb.y + n > Hc ||
+          (unsigned long long)rb.coeff_ofs + rb.ncoeff > p.n_coeffs ||
+          ((rb.flags & M355_RBF_DEFERRED) && (unsigned long long)rb.res_ofs + (unsigned)(n * n) > p.res_len) ||
+          ((pp.flags & M355_PF_SCALING_LIST) && (rb.matrix_id & 7) > 5) || (rb.kind == M355_RK_DST && sb != 0);
+  } else {
+    const m355_ib ib = p.ibs[i];          /* (the sorted copy: same records as the caller's) */
+    const int n = 1 << (ib.log2_size & 7);
+    const int Wc = ib.cidx ? W / p.sw : W, Hc = ib.cidx ? H / p.sh : H;
+    bad = ib.log2_size < 2 || ib.log2_size > 5 || ib.cidx > 2 || ib.mode > 34 || ib.x + n > Wc || ib.y + n > Hc ||
+          ((ib.flags & M355_IBF_HAS_RESIDUAL) && (unsigned long long)ib.res_ofs + (unsigned)(n * n) > p.res_len) ||
+          ((ib.flags & M355_IBF_PCM) && (unsigned long long)ib.res_ofs + (unsigned)(n * n) > p.n_pcm);
+  }
+  if (bad) {
+    const int list = q < 4 ? q + 1 : (q < 8 ? 5 : 6);       /* numbering of the host's messages: cu tu pb weight rb ib = 1..6 */
+    atomicOr(&p.timeout[1], 1u);
+    atomicMin(&p.timeout[2], ((uint32_t)list << 28) | (i < 0x0FFFFFFFu ? i : 0x0FFFFFFFu));
+  }
+}
+
+void m355_launch_validate(const DevPic& p, hipStream_t st)
+{
+  const uint64_t n = (uint64_t)p.n_cus + p.n_tus + p.n_pbs + p.n_wts + p.rb_count[0] + p.rb_count[1] + p.rb_count[2] + p.rb_count[3] + p.n_ibs;
+  if (!n) return;
+  hipLaunchKernelGGL(k_validate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, (uint32_t)n);
 }

@@ -215,7 +215,7 @@ __device__ __forceinline__ m355_rb d_rb_idle(int log2)
 }
 
 template <int LOG2, class PIX>
-__device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, int rb_n, int group, uint32_t* smem)
+__device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb* rbs, int rb_n, int group, uint32_t* smem)
 {
   constexpr int NT = 1 << LOG2;
   constexpr int BPW = 64 / NT;           /* blocks per wave */
@@ -230,7 +230,7 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
   uint32_t* cfp = smem + (wave * BPW + b) * BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
 
   m355_rb rb = d_rb_idle(LOG2);
-  if (active) rb = p.rbs[rb_base + tbi];
+  if (active) rb = rbs[tbi];
   const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
 
   /* the lane's destination row (prediction samples the residual is added to) is requested BEFORE the transform: its
@@ -270,7 +270,7 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
     bool ccp = v != 0 && tbi - back >= 0;
     m355_rb rl = d_rb_idle(LOG2);
     if (ccp) {
-      rl = p.rbs[rb_base + tbi - back];
+      rl = rbs[tbi - back];
       if (rl.cidx != 0) { ccp = false; rl = d_rb_idle(LOG2); }
     }
     if (__any(ccp)) {
@@ -322,13 +322,13 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, int rb_base, i
 template <class PIX>
 __global__ void __launch_bounds__(256) k_residual(DevPic p, int ng5, int ng4, int ng3)
 {
+  M355_GATE(p);
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[RES_LDS_DWORDS];
   const int g = blockIdx.x;
-  const int base3 = p.rb_count[0], base4 = base3 + p.rb_count[1], base5 = base4 + p.rb_count[2];
-  if (g < ng5) d_residual_group<5, PIX>(p, base5, p.rb_count[3], g, s_buf);
-  else if (g < ng5 + ng4) d_residual_group<4, PIX>(p, base4, p.rb_count[2], g - ng5, s_buf);
-  else if (g < ng5 + ng4 + ng3) d_residual_group<3, PIX>(p, base3, p.rb_count[1], g - ng5 - ng4, s_buf);
-  else d_residual_group<2, PIX>(p, 0, p.rb_count[0], g - ng5 - ng4 - ng3, s_buf);
+  if (g < ng5) d_residual_group<5, PIX>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
+  else if (g < ng5 + ng4) d_residual_group<4, PIX>(p, p.rb_bin[2], p.rb_count[2], g - ng5, s_buf);
+  else if (g < ng5 + ng4 + ng3) d_residual_group<3, PIX>(p, p.rb_bin[1], p.rb_count[1], g - ng5 - ng4, s_buf);
+  else d_residual_group<2, PIX>(p, p.rb_bin[0], p.rb_count[0], g - ng5 - ng4 - ng3, s_buf);
 }
 
 void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st)

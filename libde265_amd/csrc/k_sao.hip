@@ -99,6 +99,7 @@ __device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint3
 template <class PIX>
 __global__ void __launch_bounds__(256) k_sao(DevPic p)
 {
+  M355_GATE(p);
   /* one thread = a 4x4 sample block (always inside one CTB: component CTB sizes are >= 8 and planes are
      multiples of 4 wide; the row count is clipped at the picture bottom).  A wave covers 64 x 16 samples
      = 16 x 4 threads, i.e. it stays inside ONE 64x64 luma CTB, so the SAO type / edge class branches

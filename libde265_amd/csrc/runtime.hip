@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -109,6 +111,10 @@ struct Resident {
   hipEvent_t ev_done = nullptr; /* last decode of these lists finished: the arenas may be overwritten */
   bool done_pending = false;
   bool fresh = false;          /* uploaded and not decoded since: nothing in flight reads its reference table */
+  bool arena = false;          /* m355_arena_begin handed out list pointers into `host`: the next upload of lists that sit there copies nothing */
+  m355_arena_caps caps;        /* ... with room for this many entries */
+  std::vector<uint32_t> job_cnt;   /* per 256-PB chunk and range: inter jobs (filled by the validation sweep) */
+  bool device_validate = false;    /* the record checks of these lists run on the device (k_validate) */
 };
 
 /* Everything ONE picture in flight writes: streams, working planes, metadata / job / residual scratch.  The context's
@@ -127,6 +133,7 @@ struct Lane {
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
   size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
+  size_t gate_used = 0;        /* a device-validated decode ran on this lane: its gate word must be cleared before the next decode */
 };
 
 struct m355_ctx {
@@ -149,6 +156,7 @@ struct m355_ctx {
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
   size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
+  size_t gate_used = 0;
   uint32_t epoch = 0;
   int stages = M355_STAGE_ALL;
   int shard_rank = 0, shard_n = 0;   /* shard_n == 0: sharding off */
@@ -159,7 +167,7 @@ struct m355_ctx {
 };
 
 #define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
-  X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
+  X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao) X(gate_used)
 static void select_lane(m355_ctx* c, int lane)
 {
   if (lane == c->active) return;
@@ -181,6 +189,7 @@ static int lane_create(m355_ctx* c, Lane& l)
   HIPCHK(hipMalloc(&l.timeout, 128));
   HIPCHK(hipMemsetAsync(l.ticket, 0, 64, l.stream));
   HIPCHK(hipMemsetAsync(l.timeout, 0, 128, l.stream));
+  HIPCHK(hipMemsetAsync(l.timeout + 2, 0xFF, 4, l.stream));     /* lowest rejected record: none */
   HIPCHK(hipStreamSynchronize(l.stream));
   return M355_OK;
 }
@@ -376,6 +385,8 @@ int m355_frame_create(m355_ctx* c, int width, int height, int cf, int bdl, int b
   frame_geometry(f, width, height, cf, bdl, bdc);
   int rc = frame_alloc(f, c->stream);
   if (rc) { frame_free(f); return -rc; }
+  /* the zero fill is this frame's first write: whichever lane touches the frame next orders itself after it */
+  if (hipEventCreateWithFlags(&f.ev_wr, hipEventDisableTiming) == hipSuccess) { hipEventRecord(f.ev_wr, c->stream); f.wr_pending = true; }
   return idx;
 }
 static Frame* get_frame(m355_ctx* c, int h)
@@ -503,21 +514,80 @@ static int host_threads()
   static int n = 0;
   if (!n) {
     const unsigned hc = std::thread::hardware_concurrency();
-    n = hc >= 16 ? 8 : (hc >= 4 ? 4 : 1);
+    n = hc >= 128 ? 32 : (hc >= 32 ? 16 : (hc >= 16 ? 8 : (hc >= 4 ? 4 : 1)));
     if (const char* e = getenv("M355_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n = v; }   /* validation / staging threads per submit */
   }
   return n;
 }
+/* persistent workers: a submit runs several short parallel phases (validation, copies, schedules); creating threads for each
+   of them costs more than the phases themselves */
+struct HostPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  const std::function<void(int)>* job = nullptr;
+  int n_parts = 0, next = 0, pending = 0;
+  unsigned long long gen = 0;
+  bool stop = false;
+  explicit HostPool(int workers)
+  {
+    for (int i = 0; i < workers; i++) th.emplace_back([this]() { work(); });
+  }
+  ~HostPool()
+  {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv_go.notify_all();
+    for (auto& t : th) t.join();
+  }
+  void work()
+  {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_go.wait(lk, [&]() { return stop || (gen != seen && next < n_parts); });
+      if (stop) return;
+      while (next < n_parts) {
+        const int part = next++;
+        const std::function<void(int)>* f = job;
+        lk.unlock();
+        (*f)(part);
+        lk.lock();
+        if (--pending == 0) cv_done.notify_all();
+      }
+      seen = gen;
+    }
+  }
+  void run(int parts, const std::function<void(int)>& f)      /* f(0 .. parts-1); the caller works too */
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    job = &f; n_parts = parts; next = 0; pending = parts; gen++;
+    cv_go.notify_all();
+    while (next < n_parts) {
+      const int part = next++;
+      lk.unlock();
+      f(part);
+      lk.lock();
+      --pending;
+    }
+    cv_done.wait(lk, [&]() { return pending == 0; });
+    job = nullptr; n_parts = 0;
+  }
+};
+static HostPool& host_pool()
+{
+  static HostPool* p = new HostPool(host_threads() - 1);    /* lives until process exit (worker threads must not outlive it) */
+  return *p;
+}
+static std::mutex g_pool_mu;                                 /* one parallel phase at a time (contexts on several threads share the pool) */
 template <class F> static void parallel_ranges(size_t n, size_t min_per_thread, F f)   /* f(begin, end) */
 {
   int T = host_threads();
   if (n < 2 * min_per_thread) T = 1;
   else if (n / min_per_thread < (size_t)T) T = (int)(n / min_per_thread);
   if (T <= 1) { f((size_t)0, n); return; }
-  std::vector<std::thread> th;
-  for (int t = 1; t < T; t++) th.emplace_back([=]() { f(n * t / T, n * (t + 1) / T); });
-  f((size_t)0, n / T);
-  for (auto& x : th) x.join();
+  const std::function<void(int)> part = [&](int t) { f(n * (size_t)t / T, n * ((size_t)t + 1) / T); };
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  host_pool().run(T, part);
 }
 /* check(i) -> nullptr or a message; the LOWEST failing index is reported as "<what> <i>: <message>" */
 template <class F> static int check_all(const char* what, size_t n, F check)
@@ -540,7 +610,7 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes)
 }
 } /* extern "C++" */
 
-static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
+static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, uint32_t* job_cnt, bool records_on_device, int* ctbW_out, int* ctbH_out)
 {
   const m355_pic_params& pp = pic->pp;
   if (pp.width <= 0 || pp.height <= 0 || pp.chroma_format_idc > 3) return fail(M355_ERR_INVALID, "bad picture size / chroma format");
@@ -603,7 +673,7 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
     const m355_pb& pb = pic->pbs[i];
     if (pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3) || pb.x + pb.w > pp.width || pb.y + pb.h > pp.height) return "geometry";
     if (!(pb.flags & (M355_PBF_MC_L0 | M355_PBF_MC_L1))) return "no list selected";
-    for (int l = 0; l < 2; l++) {
+    for (int l = 0; l < 2 && !records_on_device; l++) {
       if (!(pb.flags & (M355_PBF_MC_L0 << l))) continue;
       if (!(pb.flags & (M355_PBF_FILL_L0 << l)) && (pb.ref_slot[l] < 0 || pb.ref_slot[l] >= M355_MAX_REF_FRAMES || pic->ref_frames[pb.ref_slot[l]] < 0)) return "reference slot invalid";
       if ((pb.flags & M355_PBF_WEIGHTED) && pb.wt_idx[l] >= pic->n_wts) return "weight index";
@@ -613,9 +683,12 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
   auto chk_wt = [&](size_t i) -> const char* {
     return (pic->wts[i].log2wd_luma < 1 || pic->wts[i].log2wd_luma > 31 || (pp.chroma_format_idc && (pic->wts[i].log2wd_chroma < 1 || pic->wts[i].log2wd_chroma > 31))) ? "log2WD out of range" : nullptr;
   };
+  /* the four size bins: consecutive in rbs[], or (lists recorded in place) in the regions m355_arena_begin handed out */
+  const m355_rb* rb_bin[4];
+  for (int b = 0; b < 4; b++) rb_bin[b] = rb_bin_in ? rb_bin_in[b] : pic->rbs + (b ? bin_end[b - 1] : 0);
   auto chk_rb = [&](size_t k) -> const char* {
-    const m355_rb& rb = pic->rbs[k];
     const int s = k < bin_end[0] ? 0 : (k < bin_end[1] ? 1 : (k < bin_end[2] ? 2 : 3));
+    const m355_rb& rb = rb_bin[s][k - (s ? bin_end[s - 1] : 0)];
     const int n = 1 << (s + 2);
     const int W = rb.cidx ? pp.width / sw : pp.width, H = rb.cidx ? pp.height / sh : pp.height;
     if (rb.log2_size != s + 2 || rb.cidx > 2 || rb.kind > 3 || rb.x + n > W || rb.y + n > H) return "malformed";
@@ -635,20 +708,53 @@ static int validate(const m355_picture* pic, int* ctbW_out, int* ctbH_out)
     return nullptr;
   };
   const char* const names[7] = {"ctb", "cu", "tu", "pb", "weight", "rb", "ib"};
-  const size_t cnts[7] = {(size_t)pic->n_ctbs, (size_t)pic->n_cus, (size_t)pic->n_tus, (size_t)pic->n_pbs, (size_t)pic->n_wts, nrb, (size_t)pic->n_ibs};
+  /* records_on_device: only what the host's own schedules index by is checked here — the CTB table with each CTB's intra blocks,
+     and the PB sizes the job counts are made of; every record check runs in k_validate before any kernel acts on the lists */
+  const size_t cnts[7] = {(size_t)pic->n_ctbs, records_on_device ? 0 : (size_t)pic->n_cus, records_on_device ? 0 : (size_t)pic->n_tus, (size_t)pic->n_pbs,
+                          records_on_device ? 0 : (size_t)pic->n_wts, records_on_device ? 0 : nrb, records_on_device ? 0 : (size_t)pic->n_ibs};
   size_t ofs[8];
   ofs[0] = 0;
   for (int q = 0; q < 7; q++) ofs[q + 1] = ofs[q] + cnts[q];
   std::atomic<size_t> first(ofs[7]);
   std::atomic<const char*> first_msg(nullptr);
   std::mutex mu;
-  parallel_ranges(ofs[7], 65536, [&](size_t b, size_t e) {
-    for (size_t g = b; g < e && g < first.load(std::memory_order_relaxed); g++) {
-      int q = 0;
-      while (g >= ofs[q + 1]) q++;
-      const size_t i = g - ofs[q];
-      const char* m = q == 0 ? chk_ctb(i) : q == 1 ? chk_cu(i) : q == 2 ? chk_tu(i) : q == 3 ? chk_pb(i) : q == 4 ? chk_wt(i) : q == 5 ? chk_rb(i) : chk_ib(i);
-      if (m) { std::lock_guard<std::mutex> gd(mu); if (g < first.load()) { first.store(g); first_msg.store(m); } return; }
+  parallel_ranges(ofs[7], 8192, [&](size_t b, size_t e) {
+    /* the range cut by list: one tight loop per list (the compiler sees ONE check function per loop) */
+    for (int q = 0; q < 7; q++) {
+      const size_t lo = std::max(b, ofs[q]), hi = std::min(e, ofs[q + 1]);
+      if (lo >= hi || lo >= first.load(std::memory_order_relaxed)) continue;
+      size_t bad = hi;
+      const char* m = nullptr;
+      const size_t base = ofs[q];
+#define SWEEP(chk) for (size_t g = lo; g < hi; g++) if ((m = chk(g - base)) != nullptr) { bad = g; break; }
+      switch (q) {
+        case 0: SWEEP(chk_ctb) break;
+        case 1: SWEEP(chk_cu) break;
+        case 2: SWEEP(chk_tu) break;
+        case 3: {
+          /* with each record in the cache: its share of the inter job counts, per 256-PB chunk (= one k_meta_pb workgroup) and
+             range (one list / two lists / picture-edge windows); a thread's partial sums are flushed once per chunk */
+          uint32_t acc[3] = {0, 0, 0};
+          size_t chunk = (lo - base) >> 8;
+          auto flush = [&]() { for (int k = 0; k < 3; k++) if (acc[k]) { __atomic_fetch_add(&job_cnt[chunk * 3 + k], acc[k], __ATOMIC_RELAXED); acc[k] = 0; } };
+          for (size_t g = lo; g < hi; g++) {
+            const size_t i = g - base;
+            if ((m = chk_pb(i)) != nullptr) { bad = g; break; }
+            if ((i >> 8) != chunk) { flush(); chunk = i >> 8; }
+            const m355_pb& pb = pic->pbs[i];
+            int cls = 2;
+            if (!m355_pb_is_edge(pb, pp.width, pp.chroma_format_idc)) cls = ((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0;
+            acc[cls] += (uint32_t)(pb.w >> 2) * ((pb.h + 7) >> 3);
+          }
+          flush();
+          break;
+        }
+        case 4: SWEEP(chk_wt) break;
+        case 5: SWEEP(chk_rb) break;
+        default: SWEEP(chk_ib) break;
+      }
+#undef SWEEP
+      if (bad < hi) { std::lock_guard<std::mutex> gd(mu); if (bad < first.load()) { first.store(bad); first_msg.store(m); } return; }
     }
   });
   if (first.load() < ofs[7]) {
@@ -672,27 +778,32 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
   const int nCtb = ctbW * ctbH;
   std::vector<uint8_t> touch(nCtb, 0), need(nCtb, 0);
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
-  for (int c = 0; c < nCtb; c++) {
-    const m355_ctb& ctb = pic->ctbs[c];
-    const int cx = c % ctbW, cy = c / ctbW;
-    for (uint32_t k = 0; k < ctb.ib_count; k++) {
-      const m355_ib& ib = pic->ibs[ctb.ib_start + k];
-      const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
-      const int cw = (1 << pp.log2_ctb_size) >> csw, ch = (1 << pp.log2_ctb_size) >> csh;
-      const int lx = ib.x - ((cx << pp.log2_ctb_size) >> csw), ly = ib.y - ((cy << pp.log2_ctb_size) >> csh);
-      const int n = 1 << ib.log2_size;
-      if (lx + n == cw) touch[c] |= 1;
-      if (ly + n == ch) touch[c] |= 2;
-      if (lx + n == cw && ly + n == ch) touch[c] |= 4;
-      if (ib.flags & M355_IBF_PCM) continue;              /* raw blocks read no neighbours */
-      if (lx == 0) need[c] |= 1;                           /* L  */
-      if (lx == 0 && ly == 0) need[c] |= 2;                /* TL */
-      if (ly == 0) need[c] |= 4;                           /* T  */
-      if (ly == 0 && lx + 2 * n > cw) need[c] |= 8;        /* TR */
+  parallel_ranges((size_t)nCtb, 512, [&](size_t cb, size_t ce) {
+    for (size_t c = cb; c < ce; c++) {
+      const m355_ctb& ctb = pic->ctbs[c];
+      const int cx = (int)c % ctbW, cy = (int)c / ctbW;
+      uint8_t t = 0, n_ = 0;
+      for (uint32_t k = 0; k < ctb.ib_count; k++) {
+        const m355_ib& ib = pic->ibs[ctb.ib_start + k];
+        const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
+        const int cw = (1 << pp.log2_ctb_size) >> csw, ch = (1 << pp.log2_ctb_size) >> csh;
+        const int lx = ib.x - ((cx << pp.log2_ctb_size) >> csw), ly = ib.y - ((cy << pp.log2_ctb_size) >> csh);
+        const int n = 1 << ib.log2_size;
+        if (lx + n == cw) t |= 1;
+        if (ly + n == ch) t |= 2;
+        if (lx + n == cw && ly + n == ch) t |= 4;
+        if (ib.flags & M355_IBF_PCM) continue;              /* raw blocks read no neighbours */
+        if (lx == 0) n_ |= 1;                                /* L  */
+        if (lx == 0 && ly == 0) n_ |= 2;                     /* TL */
+        if (ly == 0) n_ |= 4;                                /* T  */
+        if (ly == 0 && lx + 2 * n > cw) n_ |= 8;             /* TR */
+      }
+      touch[c] = t; need[c] = n_; dep[c] = 0;
     }
-  }
-  for (int c = 0; c < nCtb; c++) dep[c] = 0;
+  });
+  /* serial and short: one pass over the CTBs (the "somebody reads ours" bit lands on a neighbour) */
   for (int c = 0; c < nCtb; c++) {
+    if (!need[c]) continue;
     const int cx = c % ctbW, cy = c / ctbW;
     const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
     const uint8_t tbit[4] = {1, 4, 2, 2};                   /* what the neighbour must touch on its side */
@@ -703,7 +814,7 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
       if (tile_id[nb] != tile_id[c]) continue;             /* never read across tiles (intrapred.h:499-508) */
       if (((need[c] >> n) & 1) && (touch[nb] & tbit[n])) {
         dep[c] |= (uint8_t)(1 << n);
-        dep[nb] |= 16;                                     /* somebody waits for nb: it must publish */
+        dep[nb] |= 16;                                     /* somebody reads nb's output */
       }
     }
   }
@@ -792,49 +903,118 @@ static void halo_layout(const m355_pic_params& pp, HaloLayout& h)
   h.n_units = 2 * h.n_vb * h4 + 2 * h.n_hb * w4;
 }
 
+struct Seg { const void* src; size_t bytes; size_t ofs; };
+struct Lay {
+  Seg seg[32];
+  int ns;
+  size_t total;
+  int i_sl, i_ct, i_cu, i_tu, i_pb, i_wt, i_rb[4], i_ibin, i_ib, i_il, i_co, i_pc, i_sc, i_ts, i_rs, i_ti, i_iw, i_dp, i_jb, i_ow;
+};
+static void caps_of(const m355_picture* pic, m355_arena_caps& k)
+{
+  memset(&k, 0, sizeof(k));
+  k.n_slices = pic->n_slices; k.n_ctbs = pic->n_ctbs; k.n_cus = pic->n_cus; k.n_tus = pic->n_tus; k.n_pbs = pic->n_pbs; k.n_wts = pic->n_wts;
+  for (int b = 0; b < 4; b++) k.n_rbs[b] = pic->rb_count[b];
+  k.n_ibs = pic->n_ibs; k.n_coeffs = pic->n_coeffs; k.n_pcm = pic->n_pcm; k.scaling = pic->scaling_factors != nullptr;
+}
+/* where everything of one picture sits in the (pinned host / device) arena, for given list capacities */
+static void make_layout(const m355_arena_caps& k, int nCtb, int halo_units, bool sharded, bool with_ib_input, Lay& L)
+{
+  L.ns = 0; L.total = 0;
+  auto add = [&](size_t bytes) { L.seg[L.ns].src = nullptr; L.seg[L.ns].bytes = 0; L.seg[L.ns].ofs = L.total; L.total += al(bytes ? bytes : 1); return L.ns++; };
+  L.i_sl = add(sizeof(m355_slice) * (size_t)k.n_slices);
+  L.i_ct = add(sizeof(m355_ctb) * (size_t)k.n_ctbs);
+  L.i_cu = add(sizeof(m355_cu) * ((size_t)k.n_cus + (size_t)halo_units));
+  L.i_tu = add(sizeof(m355_tu) * (size_t)k.n_tus);
+  L.i_pb = add(sizeof(m355_pb) * ((size_t)k.n_pbs + (size_t)halo_units));
+  L.i_wt = add(sizeof(m355_wt) * (size_t)k.n_wts);
+  for (int b = 0; b < 4; b++) L.i_rb[b] = add(sizeof(m355_rb) * (size_t)k.n_rbs[b]);
+  L.i_ibin = add(with_ib_input ? sizeof(m355_ib) * (size_t)k.n_ibs : 0);   /* in place: the caller's blocks in decode order (host only) */
+  L.i_ib = add(sizeof(m355_ib) * (size_t)k.n_ibs);      /* each CTB's blocks sorted by dependency level */
+  L.i_il = add(2 * (size_t)k.n_ibs);                    /* ib_level */
+  L.i_co = add(4 * (size_t)k.n_coeffs);
+  L.i_pc = add(2 * (size_t)k.n_pcm);
+  L.i_sc = add(k.scaling ? 6 * (16 + 64 + 256 + 1024) : 0);
+  L.i_ts = add(4 * (size_t)nCtb);   /* ctb_ts   */
+  L.i_rs = add(4 * (size_t)nCtb);   /* ts2rs    */
+  L.i_ti = add(2 * (size_t)nCtb);   /* tile_id  */
+  L.i_iw = add(4 * (size_t)nCtb);   /* intra_work */
+  L.i_dp = add((size_t)nCtb);       /* ctb_dep */
+  L.i_jb = add(12 * (size_t)(((size_t)k.n_pbs + 255) / 256 + 1));   /* job_base */
+  L.i_ow = add(sharded ? (size_t)nCtb : 0);                          /* ctb_owner */
+}
+
 static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
 {
   static const bool prof = getenv("M355_PROFILE_UPLOAD") != nullptr;     /* phase times of this function on stderr */
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t_start = now();
+  const m355_pic_params& pp = pic->pp;
+  const bool in_place = r.arena && r.host && pic->n_ctbs > 0 && (const char*)pic->ctbs >= r.host && (const char*)pic->ctbs < r.host + r.cap;
   int ctbW, ctbH;
-  int rc = validate(pic, &ctbW, &ctbH);
+  const int n_chunks = (pic->n_pbs > 0 ? pic->n_pbs + 255 : 0) / 256;
+  r.job_cnt.assign((size_t)n_chunks * 3 + 3, 0);
+  static const bool host_only = getenv("M355_HOST_VALIDATION") != nullptr;     /* diagnostics: all record checks on the host */
+  r.device_validate = in_place && !host_only;
+  int rc = validate(pic, in_place ? (const m355_rb* const*)r.caps.rb_bin : nullptr, r.job_cnt.data(), r.device_validate, &ctbW, &ctbH);
   if (rc) return rc;
   const auto t_valid = now();
-  const m355_pic_params& pp = pic->pp;
   const int nCtb = ctbW * ctbH;
-  const int nrb = pic->rb_count[0] + pic->rb_count[1] + pic->rb_count[2] + pic->rb_count[3];
-  struct Seg { const void* src; size_t bytes; size_t ofs; };
-  Seg seg[24];
-  int ns = 0;
-  size_t total = 0;
-  auto add = [&](const void* src, size_t bytes, size_t room = 0) { seg[ns].src = src; seg[ns].bytes = bytes; seg[ns].ofs = total; total += al(bytes + room ? bytes + room : 1); return ns++; };
   /* tile sharding: foreign border units are appended to cus[] / pbs[] by k_halo_unpack_meta */
   const bool sharded = c->shard_n >= 1;
   HaloLayout halo;
   memset(&halo, 0, sizeof(halo));
   if (sharded) halo_layout(pp, halo);
-  const int i_sl = add(pic->slices, sizeof(m355_slice) * pic->n_slices);
-  const int i_ct = add(pic->ctbs, sizeof(m355_ctb) * pic->n_ctbs);
-  const int i_cu = add(pic->cus, sizeof(m355_cu) * pic->n_cus, sizeof(m355_cu) * (size_t)halo.n_units);
-  const int i_tu = add(pic->tus, sizeof(m355_tu) * pic->n_tus);
-  const int i_pb = add(pic->pbs, sizeof(m355_pb) * pic->n_pbs, sizeof(m355_pb) * (size_t)halo.n_units);
-  const int i_wt = add(pic->wts, sizeof(m355_wt) * pic->n_wts);
-  const int i_rb = add(pic->rbs, sizeof(m355_rb) * nrb);
-  const int i_ib = add(nullptr, sizeof(m355_ib) * pic->n_ibs);   /* written below: each CTB's blocks sorted by dependency level */
-  const int i_il = add(nullptr, 2 * (size_t)pic->n_ibs);         /* ib_level */
-  const int i_co = add(pic->coeffs, 4 * (size_t)pic->n_coeffs);
-  const int i_pc = add(pic->pcm, 2 * (size_t)pic->n_pcm);
-  const int i_sc = add(pic->scaling_factors, pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0);
-  const int i_ts = add(nullptr, 4 * (size_t)nCtb);   /* ctb_ts   */
-  const int i_rs = add(nullptr, 4 * (size_t)nCtb);   /* ts2rs    */
-  const int i_ti = add(nullptr, 2 * (size_t)nCtb);   /* tile_id  */
-  const int i_iw = add(nullptr, 4 * (size_t)nCtb);   /* intra_work */
-  const int i_dp = add(nullptr, (size_t)nCtb);       /* ctb_dep */
-  const int n_chunks = (pic->n_pbs + 255) / 256;
-  const int i_jb = add(nullptr, 12 * (size_t)(n_chunks ? n_chunks : 1));   /* job_base */
-  const int i_ow = add(nullptr, sharded ? (size_t)nCtb : 0);               /* ctb_owner */
+  /* in place: the lists were written into this arena through m355_arena_begin (same capacities -> same layout) */
+  m355_arena_caps cp;
+  caps_of(pic, cp);
+  if (in_place) {
+    const m355_arena_caps& k = r.caps;
+    if (cp.n_slices > k.n_slices || cp.n_ctbs > k.n_ctbs || cp.n_cus > k.n_cus || cp.n_tus > k.n_tus || cp.n_pbs > k.n_pbs || cp.n_wts > k.n_wts ||
+        cp.n_rbs[0] > k.n_rbs[0] || cp.n_rbs[1] > k.n_rbs[1] || cp.n_rbs[2] > k.n_rbs[2] || cp.n_rbs[3] > k.n_rbs[3] || cp.n_ibs > k.n_ibs ||
+        cp.n_coeffs > k.n_coeffs || cp.n_pcm > k.n_pcm || (cp.scaling && !k.scaling))
+      return fail(M355_ERR_INVALID, "lists exceed the capacities given to m355_arena_begin");
+    cp = k;
+  }
+  Lay L;
+  make_layout(cp, nCtb, halo.n_units, sharded, in_place, L);
+  Seg* seg = L.seg;
+  const int ns = L.ns;
+  const size_t total = L.total;
+  const int i_sl = L.i_sl, i_ct = L.i_ct, i_cu = L.i_cu, i_tu = L.i_tu, i_pb = L.i_pb, i_wt = L.i_wt, i_ib = L.i_ib, i_il = L.i_il, i_co = L.i_co, i_pc = L.i_pc,
+            i_sc = L.i_sc, i_ts = L.i_ts, i_rs = L.i_rs, i_ti = L.i_ti, i_iw = L.i_iw, i_dp = L.i_dp, i_jb = L.i_jb, i_ow = L.i_ow;
+  /* used bytes (what travels to the device) and, when copying, where they come from */
+  {
+    size_t rb_o = 0;
+    const void* srcs[32]; size_t used[32];
+    for (int i = 0; i < ns; i++) { srcs[i] = nullptr; used[i] = 0; }
+    srcs[i_sl] = pic->slices; used[i_sl] = sizeof(m355_slice) * (size_t)pic->n_slices;
+    srcs[i_ct] = pic->ctbs; used[i_ct] = sizeof(m355_ctb) * (size_t)pic->n_ctbs;
+    srcs[i_cu] = pic->cus; used[i_cu] = sizeof(m355_cu) * (size_t)pic->n_cus;
+    srcs[i_tu] = pic->tus; used[i_tu] = sizeof(m355_tu) * (size_t)pic->n_tus;
+    srcs[i_pb] = pic->pbs; used[i_pb] = sizeof(m355_pb) * (size_t)pic->n_pbs;
+    srcs[i_wt] = pic->wts; used[i_wt] = sizeof(m355_wt) * (size_t)pic->n_wts;
+    for (int b = 0; b < 4; b++) { srcs[L.i_rb[b]] = pic->rbs + rb_o; used[L.i_rb[b]] = sizeof(m355_rb) * (size_t)pic->rb_count[b]; rb_o += (size_t)pic->rb_count[b]; }
+    used[i_ib] = sizeof(m355_ib) * (size_t)pic->n_ibs; used[i_il] = 2 * (size_t)pic->n_ibs;
+    srcs[i_co] = pic->coeffs; used[i_co] = 4 * (size_t)pic->n_coeffs;
+    srcs[i_pc] = pic->pcm; used[i_pc] = 2 * (size_t)pic->n_pcm;
+    srcs[i_sc] = pic->scaling_factors; used[i_sc] = pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0;
+    used[i_ts] = used[i_rs] = used[i_iw] = 4 * (size_t)nCtb; used[i_ti] = 2 * (size_t)nCtb; used[i_dp] = (size_t)nCtb;
+    used[i_jb] = 12 * (size_t)(n_chunks ? n_chunks : 1); used[i_ow] = sharded ? (size_t)nCtb : 0;
+    for (int i = 0; i < ns; i++) { seg[i].src = srcs[i]; seg[i].bytes = used[i]; }
+    if (in_place) {
+      /* every list must sit where the arena put it (the four size bins of rbs[] in their own regions: m355_arena_begin
+         returns them through m355_arena_caps.rb_bin) */
+      const void* want[] = {pic->slices, pic->ctbs, pic->cus, pic->tus, pic->pbs, pic->wts, pic->coeffs, pic->pcm};
+      const int idx[] = {i_sl, i_ct, i_cu, i_tu, i_pb, i_wt, i_co, i_pc};
+      for (int k = 0; k < 8; k++)
+        if (seg[idx[k]].bytes && want[k] != (const void*)(r.host + seg[idx[k]].ofs)) return fail(M355_ERR_INVALID, "in-place submit: a list is not where m355_arena_begin put it");
+      if (pic->n_ibs && pic->ibs != (const m355_ib*)(r.host + seg[L.i_ibin].ofs)) return fail(M355_ERR_INVALID, "in-place submit: ibs[] is not where m355_arena_begin put it");
+      if (pic->rbs != (const m355_rb*)(r.host + seg[L.i_rb[0]].ofs)) return fail(M355_ERR_INVALID, "in-place submit: rbs must point at the first size bin's region");
+      for (int i = 0; i < ns; i++) seg[i].src = nullptr;        /* nothing to copy */
+    }
+  }
 
   hipSetDevice(c->device);
   if (total > r.cap) {
@@ -857,6 +1037,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   std::vector<uint8_t> log2_waves((size_t)nCtb, 0);
   int intra_dense = 0;
   intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint16_t*)(r.host + seg[i_il].ofs), log2_waves.data(), &intra_dense);
+  const auto t_sched = now();
   /* derived scan tables (pps.cc:589-606) */
   uint32_t* ctb_ts = (uint32_t*)(r.host + seg[i_ts].ofs);
   uint32_t* ts2rs = (uint32_t*)(r.host + seg[i_rs].ofs);
@@ -878,6 +1059,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
      earlier) or on dependent ones earlier in decode order. */
   intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
   for (int i = 0; i < nCtb; i++) ((uint8_t*)(r.host + seg[i_dp].ofs))[i] |= (uint8_t)(log2_waves[i] << 5);
+  const auto t_deps = now();
   int nw = 0, n_free = 0;
   {
     const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
@@ -896,17 +1078,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
        index of the chunk in each range */
     long long nj = 0, nm = 0, nu = 0;
     uint32_t* jb = (uint32_t*)(r.host + seg[i_jb].ofs);
-    std::vector<uint32_t> cnt((size_t)n_chunks * 3 + 3, 0);
-    parallel_ranges((size_t)n_chunks, 64, [&](size_t kb, size_t ke) {
-      for (size_t k = kb; k < ke; k++)
-        for (int i = (int)k * 256; i < pic->n_pbs && i < (int)(k + 1) * 256; i++) {
-          const m355_pb& pb = pic->pbs[i];
-          const uint32_t n = (uint32_t)(pb.w >> 2) * ((pb.h + 7) >> 3);
-          int cls = 2;
-          if (!m355_pb_is_edge(pb, pp.width, pp.chroma_format_idc)) cls = ((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0;
-          cnt[k * 3 + cls] += n;
-        }
-    });
+    const std::vector<uint32_t>& cnt = r.job_cnt;          /* counted by the validation sweep */
     for (int k = 0; k < n_chunks; k++) { nu += cnt[(size_t)k * 3]; nm += (long long)cnt[(size_t)k * 3] + cnt[(size_t)k * 3 + 1]; nj += (long long)cnt[(size_t)k * 3] + cnt[(size_t)k * 3 + 1] + cnt[(size_t)k * 3 + 2]; }
     {
       uint32_t run[3] = {0, (uint32_t)nu, (uint32_t)nm};
@@ -928,9 +1100,20 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   }
   r.sharded = sharded; r.shard_rank = c->shard_rank; r.shard_n = c->shard_n; r.halo = halo; r.live_valid = false; r.xprev = nullptr;
   r.bytes = total; r.fresh = true; r.refs_valid = false;
-  if (prof) fprintf(stderr, "m355 upload: validate %.3f ms, wait/alloc %.3f, copy %.3f (%.1f MB), derive (schedule, jobs, dependencies) %.3f\n",
-                    ms(t_start, t_valid), ms(t_valid, t_wait), ms(t_wait, t_copy), total / 1e6, ms(t_copy, now()));
-  HIPCHK(hipMemcpyAsync(r.dev, r.host, total, hipMemcpyHostToDevice, c->stream));
+  if (prof) fprintf(stderr, "m355 upload%s: validate %.3f ms, wait/alloc %.3f, copy %.3f (%.1f MB), intra schedule %.3f, tables + dependencies %.3f, work list + jobs %.3f\n",
+                    in_place ? " (in place)" : "", ms(t_start, t_valid), ms(t_valid, t_wait), ms(t_wait, t_copy), total / 1e6, ms(t_copy, t_sched), ms(t_sched, t_deps), ms(t_deps, now()));
+  {
+    /* host -> device: what is used of every segment (capacities handed out by m355_arena_begin may be far larger); adjacent
+       segments travel together */
+    size_t run_b = 0, run_e = 0;
+    for (int i = 0; i <= ns; i++) {
+      const bool used = i < ns && seg[i].bytes && i != L.i_ibin;
+      const size_t b = used ? seg[i].ofs : 0, e = used ? seg[i].ofs + seg[i].bytes : 0;
+      if (used && run_e > run_b && b - run_e <= 4096) { run_e = e; continue; }      /* small gap: one copy */
+      if (run_e > run_b) HIPCHK(hipMemcpyAsync(r.dev + run_b, r.host + run_b, run_e - run_b, hipMemcpyHostToDevice, c->stream));
+      run_b = b; run_e = e;
+    }
+  }
   if (!r.ev_up) HIPCHK(hipEventCreateWithFlags(&r.ev_up, hipEventDisableTiming));
   HIPCHK(hipEventRecord(r.ev_up, c->stream));      /* a decode on the other lane waits for the lists */
 
@@ -950,7 +1133,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.tus = (const m355_tu*)(r.dev + seg[i_tu].ofs);
   d.pbs = (const m355_pb*)(r.dev + seg[i_pb].ofs);
   d.wts = (const m355_wt*)(r.dev + seg[i_wt].ofs);
-  d.rbs = (const m355_rb*)(r.dev + seg[i_rb].ofs);
+  for (int b = 0; b < 4; b++) d.rb_bin[b] = (const m355_rb*)(r.dev + seg[L.i_rb[b]].ofs);
   d.ibs = (const m355_ib*)(r.dev + seg[i_ib].ofs);
   d.ib_level = (const uint16_t*)(r.dev + seg[i_il].ofs);
   d.intra_dense = intra_dense;
@@ -970,6 +1153,8 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.ctb_owner = sharded ? (const uint8_t*)(r.dev + seg[i_ow].ofs) : nullptr;
   d.halo_cu_base = pic->n_cus; d.halo_pb_base = pic->n_pbs;
   d.n_pb_records = pic->n_pbs + halo.n_units;
+  d.device_validate = r.device_validate ? 1 : 0;
+  d.n_wts = pic->n_wts; d.n_coeffs = pic->n_coeffs; d.n_pcm = pic->n_pcm; d.res_len = pic->res_len;
   r.used = true;
   return M355_OK;
 }
@@ -987,6 +1172,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   if (dst->w != pp.width || dst->h != pp.height || dst->cf != pp.chroma_format_idc || dst->bdl != pp.bit_depth_luma || dst->bdc != pp.bit_depth_chroma)
     return fail(M355_ERR_INVALID, "dst frame geometry does not match the picture parameters");
   DevPic d = r.dp;
+  d.ref_valid = 0;
   DevRef refs[M355_MAX_REF_FRAMES];
   memset(refs, 0, sizeof(refs));
   for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
@@ -998,6 +1184,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
     if (f == dst) return fail(M355_ERR_INVALID, "a picture cannot reference itself");
     for (int cc = 0; cc < 3; cc++) { refs[i].plane[cc] = f->plane[cc]; refs[i].stride[cc] = f->stride[cc]; }
     refs[i].valid = 1;
+    d.ref_valid |= 1u << i;
   }
   if (!r.refs_dev) {
     HIPCHK(hipMalloc(&r.refs_dev, sizeof(refs)));
@@ -1069,10 +1256,10 @@ static hipError_t frame_event(hipEvent_t* e)
   return hipEventCreateWithFlags(e, hipEventDisableTiming);
 }
 
-static int decode(m355_ctx* c, Resident& r)
+static int decode(m355_ctx* c, Resident& r, bool rotate = true)
 {
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
-  if (c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);   /* consecutive pictures go round the lanes */
+  if (rotate && c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);   /* consecutive pictures go round the lanes */
   DevPic d;
   bool want_sao;
   int rc = prepare(c, r, d, want_sao);
@@ -1102,6 +1289,11 @@ static int decode(m355_ctx* c, Resident& r)
   hipEvent_t* ev = &c->evs[c->ev_used * 7];
   c->ev_used++;
   hipEventRecord(ev[0], st);
+  if (c->gate_used || r.device_validate) {
+    hipMemsetAsync(c->timeout + 1, 0, 4, st);               /* this decode's gate word */
+    c->gate_used = r.device_validate ? 1 : 0;
+  }
+  if (r.device_validate) m355_launch_validate(d, st);
   if (!want_sao) dst_hazards();
   if (pp.flags & M355_PF_CLEAR_DST) {
     /* a new picture starts from zero in the reference (image.cc:164); the planes being reconstructed are this lane's
@@ -1247,13 +1439,58 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   return M355_OK;
 }
 
+int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)
+{
+  if (!k || !pic || k->n_ctbs <= 0 || k->n_slices <= 0 || k->n_cus < 0 || k->n_tus < 0 || k->n_pbs < 0 || k->n_wts < 0 || k->n_ibs < 0 ||
+      k->n_rbs[0] < 0 || k->n_rbs[1] < 0 || k->n_rbs[2] < 0 || k->n_rbs[3] < 0)
+    return fail(M355_ERR_INVALID, "bad arena capacities");
+  if (c->shard_n >= 1) return fail(M355_ERR_INVALID, "m355_arena_begin is not available on a tile-sharded context");
+  hipSetDevice(c->device);
+  Resident& r = c->transient[c->next_transient];         /* the arena the next m355_submit_picture uses */
+  Lay L;
+  make_layout(*k, k->n_ctbs, 0, false, true, L);
+  if (L.total > r.cap) {
+    if (r.dev || r.host) HIPCHK(sync_all(c));
+    if (r.dev) hipFree(r.dev);
+    if (r.host) hipHostFree(r.host);
+    r.dev = r.host = nullptr;
+    r.cap = L.total + L.total / 4;
+    HIPCHK(hipMalloc(&r.dev, r.cap));
+    HIPCHK(hipHostMalloc(&r.host, r.cap, hipHostMallocDefault));
+  } else if (r.done_pending) {
+    HIPCHK(hipEventSynchronize(r.ev_done));                /* the last decode of the lists that lived here */
+    r.done_pending = false;
+  }
+  memset(pic, 0, sizeof(*pic));
+  pic->slices = (const m355_slice*)(r.host + L.seg[L.i_sl].ofs);
+  pic->ctbs = (const m355_ctb*)(r.host + L.seg[L.i_ct].ofs);
+  pic->cus = (const m355_cu*)(r.host + L.seg[L.i_cu].ofs);
+  pic->tus = (const m355_tu*)(r.host + L.seg[L.i_tu].ofs);
+  pic->pbs = (const m355_pb*)(r.host + L.seg[L.i_pb].ofs);
+  pic->wts = (const m355_wt*)(r.host + L.seg[L.i_wt].ofs);
+  pic->rbs = (const m355_rb*)(r.host + L.seg[L.i_rb[0]].ofs);
+  for (int b = 0; b < 4; b++) k->rb_bin[b] = (m355_rb*)(r.host + L.seg[L.i_rb[b]].ofs);
+  r.arena = true; r.caps = *k;
+  pic->ibs = (const m355_ib*)(r.host + L.seg[L.i_ibin].ofs);
+  pic->coeffs = (const uint32_t*)(r.host + L.seg[L.i_co].ofs);
+  pic->pcm = (const uint16_t*)(r.host + L.seg[L.i_pc].ofs);
+  pic->scaling_factors = k->scaling ? (const uint8_t*)(r.host + L.seg[L.i_sc].ofs) : nullptr;
+  pic->dst_frame = -1;
+  for (int i = 0; i < M355_MAX_REF_FRAMES; i++) pic->ref_frames[i] = -1;
+  return M355_OK;
+}
+
 int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
 {
   Resident& t = c->transient[c->next_transient];
   c->next_transient = (c->next_transient + 1) % 3;
+  /* the lists travel on the stream of the lane that decodes them: the copy of picture k runs beside the kernels of
+     picture k-1 on the previous lane (uploading on the lane that is still active would queue it BEHIND those kernels) */
+  if (c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);
   int rc = upload(c, t, pic);
+  t.arena = false;                                          /* pointers handed out by m355_arena_begin are spent */
   if (rc) return rc;
-  return decode(c, t);
+  return decode(c, t, false);
 }
 
 int m355_wait(m355_ctx* c)
@@ -1265,12 +1502,29 @@ int m355_wait(m355_ctx* c)
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
   if (getenv("M355_INTRA_TIMING")) {   /* kernels built with -DM355_X_TIMING: clock sums of wave 0 of every CTB, per phase */
     unsigned long long tt[8];
-    HIPCHK(hipMemcpy(tt, c->timeout + 2, sizeof(tt), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tt, c->timeout + 16, sizeof(tt), hipMemcpyDeviceToHost));
     fprintf(stderr, "m355 intra timing (clocks): rec %llu gather %llu subst %llu filter %llu ref %llu predict %llu publish %llu barrier %llu\n", tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], tt[7]);
-    hipMemset(c->timeout + 2, 0, sizeof(tt));
+    hipMemset(c->timeout + 16, 0, sizeof(tt));
   }
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].timeout) { uint32_t t2 = 0; HIPCHK(hipMemcpy(&t2, c->lanes[k].timeout, 4, hipMemcpyDeviceToHost)); t |= t2; }
+  {
+    /* lists checked on the device (recorded in place): the lowest rejected record of any decode since the last wait */
+    uint32_t bad = 0xFFFFFFFFu;
+    for (int k = 0; k < M355_MAX_LANES; k++) {
+      uint32_t* w = k == c->active ? c->timeout : c->lanes[k].timeout;
+      hipStream_t ws = k == c->active ? c->stream : c->lanes[k].stream;
+      if (!w) continue;
+      uint32_t b2 = 0xFFFFFFFFu;
+      HIPCHK(hipMemcpy(&b2, w + 2, 4, hipMemcpyDeviceToHost));
+      if (b2 != 0xFFFFFFFFu) { HIPCHK(hipMemsetAsync(w + 2, 0xFF, 4, ws)); HIPCHK(hipStreamSynchronize(ws)); }
+      bad = std::min(bad, b2);
+    }
+    if (bad != 0xFFFFFFFFu) {
+      static const char* const names[8] = {"?", "cu", "tu", "pb", "weight", "rb", "ib", "?"};
+      return fail(M355_ERR_INVALID, "%s %u: rejected by the device-side list validation (the picture was not decoded)", names[(bad >> 28) & 7], bad & 0x0FFFFFFFu);
+    }
+  }
   if (t) {
     hipMemsetAsync(c->timeout, 0, 4, c->stream);
     for (int k = 0; k < M355_MAX_LANES; k++)

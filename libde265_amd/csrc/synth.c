@@ -528,3 +528,52 @@ __attribute__((visibility("default"))) void m355_synth_ref_plane(uint32_t seed, 
     }
   free(n);
 }
+
+/* ---- stand-in for a recorder that writes its lists IN PLACE (m355_arena_begin): copies a generated picture's lists into the
+ * arena pointers of `dst` (all plain memory traffic, spread over `threads` OpenMP threads like parser threads would be) and
+ * fills in dst's counts / parameters.  Benchmarks only. ---- */
+#include <omp.h>
+__attribute__((visibility("default"))) void m355_synth_fill_arena(const m355_picture* src, const m355_arena_caps* caps, m355_picture* dst, int threads)
+{
+  struct { void* d; const void* s; size_t n; } job[16];
+  int nj = 0;
+#define JOB(D, S, N) do { job[nj].d = (void*)(D); job[nj].s = (S); job[nj].n = (N); nj++; } while (0)
+  JOB(dst->slices, src->slices, sizeof(m355_slice) * (size_t)src->n_slices);
+  JOB(dst->ctbs, src->ctbs, sizeof(m355_ctb) * (size_t)src->n_ctbs);
+  JOB(dst->cus, src->cus, sizeof(m355_cu) * (size_t)src->n_cus);
+  JOB(dst->tus, src->tus, sizeof(m355_tu) * (size_t)src->n_tus);
+  JOB(dst->pbs, src->pbs, sizeof(m355_pb) * (size_t)src->n_pbs);
+  JOB(dst->wts, src->wts, sizeof(m355_wt) * (size_t)src->n_wts);
+  size_t o = 0;
+  for (int b = 0; b < 4; b++) { JOB(caps->rb_bin[b], src->rbs + o, sizeof(m355_rb) * (size_t)src->rb_count[b]); o += (size_t)src->rb_count[b]; }
+  JOB(dst->ibs, src->ibs, sizeof(m355_ib) * (size_t)src->n_ibs);
+  JOB(dst->coeffs, src->coeffs, 4 * (size_t)src->n_coeffs);
+  JOB(dst->pcm, src->pcm, 2 * (size_t)src->n_pcm);
+  if (src->scaling_factors && dst->scaling_factors) JOB(dst->scaling_factors, src->scaling_factors, 6 * (16 + 64 + 256 + 1024));
+#undef JOB
+  const size_t CH = (size_t)1 << 18;
+  size_t nchunks[16], tot = 0;
+  for (int j = 0; j < nj; j++) { nchunks[j] = (job[j].n + CH - 1) / CH; tot += nchunks[j]; }
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+  for (long long g = 0; g < (long long)tot; g++) {
+    size_t k = (size_t)g; int j = 0;
+    while (k >= nchunks[j]) { k -= nchunks[j]; j++; }
+    const size_t b = k * CH, e = b + CH < job[j].n ? b + CH : job[j].n;
+    memcpy((char*)job[j].d + b, (const char*)job[j].s + b, e - b);
+  }
+  dst->pp = src->pp;
+  dst->n_slices = src->n_slices; dst->n_ctbs = src->n_ctbs; dst->n_cus = src->n_cus; dst->n_tus = src->n_tus; dst->n_pbs = src->n_pbs;
+  dst->n_wts = src->n_wts; dst->n_ibs = src->n_ibs; dst->n_coeffs = src->n_coeffs; dst->n_pcm = src->n_pcm; dst->res_len = src->res_len;
+  for (int b = 0; b < 4; b++) dst->rb_count[b] = src->rb_count[b];
+  if (!src->scaling_factors) dst->scaling_factors = NULL;
+}
+/* counts / parameters only (the arena still holds the lists of an earlier fill) */
+__attribute__((visibility("default"))) void m355_synth_fill_arena_header(const m355_picture* src, m355_picture* dst)
+{
+  dst->pp = src->pp;
+  dst->n_slices = src->n_slices; dst->n_ctbs = src->n_ctbs; dst->n_cus = src->n_cus; dst->n_tus = src->n_tus; dst->n_pbs = src->n_pbs;
+  dst->n_wts = src->n_wts; dst->n_ibs = src->n_ibs; dst->n_coeffs = src->n_coeffs; dst->n_pcm = src->n_pcm; dst->res_len = src->res_len;
+  for (int b = 0; b < 4; b++) dst->rb_count[b] = src->rb_count[b];
+  if (!src->scaling_factors) dst->scaling_factors = NULL;
+}

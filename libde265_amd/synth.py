@@ -36,6 +36,10 @@ def _lib():
         _LIB.m355_synth_picture.argtypes = [ctypes.POINTER(SynthCfg), ctypes.POINTER(_SynthOut)]
         _LIB.m355_synth_free.argtypes = [ctypes.POINTER(_SynthOut)]
         _LIB.m355_synth_ref_plane.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _LIB.m355_synth_fill_arena.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        _LIB.m355_synth_fill_arena.restype = None
+        _LIB.m355_synth_fill_arena_header.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _LIB.m355_synth_fill_arena_header.restype = None
     return _LIB
 
 
