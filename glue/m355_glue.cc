@@ -11,8 +11,8 @@
  *   generate_inter_prediction_samples   motion.cc:288      -> record one m355_pb with the host-side decisions
  *   decoder_context::run_postprocessing_filters_sequential / _parallel   decctx.cc:1783 / 1811
  *                                                          -> walk the picture's metadata, m355_submit_picture()
- *   de265_new_decoder / de265_free_decoder / de265_peek_next_picture / de265_get_next_picture   de265.cc:254-449
- *                                                          -> backend context; download a picture when it is output
+ *   de265_new_decoder / de265_free_decoder / de265_get_image_plane   de265.cc:254-281, 729-738 (renamed in de265.o, wrapped here)
+ *                                                          -> backend context; a picture is downloaded when its samples are asked for
  * deblock.cc and sao.cc are not linked at all (their four entry points exist here only as traps).
  *
  * The host keeps doing everything it did before — NAL / CABAC parsing, MV and QP derivation, DPB management,
@@ -34,8 +34,10 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "libde265/de265.h"
@@ -56,6 +58,7 @@
 extern "C" {
 de265_decoder_context* m355ref_de265_new_decoder(void);
 de265_error m355ref_de265_free_decoder(de265_decoder_context*);
+const uint8_t* m355ref_de265_get_image_plane(const struct de265_image*, int, int*);
 }
 
 namespace {
@@ -65,7 +68,7 @@ namespace {
 #define M355_FUNCS(X) \
   X(m355_last_error) X(m355_device_count) X(m355_create) X(m355_destroy) X(m355_frame_create) X(m355_frame_destroy) \
   X(m355_frame_upload) X(m355_frame_download) X(m355_submit_picture) X(m355_wait) X(m355_set_pipeline_depth) \
-  X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash)
+  X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash) X(m355_arena_begin)
 
 struct Api {
   void* handle = nullptr;
@@ -119,10 +122,11 @@ struct ThreadRec {
   int last_ib = -1;                 /* the intra block just predicted: its residual (if any) comes next (slice.cc:3489-3508) */
   int luma_rb = -1;                 /* cross-component prediction: the transform unit's luma block in its size bin */
   int skipped_pbs = 0;              /* prediction units the reference leaves unwritten (motion.cc warnings) */
+  bool any_weighted = false;
   void clear()
   {
     pbs.clear(); for (auto& v : rbs) v.clear(); ibs.clear(); coeffs.clear(); runs.clear();
-    res_len = 0; last_ib = -1; luma_rb = -1; skipped_pbs = 0; img_id = 0xFFFFFFFFu; owner = nullptr; thread = nullptr;
+    res_len = 0; last_ib = -1; luma_rb = -1; skipped_pbs = 0; any_weighted = false; img_id = 0xFFFFFFFFu; owner = nullptr; thread = nullptr;
   }
 };
 
@@ -276,9 +280,10 @@ int glue_get_buffer(de265_decoder_context* ctx, de265_image_spec* spec, de265_im
     ok = ok && p[1] && p[2];
   } else cs = 0;
   if (!ok) { for (void* q : p) if (q) g->planes.put(q); return 0; }
-  de265_set_image_plane(img, 0, p[0], (int)ls, nullptr);
-  de265_set_image_plane(img, 1, p[1], (int)cs, nullptr);
-  de265_set_image_plane(img, 2, p[2], (int)cs, nullptr);
+  /* de265_set_image_plane takes the stride in BYTES (de265.cc:747-752 divides by the bytes per sample) */
+  de265_set_image_plane(img, 0, p[0], (int)(ls * ((img->get_bit_depth(0) + 7) / 8)), nullptr);
+  de265_set_image_plane(img, 1, p[1], (int)(cs * ((img->get_bit_depth(1) + 7) / 8)), nullptr);
+  de265_set_image_plane(img, 2, p[2], (int)(cs * ((img->get_bit_depth(1) + 7) / 8)), nullptr);
   (void)ctx;
   return 1;
 }
@@ -333,6 +338,11 @@ void download_if_needed(Glue* g, de265_image* img)
   if (slot < 0 || g->frame_of_slot[slot] < 0) return;
   if (g->dev_id[slot] != img->get_ID() || g->host_id[slot] == img->get_ID()) return;
   const auto t0 = std::chrono::steady_clock::now();
+  if (api()->m355_wait(g->mctx) != M355_OK) {      /* device-side list validation / spin bounds report here */
+    g->error = api()->m355_last_error();
+    fprintf(stderr, "libde265 (MI355X glue): %s\n", g->error.c_str());
+    img->integrity = INTEGRITY_DECODING_ERRORS;
+  }
   const int nc = img->get_chroma_format() == de265_chroma_mono ? 1 : 3;
   for (int c = 0; c < nc; c++)
     if (api()->m355_frame_download(g->mctx, g->frame_of_slot[slot], c, img->get_image_plane(c), img->get_image_stride(c)) != M355_OK) {
@@ -370,6 +380,29 @@ inline uint32_t z_rank(int x, int y)
   uint32_t r = 0;
   for (int b = 0; b < 4; b++) r |= (uint32_t)(((x >> (3 + b)) & 1) << (2 * b)) | (uint32_t)(((y >> (3 + b)) & 1) << (2 * b + 1));
   return r;
+}
+
+/* the submit step's own data-parallel work (metadata walk, copies into the arena): a handful of short-lived threads per picture */
+int glue_threads()
+{
+  static int n = 0;
+  if (!n) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    n = hc >= 32 ? 16 : (hc >= 8 ? 8 : (hc >= 4 ? 4 : 1));
+    if (const char* e = getenv("M355_GLUE_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n = v; }
+  }
+  return n;
+}
+void parallel_tasks(size_t n_tasks, const std::function<void(size_t)>& f)
+{
+  const int T = (int)std::min<size_t>((size_t)glue_threads(), n_tasks);
+  if (T <= 1) { for (size_t i = 0; i < n_tasks; i++) f(i); return; }
+  std::atomic<size_t> next(0);
+  auto work = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n_tasks) return; f(i); } };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
 }
 
 bool submit_picture(Glue* g, de265_image* img)
@@ -441,22 +474,39 @@ bool submit_picture(Glue* g, de265_image* img)
   std::vector<uint32_t> pcm_cus;
   const int minCb = sps.MinCbSizeY;
   long long covered = 0;
-  for (int cy = 0; cy < sps.PicHeightInMinCbsY; cy++)
-    for (int cx = 0; cx < sps.PicWidthInMinCbsY; cx++) {
-      const int l2 = img->get_log2CbSize_cbUnits(cx, cy);
-      if (l2 == 0) continue;
-      const int x0 = cx * minCb, y0 = cy * minCb;
-      m355_cu cu; memset(&cu, 0, sizeof(cu));
-      cu.x = (uint16_t)x0; cu.y = (uint16_t)y0; cu.log2_size = (uint8_t)l2;
-      cu.pred_mode = (uint8_t)img->get_pred_mode(x0, y0);
-      cu.part_mode = (uint8_t)img->get_PartMode(x0, y0);
-      cu.qp_y = (int8_t)img->get_QPY(x0, y0);
-      if (img->get_pcm_flag(x0, y0)) { cu.flags |= M355_CUF_PCM; pcm_cus.push_back((uint32_t)cus.size()); any_pcm = true; }
-      if (img->get_cu_transquant_bypass(x0, y0)) cu.flags |= M355_CUF_TRANSQUANT_BYPASS;
-      cus.push_back(cu);
-      covered += 1ll << (2 * l2);
-      walk_tu(img, x0, y0, l2, 0, tus);
-    }
+  {
+    /* bands of min-CB rows, walked in parallel, concatenated in raster order */
+    const int rows = sps.PicHeightInMinCbsY, per = std::max(1, (rows + 4 * glue_threads() - 1) / (4 * glue_threads()));
+    const size_t nb = (size_t)((rows + per - 1) / per);
+    std::vector<std::vector<m355_cu>> bcu(nb);
+    std::vector<std::vector<m355_tu>> btu(nb);
+    std::vector<long long> bcov(nb, 0);
+    parallel_tasks(nb, [&](size_t b) {
+      std::vector<m355_cu>& vc = bcu[b];
+      std::vector<m355_tu>& vt = btu[b];
+      for (int cy = (int)b * per; cy < rows && cy < ((int)b + 1) * per; cy++)
+        for (int cx = 0; cx < sps.PicWidthInMinCbsY; cx++) {
+          const int l2 = img->get_log2CbSize_cbUnits(cx, cy);
+          if (l2 == 0) continue;
+          const int x0 = cx * minCb, y0 = cy * minCb;
+          m355_cu cu; memset(&cu, 0, sizeof(cu));
+          cu.x = (uint16_t)x0; cu.y = (uint16_t)y0; cu.log2_size = (uint8_t)l2;
+          cu.pred_mode = (uint8_t)img->get_pred_mode(x0, y0);
+          cu.part_mode = (uint8_t)img->get_PartMode(x0, y0);
+          cu.qp_y = (int8_t)img->get_QPY(x0, y0);
+          if (img->get_pcm_flag(x0, y0)) cu.flags |= M355_CUF_PCM;
+          if (img->get_cu_transquant_bypass(x0, y0)) cu.flags |= M355_CUF_TRANSQUANT_BYPASS;
+          vc.push_back(cu);
+          bcov[b] += 1ll << (2 * l2);
+          walk_tu(img, x0, y0, l2, 0, vt);
+        }
+    });
+    size_t ncu = 0, ntu = 0;
+    for (size_t b = 0; b < nb; b++) { ncu += bcu[b].size(); ntu += btu[b].size(); covered += bcov[b]; }
+    cus.reserve(ncu); tus.reserve(ntu);
+    for (size_t b = 0; b < nb; b++) { cus.insert(cus.end(), bcu[b].begin(), bcu[b].end()); tus.insert(tus.end(), btu[b].begin(), btu[b].end()); }
+    for (size_t i = 0; i < cus.size(); i++) if (cus[i].flags & M355_CUF_PCM) { pcm_cus.push_back((uint32_t)i); any_pcm = true; }
+  }
 
   /* ---- concatenate the threads' lists ---- */
   std::vector<ThreadRec*> recs;
@@ -474,40 +524,95 @@ bool submit_picture(Glue* g, de265_image* img)
     for (int s = 0; s < 4; s++) n_rb[s] += recs[t]->rbs[s].size();
     skipped += recs[t]->skipped_pbs;
   }
-  std::vector<m355_pb> pbs; pbs.reserve(n_pb);
-  std::vector<uint32_t> coeffs; coeffs.reserve(n_co);
-  std::vector<m355_rb> rbs; rbs.reserve(n_rb[0] + n_rb[1] + n_rb[2] + n_rb[3]);
-  for (ThreadRec* r : recs) { pbs.insert(pbs.end(), r->pbs.begin(), r->pbs.end()); coeffs.insert(coeffs.end(), r->coeffs.begin(), r->coeffs.end()); }
-  for (int s = 0; s < 4; s++)
-    for (size_t t = 0; t < recs.size(); t++)
-      for (m355_rb rb : recs[t]->rbs[s]) {
-        rb.coeff_ofs += co_base[t];
-        if (rb.flags & M355_RBF_DEFERRED) rb.res_ofs += res_base[t];
-        rbs.push_back(rb);
-      }
   for (int s = 0; s < 4; s++) pic.rb_count[s] = (int32_t)n_rb[s];
+  bool any_weighted = false;
+  for (ThreadRec* r : recs) any_weighted = any_weighted || r->any_weighted;
 
   /* intra blocks: each CTB's run (one thread decodes a whole CTB), CTBs in raster order */
-  std::vector<m355_ib> ibs; ibs.reserve(n_ib);
-  std::vector<uint16_t> pcm;
+  struct Ref { uint32_t ctb; uint16_t t; uint32_t start, count; };
+  std::vector<Ref> order;
+  size_t n_ib_final = 0;
   {
-    struct Ref { uint32_t ctb; uint16_t t; uint32_t start, count; };
-    std::vector<Ref> order;
+    std::vector<Ref> all;
     for (size_t t = 0; t < recs.size(); t++)
-      for (const Run& rn : recs[t]->runs) order.push_back(Ref{rn.ctb, (uint16_t)t, rn.start, rn.count});
-    std::stable_sort(order.begin(), order.end(), [](const Ref& a, const Ref& b) { return a.ctb < b.ctb; });
-    for (size_t k = 0; k < order.size(); k++) {
-      if (k + 1 < order.size() && order[k + 1].ctb == order[k].ctb) continue;     /* a CTB coded twice (damaged stream): the last one stands */
-      const Ref& o = order[k];
-      if (o.ctb >= ctbs.size()) continue;
-      m355_ctb& c = ctbs[o.ctb];
-      c.ib_start = (uint32_t)ibs.size(); c.ib_count = o.count;
-      for (uint32_t i = 0; i < o.count; i++) {
-        m355_ib ib = recs[o.t]->ibs[o.start + i];
-        if (ib.flags & M355_IBF_HAS_RESIDUAL) ib.res_ofs += res_base[o.t];
-        ibs.push_back(ib);
-      }
+      for (const Run& rn : recs[t]->runs) all.push_back(Ref{rn.ctb, (uint16_t)t, rn.start, rn.count});
+    std::stable_sort(all.begin(), all.end(), [](const Ref& a, const Ref& b) { return a.ctb < b.ctb; });
+    for (size_t k = 0; k < all.size(); k++) {
+      if (k + 1 < all.size() && all[k + 1].ctb == all[k].ctb) continue;     /* a CTB coded twice (damaged stream): the last one stands */
+      if (all[k].ctb >= ctbs.size()) continue;
+      m355_ctb& c = ctbs[all[k].ctb];
+      c.ib_start = (uint32_t)n_ib_final; c.ib_count = all[k].count;
+      n_ib_final += all[k].count;
+      order.push_back(all[k]);
     }
+  }
+
+  /* Where the lists go.  Normally straight into the backend's pinned arena (m355_arena_begin: the submit then copies nothing
+     and checks the records on the device); pictures with PCM units (their raw blocks are merged into the intra lists below)
+     and M355_GLUE_COPY=1 take the copying m355_submit_picture through host vectors. */
+  static const bool force_copy = getenv("M355_GLUE_COPY") != nullptr;
+  const bool in_place = !any_pcm && !force_copy;
+  std::vector<m355_pb> pbs;
+  std::vector<uint32_t> coeffs;
+  std::vector<m355_rb> rbs;
+  std::vector<m355_ib> ibs;
+  std::vector<uint16_t> pcm;
+  m355_picture apic; memset(&apic, 0, sizeof(apic));
+  m355_arena_caps caps; memset(&caps, 0, sizeof(caps));
+  m355_pb* d_pbs = nullptr; uint32_t* d_co = nullptr; m355_ib* d_ibs = nullptr; m355_rb* d_rb[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (in_place) {
+    caps.n_slices = (int32_t)slices.size(); caps.n_ctbs = (int32_t)ctbs.size(); caps.n_cus = (int32_t)cus.size() + 1; caps.n_tus = (int32_t)tus.size() + 1;
+    caps.n_pbs = (int32_t)n_pb + 1; caps.n_wts = any_weighted ? (int32_t)img->slices.size() * 32 : 1; caps.n_ibs = (int32_t)n_ib_final + 1;
+    for (int s = 0; s < 4; s++) caps.n_rbs[s] = (int32_t)n_rb[s] + 1;
+    caps.n_coeffs = (uint32_t)n_co + 1; caps.n_pcm = 1; caps.scaling = sps.scaling_list_enable_flag ? 1 : 0;
+    if (A->m355_arena_begin(g->mctx, &caps, &apic) != M355_OK) { g->error = A->m355_last_error(); return false; }
+    d_pbs = (m355_pb*)apic.pbs; d_co = (uint32_t*)apic.coeffs; d_ibs = (m355_ib*)apic.ibs;
+    for (int s = 0; s < 4; s++) d_rb[s] = caps.rb_bin[s];
+  } else {
+    pbs.resize(n_pb); coeffs.resize(n_co); rbs.resize(n_rb[0] + n_rb[1] + n_rb[2] + n_rb[3]); ibs.resize(n_ib_final);
+    d_pbs = pbs.data(); d_co = coeffs.data(); d_ibs = ibs.data();
+    size_t o = 0;
+    for (int s = 0; s < 4; s++) { d_rb[s] = rbs.data() + o; o += n_rb[s]; }
+  }
+  {
+    /* one task per (thread list, kind) + slices of the intra runs: plain copies, with each thread's coefficient / residual
+       offsets rebased into the picture-wide arrays */
+    std::vector<size_t> pb_base(recs.size()), rb_base[4];
+    size_t acc = 0;
+    for (size_t t = 0; t < recs.size(); t++) { pb_base[t] = acc; acc += recs[t]->pbs.size(); }
+    for (int s = 0; s < 4; s++) { rb_base[s].resize(recs.size()); acc = 0; for (size_t t = 0; t < recs.size(); t++) { rb_base[s][t] = acc; acc += recs[t]->rbs[s].size(); } }
+    const size_t ib_chunk = 256, n_ib_tasks = (order.size() + ib_chunk - 1) / ib_chunk;
+    const size_t per_rec = 6, n_tasks = recs.size() * per_rec + n_ib_tasks;
+    parallel_tasks(n_tasks, [&](size_t k) {
+      if (k < recs.size() * per_rec) {
+        const size_t t = k / per_rec; const int what = (int)(k % per_rec);
+        ThreadRec* r = recs[t];
+        if (what == 0) { if (!r->pbs.empty()) memcpy(d_pbs + pb_base[t], r->pbs.data(), r->pbs.size() * sizeof(m355_pb)); }
+        else if (what == 1) { if (!r->coeffs.empty()) memcpy(d_co + co_base[t], r->coeffs.data(), r->coeffs.size() * 4); }
+        else {
+          const int sb = what - 2;
+          m355_rb* dst = d_rb[sb] + rb_base[sb][t];
+          const std::vector<m355_rb>& v = r->rbs[sb];
+          for (size_t i = 0; i < v.size(); i++) {
+            m355_rb rb = v[i];
+            rb.coeff_ofs += co_base[t];
+            if (rb.flags & M355_RBF_DEFERRED) rb.res_ofs += res_base[t];
+            dst[i] = rb;
+          }
+        }
+      } else {
+        const size_t c0 = (k - recs.size() * per_rec) * ib_chunk, c1 = std::min(order.size(), c0 + ib_chunk);
+        for (size_t q = c0; q < c1; q++) {
+          const Ref& o = order[q];
+          m355_ib* dst = d_ibs + ctbs[o.ctb].ib_start;
+          for (uint32_t i = 0; i < o.count; i++) {
+            m355_ib ib = recs[o.t]->ibs[o.start + i];
+            if (ib.flags & M355_IBF_HAS_RESIDUAL) ib.res_ofs += res_base[o.t];
+            dst[i] = ib;
+          }
+        }
+      }
+    });
   }
   if (any_pcm) {
     /* PCM coding units (slice.cc:4211-4255): the parser has stored the raw samples in the host planes (bitstream reading,
@@ -562,8 +667,6 @@ bool submit_picture(Glue* g, de265_image* img)
 
   /* ---- explicit weights: one entry per (slice, list, refIdx) (motion.cc:508-529, 571-598, 633-652) ---- */
   std::vector<m355_wt> wts;
-  bool any_weighted = false;
-  for (const m355_pb& pb : pbs) if (pb.flags & M355_PBF_WEIGHTED) { any_weighted = true; break; }
   if (any_weighted) {
     if (img->slices.size() * 32 > 65535) { g->error = "too many slices for the weight table index"; return false; }
     const int shift1_L = std::max(2, 14 - sps.BitDepth_Y), shift1_C = std::max(2, 14 - sps.BitDepth_C);
@@ -588,9 +691,11 @@ bool submit_picture(Glue* g, de265_image* img)
   pic.dst_frame = g->frame_of_slot[dslot];
   for (int i = 0; i < M355_MAX_REF_FRAMES; i++) pic.ref_frames[i] = -1;
   bool used[M355_MAX_REF_FRAMES] = {};
-  for (const m355_pb& pb : pbs)
+  for (size_t i = 0; i < n_pb; i++) {
+    const m355_pb& pb = d_pbs[i];
     for (int l = 0; l < 2; l++)
       if ((pb.flags & (M355_PBF_MC_L0 << l)) && !(pb.flags & (M355_PBF_FILL_L0 << l))) used[pb.ref_slot[l]] = true;
+  }
   for (int s = 0; s < M355_MAX_REF_FRAMES; s++) {
     if (!used[s]) continue;
     const de265_image* rp = d->get_image(s);
@@ -618,10 +723,24 @@ bool submit_picture(Glue* g, de265_image* img)
   }
 
   pic.n_slices = (int32_t)slices.size(); pic.n_ctbs = (int32_t)ctbs.size(); pic.n_cus = (int32_t)cus.size(); pic.n_tus = (int32_t)tus.size();
-  pic.n_pbs = (int32_t)pbs.size(); pic.n_wts = (int32_t)wts.size(); pic.n_ibs = (int32_t)ibs.size();
-  pic.n_coeffs = (uint32_t)coeffs.size(); pic.n_pcm = (uint32_t)pcm.size(); pic.res_len = res_len;
-  pic.slices = slices.data(); pic.ctbs = ctbs.data(); pic.cus = cus.data(); pic.tus = tus.data(); pic.pbs = pbs.data();
-  pic.wts = wts.data(); pic.rbs = rbs.data(); pic.ibs = ibs.data(); pic.coeffs = coeffs.data(); pic.pcm = pcm.data();
+  pic.n_pbs = (int32_t)n_pb; pic.n_wts = (int32_t)wts.size(); pic.n_ibs = (int32_t)(in_place ? n_ib_final : ibs.size());
+  pic.n_coeffs = (uint32_t)n_co; pic.n_pcm = (uint32_t)pcm.size(); pic.res_len = res_len;
+  if (in_place) {
+    /* the small lists and the metadata walk's output go next to the block lists in the arena */
+    parallel_tasks(5, [&](size_t k) {
+      if (k == 0) memcpy((void*)apic.cus, cus.data(), cus.size() * sizeof(m355_cu));
+      else if (k == 1) memcpy((void*)apic.tus, tus.data(), tus.size() * sizeof(m355_tu));
+      else if (k == 2) memcpy((void*)apic.ctbs, ctbs.data(), ctbs.size() * sizeof(m355_ctb));
+      else if (k == 3) { memcpy((void*)apic.slices, slices.data(), slices.size() * sizeof(m355_slice)); if (!wts.empty()) memcpy((void*)apic.wts, wts.data(), wts.size() * sizeof(m355_wt)); }
+      else if (pic.scaling_factors) memcpy((void*)apic.scaling_factors, sf, sizeof(sf));
+    });
+    pic.slices = apic.slices; pic.ctbs = apic.ctbs; pic.cus = apic.cus; pic.tus = apic.tus; pic.pbs = apic.pbs; pic.wts = apic.wts;
+    pic.rbs = apic.rbs; pic.ibs = apic.ibs; pic.coeffs = apic.coeffs; pic.pcm = apic.pcm;
+    if (pic.scaling_factors) pic.scaling_factors = apic.scaling_factors;
+  } else {
+    pic.slices = slices.data(); pic.ctbs = ctbs.data(); pic.cus = cus.data(); pic.tus = tus.data(); pic.pbs = pbs.data();
+    pic.wts = wts.data(); pic.rbs = rbs.data(); pic.ibs = ibs.data(); pic.coeffs = coeffs.data(); pic.pcm = pcm.data();
+  }
 
   const auto t1 = std::chrono::steady_clock::now();
   const int rc = A->m355_submit_picture(g->mctx, &pic);
@@ -808,6 +927,7 @@ void generate_inter_prediction_samples(base_context* ctx, const slice_segment_he
   /* a FILL of a list that is not interpolated has no meaning for the kernels */
   for (int l = 0; l < 2; l++) if (!(pb.flags & (M355_PBF_MC_L0 << l))) pb.flags &= (uint8_t)~(M355_PBF_FILL_L0 << l);
   if (weighted) {
+    r->any_weighted = true;
     pb.flags |= M355_PBF_WEIGHTED;
     const unsigned si = img->get_SliceHeaderIndex(xP, yP);
     for (int l = 0; l < 2; l++) pb.wt_idx[l] = (uint16_t)(si * 32 + l * 16 + (vi->refIdx[l] & 15));
@@ -883,21 +1003,16 @@ LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)
   return e;
 }
 
-LIBDE265_API const struct de265_image* de265_peek_next_picture(de265_decoder_context* c)
+/* The application touches a decoded picture's samples through this call (de265.cc:729-738; dec265's writer, a player's
+ * upload): only then is the picture brought back from the device — an application that never looks (dec265 -q without -o, or one
+ * that takes the device frame by other means) costs no transfer at all. */
+LIBDE265_API const uint8_t* de265_get_image_plane(const struct de265_image* img, int channel, int* stride)
 {
-  decoder_context* ctx = (decoder_context*)c;
-  if (ctx->num_pictures_in_output_queue() <= 0) return nullptr;     /* de265.cc:437-449 */
-  de265_image* img = ctx->get_next_picture_in_output_queue();
-  Glue* g = glue_of(ctx);
-  if (g && img) download_if_needed(g, img);
-  return img;
-}
-
-LIBDE265_API const struct de265_image* de265_get_next_picture(de265_decoder_context* c)
-{
-  const struct de265_image* img = de265_peek_next_picture(c);      /* de265.cc:426-435 */
-  if (img) de265_release_next_picture(c);
-  return img;
+  if (img && img->decctx) {
+    Glue* g = glue_of(img->decctx);
+    if (g) download_if_needed(g, const_cast<de265_image*>(img));
+  }
+  return m355ref_de265_get_image_plane(img, channel, stride);
 }
 
 /* test / diagnostics hooks of this build (not part of de265.h) */

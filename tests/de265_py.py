@@ -74,7 +74,7 @@ def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=Fa
                     bpp = (lib.de265_get_bits_per_pixel(img, c) + 7) // 8
                     row = ctypes.c_char * (w * bpp)
                     for y in range(h):
-                        md5.update(row.from_address(p + y * stride.value * bpp))
+                        md5.update(row.from_address(p + y * stride.value))      # stride is in BYTES (de265.cc:735)
                 n += 1
                 if max_frames and n >= max_frames:
                     more.value = 0
