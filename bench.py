@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", type=int, default=31, help="DIAGNOSTIC ONLY: M355_STAGE_* mask (anything but 31 is not a valid benchmark)")
     ap.add_argument("--no-with-upload", action="store_true", help="skip the PCIe-inclusive legs (lists recorded into the pinned arena -> validation -> H2D -> decode, per step)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the bitstream-level leg (synthetic 8K stream through the reference CLI on the reference library and on the glue library)")
     ap.add_argument("--no-dependent-chain", action="store_true", help="skip the leg in which every picture references the two decoded before it")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
@@ -243,6 +244,10 @@ def main():
             out["dependent_chain"] = chain
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, synth, worklist)
+        if not args.no_end_to_end and world == 1:
+            e2e = end_to_end(cfg)
+            if e2e is not None:
+                out["end_to_end"] = e2e
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
@@ -348,6 +353,48 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
                 "exchange": {"halo_allreduce_bytes": xb[:3], "tile_allgather_bytes": xb[3]}}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
+
+
+def end_to_end(cfg):
+    """Bitstream level, through the reference's public API: a synthetic stream of the workload's geometry (oracle/_ref/streamgen:
+    I + P/B pictures, the workload's tiles and bit depth) decoded by the reference CLI (dec265 -q -t N) linked with (a) the
+    reference library — its SSE/AVX paths where it has them — and (b) glue/_build/libde265.so = the same parser with every pixel
+    produced by the MI355X backend.  Both are bounded by the reference's CABAC parser (one thread per tile); the figure that
+    isolates the backend is `value`.  None when the reference-side binaries are not in the tree."""
+    import re
+    import subprocess
+    import tempfile
+    gen = os.path.join(ROOT, "oracle", "_ref", "streamgen")
+    ref = os.path.join(ROOT, "oracle", "_ref", "dec265")
+    glue = os.path.join(ROOT, "glue", "_build", "dec265")
+    if not all(os.path.exists(p) for p in (gen, ref, glue)):
+        return None
+    try:
+        frames = 16
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "s.h265")
+            subprocess.run([gen, path, str(cfg["width"]), str(cfg["height"]), str(cfg["bit_depth"]), str(cfg["tile_cols"]), str(cfg["tile_rows"]),
+                            str(frames), "77", "5", "1", "1"], check=True, timeout=300)
+            size = os.path.getsize(path)
+            threads = max(1, min(32, cfg["tile_cols"] * cfg["tile_rows"]))   # the parser runs one thread per tile
+
+            def run(exe):
+                env = dict(os.environ, M355_PIPELINE_DEPTH="3")
+                env.pop("M355_LIB", None)
+                r = subprocess.run([exe, "-q", "-t", str(threads), path], capture_output=True, text=True, timeout=600, env=env)
+                m = re.search(r"nFrames decoded: (\d+) \(\d+x\d+ @\s*([0-9.]+) fps\)", r.stdout + r.stderr)
+                return (int(m.group(1)), float(m.group(2))) if m else (0, 0.0)
+            run(glue)                                                       # warm-up (device context, arenas)
+            nr, fr = run(ref)
+            ng, fg = run(glue)
+        ctbs = ((cfg["width"] + 63) // 64) * ((cfg["height"] + 63) // 64)
+        return {"stream": "%dx%d %d-bit, %dx%d tiles, %d pictures (I + P/B, 2 references), %d bytes; dec265 -q -t %d" %
+                          (cfg["width"], cfg["height"], cfg["bit_depth"], cfg["tile_cols"], cfg["tile_rows"], frames, size, threads),
+                "reference_fps": fr, "reference_ctb64_per_s": fr * ctbs, "mi355x_fps": fg, "mi355x_ctb64_per_s": fg * ctbs,
+                "pictures": [nr, ng], "speedup": (fg / fr) if fr > 0 else None,
+                "note": "both decoders spend most of each picture in the reference's CABAC / syntax parser (host, one thread per tile); the backend's own rate is `value` / `with_upload`"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
 
 
 def cpu_baseline(cfg, synth, worklist):

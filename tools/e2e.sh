@@ -15,7 +15,7 @@ run() { # name W H bd tc tr frames
   $R -q -t 8 -o /tmp/r.yuv /tmp/$n.h265 > /dev/null 2>&1; $M -q -t 8 -o /tmp/m.yuv /tmp/$n.h265 > /dev/null 2>&1
   echo "md5 ref $(md5sum < /tmp/r.yuv | cut -c1-32) glue $(md5sum < /tmp/m.yuv | cut -c1-32)" >> $OUT/e2e.txt
 }
-run s1080p 1920 1080 8 2 2 12
-run s4k10 3840 2160 10 2 2 8
-run s8k10 7680 4320 10 4 2 6
+run s1080p 1920 1080 8 2 2 40
+run s4k10 3840 2160 10 2 2 24
+run s8k10 7680 4320 10 4 2 16
 cat $OUT/e2e.txt
