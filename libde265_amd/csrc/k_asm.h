@@ -10,6 +10,11 @@
  * zero, letting the flag store overtake the L2 write-back (MI355X guide, "Compiler hazard"). */
 __device__ __forceinline__ void d_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+/* streaming stores (the `nt` bit): written samples do not displace the reference windows other workgroups are reading through the
+ * same L2 — k_inter_jobs' own output is next read a kernel later, when the 4 MB L2 of an XCD has long been turned over */
+__device__ __forceinline__ void d_st_nt4(void* p, unsigned v) { __builtin_nontemporal_store(v, (unsigned*)p); }
+__device__ __forceinline__ void d_st_nt8(void* p, unsigned v0, unsigned v1) { __builtin_nontemporal_store(v0, (unsigned*)p); __builtin_nontemporal_store(v1, (unsigned*)p + 1); }
+
 /* spin bound of k_intra's granule polls: ~2^22 polls x (one L2 round trip + s_sleep) is seconds — far beyond any real wait */
 #define M355_SPIN_LIMIT (1u << 22)
 

@@ -651,8 +651,9 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
           const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
           o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
         }
-        if (sizeof(PIX) == 2) *(uint2*)(d + (size_t)y * p.stride[0]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-        else *(unsigned*)(d + (size_t)y * p.stride[0]) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+        /* streaming stores (k_asm.h): -4 % kernel time, -10 % fabric fetch (profiles/r02_b_inter_variants.txt) */
+        if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+        else d_st_nt4(d + (size_t)y * p.stride[0], o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24));
       }
     }
   }
@@ -694,13 +695,13 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         {
           const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
           const unsigned o0 = (unsigned)d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd);
-          if (sizeof(PIX) == 2) *(unsigned*)(d1 + (size_t)y * p.stride[1]) = o0 | (o1 << 16);
+          if (sizeof(PIX) == 2) d_st_nt4(d1 + (size_t)y * p.stride[1], o0 | (o1 << 16));
           else *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)(o0 | (o1 << 8));
         }
         {
           const unsigned a = bi ? pa2[y] : cur2[y], b = cur2[y];
           const unsigned o0 = (unsigned)d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd);
-          if (sizeof(PIX) == 2) *(unsigned*)(d2 + (size_t)y * p.stride[2]) = o0 | (o1 << 16);
+          if (sizeof(PIX) == 2) d_st_nt4(d2 + (size_t)y * p.stride[2], o0 | (o1 << 16));
           else *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)(o0 | (o1 << 8));
         }
       }

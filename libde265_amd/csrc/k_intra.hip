@@ -272,12 +272,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      (every G-th) by broadcasting the record from the owning lane, then all waves meet at the workgroup barrier.  The
      loop bounds come from the records alone, so all waves (also those of absent components) execute the same
      barriers. */
-#ifdef M355_X_TIMING
-  long long tT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmark = clock64();
-#define TMARK(i) do { const long long n_ = clock64(); tT[i] += n_ - tmark; tmark = n_; } while (0)
-#else
-#define TMARK(i)
-#endif
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
     uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
     int lv = -1;
@@ -304,7 +298,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       }
       const int nT = 1 << ib.log2_size;
       const int xB = ib.x, yB = ib.y, lx = xB - x0c, ly = yB - y0c;
-      TMARK(0);
       /* does the block complete a piece of the CTB's right column / bottom row that a neighbour CTB may read? */
       const bool pub_col = lx + nT == cw && ctbX + 1 < p.ctbW, pub_row = ly + nT == ch && ctbY + 1 < p.ctbH;
 
@@ -397,7 +390,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         am[q] = __ballot(av);
       }
       wave_sync();
-      TMARK(1);
       /* ---- reference_sample_substitution (only when something is missing: the common interior block keeps its gathered
          border as it is) ---- */
       const bool none = (am[0] | am[1] | am[2]) == 0;
@@ -426,7 +418,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         wave_sync();
         pp_ = psub;
       }
-      TMARK(2);
       /* ---- intra_prediction_sample_filtering (intrapred.h:185-258) ---- */
       const int mode = ib.mode;
       uint16_t* P = pp_; /* border in use, entry index = i + 2nT */
@@ -459,8 +450,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
       }
 #define BRD(i) ((int)P[(i) + Z])
-
-      TMARK(3);
       /* ---- prediction (intrapred.h:261-433) ---- */
       const int log2 = ib.log2_size;
       int dcVal = 0;
@@ -478,7 +467,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const int sgn = mode >= 18 ? 1 : -1;
       const int inv = (mode >= 2 && angle < 0) ? c_intra_inv_angle[mode - 11] : 0;
 #define REFV(x_) ((x_) >= 0 ? BRD(sgn * (x_)) : BRD(-sgn * (((x_) * inv + 128) >> 8)))
-      TMARK(4);
       const bool has_res = (ib.flags & M355_IBF_HAS_RESIDUAL) != 0;
       const bool edge = (c == 0 && nT < 32);
       const bool bfilt = edge && !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER);
@@ -522,7 +510,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
       }
       wave_sync();
-      TMARK(5);
       /* ---- publish: the block's share of the CTB's right column / bottom row, two samples per granule ---- */
       if (pub_col && lane < (nT >> 1)) {
         const int y = ly + 2 * lane;
@@ -534,16 +521,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const uint32_t s0 = body[(ly + nT - 1) * BODY_PITCH + x + BODY_X0], s1 = body[(ly + nT - 1) * BODY_PITCH + x + 1 + BODY_X0];
         __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + x), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      TMARK(6);
     }   /* this wave's blocks of the level */
     if (multi) __syncthreads();
-    TMARK(7);   /* level done: its samples are in LDS for the next level's borders (one wave per component:
-                                     its own blocks are ordered by wave_sync above; components do not interact) */
+    /* level done: its samples are in LDS for the next level's borders (one wave per component: its own blocks are ordered
+       by wave_sync above; components do not interact) */
     }   /* levels in the batch */
   }   /* 64-record batches */
-#ifdef M355_X_TIMING
-  if (lane == 0 && wv == 0) for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)(p.timeout + 16) + i, (unsigned long long)tT[i]);
-#endif
 #undef SYNC_CTB
 }
 
@@ -551,11 +534,10 @@ template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, hipStream_t st)
 {
   hipMemsetAsync(p.ticket, 0, 4, st);
-  static const int nw_sparse = getenv("M355_INTRA_NW") ? atoi(getenv("M355_INTRA_NW")) : 4;     /* experiment knob */
+  /* dense intra pictures: 12 waves (up to 8 luma + 2 + 2 chroma blocks of a level at once); sparse ones: 4 (3 and 6 measured
+     slower) */
   if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 12>), dim3(p.n_intra_work), dim3(64 * 12), 0, st, p, p.n_intra_work);
-  else if (nw_sparse == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 3>), dim3(p.n_intra_work), dim3(64 * 3), 0, st, p, p.n_intra_work);
-  else if (nw_sparse == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 6>), dim3(p.n_intra_work), dim3(64 * 6), 0, st, p, p.n_intra_work);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work);
 }
 
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)

@@ -94,11 +94,7 @@ __device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb,
     /* the (pos, level) pairs are fetched eight per lane at a time: a dense 32x32 block holds 1024 of them, and one
        dependent load -> scatter step per pair (32 memory round trips per lane) was what the whole launch waited for */
     constexpr int GB = 8;
-#ifdef M355_X_NOCOEF            /* experiment: no coefficient pairs are fetched (all blocks empty) */
-    for (int k0 = c; k0 < 0; k0 += NT * GB) {
-#else
     for (int k0 = c; k0 < rb.ncoeff; k0 += NT * GB) {
-#endif
       uint32_t eb[GB];
 #pragma unroll
       for (int j = 0; j < GB; j++) {
@@ -139,11 +135,7 @@ __device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb,
 #pragma unroll
   for (int i = 0; i < NT; i++) res[i] = 0;
 
-#ifdef M355_X_NOXFORM_BIG       /* experiment (tools/variants.sh): no transform arithmetic for 16x16 / 32x32 — bounds what ANY faster transform could save */
-  if (any_tr && LOG2 < 4) {
-#else
   if (any_tr) {
-#endif
     const uint32_t dstmask = ((LOG2 == 2) && rb.kind == M355_RK_DST) ? ~0u : 0u;
     const uint32_t* mt = c_res.dct[LOG2 - 2];
     /* column pass: g[i][col] = clip16((sum_j M[j][i] * coef[j][col] + 64) >> 7), lane = (col, block) */
@@ -248,11 +240,7 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   uint32_t w[NVP];
 #pragma unroll
   for (int i = 0; i < NVP; i++) w[i] = 0;
-#ifdef M355_X_NORMW             /* experiment: inter residuals are neither read-modified nor written */
-  const bool rmw = false;
-#else
   const bool rmw = active && !(rb.flags & M355_RBF_DEFERRED);
-#endif
   PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
   if (rmw) {
     if (sizeof(PIX) == 2) {
@@ -298,9 +286,6 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   }
 
   if (!active) return;
-#ifdef M355_X_NORMW
-  if (!(rb.flags & M355_RBF_DEFERRED)) return;
-#endif
   const int y = c;
   if (rb.flags & M355_RBF_DEFERRED) {
     int16_t* out = p.resbuf + rb.res_ofs + y * NT;

@@ -1500,12 +1500,6 @@ int m355_wait(m355_ctx* c)
   for (auto& f : c->frames) { f.wr_pending = false; for (int k = 0; k < M355_MAX_LANES; k++) f.rd_pending[k] = false; }   /* everything is complete */
   uint32_t t = 0;
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
-  if (getenv("M355_INTRA_TIMING")) {   /* kernels built with -DM355_X_TIMING: clock sums of wave 0 of every CTB, per phase */
-    unsigned long long tt[8];
-    HIPCHK(hipMemcpy(tt, c->timeout + 16, sizeof(tt), hipMemcpyDeviceToHost));
-    fprintf(stderr, "m355 intra timing (clocks): rec %llu gather %llu subst %llu filter %llu ref %llu predict %llu publish %llu barrier %llu\n", tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], tt[7]);
-    hipMemset(c->timeout + 16, 0, sizeof(tt));
-  }
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].timeout) { uint32_t t2 = 0; HIPCHK(hipMemcpy(&t2, c->lanes[k].timeout, 4, hipMemcpyDeviceToHost)); t |= t2; }
   {
