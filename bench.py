@@ -308,33 +308,60 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
             ctx.frame_upload(f, synth.ref_planes(cfg["seed"] + 17 * i, int(pp["width"]), int(pp["height"]),
                                                  int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
             refs.append(f)
+        # pictures in flight, like the main line: `depth` copies of the picture's lists with their own destination frames go round the lanes
+        depth = max(1, args.pipeline_depth)
+        ctx.set_pipeline_depth(depth)
         sp = shard.shard_picture(pic, rank, world)
-        sp.dst_frame = ctx.frame_create_for(pp)
         sp.ref_frames = [refs[i] if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
-        h = dec.upload(sp)
-        for _ in range(args.warmup):
-            dec.decode(h)
+        hs, dsts = [], []
+        for _ in range(depth):
+            sp.dst_frame = ctx.frame_create_for(pp)
+            dsts.append(sp.dst_frame)
+            hs.append(dec.upload(sp))
+        h = hs[0]
+
+        def timed(gather):
+            for i in range(args.warmup):
+                dec.decode(hs[i % depth], gather=gather)
+            ctx.wait()
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                dec.decode(hs[i % depth], gather=gather)
+            ctx.wait()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        dt = timed(True)
+        dt_ng = timed(False)                # the same without the finished-tile all-gather (a non-reference picture)
+        # one picture at a time (latency of a single sharded picture)
         ctx.wait()
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        n1 = max(1, min(args.steps, 100))
+        for _ in range(n1):
             dec.decode(h)
-        ctx.wait()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # the same without the finished-tile all-gather (a non-reference picture)
-        dist.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            dec.decode(h, gather=False)
-        ctx.wait()
-        torch.cuda.synchronize()
+            ctx.wait()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_ng = float(t.item())
+        dt_one = float(t.item()) / n1
+        # the exchanges on their own (device time per collective, the buffers of this picture)
+        ex_ms = None
+        if world > 1:
+            ex_ms = []
+            for k in range(4):
+                buf = dec.xbufs[h][k]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(3):
+                    dec._exchange(buf, k)
+                torch.cuda.synchronize(); dist.barrier()
+                e0.record()
+                for _ in range(20):
+                    dec._exchange(buf, k)
+                e1.record(); torch.cuda.synchronize()
+                ex_ms.append(e0.elapsed_time(e1) / 20)
+        sp.dst_frame = dsts[0]
         dec.decode(h)                       # leave the complete picture behind for the check below
         ctx.wait()
         # every rank must now hold the identical, complete picture: compare a checksum of the frames
@@ -348,7 +375,9 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         dist.barrier()
         ctx.close()
         return {"value": args.steps * len(pic.ctbs) / dt, "unit": "CTB64/s", "ms_per_picture": 1e3 * dt / args.steps, "scaling": "strong",
+                "pictures_in_flight": depth, "ms_per_picture_one_at_a_time": 1e3 * dt_one,
                 "non_reference_picture": {"value": args.steps * len(pic.ctbs) / dt_ng, "ms_per_picture": 1e3 * dt_ng / args.steps},
+                "exchange_ms": ex_ms,
                 "tiles_per_rank": (cfg["tile_cols"] * cfg["tile_rows"]) / world, "frames_identical_on_all_ranks": bool(same),
                 "exchange": {"halo_allreduce_bytes": xb[:3], "tile_allgather_bytes": xb[3]}}
     except Exception as e:  # noqa: BLE001

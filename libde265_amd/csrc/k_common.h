@@ -122,6 +122,12 @@ __host__ __device__ inline bool m355_pb_is_edge(const m355_pb& pb, int width, in
   return false;
 }
 
+/* rectangles of one k_tiles_copy launch (finished tiles <-> all-gather buffer); wb / xb in bytes, ofs = byte offset in the buffer */
+struct TileCopyRect { uint32_t plane, xb, y, wb, h, pad; uint64_t ofs; };
+#define M355_TILE_COPY_RECTS 48
+struct TileCopyArgs { char* plane[3]; size_t pitch[3]; TileCopyRect r[M355_TILE_COPY_RECTS]; };
+void m355_launch_tiles_copy(const TileCopyArgs& a, int n, void* xbuf, bool to_slot, hipStream_t st);
+
 /* first statement of every kernel of a decode: a picture whose lists k_validate rejected is never acted upon */
 #define M355_GATE(p) do { if ((p).timeout[1] != 0u) return; } while (0)
 

@@ -175,3 +175,41 @@ void m355_launch_halo_unpack(const DevPic& p, const HaloLayout& h, bool hbd, int
   if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_unpack_samples<uint16_t>), dim3((n + 255) / 256), dim3(256), 0, st, p, h, which, n, (const uint16_t*)samples);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_halo_unpack_samples<uint8_t>), dim3((n + 255) / 256), dim3(256), 0, st, p, h, which, n, (const uint8_t*)samples);
 }
+
+/* ---- finished tiles <-> the all-gather buffer X3: every rectangle of a call in ONE launch (a picture with many tiles would
+ * otherwise cost a 2-D copy per tile and plane; the launches, not the bytes, were what phases 3 / 4 took) ---- */
+template <int V>
+__global__ void __launch_bounds__(256) k_tiles_copy(TileCopyArgs a, char* xbuf, int to_slot)
+{
+  const TileCopyRect r = a.r[blockIdx.y];
+  const unsigned upr = r.wb / V;                               /* V-byte units per row */
+  const unsigned long long total = (unsigned long long)upr * r.h;
+  char* plane = a.plane[r.plane] + (size_t)r.y * a.pitch[r.plane] + r.xb;
+  char* slot = xbuf + r.ofs;
+  for (unsigned long long u = (unsigned long long)blockIdx.x * 256 + threadIdx.x; u < total; u += (unsigned long long)gridDim.x * 256) {
+    const unsigned row = (unsigned)(u / upr), col = (unsigned)(u - (unsigned long long)row * upr);
+    char* pf = plane + (size_t)row * a.pitch[r.plane] + (size_t)col * V;
+    char* ps = slot + (size_t)row * r.wb + (size_t)col * V;
+    if (V == 16) { if (to_slot) *(uint4*)ps = *(const uint4*)pf; else *(uint4*)pf = *(const uint4*)ps; }
+    else { if (to_slot) *(uint32_t*)ps = *(const uint32_t*)pf; else *(uint32_t*)pf = *(const uint32_t*)ps; }
+  }
+}
+
+void m355_launch_tiles_copy(const TileCopyArgs& a, int n, void* xbuf, bool to_slot, hipStream_t st)
+{
+  if (n <= 0) return;
+  bool wide = ((uintptr_t)xbuf & 15) == 0;
+  unsigned long long most = 0;
+  for (int i = 0; i < n; i++) {
+    const TileCopyRect& r = a.r[i];
+    if ((r.wb | r.xb | r.ofs) & 15) wide = false;
+    const unsigned long long b = (unsigned long long)r.wb * r.h;
+    if (b > most) most = b;
+  }
+  for (int c = 0; c < 3; c++) if (((uintptr_t)a.plane[c] | a.pitch[c]) & 15) wide = false;
+  const int V = wide ? 16 : 4;
+  unsigned gx = (unsigned)((most / V + 256 * 8 - 1) / (256 * 8));      /* ~8 units per thread */
+  if (gx < 1) gx = 1;
+  if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tiles_copy<16>), dim3(gx, n), dim3(256), 0, st, a, (char*)xbuf, to_slot ? 1 : 0);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tiles_copy<4>), dim3(gx, n), dim3(256), 0, st, a, (char*)xbuf, to_slot ? 1 : 0);
+}

@@ -107,6 +107,7 @@ struct Resident {
   DevPic live;                 /* the descriptor prepared by phase 0, reused by phases 1..4 */
   bool live_sao = false, live_valid = false;
   void* xprev = nullptr;       /* exchange buffer handed to the previous phase */
+  int lane = 0;                /* the lane phase 0 ran on: the picture's working planes and scratch live there */
   hipEvent_t ev_up = nullptr;  /* lists copied to the device (decodes on the other lane wait for it) */
   hipEvent_t ev_done = nullptr; /* last decode of these lists finished: the arenas may be overwritten */
   bool done_pending = false;
@@ -261,25 +262,34 @@ static size_t slot_bytes(const m355_pic_params& pp, int nranks)
   for (int k = 0; k < nranks; k++) { const size_t b = tiles_bytes(pp, rank_tiles(pp, k, nranks)); if (b > m) m = b; }
   return m;
 }
-/* copy the tiles of `rank` between the frame planes and its slot (to_slot) or back */
-static int copy_tiles(m355_ctx* c, const m355_pic_params& pp, Frame* f, int rank, int nranks, char* slot, bool to_slot)
+/* copy the tiles of ranks [k0, k1) except `skip` between the frame planes and their slots of the all-gather buffer (to_slot) or
+   back: all rectangles in as few launches as the argument block allows */
+static int copy_tiles(m355_ctx* c, const m355_pic_params& pp, Frame* f, int k0, int k1, int skip, int nranks, char* xbuf, size_t slot, bool to_slot)
 {
   const int cf = pp.chroma_format_idc;
   const int sw = (cf == 1 || cf == 2) ? 2 : 1, sh = cf == 1 ? 2 : 1;
-  size_t o = 0;
-  for (const TileRect& r : rank_tiles(pp, rank, nranks))
-    for (int cc = 0; cc < 3; cc++) {
-      if (cc && !cf) continue;
-      const int x = cc ? r.x0 / sw : r.x0, y = cc ? r.y0 / sh : r.y0;
-      const int w = cc ? (r.x1 - r.x0) / sw : r.x1 - r.x0, h = cc ? (r.y1 - r.y0) / sh : r.y1 - r.y0;
-      const size_t bpp = f->bpp[cc], pitch = (size_t)f->stride[cc] * bpp, wb = (size_t)w * bpp;
-      char* fp = (char*)f->plane[cc] + (size_t)y * pitch + (size_t)x * bpp;
-      if (w > 0 && h > 0) {
-        if (to_slot) HIPCHK(hipMemcpy2DAsync(slot + o, wb, fp, pitch, wb, h, hipMemcpyDeviceToDevice, c->stream));
-        else HIPCHK(hipMemcpy2DAsync(fp, pitch, slot + o, wb, wb, h, hipMemcpyDeviceToDevice, c->stream));
+  TileCopyArgs a;
+  for (int cc = 0; cc < 3; cc++) { a.plane[cc] = (char*)f->plane[cc]; a.pitch[cc] = (size_t)f->stride[cc] * f->bpp[cc]; }
+  int n = 0;
+  for (int k = k0; k < k1; k++) {
+    if (k == skip) continue;
+    size_t o = slot * (size_t)k;
+    for (const TileRect& r : rank_tiles(pp, k, nranks))
+      for (int cc = 0; cc < 3; cc++) {
+        if (cc && !cf) continue;
+        const int x = cc ? r.x0 / sw : r.x0, y = cc ? r.y0 / sh : r.y0;
+        const int w = cc ? (r.x1 - r.x0) / sw : r.x1 - r.x0, h = cc ? (r.y1 - r.y0) / sh : r.y1 - r.y0;
+        const size_t bpp = f->bpp[cc], wb = (size_t)w * bpp;
+        if (w > 0 && h > 0) {
+          if ((wb | (x * bpp)) & 3) return fail(M355_ERR_INVALID, "tile rectangle is not a whole number of 32-bit words");
+          TileCopyRect& t = a.r[n++];
+          t.plane = (uint32_t)cc; t.xb = (uint32_t)(x * bpp); t.y = (uint32_t)y; t.wb = (uint32_t)wb; t.h = (uint32_t)h; t.pad = 0; t.ofs = o;
+          if (n == M355_TILE_COPY_RECTS) { m355_launch_tiles_copy(a, n, xbuf, to_slot, c->stream); n = 0; }
+        }
+        o += wb * h;
       }
-      o += wb * h;
-    }
+  }
+  m355_launch_tiles_copy(a, n, xbuf, to_slot, c->stream);
   return M355_OK;
 }
 
@@ -1383,6 +1393,12 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   if (phase < 0 || phase > 4 || (phase < 4 && !xbuf)) return fail(M355_ERR_INVALID, "bad phase / buffer");
   if (phase > 0 && !r.live_valid) return fail(M355_ERR_INVALID, "phase %d before phase 0", phase);
   hipSetDevice(c->device);
+  /* pictures in flight: phase 0 of consecutive pictures goes round the lanes like decode(); the later phases of a picture run
+     on the lane that holds its working planes.  m355_stream() is that lane's stream after every call, so the host orders its
+     exchange of this picture against it while other pictures' phases run on the other lanes. */
+  const bool piped = c->depth >= 2;
+  if (phase == 0) { if (piped) select_lane(c, (c->active + 1) % c->depth); r.lane = c->active; }
+  else if (r.lane != c->active) select_lane(c, r.lane);
   hipStream_t st = c->stream;
   const m355_pic_params& pp = r.hdr.pp;
   const bool hbd = pp.bit_depth_luma > 8;
@@ -1394,14 +1410,57 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   }
   const DevPic& d = r.live;
   const bool deblock = (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED);
+  Frame* dstf = get_frame(c, r.hdr.dst_frame);
+  auto dst_hazards = [&]() {     /* as in decode(): right before the first write of the destination frame */
+    if (!piped) return;
+    if (dstf->wr_pending) hipStreamWaitEvent(st, dstf->ev_wr, 0);
+    for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(st, dstf->ev_rd[k], 0);
+  };
+  auto dst_written = [&]() -> int {
+    if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+    hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
+    if (!piped) return M355_OK;
+    if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+    hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
+    return M355_OK;
+  };
   switch (phase) {
-    case 0:
-      m355_launch_meta(d, st);
+    case 0: {
+      if (piped) {
+        if (r.ev_up) hipStreamWaitEvent(st, r.ev_up, 0);
+        for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+          Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+          if (f && f->wr_pending) hipStreamWaitEvent(st, f->ev_wr, 0);
+        }
+      }
+      if (c->gate_used || r.device_validate) { hipMemsetAsync(c->timeout + 1, 0, 4, st); c->gate_used = r.device_validate ? 1 : 0; }
+      if (r.device_validate) m355_launch_validate(d, st);
+      if (!r.live_sao) dst_hazards();
+      if (pp.flags & M355_PF_CLEAR_DST) {
+        Frame* tgt = r.live_sao ? &c->work : dstf;
+        for (int cc = 0; cc < 3; cc++)
+          if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
+      }
+      /* metadata planes on the side stream beside job list -> inter prediction -> residual (as in decode()) */
+      hipEventRecord(c->ev_fork, st);
+      hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+      m355_launch_meta_planes(d, c->stream2);
+      hipEventRecord(c->ev_join, c->stream2);
+      m355_launch_meta_jobs(d, st);
       if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
       if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
+      hipStreamWaitEvent(st, c->ev_join, 0);
       if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
+      if (piped)      /* the reference frames are not read after this phase */
+        for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+          Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+          if (!f) continue;
+          if (frame_event(&f->ev_rd[c->active]) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+          hipEventRecord(f->ev_rd[c->active], st); f->rd_pending[c->active] = true;
+        }
       m355_launch_halo_pack(d, r.halo, hbd, 1, (char*)xbuf + meta_bytes, (uint32_t*)xbuf, st);
       break;
+    }
     case 1:
       m355_launch_halo_unpack(d, r.halo, hbd, 1, (const char*)r.xprev + meta_bytes, (const uint32_t*)r.xprev, st);
       if (deblock) m355_launch_deblock_pass(d, hbd, true, st);
@@ -1414,21 +1473,20 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
       break;
     case 3: {
       m355_launch_halo_unpack(d, r.halo, hbd, 3, r.xprev, nullptr, st);
-      if (r.live_sao) m355_launch_sao(d, hbd, st);
-      Frame* dst = get_frame(c, r.hdr.dst_frame);
-      const size_t slot = slot_bytes(pp, r.shard_n);
-      int rc = copy_tiles(c, pp, dst, r.shard_rank, r.shard_n, (char*)xbuf + slot * (size_t)r.shard_rank, true);
+      if (r.live_sao) { dst_hazards(); m355_launch_sao(d, hbd, st); }
+      if (r.shard_n > 1) {     /* (a single rank owns every tile: nothing to hand to anybody) */
+        int rc = copy_tiles(c, pp, dstf, r.shard_rank, r.shard_rank + 1, -1, r.shard_n, (char*)xbuf, slot_bytes(pp, r.shard_n), true);
+        if (rc) return rc;
+      }
+      int rc = dst_written();    /* a non-reference picture ends here: its tiles stay where they were decoded */
       if (rc) return rc;
       break;
     }
     case 4: {
-      Frame* dst = get_frame(c, r.hdr.dst_frame);
-      const size_t slot = slot_bytes(pp, r.shard_n);
-      for (int k = 0; k < r.shard_n; k++) {
-        if (k == r.shard_rank) continue;
-        int rc = copy_tiles(c, pp, dst, k, r.shard_n, (char*)r.xprev + slot * (size_t)k, false);
-        if (rc) return rc;
-      }
+      int rc = copy_tiles(c, pp, dstf, 0, r.shard_n, r.shard_rank, r.shard_n, (char*)r.xprev, slot_bytes(pp, r.shard_n), false);
+      if (rc) return rc;
+      rc = dst_written();
+      if (rc) return rc;
       r.live_valid = false;
       break;
     }

@@ -118,12 +118,20 @@ class ShardedDecoder:
         self.device = torch.device(device)
         self.ctx.shard_set(rank, nranks)
         self.xbufs = {}
-        self.stream = None
-        if self.device.type == "cuda":
-            # (torch's HIP runtime must have been initialised before the library's first HIP call in this
-            # process — torch.cuda.init() / set_device() first — or torch finds no device.)
-            # collectives are ordered against the library's own HIP stream
-            self.stream = torch.cuda.ExternalStream(int(ctx.stream()), device=self.device)
+        self._streams = {}
+        # (torch's HIP runtime must have been initialised before the library's first HIP call in this
+        # process — torch.cuda.init() / set_device() first — or torch finds no device.)
+
+    def _lane_stream(self):
+        """The library stream the picture's last phase was enqueued on (pictures in flight: one per lane) as a torch
+        stream, so the collective that follows is ordered after that phase and before the picture's next one."""
+        if self.device.type != "cuda":
+            return None
+        ptr = int(self.ctx.stream())
+        st = self._streams.get(ptr)
+        if st is None:
+            st = self._streams[ptr] = self.torch.cuda.ExternalStream(ptr, device=self.device)
+        return st
 
     def upload(self, pic_shard):
         h = self.ctx.upload(pic_shard)
@@ -139,9 +147,12 @@ class ShardedDecoder:
         self.ctx.decode_phase(h, k, self.xbufs[h][k].data_ptr() if k < 4 else None)
 
     def exchange(self, h, k):
+        if self.nranks == 1:
+            return                           # a single rank owns every tile: nothing to exchange
         buf = self.xbufs[h][k]
-        if self.stream is not None:
-            with self.torch.cuda.stream(self.stream):
+        st = self._lane_stream()
+        if st is not None:
+            with self.torch.cuda.stream(st):
                 self._exchange(buf, k)
         else:
             self.ctx.wait()                  # emulator: the "device" work is synchronous anyway
@@ -154,8 +165,11 @@ class ShardedDecoder:
             self.comm.all_gather_slots(buf)
 
     def decode(self, h, gather=True):
-        """All phases of one picture; asynchronous on the context's stream (GPU).  gather=False: a NON-reference
-        picture — the finished tiles stay where they were decoded (each rank outputs its own tiles), no X3."""
+        """All phases of one picture; asynchronous (GPU).  With ctx.set_pipeline_depth(n) consecutive pictures run on n lanes:
+        the exchanges and filter phases of one picture overlap the prediction phase of the next wherever the frames they touch
+        allow (every rank must then issue the same pictures in the same order — the collectives pair up by issue order).
+        gather=False: a NON-reference picture — the finished tiles stay where they were decoded (each rank outputs its own
+        tiles), no X3."""
         for k in range(5 if gather else 4):
             self.run_phase(h, k)
             if k < (4 if gather else 3):

@@ -56,17 +56,31 @@ def local_sharded_decode(lib, pic, refs, nranks, device="cpu", stages=worklist.S
             ctx.close()
 
 
-def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL, local_device=0):
-    """inside an initialised torch.distributed process group: this rank's destination planes"""
+def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL, local_device=0, depth=1):
+    """inside an initialised torch.distributed process group: this rank's destination planes.  depth > 1: pictures in
+    flight — the picture is decoded into `depth` destination frames back to back, and once more into the first (a
+    write-after-write on a frame whose previous decode may still be running); every frame must hold the same picture."""
     comm = shard.DistComm()
     ctx = capi.Context(lib, local_device)
     try:
         ctx.set_stages(stages)
+        ctx.set_pipeline_depth(depth)
         d = shard.ShardedDecoder(ctx, comm.rank, comm.nranks, comm=comm, device=device)
         sp, dst = _setup_rank(ctx, pic, refs, comm.rank, comm.nranks, device)
-        h = d.upload(sp)
-        d.decode(h)
+        hs, dsts = [d.upload(sp)], [dst]
+        for _ in range(depth - 1):
+            sp.dst_frame = ctx.frame_create_for(pic.pp[0])
+            dsts.append(sp.dst_frame)
+            hs.append(d.upload(sp))
+        for h in hs:
+            d.decode(h)
+        if depth > 1:
+            d.decode(hs[0])
         ctx.wait()
-        return ctx.frame_download(dst)
+        out = [ctx.frame_download(f) for f in dsts]
+        for o in out[1:]:
+            for a, b in zip(out[0], o):
+                assert np.array_equal(a, b), "pictures in flight: destination frames differ"
+        return out[0]
     finally:
         ctx.close()

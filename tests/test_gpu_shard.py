@@ -48,12 +48,14 @@ def test_sharded_baseline_configs(lib, oracle, name, nranks):
         assert_planes_equal(got, want, "%s rank %d of %d" % (name, r, nranks))
 
 
-def test_rccl_path_world_size_1(lib, oracle):
+@pytest.mark.parametrize("depth", [1, 3])
+def test_rccl_path_world_size_1(lib, oracle, depth):
     """the multi-process driver (ShardedDecoder + DistComm on the nccl backend, collectives ordered on the
     library's stream) with the one GPU this box has"""
-    cases = [dict(width=416, height=240, bit_depth=8, seed=63, tile_cols=2, tile_rows=2)]
+    cases = [dict(width=416, height=240, bit_depth=8, seed=63, tile_cols=2, tile_rows=2),
+             dict(width=1280, height=720, bit_depth=10, seed=64, tile_cols=3, tile_rows=2)]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "shard_worker.py"), "nccl", "default", json.dumps(cases)]
+           os.path.join(ROOT, "tests", "shard_worker.py"), "nccl", "default", json.dumps(cases), str(depth)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARD_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
