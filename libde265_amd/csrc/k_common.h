@@ -139,7 +139,7 @@ void m355_launch_meta(const DevPic& p, hipStream_t st);
 void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for k_inter */
 void m355_launch_meta_planes(const DevPic& p, hipStream_t st);   /* planes for intra / deblock / SAO */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
-void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st);   /* one direction (tile sharding) */

@@ -8,8 +8,8 @@
  * 269-407), transform_skip_residual / rdpcm_* / transform_bypass* / rotate_coefficients
  * (fallback-dct.cc:81-256) and add_residual (fallback-dct.h:65-73).
  *
- * Mapping: blocks are binned by size on the host (m355_picture.rb_count); ONE launch covers all four
- * sizes (largest first), a workgroup handles 4 * 64/nT blocks of one size.  Within a wave, lane =
+ * Mapping: blocks are binned by size on the host (m355_picture.rb_count); two launches (32/16 and 8/4, see
+ * k_residual below), a wave handles 64/nT blocks of one size.  Within a wave, lane =
  * (column c, block b): the sparse (pos,level) pairs are dequantised and scattered into an LDS tile
  * stored as vertical int16 PAIRS, so the column pass is v_dot2c_i32_i16 over (row 2q, row 2q+1) with
  * the matrix pair coming from a compile-time table in constant memory — the matrix entry depends only
@@ -57,7 +57,10 @@ __constant__ ResTables c_res = make_res_tables();
 
 __device__ __forceinline__ uint32_t d_sel_u(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
 
-#define RES_LDS_DWORDS (8 * (1024 + 32))   /* 32x32: 8 blocks per workgroup, nT^2/2 coefficient pairs + nT * (nT/2+1) first-stage pairs each */
+/* waves per workgroup: the waves of a workgroup never cooperate (wave_sync only), so ONE — the finest scheduling grain and the
+   smallest LDS footprint per workgroup (measured: within noise of 4 waves per workgroup, profiles/r02_b notes) */
+#define RES_WPG 1
+#define RES_LDS_DWORDS (2 * RES_WPG * (1024 + 32))   /* 32x32: 2 blocks per wave, nT^2/2 coefficient pairs + nT * (nT/2+1) first-stage pairs each */
 
 /* Residual of one block per lane group (all lanes of the wave call this together): res[] = row `c` of the block,
  * NT adjacent samples, before it is added to the picture / stored.  smem pointers are the lane group's tile. */
@@ -225,7 +228,7 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = lane & (NT - 1), b = lane >> LOG2;
-  const int tbi = (group * 4 + wave) * BPW + b;
+  const int tbi = (group * RES_WPG + wave) * BPW + b;
   const bool active = tbi < rb_n;
   uint32_t* cfp = smem + (wave * BPW + b) * BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
 
@@ -318,25 +321,38 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   }
 }
 
-/* groups of 32x32 blocks first (longest), then 16x16, 8x8, 4x4: ng5/ng4/ng3 = group counts of the larger sizes */
-template <class PIX>
-__global__ void __launch_bounds__(256) k_residual(DevPic p, int ng5, int ng4, int ng3)
+/* Two launches, issued side by side on the lane's two streams (runtime.hip, launch_prediction): 32x32 + 16x16 blocks (2 / 4 per
+ * wave; 128 VGPRs, 8 KB of LDS tiles per wave) and 8x8 + 4x4 blocks (8 / 16 per wave; 66 VGPRs -> 7 waves per SIMD instead of the
+ * 3 the 32-point transform's registers would impose on every size).  The stage is a chain of dependent round trips per wave —
+ * record, coefficient pairs, destination rows — so resident waves are what hides it.  Larger size first within each launch. */
+#define RES_LDS_DWORDS_SMALL (8 * RES_WPG * (4 * 8 + 8 * 5))   /* 8x8: 8 blocks per wave (4x4: 16 x 20 dwords fit too) */
+template <class PIX, bool BIG>
+__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual(DevPic p, int ng_hi)
 {
   M355_GATE(p);
-  __shared__ __attribute__((aligned(16))) uint32_t s_buf[RES_LDS_DWORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
   const int g = blockIdx.x;
-  if (g < ng5) d_residual_group<5, PIX>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
-  else if (g < ng5 + ng4) d_residual_group<4, PIX>(p, p.rb_bin[2], p.rb_count[2], g - ng5, s_buf);
-  else if (g < ng5 + ng4 + ng3) d_residual_group<3, PIX>(p, p.rb_bin[1], p.rb_count[1], g - ng5 - ng4, s_buf);
-  else d_residual_group<2, PIX>(p, p.rb_bin[0], p.rb_count[0], g - ng5 - ng4 - ng3, s_buf);
+  if (BIG) {
+    if (g < ng_hi) d_residual_group<5, PIX>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
+    else d_residual_group<4, PIX>(p, p.rb_bin[2], p.rb_count[2], g - ng_hi, s_buf);
+  } else {
+    if (g < ng_hi) d_residual_group<3, PIX>(p, p.rb_bin[1], p.rb_count[1], g, s_buf);
+    else d_residual_group<2, PIX>(p, p.rb_bin[0], p.rb_count[0], g - ng_hi, s_buf);
+  }
 }
 
-void m355_launch_residual(const DevPic& p, bool hbd, hipStream_t st)
+void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)
 {
-  /* blocks per workgroup: 4 waves * 64/nT */
-  const int ng2 = (p.rb_count[0] + 63) / 64, ng3 = (p.rb_count[1] + 31) / 32, ng4 = (p.rb_count[2] + 15) / 16, ng5 = (p.rb_count[3] + 7) / 8;
-  const int n = ng2 + ng3 + ng4 + ng5;
-  if (!n) return;
-  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint16_t>), dim3(n), dim3(256), 0, st, p, ng5, ng4, ng3);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint8_t>), dim3(n), dim3(256), 0, st, p, ng5, ng4, ng3);
+  /* blocks per workgroup: RES_WPG waves * 64/nT */
+  auto groups = [](int n, int per_wave) { return (n + per_wave * RES_WPG - 1) / (per_wave * RES_WPG); };
+  const int ng2 = groups(p.rb_count[0], 16), ng3 = groups(p.rb_count[1], 8), ng4 = groups(p.rb_count[2], 4), ng5 = groups(p.rb_count[3], 2);
+  const dim3 blk(64 * RES_WPG);
+  if (big && ng5 + ng4) {
+    if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint16_t, true>), dim3(ng5 + ng4), blk, 0, st, p, ng5);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint8_t, true>), dim3(ng5 + ng4), blk, 0, st, p, ng5);
+  }
+  if (!big && ng3 + ng2) {
+    if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint16_t, false>), dim3(ng3 + ng2), blk, 0, st, p, ng3);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint8_t, false>), dim3(ng3 + ng2), blk, 0, st, p, ng3);
+  }
 }

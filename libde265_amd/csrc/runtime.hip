@@ -125,7 +125,7 @@ struct Resident {
  * the next picture's prediction; frame hazards are ordered with per-frame events). */
 struct Lane {
   hipStream_t stream = nullptr, stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   Frame work;
   uint32_t *pb_of = nullptr, *ticket = nullptr, *timeout = nullptr;
   unsigned long long* edge = nullptr;   /* k_intra halo granules */
@@ -143,7 +143,7 @@ struct m355_ctx {
   int depth = 1, active = 0;   /* pipeline depth, index of the active lane */
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   std::vector<Frame> frames;
   std::vector<Resident> resident;
   Resident transient[3];       /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes */
@@ -167,7 +167,7 @@ struct m355_ctx {
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
 };
 
-#define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
+#define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
   X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao) X(gate_used)
 static void select_lane(m355_ctx* c, int lane)
 {
@@ -185,6 +185,7 @@ static int lane_create(m355_ctx* c, Lane& l)
   HIPCHK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&l.stream2, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&l.ev_fork2, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&l.ev_join, hipEventDisableTiming));
   HIPCHK(hipMalloc(&l.ticket, 64));
   HIPCHK(hipMalloc(&l.timeout, 128));
@@ -202,6 +203,7 @@ static void lane_destroy(Lane& l)
   void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb};
   for (void* b : bufs) if (b) hipFree(b);
   if (l.ev_fork) hipEventDestroy(l.ev_fork);
+  if (l.ev_fork2) hipEventDestroy(l.ev_fork2);
   if (l.ev_join) hipEventDestroy(l.ev_join);
   if (l.stream2) hipStreamDestroy(l.stream2);
   if (l.stream) hipStreamDestroy(l.stream);
@@ -1266,6 +1268,33 @@ static hipError_t frame_event(hipEvent_t* e)
   return hipEventCreateWithFlags(e, hipEventDisableTiming);
 }
 
+/* The prediction half of a decode on the active lane: the metadata planes (read first by k_intra) are rasterised on the side
+ * stream while the main stream runs job list -> inter prediction, which do not read them; the residual stage then runs in two
+ * launches side by side — 32x32 + 16x16 blocks on the main stream, 8x8 + 4x4 on the side stream — and k_intra follows the join.
+ * ev: the decode's timing events [1..4] (after meta jobs / inter / residual / intra) or nullptr. */
+static void launch_prediction(m355_ctx* c, const DevPic& d, bool hbd, hipEvent_t* ev)
+{
+  hipStream_t st = c->stream;
+  hipEventRecord(c->ev_fork, st);
+  hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+  m355_launch_meta_planes(d, c->stream2);
+  m355_launch_meta_jobs(d, st);
+  if (ev) hipEventRecord(ev[1], st);
+  if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
+  if (ev) hipEventRecord(ev[2], st);
+  if (c->stages & M355_STAGE_RESIDUAL) {
+    hipEventRecord(c->ev_fork2, st);                   /* inter residuals are added to the prediction samples */
+    hipStreamWaitEvent(c->stream2, c->ev_fork2, 0);
+    m355_launch_residual(d, hbd, false, c->stream2);
+    m355_launch_residual(d, hbd, true, st);
+  }
+  hipEventRecord(c->ev_join, c->stream2);
+  hipStreamWaitEvent(st, c->ev_join, 0);     /* join */
+  if (ev) hipEventRecord(ev[3], st);
+  if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
+  if (ev) hipEventRecord(ev[4], st);
+}
+
 static int decode(m355_ctx* c, Resident& r, bool rotate = true)
 {
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
@@ -1312,21 +1341,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
     for (int cc = 0; cc < 3; cc++)
       if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
   }
-  /* fork: the metadata planes (read first by k_intra) are rasterised on the side stream while the main
-     stream runs job list -> inter prediction -> residual, which do not read them */
-  hipEventRecord(c->ev_fork, st);
-  hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-  m355_launch_meta_planes(d, c->stream2);
-  hipEventRecord(c->ev_join, c->stream2);
-  m355_launch_meta_jobs(d, st);
-  hipEventRecord(ev[1], st);
-  if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
-  hipEventRecord(ev[2], st);
-  if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
-  hipStreamWaitEvent(st, c->ev_join, 0);     /* join */
-  hipEventRecord(ev[3], st);
-  if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
-  hipEventRecord(ev[4], st);
+  launch_prediction(c, d, hbd, ev);
   if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
   hipEventRecord(ev[5], st);
   if (want_sao) { dst_hazards(); m355_launch_sao(d, hbd, st); }
@@ -1441,16 +1456,7 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
         for (int cc = 0; cc < 3; cc++)
           if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
       }
-      /* metadata planes on the side stream beside job list -> inter prediction -> residual (as in decode()) */
-      hipEventRecord(c->ev_fork, st);
-      hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-      m355_launch_meta_planes(d, c->stream2);
-      hipEventRecord(c->ev_join, c->stream2);
-      m355_launch_meta_jobs(d, st);
-      if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
-      if (c->stages & M355_STAGE_RESIDUAL) m355_launch_residual(d, hbd, st);
-      hipStreamWaitEvent(st, c->ev_join, 0);
-      if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
+      launch_prediction(c, d, hbd, nullptr);
       if (piped)      /* the reference frames are not read after this phase */
         for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
           Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
