@@ -504,8 +504,11 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
 #ifndef M355_INTER_WAVES
 #define M355_INTER_WAVES 3   /* waves per SIMD the register budget is sized for (tools/variants.sh sweeps it) */
 #endif
+#ifndef M355_INTER_BLOCK
+#define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
+#endif
 template <class PIX, bool BIAS>
-__global__ void __launch_bounds__(256, M355_INTER_WAVES) k_inter_jobs(DevPic p, int nblk_edge8, int nblk_bi8)
+__global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jobs(DevPic p, int nblk_edge8, int nblk_bi8)
 {
   M355_GATE(p);
   __shared__ unsigned s_qt[4 * QT_STRIDE];
@@ -517,7 +520,7 @@ __global__ void __launch_bounds__(256, M355_INTER_WAVES) k_inter_jobs(DevPic p, 
   {
     const unsigned* src = (const unsigned*)p.refs;
     unsigned* dst = (unsigned*)s_refs;
-    for (int i = threadIdx.x; i < (int)(sizeof(s_refs) / 4); i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(s_refs) / 4); i += M355_INTER_BLOCK) dst[i] = src[i];
   }
   if (threadIdx.x < 4) {
     const int8_t* t = c_qpel_taps[threadIdx.x];
@@ -526,9 +529,9 @@ __global__ void __launch_bounds__(256, M355_INTER_WAVES) k_inter_jobs(DevPic p, 
     o[4] = d_pack16(0, t[0]);
     for (int k = 1; k < 4; k++) o[4 + k] = d_pack16(t[2 * k - 1], t[2 * k]);
     o[8] = d_pack16(t[7], 0);
-  } else if (threadIdx.x >= 64 && threadIdx.x < 72) {
-    const int8_t* t = c_epel_taps[threadIdx.x - 64];
-    unsigned* o = s_et + (threadIdx.x - 64) * ET_STRIDE;
+  } else if (threadIdx.x >= 8 && threadIdx.x < 16) {
+    const int8_t* t = c_epel_taps[threadIdx.x - 8];
+    unsigned* o = s_et + (threadIdx.x - 8) * ET_STRIDE;
     o[0] = d_pack16(t[0], t[1]); o[1] = d_pack16(t[2], t[3]);
     o[2] = d_pack16(0, t[0]); o[3] = d_pack16(t[1], t[2]); o[4] = d_pack16(t[3], 0);
   }
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(256, M355_INTER_WAVES) k_inter_jobs(DevPic p, 
      each range (= compact regions of the picture) so reference-window overlap hits that XCD's own L2. */
   const int b = blockIdx.x;
   if (b < nblk_edge8) {
-    const int ji = p.n_jobs_main + b * 256 + threadIdx.x;
+    const int ji = p.n_jobs_main + b * M355_INTER_BLOCK + threadIdx.x;
     if (ji < p.n_jobs) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et, s_refs);
     return;
   }
@@ -555,18 +558,18 @@ __global__ void __launch_bounds__(256, M355_INTER_WAVES) k_inter_jobs(DevPic p, 
   const int per = per_bi + per_uni;
   const int bi_before = (int)(((long long)slot * per_bi) / per), bi_after = (int)(((long long)(slot + 1) * per_bi) / per);
   if (bi_after != bi_before) {
-    const int ji = p.n_jobs_uni + (xcd * per_bi + bi_before) * 256 + threadIdx.x;
+    const int ji = p.n_jobs_uni + (xcd * per_bi + bi_before) * M355_INTER_BLOCK + threadIdx.x;
     if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   } else {
-    const int ji = (xcd * per_uni + slot - bi_before) * 256 + threadIdx.x;
+    const int ji = (xcd * per_uni + slot - bi_before) * M355_INTER_BLOCK + threadIdx.x;
     if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   }
 #else
   if (slot < per_bi) {
-    const int ji = p.n_jobs_uni + (xcd * per_bi + slot) * 256 + threadIdx.x;
+    const int ji = p.n_jobs_uni + (xcd * per_bi + slot) * M355_INTER_BLOCK + threadIdx.x;
     if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   } else {
-    const int ji = (xcd * per_uni + slot - per_bi) * 256 + threadIdx.x;
+    const int ji = (xcd * per_uni + slot - per_bi) * M355_INTER_BLOCK + threadIdx.x;
     if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   }
 #endif
@@ -713,10 +716,10 @@ template <class PIX, bool BIAS>
 static void launch_jobs(const DevPic& p, hipStream_t st)
 {
   /* grid padded to a multiple of 8 blocks for the XCD-contiguous block order */
-  auto blocks8 = [](int jobs) { return (((jobs + 255) / 256 + 7) / 8) * 8; };
+  auto blocks8 = [](int jobs) { return (((jobs + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK + 7) / 8) * 8; };
   const int nblk_uni8 = blocks8(p.n_jobs_uni), nblk_bi8 = blocks8(p.n_jobs_main - p.n_jobs_uni), nblk_edge8 = blocks8(p.n_jobs - p.n_jobs_main);
   if (!(nblk_uni8 + nblk_bi8 + nblk_edge8)) return;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(nblk_edge8 + nblk_bi8 + nblk_uni8), dim3(256), 0, st, p, nblk_edge8, nblk_bi8);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(nblk_edge8 + nblk_bi8 + nblk_uni8), dim3(M355_INTER_BLOCK), 0, st, p, nblk_edge8, nblk_bi8);
 }
 
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
