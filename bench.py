@@ -90,9 +90,14 @@ def main():
         ctx.frame_upload(f, synth.ref_planes(cfg["seed"] + 17 * i, int(pp["width"]), int(pp["height"]),
                                              int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
         refs.append(f)
-    pic.dst_frame = ctx.frame_create_for(pp)
     pic.ref_frames = [refs[i] if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
-    handle = ctx.upload(pic)
+    # one resident copy of the lists per picture in flight, each with its own destination frame (a decoder never reconstructs
+    # consecutive pictures into the same frame; with one shared frame a picture without SAO could not overlap its predecessor at all)
+    handles = []
+    for _ in range(max(1, args.pipeline_depth)):
+        pic.dst_frame = ctx.frame_create_for(pp)
+        handles.append(ctx.upload(pic))
+    handle = handles[0]
     ctx.wait()
     if args.stages != 31:
         ctx.set_stages(args.stages)
@@ -109,19 +114,19 @@ def main():
     ctx.wait()
     dt_serial = (time.perf_counter() - t0) * args.steps / side_steps
     n_dec, avg_total_ms, stage_ms = ctx.timing_collect()
-    # (2) THE timed region: the same K steps with two pictures in flight (m355_set_pipeline_depth: consecutive decodes
-    # alternate between two lanes; every step still runs the whole chain for one picture — here each step's SAO, the only
-    # stage writing the shared destination frame, is ordered after the previous step's by the frame events)
+    # (2) THE timed region: the same K steps with --pipeline-depth pictures in flight (m355_set_pipeline_depth: consecutive decodes
+    # go round the lanes; every step still runs the whole chain for one picture, into the next of `depth` destination frames —
+    # reusing a frame waits for its previous decode through the frame events)
     ctx.set_pipeline_depth(args.pipeline_depth)
-    for _ in range(args.warmup):
-        ctx.decode_resident(handle)
+    for i in range(args.warmup):
+        ctx.decode_resident(handles[i % len(handles)])
     ctx.wait()
     if dist:
         import torch
         dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.decode_resident(handle)
+    for i in range(args.steps):
+        ctx.decode_resident(handles[i % len(handles)])
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (launches are asynchronous)
     ctx.wait()
     if dist:
