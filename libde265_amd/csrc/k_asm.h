@@ -21,6 +21,16 @@ __device__ __forceinline__ void d_st_nt8(void* p, unsigned v0, unsigned v1) { __
 /* pointers loaded from device tables: tell hipcc they are global (else it emits flat_load) */
 #define M355_GLOBAL __attribute__((address_space(1)))
 
+/* request a cache line without using it: a later load of the same line then finds it in the L2 instead of paying a whole HBM
+ * round trip on a dependent chain (k_intra: the residuals of a CTB's blocks, consumed one dependency level at a time).  The
+ * data goes to a 256-byte LDS scratch area (global_load_lds_dword: lane i writes scratch[i]) that nobody reads: no VGPR is
+ * tied up and nothing ever waits for it. */
+__device__ __forceinline__ void d_touch(const void* p, unsigned* lds_scratch64)
+{
+  __builtin_amdgcn_global_load_lds((const M355_GLOBAL void*)p, (__attribute__((address_space(3))) void*)lds_scratch64, 4, 0, 0);
+}
+
+
 /* unaligned (2-byte / 1-byte aligned) vector loads from global memory: gfx950 executes them as single
  * global_load_dwordx4/x3/x2 (checked on hardware, tools/ubench/ub_inter.hip) */
 typedef unsigned m355_u4 __attribute__((ext_vector_type(4), aligned(1)));

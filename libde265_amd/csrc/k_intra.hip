@@ -43,11 +43,6 @@
 #define BODY_X0 8
 #define SPIN_LIMIT M355_SPIN_LIMIT   /* k_asm.h: bound on the polls for one granule (a list that promises a sample nobody produces) */
 
-__constant__ int8_t c_intra_angle[35] = {0,   0,   32,  26,  21,  17, 13, 9,  5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
-                                         -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9,  13, 17, 21,  26,  32};
-__constant__ int16_t c_intra_inv_angle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256,
-                                              -315,  -390,  -482, -630, -910, -1638, -4096};
-
 /* z-scan order inside a CTB (pps.cc:608-623 MinTbAddrZS, low bits): Morton code of the min-TB coordinates */
 __device__ __forceinline__ uint32_t d_spread4(uint32_t v) { v = (v | (v << 2)) & 0x33u; return (v | (v << 1)) & 0x55u; }
 __device__ __forceinline__ uint32_t d_morton(uint32_t x, uint32_t y) { return d_spread4(x) | (d_spread4(y) << 1); }
@@ -109,6 +104,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint16_t s_f[NWV][4 * 32 + 8];        /* filtered border */
   __shared__ uint32_t s_ticket;
   __shared__ uint32_t s_need[3][MAXCTB];         /* per component and CTB row, which 8-sample vectors some block's border reads */
+  __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
+  __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
   __shared__ uint32_t s_nts[9];                  /* CtbAddrRStoTS of the 3x3 CTB neighbourhood (0xFFFFFFFF outside the picture) */
   __shared__ uint8_t s_nsame[9];                 /* neighbour CTB in the picture, same slice (SliceAddrRS) and same tile */
 
@@ -175,6 +172,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      blocks: ~6 of its 512 luma vectors.  Samples that blocks of this CTB produce land in the same LDS tile later. ---- */
   if (comp && g == 0) {
     for (int y = lane; y < ch; y += 64) s_need[cs][y] = 0;
+    if (lane < 8) s_hneed[cs][lane] = 0;
     wave_sync();
     const int nvr = cw >> 3;                                /* vectors per row */
     for (uint32_t k = lane; k < ctbinfo.ib_count; k += 64) {
@@ -183,6 +181,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       if ((w1 & 0xFFu) != (uint32_t)c) continue;
       const int nT = 1 << ((w1 >> 8) & 0xFFu);
       const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
+      if (!RES_LDS && ((w1 >> 24) & M355_IBF_HAS_RESIDUAL) && !((w1 >> 24) & M355_IBF_PCM)) {
+        /* the block's residual is read when its dependency level comes up: ask for its cache lines now */
+        const char* rp_ = (const char*)(p.resbuf + r[2]);
+        for (int o = 0; o < nT * nT * 2; o += 128) d_touch(rp_ + o, s_touch);
+      }
       if (ly >= 1) {
         const int v0 = max(lx - 1, 0) >> 3, v1 = min((lx + 2 * nT - 1) >> 3, nvr - 1);
         if (v1 >= v0) atomicOr(&s_need[cs][ly - 1], ((2u << v1) - 1u) & ~((1u << v0) - 1u));
@@ -192,27 +195,53 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const int y1 = min(ly + 2 * nT, ch);
         for (int y = max(ly, 0); y < y1; y++) atomicOr(&s_need[cs][y], bit);
       }
+      /* halo entries behind this block's border: top[lx .. lx+2nT] for a block in the CTB's first row, left[ly-1 .. ly+2nT-1]
+         for one in its first column (ranges as 32-bit word masks) */
+      auto need_range = [&](int h0, int h1) {              /* halo entries h0 .. h1 inclusive */
+        for (int w = h0 >> 5; w <= (h1 >> 5); w++) {
+          const int a = max(h0 - 32 * w, 0), b = min(h1 - 32 * w, 31);
+          atomicOr(&s_hneed[cs][w], (b >= 31 ? ~0u : ((2u << b) - 1u)) & ~((1u << a) - 1u));
+        }
+      };
+      if (ly == 0) need_range(lx, min(lx + 2 * nT, 2 * cw));
+      if (lx == 0) need_range(2 * cw + 1 + max(ly - 1, 0), 2 * cw + 1 + min(ly + 2 * nT - 1, ch - 1));
     }
   }
   SYNC_CTB();
   if (comp) {
-    /* ---- stage those vectors: 8 samples each, all loads of a lane in flight at once ---- */
+    /* ---- stage those vectors: 8 samples each; four per lane are requested before the first is stored (a loop of
+       load -> store steps costs one memory round trip per step, and a CTB has up to eight steps per lane) ---- */
     {
       const int l2v = (l2c - csw) - 3;                       /* log2(vectors per row); cw >= 8 */
       const int nvec = ch << l2v;
-      for (int idx = lane + 64 * g; idx < nvec; idx += 64 * G) {
-        const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
-        if (!((s_need[cs][y] >> (xv >> 3)) & 1u)) continue;
-        if (x0c + xv < pw && y0c + y < ph) {
-          const PIX* src = plane + (size_t)(y0c + y) * stride + x0c + xv;
-          uint4 v;
-          if (sizeof(PIX) == 2) v = *(const uint4*)src;
-          else {
-            const uint2 b = *(const uint2*)src;
-            v.x = (b.x & 0xFFu) | ((b.x & 0xFF00u) << 8); v.y = ((b.x >> 16) & 0xFFu) | ((b.x >> 8) & 0xFF0000u);
-            v.z = (b.y & 0xFFu) | ((b.y & 0xFF00u) << 8); v.w = ((b.y >> 16) & 0xFFu) | ((b.y >> 8) & 0xFF0000u);
+      constexpr int U = 4;
+      for (int idx0 = lane + 64 * g; idx0 < nvec; idx0 += 64 * G * U) {
+        uint4 v[U];
+        bool take[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int idx = idx0 + u * 64 * G;
+          const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
+          take[u] = idx < nvec && ((s_need[cs][min(y, ch - 1)] >> (xv >> 3)) & 1u) && x0c + xv < pw && y0c + y < ph;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (take[u]) {
+            const PIX* src = plane + (size_t)(y0c + y) * stride + x0c + xv;
+            if (sizeof(PIX) == 2) v[u] = *(const uint4*)src;
+            else { const uint2 b = *(const uint2*)src; v[u].x = b.x; v[u].y = b.y; }
           }
-          *(uint4*)(body + y * BODY_PITCH + BODY_X0 + xv) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (!take[u]) continue;
+          const int idx = idx0 + u * 64 * G;
+          const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
+          uint4 o = v[u];
+          if (sizeof(PIX) == 1) {
+            const uint32_t bx = v[u].x, by = v[u].y;
+            o.x = (bx & 0xFFu) | ((bx & 0xFF00u) << 8); o.y = ((bx >> 16) & 0xFFu) | ((bx >> 8) & 0xFF0000u);
+            o.z = (by & 0xFFu) | ((by & 0xFF00u) << 8); o.w = ((by >> 16) & 0xFFu) | ((by >> 8) & 0xFF0000u);
+          }
+          *(uint4*)(body + y * BODY_PITCH + BODY_X0 + xv) = o;
         }
       }
     }
@@ -221,18 +250,40 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
        HALO_NOT_READY and the block that needs it polls for it.  Everything else was finished by the preceding kernels
        (stream order) and is read from the picture. ---- */
     const int nhalo = (2 * cw + 1) + ch;
-    for (int h = lane + 64 * g; h < nhalo; h += 64 * G) {
-      const bool is_top = h < 2 * cw + 1;
-      const int hx = is_top ? x0c - 1 + h : x0c - 1, hy = is_top ? y0c - 1 : y0c + (h - (2 * cw + 1));
-      uint32_t v = 0;
-      if (hx >= 0 && hy >= 0 && hx < pw && hy < ph) {
-        const uint32_t ci = d_cu_index_at(p, hx << csw, hy << csh);
-        if (ci != 0 && p.cus[ci - 1].pred_mode == 0) {
-          const m355_granule gr = __hip_atomic_load(is_top ? d_edge_row(p, cs, ctbY - 1, hx) : d_edge_col(p, cs, ctbX - 1, hy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          v = (uint32_t)(gr >> 32) == epoch ? (uint32_t)((gr >> (16 * ((is_top ? hx : hy) & 1))) & 0xFFFFu) : HALO_NOT_READY;
-        } else v = plane[(size_t)hy * stride + hx];
+    /* only the entries some block's border reads (s_hneed); per entry up to three dependent loads (CU plane -> CU record ->
+       sample or granule): the lane's (up to four) entries go through each step together */
+    {
+      constexpr int U = 4;
+      for (int h0 = lane + 64 * g; h0 < nhalo; h0 += 64 * G * U) {
+        int hx[U], hy[U];
+        bool in[U], top_[U];
+        uint32_t ci[U], val[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int h = h0 + u * 64 * G;
+          top_[u] = h < 2 * cw + 1;
+          hx[u] = top_[u] ? x0c - 1 + h : x0c - 1; hy[u] = top_[u] ? y0c - 1 : y0c + (h - (2 * cw + 1));
+          in[u] = h < nhalo && ((s_hneed[cs][min(h, nhalo - 1) >> 5] >> (h & 31)) & 1u) && hx[u] >= 0 && hy[u] >= 0 && hx[u] < pw && hy[u] < ph;
+          ci[u] = in[u] ? d_cu_index_at(p, hx[u] << csw, hy[u] << csh) : 0u;
+        }
+        bool intra[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) intra[u] = in[u] && ci[u] != 0 && p.cus[ci[u] - 1].pred_mode == 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          val[u] = 0;
+          if (intra[u]) {
+            const m355_granule gr = __hip_atomic_load(top_[u] ? d_edge_row(p, cs, ctbY - 1, hx[u]) : d_edge_col(p, cs, ctbX - 1, hy[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            val[u] = (uint32_t)(gr >> 32) == epoch ? (uint32_t)((gr >> (16 * ((top_[u] ? hx[u] : hy[u]) & 1))) & 0xFFFFu) : HALO_NOT_READY;
+          } else if (in[u]) val[u] = plane[(size_t)hy[u] * stride + hx[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int h = h0 + u * 64 * G;
+          if (h >= nhalo) continue;
+          if (top_[u]) top[h] = val[u]; else left[h - (2 * cw + 1)] = val[u];
+        }
       }
-      if (is_top) top[h] = v; else left[h - (2 * cw + 1)] = v;
     }
   }
   /* ---- residual pre-pass (intra pictures): the CTB's deferred residuals go to LDS, each component's waves taking its
@@ -302,15 +353,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const bool pub_col = lx + nT == cw && ctbX + 1 < p.ctbW, pub_row = ly + nT == ch && ctbY + 1 < p.ctbH;
 
       if (!(ib.flags & M355_IBF_PCM)) {
-      /* residual of this block (written by k_residual): issue the loads now, consume them after the
-         border/prediction chain — up to 16 samples per lane (32x32) */
-      int16_t rv[16];
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int o = lane + 64 * q;
-        rv[q] = (!RES_LDS && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
-      }
-
       /* ---- preproc (intrapred.h:436-531): CTB-level availability from the neighbourhood table ---- */
       const int xBL = xB * SubW, yBL = yB * SubH;
       bool aL = xBL != 0, aT = yBL != 0, aTL = xBL != 0 && yBL != 0, aTR = yBL != 0;
@@ -390,6 +432,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         am[q] = __ballot(av);
       }
       wave_sync();
+      /* residual of this block (written by k_residual; its cache lines were requested in the prologue): the loads are issued
+         here, BEHIND the border gather — hipcc drains the vector-memory counter in front of the gather's poll loop, so loads
+         issued before it are waited for at once — and consumed after substitution / smoothing, up to 16 samples per lane (32x32) */
+      int16_t rv[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int o = lane + 64 * q;
+        rv[q] = (!RES_LDS && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
+      }
       /* ---- reference_sample_substitution (only when something is missing: the common interior block keeps its gathered
          border as it is) ---- */
       const bool none = (am[0] | am[1] | am[2]) == 0;
@@ -463,9 +514,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       /* angular modes (intrapred.h:330-433): the projected reference array ref[] of the reference is not built — its entry x is
          border entry sgn*x for x >= 0 and, left of the corner (negative angles only), -sgn*((x*invAngle+128)>>8): the two taps
          of a sample are read straight from the border */
-      const int angle = c_intra_angle[mode];
+      /* intraPredAngle / invAngle (intrapred.h:313-326) from the distance d of the mode to the pure horizontal (10) / vertical
+         (26) mode, looked up in packed constants: a table in memory would be a dependent vector load per block (the mode is
+         per-lane data to the compiler), i.e. a memory round trip on the block chain — and, the vector-memory counter being
+         in-order, a wait for everything else this wave has in flight */
+      const int d_ang = mode >= 18 ? d_abs(mode - 26) : d_abs(mode - 10);                    /* 0..8 */
+      const int mag = (int)((0x20345488D1214100ull >> (7 * d_ang)) & 0x7Full);                 /* {0,2,5,9,13,17,21,26,32}, 7 bits each */
+      const bool neg = mode >= 18 ? mode < 26 : mode > 10;
+      const int angle = mode < 2 ? 0 : (neg ? -mag : mag);
       const int sgn = mode >= 18 ? 1 : -1;
-      const int inv = (mode >= 2 && angle < 0) ? c_intra_inv_angle[mode - 11] : 0;
+      /* invAngle = -round(8192 / |angle|): {4096,1638,910,630 | 482,390,315,256} for d = 1..8, 16 bits each */
+      const unsigned long long inv_tab = d_ang <= 4 ? 0x0276038E06661000ull : 0x0100013B018601E2ull;
+      const int inv = (mode >= 2 && angle < 0) ? -(int)((inv_tab >> (16 * ((d_ang - 1) & 3))) & 0xFFFFull) : 0;
 #define REFV(x_) ((x_) >= 0 ? BRD(sgn * (x_)) : BRD(-sgn * (((x_) * inv + 128) >> 8)))
       const bool has_res = (ib.flags & M355_IBF_HAS_RESIDUAL) != 0;
       const bool edge = (c == 0 && nT < 32);
