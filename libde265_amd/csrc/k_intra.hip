@@ -109,12 +109,16 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint32_t s_nts[9];                  /* CtbAddrRStoTS of the 3x3 CTB neighbourhood (0xFFFFFFFF outside the picture) */
   __shared__ uint8_t s_nsame[9];                 /* neighbour CTB in the picture, same slice (SliceAddrRS) and same tile */
 
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  /* everything derived from the wave index or from a block record is wave-uniform: say so (readfirstlane / readlane), so that
+     the component's plane pointers, pitches and granule offsets are scalar loads from the kernel arguments instead of vector
+     loads (each one a wait on the in-order vector-memory counter, i.e. on every sample store still in flight), record
+     fields live in SGPRs and the per-block branches are scalar */
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 
   if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
   __syncthreads();
   if ((int)s_ticket >= work_n) return;
-  const int ctb = (int)p.intra_work[(int)s_ticket];
+  const int ctb = __builtin_amdgcn_readfirstlane((int)p.intra_work[__builtin_amdgcn_readfirstlane((int)s_ticket)]);
   /* wave -> (colour component c, sub-wave g of G): GL luma waves, then GC for Cb, GC for Cr; the rest leave at once
      (finished waves do not take part in later barriers) */
   int GL, GC;
@@ -301,7 +305,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const int src = __ffsll(mine) - 1;
         mine &= mine - 1;
         if ((taken++ & (G - 1)) != g) continue;
-        const uint32_t w0 = __shfl(rw0, src, 64), w1 = __shfl(rw1, src, 64), w2 = __shfl(rw2, src, 64);
+        const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src), w2 = __builtin_amdgcn_readlane(rw2, src);
         const int flags = (int)(w1 >> 24), log2 = (int)((w1 >> 8) & 0xFFu), nT = 1 << log2;
         if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
         const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
       lv = p.ib_level[ctbinfo.ib_start + kbase + lane];
     }
-    const int lv_first = __shfl(lv, 0, 64), lv_last = __shfl(lv, nvalid - 1, 64);
+    const int lv_first = __builtin_amdgcn_readlane(lv, 0), lv_last = __builtin_amdgcn_readlane(lv, nvalid - 1);
     for (int L = lv_first; L <= lv_last; L++) {
     unsigned long long mine = __ballot((int)(comp && lv == L && (rw1 & 0xFFu) == (uint32_t)c));
     int rank = 0;
@@ -342,7 +346,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       if ((rank++ & (G - 1)) != g) continue;             /* another wave of this component takes it */
       m355_ib ib;
       {
-        const uint32_t w0 = __shfl(rw0, src, 64), w1 = __shfl(rw1, src, 64), w2 = __shfl(rw2, src, 64);
+        const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src), w2 = __builtin_amdgcn_readlane(rw2, src);
         ib.x = (uint16_t)(w0 & 0xFFFFu); ib.y = (uint16_t)(w0 >> 16);
         ib.cidx = (uint8_t)(w1 & 0xFFu); ib.log2_size = (uint8_t)((w1 >> 8) & 0xFFu); ib.mode = (uint8_t)((w1 >> 16) & 0xFFu); ib.flags = (uint8_t)(w1 >> 24);
         ib.res_ofs = w2;

@@ -196,6 +196,8 @@ template <class T> static inline T __builtin_amdgcn_readfirstlane(T v)
   return simt_exchange(v, __builtin_ctzll(live));
 }
 
+template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return simt_exchange(v, lane & 63); }
+
 /* atomics: one OS thread, fibers switch only at rendezvous points */
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
