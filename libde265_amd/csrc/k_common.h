@@ -26,6 +26,19 @@ struct DevRef {            /* one reference frame (indexed by m355_pb.ref_slot) 
   int pad;
 };
 
+/* k_intra's work item: everything a workgroup needs to know about its CTB in ONE 32-byte record (one scalar load behind the
+ * ticket instead of a chain of dependent lookups: work list -> CTB record -> neighbours' slices / tiles / scan positions) */
+struct DevIntraWork {
+  uint32_t ctb;                     /* raster address */
+  uint32_t ib_start, ib_count;      /* the CTB's intra blocks (sorted by dependency level) */
+  uint16_t nb_same;                 /* bit k: 3x3 neighbour k (row-major, 4 = the CTB itself) lies in the picture, in the same slice
+                                       (SliceAddrRS) and in the same tile */
+  uint16_t nb_earlier;              /* bit k: neighbour k precedes the CTB in decode (tile-scan) order */
+  uint8_t waves_code;               /* widest dependency level of the CTB (runtime.hip intra_schedule): 0..3 */
+  uint8_t pad[3];
+  uint32_t reserved[3];
+};
+
 struct DevPic {
   m355_pic_params pp;
   int sw, sh;                       /* SubWidthC, SubHeightC */
@@ -80,8 +93,8 @@ struct DevPic {
   int n_wts;
   uint32_t n_coeffs, n_pcm, res_len, ref_valid;   /* list lengths the records index into; bit s of ref_valid = ref_frames[s] is a frame */
   uint32_t epoch;                   /* value meaning "done" for this submission */
-  const uint32_t* intra_work;       /* raster addresses of the CTBs that hold intra blocks: first the n_intra_free CTBs that wait
-                                       for nobody, then the others in decode order */
+  const DevIntraWork* intra_work;   /* one descriptor per CTB that holds intra blocks: first the n_intra_free CTBs that wait for no
+                                       neighbour (longest first), then the dependent ones in decode order (k_intra's ticket order) */
   int n_intra_work, n_intra_free;
   const uint8_t* ctb_dep;           /* per CTB: bit n = reads intra output of neighbour n (0 L, 1 TL, 2 T, 3 TR; orders the work list);
                                        bit 4 = a neighbour reads ours; bits 5-6 = the CTB's widest level (0: 1 luma block, 1: 2, 2: 3-4, 3: more) -> waves in k_intra */

@@ -106,8 +106,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint32_t s_need[3][MAXCTB];         /* per component and CTB row, which 8-sample vectors some block's border reads */
   __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
   __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
-  __shared__ uint32_t s_nts[9];                  /* CtbAddrRStoTS of the 3x3 CTB neighbourhood (0xFFFFFFFF outside the picture) */
-  __shared__ uint8_t s_nsame[9];                 /* neighbour CTB in the picture, same slice (SliceAddrRS) and same tile */
 
   /* everything derived from the wave index or from a block record is wave-uniform: say so (readfirstlane / readlane), so that
      the component's plane pointers, pitches and granule offsets are scalar loads from the kernel arguments instead of vector
@@ -118,12 +116,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
   __syncthreads();
   if ((int)s_ticket >= work_n) return;
-  const int ctb = __builtin_amdgcn_readfirstlane((int)p.intra_work[__builtin_amdgcn_readfirstlane((int)s_ticket)]);
+  /* the CTB's descriptor (host-prepared, runtime.hip): one scalar 32-byte load */
+  const DevIntraWork* wp = p.intra_work + __builtin_amdgcn_readfirstlane((int)s_ticket);
+  const uint4 wd0 = *(const uint4*)wp;
+  const uint32_t wd1 = ((const uint32_t*)wp)[4];
+  const int ctb = __builtin_amdgcn_readfirstlane((int)wd0.x);
+  struct { uint32_t ib_start, ib_count; } ctbinfo = {(uint32_t)__builtin_amdgcn_readfirstlane((int)wd0.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)wd0.z)};
+  const uint32_t nb_same = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w & 0xFFFFu)), nb_earlier = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w >> 16));
   /* wave -> (colour component c, sub-wave g of G): GL luma waves, then GC for Cb, GC for Cr; the rest leave at once
      (finished waves do not take part in later barriers) */
   int GL, GC;
   {
-    const int code = (p.ctb_dep[ctb] >> 5) & 3;          /* widest level of the CTB: luma 1 / 2 / 3-4 / more blocks */
+    const int code = __builtin_amdgcn_readfirstlane((int)(wd1 & 3u));   /* widest level of the CTB: luma 1 / 2 / 3-4 / more blocks */
     GL = code == 0 ? 1 : (code == 1 ? 2 : (code == 2 || NW < 12 ? 4 : 8));
     GC = (code == 3 && NW >= 12) ? 2 : 1;
     if (GL > NW - 2) GL = NW - 2;
@@ -133,21 +137,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   const int G = c == 0 ? GL : GC, g = c == 0 ? wv : (wv - GL - (c - 1) * GC);
   const bool multi = GL + GC > 2;                        /* more than one wave per component somewhere: levels end in a barrier */
   const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
-  const m355_ctb ctbinfo = p.ctbs[ctb];
   const int l2c = p.pp.log2_ctb_size;
-
-  /* 3x3 CTB neighbourhood facts, once per CTB: every availability test of intrapred.h:486-508 / :534-633
-     (picture, slice, tile, z-scan order across CTBs) becomes an LDS lookup instead of dependent global loads */
-  if (threadIdx.x < 9) {
-    const int i = threadIdx.x, nx = ctbX + i % 3 - 1, ny = ctbY + i / 3 - 1;
-    uint32_t ts = 0xFFFFFFFFu; uint8_t same = 0;
-    if (nx >= 0 && ny >= 0 && nx < p.ctbW && ny < p.ctbH) {
-      const int n = ny * p.ctbW + nx;
-      ts = p.ctb_ts[n];
-      same = p.slices[p.ctbs[n].slice_idx].slice_addr_rs == p.slices[ctbinfo.slice_idx].slice_addr_rs && p.tile_id[n] == p.tile_id[ctb];
-    }
-    s_nts[i] = ts; s_nsame[i] = same;
-  }
 
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
   const bool comp = c < nc;
@@ -316,12 +306,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       }
     }
   }
-  __syncthreads();     /* neighbourhood table (wave 0), bodies, halos and residuals staged */
-  /* the 3x3 neighbourhood as two 9-bit masks in registers: same slice + tile / earlier in decode order than this CTB */
-  uint32_t nb_same = 0, nb_earlier = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++) { nb_same |= (uint32_t)(s_nsame[k] != 0) << k; nb_earlier |= (uint32_t)(s_nts[k] < s_nts[4]) << k; }
-
+  __syncthreads();     /* bodies, halos and residuals staged */
   /* The CTB's block records (sorted by level, then component) are fetched 64 at a time (one per lane, coalesced) by
      EVERY wave; for each level present in the batch, a wave takes the blocks of its component that fall to it
      (every G-th) by broadcasting the record from the owning lane, then all waves meet at the workgroup barrier.  The

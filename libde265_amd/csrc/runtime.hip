@@ -950,7 +950,7 @@ static void make_layout(const m355_arena_caps& k, int nCtb, int halo_units, bool
   L.i_ts = add(4 * (size_t)nCtb);   /* ctb_ts   */
   L.i_rs = add(4 * (size_t)nCtb);   /* ts2rs    */
   L.i_ti = add(2 * (size_t)nCtb);   /* tile_id  */
-  L.i_iw = add(4 * (size_t)nCtb);   /* intra_work */
+  L.i_iw = add(sizeof(DevIntraWork) * (size_t)nCtb);   /* intra_work */
   L.i_dp = add((size_t)nCtb);       /* ctb_dep */
   L.i_jb = add(12 * (size_t)(((size_t)k.n_pbs + 255) / 256 + 1));   /* job_base */
   L.i_ow = add(sharded ? (size_t)nCtb : 0);                          /* ctb_owner */
@@ -1012,7 +1012,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     srcs[i_co] = pic->coeffs; used[i_co] = 4 * (size_t)pic->n_coeffs;
     srcs[i_pc] = pic->pcm; used[i_pc] = 2 * (size_t)pic->n_pcm;
     srcs[i_sc] = pic->scaling_factors; used[i_sc] = pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0;
-    used[i_ts] = used[i_rs] = used[i_iw] = 4 * (size_t)nCtb; used[i_ti] = 2 * (size_t)nCtb; used[i_dp] = (size_t)nCtb;
+    used[i_ts] = used[i_rs] = 4 * (size_t)nCtb; used[i_iw] = sizeof(DevIntraWork) * (size_t)nCtb;   /* (cut down to the items in use below) */ used[i_ti] = 2 * (size_t)nCtb; used[i_dp] = (size_t)nCtb;
     used[i_jb] = 12 * (size_t)(n_chunks ? n_chunks : 1); used[i_ow] = sharded ? (size_t)nCtb : 0;
     for (int i = 0; i < ns; i++) { seg[i].src = srcs[i]; seg[i].bytes = used[i]; }
     if (in_place) {
@@ -1054,7 +1054,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   uint32_t* ctb_ts = (uint32_t*)(r.host + seg[i_ts].ofs);
   uint32_t* ts2rs = (uint32_t*)(r.host + seg[i_rs].ofs);
   uint16_t* tile_id = (uint16_t*)(r.host + seg[i_ti].ofs);
-  uint32_t* iw = (uint32_t*)(r.host + seg[i_iw].ofs);
+  DevIntraWork* iw = (DevIntraWork*)(r.host + seg[i_iw].ofs);
   uint32_t ts = 0; int tidx = 0;
   for (int ty = 0; ty < pp.num_tile_rows; ty++)
     for (int tx = 0; tx < pp.num_tile_cols; tx++) {
@@ -1079,11 +1079,30 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     for (int t = 0; t < nCtb; t++)
       if (pic->ctbs[ts2rs[t]].ib_count && !(dep[ts2rs[t]] & 15)) freec.push_back(std::make_pair(pic->ctbs[ts2rs[t]].ib_count, ts2rs[t]));
     std::stable_sort(freec.begin(), freec.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
-    for (const auto& e : freec) iw[nw++] = e.second;
+    /* a work item = the CTB's descriptor: block range, wave count code, and the 3x3 neighbourhood facts every availability
+       test of intrapred.h:486-508 / :534-633 needs (picture, slice, tile, decode order across CTBs) */
+    auto item = [&](uint32_t rs) {
+      DevIntraWork w;
+      memset(&w, 0, sizeof(w));
+      w.ctb = rs; w.ib_start = pic->ctbs[rs].ib_start; w.ib_count = pic->ctbs[rs].ib_count;
+      w.waves_code = (uint8_t)(log2_waves[rs] & 3);
+      const int cx = (int)rs % ctbW, cy = (int)rs / ctbW;
+      const uint32_t my_sa = pic->slices[pic->ctbs[rs].slice_idx].slice_addr_rs;
+      for (int k = 0; k < 9; k++) {
+        const int nx = cx + k % 3 - 1, ny = cy + k / 3 - 1;
+        if (nx < 0 || ny < 0 || nx >= ctbW || ny >= ctbH) continue;
+        const int n = ny * ctbW + nx;
+        if (pic->slices[pic->ctbs[n].slice_idx].slice_addr_rs == my_sa && tile_id[n] == tile_id[rs]) w.nb_same |= (uint16_t)(1u << k);
+        if (ctb_ts[n] < ctb_ts[rs]) w.nb_earlier |= (uint16_t)(1u << k);
+      }
+      iw[nw++] = w;
+    };
+    for (const auto& e : freec) item(e.second);
     n_free = nw;
     for (int t = 0; t < nCtb; t++)
-      if (pic->ctbs[ts2rs[t]].ib_count && (dep[ts2rs[t]] & 15)) iw[nw++] = ts2rs[t];
+      if (pic->ctbs[ts2rs[t]].ib_count && (dep[ts2rs[t]] & 15)) item(ts2rs[t]);
   }
+  seg[i_iw].bytes = sizeof(DevIntraWork) * (size_t)(nw ? nw : 1);
   r.n_intra_work = nw;
   {
     /* job counts per range (k_inter_jobs) and, per 256-PB chunk (= one k_meta_pb workgroup), the first job
@@ -1157,7 +1176,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.ctb_ts = (const uint32_t*)(r.dev + seg[i_ts].ofs);
   d.ts2rs = (const uint32_t*)(r.dev + seg[i_rs].ofs);
   d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
-  d.intra_work = (const uint32_t*)(r.dev + seg[i_iw].ofs);
+  d.intra_work = (const DevIntraWork*)(r.dev + seg[i_iw].ofs);
   d.n_intra_work = nw; d.n_intra_free = n_free;
   d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main; d.n_jobs_uni = r.n_jobs_uni;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
