@@ -113,11 +113,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      fields live in SGPRs and the per-block branches are scalar */
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 
-  if (threadIdx.x == 0) s_ticket = atomicAdd(p.ticket, 1u);
-  __syncthreads();
-  if ((int)s_ticket >= work_n) return;
+  /* work item: the first n_intra_free items are CTBs that wait for no neighbour — any workgroup may take any of them, so they go
+     by workgroup index (no atomic, no barrier); the dependent CTBs behind them are claimed through the ticket, in decode order,
+     so that a workgroup only ever waits on items claimed before its own (free ones, or lower tickets) */
+  int item = (int)blockIdx.x;
+  if (item >= p.n_intra_free) {          /* (uniform per workgroup) */
+    if (threadIdx.x == 0) s_ticket = (uint32_t)p.n_intra_free + atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane((int)s_ticket);
+  }
+  if (item >= work_n) return;
   /* the CTB's descriptor (host-prepared, runtime.hip): one scalar 32-byte load */
-  const DevIntraWork* wp = p.intra_work + __builtin_amdgcn_readfirstlane((int)s_ticket);
+  const DevIntraWork* wp = p.intra_work + item;
   const uint4 wd0 = *(const uint4*)wp;
   const uint32_t wd1 = ((const uint32_t*)wp)[4];
   const int ctb = __builtin_amdgcn_readfirstlane((int)wd0.x);
