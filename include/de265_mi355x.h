@@ -498,7 +498,10 @@ M355_API int m355_shard_owner_of_tile(int tile, int n_tiles, int nranks);
 M355_API int64_t m355_shard_xbuf_bytes(m355_ctx* ctx, int handle, int which);
 /* run one phase (0..4) of a resident picture; xbuf = the buffer the phase packs into (phases 0..3) —
  * the buffer it unpacks is the one passed to the previous phase, which must still be valid and hold
- * the exchanged contents.  Asynchronous on the context's stream (m355_stream()). */
+ * the exchanged contents.  Asynchronous.  With m355_set_pipeline_depth(ctx, n >= 2) consecutive pictures run on n lanes: phase 0
+ * takes the next lane, the later phases of a picture follow it there, frame hazards are ordered as for m355_decode_resident —
+ * the exchanges and filter phases of one picture overlap the prediction phase of the next.  After every call m355_stream() is
+ * the stream of the picture's lane: order the exchange that follows on it. */
 M355_API int m355_decode_phase(m355_ctx* ctx, int handle, int phase, void* xbuf);
 
 /* Per-stage device timing from HIP events recorded on the context's OWN stream around every decode
@@ -506,7 +509,7 @@ M355_API int m355_decode_phase(m355_ctx* ctx, int handle, int phase, void* xbuf)
  * [meta, inter, residual, intra, deblock, sao]. m355_timing_collect() waits for the work. */
 M355_API int m355_timing_reset(m355_ctx* ctx);
 M355_API int m355_timing_collect(m355_ctx* ctx, int* n_decodes, float* total_ms, float stage_ms[6]);
-M355_API void* m355_stream(m355_ctx* ctx);   /* hipStream_t of the context */
+M355_API void* m355_stream(m355_ctx* ctx);   /* hipStream_t of the context's active lane (the lane of the last decode / phase call) */
 
 #ifdef __cplusplus
 }
