@@ -291,8 +291,8 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       PIX* q = out + (size_t)(y0 + j) * os + x0;
-      if (sizeof(PIX) == 2) *(uint2*)q = make_uint2(O[j][0], O[j][1]);
-      else *(uint32_t*)q = d_perm(O[j][1], O[j][0], 0x06040200u);
+      if (sizeof(PIX) == 2) d_st_nt8(q, O[j][0], O[j][1]);
+      else d_st_nt4(q, d_perm(O[j][1], O[j][0], 0x06040200u));
     }
     return;
   }
@@ -335,8 +335,8 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
   for (int j = 0; j < 4; j++) {
     if (j >= rows) break;
     PIX* q = out + (size_t)(y0 + j) * os + x0;
-    if (sizeof(PIX) == 2) *(uint2*)q = make_uint2((uint32_t)res[j][0] | ((uint32_t)res[j][1] << 16), (uint32_t)res[j][2] | ((uint32_t)res[j][3] << 16));
-    else *(uint32_t*)q = (uint32_t)res[j][0] | ((uint32_t)res[j][1] << 8) | ((uint32_t)res[j][2] << 16) | ((uint32_t)res[j][3] << 24);
+    if (sizeof(PIX) == 2) d_st_nt8(q, (uint32_t)res[j][0] | ((uint32_t)res[j][1] << 16), (uint32_t)res[j][2] | ((uint32_t)res[j][3] << 16));
+    else d_st_nt4(q, (uint32_t)res[j][0] | ((uint32_t)res[j][1] << 8) | ((uint32_t)res[j][2] << 16) | ((uint32_t)res[j][3] << 24));
   }
 }
 
