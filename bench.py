@@ -359,11 +359,11 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
                 buf = dec.xbufs[h][k]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 for _ in range(3):
-                    dec._exchange(buf, k)
+                    dec._exchange(buf, k, h)
                 torch.cuda.synchronize(); dist.barrier()
                 e0.record()
                 for _ in range(20):
-                    dec._exchange(buf, k)
+                    dec._exchange(buf, k, h)
                 e1.record(); torch.cuda.synchronize()
                 ex_ms.append(e0.elapsed_time(e1) / 20)
         sp.dst_frame = dsts[0]
@@ -382,7 +382,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         return {"value": args.steps * len(pic.ctbs) / dt, "unit": "CTB64/s", "ms_per_picture": 1e3 * dt / args.steps, "scaling": "strong",
                 "pictures_in_flight": depth, "ms_per_picture_one_at_a_time": 1e3 * dt_one,
                 "non_reference_picture": {"value": args.steps * len(pic.ctbs) / dt_ng, "ms_per_picture": 1e3 * dt_ng / args.steps},
-                "exchange_ms": ex_ms,
+                "exchange_ms": ex_ms, "halo_exchange": dec.halo,
                 "tiles_per_rank": (cfg["tile_cols"] * cfg["tile_rows"]) / world, "frames_identical_on_all_ranks": bool(same),
                 "exchange": {"halo_allreduce_bytes": xb[:3], "tile_allgather_bytes": xb[3]}}
     except Exception as e:  # noqa: BLE001

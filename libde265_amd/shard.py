@@ -6,15 +6,16 @@ receives only those tiles' work lists (`shard_picture` cuts a whole-picture list
 and the benchmark; a real host parses just its tiles), and runs the five phases of a picture with an
 exchange after each of the first four:
 
-    X0  border-unit metadata + pre-deblock column strips   -> SUM all-reduce  (deblock.cc:191-209, :243-383)
-    X1  post-vertical-pass row strips                       -> SUM all-reduce  (deblock.cc:919-939)
-    X2  deblocked column + row strips (SAO ring)            -> SUM all-reduce  (sao.cc:83-88, :158-163)
+    X0  border-unit metadata + pre-deblock column strips   -> halo sum  (deblock.cc:191-209, :243-383)
+    X1  post-vertical-pass row strips                       -> halo sum  (deblock.cc:919-939)
+    X2  deblocked column + row strips (SAO ring)            -> halo sum  (sao.cc:83-88, :158-163)
     X3  finished tiles of the destination frame             -> all-gather      (reference for later pictures)
 
 The buffers are torch tensors (device memory handed to RCCL through torch.distributed; CPU tensors when
 the kernel-logic emulator of the test tier is the library).  Every element of X0..X2 is produced by
-exactly one rank and zero elsewhere, so an integer SUM all-reduce completes them whatever the tile ->
-rank map is; traffic is a few hundred kB per picture, i.e. latency-bound on xGMI.  X3 is the real
+exactly one rank and zero elsewhere, so a sum completes them whatever the tile -> rank map is: by default a point-to-point
+exchange with the ranks that own adjacent tiles (`neighbour_ranks`: one hop, the only producers of what a rank reads), or
+an integer SUM all-reduce over all ranks (`halo="allreduce"`); traffic is a few hundred kB per picture, i.e. latency-bound on xGMI.  X3 is the real
 volume (one picture per reference picture, 1/nranks of it sent by each rank).
 """
 import numpy as np
@@ -92,6 +93,26 @@ def shard_picture(pic, rank, nranks):
     return out
 
 
+def neighbour_ranks(pp, rank, nranks):
+    """Ranks that own a tile touching (edge or corner) a tile of `rank`: the only ranks whose halo elements `rank` consumes —
+    deblocking reads across an edge, SAO the 1-sample ring incl. the diagonal corner.  Symmetric by construction."""
+    ntc, ntr = int(pp["num_tile_cols"]), int(pp["num_tile_rows"])
+    n = ntc * ntr
+    out = set()
+    for ty in range(ntr):
+        for tx in range(ntc):
+            if owner_of_tile(ty * ntc + tx, n, nranks) != rank:
+                continue
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    x, y = tx + dx, ty + dy
+                    if 0 <= x < ntc and 0 <= y < ntr:
+                        q = owner_of_tile(y * ntc + x, n, nranks)
+                        if q != rank:
+                            out.add(q)
+    return sorted(out)
+
+
 class DistComm:
     """Exchanges over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
 
@@ -103,6 +124,26 @@ class DistComm:
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def neighbour_sum(self, t, peers, scratch):
+        """t += the same buffer of every rank in `peers` (point-to-point: one hop per neighbour instead of a ring / tree over all
+        ranks; every element of a halo buffer has exactly one producer, and only adjacent ranks produce what this one reads).
+        `scratch[i]` receives peer i's buffer.  Peers must list each other (neighbour_ranks is symmetric)."""
+        if not peers:
+            return
+        d = self.dist
+        g = self.group
+
+        def gr(q):                                       # rank inside `group` -> global rank (P2POp takes global ranks)
+            return d.get_global_rank(g, q) if g is not None else q
+        ops = []
+        for q, tmp in zip(peers, scratch):
+            ops.append(d.P2POp(d.isend, t, gr(q), group=g))
+            ops.append(d.P2POp(d.irecv, tmp, gr(q), group=g))
+        for r in d.batch_isend_irecv(ops):
+            r.wait()
+        for tmp in scratch[:len(peers)]:
+            t.add_(tmp)
+
     def all_gather_slots(self, t):
         n = t.numel() // self.nranks
         self.dist.all_gather_into_tensor(t, t[self.rank * n:(self.rank + 1) * n].clone(), group=self.group)
@@ -111,13 +152,16 @@ class DistComm:
 class ShardedDecoder:
     """One rank's executor: context + exchange buffers + the phase loop."""
 
-    def __init__(self, ctx, rank, nranks, comm=None, device="cuda"):
+    def __init__(self, ctx, rank, nranks, comm=None, device="cuda", halo="p2p"):
         import torch
         self.torch = torch
         self.ctx, self.rank, self.nranks, self.comm = ctx, rank, nranks, comm
         self.device = torch.device(device)
         self.ctx.shard_set(rank, nranks)
         self.xbufs = {}
+        self.halo = halo                     # "p2p": halos from the neighbour ranks only; "allreduce": SUM all-reduce over all ranks
+        self.peers = {}                      # picture handle -> neighbour ranks
+        self.scratch = {}
         self._streams = {}
         # (torch's HIP runtime must have been initialised before the library's first HIP call in this
         # process — torch.cuda.init() / set_device() first — or torch finds no device.)
@@ -137,11 +181,15 @@ class ShardedDecoder:
         h = self.ctx.upload(pic_shard)
         self.xbufs[h] = [self.torch.zeros(max(1, self.ctx.shard_xbuf_bytes(h, k) // 4), dtype=self.torch.int32, device=self.device)
                          for k in range(4)]
+        self.peers[h] = neighbour_ranks(pic_shard.pp[0], self.rank, self.nranks) if self.nranks > 1 else []
+        if self.halo == "p2p" and self.peers[h]:
+            big = max(self.xbufs[h][k].numel() for k in range(3))
+            self.scratch[h] = [self.torch.empty(big, dtype=self.torch.int32, device=self.device) for _ in self.peers[h]]
         return h
 
     def release(self, h):
         self.ctx.release(h)
-        self.xbufs.pop(h, None)
+        self.xbufs.pop(h, None); self.peers.pop(h, None); self.scratch.pop(h, None)
 
     def run_phase(self, h, k):
         self.ctx.decode_phase(h, k, self.xbufs[h][k].data_ptr() if k < 4 else None)
@@ -153,14 +201,17 @@ class ShardedDecoder:
         st = self._lane_stream()
         if st is not None:
             with self.torch.cuda.stream(st):
-                self._exchange(buf, k)
+                self._exchange(buf, k, h)
         else:
             self.ctx.wait()                  # emulator: the "device" work is synchronous anyway
-            self._exchange(buf, k)
+            self._exchange(buf, k, h)
 
-    def _exchange(self, buf, k):
+    def _exchange(self, buf, k, h=None):
         if k < 3:
-            self.comm.all_reduce_sum(buf)
+            if self.halo == "p2p" and h is not None:
+                self.comm.neighbour_sum(buf, self.peers[h], [t[:buf.numel()] for t in self.scratch.get(h, [])])
+            else:
+                self.comm.all_reduce_sum(buf)
         else:
             self.comm.all_gather_slots(buf)
 

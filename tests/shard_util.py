@@ -56,7 +56,7 @@ def local_sharded_decode(lib, pic, refs, nranks, device="cpu", stages=worklist.S
             ctx.close()
 
 
-def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL, local_device=0, depth=1):
+def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL, local_device=0, depth=1, halo="p2p"):
     """inside an initialised torch.distributed process group: this rank's destination planes.  depth > 1: pictures in
     flight — the picture is decoded into `depth` destination frames back to back, and once more into the first (a
     write-after-write on a frame whose previous decode may still be running); every frame must hold the same picture."""
@@ -65,7 +65,7 @@ def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL,
     try:
         ctx.set_stages(stages)
         ctx.set_pipeline_depth(depth)
-        d = shard.ShardedDecoder(ctx, comm.rank, comm.nranks, comm=comm, device=device)
+        d = shard.ShardedDecoder(ctx, comm.rank, comm.nranks, comm=comm, device=device, halo=halo)
         sp, dst = _setup_rank(ctx, pic, refs, comm.rank, comm.nranks, device)
         hs, dsts = [d.upload(sp)], [dst]
         for _ in range(depth - 1):

@@ -21,6 +21,7 @@ def main():
 
     backend, libpath, cases = sys.argv[1], sys.argv[2], json.loads(sys.argv[3])
     depth = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    halo = sys.argv[5] if len(sys.argv) > 5 else "p2p"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
@@ -33,7 +34,7 @@ def main():
         pic, refs = make_case(**case)
         want = oracle_decode(o, pic, refs)
         got = dist_sharded_decode(lib, pic, refs, device="cuda:%d" % local_rank if backend == "nccl" else "cpu",
-                                  local_device=local_rank if backend == "nccl" else 0, depth=depth)
+                                  local_device=local_rank if backend == "nccl" else 0, depth=depth, halo=halo)
         assert_planes_equal(got, want, "rank %d case %s" % (dist.get_rank(), case))
     dist.barrier()
     if dist.get_rank() == 0:
