@@ -160,6 +160,7 @@ class ShardedDecoder:
         self.ctx.shard_set(rank, nranks)
         self.xbufs = {}
         self.halo = halo                     # "p2p": halos from the neighbour ranks only; "allreduce": SUM all-reduce over all ranks
+        self._ptrs = {}
         self.peers = {}                      # picture handle -> neighbour ranks
         self.scratch = {}
         self._streams = {}
@@ -181,6 +182,7 @@ class ShardedDecoder:
         h = self.ctx.upload(pic_shard)
         self.xbufs[h] = [self.torch.zeros(max(1, self.ctx.shard_xbuf_bytes(h, k) // 4), dtype=self.torch.int32, device=self.device)
                          for k in range(4)]
+        self._ptrs[h] = [t.data_ptr() for t in self.xbufs[h]]
         self.peers[h] = neighbour_ranks(pic_shard.pp[0], self.rank, self.nranks) if self.nranks > 1 else []
         if self.halo == "p2p" and self.peers[h]:
             big = max(self.xbufs[h][k].numel() for k in range(3))
@@ -189,10 +191,10 @@ class ShardedDecoder:
 
     def release(self, h):
         self.ctx.release(h)
-        self.xbufs.pop(h, None); self.peers.pop(h, None); self.scratch.pop(h, None)
+        self.xbufs.pop(h, None); self._ptrs.pop(h, None); self.peers.pop(h, None); self.scratch.pop(h, None)
 
     def run_phase(self, h, k):
-        self.ctx.decode_phase(h, k, self.xbufs[h][k].data_ptr() if k < 4 else None)
+        self.ctx.decode_phase(h, k, self._ptrs[h][k] if k < 4 else None)
 
     def exchange(self, h, k):
         if self.nranks == 1:
