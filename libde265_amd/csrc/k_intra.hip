@@ -11,9 +11,11 @@
  * left / above / above-right neighbours, so the blocks of one CTB form a serial chain and CTBs form
  * the classic WPP wavefront (needs CTB (x+1,y-1)).  This is the reference's ctb_progress protocol
  * (image.h:76-80, slice.cc:4789-4795) moved onto the device:
- *   - one workgroup per CTB that contains intra blocks; CTBs are claimed from an atomic ticket in
- *     DECODE (tile-scan) order, so a workgroup only ever waits on CTBs claimed before it — no
- *     residency assumption, no deadlock;
+ *   - one workgroup per CTB that contains intra blocks, described by one host-prepared 32-byte record (DevIntraWork: block
+ *     range, wave count, the 3x3 neighbourhood's slice / tile / decode-order facts).  CTBs that read no intra sample of a
+ *     neighbour are taken by workgroup index; the dependent ones are claimed from an atomic ticket in DECODE (tile-scan)
+ *     order, so a workgroup only ever waits on CTBs claimed before it (or on ticket-free ones, which wait for nobody and
+ *     are dispatched first);
  *   - dependencies between CTBs are tracked at the granularity of the SAMPLES ACTUALLY READ, not per CTB: a block that
  *     finishes a piece of its CTB's right column or bottom row publishes those samples as 8-byte granules
  *     {tag = this decode's epoch, two samples} with agent-scope (write-through) stores — "the data is the flag"
@@ -78,9 +80,10 @@ __device__ __forceinline__ m355_granule* d_edge_col(const DevPic& p, int c, int 
 __device__ __forceinline__ m355_granule* d_edge_row(const DevPic& p, int c, int row, int x) { return p.edge + p.edge_row_ofs[c] + (size_t)row * (size_t)(p.pw[c] >> 1) + (size_t)(x >> 1); }
 
 /* NW = waves per workgroup: 12 for intra pictures (CTBs with hundreds of blocks: up to 8 luma + 2 + 2 chroma waves share a
- * level, the CTB's residuals are fetched into LDS up front), 6 for inter pictures (a handful of intra blocks per CTB: up to
- * 4 + 1 + 1 waves, residuals fetched per block under its border phase; the smaller footprint keeps ~2.5x as many CTBs in
- * flight).  The CTB's own wave counts come from ctb_dep bits 5-6 (runtime.hip intra_schedule). */
+ * level, the CTB's residuals are fetched into LDS up front), 4 for inter pictures (a handful of intra blocks per CTB: up to
+ * 1-2 + 1 + 1 waves, residual cache lines requested in the prologue and loaded per block behind its border gather; the
+ * smaller footprint keeps ~2.5x as many CTBs in flight).  The CTB's own wave counts come from DevIntraWork.waves_code
+ * (runtime.hip intra_schedule). */
 template <class PIX, int CF, int NW>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p, int work_n)
 {
