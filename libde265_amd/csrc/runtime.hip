@@ -1291,7 +1291,7 @@ static hipError_t frame_event(hipEvent_t* e)
  * stream while the main stream runs job list -> inter prediction, which do not read them; the residual stage then runs in two
  * launches side by side — 32x32 + 16x16 blocks on the main stream, 8x8 + 4x4 on the side stream — and k_intra follows the join.
  * ev: the decode's timing events [1..4] (after meta jobs / inter / residual / intra) or nullptr. */
-static void launch_prediction(m355_ctx* c, const DevPic& d, bool hbd, hipEvent_t* ev)
+static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev)
 {
   hipStream_t st = c->stream;
   hipEventRecord(c->ev_fork, st);
@@ -1299,6 +1299,14 @@ static void launch_prediction(m355_ctx* c, const DevPic& d, bool hbd, hipEvent_t
   m355_launch_meta_planes(d, c->stream2);
   m355_launch_meta_jobs(d, st);
   if (ev) hipEventRecord(ev[1], st);
+  /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
+     reference — the list copy, validation, metadata planes and job list of a picture run beside the tail (filters) of the picture
+     it references */
+  if (c->depth >= 2)
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+      if (f && f->wr_pending) hipStreamWaitEvent(st, f->ev_wr, 0);
+    }
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   if (ev) hipEventRecord(ev[2], st);
   if (c->stages & M355_STAGE_RESIDUAL) {
@@ -1327,12 +1335,8 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   const bool piped = c->depth >= 2;
   Frame* dstf = get_frame(c, r.hdr.dst_frame);
   if (piped) {
-    /* read-after-write: the lists (uploaded on whichever lane was active) and every reference frame's last writer */
+    /* read-after-write: the lists (uploaded on whichever lane was active); the reference frames' last writers: launch_prediction */
     if (r.ev_up) hipStreamWaitEvent(c->stream, r.ev_up, 0);
-    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
-      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
-      if (f && f->wr_pending) hipStreamWaitEvent(c->stream, f->ev_wr, 0);
-    }
   }
   /* write-after-write / write-after-read on the destination: waited for right before the first kernel that writes
      it — the SAO stage when SAO runs (everything before writes this lane's working planes), else the first stage */
@@ -1360,7 +1364,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
     for (int cc = 0; cc < 3; cc++)
       if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
   }
-  launch_prediction(c, d, hbd, ev);
+  launch_prediction(c, r, d, hbd, ev);
   if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
   hipEventRecord(ev[5], st);
   if (want_sao) { dst_hazards(); m355_launch_sao(d, hbd, st); }
@@ -1462,10 +1466,6 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
     case 0: {
       if (piped) {
         if (r.ev_up) hipStreamWaitEvent(st, r.ev_up, 0);
-        for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
-          Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
-          if (f && f->wr_pending) hipStreamWaitEvent(st, f->ev_wr, 0);
-        }
       }
       if (c->gate_used || r.device_validate) { hipMemsetAsync(c->timeout + 1, 0, 4, st); c->gate_used = r.device_validate ? 1 : 0; }
       if (r.device_validate) m355_launch_validate(d, st);
@@ -1475,7 +1475,7 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
         for (int cc = 0; cc < 3; cc++)
           if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
       }
-      launch_prediction(c, d, hbd, nullptr);
+      launch_prediction(c, r, d, hbd, nullptr);
       if (piped)      /* the reference frames are not read after this phase */
         for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
           Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
