@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1200, help="steps of THE timed region (default: ~0.5 s of device time at the default workload)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c5_8k10_8tiles")
-    ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1..4)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1..16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", type=int, default=31, help="DIAGNOSTIC ONLY: M355_STAGE_* mask (anything but 31 is not a valid benchmark)")
     ap.add_argument("--no-with-upload", action="store_true", help="skip the PCIe-inclusive legs (lists recorded into the pinned arena -> validation -> H2D -> decode, per step)")

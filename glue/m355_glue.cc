@@ -970,7 +970,7 @@ LIBDE265_API de265_decoder_context* de265_new_decoder()
   }
   int depth = 2;
   if (const char* e = getenv("M355_PIPELINE_DEPTH")) depth = atoi(e);
-  if (depth >= 1 && depth <= 4) A->m355_set_pipeline_depth(g->mctx, depth);
+  if (depth >= 1 && depth <= 16) A->m355_set_pipeline_depth(g->mctx, depth);
   install_traps(g->dctx->acceleration);
   de265_image_allocation alloc = {glue_get_buffer, glue_release_buffer};
   de265_set_image_allocation_functions(c, &alloc, g);

@@ -36,8 +36,16 @@ struct DevIntraWork {
   uint16_t nb_earlier;              /* bit k: neighbour k precedes the CTB in decode (tile-scan) order */
   uint8_t waves_code;               /* widest dependency level of the CTB (runtime.hip intra_schedule): 0..3 */
   uint8_t pad[3];
-  uint32_t reserved[3];
+  uint32_t plan_base;               /* first entry of the CTB's border plans in DevPic.iplan (a multiple of 8 entries) */
+  uint32_t plan_count;              /* ... and how many entries they are (<= M355_INTRA_PLAN_CAP) */
+  uint32_t reserved;
 };
+/* Border plans (k_intra_plan -> k_intra): per intra block 4nT + 2 16-bit entries (header + one LDS source per border entry).
+ * The blocks of one component of a CTB are disjoint (runtime.hip intra_schedule rejects lists where they are not), which bounds a
+ * CTB's plans by its 4x4-only case, 18 entries per 4x4 block, ... */
+#define M355_INTRA_PLAN_CAP(cf) ((cf) == 0 ? 4608 : ((cf) == 1 ? 6912 : ((cf) == 2 ? 9216 : 13824)))
+/* ... and the plans of any 64 blocks of a CTB by 2176 / 2496 / 2848 / 3520 entries (+ 7 of alignment) */
+#define M355_INTRA_PLAN_BATCH(cf) ((cf) == 0 ? 2304 : ((cf) == 1 ? 2560 : ((cf) == 2 ? 3072 : 3584)))
 
 struct DevPic {
   m355_pic_params pp;
@@ -58,7 +66,8 @@ struct DevPic {
   const m355_wt* wts;
   const m355_rb* rb_bin[4];         /* residual blocks of 4x4, 8x8, 16x16, 32x32 (rb_count[] entries each) */
   const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime.hip intra_schedule) */
-  const uint16_t* ib_level;         /* level of ibs[i] inside its CTB */
+  const uint32_t* ib_aux;           /* per ibs[i]: offset of its border plan inside the CTB's plans | dependency level inside its CTB << 16 */
+  uint16_t* iplan;                  /* border plans of all intra blocks (k_intra_plan writes, k_intra reads), lane scratch */
   int intra_dense;                  /* k_intra variant: 1 = intra picture (12-wave workgroups, residuals in LDS), 0 = a handful of blocks per CTB */
   const uint32_t* coeffs;
   const uint16_t* pcm;
@@ -153,6 +162,7 @@ void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for
 void m355_launch_meta_planes(const DevPic& p, hipStream_t st);   /* planes for intra / deblock / SAO */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
+void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st);   /* one direction (tile sharding) */

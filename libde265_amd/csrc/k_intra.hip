@@ -10,40 +10,54 @@
  * Why it looks like this: intra prediction of a block reads the reconstructed samples of its
  * left / above / above-right neighbours, so the blocks of one CTB form a serial chain and CTBs form
  * the classic WPP wavefront (needs CTB (x+1,y-1)).  This is the reference's ctb_progress protocol
- * (image.h:76-80, slice.cc:4789-4795) moved onto the device:
- *   - one workgroup per CTB that contains intra blocks, described by one host-prepared 32-byte record (DevIntraWork: block
- *     range, wave count, the 3x3 neighbourhood's slice / tile / decode-order facts).  CTBs that read no intra sample of a
- *     neighbour are taken by workgroup index; the dependent ones are claimed from an atomic ticket in DECODE (tile-scan)
- *     order, so a workgroup only ever waits on CTBs claimed before it (or on ticket-free ones, which wait for nobody and
- *     are dispatched first);
- *   - dependencies between CTBs are tracked at the granularity of the SAMPLES ACTUALLY READ, not per CTB: a block that
- *     finishes a piece of its CTB's right column or bottom row publishes those samples as 8-byte granules
- *     {tag = this decode's epoch, two samples} with agent-scope (write-through) stores — "the data is the flag"
- *     (MI355X guide, guideline 16, form R2: no fences, no write-back of the L2).  A consumer stages its halo from the
- *     picture where the neighbouring samples come from the preceding kernels (inter prediction: final by stream order)
- *     and from the granules where they come from an intra block of a neighbour CTB; a granule that is not there yet is
- *     polled only by the block whose border gather needs it, when it needs it.  A CTB therefore starts at once, runs
- *     beside its neighbours, and the critical path of an intra picture is the diagonal of BLOCKS (about 15 levels of
- *     lag per CTB column and 30 per CTB row for a picture of 4x4 blocks), not (W_ctb + 2 H_ctb) whole-CTB steps;
- *   - inside the workgroup the CTB is resident in LDS and its blocks run LEVEL BY LEVEL: the host sorts each CTB's
- *     blocks by dependency level (runtime.hip intra_schedule: a block depends on the earlier blocks that cover its left
- *     column / top row), blocks of one level are independent, and each colour component has 1, 2 or 4 wavefronts (per
- *     CTB, from the widest level: a lone intra CU in an inter picture needs one, a CTB of 4x4 blocks four) that share a
- *     level's blocks, with a workgroup barrier between levels when there is more than one wave per component — the
- *     serial chain per CTB shrinks from the block count to the level count (about 46 instead of 256 for 4x4 blocks);
+ * (image.h:76-80, slice.cc:4789-4795) moved onto the device.  An intra picture is DEPENDENCY-bound: the 1080p
+ * picture of BASELINE config 2 is a chain of ~1900 dependent block levels of which only ~60 cross a CTB
+ * boundary, and a wave that runs alone on its SIMD retires one instruction every ~5 cycles — so what decides the
+ * stage is the number of INSTRUCTIONS between two dependent blocks, not memory latency.  Hence two kernels:
+ *
+ *   k_intra_plan  (fully parallel, off the chain, runs beside k_inter / k_residual on the side stream): everything of
+ *     a block that does not depend on sample VALUES — which of its 4nT+1 border entries are available (picture,
+ *     slice, tile, z-scan order, constrained intra prediction: intrapred.h:436-633), where each entry's sample will
+ *     live in the CTB's LDS tile, and the substitution of unavailable entries (intrapred.h:637-665) — is resolved into
+ *     a PLAN: one 16-bit LDS source per border entry (+ one header entry: smoothing decisions);
+ *   k_intra  (the chain): one workgroup per CTB that contains intra blocks, described by one host-prepared 32-byte
+ *     record (DevIntraWork).  The CTB's samples, its residuals and its plan are resident in LDS; a block is: gather the
+ *     border through the plan -> (smooth) -> predict -> add residual -> LDS.  No picture store, no metadata lookup and
+ *     no availability arithmetic sits between two dependent blocks; the CTB's intra samples are written to the picture
+ *     once, coalesced, when the CTB is finished.
+ *   - CTBs that read no intra sample of a neighbour are taken by workgroup index; the dependent ones are claimed from
+ *     an atomic ticket in DECODE (tile-scan) order, so a workgroup only ever waits on CTBs claimed before it;
+ *   - dependencies between CTBs are tracked at the granularity of the SAMPLES ACTUALLY READ: a block that finishes a
+ *     piece of its CTB's right column or bottom row publishes those samples as 8-byte granules {tag = this decode's
+ *     epoch, two samples} with agent-scope (write-through) stores — "the data is the flag" (MI355X guide, guideline
+ *     16, form R2: no fences, no write-back of the L2).  A consumer stages its halo from the picture where the
+ *     neighbouring samples come from the preceding kernels and from the granules where they come from an intra block
+ *     of a neighbour CTB; a granule that is not there yet is polled only by the block whose border needs it;
+ *   - inside the workgroup the blocks run LEVEL BY LEVEL (host-derived levels, runtime.hip intra_schedule: blocks of
+ *     one level are independent); each colour component has 1, 2, 4 or 8 wavefronts that share a level's blocks, with
+ *     a workgroup barrier between levels when there is more than one wave per component;
  *   - the inverse transforms were done up front, in parallel, by k_residual.
- * This stage is dependency-bound, not bandwidth-bound.
  */
 #include <stdlib.h>
 #include "k_common.h"
 
 #define MAXCTB 64
-/* body rows of a component: CTB width + 8 samples — sample x lives at column x + 8 (16-byte aligned 8-sample vectors),
-   the left halo at column 7.  Chroma bodies are sized for the chroma format (template parameter CF): the LDS
-   footprint decides how many CTBs a CU works on at once, and this stage lives on concurrency. */
+/* body rows of a component: CTB width + 8 samples — sample x lives at column x + 8 (16-byte aligned 8-sample vectors).
+   Chroma bodies are sized for the chroma format (template parameter CF): the LDS footprint decides how many CTBs a CU
+   works on at once, and this stage lives on concurrency. */
 #define BODY_PITCH_OF(cw) ((cw) + 8)
 #define BODY_X0 8
 #define SPIN_LIMIT M355_SPIN_LIMIT   /* k_asm.h: bound on the polls for one granule (a list that promises a sample nobody produces) */
+/* halo of a component, 32-bit words (a sample, or HALO_NOT_READY while the neighbour CTB has not published it):
+   the row above the CTB, x = -1 .. 2cw-1 at index x + 1, then the column left of it, y at index HALO_TOP_N + y */
+#define HALO_TOP_N (2 * MAXCTB + 2)
+#define HALO_N (HALO_TOP_N + MAXCTB)
+#define HALO_NOT_READY 0xFFFFFFFFu
+/* plan entry: where border entry e of a block comes from, substitution already applied */
+#define PLAN_HALO 0x8000u            /* | index into the component's halo words; else: element index into its body */
+#define PLAN_CONST 0xFFFFu           /* nothing is available: 1 << (bitDepth - 1) (intrapred.h:645-649) */
+#define PLAN_H_FILT 1u               /* header entry: [1 2 1] smoothing applies (intrapred.h:195-212) */
+#define PLAN_H_STRONG 2u             /* ... and the bilinear variant is allowed if the border is flat (intrapred.h:216-234) */
 
 /* z-scan order inside a CTB (pps.cc:608-623 MinTbAddrZS, low bits): Morton code of the min-TB coordinates */
 __device__ __forceinline__ uint32_t d_spread4(uint32_t v) { v = (v | (v << 2)) & 0x33u; return (v | (v << 1)) & 0x55u; }
@@ -70,8 +84,6 @@ __device__ __forceinline__ int d_subst_src(int e, unsigned long long m0, unsigne
   return 128;
 }
 
-#define HALO_NOT_READY 0xFFFFFFFFu
-
 typedef unsigned long long m355_granule;   /* (epoch << 32) | sample1 << 16 | sample0 */
 
 /* right-column granules of CTB column `col` of component c: index (row of the picture) >> 1 */
@@ -79,41 +91,168 @@ __device__ __forceinline__ m355_granule* d_edge_col(const DevPic& p, int c, int 
 /* bottom-row granules of CTB row `row`: index (column of the picture) >> 1 */
 __device__ __forceinline__ m355_granule* d_edge_row(const DevPic& p, int c, int row, int x) { return p.edge + p.edge_row_ofs[c] + (size_t)row * (size_t)(p.pw[c] >> 1) + (size_t)(x >> 1); }
 
+/* chroma CTB geometry of a chroma format */
+template <int CF> struct IntraGeo {
+  static constexpr int CW_C = (CF == 1 || CF == 2) ? MAXCTB / 2 : MAXCTB, CH_C = CF == 1 ? MAXCTB / 2 : MAXCTB;
+  static constexpr int BODY_L = MAXCTB * BODY_PITCH_OF(MAXCTB), BODY_C = CF == 0 ? 8 : CH_C * BODY_PITCH_OF(CW_C);
+};
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * k_intra_plan: PLAN_SPLIT workgroups of 4 waves per CTB with intra blocks; a wave takes every (4 * PLAN_SPLIT)-th block, one
+ * border entry per lane (up to three passes for the 129 entries of a 32x32 block).
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define PLAN_SPLIT 4
+template <int CF>
+__global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
+{
+  M355_GATE(p);
+  __shared__ uint16_t s_code[4][4 * 32 + 8];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int item = (int)blockIdx.x;
+  if (item >= work_n) return;
+  const DevIntraWork* wp = p.intra_work + item;
+  const int ctb = __builtin_amdgcn_readfirstlane((int)wp->ctb);
+  const uint32_t ib_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->ib_start), ib_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->ib_count);
+  const uint32_t nb_same = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->nb_same), nb_earlier = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->nb_earlier);
+  const uint32_t plan_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->plan_base);
+  const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
+  const int l2c = p.pp.log2_ctb_size;
+  uint16_t* codes = s_code[wv];
+  for (uint32_t k = (uint32_t)(wv + 4 * (int)blockIdx.y); k < ib_count; k += 4 * PLAN_SPLIT) {
+    const uint32_t* r = (const uint32_t*)&p.ibs[ib_start + k];
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[0]), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[1]);
+    const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[ib_start + k]);
+    const int c = (int)(w1 & 0xFFu), log2 = (int)((w1 >> 8) & 0xFFu), mode = (int)((w1 >> 16) & 0xFFu), flags = (int)(w1 >> 24);
+    if (flags & M355_IBF_PCM) continue;                      /* raw blocks read no border: no plan entries */
+    const int nT = 1 << log2;
+    const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
+    const int SubW = 1 << csw, SubH = 1 << csh;
+    const int x0c = (ctbX << l2c) >> csw, y0c = (ctbY << l2c) >> csh;
+    const int BODY_PITCH = c == 0 ? BODY_PITCH_OF(MAXCTB) : BODY_PITCH_OF(IntraGeo<CF>::CW_C);
+    const int xB = (int)(w0 & 0xFFFFu), yB = (int)(w0 >> 16), lx = xB - x0c, ly = yB - y0c;
+    /* ---- preproc (intrapred.h:436-531): CTB-level availability from the neighbourhood table ---- */
+    const int xBL = xB * SubW, yBL = yB * SubH;
+    bool aL = xBL != 0, aT = yBL != 0, aTL = xBL != 0 && yBL != 0, aTR = yBL != 0;
+    if (xBL + nT * SubW >= p.pp.width) aTR = false;
+    {
+      const int dxL = ((xBL - 1) >> l2c) - ctbX, dxR = ((xBL + nT * SubW) >> l2c) - ctbX, dyT = ((yBL - 1) >> l2c) - ctbY;
+      if (aL && !((nb_same >> (3 + dxL + 1)) & 1u)) aL = false;
+      if (aT && !((nb_same >> ((dyT + 1) * 3 + 1)) & 1u)) aT = false;
+      if (aTL && !((nb_same >> ((dyT + 1) * 3 + dxL + 1)) & 1u)) aTL = false;
+      if (aTR && !((nb_same >> ((dyT + 1) * 3 + dxR + 1)) & 1u)) aTR = false;
+    }
+    int nBottom = p.pp.height - yB * SubH;
+    nBottom = (nBottom + SubH - 1) >> csh;
+    if (nBottom > 2 * nT) nBottom = 2 * nT;
+    int nRight = p.pp.width - xB * SubW;
+    nRight = (nRight + SubW - 1) >> csw;
+    if (nRight > 2 * nT) nRight = 2 * nT;
+    const int l2tb = p.pp.log2_min_tb_size, cmask = (1 << l2c) - 1;
+    const uint32_t curZ = d_morton((uint32_t)(xBL & cmask) >> l2tb, (uint32_t)(yBL & cmask) >> l2tb);
+    const bool cip = (p.pp.flags & M355_PF_CONSTRAINED_INTRA_PRED) != 0;
+    const int nEnt = 4 * nT + 1;
+    /* ---- fill_from_image (intrapred.h:534-633): availability and LDS source of every border entry ---- */
+    unsigned long long am[3] = {0, 0, 0};
+    uint32_t code[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      if (64 * q >= nEnt) continue;              /* wave-uniform: 4x4 / 8x8 blocks have 17 / 33 border entries */
+      const int e = lane + 64 * q;
+      bool av = false;
+      if (e < nEnt) {
+        const int i = e - 2 * nT;
+        int xN, yN, sx, sy; /* test position (luma), sample position (local) */
+        if (i < 0) {
+          const int yy = -i - 1, g4 = yy & ~3;
+          av = aL && (g4 + 3 < nBottom);
+          xN = (xB - 1) * SubW; yN = (yB + g4 + 3) * SubH; sx = lx - 1; sy = ly + yy;
+        } else if (i == 0) {
+          av = aTL;
+          xN = (xB - 1) * SubW; yN = (yB - 1) * SubH; sx = lx - 1; sy = ly - 1;
+        } else {
+          const int xx = i - 1, g4 = xx & ~3;
+          av = (g4 < nT ? aT : aTR) && (g4 < nRight);
+          xN = (xB + g4) * SubW; yN = (yB - 1) * SubH; sx = lx + xx; sy = ly - 1;
+        }
+        if (av) {     /* MinTbAddrZS[neighbour] <= MinTbAddrZS[current] (intrapred.h:560-566) */
+          const int dcx = (xN >> l2c) - ctbX, dcy = (yN >> l2c) - ctbY;
+          if (dcx == 0 && dcy == 0) av = d_morton((uint32_t)(xN & cmask) >> l2tb, (uint32_t)(yN & cmask) >> l2tb) <= curZ;
+          else av = (nb_earlier >> ((dcy + 1) * 3 + dcx + 1)) & 1u;
+        }
+        if (av && cip) av = d_is_intra_at(p, xN, yN);
+        if (av) code[q] = sy < 0 ? (PLAN_HALO | (uint32_t)(sx + 1)) : (sx < 0 ? (PLAN_HALO | (uint32_t)(HALO_TOP_N + sy)) : (uint32_t)(sy * BODY_PITCH + sx + BODY_X0));
+      }
+      am[q] = __ballot(av);
+    }
+    /* ---- reference_sample_substitution (intrapred.h:637-665), on the sources ---- */
+    const bool none = (am[0] | am[1] | am[2]) == 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      if (64 * q >= nEnt) continue;
+      const int e = lane + 64 * q;
+      if (e < nEnt) codes[e] = (uint16_t)code[q];
+    }
+    wave_sync();
+    uint16_t* out = p.iplan + plan_base + (aux & 0xFFFFu);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      if (64 * q >= nEnt) continue;
+      const int e = lane + 64 * q;
+      if (e < nEnt) {
+        uint32_t v;
+        if (none) v = PLAN_CONST;
+        else if ((am[q] >> lane) & 1) v = code[q];
+        else v = codes[d_subst_src(e, am[0], am[1], am[2])];
+        out[1 + e] = (uint16_t)v;
+      }
+    }
+    if (lane == 0) {
+      /* ---- which smoothing intra_prediction_sample_filtering (intrapred.h:185-258) will apply ---- */
+      uint32_t h = 0;
+      if (!(p.pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (c == 0 || p.pp.chroma_format_idc == 3) && mode != 1 && nT != 4) {
+        const int minDist = min(d_abs(mode - 26), d_abs(mode - 10));
+        const bool filt = nT == 8 ? minDist > 7 : (nT == 16 ? minDist > 1 : (nT == 32 ? minDist > 0 : false));
+        if (filt) h = PLAN_H_FILT | (((p.pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) && c == 0 && nT == 32) ? PLAN_H_STRONG : 0u);
+      }
+      out[0] = (uint16_t)h;
+    }
+    wave_sync();                                             /* codes[] is reused by the wave's next block */
+  }
+}
+
 /* NW = waves per workgroup: 12 for intra pictures (CTBs with hundreds of blocks: up to 8 luma + 2 + 2 chroma waves share a
- * level, the CTB's residuals are fetched into LDS up front), 4 for inter pictures (a handful of intra blocks per CTB: up to
- * 1-2 + 1 + 1 waves, residual cache lines requested in the prologue and loaded per block behind its border gather; the
- * smaller footprint keeps ~2.5x as many CTBs in flight).  The CTB's own wave counts come from DevIntraWork.waves_code
- * (runtime.hip intra_schedule). */
-template <class PIX, int CF, int NW>
+ * level, the CTB's residuals and its whole plan are fetched into LDS up front), 4 for inter pictures (a handful of intra
+ * blocks per CTB: up to 1-2 + 1 + 1 waves, residual cache lines requested in the prologue and loaded per block behind its
+ * border gather, the plan of 64 blocks at a time; the smaller footprint keeps more CTBs in flight).  The CTB's own wave
+ * counts come from DevIntraWork.waves_code (runtime.hip intra_schedule). */
+template <class PIX, int CF, int NW, bool DENSE>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p, int work_n)
 {
   M355_GATE(p);
-  constexpr bool RES_LDS = NW >= 12;
-  /* per component: halo (top row x = -1 .. 2*cw-1 at index x+1; left column) as 32-bit words: a sample, or
-     HALO_NOT_READY while the neighbour CTB has not published it; body rows */
-  constexpr int CW_C = (CF == 1 || CF == 2) ? MAXCTB / 2 : MAXCTB, CH_C = CF == 1 ? MAXCTB / 2 : MAXCTB;   /* chroma CTB size */
-  constexpr int BODY_L = MAXCTB * BODY_PITCH_OF(MAXCTB), BODY_C = CF == 0 ? 8 : CH_C * BODY_PITCH_OF(CW_C);
-  __shared__ uint32_t s_top[3][2 * MAXCTB + 2];
-  __shared__ uint32_t s_left[3][MAXCTB];
+  constexpr int CW_C = IntraGeo<CF>::CW_C, CH_C = IntraGeo<CF>::CH_C;
+  constexpr int BODY_L = IntraGeo<CF>::BODY_L, BODY_C = IntraGeo<CF>::BODY_C;
+  __shared__ uint32_t s_halo[3][HALO_N];
   __shared__ __attribute__((aligned(16))) uint16_t s_body[BODY_L + 2 * BODY_C];
   /* the CTB's deferred residuals in picture layout (pitch = component CTB width): fetched up front, all loads in flight
      together, so that the per-block chain reads them from LDS instead of paying a global-memory latency per block */
-  constexpr int RES_L = RES_LDS ? MAXCTB * MAXCTB : 8, RES_C = (CF == 0 || !RES_LDS) ? 8 : CH_C * CW_C;
+  constexpr int RES_L = DENSE ? MAXCTB * MAXCTB : 8, RES_C = (CF == 0 || !DENSE) ? 8 : CH_C * CW_C;
   __shared__ __attribute__((aligned(16))) int16_t s_res[RES_L + 2 * RES_C];
+  /* the plan (k_intra_plan): the whole CTB's (dense: M355_INTRA_PLAN_CAP entries, runtime.hip rejects CTBs beyond it) or 64
+     blocks' at a time (M355_INTRA_PLAN_BATCH) */
+  constexpr int PLAN_LDS = DENSE ? M355_INTRA_PLAN_CAP(CF) : M355_INTRA_PLAN_BATCH(CF);
+  __shared__ __attribute__((aligned(16))) uint16_t s_plan[PLAN_LDS];
   /* per WAVE (a wave works on one block at a time): */
-  constexpr int NWV = NW;
-  __shared__ uint16_t s_raw[NWV][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
-  __shared__ uint16_t s_p[NWV][4 * 32 + 8];        /* substituted border */
-  __shared__ uint16_t s_f[NWV][4 * 32 + 8];        /* filtered border */
+  __shared__ uint16_t s_raw[NW][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
+  __shared__ uint16_t s_f[NW][4 * 32 + 8];        /* filtered border */
   __shared__ uint32_t s_ticket;
   __shared__ uint32_t s_need[3][MAXCTB];         /* per component and CTB row, which 8-sample vectors some block's border reads */
+  __shared__ uint32_t s_cover[3][MAXCTB / 4];    /* per component and row of 4x4 units, which units an intra block of this CTB writes */
   __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
   __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
 
   /* everything derived from the wave index or from a block record is wave-uniform: say so (readfirstlane / readlane), so that
      the component's plane pointers, pitches and granule offsets are scalar loads from the kernel arguments instead of vector
-     loads (each one a wait on the in-order vector-memory counter, i.e. on every sample store still in flight), record
-     fields live in SGPRs and the per-block branches are scalar */
+     loads, record fields live in SGPRs and the per-block branches are scalar */
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 
   /* work item: the first n_intra_free items are CTBs that wait for no neighbour — any workgroup may take any of them, so they go
@@ -129,22 +268,23 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   /* the CTB's descriptor (host-prepared, runtime.hip): one scalar 32-byte load */
   const DevIntraWork* wp = p.intra_work + item;
   const uint4 wd0 = *(const uint4*)wp;
-  const uint32_t wd1 = ((const uint32_t*)wp)[4];
+  const uint4 wd1 = ((const uint4*)wp)[1];
   const int ctb = __builtin_amdgcn_readfirstlane((int)wd0.x);
   struct { uint32_t ib_start, ib_count; } ctbinfo = {(uint32_t)__builtin_amdgcn_readfirstlane((int)wd0.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)wd0.z)};
-  const uint32_t nb_same = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w & 0xFFFFu)), nb_earlier = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w >> 16));
+  const uint32_t plan_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wd1.y), plan_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)wd1.z);
   /* wave -> (colour component c, sub-wave g of G): GL luma waves, then GC for Cb, GC for Cr; the rest leave at once
      (finished waves do not take part in later barriers) */
   int GL, GC;
   {
-    const int code = __builtin_amdgcn_readfirstlane((int)(wd1 & 3u));   /* widest level of the CTB: luma 1 / 2 / 3-4 / more blocks */
-    GL = code == 0 ? 1 : (code == 1 ? 2 : (code == 2 || NW < 12 ? 4 : 8));
-    GC = (code == 3 && NW >= 12) ? 2 : 1;
-    if (GL > NW - 2) GL = NW - 2;
+    const int code = __builtin_amdgcn_readfirstlane((int)(wd1.x & 3u));   /* widest level of the CTB: luma 1 / 2 / 3-4 / more blocks */
+    constexpr int GLMAX = NW >= 12 ? 8 : (NW >= 6 ? 4 : 2), GCMAX = (NW - GLMAX) / 2 >= 2 ? 2 : 1;
+    GL = min(GLMAX, code == 0 ? 1 : (code == 1 ? 2 : (code == 2 ? 4 : 8)));
+    GC = code == 3 ? GCMAX : 1;
   }
   if (wv >= GL + 2 * GC) return;
   const int c = wv < GL ? 0 : (wv < GL + GC ? 1 : 2);
   const int G = c == 0 ? GL : GC, g = c == 0 ? wv : (wv - GL - (c - 1) * GC);
+  const int NWV = GL + 2 * GC;                           /* waves at work on this CTB */
   const bool multi = GL + GC > 2;                        /* more than one wave per component somewhere: levels end in a barrier */
   const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
   const int l2c = p.pp.log2_ctb_size;
@@ -152,31 +292,39 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
   const bool comp = c < nc;
   const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
-  const int SubW = 1 << csw, SubH = 1 << csh;
   const int cw = (1 << l2c) >> csw, ch = (1 << l2c) >> csh;
   const int x0c = (ctbX << l2c) >> csw, y0c = (ctbY << l2c) >> csh;
   const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
   const int cs = comp ? c : 0;
   PIX* plane = (PIX*)p.plane[cs];
   const int stride = p.stride[cs], pw = p.pw[cs], ph = p.ph[cs];
-  uint32_t* top = s_top[cs];
-  uint32_t* left = s_left[cs];
+  uint32_t* halo = s_halo[cs];
   uint16_t* body = s_body + (cs == 0 ? 0 : BODY_L + (cs - 1) * BODY_C);
   const int BODY_PITCH = cs == 0 ? BODY_PITCH_OF(MAXCTB) : BODY_PITCH_OF(CW_C);
   uint16_t* raw = s_raw[wv];
-  uint16_t* psub = s_p[wv];
   uint16_t* pf = s_f[wv];
   const uint32_t epoch = p.epoch;
 #define SYNC_CTB() do { if (multi) __syncthreads(); else wave_sync(); } while (0)
   int16_t* resl = s_res + (cs == 0 ? 0 : RES_L + (cs - 1) * RES_C);
   const int RES_PITCH = cs == 0 ? MAXCTB : CW_C;
 
+  /* ---- the plan: the whole CTB's (dense) or its first PLAN_LDS entries (a later batch of 64 blocks reloads), 16 bytes per
+     lane and step, requested before anything else ---- */
+  uint32_t plan_lo = 0;                                    /* first entry held in s_plan */
+  {
+    const uint32_t n = min(plan_count, (uint32_t)PLAN_LDS);
+    const uint4* src = (const uint4*)(p.iplan + plan_base);  /* plan_base is a multiple of 8 entries */
+    for (uint32_t o = (uint32_t)(wv * 64 + lane) * 8u; o < n; o += (uint32_t)NWV * 512u) *(uint4*)(s_plan + o) = src[o >> 3];
+  }
   /* ---- which body vectors does some block's border read?  Only those are staged: the row above a block
      (x-1 .. x+2nT-1) and the column left of it (y .. y+2nT-1), intrapred.h:436-674 — a 64x64 CTB with two 8x8 intra
-     blocks: ~6 of its 512 luma vectors.  Samples that blocks of this CTB produce land in the same LDS tile later. ---- */
+     blocks: ~6 of its 512 luma vectors — and of those only what no intra block of this CTB produces itself (s_cover:
+     those samples reach the same LDS tile when their block is predicted; they are also what the CTB writes to the
+     picture at the end). ---- */
   if (comp && g == 0) {
     for (int y = lane; y < ch; y += 64) s_need[cs][y] = 0;
     if (lane < 8) s_hneed[cs][lane] = 0;
+    if (lane < MAXCTB / 4) s_cover[cs][lane] = 0;
     wave_sync();
     const int nvr = cw >> 3;                                /* vectors per row */
     for (uint32_t k = lane; k < ctbinfo.ib_count; k += 64) {
@@ -185,7 +333,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       if ((w1 & 0xFFu) != (uint32_t)c) continue;
       const int nT = 1 << ((w1 >> 8) & 0xFFu);
       const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
-      if (!RES_LDS && ((w1 >> 24) & M355_IBF_HAS_RESIDUAL) && !((w1 >> 24) & M355_IBF_PCM)) {
+      {
+        const uint32_t um = ((1u << (nT >> 2)) - 1u) << (lx >> 2);
+        for (int uy = ly >> 2; uy < (ly + nT) >> 2; uy++) atomicOr(&s_cover[cs][uy], um);
+      }
+      if ((w1 >> 24) & M355_IBF_PCM) continue;               /* raw blocks read no border */
+      if (!DENSE && ((w1 >> 24) & M355_IBF_HAS_RESIDUAL)) {
         /* the block's residual is read when its dependency level comes up: ask for its cache lines now */
         const char* rp_ = (const char*)(p.resbuf + r[2]);
         for (int o = 0; o < nT * nT * 2; o += 128) d_touch(rp_ + o, s_touch);
@@ -226,7 +379,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         for (int u = 0; u < U; u++) {
           const int idx = idx0 + u * 64 * G;
           const int y = idx >> l2v, xv = (idx & ((1 << l2v) - 1)) * 8;
-          take[u] = idx < nvec && ((s_need[cs][min(y, ch - 1)] >> (xv >> 3)) & 1u) && x0c + xv < pw && y0c + y < ph;
+          const int yc = min(y, ch - 1);
+          take[u] = idx < nvec && ((s_need[cs][yc] >> (xv >> 3)) & 1u) && ((s_cover[cs][yc >> 2] >> (xv >> 2)) & 3u) != 3u && x0c + xv < pw && y0c + y < ph;
           v[u] = make_uint4(0, 0, 0, 0);
           if (take[u]) {
             const PIX* src = plane + (size_t)(y0c + y) * stride + x0c + xv;
@@ -285,14 +439,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         for (int u = 0; u < U; u++) {
           const int h = h0 + u * 64 * G;
           if (h >= nhalo) continue;
-          if (top_[u]) top[h] = val[u]; else left[h - (2 * cw + 1)] = val[u];
+          if (top_[u]) halo[h] = val[u]; else halo[HALO_TOP_N + h - (2 * cw + 1)] = val[u];
         }
       }
     }
   }
   /* ---- residual pre-pass (intra pictures): the CTB's deferred residuals go to LDS, each component's waves taking its
      blocks in turn ---- */
-  if (RES_LDS) {
+  if (DENSE) {
     int taken = 0;                                           /* blocks of this component seen so far (wave-uniform) */
     for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
       uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
@@ -316,20 +470,35 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       }
     }
   }
-  __syncthreads();     /* bodies, halos and residuals staged */
+  __syncthreads();     /* bodies, halos, residuals and the plan staged */
   /* The CTB's block records (sorted by level, then component) are fetched 64 at a time (one per lane, coalesced) by
      EVERY wave; for each level present in the batch, a wave takes the blocks of its component that fall to it
      (every G-th) by broadcasting the record from the owning lane, then all waves meet at the workgroup barrier.  The
      loop bounds come from the records alone, so all waves (also those of absent components) execute the same
      barriers. */
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
-    uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
+    uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0, rw3 = 0;
     int lv = -1;
     const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
     if (lane < nvalid) {
       const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
       rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
-      lv = p.ib_level[ctbinfo.ib_start + kbase + lane];
+      rw3 = p.ib_aux[ctbinfo.ib_start + kbase + lane];     /* plan offset inside the CTB | level << 16 */
+      lv = (int)(rw3 >> 16);
+    }
+    if (!DENSE) {
+      /* this batch's plan entries: [first block's offset, + PLAN_LDS) — reload when the window in LDS does not hold them */
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rw3, 0) & 0xFFFFu;
+      const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)rw3, nvalid - 1) & 0xFFFFu;
+      if (last + 130u > plan_lo + (uint32_t)PLAN_LDS && plan_count > (uint32_t)PLAN_LDS) {
+        __syncthreads();                                     /* everybody is done with the previous window */
+        const uint32_t lo8 = lo & ~7u;
+        const uint32_t n = min(plan_count - lo8, (uint32_t)PLAN_LDS);
+        const uint4* src = (const uint4*)(p.iplan + plan_base + lo8);
+        for (uint32_t o = (uint32_t)(wv * 64 + lane) * 8u; o < n; o += (uint32_t)NWV * 512u) *(uint4*)(s_plan + o) = src[o >> 3];
+        plan_lo = lo8;
+        __syncthreads();
+      }
     }
     const int lv_first = __builtin_amdgcn_readlane(lv, 0), lv_last = __builtin_amdgcn_readlane(lv, nvalid - 1);
     for (int L = lv_first; L <= lv_last; L++) {
@@ -340,11 +509,13 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       mine &= mine - 1;
       if ((rank++ & (G - 1)) != g) continue;             /* another wave of this component takes it */
       m355_ib ib;
+      uint32_t prel;
       {
         const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src), w2 = __builtin_amdgcn_readlane(rw2, src);
         ib.x = (uint16_t)(w0 & 0xFFFFu); ib.y = (uint16_t)(w0 >> 16);
         ib.cidx = (uint8_t)(w1 & 0xFFu); ib.log2_size = (uint8_t)((w1 >> 8) & 0xFFu); ib.mode = (uint8_t)((w1 >> 16) & 0xFFu); ib.flags = (uint8_t)(w1 >> 24);
         ib.res_ofs = w2;
+        prel = ((uint32_t)__builtin_amdgcn_readlane((int)rw3, src) & 0xFFFFu) - plan_lo;
       }
       const int nT = 1 << ib.log2_size;
       const int xB = ib.x, yB = ib.y, lx = xB - x0c, ly = yB - y0c;
@@ -352,152 +523,80 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const bool pub_col = lx + nT == cw && ctbX + 1 < p.ctbW, pub_row = ly + nT == ch && ctbY + 1 < p.ctbH;
 
       if (!(ib.flags & M355_IBF_PCM)) {
-      /* ---- preproc (intrapred.h:436-531): CTB-level availability from the neighbourhood table ---- */
-      const int xBL = xB * SubW, yBL = yB * SubH;
-      bool aL = xBL != 0, aT = yBL != 0, aTL = xBL != 0 && yBL != 0, aTR = yBL != 0;
-      if (xBL + nT * SubW >= p.pp.width) aTR = false;
-      {
-        const int dxL = ((xBL - 1) >> l2c) - ctbX, dxR = ((xBL + nT * SubW) >> l2c) - ctbX, dyT = ((yBL - 1) >> l2c) - ctbY;
-        if (aL && !((nb_same >> (3 + dxL + 1)) & 1u)) aL = false;
-        if (aT && !((nb_same >> ((dyT + 1) * 3 + 1)) & 1u)) aT = false;
-        if (aTL && !((nb_same >> ((dyT + 1) * 3 + dxL + 1)) & 1u)) aTL = false;
-        if (aTR && !((nb_same >> ((dyT + 1) * 3 + dxR + 1)) & 1u)) aTR = false;
-      }
-      int nBottom = p.pp.height - yB * SubH;
-      nBottom = (nBottom + SubH - 1) >> csh;
-      if (nBottom > 2 * nT) nBottom = 2 * nT;
-      int nRight = p.pp.width - xB * SubW;
-      nRight = (nRight + SubW - 1) >> csw;
-      if (nRight > 2 * nT) nRight = 2 * nT;
-      const int l2tb = p.pp.log2_min_tb_size, cmask = (1 << l2c) - 1;
-      const uint32_t curZ = d_morton((uint32_t)(xBL & cmask) >> l2tb, (uint32_t)(yBL & cmask) >> l2tb);
-      const bool cip = (p.pp.flags & M355_PF_CONSTRAINED_INTRA_PRED) != 0;
       const int nEnt = 4 * nT + 1;
-
-      /* ---- fill_from_image (intrapred.h:534-633): one border entry per lane and chunk ---- */
-      unsigned long long am[3] = {0, 0, 0};
+      const uint16_t* pl = s_plan + prel;
+      const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl[0]);
+      /* ---- the border (fill_from_image + substitution, intrapred.h:534-665, resolved by k_intra_plan): one entry per lane
+         and chunk, each from the LDS source its plan entry names ---- */
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         if (64 * q >= nEnt) continue;              /* wave-uniform: 4x4 / 8x8 blocks have 17 / 33 border entries */
         const int e = lane + 64 * q;
-        bool av = false;
-        uint32_t val = 0;
-        uint32_t* hslot = nullptr;                 /* the halo word behind this entry, if it is one */
-        const m355_granule* gsrc = nullptr;
-        int ghalf = 0;
+        uint32_t val = 0, code = 0;
         if (e < nEnt) {
-          const int i = e - 2 * nT;
-          int xN, yN, sx, sy; /* test position (luma), sample position (local) */
-          if (i < 0) {
-            const int yy = -i - 1, g4 = yy & ~3;
-            av = aL && (g4 + 3 < nBottom);
-            xN = (xB - 1) * SubW; yN = (yB + g4 + 3) * SubH; sx = lx - 1; sy = ly + yy;
-          } else if (i == 0) {
-            av = aTL;
-            xN = (xB - 1) * SubW; yN = (yB - 1) * SubH; sx = lx - 1; sy = ly - 1;
-          } else {
-            const int xx = i - 1, g4 = xx & ~3;
-            av = (g4 < nT ? aT : aTR) && (g4 < nRight);
-            xN = (xB + g4) * SubW; yN = (yB - 1) * SubH; sx = lx + xx; sy = ly - 1;
-          }
-          if (av) {     /* MinTbAddrZS[neighbour] <= MinTbAddrZS[current] (intrapred.h:560-566) */
-            const int dcx = (xN >> l2c) - ctbX, dcy = (yN >> l2c) - ctbY;
-            if (dcx == 0 && dcy == 0) av = d_morton((uint32_t)(xN & cmask) >> l2tb, (uint32_t)(yN & cmask) >> l2tb) <= curZ;
-            else av = (nb_earlier >> ((dcy + 1) * 3 + dcx + 1)) & 1u;
-          }
-          if (av && cip) av = d_is_intra_at(p, xN, yN);
-          if (av) {
-            if (sy < 0) { hslot = &top[sx + 1]; val = *hslot; gsrc = d_edge_row(p, cs, ctbY - 1, x0c + sx); ghalf = (x0c + sx) & 1; }
-            else if (sx < 0) { hslot = &left[sy]; val = *hslot; gsrc = d_edge_col(p, cs, ctbX - 1, y0c + sy); ghalf = (y0c + sy) & 1; }
-            else val = body[sy * BODY_PITCH + sx + BODY_X0];
-          }
+          code = pl[1 + e];
+          val = code == PLAN_CONST ? (1u << (bd - 1)) : ((code & PLAN_HALO) ? halo[code & 0x7FFFu] : (uint32_t)body[code]);
         }
         /* a halo sample its CTB has not published yet: poll its granule (relaxed, agent scope: served by the L2 / fabric,
            never by this CU's L1); every waiting lane has its own word, the wave leaves when all have arrived */
-        bool pending = av && hslot != nullptr && val == HALO_NOT_READY;
+        bool pending = e < nEnt && code != PLAN_CONST && (code & PLAN_HALO) && val == HALO_NOT_READY;
         if (__any(pending)) {
+          const int hi = (int)(code & 0x7FFFu);
+          const bool is_top = hi < HALO_TOP_N;
+          const int pos = is_top ? x0c - 1 + hi : y0c + hi - HALO_TOP_N;      /* picture column of a top entry / row of a left entry */
+          const m355_granule* gsrc = pending ? (is_top ? d_edge_row(p, cs, ctbY - 1, pos) : d_edge_col(p, cs, ctbX - 1, pos)) : nullptr;
           unsigned spins = 0;
           for (;;) {
             if (pending) {
               const m355_granule gr = __hip_atomic_load(gsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((uint32_t)(gr >> 32) == epoch) { val = (uint32_t)((gr >> (16 * ghalf)) & 0xFFFFu); *hslot = val; pending = false; }
+              if ((uint32_t)(gr >> 32) == epoch) { val = (uint32_t)((gr >> (16 * (pos & 1))) & 0xFFFFu); halo[hi] = val; pending = false; }
             }
             if (!__any(pending)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) { if (lane == 0) atomicExch(p.timeout, 1u); break; }
+            if ((++spins & 1023u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(p.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+              if (lane == 0) atomicExch(p.timeout, 1u);      /* a list that promises a sample nobody produces: ONE bounded wait per decode */
+              break;
+            }
           }
         }
         if (e < nEnt) raw[e] = (uint16_t)val;
-        am[q] = __ballot(av);
       }
       wave_sync();
       /* residual of this block (written by k_residual; its cache lines were requested in the prologue): the loads are issued
          here, BEHIND the border gather — hipcc drains the vector-memory counter in front of the gather's poll loop, so loads
-         issued before it are waited for at once — and consumed after substitution / smoothing, up to 16 samples per lane (32x32) */
+         issued before it are waited for at once — and consumed after smoothing, up to 16 samples per lane (32x32) */
       int16_t rv[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         const int o = lane + 64 * q;
-        rv[q] = (!RES_LDS && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
+        rv[q] = (!DENSE && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
       }
-      /* ---- reference_sample_substitution (only when something is missing: the common interior block keeps its gathered
-         border as it is) ---- */
-      const bool none = (am[0] | am[1] | am[2]) == 0;
-      bool all_av;
-      {
-        const unsigned long long full = ~0ull;
-        const int r1 = nEnt - 64, r2 = nEnt - 128;      /* entries in the 2nd / 3rd mask word */
-        all_av = am[0] == (nEnt >= 64 ? full : ((1ull << nEnt) - 1ull)) &&
-                 (r1 <= 0 || am[1] == (r1 >= 64 ? full : ((1ull << r1) - 1ull))) &&
-                 (r2 <= 0 || am[2] == ((1ull << r2) - 1ull));
-      }
-      uint16_t* pp_ = raw;
-      if (!all_av) {
+      /* ---- intra_prediction_sample_filtering (intrapred.h:185-258) ---- */
+      const int mode = ib.mode;
+      uint16_t* P = raw; /* border in use, entry index = i + 2nT */
+      const int Z = 2 * nT;
+      if (hdr & PLAN_H_FILT) {
+        const bool bi = (hdr & PLAN_H_STRONG) &&
+                        d_abs((int)raw[Z] + raw[Z + 64] - 2 * raw[Z + 32]) < (1 << (p.pp.bit_depth_luma - 5)) &&
+                        d_abs((int)raw[Z] + raw[Z - 64] - 2 * raw[Z - 32]) < (1 << (p.pp.bit_depth_luma - 5));
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           if (64 * q >= nEnt) continue;
           const int e = lane + 64 * q;
           if (e < nEnt) {
+            const int i = e - Z;
             int v;
-            if (none) v = 1 << (bd - 1);
-            else if ((am[q] >> lane) & 1) v = raw[e];
-            else v = raw[d_subst_src(e, am[0], am[1], am[2])];
-            psub[e] = (uint16_t)v;
+            if (i == -Z || i == Z) v = raw[e];
+            else if (bi) {
+              if (i == 0) v = raw[Z];
+              else if (i < 0) v = raw[Z] + (((-i) * ((int)raw[Z - 64] - raw[Z]) + 32) >> 6);
+              else v = raw[Z] + ((i * ((int)raw[Z + 64] - raw[Z]) + 32) >> 6);
+            } else v = (raw[e + 1] + 2 * raw[e] + raw[e - 1] + 2) >> 2;
+            pf[e] = (uint16_t)v;
           }
         }
         wave_sync();
-        pp_ = psub;
-      }
-      /* ---- intra_prediction_sample_filtering (intrapred.h:185-258) ---- */
-      const int mode = ib.mode;
-      uint16_t* P = pp_; /* border in use, entry index = i + 2nT */
-      const int Z = 2 * nT;
-      if (!(p.pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (c == 0 || p.pp.chroma_format_idc == 3) && mode != 1 && nT != 4) {
-        const int minDist = min(d_abs(mode - 26), d_abs(mode - 10));
-        const bool filt = nT == 8 ? minDist > 7 : (nT == 16 ? minDist > 1 : (nT == 32 ? minDist > 0 : false));
-        if (filt) {
-          const bool bi = (p.pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) && c == 0 && nT == 32 &&
-                          d_abs((int)pp_[Z] + pp_[Z + 64] - 2 * pp_[Z + 32]) < (1 << (p.pp.bit_depth_luma - 5)) &&
-                          d_abs((int)pp_[Z] + pp_[Z - 64] - 2 * pp_[Z - 32]) < (1 << (p.pp.bit_depth_luma - 5));
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            if (64 * q >= nEnt) continue;
-            const int e = lane + 64 * q;
-            if (e < nEnt) {
-              const int i = e - Z;
-              int v;
-              if (i == -Z || i == Z) v = pp_[e];
-              else if (bi) {
-                if (i == 0) v = pp_[Z];
-                else if (i < 0) v = pp_[Z] + (((-i) * ((int)pp_[Z - 64] - pp_[Z]) + 32) >> 6);
-                else v = pp_[Z] + ((i * ((int)pp_[Z + 64] - pp_[Z]) + 32) >> 6);
-              } else v = (pp_[e + 1] + 2 * pp_[e] + pp_[e - 1] + 2) >> 2;
-              pf[e] = (uint16_t)v;
-            }
-          }
-          wave_sync();
-          P = pf;
-        }
+        P = pf;
       }
 #define BRD(i) ((int)P[(i) + Z])
       /* ---- prediction (intrapred.h:261-433) ---- */
@@ -514,9 +613,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
          border entry sgn*x for x >= 0 and, left of the corner (negative angles only), -sgn*((x*invAngle+128)>>8): the two taps
          of a sample are read straight from the border */
       /* intraPredAngle / invAngle (intrapred.h:313-326) from the distance d of the mode to the pure horizontal (10) / vertical
-         (26) mode, looked up in packed constants: a table in memory would be a dependent vector load per block (the mode is
-         per-lane data to the compiler), i.e. a memory round trip on the block chain — and, the vector-memory counter being
-         in-order, a wait for everything else this wave has in flight */
+         (26) mode, looked up in packed constants (a table in memory would be a dependent vector load per block) */
       const int d_ang = mode >= 18 ? d_abs(mode - 26) : d_abs(mode - 10);                    /* 0..8 */
       const int mag = (int)((0x20345488D1214100ull >> (7 * d_ang)) & 0x7Full);                 /* {0,2,5,9,13,17,21,26,32}, 7 bits each */
       const bool neg = mode >= 18 ? mode < 26 : mode > 10;
@@ -529,10 +626,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const bool has_res = (ib.flags & M355_IBF_HAS_RESIDUAL) != 0;
       const bool edge = (c == 0 && nT < 32);
       const bool bfilt = edge && !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER);
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int o = lane + 64 * q;
-        if (o >= nT * nT) break;
+      auto predict = [&](int o, int resv) {
         const int y = o >> log2, x = o & (nT - 1);
         int v;
         if (mode == 0) {
@@ -554,18 +648,27 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             if (mode == 10 && y == 0) v = d_clip_bd(BRD(-1) + ((BRD(1 + x) - BRD(0)) >> 1), bd);
           }
         }
-        if (has_res) v = d_clip_bd(v + (RES_LDS ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (int)rv[q]), bd);
-        body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders */
-        plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;                /* the picture: only intra samples are (re)written */
+        if (has_res) v = d_clip_bd(v + (DENSE ? (int)resl[(ly + y) * RES_PITCH + lx + x] : resv), bd);
+        body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders; the picture is written at the end */
+      };
+      if (DENSE) {
+        /* (a loop, not 16 unrolled copies: the chain of an intra picture should sit in the instruction cache) */
+#pragma unroll 1
+        for (int o = lane; o < nT * nT; o += 64) predict(o, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int o = lane + 64 * q;
+          if (o >= nT * nT) break;
+          predict(o, (int)rv[q]);
+        }
       }
 #undef BRD
 #undef REFV
       } else { /* raw block (slice.cc:4211-4255) */
         for (int o = lane; o < nT * nT; o += 64) {
           const int y = o >> ib.log2_size, x = o & (nT - 1);
-          const uint16_t v = p.pcm[ib.res_ofs + o];
-          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = v;
-          plane[(size_t)(yB + y) * stride + xB + x] = (PIX)v;
+          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = p.pcm[ib.res_ofs + o];
         }
       }
       wave_sync();
@@ -586,17 +689,34 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
        by wave_sync above; components do not interact) */
     }   /* levels in the batch */
   }   /* 64-record batches */
+  /* ---- the CTB's intra samples -> the picture: every 4x4 unit some intra block covered (s_cover), one 4-sample row piece per
+     lane, neighbouring lanes on neighbouring pieces of a row (the last level's barrier / wave_sync made them all visible) ---- */
+  if (comp) {
+    const int l2u = (l2c - csw) - 2;                         /* log2(units per row) */
+    const int npieces = ch << l2u;
+    for (int idx = lane + 64 * g; idx < npieces; idx += 64 * G) {
+      const int y = idx >> l2u, u = idx & ((1 << l2u) - 1);
+      if (!((s_cover[cs][y >> 2] >> u) & 1u)) continue;
+      const uint2 v = *(const uint2*)(body + y * BODY_PITCH + BODY_X0 + 4 * u);
+      PIX* dst = plane + (size_t)(y0c + y) * stride + x0c + 4 * u;
+      if (sizeof(PIX) == 2) *(uint2*)dst = v;
+      else *(uint32_t*)dst = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y & 0xFF0000u) << 8);
+    }
+  }
 #undef SYNC_CTB
 }
 
+#ifndef M355_INTRA_DENSE_NW
+#define M355_INTRA_DENSE_NW 12
+#endif
 template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, hipStream_t st)
 {
   hipMemsetAsync(p.ticket, 0, 4, st);
   /* dense intra pictures: 12 waves (up to 8 luma + 2 + 2 chroma blocks of a level at once); sparse ones: 4 (3 and 6 measured
      slower) */
-  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 12>), dim3(p.n_intra_work), dim3(64 * 12), 0, st, p, p.n_intra_work);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work);
+  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true>), dim3(p.n_intra_work), dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work);
 }
 
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)
@@ -607,5 +727,18 @@ void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)
     case 1: if (hbd) launch_intra_cf<uint16_t, 1>(p, st); else launch_intra_cf<uint8_t, 1>(p, st); break;
     case 2: if (hbd) launch_intra_cf<uint16_t, 2>(p, st); else launch_intra_cf<uint8_t, 2>(p, st); break;
     default: if (hbd) launch_intra_cf<uint16_t, 3>(p, st); else launch_intra_cf<uint8_t, 3>(p, st); break;
+  }
+}
+
+/* the plans of all intra blocks of the picture (needs the CU plane only under constrained intra prediction: launched behind
+   the metadata planes on the side stream, beside k_inter / k_residual) */
+void m355_launch_intra_plan(const DevPic& p, hipStream_t st)
+{
+  if (!p.n_intra_work) return;
+  switch (p.pp.chroma_format_idc) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<0>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<1>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<2>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<3>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
   }
 }

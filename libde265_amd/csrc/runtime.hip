@@ -38,7 +38,7 @@ static int fail(int code, const char* fmt, ...)
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(M355_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
-#define M355_MAX_LANES 4   /* pictures in flight per context (m355_set_pipeline_depth) */
+#define M355_MAX_LANES 16  /* pictures in flight per context (m355_set_pipeline_depth) */
 
 struct Frame {
   bool used = false;
@@ -99,6 +99,7 @@ struct Resident {
   DevRef* refs_host = nullptr; /* pinned staging + last uploaded contents */
   bool refs_valid = false;
   int n_intra_work = 0;
+  uint32_t n_iplan = 0;        /* border-plan entries of the picture's intra blocks (k_intra_plan -> k_intra) */
   int n_jobs = 0, n_jobs_main = 0, n_jobs_uni = 0;   /* inter jobs (k_inter_jobs), from the PB geometry */
   /* tile sharding (m355_decode_phase) */
   bool sharded = false;
@@ -133,7 +134,8 @@ struct Lane {
   int16_t* resbuf = nullptr;
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
+  uint16_t* iplan = nullptr;   /* border plans of the picture's intra blocks */
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0;
   size_t gate_used = 0;        /* a device-validated decode ran on this lane: its gate word must be cleared before the next decode */
 };
 
@@ -156,7 +158,8 @@ struct m355_ctx {
   int16_t* resbuf = nullptr;
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0;
+  uint16_t* iplan = nullptr;
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0;
   size_t gate_used = 0;
   uint32_t epoch = 0;
   int stages = M355_STAGE_ALL;
@@ -168,7 +171,7 @@ struct m355_ctx {
 };
 
 #define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
-  X(resbuf) X(jobs) X(sao_nb) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao) X(gate_used)
+  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao) X(gate_used)
 static void select_lane(m355_ctx* c, int lane)
 {
   if (lane == c->active) return;
@@ -200,7 +203,7 @@ static void lane_destroy(Lane& l)
   if (l.stream) hipStreamSynchronize(l.stream);
   if (l.stream2) hipStreamSynchronize(l.stream2);
   if (l.work.used) frame_free(l.work);
-  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb};
+  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb, l.iplan};
   for (void* b : bufs) if (b) hipFree(b);
   if (l.ev_fork) hipEventDestroy(l.ev_fork);
   if (l.ev_fork2) hipEventDestroy(l.ev_fork2);
@@ -837,26 +840,31 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
  * of those samples (a superset of what the availability rules of intrapred.h:534-633 let it read); level = 1 + the
  * highest level among them.  Blocks of one level are independent: k_intra runs them concurrently on several waves with
  * a workgroup barrier between levels, instead of walking the CTB's blocks one by one.  `out` receives each CTB's blocks
- * sorted by (level, component), decode order kept inside; `lvl` their levels; log2_waves[ctb] = how wide the CTB's widest
- * level is in luma blocks (0: 1, 1: 2, 2: 3-4, 3: more) -> how many waves k_intra runs on it; *dense = intra picture
- * (24 or more blocks per intra CTB on average). */
-static void intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint16_t* lvl, uint8_t* log2_waves, int* dense)
+ * sorted by (level, component), decode order kept inside; `aux` per sorted block: the offset of its border plan inside the
+ * CTB's plans (k_intra_plan: 4nT + 2 entries per predicted block, none for a raw block) | level << 16; plan_count[ctb] =
+ * the CTB's plan entries; log2_waves[ctb] = how wide the CTB's widest level is in luma blocks (0: 1, 1: 2, 2: 3-4,
+ * 3: more) -> how many waves k_intra runs on it; *dense = intra picture (24 or more blocks per intra CTB on average).
+ * Returns the first CTB whose intra blocks overlap (they never do in a picture the reference decodes: one
+ * decode_intra_prediction per transform block; the LDS budgets of k_intra rest on it), or -1. */
+static int intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint32_t* aux, uint32_t* plan_count, uint8_t* log2_waves, int* dense)
 {
   const m355_pic_params& pp = pic->pp;
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
   std::atomic<long long> n_blocks(0), n_intra_ctbs(0);
+  std::atomic<int> overlap(-1);
   parallel_ranges((size_t)pic->n_ctbs, 256, [&](size_t cb, size_t ce) {
     std::vector<std::pair<uint32_t, uint32_t>> key;      /* (level << 2 | cidx, index) */
     long long my_blocks = 0, my_ctbs = 0;
     for (size_t c = cb; c < ce; c++) {
       const m355_ctb& ctb = pic->ctbs[c];
-      log2_waves[c] = 0;
+      log2_waves[c] = 0; plan_count[c] = 0;
       if (!ctb.ib_count) continue;
       my_ctbs++; my_blocks += ctb.ib_count;
       const int cx = (int)c % ctbW, cy = (int)c / ctbW;
       int16_t grid[3][16][16];
       memset(grid, 0xFF, sizeof(grid));                  /* -1: no intra block of this CTB there (yet) */
       key.clear();
+      bool clash = false;
       for (uint32_t k = 0; k < ctb.ib_count; k++) {
         const m355_ib& ib = pic->ibs[ctb.ib_start + k];
         const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
@@ -871,22 +879,27 @@ static void intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint
           }
         }
         for (int y = uy; y < uy + n4 && y < 16; y++)
-          for (int x = ux; x < ux + n4 && x < 16; x++) grid[ib.cidx][y][x] = (int16_t)level;
+          for (int x = ux; x < ux + n4 && x < 16; x++) { if (grid[ib.cidx][y][x] >= 0) clash = true; grid[ib.cidx][y][x] = (int16_t)level; }
         key.push_back(std::make_pair(((uint32_t)level << 2) | ib.cidx, k));
       }
+      if (clash) { int e = -1; overlap.compare_exchange_strong(e, (int)c); }
       std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
-      uint32_t widest = 1, run = 0;
+      uint32_t widest = 1, run = 0, rel = 0;
       for (uint32_t k = 0; k < ctb.ib_count; k++) {
-        out[ctb.ib_start + k] = pic->ibs[ctb.ib_start + key[k].second];
-        lvl[ctb.ib_start + k] = (uint16_t)(key[k].first >> 2);
+        const m355_ib& ib = pic->ibs[ctb.ib_start + key[k].second];
+        out[ctb.ib_start + k] = ib;
+        aux[ctb.ib_start + k] = (rel & 0xFFFFu) | ((key[k].first >> 2) << 16);
+        if (!(ib.flags & M355_IBF_PCM) && ib.log2_size >= 2 && ib.log2_size <= 5) rel += (4u << ib.log2_size) + 2u;
         run = (k && key[k].first == key[k - 1].first) ? run + 1 : 1;
         if ((key[k].first & 3) == 0) widest = std::max(widest, run);      /* luma blocks of one level */
       }
+      plan_count[c] = rel;
       log2_waves[c] = widest >= 5 ? 3 : (widest >= 3 ? 2 : (widest == 2 ? 1 : 0));
     }
     n_blocks += my_blocks; n_intra_ctbs += my_ctbs;
   });
   *dense = (n_intra_ctbs.load() && n_blocks.load() / n_intra_ctbs.load() >= 24) ? 1 : 0;
+  return overlap.load();
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -943,7 +956,7 @@ static void make_layout(const m355_arena_caps& k, int nCtb, int halo_units, bool
   for (int b = 0; b < 4; b++) L.i_rb[b] = add(sizeof(m355_rb) * (size_t)k.n_rbs[b]);
   L.i_ibin = add(with_ib_input ? sizeof(m355_ib) * (size_t)k.n_ibs : 0);   /* in place: the caller's blocks in decode order (host only) */
   L.i_ib = add(sizeof(m355_ib) * (size_t)k.n_ibs);      /* each CTB's blocks sorted by dependency level */
-  L.i_il = add(2 * (size_t)k.n_ibs);                    /* ib_level */
+  L.i_il = add(4 * (size_t)k.n_ibs);                    /* ib_aux: plan offset | level << 16 */
   L.i_co = add(4 * (size_t)k.n_coeffs);
   L.i_pc = add(2 * (size_t)k.n_pcm);
   L.i_sc = add(k.scaling ? 6 * (16 + 64 + 256 + 1024) : 0);
@@ -1008,7 +1021,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     srcs[i_pb] = pic->pbs; used[i_pb] = sizeof(m355_pb) * (size_t)pic->n_pbs;
     srcs[i_wt] = pic->wts; used[i_wt] = sizeof(m355_wt) * (size_t)pic->n_wts;
     for (int b = 0; b < 4; b++) { srcs[L.i_rb[b]] = pic->rbs + rb_o; used[L.i_rb[b]] = sizeof(m355_rb) * (size_t)pic->rb_count[b]; rb_o += (size_t)pic->rb_count[b]; }
-    used[i_ib] = sizeof(m355_ib) * (size_t)pic->n_ibs; used[i_il] = 2 * (size_t)pic->n_ibs;
+    used[i_ib] = sizeof(m355_ib) * (size_t)pic->n_ibs; used[i_il] = 4 * (size_t)pic->n_ibs;
     srcs[i_co] = pic->coeffs; used[i_co] = 4 * (size_t)pic->n_coeffs;
     srcs[i_pc] = pic->pcm; used[i_pc] = 2 * (size_t)pic->n_pcm;
     srcs[i_sc] = pic->scaling_factors; used[i_sc] = pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0;
@@ -1048,7 +1061,13 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const auto t_copy = now();
   std::vector<uint8_t> log2_waves((size_t)nCtb, 0);
   int intra_dense = 0;
-  intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint16_t*)(r.host + seg[i_il].ofs), log2_waves.data(), &intra_dense);
+  std::vector<uint32_t> plan_count((size_t)nCtb, 0);
+  {
+    const int bad = intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint32_t*)(r.host + seg[i_il].ofs), plan_count.data(), log2_waves.data(), &intra_dense);
+    if (bad >= 0) return fail(M355_ERR_INVALID, "ctb %d: intra blocks overlap", bad);
+    const uint32_t cap = (uint32_t)M355_INTRA_PLAN_CAP(pp.chroma_format_idc);
+    for (int i = 0; i < nCtb; i++) if (plan_count[(size_t)i] > cap) return fail(M355_ERR_INVALID, "ctb %d: more intra blocks than a CTB holds", i);
+  }
   const auto t_sched = now();
   /* derived scan tables (pps.cc:589-606) */
   uint32_t* ctb_ts = (uint32_t*)(r.host + seg[i_ts].ofs);
@@ -1073,6 +1092,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   for (int i = 0; i < nCtb; i++) ((uint8_t*)(r.host + seg[i_dp].ofs))[i] |= (uint8_t)(log2_waves[i] << 5);
   const auto t_deps = now();
   int nw = 0, n_free = 0;
+  uint32_t n_iplan = 0;                                     /* border-plan entries of the picture (k_intra_plan) */
   {
     const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
     std::vector<std::pair<uint32_t, uint32_t>> freec;     /* (block count, raster address) */
@@ -1086,6 +1106,8 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
       memset(&w, 0, sizeof(w));
       w.ctb = rs; w.ib_start = pic->ctbs[rs].ib_start; w.ib_count = pic->ctbs[rs].ib_count;
       w.waves_code = (uint8_t)(log2_waves[rs] & 3);
+      w.plan_base = n_iplan; w.plan_count = plan_count[rs];
+      n_iplan += (plan_count[rs] + 7u) & ~7u;
       const int cx = (int)rs % ctbW, cy = (int)rs / ctbW;
       const uint32_t my_sa = pic->slices[pic->ctbs[rs].slice_idx].slice_addr_rs;
       for (int k = 0; k < 9; k++) {
@@ -1103,7 +1125,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
       if (pic->ctbs[ts2rs[t]].ib_count && (dep[ts2rs[t]] & 15)) item(ts2rs[t]);
   }
   seg[i_iw].bytes = sizeof(DevIntraWork) * (size_t)(nw ? nw : 1);
-  r.n_intra_work = nw;
+  r.n_intra_work = nw; r.n_iplan = n_iplan;
   {
     /* job counts per range (k_inter_jobs) and, per 256-PB chunk (= one k_meta_pb workgroup), the first job
        index of the chunk in each range */
@@ -1166,7 +1188,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.wts = (const m355_wt*)(r.dev + seg[i_wt].ofs);
   for (int b = 0; b < 4; b++) d.rb_bin[b] = (const m355_rb*)(r.dev + seg[L.i_rb[b]].ofs);
   d.ibs = (const m355_ib*)(r.dev + seg[i_ib].ofs);
-  d.ib_level = (const uint16_t*)(r.dev + seg[i_il].ofs);
+  d.ib_aux = (const uint32_t*)(r.dev + seg[i_il].ofs);
   d.intra_dense = intra_dense;
   d.coeffs = (const uint32_t*)(r.dev + seg[i_co].ofs);
   d.pcm = (const uint16_t*)(r.dev + seg[i_pc].ofs);
@@ -1252,6 +1274,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   if ((rc = grow(&c->resbuf, &c->cap_res, (size_t)pic.res_len + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
   if ((rc = grow(&c->jobs, &c->cap_jobs, (size_t)r.n_jobs + 1, c->stream, false))) return rc;
+  if ((rc = grow(&c->iplan, &c->cap_iplan, (size_t)r.n_iplan + 8, c->stream, false))) return rc;
 
   const bool want_sao = (c->stages & M355_STAGE_SAO) && (pp.flags & M355_PF_SAO_ENABLED);
   Frame* target = dst;
@@ -1273,7 +1296,7 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   d.cb_cu = (uint32_t*)(c->edge_tu + (((size_t)2 * d.w4 * d.h4 + 63) & ~(size_t)63));
   d.cuf = c->cuf; d.pb_of = c->pb_of;
   d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && pp.chroma_format_idc <= 1) ? 0 : 1;   /* else k_inter_jobs writes it */
-  d.jobs = c->jobs; d.sao_nb = c->sao_nb;
+  d.jobs = c->jobs; d.sao_nb = c->sao_nb; d.iplan = c->iplan;
   d.resbuf = c->resbuf; d.edge = c->edge; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;
@@ -1297,6 +1320,7 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   hipEventRecord(c->ev_fork, st);
   hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
   m355_launch_meta_planes(d, c->stream2);
+  if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, c->stream2);   /* reads the CU plane (constrained intra prediction) */
   m355_launch_meta_jobs(d, st);
   if (ev) hipEventRecord(ev[1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
