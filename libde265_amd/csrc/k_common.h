@@ -40,9 +40,12 @@ struct DevIntraWork {
   uint32_t plan_count;              /* ... and how many entries they are (<= M355_INTRA_PLAN_CAP) */
   uint32_t reserved;
 };
-/* Border plans (k_intra_plan -> k_intra): per intra block 4nT + 2 16-bit entries (header + one LDS source per border entry).
+/* Border plans (k_intra_plan -> k_intra): per intra block 4nT + 1 16-bit entries (one LDS source per border entry).
  * The blocks of one component of a CTB are disjoint (runtime.hip intra_schedule rejects lists where they are not), which bounds a
  * CTB's plans by its 4x4-only case, 18 entries per 4x4 block, ... */
+/* DevPic.ib_aux word (runtime.hip intra_schedule): bits 0-15 plan offset, 16-29 dependency level inside the CTB */
+#define M355_IBA_FILT 0x40000000u    /* [1 2 1] border smoothing applies (intrapred.h:195-212: mode, size and component decide) */
+#define M355_IBA_STRONG 0x80000000u  /* ... and the bilinear variant is allowed if the border is flat (intrapred.h:216-234) */
 #define M355_INTRA_PLAN_CAP(cf) ((cf) == 0 ? 4608 : ((cf) == 1 ? 6912 : ((cf) == 2 ? 9216 : 13824)))
 /* ... and the plans of any 64 blocks of a CTB by 2176 / 2496 / 2848 / 3520 entries (+ 7 of alignment) */
 #define M355_INTRA_PLAN_BATCH(cf) ((cf) == 0 ? 2304 : ((cf) == 1 ? 2560 : ((cf) == 2 ? 3072 : 3584)))
@@ -66,7 +69,10 @@ struct DevPic {
   const m355_wt* wts;
   const m355_rb* rb_bin[4];         /* residual blocks of 4x4, 8x8, 16x16, 32x32 (rb_count[] entries each) */
   const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime.hip intra_schedule) */
-  const uint32_t* ib_aux;           /* per ibs[i]: offset of its border plan inside the CTB's plans | dependency level inside its CTB << 16 */
+  const uint32_t* ib_aux;           /* per ibs[i]: M355_IBA_* (offset of its border plan inside the CTB's plans, dependency level, smoothing) */
+#ifdef M355_X_PROF
+  unsigned long long* prof;         /* timing hooks of experiment builds (tools/variants.sh -DM355_X_PROF=<work item>) */
+#endif
   uint16_t* iplan;                  /* border plans of all intra blocks (k_intra_plan writes, k_intra reads), lane scratch */
   int intra_dense;                  /* k_intra variant: 1 = intra picture (12-wave workgroups, residuals in LDS), 0 = a handful of blocks per CTB */
   const uint32_t* coeffs;

@@ -19,7 +19,7 @@
  *     a block that does not depend on sample VALUES — which of its 4nT+1 border entries are available (picture,
  *     slice, tile, z-scan order, constrained intra prediction: intrapred.h:436-633), where each entry's sample will
  *     live in the CTB's LDS tile, and the substitution of unavailable entries (intrapred.h:637-665) — is resolved into
- *     a PLAN: one 16-bit LDS source per border entry (+ one header entry: smoothing decisions);
+ *     a PLAN: one 16-bit LDS source per border entry;
  *   k_intra  (the chain): one workgroup per CTB that contains intra blocks, described by one host-prepared 32-byte
  *     record (DevIntraWork).  The CTB's samples, its residuals and its plan are resident in LDS; a block is: gather the
  *     border through the plan -> (smooth) -> predict -> add residual -> LDS.  No picture store, no metadata lookup and
@@ -56,8 +56,6 @@
 /* plan entry: where border entry e of a block comes from, substitution already applied */
 #define PLAN_HALO 0x8000u            /* | index into the component's halo words; else: element index into its body */
 #define PLAN_CONST 0xFFFFu           /* nothing is available: 1 << (bitDepth - 1) (intrapred.h:645-649) */
-#define PLAN_H_FILT 1u               /* header entry: [1 2 1] smoothing applies (intrapred.h:195-212) */
-#define PLAN_H_STRONG 2u             /* ... and the bilinear variant is allowed if the border is flat (intrapred.h:216-234) */
 
 /* z-scan order inside a CTB (pps.cc:608-623 MinTbAddrZS, low bits): Morton code of the min-TB coordinates */
 __device__ __forceinline__ uint32_t d_spread4(uint32_t v) { v = (v | (v << 2)) & 0x33u; return (v | (v << 1)) & 0x55u; }
@@ -122,7 +120,7 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
     const uint32_t* r = (const uint32_t*)&p.ibs[ib_start + k];
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[0]), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[1]);
     const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[ib_start + k]);
-    const int c = (int)(w1 & 0xFFu), log2 = (int)((w1 >> 8) & 0xFFu), mode = (int)((w1 >> 16) & 0xFFu), flags = (int)(w1 >> 24);
+    const int c = (int)(w1 & 0xFFu), log2 = (int)((w1 >> 8) & 0xFFu), flags = (int)(w1 >> 24);
     if (flags & M355_IBF_PCM) continue;                      /* raw blocks read no border: no plan entries */
     const int nT = 1 << log2;
     const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
@@ -203,18 +201,8 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
         if (none) v = PLAN_CONST;
         else if ((am[q] >> lane) & 1) v = code[q];
         else v = codes[d_subst_src(e, am[0], am[1], am[2])];
-        out[1 + e] = (uint16_t)v;
+        out[e] = (uint16_t)v;
       }
-    }
-    if (lane == 0) {
-      /* ---- which smoothing intra_prediction_sample_filtering (intrapred.h:185-258) will apply ---- */
-      uint32_t h = 0;
-      if (!(p.pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (c == 0 || p.pp.chroma_format_idc == 3) && mode != 1 && nT != 4) {
-        const int minDist = min(d_abs(mode - 26), d_abs(mode - 10));
-        const bool filt = nT == 8 ? minDist > 7 : (nT == 16 ? minDist > 1 : (nT == 32 ? minDist > 0 : false));
-        if (filt) h = PLAN_H_FILT | (((p.pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) && c == 0 && nT == 32) ? PLAN_H_STRONG : 0u);
-      }
-      out[0] = (uint16_t)h;
     }
     wave_sync();                                             /* codes[] is reused by the wave's next block */
   }
@@ -472,10 +460,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   }
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
   /* The CTB's block records (sorted by level, then component) are fetched 64 at a time (one per lane, coalesced) by
-     EVERY wave; for each level present in the batch, a wave takes the blocks of its component that fall to it
-     (every G-th) by broadcasting the record from the owning lane, then all waves meet at the workgroup barrier.  The
-     loop bounds come from the records alone, so all waves (also those of absent components) execute the same
-     barriers. */
+     EVERY wave.  A wave's blocks of the batch — those of its component whose rank inside their (level, component) group
+     falls to it — are one 64-bit mask; it walks them level by level, and all waves meet at the workgroup barrier after
+     every level of the batch (the loop bounds come from the records alone, so the waves of absent components execute the
+     same barriers).  The walk is software-pipelined: a block's record and its plan entries (LDS reads that depend on no
+     sample) are fetched while the block before it is being predicted, so that what stands between two dependent blocks is
+     sample read -> taps -> sample write. */
+  const int thr_strong = 1 << (p.pp.bit_depth_luma - 5);
+  const bool can_pub_col = ctbX + 1 < p.ctbW, can_pub_row = ctbY + 1 < p.ctbH;
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
     uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0, rw3 = 0;
     int lv = -1;
@@ -483,8 +475,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     if (lane < nvalid) {
       const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
       rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
-      rw3 = p.ib_aux[ctbinfo.ib_start + kbase + lane];     /* plan offset inside the CTB | level << 16 */
-      lv = (int)(rw3 >> 16);
+      rw3 = p.ib_aux[ctbinfo.ib_start + kbase + lane];     /* M355_IBA_*: plan offset inside the CTB, level, smoothing flags */
+      lv = (int)((rw3 >> 16) & 0x3FFFu);
     }
     if (!DENSE) {
       /* this batch's plan entries: [first block's offset, + PLAN_LDS) — reload when the window in LDS does not hold them */
@@ -501,47 +493,77 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       }
     }
     const int lv_first = __builtin_amdgcn_readlane(lv, 0), lv_last = __builtin_amdgcn_readlane(lv, nvalid - 1);
-    for (int L = lv_first; L <= lv_last; L++) {
-    unsigned long long mine = __ballot((int)(comp && lv == L && (rw1 & 0xFFu) == (uint32_t)c));
-    int rank = 0;
-    while (mine) {
-      const int src = __ffsll(mine) - 1;
+    unsigned long long mine;
+    {
+      /* the records of one (level, component) group sit in consecutive lanes: rank in the group = lane - first lane of the group */
+      const uint32_t key = lane < nvalid ? (((uint32_t)lv << 2) | (rw1 & 3u)) : 0xFFFFFFFFu;
+      const uint32_t prevk = __shfl_up(key, 1u, 64);
+      const unsigned long long heads = __ballot((int)(lane == 0 || key != prevk));
+      const int start = 63 - __clzll(heads & ((2ull << lane) - 1ull));
+      mine = __ballot((int)(comp && lane < nvalid && (rw1 & 0xFFu) == (uint32_t)c && (((lane - start) & (G - 1)) == g)));
+    }
+    /* the wave's NEXT block: record words + the plan entries of its border (one per lane and 64-entry chunk) */
+    uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, ncode[3] = {PLAN_CONST, PLAN_CONST, PLAN_CONST};
+    int nsrc = -1;
+    auto fetch_next = [&]() {
+      nsrc = mine ? __ffsll(mine) - 1 : -1;
       mine &= mine - 1;
-      if ((rank++ & (G - 1)) != g) continue;             /* another wave of this component takes it */
-      m355_ib ib;
-      uint32_t prel;
-      {
-        const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src), w2 = __builtin_amdgcn_readlane(rw2, src);
-        ib.x = (uint16_t)(w0 & 0xFFFFu); ib.y = (uint16_t)(w0 >> 16);
-        ib.cidx = (uint8_t)(w1 & 0xFFu); ib.log2_size = (uint8_t)((w1 >> 8) & 0xFFu); ib.mode = (uint8_t)((w1 >> 16) & 0xFFu); ib.flags = (uint8_t)(w1 >> 24);
-        ib.res_ofs = w2;
-        prel = ((uint32_t)__builtin_amdgcn_readlane((int)rw3, src) & 0xFFFFu) - plan_lo;
+      if (nsrc < 0) return;
+      nw0 = __builtin_amdgcn_readlane(rw0, nsrc); nw1 = __builtin_amdgcn_readlane(rw1, nsrc);
+      nw2 = __builtin_amdgcn_readlane(rw2, nsrc); nw3 = __builtin_amdgcn_readlane(rw3, nsrc);
+      if ((nw1 >> 24) & M355_IBF_PCM) return;
+      const int nEnt = (4 << ((nw1 >> 8) & 0xFFu)) + 1;
+      const uint16_t* pl = s_plan + ((nw3 & 0xFFFFu) - plan_lo);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        if (64 * q >= nEnt) continue;
+        const int e = lane + 64 * q;
+        ncode[q] = e < nEnt ? (uint32_t)pl[e] : PLAN_CONST;
       }
+    };
+    fetch_next();
+#ifdef M355_X_PROF
+#define PROF_T(k) do { if (prof_on) pt[k] = __builtin_readcyclecounter(); } while (0)
+    const bool prof_on = p.prof != nullptr && item == M355_X_PROF && wv == 0;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+    if (prof_on && kbase == 0 && lane == 0) { p.prof[0] = __builtin_readcyclecounter(); p.prof[1] = wall_clock64(); }
+#else
+#define PROF_T(k) do { } while (0)
+#endif
+    for (int L = lv_first; L <= lv_last; L++) {
+    PROF_T(0);
+    while (nsrc >= 0 && (int)((nw3 >> 16) & 0x3FFFu) == L) {
+      m355_ib ib;
+      ib.x = (uint16_t)(nw0 & 0xFFFFu); ib.y = (uint16_t)(nw0 >> 16);
+      ib.cidx = (uint8_t)(nw1 & 0xFFu); ib.log2_size = (uint8_t)((nw1 >> 8) & 0xFFu); ib.mode = (uint8_t)((nw1 >> 16) & 0xFFu); ib.flags = (uint8_t)(nw1 >> 24);
+      ib.res_ofs = nw2;
+      const bool f_filt = (nw3 & M355_IBA_FILT) != 0, f_strong = (nw3 & M355_IBA_STRONG) != 0;
+      const uint32_t code[3] = {ncode[0], ncode[1], ncode[2]};
+      fetch_next();                                          /* the block after this one: its LDS reads run beside this block's */
       const int nT = 1 << ib.log2_size;
       const int xB = ib.x, yB = ib.y, lx = xB - x0c, ly = yB - y0c;
       /* does the block complete a piece of the CTB's right column / bottom row that a neighbour CTB may read? */
-      const bool pub_col = lx + nT == cw && ctbX + 1 < p.ctbW, pub_row = ly + nT == ch && ctbY + 1 < p.ctbH;
+      const bool pub_col = lx + nT == cw && can_pub_col, pub_row = ly + nT == ch && can_pub_row;
+      bool published = false;
 
       if (!(ib.flags & M355_IBF_PCM)) {
       const int nEnt = 4 * nT + 1;
-      const uint16_t* pl = s_plan + prel;
-      const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)pl[0]);
+      const bool small = nT <= 8;                            /* the whole border (17 / 33 entries) sits in ONE register, entry e in lane e */
       /* ---- the border (fill_from_image + substitution, intrapred.h:534-665, resolved by k_intra_plan): one entry per lane
          and chunk, each from the LDS source its plan entry names ---- */
+      uint32_t bv = 0;
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         if (64 * q >= nEnt) continue;              /* wave-uniform: 4x4 / 8x8 blocks have 17 / 33 border entries */
         const int e = lane + 64 * q;
-        uint32_t val = 0, code = 0;
-        if (e < nEnt) {
-          code = pl[1 + e];
-          val = code == PLAN_CONST ? (1u << (bd - 1)) : ((code & PLAN_HALO) ? halo[code & 0x7FFFu] : (uint32_t)body[code]);
-        }
+        const uint32_t cd = code[q];
+        uint32_t val = 0;
+        if (e < nEnt) val = cd == PLAN_CONST ? (1u << (bd - 1)) : ((cd & PLAN_HALO) ? halo[cd & 0x7FFFu] : (uint32_t)body[cd]);
         /* a halo sample its CTB has not published yet: poll its granule (relaxed, agent scope: served by the L2 / fabric,
            never by this CU's L1); every waiting lane has its own word, the wave leaves when all have arrived */
-        bool pending = e < nEnt && code != PLAN_CONST && (code & PLAN_HALO) && val == HALO_NOT_READY;
+        bool pending = e < nEnt && cd != PLAN_CONST && (cd & PLAN_HALO) && val == HALO_NOT_READY;
         if (__any(pending)) {
-          const int hi = (int)(code & 0x7FFFu);
+          const int hi = (int)(cd & 0x7FFFu);
           const bool is_top = hi < HALO_TOP_N;
           const int pos = is_top ? x0c - 1 + hi : y0c + hi - HALO_TOP_N;      /* picture column of a top entry / row of a left entry */
           const m355_granule* gsrc = pending ? (is_top ? d_edge_row(p, cs, ctbY - 1, pos) : d_edge_col(p, cs, ctbX - 1, pos)) : nullptr;
@@ -559,9 +581,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             }
           }
         }
-        if (e < nEnt) raw[e] = (uint16_t)val;
+        if (small) bv = val;
+        else if (e < nEnt) raw[e] = (uint16_t)val;
       }
-      wave_sync();
+      if (!small) wave_sync();
+      PROF_T(1);
       /* residual of this block (written by k_residual; its cache lines were requested in the prologue): the loads are issued
          here, BEHIND the border gather — hipcc drains the vector-memory counter in front of the gather's poll loop, so loads
          issued before it are waited for at once — and consumed after smoothing, up to 16 samples per lane (32x32) */
@@ -571,44 +595,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const int o = lane + 64 * q;
         rv[q] = (!DENSE && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
       }
-      /* ---- intra_prediction_sample_filtering (intrapred.h:185-258) ---- */
       const int mode = ib.mode;
-      uint16_t* P = raw; /* border in use, entry index = i + 2nT */
       const int Z = 2 * nT;
-      if (hdr & PLAN_H_FILT) {
-        const bool bi = (hdr & PLAN_H_STRONG) &&
-                        d_abs((int)raw[Z] + raw[Z + 64] - 2 * raw[Z + 32]) < (1 << (p.pp.bit_depth_luma - 5)) &&
-                        d_abs((int)raw[Z] + raw[Z - 64] - 2 * raw[Z - 32]) < (1 << (p.pp.bit_depth_luma - 5));
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          if (64 * q >= nEnt) continue;
-          const int e = lane + 64 * q;
-          if (e < nEnt) {
-            const int i = e - Z;
-            int v;
-            if (i == -Z || i == Z) v = raw[e];
-            else if (bi) {
-              if (i == 0) v = raw[Z];
-              else if (i < 0) v = raw[Z] + (((-i) * ((int)raw[Z - 64] - raw[Z]) + 32) >> 6);
-              else v = raw[Z] + ((i * ((int)raw[Z + 64] - raw[Z]) + 32) >> 6);
-            } else v = (raw[e + 1] + 2 * raw[e] + raw[e - 1] + 2) >> 2;
-            pf[e] = (uint16_t)v;
-          }
-        }
-        wave_sync();
-        P = pf;
-      }
-#define BRD(i) ((int)P[(i) + Z])
-      /* ---- prediction (intrapred.h:261-433) ---- */
       const int log2 = ib.log2_size;
-      int dcVal = 0;
-      if (mode == 1) {
-        int s = 0;
-        if (lane < nT) s = BRD(lane + 1) + BRD(-lane - 1);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        dcVal = (s + nT) >> (log2 + 1);
-      }
       /* angular modes (intrapred.h:330-433): the projected reference array ref[] of the reference is not built — its entry x is
          border entry sgn*x for x >= 0 and, left of the corner (negative angles only), -sgn*((x*invAngle+128)>>8): the two taps
          of a sample are read straight from the border */
@@ -622,71 +611,164 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       /* invAngle = -round(8192 / |angle|): {4096,1638,910,630 | 482,390,315,256} for d = 1..8, 16 bits each */
       const unsigned long long inv_tab = d_ang <= 4 ? 0x0276038E06661000ull : 0x0100013B018601E2ull;
       const int inv = (mode >= 2 && angle < 0) ? -(int)((inv_tab >> (16 * ((d_ang - 1) & 3))) & 0xFFFFull) : 0;
-#define REFV(x_) ((x_) >= 0 ? BRD(sgn * (x_)) : BRD(-sgn * (((x_) * inv + 128) >> 8)))
       const bool has_res = (ib.flags & M355_IBF_HAS_RESIDUAL) != 0;
       const bool edge = (c == 0 && nT < 32);
       const bool bfilt = edge && !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER);
-      auto predict = [&](int o, int resv) {
-        const int y = o >> log2, x = o & (nT - 1);
+      /* one sample (x, y) of the block from border taps BRD(i), i = -2nT .. 2nT (intrapred.h:261-433) */
+#define PREDICT_SAMPLE(v, x, y, dcVal)                                                                                              \
+      do {                                                                                                                          \
+        if (mode == 0) {                                                                                                            \
+          v = ((nT - 1 - (x)) * BRD(-1 - (y)) + ((x) + 1) * BRD(1 + nT) + (nT - 1 - (y)) * BRD(1 + (x)) + ((y) + 1) * BRD(-1 - nT) + nT) >> (log2 + 1); \
+        } else if (mode == 1) {                                                                                                     \
+          v = dcVal;                                                                                                                \
+          if (edge) {                                                                                                               \
+            const int e0_ = BRD(-1), e1_ = BRD(1), ex_ = BRD((x) + 1), ey_ = BRD(-(y) - 1);                                         \
+            if ((x) == 0 && (y) == 0) v = (e0_ + 2 * dcVal + e1_ + 2) >> 2;                                                         \
+            else if ((y) == 0) v = (ex_ + 3 * dcVal + 2) >> 2;                                                                      \
+            else if ((x) == 0) v = (ey_ + 3 * dcVal + 2) >> 2;                                                                      \
+          }                                                                                                                         \
+        } else {                                                                                                                    \
+          const int a_ = mode >= 18 ? (y) : (x), b_ = mode >= 18 ? (x) : (y);                                                       \
+          const int iIdx_ = ((a_ + 1) * angle) >> 5, iFact_ = ((a_ + 1) * angle) & 31;                                              \
+          const int x1_ = b_ + iIdx_ + 1, x2_ = b_ + iIdx_ + 2;                                                                     \
+          const int r1_ = BRD(x1_ >= 0 ? sgn * x1_ : -sgn * ((x1_ * inv + 128) >> 8));                                              \
+          const int r2_ = BRD(x2_ >= 0 ? sgn * x2_ : -sgn * ((x2_ * inv + 128) >> 8));                                              \
+          v = iFact_ ? ((32 - iFact_) * r1_ + iFact_ * r2_ + 16) >> 5 : r1_;                                                        \
+          if (bfilt && (mode == 26 || mode == 10)) {                                                                                \
+            const int t0_ = BRD(0), t1_ = BRD(mode == 26 ? 1 : -1), t2_ = BRD(mode == 26 ? -1 - (y) : 1 + (x));                      \
+            if (mode == 26 ? (x) == 0 : (y) == 0) v = d_clip_bd(t1_ + ((t2_ - t0_) >> 1), bd);                                      \
+          }                                                                                                                         \
+        }                                                                                                                           \
+      } while (0)
+      if (small) {
+        /* ---- 4x4 / 8x8: border, smoothing and taps in registers (cross-lane reads), one sample per lane; every lane runs the
+           arithmetic (a cross-lane read needs its source lane active), lanes beyond the block do not store ---- */
+        if (f_filt) {     /* intra_prediction_sample_filtering (intrapred.h:185-258), [1 2 1] only (strong smoothing is 32x32) */
+          const uint32_t up = __shfl_up(bv, 1u, 64), dn = __shfl_down(bv, 1u, 64);
+          if (lane > 0 && lane < nEnt - 1) bv = (dn + 2u * bv + up + 2u) >> 2;
+        }
+#define BRD(i) ((int)__shfl(bv, ((i) + Z) & 63, 64))
+        int dcVal = 0;
+        if (mode == 1) {
+          const int t1 = BRD(lane + 1), t2 = BRD(-lane - 1);
+          int s_ = lane < nT ? t1 + t2 : 0;
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m, 64);
+          dcVal = (s_ + nT) >> (log2 + 1);
+        }
+        const int y = lane >> log2, x = lane & (nT - 1);
         int v;
-        if (mode == 0) {
-          v = ((nT - 1 - x) * BRD(-1 - y) + (x + 1) * BRD(1 + nT) + (nT - 1 - y) * BRD(1 + x) + (y + 1) * BRD(-1 - nT) + nT) >> (log2 + 1);
-        } else if (mode == 1) {
-          v = dcVal;
-          if (edge) {
-            if (x == 0 && y == 0) v = (BRD(-1) + 2 * dcVal + BRD(1) + 2) >> 2;
-            else if (y == 0) v = (BRD(x + 1) + 3 * dcVal + 2) >> 2;
-            else if (x == 0) v = (BRD(-y - 1) + 3 * dcVal + 2) >> 2;
+        PREDICT_SAMPLE(v, x, y, dcVal);
+        const bool inb = lane < nT * nT;
+        if (has_res && inb) v = d_clip_bd(v + (DENSE ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (int)rv[0]), bd);
+        if (inb) body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;
+#undef BRD
+        /* ---- publish from the registers: a granule = two samples, the second one comes from the lane below / beside ---- */
+        if (pub_col) {
+          const uint32_t v2 = (uint32_t)__shfl(v, (lane + nT) & 63, 64);
+          if (inb && x == nT - 1 && !(y & 1))
+            __hip_atomic_store(d_edge_col(p, cs, ctbX, y0c + ly + y), ((m355_granule)epoch << 32) | (v2 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pub_row) {
+          const uint32_t v2 = (uint32_t)__shfl(v, (lane + 1) & 63, 64);
+          if (inb && y == nT - 1 && !(x & 1))
+            __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + lx + x), ((m355_granule)epoch << 32) | (v2 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        published = true;
+      } else {
+        /* ---- 16x16 / 32x32: the border lives in LDS (65 / 129 entries) ---- */
+        uint16_t* P = raw; /* border in use, entry index = i + 2nT */
+        if (f_filt) {     /* intra_prediction_sample_filtering (intrapred.h:185-258) */
+          const bool bi = f_strong && d_abs((int)raw[Z] + raw[Z + 64] - 2 * raw[Z + 32]) < thr_strong && d_abs((int)raw[Z] + raw[Z - 64] - 2 * raw[Z - 32]) < thr_strong;
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            if (64 * q >= nEnt) continue;
+            const int e = lane + 64 * q;
+            if (e < nEnt) {
+              const int i = e - Z;
+              int v;
+              if (i == -Z || i == Z) v = raw[e];
+              else if (bi) {
+                if (i == 0) v = raw[Z];
+                else if (i < 0) v = raw[Z] + (((-i) * ((int)raw[Z - 64] - raw[Z]) + 32) >> 6);
+                else v = raw[Z] + ((i * ((int)raw[Z + 64] - raw[Z]) + 32) >> 6);
+              } else v = (raw[e + 1] + 2 * raw[e] + raw[e - 1] + 2) >> 2;
+              pf[e] = (uint16_t)v;
+            }
+          }
+          wave_sync();
+          P = pf;
+        }
+#define BRD(i) ((int)P[(i) + Z])
+        int dcVal = 0;
+        if (mode == 1) {
+          int s_ = 0;
+          if (lane < nT) s_ = BRD(lane + 1) + BRD(-lane - 1);
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m, 64);
+          dcVal = (s_ + nT) >> (log2 + 1);
+        }
+        if (DENSE) {
+          /* (a loop, not 16 unrolled copies: the chain of an intra picture should sit in the instruction cache) */
+#pragma unroll 1
+          for (int o = lane; o < nT * nT; o += 64) {
+            const int y = o >> log2, x = o & (nT - 1);
+            int v;
+            PREDICT_SAMPLE(v, x, y, dcVal);
+            if (has_res) v = d_clip_bd(v + (int)resl[(ly + y) * RES_PITCH + lx + x], bd);
+            body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders; the picture is written at the end */
           }
         } else {
-          const int a = mode >= 18 ? y : x, b = mode >= 18 ? x : y;
-          const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
-          const int r1 = REFV(b + iIdx + 1);
-          v = iFact ? ((32 - iFact) * r1 + iFact * REFV(b + iIdx + 2) + 16) >> 5 : r1;
-          if (bfilt) {
-            if (mode == 26 && x == 0) v = d_clip_bd(BRD(1) + ((BRD(-1 - y) - BRD(0)) >> 1), bd);
-            if (mode == 10 && y == 0) v = d_clip_bd(BRD(-1) + ((BRD(1 + x) - BRD(0)) >> 1), bd);
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const int o = lane + 64 * q;
+            if (o >= nT * nT) break;
+            const int y = o >> log2, x = o & (nT - 1);
+            int v;
+            PREDICT_SAMPLE(v, x, y, dcVal);
+            if (has_res) v = d_clip_bd(v + (int)rv[q], bd);
+            body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;
           }
         }
-        if (has_res) v = d_clip_bd(v + (DENSE ? (int)resl[(ly + y) * RES_PITCH + lx + x] : resv), bd);
-        body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders; the picture is written at the end */
-      };
-      if (DENSE) {
-        /* (a loop, not 16 unrolled copies: the chain of an intra picture should sit in the instruction cache) */
-#pragma unroll 1
-        for (int o = lane; o < nT * nT; o += 64) predict(o, 0);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const int o = lane + 64 * q;
-          if (o >= nT * nT) break;
-          predict(o, (int)rv[q]);
-        }
-      }
 #undef BRD
-#undef REFV
+      }
+#undef PREDICT_SAMPLE
       } else { /* raw block (slice.cc:4211-4255) */
         for (int o = lane; o < nT * nT; o += 64) {
           const int y = o >> ib.log2_size, x = o & (nT - 1);
           body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = p.pcm[ib.res_ofs + o];
         }
       }
-      wave_sync();
       /* ---- publish: the block's share of the CTB's right column / bottom row, two samples per granule ---- */
-      if (pub_col && lane < (nT >> 1)) {
-        const int y = ly + 2 * lane;
-        const uint32_t s0 = body[y * BODY_PITCH + lx + nT - 1 + BODY_X0], s1 = body[(y + 1) * BODY_PITCH + lx + nT - 1 + BODY_X0];
-        __hip_atomic_store(d_edge_col(p, cs, ctbX, y0c + y), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!published && (pub_col || pub_row)) {
+        wave_sync();
+        if (pub_col && lane < (nT >> 1)) {
+          const int y = ly + 2 * lane;
+          const uint32_t s0 = body[y * BODY_PITCH + lx + nT - 1 + BODY_X0], s1 = body[(y + 1) * BODY_PITCH + lx + nT - 1 + BODY_X0];
+          __hip_atomic_store(d_edge_col(p, cs, ctbX, y0c + y), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pub_row && lane >= 32 && lane < 32 + (nT >> 1)) {
+          const int x = lx + 2 * (lane - 32);
+          const uint32_t s0 = body[(ly + nT - 1) * BODY_PITCH + x + BODY_X0], s1 = body[(ly + nT - 1) * BODY_PITCH + x + 1 + BODY_X0];
+          __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + x), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
-      if (pub_row && lane >= 32 && lane < 32 + (nT >> 1)) {
-        const int x = lx + 2 * (lane - 32);
-        const uint32_t s0 = body[(ly + nT - 1) * BODY_PITCH + x + BODY_X0], s1 = body[(ly + nT - 1) * BODY_PITCH + x + 1 + BODY_X0];
-        __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + x), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      PROF_T(2);
     }   /* this wave's blocks of the level */
-    if (multi) __syncthreads();
+    PROF_T(3);
+    SYNC_CTB();
+    PROF_T(4);
+#ifdef M355_X_PROF
+    if (prof_on && lane == 0) {
+      const int slot = 4 + 8 * (int)(p.prof[3]++ & 1023);
+      for (int k = 0; k < 5; k++) p.prof[slot + k] = pt[k];
+      p.prof[slot + 5] = (unsigned long long)L | ((unsigned long long)kbase << 32);
+      p.prof[2] = wall_clock64();
+    }
+    pt[1] = pt[2] = 0;
+#endif
     /* level done: its samples are in LDS for the next level's borders (one wave per component: its own blocks are ordered
-       by wave_sync above; components do not interact) */
+       by the wave-level sync; components do not interact) */
     }   /* levels in the batch */
   }   /* 64-record batches */
   /* ---- the CTB's intra samples -> the picture: every 4x4 unit some intra block covered (s_cover), one 4-sample row piece per

@@ -29,6 +29,10 @@
 #include "k_hash.h"
 
 static thread_local std::string g_err;
+#ifdef M355_X_PROF
+static unsigned long long* g_prof = nullptr;
+extern "C" __attribute__((visibility("default"))) int m355_x_prof_read(unsigned long long* out, int n) { return g_prof ? (int)hipMemcpy(out, g_prof, 8 * (size_t)n, hipMemcpyDeviceToHost) : -1; }
+#endif
 static int fail(int code, const char* fmt, ...)
 {
   char buf[512];
@@ -841,7 +845,7 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
  * highest level among them.  Blocks of one level are independent: k_intra runs them concurrently on several waves with
  * a workgroup barrier between levels, instead of walking the CTB's blocks one by one.  `out` receives each CTB's blocks
  * sorted by (level, component), decode order kept inside; `aux` per sorted block: the offset of its border plan inside the
- * CTB's plans (k_intra_plan: 4nT + 2 entries per predicted block, none for a raw block) | level << 16; plan_count[ctb] =
+ * CTB's plans (k_intra_plan: 4nT + 1 entries per predicted block, none for a raw block), level, smoothing flags (M355_IBA_*); plan_count[ctb] =
  * the CTB's plan entries; log2_waves[ctb] = how wide the CTB's widest level is in luma blocks (0: 1, 1: 2, 2: 3-4,
  * 3: more) -> how many waves k_intra runs on it; *dense = intra picture (24 or more blocks per intra CTB on average).
  * Returns the first CTB whose intra blocks overlap (they never do in a picture the reference decodes: one
@@ -888,8 +892,14 @@ static int intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint3
       for (uint32_t k = 0; k < ctb.ib_count; k++) {
         const m355_ib& ib = pic->ibs[ctb.ib_start + key[k].second];
         out[ctb.ib_start + k] = ib;
-        aux[ctb.ib_start + k] = (rel & 0xFFFFu) | ((key[k].first >> 2) << 16);
-        if (!(ib.flags & M355_IBF_PCM) && ib.log2_size >= 2 && ib.log2_size <= 5) rel += (4u << ib.log2_size) + 2u;
+        uint32_t sm = 0;                                 /* which smoothing intra_prediction_sample_filtering (intrapred.h:185-258) will apply */
+        if (!(ib.flags & M355_IBF_PCM) && !(pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (ib.cidx == 0 || pp.chroma_format_idc == 3) && ib.mode != 1 && ib.log2_size != 2) {
+          const int minDist = std::min(abs((int)ib.mode - 26), abs((int)ib.mode - 10));
+          const bool filt = ib.log2_size == 3 ? minDist > 7 : (ib.log2_size == 4 ? minDist > 1 : (ib.log2_size == 5 ? minDist > 0 : false));
+          if (filt) sm = M355_IBA_FILT | (((pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) && ib.cidx == 0 && ib.log2_size == 5) ? M355_IBA_STRONG : 0u);
+        }
+        aux[ctb.ib_start + k] = (rel & 0xFFFFu) | (((key[k].first >> 2) & 0x3FFFu) << 16) | sm;
+        if (!(ib.flags & M355_IBF_PCM) && ib.log2_size >= 2 && ib.log2_size <= 5) rel += (4u << ib.log2_size) + 1u;
         run = (k && key[k].first == key[k - 1].first) ? run + 1 : 1;
         if ((key[k].first & 3) == 0) widest = std::max(widest, run);      /* luma blocks of one level */
       }
@@ -1121,8 +1131,24 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     };
     for (const auto& e : freec) item(e.second);
     n_free = nw;
-    for (int t = 0; t < nCtb; t++)
-      if (pic->ctbs[ts2rs[t]].ib_count && (dep[ts2rs[t]] & 15)) item(ts2rs[t]);
+    /* the dependent CTBs in WAVEFRONT order of their tile (x + 2y, the time at which the CTB's neighbours L / TL / T / TR — all
+       of smaller x + 2y — can have delivered): workgroups are dispatched in this order, so with more CTBs than the GPU holds
+       at once (large pictures, several pictures in flight) the resident ones are those that can run, not the rest of a CTB row
+       whose turn comes much later; any order in which a CTB follows its four neighbours keeps the ticket protocol deadlock-free */
+    std::vector<std::pair<uint32_t, uint32_t>> depc;      /* (x + 2y inside the tile, decode position) */
+    {
+      std::vector<int> tx0((size_t)pp.num_tile_cols * pp.num_tile_rows), ty0(tx0.size());
+      for (int ty = 0, t = 0; ty < pp.num_tile_rows; ty++)
+        for (int tx = 0; tx < pp.num_tile_cols; tx++, t++) { tx0[t] = pp.col_bd[tx]; ty0[t] = pp.row_bd[ty]; }
+      for (int t = 0; t < nCtb; t++) {
+        const uint32_t rs = ts2rs[t];
+        if (!pic->ctbs[rs].ib_count || !(dep[rs] & 15)) continue;
+        const int cx = (int)rs % ctbW, cy = (int)rs / ctbW, ti = tile_id[rs];
+        depc.push_back(std::make_pair((uint32_t)((cx - tx0[ti]) + 2 * (cy - ty0[ti])), (uint32_t)t));
+      }
+    }
+    std::stable_sort(depc.begin(), depc.end());
+    for (const auto& e : depc) item(ts2rs[e.second]);
   }
   seg[i_iw].bytes = sizeof(DevIntraWork) * (size_t)(nw ? nw : 1);
   r.n_intra_work = nw; r.n_iplan = n_iplan;
@@ -1297,6 +1323,15 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   d.cuf = c->cuf; d.pb_of = c->pb_of;
   d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && pp.chroma_format_idc <= 1) ? 0 : 1;   /* else k_inter_jobs writes it */
   d.jobs = c->jobs; d.sao_nb = c->sao_nb; d.iplan = c->iplan;
+#ifdef M355_X_PROF
+  {
+    static unsigned long long* prof = nullptr;
+    if (!prof) { hipMalloc(&prof, 8 * 16384); }
+    hipMemsetAsync(prof, 0, 8 * 16384, c->stream);
+    d.prof = prof;
+    g_prof = prof;
+  }
+#endif
   d.resbuf = c->resbuf; d.edge = c->edge; d.ticket = c->ticket; d.timeout = c->timeout;
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;

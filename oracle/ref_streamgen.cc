@@ -15,13 +15,31 @@
  * from the same helper functions the decoder uses.
  *
  * Streams: picture 0 = IDR (I slice), then P or B pictures referencing the one or two pictures before (RPS in the SPS);
- * one slice per picture; uniform tiles (each its own CABAC substream, entry points in the slice header); 8..12 bit 4:2:0;
- * CTB 64, CUs 8..64, all inter partitions incl. AMP, merge / skip / AMVP with random mvd, intra NxN, transform trees of
- * depth <= 2, random sparse coefficient blocks, SAO parameters per CTB, deblocking on.  No weighted prediction (the
- * reference's slice header writer stops at pred_weight_table, slice.cc:1177), no cu_qp_delta, no transform skip (its
- * residual writer does not code the flag, encoder-syntax.cc:745).
+ * uniform tiles (each its own CABAC substream, entry points in the slice header); 8..12 bit; CTB 64, CUs 8..64, all inter
+ * partitions incl. AMP, merge / skip / AMVP with random mvd, intra NxN, transform trees of depth <= 2, random sparse
+ * coefficient blocks, SAO parameters per CTB, deblocking on.
+ *
+ * With `features` = 0, chroma 4:2:0 and one slice per picture the headers come from the reference's own writers.  Everything
+ * those cannot express is written by OUR writers below, from the syntax tables the reference's PARSER implements (cited per
+ * function) — the reference's writers assert or stop there (slice.cc:1176-1178 pred_weight_table, sps.cc:1085-1092
+ * scaling_list_data, pps.cc:880-891 / sps.cc:1302-1308 range extensions, encoder-syntax.cc:745 transform_skip_flag):
+ *   F_WP        explicit weighted prediction (pred_weight_table, slice.cc:159-231)
+ *   F_TSKIP     transform_skip_flag (slice.cc:2963-2970); with F_REXT also on blocks up to 32x32 (pps range extension)
+ *   F_BYPASS    cu_transquant_bypass_flag (slice.cc:4345-4356)
+ *   F_QPDELTA   cu_qp_delta_abs / sign (slice.cc:3618-3650, quantisation groups slice.cc:4671-4679), slice_qp_delta
+ *   F_PCM       pcm_flag + pcm_sample (slice.cc:4420-4434, 4211-4283), PCM bit depths below the sample bit depth
+ *   F_SCALING   scaling lists: the SPS default lists; F_SCALING_PPS: explicit lists in the PPS (scaling_list_data, sps.cc:939-1081)
+ *   F_REXT      range extensions: implicit / explicit RDPCM (slice.cc:2974-2985), transform_skip_rotation, cross-component
+ *               prediction in 4:4:4 (slice.cc:3527-3583, 3710-3760), cu_chroma_qp_offset (slice.cc:3655-3683)
+ *   F_CIP       constrained_intra_pred_flag
+ *   F_DEPSLICE  every other slice segment of a picture is a dependent one (slice.cc:503-520)
+ *   chroma      0 monochrome, 1 4:2:0, 2 4:2:2, 3 4:4:4 (transform unit layout slice.cc:3584-3860, chroma cbf pairs
+ *               slice.cc:3940-3960, chroma prediction modes slice.cc:4537-4575)
+ *   slices      slice segments per picture, each with its own deblocking override (disable flag, beta / tc offsets),
+ *               SAO flags, loop-filter-across-slices flag and QP (slice.cc:750-826)
  *
  * usage: streamgen out.h265 W H bit_depth tile_cols tile_rows n_frames seed [intra_pct=5] [b_frames=1] [sao=1]
+ *                  [features=0] [chroma=1] [slices=1]
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -52,7 +70,8 @@ void encode_mvd(encoder_context* ectx, CABAC_encoder* cabac, const int16_t mvd[2
 
 namespace {
 
-struct Cfg { int W, H, bd, tc, tr, frames; uint32_t seed; int intra_pct, b_frames, sao; };
+enum { F_WP = 1, F_TSKIP = 2, F_BYPASS = 4, F_QPDELTA = 8, F_PCM = 16, F_SCALING = 32, F_SCALING_PPS = 64, F_REXT = 256, F_CIP = 512, F_DEPSLICE = 1024 };
+struct Cfg { int W, H, bd, tc, tr, frames; uint32_t seed; int intra_pct, b_frames, sao, features, chroma, slices; };
 
 struct Gen {
   Cfg cfg;
