@@ -107,6 +107,12 @@ std::atomic<long long> g_cpu_pixel_calls(0);
 
 /* ------------------------------------------------------------------ per-thread recording --------- */
 
+/* coverage counters of the recorder (tests: a stream that carries a feature must have driven the branch that maps it) */
+enum { FEAT_PCM_CU, FEAT_WEIGHTED_PB, FEAT_BYPASS_RB, FEAT_SKIP_RB, FEAT_RDPCM_RB, FEAT_ROTATE_RB, FEAT_SCALING_RB, FEAT_CROSS_COMP_RB,
+       FEAT_MULTI_SLICE_PIC, FEAT_WEIGHTED_PB_LATER_SLICE, FEAT_NO_BOUNDARY_FILTER_IB, FEAT_FILL_PB, FEAT_CHROMA_422_RB, FEAT_CHROMA_444_RB,
+       FEAT_MONO_PIC, FEAT_DEBLOCK_OFF_SLICE, M355_GLUE_N_FEATURES };
+std::atomic<long long> g_feat[M355_GLUE_N_FEATURES];
+
 struct Run { uint32_t ctb, start, count; };
 
 struct ThreadRec {
@@ -123,10 +129,12 @@ struct ThreadRec {
   int luma_rb = -1;                 /* cross-component prediction: the transform unit's luma block in its size bin */
   int skipped_pbs = 0;              /* prediction units the reference leaves unwritten (motion.cc warnings) */
   bool any_weighted = false;
+  long long feat[M355_GLUE_N_FEATURES] = {};   /* which recorder branches this thread's blocks took (m355_glue_feature_counts) */
   void clear()
   {
     pbs.clear(); for (auto& v : rbs) v.clear(); ibs.clear(); coeffs.clear(); runs.clear();
     res_len = 0; last_ib = -1; luma_rb = -1; skipped_pbs = 0; any_weighted = false; img_id = 0xFFFFFFFFu; owner = nullptr; thread = nullptr;
+    for (long long& f : feat) f = 0;
   }
 };
 
@@ -527,6 +535,11 @@ bool submit_picture(Glue* g, de265_image* img)
   for (int s = 0; s < 4; s++) pic.rb_count[s] = (int32_t)n_rb[s];
   bool any_weighted = false;
   for (ThreadRec* r : recs) any_weighted = any_weighted || r->any_weighted;
+  for (ThreadRec* r : recs) for (int k = 0; k < M355_GLUE_N_FEATURES; k++) if (r->feat[k]) g_feat[k] += r->feat[k];
+  g_feat[FEAT_PCM_CU] += (long long)pcm_cus.size();
+  if (slices.size() > 1) g_feat[FEAT_MULTI_SLICE_PIC]++;
+  if (sps.chroma_format_idc == 0) g_feat[FEAT_MONO_PIC]++;
+  for (const m355_slice& sl : slices) if (sl.flags & M355_SF_DEBLOCK_DISABLED) g_feat[FEAT_DEBLOCK_OFF_SLICE]++;
 
   /* intra blocks: each CTB's run (one thread decodes a whole CTB), CTBs in raster order */
   struct Ref { uint32_t ctb; uint16_t t; uint32_t start, count; };
@@ -800,17 +813,23 @@ void scale_coefficients(thread_context* tctx, int xT, int yT, int x0, int y0, in
   if (tctx->cu_transquant_bypass_flag) {
     rb.kind = M355_RK_BYPASS;
     if (rotate) rb.flags |= M355_RBF_ROTATE;
+    r->feat[FEAT_BYPASS_RB]++;
   } else if (transform_skip_flag) {
     rb.kind = M355_RK_SKIP;
     if (rotate) rb.flags |= M355_RBF_ROTATE;
+    r->feat[FEAT_SKIP_RB]++;
   } else rb.kind = (nT == 4 && cIdx == 0 && cuIntra) ? M355_RK_DST : M355_RK_DCT;                          /* :601-606 */
   if (rb.kind == M355_RK_BYPASS || rb.kind == M355_RK_SKIP) {
     if (rdpcmMode == 1) rb.flags |= M355_RBF_RDPCM_H; else if (rdpcmMode == 2) rb.flags |= M355_RBF_RDPCM_V;
+    if (rdpcmMode) r->feat[FEAT_RDPCM_RB]++;
+    if (rb.flags & M355_RBF_ROTATE) r->feat[FEAT_ROTATE_RB]++;
   }
+  if (cIdx && sps.chroma_format_idc >= 2) r->feat[sps.chroma_format_idc == 2 ? FEAT_CHROMA_422_RB : FEAT_CHROMA_444_RB]++;
   if (sps.scaling_list_enable_flag) {                                 /* matrixID, transform.cc:493-502 */
     int m = nT == 32 ? 0 : cIdx;
     if (!intra) m += nT < 32 ? 3 : 1;
     rb.matrix_id = (uint8_t)m;
+    r->feat[FEAT_SCALING_RB]++;
   }
   std::vector<m355_rb>& bin = r->rbs[log2 - 2];
   if (pps.range_extension.cross_component_prediction_enabled_flag) {
@@ -820,7 +839,7 @@ void scale_coefficients(thread_context* tctx, int xT, int yT, int x0, int y0, in
       const int a = tctx->ResScaleVal < 0 ? -tctx->ResScaleVal : tctx->ResScaleVal;
       const int back = (int)bin.size() - r->luma_rb;                  /* 1 or 2 */
       if (back == 1 || back == 2)
-        rb.matrix_id |= (uint8_t)(((ilog2(a) + 1) << 4) | (tctx->ResScaleVal < 0 ? 0x80 : 0) | (back == 2 ? 8 : 0));
+      { rb.matrix_id |= (uint8_t)(((ilog2(a) + 1) << 4) | (tctx->ResScaleVal < 0 ? 0x80 : 0) | (back == 2 ? 8 : 0)); r->feat[FEAT_CROSS_COMP_RB]++; }
     }
   }
   const int n = tctx->nCoeff[cIdx];
@@ -849,7 +868,7 @@ void decode_intra_prediction(de265_image* img, int xB0, int yB0, enum IntraPredM
   const seq_parameter_set& sps = img->get_sps();
   m355_ib ib; memset(&ib, 0, sizeof(ib));
   ib.x = (uint16_t)xB0; ib.y = (uint16_t)yB0; ib.cidx = (uint8_t)cIdx; ib.log2_size = (uint8_t)ilog2(nT); ib.mode = (uint8_t)intraPredMode;
-  if (sps.range_extension.implicit_rdpcm_enabled_flag && img->get_cu_transquant_bypass(xB0, yB0)) ib.flags |= M355_IBF_DISABLE_BOUNDARY_FILTER;   /* intrapred.cc:306-308 */
+  if (sps.range_extension.implicit_rdpcm_enabled_flag && img->get_cu_transquant_bypass(xB0, yB0)) { ib.flags |= M355_IBF_DISABLE_BOUNDARY_FILTER; r->feat[FEAT_NO_BOUNDARY_FILTER_IB]++; }   /* intrapred.cc:306-308 */
   const int xl = cIdx ? xB0 * sps.SubWidthC : xB0, yl = cIdx ? yB0 * sps.SubHeightC : yB0;
   const uint32_t ctb = (uint32_t)((yl >> sps.Log2CtbSizeY) * sps.PicWidthInCtbsY + (xl >> sps.Log2CtbSizeY));
   if (r->runs.empty() || r->runs.back().ctb != ctb) r->runs.push_back(Run{ctb, (uint32_t)r->ibs.size(), 0});
@@ -906,7 +925,7 @@ void generate_inter_prediction_samples(base_context* ctx, const slice_segment_he
     else if (img->get_bit_depth(0) != refPic->get_bit_depth(0) || img->get_bit_depth(1) != refPic->get_bit_depth(1)) {
       ctx->add_warning(DE265_WARNING_REFERENCE_IMAGE_BIT_DEPTH_DOES_NOT_MATCH, false); usable = false;                                                               /* :375-380 */
     }
-    if (!usable) { img->integrity = INTEGRITY_DECODING_ERRORS; pb.flags |= (uint8_t)(M355_PBF_FILL_L0 << l); }
+    if (!usable) { img->integrity = INTEGRITY_DECODING_ERRORS; pb.flags |= (uint8_t)(M355_PBF_FILL_L0 << l); r->feat[FEAT_FILL_PB]++; }
   }
   /* weighted sample prediction: which branch of motion.cc:493-688 */
   bool weighted = false, write = true;
@@ -931,6 +950,8 @@ void generate_inter_prediction_samples(base_context* ctx, const slice_segment_he
     pb.flags |= M355_PBF_WEIGHTED;
     const unsigned si = img->get_SliceHeaderIndex(xP, yP);
     for (int l = 0; l < 2; l++) pb.wt_idx[l] = (uint16_t)(si * 32 + l * 16 + (vi->refIdx[l] & 15));
+    r->feat[FEAT_WEIGHTED_PB]++;
+    if (si > 0) r->feat[FEAT_WEIGHTED_PB_LATER_SLICE]++;
   }
   r->pbs.push_back(pb);
 }
@@ -1018,6 +1039,12 @@ LIBDE265_API const uint8_t* de265_get_image_plane(const struct de265_image* img,
 /* test / diagnostics hooks of this build (not part of de265.h) */
 LIBDE265_API long long m355_glue_cpu_pixel_calls(void) { return g_cpu_pixel_calls.load(); }
 LIBDE265_API const char* m355_glue_backend_path(void) { Api* A = api(); return A ? A->path.c_str() : ""; }
+/* how often the recorder took each feature branch since the process started (order: FEAT_* above) -> number of counters */
+LIBDE265_API int m355_glue_feature_counts(long long* out, int n)
+{
+  for (int k = 0; k < n && k < M355_GLUE_N_FEATURES; k++) out[k] = g_feat[k].load();
+  return M355_GLUE_N_FEATURES;
+}
 LIBDE265_API int m355_glue_stats(de265_decoder_context* c, long long* pictures, long long* uploads, long long* downloads)
 {
   Glue* g = glue_of((decoder_context*)c);

@@ -46,6 +46,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -86,11 +87,16 @@ struct Gen {
   CABAC_encoder_bitstream* cabac = nullptr;
   uint32_t s = 1;
   int slice_type = SLICE_TYPE_I, nref[2] = {0, 0};
+  int slice_index = 0;                        /* index of shdr in img.slices */
+  bool qg_coded = true, cqo_coded = true;     /* IsCuQpDeltaCoded / IsCuChromaQpOffsetCoded of the parser (slice.cc:4671-4685) */
+  bool cu_bypass = false;                     /* cu_transquant_bypass_flag of the coding unit being written */
 
   uint32_t rnd() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
   int below(int n) { return (int)(rnd() % (uint32_t)n); }
   int range(int lo, int hi) { return lo + below(hi - lo + 1); }
   bool pct(int p) { return below(100) < p; }
+  bool has(int f) const { return (cfg.features & f) != 0; }
+  int cat() const { return sps->ChromaArrayType; }
 
   void bit(int model, int b) { cabac->write_CABAC_bit(model, b); }
   void bypass(int b) { cabac->write_CABAC_bypass(b); }
@@ -100,7 +106,6 @@ struct Gen {
   {
     const seq_parameter_set& S = *sps;
     const int W = S.PicWidthInCtbsY;
-    sao_info info; memset(&info, 0, sizeof(info));
     int merge_left = 0, merge_up = 0;
     if (xCtb > 0) {
       const bool inSlice = ctbAddrRS > (int)shdr->SliceAddrRS;
@@ -114,7 +119,8 @@ struct Gen {
     }
     if (!merge_left && !merge_up) {
       int type_c = 0;
-      for (int c = 0; c < 3; c++) {
+      const int nc = cat() ? 3 : 1;
+      for (int c = 0; c < nc; c++) {
         if (!((shdr->slice_sao_luma_flag && c == 0) || (shdr->slice_sao_chroma_flag && c > 0))) continue;
         int type;
         if (c < 2) {
@@ -134,10 +140,9 @@ struct Gen {
         } else if (c < 2) cabac->write_CABAC_FL_bypass(below(4), 2);           /* edge class (chroma: shared by Cb / Cr) */
       }
     }
-    (void)info;
   }
 
-  /* ---------------- 7.3.8.4 coding quadtree (read_coding_quadtree, slice.cc:4640-4720) ---------------- */
+  /* ---------------- 7.3.8.4 coding quadtree (read_coding_quadtree, slice.cc:4648-4715) ---------------- */
   void coding_quadtree(int x0, int y0, int log2, int depth, int target)
   {
     const seq_parameter_set& S = *sps;
@@ -148,6 +153,9 @@ struct Gen {
       const int condL = availL && img.get_ctDepth(x0 - 1, y0) > depth, condA = availA && img.get_ctDepth(x0, y0 - 1) > depth;
       bit(CONTEXT_MODEL_SPLIT_CU_FLAG + condL + condA, split);
     } else split = log2 > S.Log2MinCbSizeY;
+    /* quantisation groups / chroma QP offset groups start here (slice.cc:4671-4685) */
+    if (pps->cu_qp_delta_enabled_flag && log2 >= pps->Log2MinCuQpDeltaSize) qg_coded = false;
+    if (shdr->cu_chroma_qp_offset_enabled_flag && log2 >= pps->Log2MinCuChromaQpOffsetSize) cqo_coded = false;
     if (split) {
       const int x1 = x0 + (1 << (log2 - 1)), y1 = y0 + (1 << (log2 - 1));
       coding_quadtree(x0, y0, log2 - 1, depth + 1, target);
@@ -206,10 +214,22 @@ struct Gen {
     return false;
   }
 
-  /* ---------------- residual: random sparse block through the reference's own residual_coding writer ---------------- */
+  /* ---------------- 7.3.8.11 residual_coding: what stands in front of the coefficients (slice.cc:2963-2985) is written here
+     (transform_skip_flag, explicit_rdpcm_flag / _dir), the coefficients by the reference's own writer; (x0, y0) = the luma
+     position the parser looks the prediction modes up at ---------------- */
   void residual(int x0, int y0, int log2, int cIdx, bool intra)
   {
     const int n = 1 << log2;
+    bool tskip = false;
+    if (pps->transform_skip_enabled_flag && !cu_bypass && log2 <= pps->Log2MaxTransformSkipSize) {
+      tskip = pct(45);
+      bit(CONTEXT_MODEL_TRANSFORM_SKIP_FLAG + (cIdx ? 1 : 0), tskip);
+    }
+    if (!intra && sps->range_extension.explicit_rdpcm_enabled_flag && (tskip || cu_bypass)) {
+      const int f = pct(60);
+      bit(CONTEXT_MODEL_RDPCM_FLAG + (cIdx ? 1 : 0), f);
+      if (f) bit(CONTEXT_MODEL_RDPCM_DIR + (cIdx ? 1 : 0), below(2));
+    }
     enc_cb cb;
     cb.PredMode = intra ? MODE_INTRA : MODE_INTER;
     enc_tb tb(x0, y0, log2, &cb);
@@ -232,11 +252,67 @@ struct Gen {
     encode_residual(&ectx, cabac, &tb, &cb, x0, y0, log2, cIdx);
   }
 
-  /* ---------------- 7.3.8.8 / 7.3.8.10 transform tree + unit (slice.cc:3870-4025, 3584-3860; 4:2:0) ---------------- */
+  /* cross_comp_pred (slice.cc:3527-3583) */
+  void write_cross_comp_pred(int c)
+  {
+    const int v = pct(35) ? 0 : 1 + below(4);                                   /* log2_res_scale_abs_plus1, TU binarisation, cMax 4 */
+    for (int b = 0; b < 4; b++) {
+      const int more = v > b;
+      bit(CONTEXT_MODEL_LOG2_RES_SCALE_ABS_PLUS1 + 4 * c + b, more);
+      if (!more) break;
+    }
+    if (v) bit(CONTEXT_MODEL_RES_SCALE_SIGN_FLAG + c, below(2));
+  }
+
+  /* ---------------- 7.3.8.10 transform unit (read_transform_unit, slice.cc:3584-3860) ---------------- */
+  void transform_unit(int x0, int y0, int xBase, int yBase, int log2, int blkIdx, bool intra, int cbf_luma, int cbf_cb, int cbf_cr)
+  {
+    const int CAT = cat();
+    const int log2C = std::max(2, CAT == CHROMA_444 ? log2 : log2 - 1);
+    const int cbfChroma = cbf_cb | cbf_cr;
+    if (cbf_luma || cbfChroma) {
+      if (pps->cu_qp_delta_enabled_flag && !qg_coded) {
+        /* cu_qp_delta_abs: prefix TU (cMax 5, first bin its own context), suffix EG0; CuQpDeltaVal stays far inside its range */
+        const int a = pct(40) ? 0 : (pct(90) ? range(1, 4) : range(5, 9));
+        bit(CONTEXT_MODEL_CU_QP_DELTA_ABS + 0, a > 0);
+        if (a > 0) {
+          for (int i = 1; i < 5; i++) { const int more = a > i; bit(CONTEXT_MODEL_CU_QP_DELTA_ABS + 1, more); if (!more) break; }
+          if (a >= 5) cabac->write_CABAC_EGk(a - 5, 0);
+          bypass(below(2));                                                     /* cu_qp_delta_sign_flag */
+        }
+        qg_coded = true;
+      }
+      if (shdr->cu_chroma_qp_offset_enabled_flag && cbfChroma && !cu_bypass && !cqo_coded) {
+        const int f = pct(60);
+        bit(CONTEXT_MODEL_CU_CHROMA_QP_OFFSET_FLAG, f);
+        if (f && pps->range_extension.chroma_qp_offset_list_len > 1) bit(CONTEXT_MODEL_CU_CHROMA_QP_OFFSET_IDX, below(2));
+        cqo_coded = true;
+      }
+    }
+    if (cbf_luma) residual(x0, y0, log2, 0, intra);
+    if (log2 > 2 || CAT == CHROMA_444) {
+      const bool cross = pps->range_extension.cross_component_prediction_enabled_flag && cbf_luma && (!intra || img.is_IntraPredModeC_Mode4(x0, y0));
+      const int yOff = (1 << log2C) * sps->SubHeightC;                          /* 4:2:2: the second chroma block of the unit, in luma rows */
+      if (cross) write_cross_comp_pred(0);
+      if (cbf_cb & 1) residual(x0, y0, log2C, 1, intra);
+      if (CAT == CHROMA_422 && (cbf_cb & 2)) residual(x0, y0 + yOff, log2C, 1, intra);
+      if (cross) write_cross_comp_pred(1);
+      if (cbf_cr & 1) residual(x0, y0, log2C, 2, intra);
+      if (CAT == CHROMA_422 && (cbf_cr & 2)) residual(x0, y0 + yOff, log2C, 2, intra);
+    } else if (blkIdx == 3) {
+      if (cbf_cb & 1) residual(xBase, yBase, 2, 1, intra);
+      if (cbf_cb & 2) residual(xBase, yBase + 4, 2, 1, intra);
+      if (cbf_cr & 1) residual(xBase, yBase, 2, 2, intra);
+      if (cbf_cr & 2) residual(xBase, yBase + 4, 2, 2, intra);
+    }
+  }
+
+  /* ---------------- 7.3.8.8 transform tree (read_transform_tree, slice.cc:3870-4025) ---------------- */
   void transform_tree(int x0, int y0, int xBase, int yBase, int log2, int depth, int blkIdx, int maxDepth, int intraSplit,
                       bool intra, int partMode, int parent_cb, int parent_cr, int cbf_pct)
   {
     const seq_parameter_set& S = *sps;
+    const int CAT = cat();
     int split;
     if (log2 <= S.Log2MaxTrafoSize && log2 > S.Log2MinTrafoSize && depth < maxDepth && !(intraSplit && depth == 0)) {
       split = pct(30);
@@ -245,10 +321,12 @@ struct Gen {
       const int interSplit = S.max_transform_hierarchy_depth_inter == 0 && depth == 0 && !intra && partMode != PART_2Nx2N;
       split = log2 > S.Log2MaxTrafoSize || (intraSplit && depth == 0) || interSplit;
     }
+    if (split) img.set_split_transform_flag(x0, y0, depth);
     int cbf_cb = -1, cbf_cr = -1;
-    if (log2 > 2) {
-      if (parent_cb) { cbf_cb = pct(cbf_pct); bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cb); }
-      if (parent_cr) { cbf_cr = pct(cbf_pct); bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cr); }
+    if ((log2 > 2 && CAT != CHROMA_MONO) || CAT == CHROMA_444) {
+      const bool two = CAT == CHROMA_422 && (!split || log2 == 3);             /* 4:2:2: a flag per stacked chroma block (slice.cc:3940-3960) */
+      if (parent_cb) { cbf_cb = pct(cbf_pct); bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cb); if (two) { const int b = pct(cbf_pct); bit(CONTEXT_MODEL_CBF_CHROMA + depth, b); cbf_cb |= b << 1; } }
+      if (parent_cr) { cbf_cr = pct(cbf_pct); bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cr); if (two) { const int b = pct(cbf_pct); bit(CONTEXT_MODEL_CBF_CHROMA + depth, b); cbf_cr |= b << 1; } }
     }
     if (cbf_cb < 0) cbf_cb = (depth > 0 && log2 == 2) ? parent_cb : 0;
     if (cbf_cr < 0) cbf_cr = (depth > 0 && log2 == 2) ? parent_cr : 0;
@@ -262,15 +340,25 @@ struct Gen {
     }
     int cbf_luma = 1;
     if (intra || depth != 0 || cbf_cb || cbf_cr) { cbf_luma = pct(cbf_pct); bit(CONTEXT_MODEL_CBF_LUMA + (depth == 0), cbf_luma); }
-    /* transform unit: no cu_qp_delta (pps.cu_qp_delta_enabled_flag = 0), no cross-component prediction */
-    if (cbf_luma) residual(x0, y0, log2, 0, intra);
-    if (log2 > 2) {
-      if (cbf_cb) residual(x0, y0, log2 - 1, 1, intra);
-      if (cbf_cr) residual(x0, y0, log2 - 1, 2, intra);
-    } else if (blkIdx == 3) {
-      if (cbf_cb) residual(xBase, yBase, 2, 1, intra);
-      if (cbf_cr) residual(xBase, yBase, 2, 2, intra);
+    transform_unit(x0, y0, xBase, yBase, log2, blkIdx, intra, cbf_luma, cbf_cb, cbf_cr);
+  }
+
+  /* ---------------- pcm_sample (read_pcm_samples, slice.cc:4211-4283): after pcm_flag the arithmetic coder is flushed, a one bit
+     and alignment zeros follow (9.3.2.5 / 9.3.4.3.5), then the raw samples, then the coder starts afresh ---------------- */
+  void pcm_samples(int log2)
+  {
+    const seq_parameter_set& S = *sps;
+    cabac->flush_CABAC();
+    cabac->add_trailing_bits();
+    const int nc = cat() ? 3 : 1;
+    for (int c = 0; c < nc; c++) {
+      const int w = (1 << log2) / (c ? S.SubWidthC : 1), h = (1 << log2) / (c ? S.SubHeightC : 1);
+      const int nb = c ? S.pcm_sample_bit_depth_chroma : S.pcm_sample_bit_depth_luma;
+      const int base = below(1 << nb);
+      for (int i = 0; i < w * h; i++) cabac->write_bits((uint32_t)((base + range(-3, 3)) & ((1 << nb) - 1)), nb);
     }
+    cabac->flush_VLC();
+    cabac->init_CABAC();
   }
 
   /* ---------------- 7.3.8.5 coding unit (read_coding_unit, slice.cc:4315-4636) ---------------- */
@@ -279,6 +367,13 @@ struct Gen {
     const seq_parameter_set& S = *sps;
     const int nCbS = 1 << log2;
     img.set_log2CbSize(x0, y0, log2, true);
+    img.clear_split_transform_flags(x0, y0, log2);
+    cu_bypass = false;
+    if (pps->transquant_bypass_enable_flag) {
+      cu_bypass = pct(18);
+      bit(CONTEXT_MODEL_CU_TRANSQUANT_BYPASS_FLAG, cu_bypass);
+      if (cu_bypass) img.set_cu_transquant_bypass(x0, y0, log2);
+    }
     int skip = 0;
     if (slice_type != SLICE_TYPE_I) {
       skip = pct(20);
@@ -321,6 +416,15 @@ struct Gen {
     img.set_PartMode(x0, y0, (enum PartMode)part);
     bool merge_2Nx2N = false;
     if (intra) {
+      if (part == PART_2Nx2N && S.pcm_enabled_flag && log2 >= S.Log2MinIpcmCbSizeY && log2 <= S.Log2MaxIpcmCbSizeY) {
+        const int pcm = pct(30);
+        cabac->write_CABAC_term_bit(pcm);                                        /* pcm_flag (slice.cc:4420-4426) */
+        if (pcm) {
+          img.set_pcm_flag(x0, y0, log2);
+          pcm_samples(log2);
+          return;
+        }
+      }
       /* prev_intra_luma_pred_flag x n, then mpm_idx / rem_intra_luma_pred_mode per block; the resulting modes are derived as
          the decoder derives them (slice.cc:4436-4500) because the residual scan order depends on them */
       const int pbOffset = part == PART_NxN ? nCbS / 2 : nCbS, log2PU = part == PART_NxN ? log2 - 1 : log2;
@@ -349,14 +453,32 @@ struct Gen {
           img.set_IntraPredMode(PUidx, log2PU, (enum IntraPredMode)mode);
           idx++;
         }
-      const int icpm = below(5);                                               /* intra_chroma_pred_mode, 4 = derived from luma */
-      bit(CONTEXT_MODEL_INTRA_CHROMA_PRED_MODE, icpm != 4);
-      if (icpm != 4) cabac->write_CABAC_FL_bypass(icpm, 2);
-      const int lumaMode = img.get_IntraPredMode(x0, y0);
-      int modeC;
-      if (icpm == 4) modeC = lumaMode;
-      else { static const int tab[4] = {0, 26, 10, 1}; modeC = tab[icpm]; if (modeC == lumaMode) modeC = 34; }
-      img.set_IntraPredModeC(x0, y0, log2, (enum IntraPredMode)modeC, icpm == 4);
+      /* intra_chroma_pred_mode (slice.cc:4537-4575): one per prediction block in 4:4:4, one per coding unit in 4:2:0 / 4:2:2
+         (mapped through Table 8-3 for 4:2:2), none in monochrome; 4 = derived from luma */
+      auto chroma_mode = [&](int lumaMode, int icpm) {
+        if (icpm == 4) return lumaMode;
+        static const int tab[4] = {0, 26, 10, 1};
+        return tab[icpm] == lumaMode ? 34 : tab[icpm];
+      };
+      auto write_icpm = [&]() {
+        const int icpm = below(5);
+        bit(CONTEXT_MODEL_INTRA_CHROMA_PRED_MODE, icpm != 4);
+        if (icpm != 4) cabac->write_CABAC_FL_bypass(icpm, 2);
+        return icpm;
+      };
+      if (cat() == CHROMA_444) {
+        for (int j = 0; j < nCbS; j += pbOffset)
+          for (int i = 0; i < nCbS; i += pbOffset) {
+            const int icpm = write_icpm();
+            img.set_IntraPredModeC(x0 + i, y0 + j, log2PU, (enum IntraPredMode)chroma_mode(img.get_IntraPredMode(x0 + i, y0 + j), icpm), icpm == 4);
+          }
+      } else if (cat() != CHROMA_MONO) {
+        static const uint8_t map422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 12, 13, 15, 17, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31};   /* H.265 Table 8-3 */
+        const int icpm = write_icpm();
+        int modeC = chroma_mode(img.get_IntraPredMode(x0, y0), icpm);
+        if (cat() == CHROMA_422) modeC = map422[modeC];
+        img.set_IntraPredModeC(x0, y0, log2, (enum IntraPredMode)modeC, icpm == 4);
+      }
     } else {
       const int q = nCbS / 4, h = nCbS / 2;
       switch (part) {
@@ -373,31 +495,34 @@ struct Gen {
     if (!intra && !(part == PART_2Nx2N && merge_2Nx2N)) { root_cbf = pct(70); bit(CONTEXT_MODEL_RQT_ROOT_CBF, root_cbf); }
     if (root_cbf) {
       const int maxDepth = intra ? S.max_transform_hierarchy_depth_intra + intraSplit : S.max_transform_hierarchy_depth_inter;
-      transform_tree(x0, y0, x0, y0, log2, 0, 0, maxDepth, intraSplit, intra, part, 1, 1, intra ? 60 : 45);
+      const int c0 = cat() == CHROMA_MONO ? 0 : 1;
+      transform_tree(x0, y0, x0, y0, log2, 0, 0, maxDepth, intraSplit, intra, part, c0, c0, intra ? 60 : 45);
     }
   }
 
-  /* ---------------- one picture: NAL header + slice header + slice data (tiles = CABAC substreams) ---------------- */
-  void slice_data(CABAC_encoder_bitstream& enc, uint32_t seed, std::vector<int>& substream_end)
+  /* ---------------- slice segment data: CTBs [ts0, ts1) in tile-scan order; a tile boundary starts a new CABAC substream
+     (entry points in the slice header).  `keep_ctx`: a dependent slice segment continues with the context models the segment
+     before it ended with (slice.cc:4917-4935). ---------------- */
+  void slice_data(CABAC_encoder_bitstream& enc, uint32_t seed, int ts0, int ts1, bool keep_ctx, const context_model_table& start_ctx, std::vector<int>& substream_end)
   {
     cabac = &enc;
     s = seed ? seed : 1;
-    img.clear_metadata();
     const seq_parameter_set& S = *sps;
-    const int nCtb = S.PicSizeInCtbsY, W = S.PicWidthInCtbsY;
+    const int W = S.PicWidthInCtbsY;
     enc.set_context_models(&ctx);
-    ctx.init(shdr->initType, shdr->SliceQPY);
+    if (keep_ctx) ctx = start_ctx.copy(); else ctx.init(shdr->initType, shdr->SliceQPY);
     enc.init_CABAC();
     const int start = enc.size();
     substream_end.clear();
-    for (int ts = 0; ts < nCtb; ts++) {
+    qg_coded = cqo_coded = true;
+    for (int ts = ts0; ts < ts1; ts++) {
       const int rs = pps->scan->CtbAddrTStoRS[ts], xCtb = rs % W, yCtb = rs / W;
       img.set_SliceAddrRS(xCtb, yCtb, shdr->SliceAddrRS);
-      img.set_SliceHeaderIndex(xCtb << S.Log2CtbSizeY, yCtb << S.Log2CtbSizeY, 0);
+      img.set_SliceHeaderIndex(xCtb << S.Log2CtbSizeY, yCtb << S.Log2CtbSizeY, slice_index);
       if (shdr->slice_sao_luma_flag || shdr->slice_sao_chroma_flag) write_sao(xCtb, yCtb, rs);
       const int target = 3 + below(S.Log2CtbSizeY - 2);
       coding_quadtree(xCtb << S.Log2CtbSizeY, yCtb << S.Log2CtbSizeY, S.Log2CtbSizeY, 0, target);
-      const bool last = ts == nCtb - 1;
+      const bool last = ts == ts1 - 1;
       enc.write_CABAC_term_bit(last);                                          /* end_of_slice_segment_flag */
       if (!last && pps->scan->TileId[ts + 1] != pps->scan->TileId[ts]) {
         enc.write_CABAC_term_bit(1);                                           /* end_of_subset_one_bit */
@@ -413,6 +538,155 @@ struct Gen {
     enc.add_trailing_bits();                                                   /* rbsp_slice_segment_trailing_bits */
     enc.flush_VLC();
   }
+
+  /* ---------------- 7.3.6.3 pred_weight_table (read_pred_weight_table, slice.cc:150-240) ---------------- */
+  void write_pred_weight_table(CABAC_encoder& out, const slice_segment_header* sh)
+  {
+    const int ldenom = below(8);
+    const int cdenom = cat() ? below(8) : ldenom;
+    out.write_uvlc(ldenom);
+    if (cat()) out.write_svlc(cdenom - ldenom);
+    for (int l = 0; l <= (sh->slice_type == SLICE_TYPE_B ? 1 : 0); l++) {
+      const int n = nref[l];
+      int lf[16], cf[16];
+      for (int i = 0; i < n; i++) { lf[i] = pct(75); out.write_bit(lf[i]); }
+      if (cat()) for (int i = 0; i < n; i++) { cf[i] = pct(75); out.write_bit(cf[i]); }
+      for (int i = 0; i < n; i++) {
+        if (lf[i]) { out.write_svlc(range(-((1 << ldenom) / 2 + 4), 24)); out.write_svlc(range(-20, 20)); }   /* delta_luma_weight, luma_offset */
+        if (cat() && cf[i]) for (int j = 0; j < 2; j++) { out.write_svlc(range(-((1 << cdenom) / 2 + 4), 24)); out.write_svlc(range(-40, 40)); }   /* delta_chroma_weight, delta_chroma_offset */
+      }
+    }
+  }
+
+  /* ---------------- 7.3.6.1 slice segment header (slice_segment_header::read, slice.cc:388-900).  RPS by SPS index, no
+     long-term pictures, no list modification, no temporal MVP (all off in the parameter sets below). ---------------- */
+  void write_slice_header(CABAC_encoder& out, const slice_segment_header* sh, int nal_type)
+  {
+    const seq_parameter_set& S = *sps;
+    const pic_parameter_set& P = *pps;
+    out.write_bit(sh->first_slice_segment_in_pic_flag);
+    if (isRapPic((uint8_t)nal_type)) out.write_bit(0);                          /* no_output_of_prior_pics_flag */
+    out.write_uvlc(0);                                                          /* slice_pic_parameter_set_id */
+    if (!sh->first_slice_segment_in_pic_flag) {
+      if (P.dependent_slice_segments_enabled_flag) out.write_bit(sh->dependent_slice_segment_flag);
+      out.write_bits(sh->slice_segment_address, ceil_log2(S.PicSizeInCtbsY));
+    }
+    if (!sh->dependent_slice_segment_flag) {
+      out.write_uvlc(sh->slice_type);
+      if (nal_type != NAL_UNIT_IDR_W_RADL && nal_type != NAL_UNIT_IDR_N_LP) {
+        out.write_bits(sh->slice_pic_order_cnt_lsb, S.log2_max_pic_order_cnt_lsb);
+        out.write_bit(1);                                                       /* short_term_ref_pic_set_sps_flag */
+        const int nb = ceil_log2(S.num_short_term_ref_pic_sets());
+        if (nb > 0) out.write_bits(sh->short_term_ref_pic_set_idx, nb);
+      }
+      if (S.sample_adaptive_offset_enabled_flag) {
+        out.write_bit(sh->slice_sao_luma_flag);
+        if (cat() != CHROMA_MONO) out.write_bit(sh->slice_sao_chroma_flag);
+      }
+      if (sh->slice_type != SLICE_TYPE_I) {
+        out.write_bit(1);                                                       /* num_ref_idx_active_override_flag */
+        out.write_uvlc(nref[0] - 1);
+        if (sh->slice_type == SLICE_TYPE_B) { out.write_uvlc(nref[1] - 1); out.write_bit(0); }   /* mvd_l1_zero_flag */
+        if ((P.weighted_pred_flag && sh->slice_type == SLICE_TYPE_P) || (P.weighted_bipred_flag && sh->slice_type == SLICE_TYPE_B)) write_pred_weight_table(out, sh);
+        out.write_uvlc(sh->five_minus_max_num_merge_cand);
+      }
+      out.write_svlc(sh->slice_qp_delta);
+      if (P.pps_slice_chroma_qp_offsets_present_flag) { out.write_svlc(sh->slice_cb_qp_offset); out.write_svlc(sh->slice_cr_qp_offset); }
+      if (P.range_extension.chroma_qp_offset_list_enabled_flag) out.write_bit(sh->cu_chroma_qp_offset_enabled_flag);
+      if (P.deblocking_filter_override_enabled_flag) out.write_bit(sh->deblocking_filter_override_flag);
+      if (sh->deblocking_filter_override_flag) {
+        out.write_bit(sh->slice_deblocking_filter_disabled_flag);
+        if (!sh->slice_deblocking_filter_disabled_flag) { out.write_svlc(sh->slice_beta_offset / 2); out.write_svlc(sh->slice_tc_offset / 2); }
+      }
+      if (P.pps_loop_filter_across_slices_enabled_flag && (sh->slice_sao_luma_flag || sh->slice_sao_chroma_flag || !sh->slice_deblocking_filter_disabled_flag))
+        out.write_bit(sh->slice_loop_filter_across_slices_enabled_flag);
+    }
+    if (P.tiles_enabled_flag || P.entropy_coding_sync_enabled_flag) {
+      out.write_uvlc(sh->num_entry_point_offsets);
+      if (sh->num_entry_point_offsets > 0) {
+        out.write_uvlc(sh->offset_len - 1);
+        for (int i = 0; i < sh->num_entry_point_offsets; i++) out.write_bits(sh->entry_point_offset[i] - (i ? sh->entry_point_offset[i - 1] : 0) - 1, sh->offset_len);
+      }
+    }
+  }
+
+  /* ---------------- 7.3.4 scaling_list_data (read_scaling_list, sps.cc:939-1081): per size and matrix either a reference
+     (0 = the default list, d = the d-th matrix before this one) or 16 / 64 coefficients as differences (+ the DC of 16x16 / 32x32) */
+  void write_scaling_list_data(CABAC_encoder& out)
+  {
+    for (int sizeId = 0; sizeId < 4; sizeId++)
+      for (int matrixId = 0; matrixId < 6; matrixId += sizeId == 3 ? 3 : 1) {
+        const int explicit_ = pct(60);
+        out.write_bit(explicit_);                                               /* scaling_list_pred_mode_flag */
+        if (!explicit_) { out.write_uvlc(below((sizeId == 3 ? matrixId / 3 : matrixId) + 1)); continue; }
+        const int n = sizeId == 0 ? 16 : 64;
+        int next = 8;
+        if (sizeId > 1) { const int dc = range(4, 40); out.write_svlc(dc - 8); next = dc; }
+        for (int i = 0; i < n; i++) {
+          const int v = std::min(255, std::max(1, 8 + i / 2 + range(-4, 12)));  /* rising with frequency, like real lists */
+          int d = v - next;
+          if (d > 127) d -= 256; else if (d < -128) d += 256;
+          out.write_svlc(d);
+          next = v;
+        }
+      }
+  }
+
+  /* ---------------- 7.3.2.3 picture parameter set incl. pps_range_extension (pic_parameter_set::read, pps.cc:280-560,
+     pps_range_extension::read pps.cc:50-143) ---------------- */
+  void write_pps(CABAC_encoder& out)
+  {
+    const pic_parameter_set& P = *pps;
+    out.write_uvlc(0); out.write_uvlc(0);                                       /* pps / sps id */
+    out.write_bit(P.dependent_slice_segments_enabled_flag);
+    out.write_bit(0);                                                           /* output_flag_present_flag */
+    out.write_bits(0, 3);                                                       /* num_extra_slice_header_bits */
+    out.write_bit(0);                                                           /* sign_data_hiding_enabled_flag */
+    out.write_bit(0);                                                           /* cabac_init_present_flag */
+    out.write_uvlc(P.num_ref_idx_l0_default_active - 1); out.write_uvlc(P.num_ref_idx_l1_default_active - 1);
+    out.write_svlc(P.pic_init_qp - 26);
+    out.write_bit(P.constrained_intra_pred_flag);
+    out.write_bit(P.transform_skip_enabled_flag);
+    out.write_bit(P.cu_qp_delta_enabled_flag);
+    if (P.cu_qp_delta_enabled_flag) out.write_uvlc(P.diff_cu_qp_delta_depth);
+    out.write_svlc(P.pic_cb_qp_offset); out.write_svlc(P.pic_cr_qp_offset);
+    out.write_bit(P.pps_slice_chroma_qp_offsets_present_flag);
+    out.write_bit(P.weighted_pred_flag); out.write_bit(P.weighted_bipred_flag);
+    out.write_bit(P.transquant_bypass_enable_flag);
+    out.write_bit(P.tiles_enabled_flag);
+    out.write_bit(0);                                                           /* entropy_coding_sync_enabled_flag */
+    if (P.tiles_enabled_flag) {
+      out.write_uvlc(P.num_tile_columns - 1); out.write_uvlc(P.num_tile_rows - 1);
+      out.write_bit(1);                                                         /* uniform_spacing_flag */
+      out.write_bit(P.loop_filter_across_tiles_enabled_flag);
+    }
+    out.write_bit(P.pps_loop_filter_across_slices_enabled_flag);
+    out.write_bit(P.deblocking_filter_control_present_flag);
+    if (P.deblocking_filter_control_present_flag) {
+      out.write_bit(P.deblocking_filter_override_enabled_flag);
+      out.write_bit(P.pic_disable_deblocking_filter_flag);
+      if (!P.pic_disable_deblocking_filter_flag) { out.write_svlc(P.beta_offset / 2); out.write_svlc(P.tc_offset / 2); }
+    }
+    out.write_bit(P.pic_scaling_list_data_present_flag);
+    if (P.pic_scaling_list_data_present_flag) write_scaling_list_data(out);
+    out.write_bit(0);                                                           /* lists_modification_present_flag */
+    out.write_uvlc(0);                                                          /* log2_parallel_merge_level_minus2 */
+    out.write_bit(0);                                                           /* slice_segment_header_extension_present_flag */
+    out.write_bit(P.pps_range_extension_flag);                                  /* pps_extension_present_flag */
+    if (P.pps_range_extension_flag) {
+      out.write_bit(1); out.write_bit(0); out.write_bits(0, 6);                 /* range / multilayer / 6 more extension flags */
+      const pps_range_extension& R = P.range_extension;
+      if (P.transform_skip_enabled_flag) out.write_uvlc(R.log2_max_transform_skip_block_size - 2);
+      out.write_bit(R.cross_component_prediction_enabled_flag);
+      out.write_bit(R.chroma_qp_offset_list_enabled_flag);
+      if (R.chroma_qp_offset_list_enabled_flag) {
+        out.write_uvlc(R.diff_cu_chroma_qp_offset_depth);
+        out.write_uvlc(R.chroma_qp_offset_list_len - 1);
+        for (int i = 0; i < R.chroma_qp_offset_list_len; i++) { out.write_svlc(R.cb_qp_offset_list[i]); out.write_svlc(R.cr_qp_offset_list[i]); }
+      }
+      out.write_uvlc(0); out.write_uvlc(0);                                     /* log2_sao_offset_scale_luma / _chroma */
+    }
+  }
 };
 
 int run(const Cfg& cfg, const char* out_name)
@@ -421,6 +695,8 @@ int run(const Cfg& cfg, const char* out_name)
   std::unique_ptr<Gen> G(new Gen);
   Gen& g = *G;
   g.cfg = cfg;
+  const bool plain = cfg.features == 0 && cfg.chroma == 1 && cfg.slices == 1;  /* then every header comes from the reference's own writers */
+  const bool rext = g.has(F_REXT);
   g.vps = std::make_shared<video_parameter_set>();
   g.sps = std::make_shared<seq_parameter_set>();
   g.pps = std::make_shared<pic_parameter_set>();
@@ -430,7 +706,7 @@ int run(const Cfg& cfg, const char* out_name)
   S.set_CB_log2size_range(3, 6);
   S.set_TB_log2size_range(2, 5);
   S.set_resolution(cfg.W, cfg.H);
-  S.chroma_format_idc = 1;
+  S.chroma_format_idc = cfg.chroma;
   S.bit_depth_luma = S.bit_depth_chroma = cfg.bd;
   S.log2_max_pic_order_cnt_lsb = 8;
   S.sps_max_dec_pic_buffering[0] = 4; S.sps_max_num_reorder_pics[0] = 0; S.sps_max_latency_increase_plus1[0] = 0;
@@ -439,9 +715,23 @@ int run(const Cfg& cfg, const char* out_name)
   S.amp_enabled_flag = 1;
   S.sample_adaptive_offset_enabled_flag = cfg.sao ? 1 : 0;
   S.pcm_enabled_flag = 0;
+  if (g.has(F_PCM)) {
+    S.pcm_enabled_flag = 1;
+    S.pcm_sample_bit_depth_luma = cfg.bd - 1; S.pcm_sample_bit_depth_chroma = cfg.bd - 2;     /* samples are shifted up to the bit depth (slice.cc:4243-4253) */
+    S.log2_min_pcm_luma_coding_block_size = 3; S.log2_diff_max_min_pcm_luma_coding_block_size = 2;
+    S.pcm_loop_filter_disable_flag = (cfg.seed >> 1) & 1;
+  }
+  if (g.has(F_SCALING) || g.has(F_SCALING_PPS)) { S.scaling_list_enable_flag = 1; S.sps_scaling_list_data_present_flag = 0; }   /* the SPS carries the default lists */
   S.long_term_ref_pics_present_flag = 0;
   S.sps_temporal_mvp_enabled_flag = 0;
   S.strong_intra_smoothing_enable_flag = 1;
+  if (rext) {
+    S.sps_extension_present_flag = 1; S.sps_range_extension_flag = 1;
+    S.range_extension.transform_skip_rotation_enabled_flag = 1;
+    S.range_extension.implicit_rdpcm_enabled_flag = 1;
+    S.range_extension.explicit_rdpcm_enabled_flag = 1;
+    S.range_extension.intra_smoothing_disabled_flag = (cfg.seed >> 2) & 1;
+  }
   S.ref_pic_sets.resize(2);
   for (int k = 0; k < 2; k++) {
     ref_pic_set& r = S.ref_pic_sets[k];
@@ -464,10 +754,33 @@ int run(const Cfg& cfg, const char* out_name)
   P.pps_loop_filter_across_slices_enabled_flag = 1;
   P.deblocking_filter_control_present_flag = 0;
   P.pic_cb_qp_offset = 1; P.pic_cr_qp_offset = -1;
+  if (!plain) {
+    P.constrained_intra_pred_flag = g.has(F_CIP);
+    P.transform_skip_enabled_flag = g.has(F_TSKIP);
+    P.transquant_bypass_enable_flag = g.has(F_BYPASS);
+    P.cu_qp_delta_enabled_flag = g.has(F_QPDELTA); P.diff_cu_qp_delta_depth = g.has(F_QPDELTA) ? 1 + (int)(cfg.seed & 1) : 0;
+    P.pps_slice_chroma_qp_offsets_present_flag = g.has(F_QPDELTA) && cfg.chroma != 0;
+    P.weighted_pred_flag = P.weighted_bipred_flag = g.has(F_WP);
+    P.dependent_slice_segments_enabled_flag = g.has(F_DEPSLICE);
+    if (cfg.slices > 1) { P.deblocking_filter_control_present_flag = 1; P.deblocking_filter_override_enabled_flag = 1; P.pic_disable_deblocking_filter_flag = 0; P.beta_offset = 2; P.tc_offset = -2; }
+    P.pic_scaling_list_data_present_flag = g.has(F_SCALING_PPS);
+    if (rext) {
+      P.pps_extension_flag = 1; P.pps_range_extension_flag = 1;
+      P.range_extension.log2_max_transform_skip_block_size = g.has(F_TSKIP) ? 5 : 2;
+      P.range_extension.cross_component_prediction_enabled_flag = cfg.chroma == 3;
+      if (cfg.chroma != 0) {
+        P.range_extension.chroma_qp_offset_list_enabled_flag = 1;
+        P.range_extension.diff_cu_chroma_qp_offset_depth = 1;
+        P.range_extension.chroma_qp_offset_list_len = 2;
+        P.range_extension.cb_qp_offset_list[0] = 3; P.range_extension.cr_qp_offset_list[0] = -4;
+        P.range_extension.cb_qp_offset_list[1] = -6; P.range_extension.cr_qp_offset_list[1] = 5;
+      }
+    }
+  }
   P.set_derived_values(g.sps.get());
   P.pps_read = true;
 
-  if (g.img.alloc_image(cfg.W, cfg.H, de265_chroma_420, g.sps, true, &g.dctx, 0, nullptr, false) != DE265_OK) return 2;
+  if (g.img.alloc_image(cfg.W, cfg.H, (de265_chroma)cfg.chroma, g.sps, true, &g.dctx, 0, nullptr, false) != DE265_OK) return 2;
   g.img.set_headers(g.vps, g.sps, g.pps);
   g.ectx.img = &g.img;
 
@@ -476,63 +789,133 @@ int run(const Cfg& cfg, const char* out_name)
   CABAC_encoder_bitstream out;
   nal_header nal;
   out.write_startcode(); nal.set(NAL_UNIT_VPS_NUT); nal.write(out); g.vps->write(&g.dctx, out); out.add_trailing_bits(); out.flush_VLC();
-  out.write_startcode(); nal.set(NAL_UNIT_SPS_NUT); nal.write(out); g.sps->write(&g.dctx, out); out.add_trailing_bits(); out.flush_VLC();
-  out.write_startcode(); nal.set(NAL_UNIT_PPS_NUT); nal.write(out); g.pps->write(&g.dctx, out, g.sps.get()); out.add_trailing_bits(); out.flush_VLC();
+  out.write_startcode(); nal.set(NAL_UNIT_SPS_NUT); nal.write(out); g.sps->write(&g.dctx, out);
+  if (rext) {
+    /* sps_range_extension (sps_range_extension::read, sps.cc:1357-1371): the reference's writer stops at sps_extension_present_flag */
+    const sps_range_extension& R = S.range_extension;
+    out.write_bit(1); out.write_bit(0); out.write_bits(0, 6);                   /* range / multilayer / 6 more extension flags */
+    out.write_bit(R.transform_skip_rotation_enabled_flag); out.write_bit(R.transform_skip_context_enabled_flag);
+    out.write_bit(R.implicit_rdpcm_enabled_flag); out.write_bit(R.explicit_rdpcm_enabled_flag);
+    out.write_bit(R.extended_precision_processing_flag); out.write_bit(R.intra_smoothing_disabled_flag);
+    out.write_bit(R.high_precision_offsets_enabled_flag); out.write_bit(R.persistent_rice_adaptation_enabled_flag);
+    out.write_bit(R.cabac_bypass_alignment_enabled_flag);
+  }
+  out.add_trailing_bits(); out.flush_VLC();
+  out.write_startcode(); nal.set(NAL_UNIT_PPS_NUT); nal.write(out);
+  if (plain) g.pps->write(&g.dctx, out, g.sps.get()); else { g.s = cfg.seed * 7919u + 13u; g.write_pps(out); }
+  out.add_trailing_bits(); out.flush_VLC();
   fwrite(out.data(), 1, out.size(), f);
 
+  const int nCtb = S.PicSizeInCtbsY;
   for (int fr = 0; fr < cfg.frames; fr++) {
-    slice_segment_header* sh = new slice_segment_header;                      /* owned by the image (img.slices) */
-    g.shdr = sh;
-    g.img.slices.clear();
-    g.img.slices.push_back(sh);
     const int type = fr == 0 ? SLICE_TYPE_I : ((cfg.b_frames && (fr & 1) == 0) ? SLICE_TYPE_B : SLICE_TYPE_P);
     const int nal_type = fr == 0 ? NAL_UNIT_IDR_W_RADL : NAL_UNIT_TRAIL_R;
     const int nrefs = fr >= 2 ? 2 : fr;
-    sh->first_slice_segment_in_pic_flag = 1;
-    sh->slice_pic_parameter_set_id = 0;
-    sh->slice_type = type;
-    sh->pic_output_flag = 1;
-    sh->slice_pic_order_cnt_lsb = fr & 0xFF;
-    sh->short_term_ref_pic_set_sps_flag = 1;
-    sh->short_term_ref_pic_set_idx = nrefs >= 2 ? 1 : 0;
-    sh->slice_sao_luma_flag = sh->slice_sao_chroma_flag = cfg.sao ? 1 : 0;
-    sh->num_ref_idx_active_override_flag = type != SLICE_TYPE_I;
-    sh->num_ref_idx_l0_active = nrefs; sh->num_ref_idx_l1_active = nrefs;
-    sh->five_minus_max_num_merge_cand = 0;
-    sh->slice_qp_delta = 0;
-    sh->slice_loop_filter_across_slices_enabled_flag = 1;
-    sh->slice_deblocking_filter_disabled_flag = P.pic_disable_deblocking_filter_flag;
-    sh->pps = g.pps;
-    sh->SliceAddrRS = 0; sh->slice_segment_address = 0;
-    sh->compute_derived_values(g.pps.get());
     g.slice_type = type; g.nref[0] = g.nref[1] = nrefs;
-    const uint32_t seed = cfg.seed * 2654435761u + 977u * (uint32_t)fr + 1u;
-
-    /* pass 1: the slice data alone, for the entry points of the tile substreams */
-    std::vector<int> ends;
-    { CABAC_encoder_bitstream scratch; g.slice_data(scratch, seed, ends); }
-    sh->num_entry_point_offsets = (int)ends.size();
-    sh->entry_point_offset.clear();
-    int maxd = 1;
-    for (size_t i = 0; i < ends.size(); i++) { const int d = ends[i] - (i ? ends[i - 1] : 0); if (d > maxd) maxd = d; sh->entry_point_offset.push_back((uint32_t)ends[i]); }
-    sh->offset_len = 1; while ((1 << sh->offset_len) < maxd) sh->offset_len++;
-    /* pass 2: NAL header, slice header, the same slice data */
-    CABAC_encoder_bitstream enc;
-    enc.write_startcode();
-    nal.set(nal_type); nal.write(enc);
-    /* the header writer takes num_ref_idx_lX_active as the syntax element (minus 1) and leaves the count behind */
-    sh->num_ref_idx_l0_active = nrefs - 1; sh->num_ref_idx_l1_active = nrefs - 1;
-    if (sh->write(&g.dctx, enc, g.sps.get(), g.pps.get(), (uint8_t)nal_type) != DE265_OK) { fprintf(stderr, "streamgen: slice header not writable\n"); return 2; }
-    if (type == SLICE_TYPE_I) { sh->num_ref_idx_l0_active = sh->num_ref_idx_l1_active = 0; }
-    if (type == SLICE_TYPE_P) sh->num_ref_idx_l1_active = 0;
-    enc.add_trailing_bits();                                                   /* byte_alignment() of the slice header */
-    enc.flush_VLC();
-    std::vector<int> ends2;
-    g.slice_data(enc, seed, ends2);
-    if (ends2 != ends) { fprintf(stderr, "streamgen: substream sizes changed between the passes\n"); return 3; }
-    fwrite(enc.data(), 1, enc.size(), f);
+    /* slice segments: [cut[k], cut[k+1]) in tile-scan order; with tiles a segment holds whole tiles (7.4.7.1) */
+    std::vector<int> cut;
+    cut.push_back(0);
+    if (cfg.slices > 1) {
+      uint32_t sr = cfg.seed * 2246822519u + 3266489917u * (uint32_t)(fr + 1);
+      auto r = [&]() { sr ^= sr << 13; sr ^= sr >> 17; sr ^= sr << 5; return sr; };
+      std::vector<int> cand;
+      for (int ts = 1; ts < nCtb; ts++) if (!P.tiles_enabled_flag || P.scan->TileId[ts] != P.scan->TileId[ts - 1]) cand.push_back(ts);
+      for (int k = 1; k < cfg.slices && !cand.empty(); k++) { const size_t i = r() % cand.size(); cut.push_back(cand[i]); cand.erase(cand.begin() + i); }
+      std::sort(cut.begin(), cut.end());
+    }
+    cut.push_back(nCtb);
+    g.img.clear_metadata();
+    for (slice_segment_header* h : g.img.slices) delete h;
     g.img.slices.clear();
-    delete sh;
+    context_model_table end_ctx;                                               /* context models at the end of the previous segment */
+    uint32_t indep_addr = 0;
+    slice_segment_header* indep = nullptr;
+    for (size_t k = 0; k + 1 < cut.size(); k++) {
+      slice_segment_header* sh = new slice_segment_header;                    /* owned by the image (img.slices) */
+      g.shdr = sh;
+      g.slice_index = (int)g.img.slices.size();
+      g.img.slices.push_back(sh);
+      const bool dependent = g.has(F_DEPSLICE) && k > 0 && (k & 1);
+      uint32_t hr = cfg.seed * 40503u + 2654435761u * (uint32_t)(fr * 64 + (int)k + 1);
+      auto r = [&]() { hr ^= hr << 13; hr ^= hr >> 17; hr ^= hr << 5; return hr; };
+      if (dependent) *sh = *indep;                                              /* a dependent segment inherits the header of its slice (slice.cc:424-444) */
+      sh->first_slice_segment_in_pic_flag = k == 0;
+      sh->dependent_slice_segment_flag = dependent;
+      sh->slice_segment_address = P.scan->CtbAddrTStoRS[cut[k]];
+      sh->slice_pic_parameter_set_id = 0;
+      sh->pps = g.pps;
+      if (!dependent) {
+        indep_addr = sh->slice_segment_address;
+        sh->slice_type = type;
+        sh->pic_output_flag = 1;
+        sh->slice_pic_order_cnt_lsb = fr & 0xFF;
+        sh->short_term_ref_pic_set_sps_flag = 1;
+        sh->short_term_ref_pic_set_idx = nrefs >= 2 ? 1 : 0;
+        sh->slice_sao_luma_flag = sh->slice_sao_chroma_flag = cfg.sao ? 1 : 0;
+        sh->num_ref_idx_active_override_flag = type != SLICE_TYPE_I;
+        sh->num_ref_idx_l0_active = nrefs; sh->num_ref_idx_l1_active = nrefs;
+        sh->five_minus_max_num_merge_cand = 0;
+        sh->slice_qp_delta = 0;
+        sh->slice_loop_filter_across_slices_enabled_flag = 1;
+        sh->slice_deblocking_filter_disabled_flag = P.pic_disable_deblocking_filter_flag;
+        sh->slice_beta_offset = P.beta_offset; sh->slice_tc_offset = P.tc_offset;
+        if (!plain) {
+          if (cfg.chroma == 0) sh->slice_sao_chroma_flag = 0;
+          if (g.has(F_QPDELTA)) { sh->slice_qp_delta = (int)(r() % 13) - 6; if (cfg.chroma) { sh->slice_cb_qp_offset = (int)(r() % 7) - 3; sh->slice_cr_qp_offset = (int)(r() % 7) - 3; } }
+          if (P.range_extension.chroma_qp_offset_list_enabled_flag) sh->cu_chroma_qp_offset_enabled_flag = 1;
+          if (cfg.slices > 1) {
+            /* every slice its own in-loop filter parameters (what deblock.cc:184-216, 521-523 and sao.cc:122-164, 367 read) */
+            if (cfg.sao) { sh->slice_sao_luma_flag = r() % 4 != 0; sh->slice_sao_chroma_flag = cfg.chroma ? r() % 4 != 0 : 0; }
+            sh->deblocking_filter_override_flag = r() % 4 != 0;
+            if (sh->deblocking_filter_override_flag) {
+              sh->slice_deblocking_filter_disabled_flag = r() % 4 == 0;
+              if (!sh->slice_deblocking_filter_disabled_flag) { sh->slice_beta_offset = 2 * ((int)(r() % 7) - 3); sh->slice_tc_offset = 2 * ((int)(r() % 7) - 3); }
+            }
+            sh->slice_loop_filter_across_slices_enabled_flag = r() % 3 != 0;
+          }
+        }
+        sh->SliceAddrRS = sh->slice_segment_address;
+        sh->compute_derived_values(g.pps.get());
+        sh->MaxNumMergeCand = 5 - sh->five_minus_max_num_merge_cand;
+        sh->SliceQPY = P.pic_init_qp + sh->slice_qp_delta;
+        sh->initType = type == SLICE_TYPE_I ? 0 : (type == SLICE_TYPE_P ? 1 : 2);
+        indep = sh;
+      } else sh->SliceAddrRS = indep_addr;
+      const uint32_t seed = cfg.seed * 2654435761u + 977u * (uint32_t)fr + 131071u * (uint32_t)k + 1u;
+
+      /* pass 1: the slice data alone, for the entry points of the tile substreams */
+      std::vector<int> ends;
+      { CABAC_encoder_bitstream scratch; g.slice_data(scratch, seed, cut[k], cut[k + 1], dependent, end_ctx, ends); }
+      sh->num_entry_point_offsets = (int)ends.size();
+      sh->entry_point_offset.clear();
+      int maxd = 1;
+      for (size_t i = 0; i < ends.size(); i++) { const int d = ends[i] - (i ? ends[i - 1] : 0); if (d > maxd) maxd = d; sh->entry_point_offset.push_back((uint32_t)ends[i]); }
+      sh->offset_len = 1; while ((1 << sh->offset_len) < maxd) sh->offset_len++;
+      /* pass 2: NAL header, slice header, the same slice data */
+      CABAC_encoder_bitstream enc;
+      enc.write_startcode();
+      nal.set(nal_type); nal.write(enc);
+      if (plain) {
+        /* the header writer takes num_ref_idx_lX_active as the syntax element (minus 1) and leaves the count behind */
+        sh->num_ref_idx_l0_active = nrefs - 1; sh->num_ref_idx_l1_active = nrefs - 1;
+        if (sh->write(&g.dctx, enc, g.sps.get(), g.pps.get(), (uint8_t)nal_type) != DE265_OK) { fprintf(stderr, "streamgen: slice header not writable\n"); return 2; }
+      } else {
+        g.s = seed ^ 0x9E3779B9u;                                              /* (the weight table draws from the generator) */
+        g.write_slice_header(enc, sh, nal_type);
+      }
+      if (type == SLICE_TYPE_I) { sh->num_ref_idx_l0_active = sh->num_ref_idx_l1_active = 0; }
+      if (type == SLICE_TYPE_P) { sh->num_ref_idx_l0_active = nrefs; sh->num_ref_idx_l1_active = 0; }
+      if (type == SLICE_TYPE_B) { sh->num_ref_idx_l0_active = sh->num_ref_idx_l1_active = nrefs; }
+      enc.add_trailing_bits();                                                   /* byte_alignment() of the slice header */
+      enc.flush_VLC();
+      std::vector<int> ends2;
+      g.slice_data(enc, seed, cut[k], cut[k + 1], dependent, end_ctx, ends2);
+      if (ends2 != ends) { fprintf(stderr, "streamgen: substream sizes changed between the passes\n"); return 3; }
+      end_ctx = g.ctx.copy();
+      fwrite(enc.data(), 1, enc.size(), f);
+    }
+    for (slice_segment_header* h : g.img.slices) delete h;
+    g.img.slices.clear();
   }
   fclose(f);
   return 0;
@@ -542,11 +925,13 @@ int run(const Cfg& cfg, const char* out_name)
 
 int main(int argc, char** argv)
 {
-  if (argc < 9) { fprintf(stderr, "usage: %s out.h265 W H bit_depth tile_cols tile_rows n_frames seed [intra_pct=5] [b_frames=1] [sao=1]\n", argv[0]); return 2; }
+  if (argc < 9) { fprintf(stderr, "usage: %s out.h265 W H bit_depth tile_cols tile_rows n_frames seed [intra_pct=5] [b_frames=1] [sao=1] [features=0] [chroma=1] [slices=1]\n", argv[0]); return 2; }
   Cfg c;
   c.W = atoi(argv[2]); c.H = atoi(argv[3]); c.bd = atoi(argv[4]); c.tc = atoi(argv[5]); c.tr = atoi(argv[6]); c.frames = atoi(argv[7]);
   c.seed = (uint32_t)strtoul(argv[8], nullptr, 0);
   c.intra_pct = argc > 9 ? atoi(argv[9]) : 5; c.b_frames = argc > 10 ? atoi(argv[10]) : 1; c.sao = argc > 11 ? atoi(argv[11]) : 1;
-  if (c.W % 8 || c.H % 8 || c.W < 16 || c.H < 16 || c.bd < 8 || c.bd > 12 || c.tc < 1 || c.tr < 1 || c.frames < 1) { fprintf(stderr, "streamgen: bad arguments\n"); return 2; }
+  c.features = argc > 12 ? (int)strtol(argv[12], nullptr, 0) : 0; c.chroma = argc > 13 ? atoi(argv[13]) : 1; c.slices = argc > 14 ? atoi(argv[14]) : 1;
+  if (c.W % 8 || c.H % 8 || c.W < 16 || c.H < 16 || c.bd < 8 || c.bd > 12 || c.tc < 1 || c.tr < 1 || c.frames < 1 || c.chroma < 0 || c.chroma > 3 || c.slices < 1 || c.slices > 32) { fprintf(stderr, "streamgen: bad arguments\n"); return 2; }
+  if ((c.features & F_PCM) && c.bd - 2 < 1) { fprintf(stderr, "streamgen: bad arguments\n"); return 2; }
   return run(c, argv[1]);
 }

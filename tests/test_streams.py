@@ -3,7 +3,12 @@ parameter-set / slice-header writers and residual writer) decoded LIVE through d
 (oracle/_ref/libde265_ref.so, scalar and SIMD) and by glue/_build/libde265.so, whose pixels come from the MI355X backend —
 and compared bit for bit.  This is what pins the glue's recorder and the kernels on what girlshy does not contain: P and B
 slices with merge / skip / AMVP motion the DECODER derives, two reference pictures, uniform tiles decoded by parallel threads,
-10-bit samples, AMP partitions, intra NxN inside inter pictures, SAO parameters with merge candidates.
+10-bit samples, AMP partitions, intra NxN inside inter pictures, SAO parameters with merge candidates — and, through the
+generator's own writers (feature streams below), explicit weighted prediction, transform skip, RDPCM, transform_skip_rotation,
+cu_transquant_bypass, cu_qp_delta / slice QP and chroma QP offsets, PCM units, default and explicit scaling lists, constrained
+intra prediction, several (dependent) slice segments per picture with their own deblocking / SAO parameters, monochrome /
+4:2:2 / 4:4:4 with cross-component prediction.  Each feature case also asserts, through the glue's coverage counters, that the
+recorder branch which maps the feature really ran.
 
 CPU tier: small streams, backend = SIMT-interpreter build.  GPU tier: up to 4K tiled 10-bit."""
 import ctypes
@@ -22,26 +27,45 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STREAMGEN = os.path.join(ROOT, "oracle", "_ref", "streamgen")
 
 
-def make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra_pct=5, b_frames=1, sao=1):
+# feature bits of oracle/ref_streamgen.cc (what the reference's own writers cannot express: written by OUR writers there)
+F_WP, F_TSKIP, F_BYPASS, F_QPDELTA, F_PCM, F_SCALING, F_SCALING_PPS, F_REXT, F_CIP, F_DEPSLICE = 1, 2, 4, 8, 16, 32, 64, 256, 512, 1024
+# coverage counters of the glue's recorder (glue/m355_glue.cc FEAT_*): a stream that carries a feature must drive its branch
+FEATS = ["pcm_cu", "weighted_pb", "bypass_rb", "skip_rb", "rdpcm_rb", "rotate_rb", "scaling_rb", "cross_comp_rb", "multi_slice_pic",
+         "weighted_pb_later_slice", "no_boundary_filter_ib", "fill_pb", "chroma_422_rb", "chroma_444_rb", "mono_pic", "deblock_off_slice"]
+
+
+def make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra_pct=5, b_frames=1, sao=1, features=0, chroma=1, slices=1):
     if not os.path.exists(STREAMGEN):
         if not os.path.isdir("/root/reference"):
             pytest.skip("oracle/_ref/streamgen not available here")
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-j8", "gen"], check=True, stdout=subprocess.DEVNULL)
     out = os.path.join(str(tmp_path), "s_%dx%d_%d_%dx%d_%d.h265" % (w, h, bd, tc, tr, seed))
-    subprocess.run([STREAMGEN, out, str(w), str(h), str(bd), str(tc), str(tr), str(frames), str(seed), str(intra_pct), str(b_frames), str(sao)], check=True)
+    subprocess.run([STREAMGEN, out, str(w), str(h), str(bd), str(tc), str(tr), str(frames), str(seed), str(intra_pct), str(b_frames), str(sao),
+                    str(features), str(chroma), str(slices)], check=True)
     return open(out, "rb").read()
 
 
-def check(ref, data, frames, threads, backend):
+def feature_counts(lib):
+    lib.m355_glue_feature_counts.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+    buf = (ctypes.c_longlong * len(FEATS))()
+    assert lib.m355_glue_feature_counts(buf, len(FEATS)) == len(FEATS)
+    return dict(zip(FEATS, list(buf)))
+
+
+def check(ref, data, frames, threads, backend, expect=()):
     want = de265_py.decode_stream(ref, data, threads=0, scalar=True)
     assert want[1] == frames and not want[2], "the reference itself rejects the generated stream: %r" % (want,)
     assert de265_py.decode_stream(ref, data, threads=threads)[0] == want[0]          # SIMD tables, tile threads
     lib = glue_lib()
+    before = feature_counts(lib)
     got = de265_py.decode_stream(lib, data, threads=threads)
     assert got[:2] == want[:2], "live decode on the backend differs from the reference decoder"
     assert set(got[2]) <= {1000}, got[2]       # (DE265_WARNING_NO_WPP_CANNOT_USE_MULTITHREADING: threads asked for on a stream without tiles)
     assert lib.m355_glue_cpu_pixel_calls() == 0
     assert os.path.realpath(lib.m355_glue_backend_path().decode()) == os.path.realpath(backend)
+    after = feature_counts(lib)
+    for name in expect:                         # the stream really drove the recorder branch it is there for
+        assert after[name] > before[name], "the stream did not exercise '%s' (%r)" % (name, {k: after[k] - before[k] for k in FEATS})
 
 
 CPU_CASES = [(416, 240, 8, 1, 1, 4, 21), (448, 256, 10, 2, 2, 4, 22)]
@@ -51,6 +75,55 @@ CPU_CASES = [(416, 240, 8, 1, 1, 4, 21), (448, 256, 10, 2, 2, 4, 22)]
 def test_generated_streams_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, w, h, bd, tc, tr, frames, seed):  # noqa: F811
     monkeypatch.setenv("M355_LIB", EMU_SO)
     check(ref, make_stream(tmp_path, w, h, bd, tc, tr, frames, seed), frames, 4, EMU_SO)
+
+
+# Feature streams: everything the glue's recorder maps by hand (glue/m355_glue.cc), each pinned against the reference DECODER.
+# (w, h, bit depth, tile cols, tile rows, frames, seed, intra %, features, chroma format, slices, recorder branches that must run)
+FEATURE_CPU_CASES = [
+    (256, 128, 8, 1, 1, 3, 41, 20, F_WP | F_TSKIP | F_BYPASS | F_QPDELTA | F_PCM | F_SCALING_PPS | F_REXT | F_CIP | F_DEPSLICE, 1, 3,
+     ("pcm_cu", "weighted_pb", "bypass_rb", "skip_rb", "rdpcm_rb", "scaling_rb", "multi_slice_pic", "weighted_pb_later_slice")),
+    (192, 128, 8, 1, 1, 3, 42, 30, F_REXT | F_TSKIP | F_BYPASS, 3, 1, ("cross_comp_rb", "chroma_444_rb", "rotate_rb", "rdpcm_rb", "no_boundary_filter_ib")),
+    (192, 128, 10, 2, 1, 3, 43, 30, F_REXT | F_TSKIP | F_PCM | F_WP, 2, 2, ("chroma_422_rb", "pcm_cu", "weighted_pb", "multi_slice_pic")),
+    (192, 128, 8, 1, 1, 3, 44, 10, F_SCALING | F_QPDELTA, 0, 2, ("mono_pic", "scaling_rb")),
+]
+
+
+@pytest.mark.parametrize("w,h,bd,tc,tr,frames,seed,intra,feat,chroma,slices,expect", FEATURE_CPU_CASES)
+def test_feature_streams_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, w, h, bd, tc, tr, frames, seed, intra, feat, chroma, slices, expect):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    check(ref, make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra, 1, 1, feat, chroma, slices), frames, 3, EMU_SO, expect)
+
+
+FEATURE_GPU_CASES = [
+    (832, 480, 8, 1, 1, 6, 51, 5, F_WP, 1, 1, ("weighted_pb",)),
+    (832, 480, 10, 2, 2, 6, 52, 10, F_WP | F_QPDELTA, 1, 4, ("weighted_pb", "weighted_pb_later_slice", "multi_slice_pic")),
+    (832, 480, 8, 1, 1, 5, 53, 10, F_TSKIP, 1, 1, ("skip_rb",)),
+    (832, 480, 8, 1, 1, 5, 54, 15, F_BYPASS, 1, 1, ("bypass_rb",)),
+    (832, 480, 9, 1, 1, 5, 55, 10, F_QPDELTA, 1, 3, ("multi_slice_pic",)),
+    (832, 480, 8, 2, 1, 5, 56, 40, F_PCM, 1, 1, ("pcm_cu",)),
+    (832, 480, 10, 1, 1, 5, 57, 40, F_PCM | F_CIP, 1, 2, ("pcm_cu",)),
+    (832, 480, 8, 1, 1, 5, 58, 10, F_SCALING, 1, 1, ("scaling_rb",)),
+    (832, 480, 10, 1, 1, 5, 59, 10, F_SCALING_PPS, 1, 1, ("scaling_rb",)),
+    (832, 480, 8, 1, 1, 5, 60, 30, F_CIP, 1, 1, ()),
+    (1280, 720, 8, 1, 1, 4, 61, 5, 0, 1, 6, ("multi_slice_pic", "deblock_off_slice")),
+    (1280, 720, 8, 3, 2, 4, 62, 5, F_DEPSLICE, 1, 5, ("multi_slice_pic",)),
+    (832, 480, 8, 1, 1, 5, 63, 10, F_REXT | F_TSKIP | F_BYPASS, 1, 1, ("rdpcm_rb", "rotate_rb", "skip_rb", "bypass_rb")),
+    (832, 480, 8, 1, 1, 5, 64, 10, 0, 2, 1, ("chroma_422_rb",)),
+    (832, 480, 8, 1, 1, 5, 65, 10, 0, 3, 1, ("chroma_444_rb",)),
+    (832, 480, 8, 1, 1, 5, 66, 10, 0, 0, 1, ("mono_pic",)),
+    (832, 480, 10, 2, 1, 5, 67, 30, F_REXT | F_TSKIP | F_BYPASS | F_WP | F_QPDELTA, 3, 2, ("cross_comp_rb", "chroma_444_rb", "rdpcm_rb", "weighted_pb")),
+    (832, 480, 12, 1, 2, 5, 68, 30, F_REXT | F_TSKIP | F_BYPASS | F_PCM | F_SCALING_PPS, 2, 2, ("chroma_422_rb", "pcm_cu", "scaling_rb")),
+    (1920, 1080, 8, 2, 2, 4, 69, 20, F_WP | F_TSKIP | F_BYPASS | F_QPDELTA | F_PCM | F_SCALING_PPS | F_REXT | F_CIP | F_DEPSLICE, 1, 6,
+     ("pcm_cu", "weighted_pb", "bypass_rb", "skip_rb", "rdpcm_rb", "scaling_rb", "multi_slice_pic", "weighted_pb_later_slice")),
+    (1920, 1080, 10, 1, 1, 3, 70, 100, F_TSKIP | F_BYPASS | F_QPDELTA | F_PCM | F_SCALING | F_REXT | F_CIP, 3, 3, ("pcm_cu", "cross_comp_rb", "scaling_rb")),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bd,tc,tr,frames,seed,intra,feat,chroma,slices,expect", FEATURE_GPU_CASES)
+def test_feature_streams_gpu(ref, tmp_path, monkeypatch, w, h, bd, tc, tr, frames, seed, intra, feat, chroma, slices, expect):
+    monkeypatch.delenv("M355_LIB", raising=False)
+    check(ref, make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra, 1, 1, feat, chroma, slices), frames, 8, capi.DEFAULT_LIB, expect)
 
 
 GPU_CASES = [(416, 240, 8, 1, 1, 8, 31, 5, 1, 1), (832, 480, 10, 3, 2, 8, 32, 10, 1, 1), (1920, 1080, 8, 2, 1, 5, 33, 30, 0, 1),
