@@ -4,16 +4,18 @@
  * Linked with the reference's OWN objects (compiled from /root/reference where it lies, see glue/Makefile)
  * into glue/_build/libde265.so: a libde265 with the unchanged public de265.h ABI whose pixel path runs on the
  * GPU.  Nothing of the reference is copied or edited; the reference functions below are REPLACED at link time
- * (their definitions in the reference objects are weakened with objcopy, ours win):
+ * (their definitions in the reference objects are weakened with objcopy, ours win, the linker drops the originals):
  *
  *   scale_coefficients                  transform.cc:645   -> record one m355_rb + the parser's sparse levels
  *   decode_intra_prediction             intrapred.cc:321   -> record one m355_ib (decode order)
  *   generate_inter_prediction_samples   motion.cc:288      -> record one m355_pb with the host-side decisions
  *   decoder_context::run_postprocessing_filters_sequential / _parallel   decctx.cc:1783 / 1811
  *                                                          -> walk the picture's metadata, m355_submit_picture()
+ *   process_sei                         sei.cc:436         -> decoded picture hash SEIs are checked against the DEVICE frame (m355_frame_hash)
  *   de265_new_decoder / de265_free_decoder / de265_get_image_plane   de265.cc:254-281, 729-738 (renamed in de265.o, wrapped here)
  *                                                          -> backend context; a picture is downloaded when its samples are asked for
- * deblock.cc and sao.cc are not linked at all (their four entry points exist here only as traps).
+ * deblock.cc, sao.cc, fallback-*.cc and x86/*.cc are not compiled at all (the entry points the parser's objects still name
+ * exist here as traps; init_acceleration_functions_fallback fills the decoder's table with counting traps).
  *
  * The host keeps doing everything it did before — NAL / CABAC parsing, MV and QP derivation, DPB management,
  * output order — and NO pixel arithmetic: every slot of the decoder's acceleration table is replaced by a trap
@@ -42,10 +44,12 @@
 
 #include "libde265/de265.h"
 #include "libde265/decctx.h"
+#include "libde265/fallback.h"
 #include "libde265/image.h"
 #include "libde265/intrapred.h"
 #include "libde265/motion.h"
 #include "libde265/pps.h"
+#include "libde265/sei.h"
 #include "libde265/slice.h"
 #include "libde265/sps.h"
 #include "libde265/transform.h"
@@ -68,7 +72,7 @@ namespace {
 #define M355_FUNCS(X) \
   X(m355_last_error) X(m355_device_count) X(m355_create) X(m355_destroy) X(m355_frame_create) X(m355_frame_destroy) \
   X(m355_frame_upload) X(m355_frame_download) X(m355_submit_picture) X(m355_wait) X(m355_set_pipeline_depth) \
-  X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash) X(m355_arena_begin)
+  X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash) X(m355_arena_begin) X(m355_last_serial) X(m355_decode_status)
 
 struct Api {
   void* handle = nullptr;
@@ -179,14 +183,20 @@ struct Glue {
   uint32_t dev_id[M355_MAX_REF_FRAMES];     /* image ID whose pixels the slot's device frame holds */
   uint32_t host_id[M355_MAX_REF_FRAMES];    /* image ID whose pixels the host planes hold (downloaded) */
   int geom[M355_MAX_REF_FRAMES][5];
+  /* asynchronous outcome of the submits (lists recorded in place are checked on the device, m355_decode_status): the serial of
+     the decode that produced each slot's device frame while its outcome is unknown, and whether that frame is damaged (its own
+     lists were rejected, or it was predicted from a damaged frame) */
+  unsigned long long pending_serial[M355_MAX_REF_FRAMES];
+  bool damaged[M355_MAX_REF_FRAMES];
+  long long n_rejected = 0;
   PlanePool planes;
   /* statistics (m355_glue_stats) */
-  long long n_pictures = 0, n_uploads = 0, n_downloads = 0;
+  long long n_pictures = 0, n_uploads = 0, n_downloads = 0, n_hashed = 0;
   double ms_walk = 0, ms_submit = 0, ms_download = 0;
   std::string error;
   Glue()
   {
-    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) { frame_of_slot[i] = -1; dev_id[i] = host_id[i] = 0xFFFFFFFFu; }
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) { frame_of_slot[i] = -1; dev_id[i] = host_id[i] = 0xFFFFFFFFu; pending_serial[i] = 0; damaged[i] = false; }
   }
 };
 
@@ -340,17 +350,38 @@ bool upload_host_planes(Glue* g, int slot, const de265_image* img)
   return true;
 }
 
+/* Collect the outcome of the decodes whose status is still open (non-blocking unless `wait_for_slot` >= 0: then that slot's
+ * decode is waited for).  A picture whose lists the device rejected was not decoded: it is marked as the reference marks a
+ * picture with decoding errors (image.h:347 integrity; decctx.cc checks it when the picture is output), pictures predicted
+ * from it are marked when they are submitted. */
+void collect_status(Glue* g, int wait_for_slot)
+{
+  for (int s = 0; s < M355_MAX_REF_FRAMES; s++) {
+    if (!g->pending_serial[s]) continue;
+    int st = api()->m355_decode_status(g->mctx, g->pending_serial[s]);
+    while (st == M355_ERR_BUSY && s == wait_for_slot) { std::this_thread::yield(); st = api()->m355_decode_status(g->mctx, g->pending_serial[s]); }
+    if (st == M355_ERR_BUSY) continue;
+    if (st != M355_OK) {
+      g->error = api()->m355_last_error();
+      fprintf(stderr, "libde265 (MI355X glue): %s\n", g->error.c_str());
+      g->damaged[s] = true;
+      g->n_rejected++;
+      de265_image* im = g->dctx->has_image(s) ? g->dctx->get_image(s) : nullptr;
+      if (im && im->get_ID() == g->dev_id[s]) im->integrity = INTEGRITY_DECODING_ERRORS;
+      g->dctx->add_warning(DE265_WARNING_INCORRECT_ENTRY_POINT_OFFSET, false);   /* there is no backend-specific warning code in de265.h */
+    }
+    g->pending_serial[s] = 0;
+  }
+}
+
 void download_if_needed(Glue* g, de265_image* img)
 {
   const int slot = slot_of(g->dctx, img);
   if (slot < 0 || g->frame_of_slot[slot] < 0) return;
   if (g->dev_id[slot] != img->get_ID() || g->host_id[slot] == img->get_ID()) return;
   const auto t0 = std::chrono::steady_clock::now();
-  if (api()->m355_wait(g->mctx) != M355_OK) {      /* device-side list validation / spin bounds report here */
-    g->error = api()->m355_last_error();
-    fprintf(stderr, "libde265 (MI355X glue): %s\n", g->error.c_str());
-    img->integrity = INTEGRITY_DECODING_ERRORS;
-  }
+  collect_status(g, slot);                         /* this picture's own outcome (waits for its decode) */
+  if (g->damaged[slot] && img->integrity == INTEGRITY_CORRECT) img->integrity = INTEGRITY_DERIVED_FROM_FAULTY_REFERENCE;
   const int nc = img->get_chroma_format() == de265_chroma_mono ? 1 : 3;
   for (int c = 0; c < nc; c++)
     if (api()->m355_frame_download(g->mctx, g->frame_of_slot[slot], c, img->get_image_plane(c), img->get_image_stride(c)) != M355_OK) {
@@ -718,6 +749,9 @@ bool submit_picture(Glue* g, de265_image* img)
     }
     pic.ref_frames[s] = g->frame_of_slot[s];
   }
+  collect_status(g, -1);                           /* outcomes known by now (non-blocking) */
+  bool from_damaged = false;
+  for (int s = 0; s < M355_MAX_REF_FRAMES; s++) if (used[s] && g->damaged[s]) from_damaged = true;
 
   long long area = 0;
   for (int y = 0; y < sps.PicHeightInMinCbsY; y++) area += (long long)sps.PicWidthInMinCbsY;
@@ -763,6 +797,9 @@ bool submit_picture(Glue* g, de265_image* img)
   if (rc != M355_OK) { g->error = A->m355_last_error(); return false; }
   g->dev_id[dslot] = img->get_ID();
   g->host_id[dslot] = 0xFFFFFFFFu;
+  g->pending_serial[dslot] = A->m355_last_serial(g->mctx);
+  g->damaged[dslot] = from_damaged;
+  if (from_damaged && img->integrity == INTEGRITY_CORRECT) img->integrity = INTEGRITY_DERIVED_FROM_FAULTY_REFERENCE;
   g->n_pictures++;
   return true;
 }
@@ -785,9 +822,7 @@ void picture_complete(decoder_context* d, de265_image* img)
       g->cur_id = 0xFFFFFFFFu;
     }
   }
-  /* a decoded-picture-hash SEI is checked by the reference on the host planes right after this call (decctx.cc:634-641,
-     sei.cc:276-356): bring the picture back for it */
-  if (d->param_sei_check_hash) download_if_needed(g, img);
+  /* (a decoded-picture-hash SEI is checked right after this call, decctx.cc:634-641: process_sei below hashes the DEVICE frame) */
 }
 
 } // namespace
@@ -960,6 +995,42 @@ void generate_inter_prediction_samples(base_context* ctx, const slice_segment_he
 void decoder_context::run_postprocessing_filters_sequential(de265_image* img) { picture_complete(this, img); }
 void decoder_context::run_postprocessing_filters_parallel(image_unit* imgunit) { picture_complete(this, imgunit->img); }
 
+/* sei.cc:436 — SEI messages attached to a decoded picture.  The reference hashes the host planes (compute_MD5 /
+ * compute_CRC_8bit_fast / compute_checksum, sei.cc:161-274, called from process_sei_decoded_picture_hash :276-356); here the
+ * picture lives on the device and is hashed THERE (m355_frame_hash: CRC and checksum by reduction kernels, nothing is copied back;
+ * MD5 — one serial chain per plane — by the backend's host threads on a copy it brings back itself): a stream that carries hash
+ * SEIs costs no download into the application's planes either. */
+de265_error process_sei(const sei_message* sei, de265_image* img)
+{
+  if (sei->payload_type != sei_payload_type_decoded_picture_hash || !img->decctx->param_sei_check_hash) return DE265_OK;
+  if (img->PicOutputFlag == false) return DE265_OK;                          /* sei.cc:280-287 */
+  Glue* g = glue_of(img->decctx);
+  if (!g) return DE265_OK;
+  const int slot = slot_of(g->dctx, img);
+  if (slot < 0 || g->frame_of_slot[slot] < 0 || g->dev_id[slot] != img->get_ID()) return DE265_OK;   /* not a picture the backend decoded */
+  collect_status(g, slot);                                                    /* waits for its decode; a rejected picture is reported there */
+  const sei_decoded_picture_hash* want = &sei->data.decoded_picture_hash;
+  const int type = want->hash_type == sei_decoded_picture_hash_type_MD5 ? M355_HASH_MD5 : (want->hash_type == sei_decoded_picture_hash_type_CRC ? M355_HASH_CRC : M355_HASH_CHECKSUM);
+  if (want->hash_type > sei_decoded_picture_hash_type_checksum) return DE265_OK;
+  m355_picture_hash got; memset(&got, 0, sizeof(got));
+  if (api()->m355_frame_hash(g->mctx, g->frame_of_slot[slot], type, &got) != M355_OK) {
+    fprintf(stderr, "libde265 (MI355X glue): picture hash: %s\n", api()->m355_last_error());
+    return DE265_ERROR_CHECKSUM_MISMATCH;
+  }
+  g->n_hashed++;
+  const int n = img->get_sps().chroma_format_idc == 0 ? 1 : 3;
+  for (int c = 0; c < n; c++) {
+    if (type == M355_HASH_MD5 && memcmp(got.md5[c], want->md5[c], 16) != 0) return DE265_ERROR_CHECKSUM_MISMATCH;
+    if (type == M355_HASH_CRC && got.crc[c] != want->crc[c]) return DE265_ERROR_CHECKSUM_MISMATCH;
+    if (type == M355_HASH_CHECKSUM && got.checksum[c] != want->checksum[c]) return DE265_ERROR_CHECKSUM_MISMATCH;
+  }
+  return DE265_OK;
+}
+
+/* fallback.cc:28 — the only table filler this build's decctx.cc knows (no SIMD switches in its config.h).  The reference's pixel
+ * kernels (fallback-*.cc, x86/*) are not compiled into this library at all: the table is filled with the counting traps. */
+void init_acceleration_functions_fallback(struct acceleration_functions* accel) { install_traps(*accel); }
+
 /* deblock.cc / sao.cc are not part of this build; their entry points only exist so that the (unreachable) weakened
  * originals of the two functions above still link */
 static void pixel_path_trap(const char* what) { fprintf(stderr, "libde265 (MI355X glue): CPU pixel path reached: %s\n", what); abort(); }
@@ -1013,7 +1084,13 @@ LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)
     fprintf(stderr, "m355 glue: %lld pictures submitted, %lld uploaded, %lld downloaded; host ms per picture: lists %.3f, submit %.3f; download %.3f ms each; cpu pixel calls %lld\n",
             g->n_pictures, g->n_uploads, g->n_downloads, g->n_pictures ? g->ms_walk / g->n_pictures : 0.0, g->n_pictures ? g->ms_submit / g->n_pictures : 0.0,
             g->n_downloads ? g->ms_download / g->n_downloads : 0.0, g_cpu_pixel_calls.load());
-  if (g) api()->m355_wait(g->mctx);
+  if (g) {
+    collect_status(g, -1);
+    while (api()->m355_wait(g->mctx) != M355_OK) {           /* (one rejected picture per call) */
+      fprintf(stderr, "libde265 (MI355X glue): at shutdown: %s\n", api()->m355_last_error());
+      if (++g->n_rejected > 1000) break;
+    }
+  }
   const de265_error e = m355ref_de265_free_decoder(c);      /* releases the images into the pool */
   if (g) {
     api()->m355_destroy(g->mctx);
@@ -1045,6 +1122,8 @@ LIBDE265_API int m355_glue_feature_counts(long long* out, int n)
   for (int k = 0; k < n && k < M355_GLUE_N_FEATURES; k++) out[k] = g_feat[k].load();
   return M355_GLUE_N_FEATURES;
 }
+LIBDE265_API long long m355_glue_hashed_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); return g ? g->n_hashed : -1; }
+LIBDE265_API long long m355_glue_rejected_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); return g ? g->n_rejected : -1; }
 LIBDE265_API int m355_glue_stats(de265_decoder_context* c, long long* pictures, long long* uploads, long long* downloads)
 {
   Glue* g = glue_of((decoder_context*)c);

@@ -48,7 +48,8 @@ enum {
   M355_ERR_HIP = 2,           /* a HIP call failed; m355_last_error() has the text   */
   M355_ERR_INVALID = 3,       /* malformed work list / bad argument                  */
   M355_ERR_NOMEM = 4,
-  M355_ERR_TIMEOUT = 5        /* intra wavefront spin bound exceeded (device flag)   */
+  M355_ERR_TIMEOUT = 5,       /* intra wavefront spin bound exceeded (device flag)   */
+  M355_ERR_BUSY = 6           /* m355_decode_status: the decode has not finished yet */
 };
 
 M355_API const char* m355_last_error(void);
@@ -445,8 +446,18 @@ typedef struct m355_arena_caps {
   m355_rb* rb_bin[4];              /* out: where the residual blocks of each size go */
 } m355_arena_caps;
 M355_API int m355_arena_begin(m355_ctx* ctx, m355_arena_caps* caps, m355_picture* pic);
-/* Blocks until all submitted work finished; returns M355_ERR_TIMEOUT if a device spin bound hit. */
+/* Blocks until all submitted work finished; returns M355_ERR_TIMEOUT if a device spin bound hit, M355_ERR_INVALID if a picture
+ * recorded in place was rejected by the device-side list validation (the message names the picture's serial and the record; the
+ * next call reports the next rejected picture, if any). */
 M355_API int m355_wait(m355_ctx* ctx);
+/* Per-picture outcome of asynchronous submits.  The record checks of lists recorded in place (m355_arena_begin) run on the device,
+ * ahead of the picture's kernels: m355_submit_picture has returned M355_OK long before a rejection is known.  Every decode gets
+ * a serial (1, 2, ...); m355_decode_status(serial) is non-blocking: M355_ERR_BUSY while the decode runs, M355_OK when it finished,
+ * M355_ERR_INVALID when its lists were rejected — none of its kernels acted on them, the destination frame was NOT written
+ * (m355_last_error names the record).  Kept for the last 64 decodes.  The caller marks the picture and whatever references it
+ * as damaged (the reference does the same bookkeeping with de265_image::integrity, image.h:347). */
+M355_API unsigned long long m355_last_serial(m355_ctx* ctx);      /* of the decode the last submit / decode call enqueued */
+M355_API int m355_decode_status(m355_ctx* ctx, unsigned long long serial);
 
 /* Resident work lists (benchmarks, replay): upload once, decode many times. */
 M355_API int m355_picture_upload(m355_ctx* ctx, const m355_picture* pic);   /* -> handle >= 0 */

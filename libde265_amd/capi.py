@@ -11,7 +11,7 @@ from . import worklist
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libde265_mi355x.so")
 
-ERRORS = {1: "M355_ERR_NO_DEVICE", 2: "M355_ERR_HIP", 3: "M355_ERR_INVALID", 4: "M355_ERR_NOMEM", 5: "M355_ERR_TIMEOUT"}
+ERRORS = {1: "M355_ERR_NO_DEVICE", 2: "M355_ERR_HIP", 3: "M355_ERR_INVALID", 4: "M355_ERR_NOMEM", 5: "M355_ERR_TIMEOUT", 6: "M355_ERR_BUSY"}
 
 
 class M355Error(RuntimeError):
@@ -65,6 +65,9 @@ class Library:
         L.m355_frame_hash.argtypes = [vp, i, i, vp]
         L.m355_submit_picture.argtypes = [vp, vp]
         L.m355_wait.argtypes = [vp]
+        L.m355_last_serial.argtypes = [vp]
+        L.m355_last_serial.restype = ctypes.c_ulonglong
+        L.m355_decode_status.argtypes = [vp, ctypes.c_ulonglong]
         L.m355_picture_upload.argtypes = [vp, vp]
         L.m355_picture_release.argtypes = [vp, i]
         L.m355_decode_resident.argtypes = [vp, i]
@@ -204,6 +207,14 @@ class Context:
 
     def wait(self):
         self.L.check(self.L.lib.m355_wait(self.h))
+
+    def last_serial(self):
+        """serial of the decode the last submit / decode call enqueued"""
+        return int(self.L.lib.m355_last_serial(self.h))
+
+    def decode_status(self, serial):
+        """non-blocking: 0 finished and fine, 6 (M355_ERR_BUSY) still running, 3 (M355_ERR_INVALID) lists rejected on the device"""
+        return int(self.L.lib.m355_decode_status(self.h, serial))
 
     def upload(self, pic):
         c, keep = pic.to_c()

@@ -101,9 +101,11 @@ struct DevPic {
                                        columns of all CTB columns [ctbX][row >> 1], then the bottom rows of all CTB rows [ctbY][col >> 1] */
   uint32_t edge_col_ofs[3], edge_row_ofs[3];   /* first granule of each component's column / row arrays */
   uint32_t* ticket;                 /* work counter */
-  uint32_t* timeout;                /* [0] set when a spin bound is exceeded; [1] this decode's lists were rejected by k_validate
-                                       (every kernel of the decode returns at once); [2] lowest rejected (list << 28 | record), sticky
-                                       until m355_wait reports it */
+  uint32_t* timeout;                /* [0] set when a spin bound is exceeded; [1] epoch of the last decode of this lane whose lists
+                                       k_validate rejected (every kernel of THAT decode returns at once: M355_GATE); [2..3] one 64-bit
+                                       word, ~epoch << 32 | lowest rejected (list << 28 | record) of that decode (atomicMin: a later
+                                       rejected decode replaces an earlier one, nothing is ever reset); copied to the host's status
+                                       ring at the end of every device-validated decode (runtime.hip) */
   int device_validate;              /* lists recorded in place: checked on the device (k_validate) instead of on the host */
   int n_wts;
   uint32_t n_coeffs, n_pcm, res_len, ref_valid;   /* list lengths the records index into; bit s of ref_valid = ref_frames[s] is a frame */
@@ -157,7 +159,7 @@ struct TileCopyArgs { char* plane[3]; size_t pitch[3]; TileCopyRect r[M355_TILE_
 void m355_launch_tiles_copy(const TileCopyArgs& a, int n, void* xbuf, bool to_slot, hipStream_t st);
 
 /* first statement of every kernel of a decode: a picture whose lists k_validate rejected is never acted upon */
-#define M355_GATE(p) do { if ((p).timeout[1] != 0u) return; } while (0)
+#define M355_GATE(p) do { if ((p).timeout[1] == (p).epoch) return; } while (0)
 
 enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
 

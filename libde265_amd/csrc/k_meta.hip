@@ -233,8 +233,9 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
 
 /* ---- device-side validation of work lists that were recorded in place (m355_arena_begin): the record checks of the host's
  * validate() (runtime.hip), one thread per record over the concatenation cus | tus | pbs | wts | rbs (4 bins) | ibs.  A rejected
- * record raises the decode's gate word (every later kernel of the decode returns at once: bad lists are never acted upon) and
- * leaves (list << 28 | record) in the sticky word that m355_wait reports.  (The CTB table and each CTB's intra block geometry
+ * record writes the decode's epoch into the lane's gate word (every later kernel of THIS decode returns at once: bad lists are
+ * never acted upon; nothing needs resetting for the next decode) and leaves (list << 28 | record), tagged with the epoch, for the
+ * per-decode status the host reads back (m355_decode_status, m355_wait).  (The CTB table and each CTB's intra block geometry
  * are checked on the host: its schedules index by them.) ---- */
 __global__ void __launch_bounds__(256) k_validate(DevPic p, uint32_t n_total)
 {
@@ -284,8 +285,8 @@ __global__ void __launch_bounds__(256) k_validate(DevPic p, uint32_t n_total)
   }
   if (bad) {
     const int list = q < 4 ? q + 1 : (q < 8 ? 5 : 6);       /* numbering of the host's messages: cu tu pb weight rb ib = 1..6 */
-    atomicOr(&p.timeout[1], 1u);
-    atomicMin(&p.timeout[2], ((uint32_t)list << 28) | (i < 0x0FFFFFFFu ? i : 0x0FFFFFFFu));
+    p.timeout[1] = p.epoch;                                  /* this decode's gate (every rejecting thread stores the same value) */
+    atomicMin((unsigned long long*)(p.timeout + 2), ((unsigned long long)(~p.epoch) << 32) | (((uint32_t)list << 28) | (i < 0x0FFFFFFFu ? i : 0x0FFFFFFFu)));
   }
 }
 

@@ -42,6 +42,7 @@ static int fail(int code, const char* fmt, ...)
 }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(M355_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
+#define M355_STATUS_RING 64
 #define M355_MAX_LANES 16  /* pictures in flight per context (m355_set_pipeline_depth) */
 
 struct Frame {
@@ -140,7 +141,6 @@ struct Lane {
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;   /* border plans of the picture's intra blocks */
   size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0;
-  size_t gate_used = 0;        /* a device-validated decode ran on this lane: its gate word must be cleared before the next decode */
 };
 
 struct m355_ctx {
@@ -164,8 +164,13 @@ struct m355_ctx {
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;
   size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0;
-  size_t gate_used = 0;
   uint32_t epoch = 0;
+  /* per-decode status (m355_decode_status): the last M355_STATUS_RING decodes; a device-validated decode copies its lane's gate
+     words into `words` (pinned) behind its last kernel */
+  struct Status { unsigned long long serial = 0; uint32_t epoch = 0; bool validated = false, reported = false; hipEvent_t ev = nullptr; };
+  Status status[M355_STATUS_RING];
+  uint32_t* status_words = nullptr;   /* pinned: 4 words per ring slot = the lane's timeout[0..3] at the end of the decode */
+  unsigned long long serial = 0;
   int stages = M355_STAGE_ALL;
   int shard_rank = 0, shard_n = 0;   /* shard_n == 0: sharding off */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
@@ -175,7 +180,7 @@ struct m355_ctx {
 };
 
 #define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
-  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao) X(gate_used)
+  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
 static void select_lane(m355_ctx* c, int lane)
 {
   if (lane == c->active) return;
@@ -198,7 +203,7 @@ static int lane_create(m355_ctx* c, Lane& l)
   HIPCHK(hipMalloc(&l.timeout, 128));
   HIPCHK(hipMemsetAsync(l.ticket, 0, 64, l.stream));
   HIPCHK(hipMemsetAsync(l.timeout, 0, 128, l.stream));
-  HIPCHK(hipMemsetAsync(l.timeout + 2, 0xFF, 4, l.stream));     /* lowest rejected record: none */
+  HIPCHK(hipMemsetAsync(l.timeout + 2, 0xFF, 8, l.stream));     /* rejected record of the latest rejected decode: none */
   HIPCHK(hipStreamSynchronize(l.stream));
   return M355_OK;
 }
@@ -355,6 +360,8 @@ void m355_destroy(m355_ctx* c)
   for (auto& t : c->transient) resident_free(t);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   if (c->hash_acc) hipFree(c->hash_acc);
+  for (auto& st_ : c->status) if (st_.ev) hipEventDestroy(st_.ev);
+  if (c->status_words) hipHostFree(c->status_words);
   {
     /* the active lane lives in the context's own fields: collect it into a Lane and destroy both */
     Lane a;
@@ -1047,6 +1054,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
         if (seg[idx[k]].bytes && want[k] != (const void*)(r.host + seg[idx[k]].ofs)) return fail(M355_ERR_INVALID, "in-place submit: a list is not where m355_arena_begin put it");
       if (pic->n_ibs && pic->ibs != (const m355_ib*)(r.host + seg[L.i_ibin].ofs)) return fail(M355_ERR_INVALID, "in-place submit: ibs[] is not where m355_arena_begin put it");
       if (pic->rbs != (const m355_rb*)(r.host + seg[L.i_rb[0]].ofs)) return fail(M355_ERR_INVALID, "in-place submit: rbs must point at the first size bin's region");
+      if (pic->scaling_factors && pic->scaling_factors != (const uint8_t*)(r.host + seg[i_sc].ofs)) return fail(M355_ERR_INVALID, "in-place submit: scaling_factors is not where m355_arena_begin put it");
       for (int i = 0; i < ns; i++) seg[i].src = nullptr;        /* nothing to copy */
     }
   }
@@ -1410,11 +1418,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   hipEvent_t* ev = &c->evs[c->ev_used * 7];
   c->ev_used++;
   hipEventRecord(ev[0], st);
-  if (c->gate_used || r.device_validate) {
-    hipMemsetAsync(c->timeout + 1, 0, 4, st);               /* this decode's gate word */
-    c->gate_used = r.device_validate ? 1 : 0;
-  }
-  if (r.device_validate) m355_launch_validate(d, st);
+  if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
   if (!want_sao) dst_hazards();
   if (pp.flags & M355_PF_CLEAR_DST) {
     /* a new picture starts from zero in the reference (image.cc:164); the planes being reconstructed are this lane's
@@ -1441,9 +1445,49 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
     }
   }
   c->timed = true;
+  {
+    /* this decode's status slot: completion event; a device-validated decode also brings its lane's gate words back (behind the
+       events the dependent decodes wait on: nobody waits for this copy but m355_decode_status / m355_wait) */
+    m355_ctx::Status& s = c->status[++c->serial % M355_STATUS_RING];
+    s.serial = c->serial; s.epoch = d.epoch; s.validated = r.device_validate; s.reported = false;
+    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+    if (r.device_validate) {
+      if (!c->status_words) HIPCHK(hipHostMalloc(&c->status_words, 16 * M355_STATUS_RING, hipHostMallocDefault));
+      hipMemcpyAsync(c->status_words + 4 * (c->serial % M355_STATUS_RING), c->timeout, 16, hipMemcpyDeviceToHost, st);
+    }
+    hipEventRecord(s.ev, st);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return M355_OK;
+}
+
+/* status of one finished decode from its ring slot: M355_OK, or M355_ERR_INVALID with the rejected record in the message */
+static int status_of(m355_ctx* c, m355_ctx::Status& s)
+{
+  if (!s.validated) return M355_OK;
+  const uint32_t* w = c->status_words + 4 * (s.serial % M355_STATUS_RING);
+  if (w[1] != s.epoch) return M355_OK;                       /* the lane's last rejected decode is another one */
+  const unsigned long long key = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+  uint32_t bad = (uint32_t)key;
+  if ((uint32_t)(key >> 32) != ~s.epoch) bad = 0;            /* (cannot happen: gate and key are written together) */
+  static const char* const names[8] = {"?", "cu", "tu", "pb", "weight", "rb", "ib", "?"};
+  s.reported = true;
+  return fail(M355_ERR_INVALID, "picture %llu: %s %u rejected by the device-side list validation (the picture was not decoded)", s.serial, names[(bad >> 28) & 7], bad & 0x0FFFFFFFu);
+}
+
+unsigned long long m355_last_serial(m355_ctx* c) { return c->serial; }
+
+int m355_decode_status(m355_ctx* c, unsigned long long serial)
+{
+  if (serial == 0 || serial > c->serial) return fail(M355_ERR_INVALID, "no decode with serial %llu", serial);
+  m355_ctx::Status& s = c->status[serial % M355_STATUS_RING];
+  if (s.serial != serial) return M355_OK;                     /* older than the ring: reported by an m355_wait since */
+  hipSetDevice(c->device);
+  const hipError_t q = hipEventQuery(s.ev);
+  if (q == hipErrorNotReady) return M355_ERR_BUSY;
+  if (q != hipSuccess) return fail(M355_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+  return status_of(c, s);
 }
 
 /* ------------------------------------------------------------------ tile-sharded decode -------- */
@@ -1526,7 +1570,6 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
       if (piped) {
         if (r.ev_up) hipStreamWaitEvent(st, r.ev_up, 0);
       }
-      if (c->gate_used || r.device_validate) { hipMemsetAsync(c->timeout + 1, 0, 4, st); c->gate_used = r.device_validate ? 1 : 0; }
       if (r.device_validate) m355_launch_validate(d, st);
       if (!r.live_sao) dst_hazards();
       if (pp.flags & M355_PF_CLEAR_DST) {
@@ -1644,22 +1687,12 @@ int m355_wait(m355_ctx* c)
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].timeout) { uint32_t t2 = 0; HIPCHK(hipMemcpy(&t2, c->lanes[k].timeout, 4, hipMemcpyDeviceToHost)); t |= t2; }
+  /* lists checked on the device (recorded in place): the first rejected decode not reported yet (everything has finished) */
   {
-    /* lists checked on the device (recorded in place): the lowest rejected record of any decode since the last wait */
-    uint32_t bad = 0xFFFFFFFFu;
-    for (int k = 0; k < M355_MAX_LANES; k++) {
-      uint32_t* w = k == c->active ? c->timeout : c->lanes[k].timeout;
-      hipStream_t ws = k == c->active ? c->stream : c->lanes[k].stream;
-      if (!w) continue;
-      uint32_t b2 = 0xFFFFFFFFu;
-      HIPCHK(hipMemcpy(&b2, w + 2, 4, hipMemcpyDeviceToHost));
-      if (b2 != 0xFFFFFFFFu) { HIPCHK(hipMemsetAsync(w + 2, 0xFF, 4, ws)); HIPCHK(hipStreamSynchronize(ws)); }
-      bad = std::min(bad, b2);
-    }
-    if (bad != 0xFFFFFFFFu) {
-      static const char* const names[8] = {"?", "cu", "tu", "pb", "weight", "rb", "ib", "?"};
-      return fail(M355_ERR_INVALID, "%s %u: rejected by the device-side list validation (the picture was not decoded)", names[(bad >> 28) & 7], bad & 0x0FFFFFFFu);
-    }
+    m355_ctx::Status* first = nullptr;
+    for (m355_ctx::Status& st_ : c->status)
+      if (st_.serial && st_.validated && !st_.reported && c->status_words[4 * (st_.serial % M355_STATUS_RING) + 1] == st_.epoch && (!first || st_.serial < first->serial)) first = &st_;
+    if (first) return status_of(c, *first);
   }
   if (t) {
     hipMemsetAsync(c->timeout, 0, 4, c->stream);

@@ -26,7 +26,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <memory>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -404,6 +406,41 @@ int m355_ref_check_hash(int width, int height, int chroma_format_idc, int bit_de
   if (crc) memcpy(sei.data.decoded_picture_hash.crc, crc, 6);
   if (checksum) memcpy(sei.data.decoded_picture_hash.checksum, checksum, 12);
   return (int)process_sei(&sei, &img);
+}
+
+
+/* CPU baseline harness (bench.py cpu_baseline): `threads` native threads, each replaying the picture into its own output planes
+ * over and over for `seconds` (one picture stream per thread, like the reference's frame-parallel decoding) — no interpreter, no
+ * shared buffers.  Returns the number of pictures replayed by all threads (negative: a replay failed); *elapsed = wall time. */
+__attribute__((visibility("default")))
+long m355_ref_bench(const m355_picture* pic, const void* const* ref_planes, int stages, int accel, int threads, double seconds, double* elapsed)
+{
+  const m355_pic_params& pp = pic->pp;
+  const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
+  const size_t bps = pp.bit_depth_luma > 8 ? 2 : 1;
+  const size_t nl = (size_t)pp.width * pp.height * bps, ncb = pp.chroma_format_idc ? (size_t)(pp.width / sw) * (pp.height / sh) * bps : 0;
+  if (threads < 1) threads = 1;
+  std::vector<long> counts((size_t)threads, 0);
+  std::vector<int> rcs((size_t)threads, 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto stop = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds));
+  auto work = [&](int t) {
+    std::vector<uint8_t> y(nl), cb(ncb ? ncb : 1), cr(ncb ? ncb : 1);
+    void* out[3] = {y.data(), ncb ? cb.data() : nullptr, ncb ? cr.data() : nullptr};
+    do {
+      const int rc = m355_ref_replay(pic, ref_planes, stages, accel, out);
+      if (rc) { rcs[(size_t)t] = rc; return; }
+      counts[(size_t)t]++;
+    } while (std::chrono::steady_clock::now() < stop);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  if (elapsed) *elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  long n = 0;
+  for (int t = 0; t < threads; t++) { if (rcs[(size_t)t]) return rcs[(size_t)t]; n += counts[(size_t)t]; }
+  return n;
 }
 
 } /* extern "C" */

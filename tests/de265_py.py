@@ -35,9 +35,12 @@ def bind(lib):
     return lib
 
 
-def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=False, scalar=False, after_create=None, max_frames=None):
+def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=False, scalar=False, after_create=None, max_frames=None, check_hash=False,
+                  planes_out=None, touch_planes=True, before_free=None):
     """-> (md5 hex of the output YUV, number of pictures, list of warnings).  The YUV is what `dec265 -o` writes: every
-    output picture, cropped to the conformance window, planes Y Cb Cr, 8-bit samples as bytes / deeper ones as 2 bytes LE."""
+    output picture, cropped to the conformance window, planes Y Cb Cr, 8-bit samples as bytes / deeper ones as 2 bytes LE.
+    planes_out: a list that receives every output picture's planes (numpy arrays); touch_planes=False: the pictures are taken
+    from the decoder but their samples are never asked for (`dec265 -q` without -o)."""
     bind(lib)
     ctx = lib.de265_new_decoder()
     if not ctx:
@@ -47,6 +50,7 @@ def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=Fa
             lib.de265_set_parameter_int(ctx, PARAM_ACCELERATION_CODE, ACCELERATION_SCALAR)
         lib.de265_set_parameter_bool(ctx, PARAM_DISABLE_DEBLOCKING, int(disable_deblocking))
         lib.de265_set_parameter_bool(ctx, PARAM_DISABLE_SAO, int(disable_sao))
+        lib.de265_set_parameter_bool(ctx, PARAM_BOOL_SEI_CHECK_HASH, int(check_hash))     # verify decoded-picture-hash SEIs (dec265 -c)
         if after_create:
             after_create(ctx)
         if threads > 0:
@@ -55,19 +59,22 @@ def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=Fa
         assert lib.de265_push_data(ctx, buf, len(data), 0, None) == DE265_OK
         assert lib.de265_flush_data(ctx) == DE265_OK
         md5 = hashlib.md5()
+        decode_errors = []
         n = 0
         more = ctypes.c_int(1)
         while more.value:
             more.value = 0
             err = lib.de265_decode(ctx, ctypes.byref(more))
             if err != DE265_OK:
+                decode_errors.append(err)      # (a decoded-picture-hash mismatch, DE265_ERROR_CHECKSUM_MISMATCH = 5, ends the decode like dec265 -c)
                 break
             while True:
                 img = lib.de265_get_next_picture(ctx)
                 if not img:
                     break
                 nc = 1 if lib.de265_get_chroma_format(img) == 0 else 3
-                for c in range(nc):
+                pic_planes = []
+                for c in range(nc if touch_planes else 0):
                     stride = ctypes.c_int()
                     p = lib.de265_get_image_plane(img, c, ctypes.byref(stride))
                     w, h = lib.de265_get_image_width(img, c), lib.de265_get_image_height(img, c)
@@ -75,6 +82,14 @@ def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=Fa
                     row = ctypes.c_char * (w * bpp)
                     for y in range(h):
                         md5.update(row.from_address(p + y * stride.value))      # stride is in BYTES (de265.cc:735)
+                    if planes_out is not None:
+                        import numpy as np
+                        a = np.empty((h, w), np.uint8 if bpp == 1 else np.uint16)
+                        for y in range(h):
+                            a[y] = np.frombuffer(row.from_address(p + y * stride.value), a.dtype, w)
+                        pic_planes.append(a)
+                if planes_out is not None:
+                    planes_out.append(pic_planes)
                 n += 1
                 if max_frames and n >= max_frames:
                     more.value = 0
@@ -85,6 +100,8 @@ def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=Fa
             if wn == DE265_OK:
                 break
             warnings.append(wn)
-        return md5.hexdigest(), n, warnings
+        if before_free:
+            before_free(ctx)
+        return md5.hexdigest(), n, warnings + decode_errors
     finally:
         lib.de265_free_decoder(ctx)

@@ -62,7 +62,7 @@ static const int warpSize = 64;
 
 /* ---- error / runtime API ---- */
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorLaunchFailure = 719 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorNotReady = 600, hipErrorLaunchFailure = 719 };
 typedef struct simt_stream* hipStream_t;
 typedef struct simt_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -97,6 +97,7 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { retu
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = 0);
 hipError_t hipEventSynchronize(hipEvent_t e);
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 enum { hipStreamNonBlocking = 1 };
