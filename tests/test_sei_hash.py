@@ -22,9 +22,11 @@ def run(ref, oracle, tmp_path, w, h, bd, tc, tr, frames, seed, feat, chroma, has
     assert plain[1] == frames and not plain[2]
     good = sei_util.add_hash_seis(data, pics, bd, hash_type, oracle)
     bad = sei_util.add_hash_seis(data, pics, bd, hash_type, oracle, corrupt_picture=frames - 1)
-    # the reference's own verdict on our SEIs
-    assert de265_py.decode_stream(ref, good, check_hash=True)[1:] == (frames, [])
-    assert de265_py.decode_stream(ref, bad, check_hash=True)[2] == [5]          # DE265_ERROR_CHECKSUM_MISMATCH
+    # the reference's own verdict on our SEIs (not for the checksum of > 8-bit pictures: its compute_checksum halves a stride that
+    # is already in samples, sei.cc:173-174, and refuses every such picture — see tests/test_hash.py, oracle/hevc_oracle.c:o_hash_checksum)
+    if not (hash_type == sei_util.CHECKSUM and bd > 8):
+        assert de265_py.decode_stream(ref, good, check_hash=True)[1:] == (frames, [])
+        assert de265_py.decode_stream(ref, bad, check_hash=True)[2] == [5]          # DE265_ERROR_CHECKSUM_MISMATCH
     lib = glue_lib()
     lib.m355_glue_hashed_pictures.restype = ctypes.c_longlong
     lib.m355_glue_hashed_pictures.argtypes = [ctypes.c_void_p]
