@@ -510,7 +510,8 @@ struct Gen {
     const seq_parameter_set& S = *sps;
     const int W = S.PicWidthInCtbsY;
     enc.set_context_models(&ctx);
-    if (keep_ctx) ctx = start_ctx.copy(); else ctx.init(shdr->initType, shdr->SliceQPY);
+    /* (a segment that begins a tile starts from fresh models even when it is a dependent one, slice.cc:4925-4929) */
+    if (keep_ctx && !(ts0 > 0 && pps->scan->TileId[ts0] != pps->scan->TileId[ts0 - 1])) ctx = start_ctx.copy(); else ctx.init(shdr->initType, shdr->SliceQPY);
     enc.init_CABAC();
     const int start = enc.size();
     substream_end.clear();
