@@ -48,14 +48,15 @@
 #define BODY_PITCH_OF(cw) ((cw) + 8)
 #define BODY_X0 8
 #define SPIN_LIMIT M355_SPIN_LIMIT   /* k_asm.h: bound on the polls for one granule (a list that promises a sample nobody produces) */
-/* halo of a component, 32-bit words (a sample, or HALO_NOT_READY while the neighbour CTB has not published it):
-   the row above the CTB, x = -1 .. 2cw-1 at index x + 1, then the column left of it, y at index HALO_TOP_N + y */
+/* A component's samples in LDS, ONE array of 16-bit elements: the body (above), then its halo — the row above the CTB, x = -1 ..
+   2cw-1 at halo index x + 1, then the column left of it, y at halo index HALO_TOP_N + y; an element is a sample, or
+   HALO_NOT_READY while the neighbour CTB has not published it — then one cell that holds 1 << (bitDepth - 1) (what a border is made
+   of when nothing is available, intrapred.h:645-649).  A plan entry (k_intra_plan) is an element index into this array: where
+   border entry e of a block comes from, substitution already applied. */
 #define HALO_TOP_N (2 * MAXCTB + 2)
 #define HALO_N (HALO_TOP_N + MAXCTB)
-#define HALO_NOT_READY 0xFFFFFFFFu
-/* plan entry: where border entry e of a block comes from, substitution already applied */
-#define PLAN_HALO 0x8000u            /* | index into the component's halo words; else: element index into its body */
-#define PLAN_CONST 0xFFFFu           /* nothing is available: 1 << (bitDepth - 1) (intrapred.h:645-649) */
+#define HALO_NOT_READY 0xFFFFu       /* (a 16-bit-deep picture may hold this value as a sample: the poll then succeeds at once) */
+#define COMP_LDS(body) ((body) + HALO_N + 8)   /* elements per component: body + halo + constant cell (+ alignment) */
 
 /* z-scan order inside a CTB (pps.cc:608-623 MinTbAddrZS, low bits): Morton code of the min-TB coordinates */
 __device__ __forceinline__ uint32_t d_spread4(uint32_t v) { v = (v | (v << 2)) & 0x33u; return (v | (v << 1)) & 0x55u; }
@@ -89,10 +90,36 @@ __device__ __forceinline__ m355_granule* d_edge_col(const DevPic& p, int c, int 
 /* bottom-row granules of CTB row `row`: index (column of the picture) >> 1 */
 __device__ __forceinline__ m355_granule* d_edge_row(const DevPic& p, int c, int row, int x) { return p.edge + p.edge_row_ofs[c] + (size_t)row * (size_t)(p.pw[c] >> 1) + (size_t)(x >> 1); }
 
+/* A halo sample its CTB has not published yet: poll its granule (relaxed, agent scope: served by the L2 / fabric, never by this
+ * CU's L1); every waiting lane has its own word, the wave leaves when all have arrived.  Returns the lane's (possibly updated)
+ * value; arrived samples are also stored in the halo words for the blocks that read them later. */
+__device__ __attribute__((noinline)) uint32_t d_poll_halo(const m355_granule* top_row, const m355_granule* left_col, uint32_t* timeout, uint16_t* halo, int hi, uint32_t val, bool pending, int x0c, int y0c, uint32_t epoch)
+{
+  const int lane = threadIdx.x & 63;
+  const bool is_top = hi < HALO_TOP_N;
+  const int pos = is_top ? x0c - 1 + hi : y0c + hi - HALO_TOP_N;      /* picture column of a top entry / row of a left entry */
+  const m355_granule* gsrc = pending ? (is_top ? top_row : left_col) + (pos >> 1) : nullptr;   /* (pos >= 0 for a pending lane) */
+  unsigned spins = 0;
+  for (;;) {
+    if (pending) {
+      const m355_granule gr = __hip_atomic_load(gsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(gr >> 32) == epoch) { val = (uint32_t)((gr >> (16 * (pos & 1))) & 0xFFFFu); halo[hi] = (uint16_t)val; pending = false; }
+    }
+    if (!__any(pending)) break;
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+      if (lane == 0) atomicExch(timeout, 1u);        /* a list that promises a sample nobody produces: ONE bounded wait per decode */
+      break;
+    }
+  }
+  return val;
+}
+
 /* chroma CTB geometry of a chroma format */
 template <int CF> struct IntraGeo {
   static constexpr int CW_C = (CF == 1 || CF == 2) ? MAXCTB / 2 : MAXCTB, CH_C = CF == 1 ? MAXCTB / 2 : MAXCTB;
   static constexpr int BODY_L = MAXCTB * BODY_PITCH_OF(MAXCTB), BODY_C = CF == 0 ? 8 : CH_C * BODY_PITCH_OF(CW_C);
+  static constexpr int SAMP_L = COMP_LDS(BODY_L), SAMP_C = COMP_LDS(BODY_C);   /* elements of a luma / chroma component's array */
 };
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -127,6 +154,7 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
     const int SubW = 1 << csw, SubH = 1 << csh;
     const int x0c = (ctbX << l2c) >> csw, y0c = (ctbY << l2c) >> csh;
     const int BODY_PITCH = c == 0 ? BODY_PITCH_OF(MAXCTB) : BODY_PITCH_OF(IntraGeo<CF>::CW_C);
+    const int HALO_BASE = c == 0 ? IntraGeo<CF>::BODY_L : IntraGeo<CF>::BODY_C;   /* first halo element of the component's array */
     const int xB = (int)(w0 & 0xFFFFu), yB = (int)(w0 >> 16), lx = xB - x0c, ly = yB - y0c;
     /* ---- preproc (intrapred.h:436-531): CTB-level availability from the neighbourhood table ---- */
     const int xBL = xB * SubW, yBL = yB * SubH;
@@ -178,7 +206,7 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
           else av = (nb_earlier >> ((dcy + 1) * 3 + dcx + 1)) & 1u;
         }
         if (av && cip) av = d_is_intra_at(p, xN, yN);
-        if (av) code[q] = sy < 0 ? (PLAN_HALO | (uint32_t)(sx + 1)) : (sx < 0 ? (PLAN_HALO | (uint32_t)(HALO_TOP_N + sy)) : (uint32_t)(sy * BODY_PITCH + sx + BODY_X0));
+        if (av) code[q] = sy < 0 ? (uint32_t)(HALO_BASE + sx + 1) : (sx < 0 ? (uint32_t)(HALO_BASE + HALO_TOP_N + sy) : (uint32_t)(sy * BODY_PITCH + sx + BODY_X0));
       }
       am[q] = __ballot(av);
     }
@@ -198,7 +226,7 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
       const int e = lane + 64 * q;
       if (e < nEnt) {
         uint32_t v;
-        if (none) v = PLAN_CONST;
+        if (none) v = (uint32_t)(HALO_BASE + HALO_N);        /* the constant cell */
         else if ((am[q] >> lane) & 1) v = code[q];
         else v = codes[d_subst_src(e, am[0], am[1], am[2])];
         out[e] = (uint16_t)v;
@@ -219,8 +247,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   M355_GATE(p);
   constexpr int CW_C = IntraGeo<CF>::CW_C, CH_C = IntraGeo<CF>::CH_C;
   constexpr int BODY_L = IntraGeo<CF>::BODY_L, BODY_C = IntraGeo<CF>::BODY_C;
-  __shared__ uint32_t s_halo[3][HALO_N];
-  __shared__ __attribute__((aligned(16))) uint16_t s_body[BODY_L + 2 * BODY_C];
+  constexpr int SAMP_L = IntraGeo<CF>::SAMP_L, SAMP_C = IntraGeo<CF>::SAMP_C;
+  __shared__ __attribute__((aligned(16))) uint16_t s_body[SAMP_L + 2 * SAMP_C];   /* per component: body | halo | constant cell */
   /* the CTB's deferred residuals in picture layout (pitch = component CTB width): fetched up front, all loads in flight
      together, so that the per-block chain reads them from LDS instead of paying a global-memory latency per block */
   constexpr int RES_L = DENSE ? MAXCTB * MAXCTB : 8, RES_C = (CF == 0 || !DENSE) ? 8 : CH_C * CW_C;
@@ -286,8 +314,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   const int cs = comp ? c : 0;
   PIX* plane = (PIX*)p.plane[cs];
   const int stride = p.stride[cs], pw = p.pw[cs], ph = p.ph[cs];
-  uint32_t* halo = s_halo[cs];
-  uint16_t* body = s_body + (cs == 0 ? 0 : BODY_L + (cs - 1) * BODY_C);
+  uint16_t* body = s_body + (cs == 0 ? 0 : SAMP_L + (cs - 1) * SAMP_C);
+  const int HALO_BASE = cs == 0 ? BODY_L : BODY_C;
+  uint16_t* halo = body + HALO_BASE;
   const int BODY_PITCH = cs == 0 ? BODY_PITCH_OF(MAXCTB) : BODY_PITCH_OF(CW_C);
   uint16_t* raw = s_raw[wv];
   uint16_t* pf = s_f[wv];
@@ -312,6 +341,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   if (comp && g == 0) {
     for (int y = lane; y < ch; y += 64) s_need[cs][y] = 0;
     if (lane < 8) s_hneed[cs][lane] = 0;
+    if (lane == 0) halo[HALO_N] = (uint16_t)(1u << (bd - 1));   /* the constant cell */
     if (lane < MAXCTB / 4) s_cover[cs][lane] = 0;
     wave_sync();
     const int nvr = cw >> 3;                                /* vectors per row */
@@ -427,7 +457,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         for (int u = 0; u < U; u++) {
           const int h = h0 + u * 64 * G;
           if (h >= nhalo) continue;
-          if (top_[u]) halo[h] = val[u]; else halo[HALO_TOP_N + h - (2 * cw + 1)] = val[u];
+          if (top_[u]) halo[h] = (uint16_t)val[u]; else halo[HALO_TOP_N + h - (2 * cw + 1)] = (uint16_t)val[u];
         }
       }
     }
@@ -503,7 +533,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       mine = __ballot((int)(comp && lane < nvalid && (rw1 & 0xFFu) == (uint32_t)c && (((lane - start) & (G - 1)) == g)));
     }
     /* the wave's NEXT block: record words + the plan entries of its border (one per lane and 64-entry chunk) */
-    uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, ncode[3] = {PLAN_CONST, PLAN_CONST, PLAN_CONST};
+    uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, ncode[3] = {0, 0, 0};
     int nsrc = -1;
     auto fetch_next = [&]() {
       nsrc = mine ? __ffsll(mine) - 1 : -1;
@@ -518,7 +548,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       for (int q = 0; q < 3; q++) {
         if (64 * q >= nEnt) continue;
         const int e = lane + 64 * q;
-        ncode[q] = e < nEnt ? (uint32_t)pl[e] : PLAN_CONST;
+        ncode[q] = e < nEnt ? (uint32_t)pl[e] : 0u;
       }
     };
     fetch_next();
@@ -558,29 +588,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const int e = lane + 64 * q;
         const uint32_t cd = code[q];
         uint32_t val = 0;
-        if (e < nEnt) val = cd == PLAN_CONST ? (1u << (bd - 1)) : ((cd & PLAN_HALO) ? halo[cd & 0x7FFFu] : (uint32_t)body[cd]);
-        /* a halo sample its CTB has not published yet: poll its granule (relaxed, agent scope: served by the L2 / fabric,
-           never by this CU's L1); every waiting lane has its own word, the wave leaves when all have arrived */
-        bool pending = e < nEnt && cd != PLAN_CONST && (cd & PLAN_HALO) && val == HALO_NOT_READY;
-        if (__any(pending)) {
-          const int hi = (int)(cd & 0x7FFFu);
-          const bool is_top = hi < HALO_TOP_N;
-          const int pos = is_top ? x0c - 1 + hi : y0c + hi - HALO_TOP_N;      /* picture column of a top entry / row of a left entry */
-          const m355_granule* gsrc = pending ? (is_top ? d_edge_row(p, cs, ctbY - 1, pos) : d_edge_col(p, cs, ctbX - 1, pos)) : nullptr;
-          unsigned spins = 0;
-          for (;;) {
-            if (pending) {
-              const m355_granule gr = __hip_atomic_load(gsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((uint32_t)(gr >> 32) == epoch) { val = (uint32_t)((gr >> (16 * (pos & 1))) & 0xFFFFu); halo[hi] = val; pending = false; }
-            }
-            if (!__any(pending)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(p.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-              if (lane == 0) atomicExch(p.timeout, 1u);      /* a list that promises a sample nobody produces: ONE bounded wait per decode */
-              break;
-            }
-          }
-        }
+        if (e < nEnt) val = body[cd];
+        /* a halo sample its CTB has not published yet: poll its granule (rare: kept out of line, off the block chain's registers) */
+        const bool pending = e < nEnt && val == HALO_NOT_READY && cd >= (uint32_t)HALO_BASE && cd < (uint32_t)(HALO_BASE + HALO_N);
+        if (__any((int)pending))
+          val = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)cd - HALO_BASE, val, pending, x0c, y0c, epoch);
         if (small) bv = val;
         else if (e < nEnt) raw[e] = (uint16_t)val;
       }
