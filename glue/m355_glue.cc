@@ -24,7 +24,10 @@
  * (de265.h:350-368), are written only when a picture is output (or when the stream carries a picture hash SEI to check).
  *
  * Threading: the recording hooks run on the decoder's worker threads (threads.h); every thread appends to its own
- * lists, which the submit step (single-threaded, after img->wait_for_completion) concatenates.
+ * lists.  When a picture is parsed (img->wait_for_completion has returned) the decoder's thread hands the lists and a snapshot
+ * of the DPB to the glue's WORKER thread and goes on parsing the next picture; the worker walks the picture's metadata, writes
+ * the lists into the backend's pinned arena and submits.  Whoever needs the picture afterwards (application, SEI check, the DPB
+ * recycling the image) first waits for its job; all calls into the backend context are serialised by one mutex.
  */
 #include <dlfcn.h>
 #include <stdint.h>
@@ -35,6 +38,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <functional>
 #include <mutex>
@@ -190,6 +195,22 @@ struct Glue {
   bool damaged[M355_MAX_REF_FRAMES];
   long long n_rejected = 0;
   PlanePool planes;
+  /* The submit step (metadata walk, lists into the arena, m355_submit_picture) of a parsed picture runs on a WORKER thread while
+     the decoder's own thread goes on to parse the next picture (m355_glue.cc picture_complete): one job per picture, in order.
+     api_mu serialises every call into the backend context (worker: submit; application / decoder thread: download, hash, status) */
+  struct Job {
+    de265_image* img = nullptr; uint32_t id = 0; int dslot = -1;
+    std::vector<ThreadRec*> recs;
+    const de265_image* dpb_img[M355_MAX_REF_FRAMES]; uint32_t dpb_id[M355_MAX_REF_FRAMES];   /* the DPB as it was when the picture completed */
+  };
+  std::mutex job_mu, api_mu;
+  std::condition_variable job_cv, idle_cv;
+  std::deque<Job> jobs;
+  bool busy = false, stop = false, sync_submit = false;
+  uint32_t busy_id = 0xFFFFFFFFu;
+  std::thread worker;
+  std::vector<int> deferred_warnings;       /* raised by the worker, handed to the decoder on its own thread */
+  double ms_main = 0;
   /* statistics (m355_glue_stats) */
   long long n_pictures = 0, n_uploads = 0, n_downloads = 0, n_hashed = 0;
   double ms_walk = 0, ms_submit = 0, ms_download = 0;
@@ -217,6 +238,8 @@ Glue* glue_of(const decoder_context* d)
 }
 
 void install_traps(acceleration_functions& a);
+void wait_submitted(Glue* g, uint32_t id);
+void flush_warnings(Glue* g);
 
 /* the calling thread's lists for the picture `img` */
 ThreadRec* rec_for(de265_image* img)
@@ -308,6 +331,7 @@ int glue_get_buffer(de265_decoder_context* ctx, de265_image_spec* spec, de265_im
 void glue_release_buffer(de265_decoder_context* ctx, de265_image* img, void* userdata)
 {
   Glue* g = (Glue*)userdata;
+  wait_submitted(g, img->get_ID());               /* the DPB recycles the image (dpb.cc:206-216): the worker may still be walking its metadata */
   for (int c = 0; c < 3; c++) {
     void* p = (void*)img->get_image_plane(c);
     if (p) g->planes.put(p);
@@ -354,7 +378,7 @@ bool upload_host_planes(Glue* g, int slot, const de265_image* img)
  * decode is waited for).  A picture whose lists the device rejected was not decoded: it is marked as the reference marks a
  * picture with decoding errors (image.h:347 integrity; decctx.cc checks it when the picture is output), pictures predicted
  * from it are marked when they are submitted. */
-void collect_status(Glue* g, int wait_for_slot)
+void collect_status(Glue* g, int wait_for_slot, const Glue::Job* job = nullptr)
 {
   for (int s = 0; s < M355_MAX_REF_FRAMES; s++) {
     if (!g->pending_serial[s]) continue;
@@ -366,9 +390,10 @@ void collect_status(Glue* g, int wait_for_slot)
       fprintf(stderr, "libde265 (MI355X glue): %s\n", g->error.c_str());
       g->damaged[s] = true;
       g->n_rejected++;
-      de265_image* im = g->dctx->has_image(s) ? g->dctx->get_image(s) : nullptr;
-      if (im && im->get_ID() == g->dev_id[s]) im->integrity = INTEGRITY_DECODING_ERRORS;
-      g->dctx->add_warning(DE265_WARNING_INCORRECT_ENTRY_POINT_OFFSET, false);   /* there is no backend-specific warning code in de265.h */
+      /* (on the worker the DPB is looked at through the job's snapshot: the decoder's thread may be reshaping it) */
+      de265_image* im = job ? const_cast<de265_image*>(job->dpb_img[s]) : (g->dctx->has_image(s) ? g->dctx->get_image(s) : nullptr);
+      if (im && (job ? job->dpb_id[s] : im->get_ID()) == g->dev_id[s]) im->integrity = INTEGRITY_DECODING_ERRORS;
+      { std::lock_guard<std::mutex> lk(g->job_mu); g->deferred_warnings.push_back(DE265_WARNING_INCORRECT_ENTRY_POINT_OFFSET); }   /* there is no backend-specific warning code in de265.h */
     }
     g->pending_serial[s] = 0;
   }
@@ -376,6 +401,9 @@ void collect_status(Glue* g, int wait_for_slot)
 
 void download_if_needed(Glue* g, de265_image* img)
 {
+  wait_submitted(g, img->get_ID());
+  flush_warnings(g);
+  std::lock_guard<std::mutex> api_lock(g->api_mu);
   const int slot = slot_of(g->dctx, img);
   if (slot < 0 || g->frame_of_slot[slot] < 0) return;
   if (g->dev_id[slot] != img->get_ID() || g->host_id[slot] == img->get_ID()) return;
@@ -444,8 +472,9 @@ void parallel_tasks(size_t n_tasks, const std::function<void(size_t)>& f)
   for (auto& t : th) t.join();
 }
 
-bool submit_picture(Glue* g, de265_image* img)
+bool submit_picture(Glue* g, Glue::Job& job)
 {
+  de265_image* img = job.img;
   Api* A = api();
   decoder_context* d = g->dctx;
   const auto t0 = std::chrono::steady_clock::now();
@@ -548,11 +577,7 @@ bool submit_picture(Glue* g, de265_image* img)
   }
 
   /* ---- concatenate the threads' lists ---- */
-  std::vector<ThreadRec*> recs;
-  {
-    std::lock_guard<std::mutex> lk(g->mu);
-    if (g->cur_id == img->get_ID()) recs = g->recs;         /* else: a picture without a single coded block */
-  }
+  const std::vector<ThreadRec*>& recs = job.recs;          /* (empty: a picture without a single coded block) */
   size_t n_pb = 0, n_ib = 0, n_co = 0, n_rb[4] = {0, 0, 0, 0};
   int skipped = 0;
   std::vector<uint32_t> co_base(recs.size()), res_base(recs.size());
@@ -596,6 +621,7 @@ bool submit_picture(Glue* g, de265_image* img)
      and M355_GLUE_COPY=1 take the copying m355_submit_picture through host vectors. */
   static const bool force_copy = getenv("M355_GLUE_COPY") != nullptr;
   const bool in_place = !any_pcm && !force_copy;
+  std::unique_lock<std::mutex> api_lock(g->api_mu, std::defer_lock);
   std::vector<m355_pb> pbs;
   std::vector<uint32_t> coeffs;
   std::vector<m355_rb> rbs;
@@ -609,6 +635,7 @@ bool submit_picture(Glue* g, de265_image* img)
     caps.n_pbs = (int32_t)n_pb + 1; caps.n_wts = any_weighted ? (int32_t)img->slices.size() * 32 : 1; caps.n_ibs = (int32_t)n_ib_final + 1;
     for (int s = 0; s < 4; s++) caps.n_rbs[s] = (int32_t)n_rb[s] + 1;
     caps.n_coeffs = (uint32_t)n_co + 1; caps.n_pcm = 1; caps.scaling = sps.scaling_list_enable_flag ? 1 : 0;
+    api_lock.lock();                                        /* the backend context from here to the end of the submit */
     if (A->m355_arena_begin(g->mctx, &caps, &apic) != M355_OK) { g->error = A->m355_last_error(); return false; }
     d_pbs = (m355_pb*)apic.pbs; d_co = (uint32_t*)apic.coeffs; d_ibs = (m355_ib*)apic.ibs;
     for (int s = 0; s < 4; s++) d_rb[s] = caps.rb_bin[s];
@@ -729,7 +756,8 @@ bool submit_picture(Glue* g, de265_image* img)
   }
 
   /* ---- frames: destination + every DPB slot a prediction block reads ---- */
-  const int dslot = slot_of(d, img);
+  if (!api_lock.owns_lock()) api_lock.lock();
+  const int dslot = job.dslot;
   if (dslot < 0) { g->error = "picture is not in the DPB"; return false; }
   if (!ensure_frame(g, dslot, img)) return false;
   pic.dst_frame = g->frame_of_slot[dslot];
@@ -742,14 +770,14 @@ bool submit_picture(Glue* g, de265_image* img)
   }
   for (int s = 0; s < M355_MAX_REF_FRAMES; s++) {
     if (!used[s]) continue;
-    const de265_image* rp = d->get_image(s);
+    const de265_image* rp = job.dpb_img[s];
     if (s == dslot || !rp) { g->error = "prediction block references its own picture / an empty slot"; return false; }
-    if (g->frame_of_slot[s] < 0 || g->dev_id[s] != rp->get_ID()) {
+    if (g->frame_of_slot[s] < 0 || g->dev_id[s] != job.dpb_id[s]) {
       if (!upload_host_planes(g, s, rp)) return false;
     }
     pic.ref_frames[s] = g->frame_of_slot[s];
   }
-  collect_status(g, -1);                           /* outcomes known by now (non-blocking) */
+  collect_status(g, -1, &job);                     /* outcomes known by now (non-blocking) */
   bool from_damaged = false;
   for (int s = 0; s < M355_MAX_REF_FRAMES; s++) if (used[s] && g->damaged[s]) from_damaged = true;
 
@@ -804,24 +832,82 @@ bool submit_picture(Glue* g, de265_image* img)
   return true;
 }
 
-/* picture complete (decode_some, decctx.cc:605-630): hand it to the device */
+/* one picture's submit step, on whichever thread runs it */
+void run_job(Glue* g, Glue::Job& job)
+{
+  if (!submit_picture(g, job)) {
+    fprintf(stderr, "libde265 (MI355X glue): picture POC %d not decoded: %s\n", job.img->PicOrderCntVal, g->error.c_str());
+    job.img->integrity = INTEGRITY_DECODING_ERRORS;
+    std::lock_guard<std::mutex> lk(g->job_mu);
+    g->deferred_warnings.push_back(DE265_WARNING_INCORRECT_ENTRY_POINT_OFFSET);   /* there is no backend-specific warning code in de265.h */
+  }
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (ThreadRec* r : job.recs) { r->clear(); g->pool.push_back(r); }
+  job.recs.clear();
+}
+
+void worker_main(Glue* g)
+{
+  std::unique_lock<std::mutex> lk(g->job_mu);
+  for (;;) {
+    g->job_cv.wait(lk, [&]() { return g->stop || !g->jobs.empty(); });
+    if (g->jobs.empty()) return;                             /* (stop: after the queue has drained) */
+    Glue::Job job = std::move(g->jobs.front());
+    g->jobs.pop_front();
+    g->busy = true; g->busy_id = job.id;
+    lk.unlock();
+    run_job(g, job);
+    lk.lock();
+    g->busy = false; g->busy_id = 0xFFFFFFFFu;
+    g->idle_cv.notify_all();
+  }
+}
+
+/* wait until the worker is done with picture `id` (0xFFFFFFFF: with everything): whoever is about to touch the picture's device
+   frame, its host planes or its metadata arrays (application, SEI check, the DPB recycling the image) comes through here */
+void wait_submitted(Glue* g, uint32_t id)
+{
+  std::unique_lock<std::mutex> lk(g->job_mu);
+  g->idle_cv.wait(lk, [&]() {
+    if (id == 0xFFFFFFFFu) return g->jobs.empty() && !g->busy;
+    if (g->busy && g->busy_id == id) return false;
+    for (const Glue::Job& j : g->jobs) if (j.id == id) return false;
+    return true;
+  });
+}
+
+/* warnings raised on the worker reach the decoder on the decoder's own thread (its error queue is not synchronised) */
+void flush_warnings(Glue* g)
+{
+  std::vector<int> w;
+  { std::lock_guard<std::mutex> lk(g->job_mu); w.swap(g->deferred_warnings); }
+  for (int code : w) g->dctx->add_warning((de265_error)code, false);
+}
+
+/* picture complete (decode_some, decctx.cc:605-630): hand it to the device.  The decoder's thread only takes the picture's lists
+   and a snapshot of the DPB and goes back to parsing; the submit step runs on the glue's worker (M355_GLUE_SYNC=1: here). */
 void picture_complete(decoder_context* d, de265_image* img)
 {
   Glue* g = glue_of(d);
   if (!g) { fprintf(stderr, "libde265 (MI355X glue): decoder without a backend context\n"); abort(); }
-  if (!submit_picture(g, img)) {
-    fprintf(stderr, "libde265 (MI355X glue): picture POC %d not decoded: %s\n", img->PicOrderCntVal, g->error.c_str());
-    img->integrity = INTEGRITY_DECODING_ERRORS;
-    d->add_warning(DE265_WARNING_INCORRECT_ENTRY_POINT_OFFSET, false);   /* there is no backend-specific warning code in de265.h */
+  const auto t0 = std::chrono::steady_clock::now();
+  Glue::Job job;
+  job.img = img; job.id = img->get_ID(); job.dslot = slot_of(d, img);
+  for (int s = 0; s < M355_MAX_REF_FRAMES; s++) {
+    job.dpb_img[s] = d->has_image(s) ? d->get_image(s) : nullptr;
+    job.dpb_id[s] = job.dpb_img[s] ? job.dpb_img[s]->get_ID() : 0xFFFFFFFFu;
   }
   {
     std::lock_guard<std::mutex> lk(g->mu);
-    if (g->cur_id == img->get_ID()) {
-      for (ThreadRec* r : g->recs) { r->clear(); g->pool.push_back(r); }
-      g->recs.clear();
-      g->cur_id = 0xFFFFFFFFu;
-    }
+    if (g->cur_id == img->get_ID()) { job.recs.swap(g->recs); g->cur_id = 0xFFFFFFFFu; }   /* else: a picture without a single coded block */
   }
+  flush_warnings(g);
+  if (g->sync_submit) run_job(g, job);
+  else {
+    { std::lock_guard<std::mutex> lk(g->job_mu); g->jobs.push_back(std::move(job)); }
+    g->job_cv.notify_one();
+  }
+  g->ms_main += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   /* (a decoded-picture-hash SEI is checked right after this call, decctx.cc:634-641: process_sei below hashes the DEVICE frame) */
 }
 
@@ -1006,6 +1092,8 @@ de265_error process_sei(const sei_message* sei, de265_image* img)
   if (img->PicOutputFlag == false) return DE265_OK;                          /* sei.cc:280-287 */
   Glue* g = glue_of(img->decctx);
   if (!g) return DE265_OK;
+  wait_submitted(g, img->get_ID());
+  std::lock_guard<std::mutex> api_lock(g->api_mu);
   const int slot = slot_of(g->dctx, img);
   if (slot < 0 || g->frame_of_slot[slot] < 0 || g->dev_id[slot] != img->get_ID()) return DE265_OK;   /* not a picture the backend decoded */
   collect_status(g, slot);                                                    /* waits for its decode; a rejected picture is reported there */
@@ -1063,6 +1151,8 @@ LIBDE265_API de265_decoder_context* de265_new_decoder()
   int depth = 2;
   if (const char* e = getenv("M355_PIPELINE_DEPTH")) depth = atoi(e);
   if (depth >= 1 && depth <= 16) A->m355_set_pipeline_depth(g->mctx, depth);
+  g->sync_submit = getenv("M355_GLUE_SYNC") != nullptr;
+  if (!g->sync_submit) g->worker = std::thread(worker_main, g);
   install_traps(g->dctx->acceleration);
   de265_image_allocation alloc = {glue_get_buffer, glue_release_buffer};
   de265_set_image_allocation_functions(c, &alloc, g);
@@ -1080,19 +1170,24 @@ LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)
     for (size_t i = 0; i < g_glues.size(); i++)
       if ((de265_decoder_context*)g_glues[i]->dctx == c) { g = g_glues[i]; g_glues.erase(g_glues.begin() + i); g_reg_gen++; break; }
   }
-  if (g && getenv("M355_GLUE_STATS"))
-    fprintf(stderr, "m355 glue: %lld pictures submitted, %lld uploaded, %lld downloaded; host ms per picture: lists %.3f, submit %.3f; download %.3f ms each; cpu pixel calls %lld\n",
-            g->n_pictures, g->n_uploads, g->n_downloads, g->n_pictures ? g->ms_walk / g->n_pictures : 0.0, g->n_pictures ? g->ms_submit / g->n_pictures : 0.0,
-            g->n_downloads ? g->ms_download / g->n_downloads : 0.0, g_cpu_pixel_calls.load());
   if (g) {
+    wait_submitted(g, 0xFFFFFFFFu);
+    std::lock_guard<std::mutex> api_lock(g->api_mu);
     collect_status(g, -1);
     while (api()->m355_wait(g->mctx) != M355_OK) {           /* (one rejected picture per call) */
       fprintf(stderr, "libde265 (MI355X glue): at shutdown: %s\n", api()->m355_last_error());
       if (++g->n_rejected > 1000) break;
     }
   }
+  if (g && getenv("M355_GLUE_STATS"))
+    fprintf(stderr, "m355 glue: %lld pictures submitted, %lld uploaded, %lld downloaded; host ms per picture: on the decoder's thread %.3f, on the worker: lists %.3f, submit %.3f; download %.3f ms each; cpu pixel calls %lld\n",
+            g->n_pictures, g->n_uploads, g->n_downloads, g->n_pictures ? g->ms_main / g->n_pictures : 0.0, g->n_pictures ? g->ms_walk / g->n_pictures : 0.0, g->n_pictures ? g->ms_submit / g->n_pictures : 0.0,
+            g->n_downloads ? g->ms_download / g->n_downloads : 0.0, g_cpu_pixel_calls.load());
   const de265_error e = m355ref_de265_free_decoder(c);      /* releases the images into the pool */
   if (g) {
+    { std::lock_guard<std::mutex> lk(g->job_mu); g->stop = true; }
+    g->job_cv.notify_all();
+    if (g->worker.joinable()) g->worker.join();
     api()->m355_destroy(g->mctx);
     g->planes.drain();
     for (ThreadRec* r : g->recs) { r->clear(); }
@@ -1122,12 +1217,13 @@ LIBDE265_API int m355_glue_feature_counts(long long* out, int n)
   for (int k = 0; k < n && k < M355_GLUE_N_FEATURES; k++) out[k] = g_feat[k].load();
   return M355_GLUE_N_FEATURES;
 }
-LIBDE265_API long long m355_glue_hashed_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); return g ? g->n_hashed : -1; }
-LIBDE265_API long long m355_glue_rejected_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); return g ? g->n_rejected : -1; }
+LIBDE265_API long long m355_glue_hashed_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); if (g) wait_submitted(g, 0xFFFFFFFFu); return g ? g->n_hashed : -1; }
+LIBDE265_API long long m355_glue_rejected_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); if (g) wait_submitted(g, 0xFFFFFFFFu); return g ? g->n_rejected : -1; }
 LIBDE265_API int m355_glue_stats(de265_decoder_context* c, long long* pictures, long long* uploads, long long* downloads)
 {
   Glue* g = glue_of((decoder_context*)c);
   if (!g) return -1;
+  wait_submitted(g, 0xFFFFFFFFu);
   if (pictures) *pictures = g->n_pictures;
   if (uploads) *uploads = g->n_uploads;
   if (downloads) *downloads = g->n_downloads;
