@@ -314,13 +314,26 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
     try:
         from libde265_amd import capi, shard
         rank, world = dist.get_rank(), dist.get_world_size()
-        grp = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None     # RCCL over xGMI for the exchanges
+        grp = None
+        if os.environ.get("M355_SHARD_TRANSPORT", "rccl") != "rccl":
+            grp = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None     # torch's RCCL group for the exchanges
         cfg = dict(synth.CONFIGS[args.workload])
         pic = synth.picture(**cfg)                                 # the SAME picture on every rank
         pp = pic.pp[0]
         ctx = capi.Context(lib, local_rank)
-        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(grp), device="cuda:%d" % local_rank,
-                                   halo=os.environ.get("M355_SHARD_HALO", "p2p"))      # neighbour point-to-point halos ("allreduce": SUM all-reduce)
+        # transport of the exchanges: "rccl" (default) = issued by the library itself (m355_decode_sharded: phase loop in C++, neighbour
+        # ncclSend / ncclRecv + ncclAllGather on the picture's stream; the unique id travels over the bootstrap group);
+        # "torch" = the same loop calling back into torch.distributed; "python" = the phase loop in Python (round-2 path)
+        transport = os.environ.get("M355_SHARD_TRANSPORT", "rccl")
+        rccl_id = None
+        if transport == "rccl":
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(lib.rccl_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(idt, 0)
+            rccl_id = bytes(idt.tolist())
+        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(grp) if transport != "rccl" else None, device="cuda:%d" % local_rank,
+                                   halo=os.environ.get("M355_SHARD_HALO", "p2p"), native=transport != "python", rccl_id=rccl_id)
         refs = []
         for i in range(cfg["n_refs"]):
             f = ctx.frame_create_for(pp)
@@ -380,7 +393,9 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         dt_one = float(t.item()) / n1
         # the exchanges on their own (device time per collective, the buffers of this picture)
         ex_ms = None
-        if world > 1:
+        if world > 1 and dec.native:
+            ex_ms = [ctx.shard_time_exchange(h, k, 20) for k in range(4)]
+        elif world > 1:
             ex_ms = []
             for k in range(4):
                 buf = dec.xbufs[h][k]
@@ -409,7 +424,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         return {"value": args.steps * len(pic.ctbs) / dt, "unit": "CTB64/s", "ms_per_picture": 1e3 * dt / args.steps, "scaling": "strong",
                 "pictures_in_flight": depth, "ms_per_picture_one_at_a_time": 1e3 * dt_one, "host_enqueue_ms_per_picture": 1e3 * t_host / args.steps,
                 "non_reference_picture": {"value": args.steps * len(pic.ctbs) / dt_ng, "ms_per_picture": 1e3 * dt_ng / args.steps},
-                "exchange_ms": ex_ms, "halo_exchange": dec.halo,
+                "exchange_ms": ex_ms, "halo_exchange": dec.halo, "transport": transport,
                 "tiles_per_rank": (cfg["tile_cols"] * cfg["tile_rows"]) / world, "frames_identical_on_all_ranks": bool(same),
                 "exchange": {"halo_allreduce_bytes": xb[:3], "tile_allgather_bytes": xb[3]}}
     except Exception as e:  # noqa: BLE001

@@ -515,6 +515,32 @@ M355_API int64_t m355_shard_xbuf_bytes(m355_ctx* ctx, int handle, int which);
  * the stream of the picture's lane: order the exchange that follows on it. */
 M355_API int m355_decode_phase(m355_ctx* ctx, int handle, int phase, void* xbuf);
 
+/* The whole sharded picture in ONE call: the five phases with the exchanges between them, issued from the library (C++; no
+ * interpreter between the launches).  The exchange buffers live in the library; the exchanges go through a small callback table,
+ * each called in issue order with the stream of the picture's lane (whatever it enqueues on that stream is ordered between the
+ * phase that packed the buffer and the phase that unpacks it):
+ *   halo_sum    buf holds this rank's elements of X0 / X1 / X2 (zero elsewhere): make it the SUM over this rank and `peers` — the
+ *               ranks that own a tile touching one of this rank's (edge or corner; the only producers of what this rank reads,
+ *               deblock.cc:191-209, sao.cc:158-163); scratch = room for one buffer per peer
+ *   all_gather  X3: nranks slots of slot_bytes, slot `rank` filled -> all slots
+ * m355_shard_rccl_init installs the built-in RCCL implementation (librccl is loaded at that moment; neighbour ncclSend / ncclRecv
+ * in one group + one add kernel, ncclAllGather in place): one process per GPU, the unique id travels over the application's own
+ * bootstrap channel.  Tests install callbacks over another transport (gloo).  gather = 0: a non-reference picture (no X3). */
+typedef struct m355_comm {
+  void* user;
+  int (*halo_sum)(void* user, void* buf, size_t bytes, const int* peers, int n_peers, void* scratch, void* stream);
+  int (*all_gather)(void* user, void* buf, size_t slot_bytes, int rank, int nranks, void* stream);
+} m355_comm;
+M355_API int m355_shard_set_comm(m355_ctx* ctx, const m355_comm* comm);
+M355_API int m355_decode_sharded(m355_ctx* ctx, int handle, int gather);
+M355_API int m355_rccl_unique_id(void* out128);                                  /* rank 0: ncclGetUniqueId (128 bytes) */
+M355_API int m355_shard_rccl_init(m355_ctx* ctx, const void* id128, int rank, int nranks);   /* m355_shard_set + an RCCL communicator on the context's device */
+/* device time (ms) of exchange `which` (0..3) of a sharded picture's buffers over the installed transport, averaged over `iters` runs;
+ * collective: every rank calls it alike, after at least one m355_decode_sharded of the picture */
+M355_API int m355_shard_time_exchange(m355_ctx* ctx, int handle, int which, int iters, float* ms_each);
+/* the ranks `rank` exchanges halos with for these picture parameters (-> count, peers[] filled up to max_peers) */
+M355_API int m355_shard_peers(const m355_pic_params* pp, int rank, int nranks, int* peers, int max_peers);
+
 /* Per-stage device timing from HIP events recorded on the context's OWN stream around every decode
  * enqueued since m355_timing_reset(): averages in milliseconds, stage order
  * [meta, inter, residual, intra, deblock, sao]. m355_timing_collect() waits for the work. */

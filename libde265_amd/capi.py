@@ -14,6 +14,15 @@ DEFAULT_LIB = os.path.join(_HERE, "libde265_mi355x.so")
 ERRORS = {1: "M355_ERR_NO_DEVICE", 2: "M355_ERR_HIP", 3: "M355_ERR_INVALID", 4: "M355_ERR_NOMEM", 5: "M355_ERR_TIMEOUT", 6: "M355_ERR_BUSY"}
 
 
+HALO_SUM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+ALL_GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+
+
+class Comm(ctypes.Structure):
+    """m355_comm (include/de265_mi355x.h): the exchange callbacks of m355_decode_sharded"""
+    _fields_ = [("user", ctypes.c_void_p), ("halo_sum", HALO_SUM_FN), ("all_gather", ALL_GATHER_FN)]
+
+
 class M355Error(RuntimeError):
     def __init__(self, code, text):
         super().__init__("%s: %s" % (ERRORS.get(code, code), text))
@@ -82,11 +91,23 @@ class Library:
         L.m355_shard_xbuf_bytes.argtypes = [vp, i, i]
         L.m355_shard_xbuf_bytes.restype = ctypes.c_int64
         L.m355_decode_phase.argtypes = [vp, i, i, vp]
+        L.m355_decode_sharded.argtypes = [vp, i, i]
+        L.m355_shard_set_comm.argtypes = [vp, vp]
+        L.m355_rccl_unique_id.argtypes = [vp]
+        L.m355_shard_rccl_init.argtypes = [vp, vp, i, i]
+        L.m355_shard_peers.argtypes = [vp, i, i, ctypes.POINTER(i), i]
+        L.m355_shard_time_exchange.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_float)]
         L.init_acceleration_functions_mi355x.argtypes = [vp]
         L.m355_transform_add_batch.argtypes = [i, i, i, i, vp, ctypes.c_size_t, vp, ctypes.c_ssize_t, vp]
 
     def error(self):
         return (self.lib.m355_last_error() or b"").decode()
+
+    def rccl_unique_id(self):
+        """rank 0 of a tile-sharded job: the RCCL unique id (128 bytes) to hand to every rank (Context.shard_rccl_init)"""
+        buf = ctypes.create_string_buffer(128)
+        self.check(self.lib.m355_rccl_unique_id(buf))
+        return buf.raw
 
     def check(self, rc):
         if rc != 0:
@@ -207,6 +228,23 @@ class Context:
 
     def wait(self):
         self.L.check(self.L.lib.m355_wait(self.h))
+
+    # ---- tile-sharded picture in one call (m355_decode_sharded) ----
+    def decode_sharded(self, handle, gather=True):
+        self.L.check(self.L.lib.m355_decode_sharded(self.h, handle, 1 if gather else 0))
+
+    def shard_time_exchange(self, handle, which, iters=20):
+        ms = ctypes.c_float(0)
+        self.L.check(self.L.lib.m355_shard_time_exchange(self.h, handle, which, iters, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def shard_set_comm(self, comm_struct):
+        """comm_struct: a ctypes m355_comm (kept alive by the caller) or None"""
+        self.L.check(self.L.lib.m355_shard_set_comm(self.h, ctypes.addressof(comm_struct) if comm_struct is not None else None))
+
+    def shard_rccl_init(self, unique_id, rank, nranks):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self.L.check(self.L.lib.m355_shard_rccl_init(self.h, buf, rank, nranks))
 
     def last_serial(self):
         """serial of the decode the last submit / decode call enqueued"""

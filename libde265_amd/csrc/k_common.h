@@ -177,6 +177,8 @@ void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStrea
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st);
 /* tile sharding: `which` bit 0 = column strips, bit 1 = row strips; meta = border-unit records (16 B each) */
 void m355_launch_halo_pack(const DevPic& p, const HaloLayout& h, bool hbd, int which, void* samples, uint32_t* meta, hipStream_t st);
+/* buf[i] += sum over the n received copies scratch[k * pitch_words + i] (halo exchange of m355_decode_sharded over RCCL) */
+void m355_launch_halo_add(uint32_t* buf, const uint32_t* scratch, uint32_t pitch_words, int n, uint32_t words, hipStream_t st);
 void m355_launch_halo_unpack(const DevPic& p, const HaloLayout& h, bool hbd, int which, const void* samples, const uint32_t* meta, hipStream_t st);
 
 /* ---- device helpers ---- */

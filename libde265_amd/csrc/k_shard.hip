@@ -213,3 +213,19 @@ void m355_launch_tiles_copy(const TileCopyArgs& a, int n, void* xbuf, bool to_sl
   if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tiles_copy<16>), dim3(gx, n), dim3(256), 0, st, a, (char*)xbuf, to_slot ? 1 : 0);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tiles_copy<4>), dim3(gx, n), dim3(256), 0, st, a, (char*)xbuf, to_slot ? 1 : 0);
 }
+
+/* halo exchange over point-to-point copies: every element has exactly one producer (zero elsewhere), so adding the peers' buffers
+   completes this rank's copy */
+__global__ void __launch_bounds__(256) k_halo_add(uint32_t* buf, const uint32_t* scratch, uint32_t pitch_words, int n, uint32_t words)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= words) return;
+  uint32_t v = buf[i];
+  for (int k = 0; k < n; k++) v += scratch[(size_t)k * pitch_words + i];
+  buf[i] = v;
+}
+void m355_launch_halo_add(uint32_t* buf, const uint32_t* scratch, uint32_t pitch_words, int n, uint32_t words, hipStream_t st)
+{
+  if (!words || !n) return;
+  hipLaunchKernelGGL(k_halo_add, dim3((words + 255) / 256), dim3(256), 0, st, buf, scratch, pitch_words, n, words);
+}

@@ -9,6 +9,7 @@
  * (slice.cc:3460, motion.cc:2190, decctx.cc:1783-1833).  Nothing here falls back to the CPU: if HIP
  * is unavailable every entry point fails with M355_ERR_NO_DEVICE.
  */
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -114,6 +115,10 @@ struct Resident {
   bool live_sao = false, live_valid = false;
   void* xprev = nullptr;       /* exchange buffer handed to the previous phase */
   int lane = 0;                /* the lane phase 0 ran on: the picture's working planes and scratch live there */
+  void* xb[4] = {nullptr, nullptr, nullptr, nullptr};   /* m355_decode_sharded: the picture's exchange buffers X0..X3 + peer scratch (library-owned) */
+  size_t xb_bytes[4] = {0, 0, 0, 0};
+  void* xscratch = nullptr;
+  std::vector<int> peers;      /* ranks this rank exchanges halos with */
   hipEvent_t ev_up = nullptr;  /* lists copied to the device (decodes on the other lane wait for it) */
   hipEvent_t ev_done = nullptr; /* last decode of these lists finished: the arenas may be overwritten */
   bool done_pending = false;
@@ -173,6 +178,8 @@ struct m355_ctx {
   unsigned long long serial = 0;
   int stages = M355_STAGE_ALL;
   int shard_rank = 0, shard_n = 0;   /* shard_n == 0: sharding off */
+  m355_comm comm = {nullptr, nullptr, nullptr};   /* exchanges of m355_decode_sharded */
+  void* rccl = nullptr;              /* built-in RCCL communicator (m355_shard_rccl_init) */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
@@ -307,6 +314,22 @@ static int copy_tiles(m355_ctx* c, const m355_pic_params& pp, Frame* f, int k0, 
   return M355_OK;
 }
 
+/* ---- built-in RCCL transport (librccl is loaded on demand: the library itself does not link against it) ---- */
+struct Id128 { char b[128]; };
+struct Rccl {
+  void* so = nullptr;
+  void* comm = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128 bytes */ Id128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, void*) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
+};
+static Rccl g_rccl;
+
 extern "C" {
 
 const char* m355_last_error(void) { return g_err.c_str(); }
@@ -341,6 +364,8 @@ int m355_create(int device, m355_ctx** out)
 
 static void resident_free(Resident& r)
 {
+  for (void* b : r.xb) if (b) hipFree(b);
+  if (r.xscratch) hipFree(r.xscratch);
   if (r.dev) hipFree(r.dev);
   if (r.host) hipHostFree(r.host);
   if (r.refs_dev) hipFree(r.refs_dev);
@@ -360,6 +385,7 @@ void m355_destroy(m355_ctx* c)
   for (auto& t : c->transient) resident_free(t);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   if (c->hash_acc) hipFree(c->hash_acc);
+  if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& st_ : c->status) if (st_.ev) hipEventDestroy(st_.ev);
   if (c->status_words) hipHostFree(c->status_words);
   {
@@ -1622,6 +1648,163 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return M355_OK;
+}
+
+
+/* ------------------------------------------------------------------ sharded picture in one call ---- */
+
+int m355_shard_peers(const m355_pic_params* pp, int rank, int nranks, int* peers, int max_peers)
+{
+  const int ntc = pp->num_tile_cols, ntr = pp->num_tile_rows, n = ntc * ntr;
+  bool is_peer[256] = {};
+  if (nranks > 256) return -fail(M355_ERR_INVALID, "more than 256 ranks");
+  for (int ty = 0; ty < ntr; ty++)
+    for (int tx = 0; tx < ntc; tx++) {
+      if (m355_shard_owner_of_tile(ty * ntc + tx, n, nranks) != rank) continue;
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          const int x = tx + dx, y = ty + dy;
+          if (x < 0 || y < 0 || x >= ntc || y >= ntr) continue;
+          const int q = m355_shard_owner_of_tile(y * ntc + x, n, nranks);
+          if (q != rank) is_peer[q] = true;
+        }
+    }
+  int k = 0;
+  for (int q = 0; q < nranks; q++) if (is_peer[q]) { if (k < max_peers) peers[k] = q; k++; }
+  return k;
+}
+
+int m355_shard_set_comm(m355_ctx* c, const m355_comm* comm)
+{
+  if (comm) c->comm = *comm; else c->comm = m355_comm{nullptr, nullptr, nullptr};
+  return M355_OK;
+}
+
+int m355_decode_sharded(m355_ctx* c, int h, int gather)
+{
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded) return fail(M355_ERR_INVALID, "not a sharded picture handle");
+  Resident& r = c->resident[h];
+  const int N = r.shard_n;
+  if (N > 1 && (!c->comm.halo_sum || !c->comm.all_gather)) return fail(M355_ERR_INVALID, "m355_decode_sharded: no exchange callbacks (m355_shard_set_comm / m355_shard_rccl_init)");
+  hipSetDevice(c->device);
+  if (!r.xb[0]) {
+    /* first decode of these lists: the exchange buffers (zeroed once: a rank's pack kernels write only its own elements, the
+       unpack kernels read what the exchange completed) and the peers */
+    size_t mx = 0;
+    for (int k = 0; k < 4; k++) {
+      const int64_t b = m355_shard_xbuf_bytes(c, h, k);
+      if (b < 0) return M355_ERR_INVALID;
+      r.xb_bytes[k] = (size_t)b;
+      HIPCHK(hipMalloc(&r.xb[k], (size_t)b + 256));
+      HIPCHK(hipMemsetAsync(r.xb[k], 0, (size_t)b + 256, c->stream));
+      if (k < 3) mx = std::max(mx, (size_t)b);
+    }
+    int peers[256];
+    const int np = m355_shard_peers(&r.hdr.pp, r.shard_rank, N, peers, 256);
+    if (np < 0) return M355_ERR_INVALID;
+    r.peers.assign(peers, peers + np);
+    if (np) HIPCHK(hipMalloc(&r.xscratch, (mx + 256) * (size_t)np));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  const int last = gather ? 4 : 3;
+  for (int k = 0; k <= last; k++) {
+    int rc = m355_decode_phase(c, h, k, k < 4 ? r.xb[k] : nullptr);
+    if (rc) return rc;
+    if (N <= 1 || k >= last) continue;                       /* a single rank owns every tile: nothing to exchange */
+    if (k < 3) {
+      if (!r.peers.empty() && (rc = c->comm.halo_sum(c->comm.user, r.xb[k], r.xb_bytes[k], r.peers.data(), (int)r.peers.size(), r.xscratch, (void*)c->stream)))
+        return fail(M355_ERR_HIP, "halo exchange %d failed (%d)", k, rc);
+    } else if ((rc = c->comm.all_gather(c->comm.user, r.xb[3], r.xb_bytes[3] / (size_t)N, r.shard_rank, N, (void*)c->stream)))
+      return fail(M355_ERR_HIP, "tile all-gather failed (%d)", rc);
+  }
+  return M355_OK;
+}
+
+/* device time of one exchange of a sharded picture's buffers, on its own (bench.py --gpus N: what X0..X3 cost over this transport);
+   every rank must call it with the same arguments; the buffers must exist (one m355_decode_sharded of the picture before) */
+int m355_shard_time_exchange(m355_ctx* c, int h, int which, int iters, float* ms_each)
+{
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded || which < 0 || which > 3 || iters < 1 || !ms_each) return fail(M355_ERR_INVALID, "bad arguments");
+  Resident& r = c->resident[h];
+  if (!r.xb[which]) return fail(M355_ERR_INVALID, "no exchange buffers yet");
+  *ms_each = 0.f;
+  if (r.shard_n <= 1) return M355_OK;
+  hipSetDevice(c->device);
+  HIPCHK(sync_all(c));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  auto once = [&]() -> int {
+    if (which < 3) return r.peers.empty() ? 0 : c->comm.halo_sum(c->comm.user, r.xb[which], r.xb_bytes[which], r.peers.data(), (int)r.peers.size(), r.xscratch, (void*)c->stream);
+    return c->comm.all_gather(c->comm.user, r.xb[3], r.xb_bytes[3] / (size_t)r.shard_n, r.shard_rank, r.shard_n, (void*)c->stream);
+  };
+  int rc = 0;
+  for (int i = 0; i < 2 && !rc; i++) rc = once();
+  hipEventRecord(e0, c->stream);
+  for (int i = 0; i < iters && !rc; i++) rc = once();
+  hipEventRecord(e1, c->stream);
+  hipError_t he = hipStreamSynchronize(c->stream);
+  float ms = 0.f;
+  if (he == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc || he != hipSuccess) return fail(M355_ERR_HIP, "exchange %d failed", which);
+  *ms_each = ms / (float)iters;
+  return M355_OK;
+}
+
+/* ---- built-in RCCL transport (struct Rccl above: librccl is loaded on demand, the library itself does not link against it) ---- */
+static int rccl_load(Rccl& R)
+{
+  if (R.so) return M355_OK;
+  R.so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!R.so) R.so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!R.so) return fail(M355_ERR_HIP, "cannot load librccl.so: %s", dlerror());
+#define RSYM(field, name) R.field = (decltype(R.field))dlsym(R.so, name); if (!R.field) return fail(M355_ERR_HIP, "librccl lacks %s", name);
+  RSYM(GetUniqueId, "ncclGetUniqueId") RSYM(CommInitRank, "ncclCommInitRank") RSYM(CommDestroy, "ncclCommDestroy") RSYM(GroupStart, "ncclGroupStart")
+  RSYM(GroupEnd, "ncclGroupEnd") RSYM(Send, "ncclSend") RSYM(Recv, "ncclRecv") RSYM(AllGather, "ncclAllGather")
+#undef RSYM
+  return M355_OK;
+}
+static int rccl_halo_sum(void* user, void* buf, size_t bytes, const int* peers, int n_peers, void* scratch, void* stream)
+{
+  Rccl& R = g_rccl;
+  void* comm = ((m355_ctx*)user)->rccl;
+  const size_t pitch = (bytes + 255) & ~(size_t)255;
+  int rc = R.GroupStart();
+  for (int i = 0; i < n_peers && !rc; i++) {
+    rc = R.Send(buf, bytes, /* ncclInt8 */ 0, peers[i], comm, stream);
+    if (!rc) rc = R.Recv((char*)scratch + pitch * (size_t)i, bytes, 0, peers[i], comm, stream);
+  }
+  const int rc2 = R.GroupEnd();
+  if (rc || rc2) return rc ? rc : rc2;
+  m355_launch_halo_add((uint32_t*)buf, (const uint32_t*)scratch, (uint32_t)(pitch / 4), n_peers, (uint32_t)((bytes + 3) / 4), (hipStream_t)stream);
+  return 0;
+}
+static int rccl_all_gather(void* user, void* buf, size_t slot_bytes, int rank, int nranks, void* stream)
+{
+  (void)nranks;
+  return g_rccl.AllGather((const char*)buf + slot_bytes * (size_t)rank, buf, slot_bytes, 0, ((m355_ctx*)user)->rccl, stream);
+}
+
+int m355_rccl_unique_id(void* out128)
+{
+  int rc = rccl_load(g_rccl);
+  if (rc) return rc;
+  if (g_rccl.GetUniqueId(out128)) return fail(M355_ERR_HIP, "ncclGetUniqueId failed");
+  return M355_OK;
+}
+
+int m355_shard_rccl_init(m355_ctx* c, const void* id128, int rank, int nranks)
+{
+  int rc = rccl_load(g_rccl);
+  if (rc) return rc;
+  if ((rc = m355_shard_set(c, rank, nranks))) return rc;
+  hipSetDevice(c->device);
+  Id128 id;
+  memcpy(&id, id128, 128);
+  if (c->rccl) { g_rccl.CommDestroy(c->rccl); c->rccl = nullptr; }
+  if (g_rccl.CommInitRank(&c->rccl, nranks, id, rank)) return fail(M355_ERR_HIP, "ncclCommInitRank failed");
+  m355_comm cm = {c, rccl_halo_sum, rccl_all_gather};
+  return m355_shard_set_comm(c, &cm);
 }
 
 int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)

@@ -149,15 +149,83 @@ class DistComm:
         self.dist.all_gather_into_tensor(t, t[self.rank * n:(self.rank + 1) * n].clone(), group=self.group)
 
 
-class ShardedDecoder:
-    """One rank's executor: context + exchange buffers + the phase loop."""
+class _DevArray:
+    """a raw device pointer as an object torch.as_tensor understands (__cuda_array_interface__)"""
 
-    def __init__(self, ctx, rank, nranks, comm=None, device="cuda", halo="p2p"):
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
+class CallbackComm:
+    """m355_comm callbacks over a DistComm (torch.distributed): what m355_decode_sharded calls between the phases when the
+    transport is not the built-in RCCL one — the gloo CPU tests, or torch's own process group on the GPU."""
+
+    def __init__(self, comm, device):
+        import ctypes
+        import torch
+        from . import capi
+        self.comm, self.torch, self.device = comm, torch, torch.device(device)
+        self._streams = {}
+        self.errors = []
+
+        def tensor(ptr, nbytes):
+            n = (nbytes + 3) // 4
+            if self.device.type == "cuda":
+                return torch.as_tensor(_DevArray(ptr, n), device=self.device)
+            return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_int32 * n).from_address(ptr)))
+
+        def on_stream(stream_ptr, fn):
+            if self.device.type != "cuda":
+                return fn()
+            st = self._streams.get(stream_ptr)
+            if st is None:
+                st = self._streams[stream_ptr] = torch.cuda.ExternalStream(stream_ptr, device=self.device)
+            with torch.cuda.stream(st):
+                return fn()
+
+        def halo_sum(user, buf, nbytes, peers, n_peers, scratch, stream):
+            try:
+                pitch = (nbytes + 255) & ~255
+                t = tensor(buf, nbytes)
+                tmp = [tensor(scratch + pitch * i, nbytes) for i in range(n_peers)]
+                on_stream(stream, lambda: self.comm.neighbour_sum(t, [peers[i] for i in range(n_peers)], tmp))
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self.errors.append(repr(e))
+                return 1
+
+        def all_gather(user, buf, slot_bytes, rank, nranks, stream):
+            try:
+                t = tensor(buf, slot_bytes * nranks)
+                on_stream(stream, lambda: self.comm.all_gather_slots(t))
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self.errors.append(repr(e))
+                return 1
+        self._keep = (capi.HALO_SUM_FN(halo_sum), capi.ALL_GATHER_FN(all_gather))
+        self.struct = capi.Comm(None, self._keep[0], self._keep[1])
+
+
+class ShardedDecoder:
+    """One rank's executor.  native=True (default): the phase loop and the exchange buffers live in the library
+    (m355_decode_sharded) and the exchanges go through the m355_comm callbacks — the built-in RCCL transport
+    (rccl_id = the unique id rank 0 made with rccl_unique_id and handed round), or `comm` (a DistComm) through CallbackComm.
+    native=False: the phase loop in Python over m355_decode_phase (exchange buffers = torch tensors), kept as the cross-check."""
+
+    def __init__(self, ctx, rank, nranks, comm=None, device="cuda", halo="p2p", native=True, rccl_id=None):
         import torch
         self.torch = torch
         self.ctx, self.rank, self.nranks, self.comm = ctx, rank, nranks, comm
         self.device = torch.device(device)
         self.ctx.shard_set(rank, nranks)
+        self.native = native and halo == "p2p"
+        self.cb = None
+        if self.native:
+            if rccl_id is not None:
+                self.ctx.shard_rccl_init(rccl_id, rank, nranks)       # ncclSend / ncclRecv / ncclAllGather issued by the library
+            elif comm is not None and nranks > 1:
+                self.cb = CallbackComm(comm, device)
+                self.ctx.shard_set_comm(self.cb.struct)
         self.xbufs = {}
         self.halo = halo                     # "p2p": halos from the neighbour ranks only; "allreduce": SUM all-reduce over all ranks
         self._ptrs = {}
@@ -180,6 +248,8 @@ class ShardedDecoder:
 
     def upload(self, pic_shard):
         h = self.ctx.upload(pic_shard)
+        if self.native:
+            return h
         self.xbufs[h] = [self.torch.zeros(max(1, self.ctx.shard_xbuf_bytes(h, k) // 4), dtype=self.torch.int32, device=self.device)
                          for k in range(4)]
         self._ptrs[h] = [t.data_ptr() for t in self.xbufs[h]]
@@ -223,6 +293,11 @@ class ShardedDecoder:
         allow (every rank must then issue the same pictures in the same order — the collectives pair up by issue order).
         gather=False: a NON-reference picture — the finished tiles stay where they were decoded (each rank outputs its own
         tiles), no X3."""
+        if self.native:
+            self.ctx.decode_sharded(h, gather)
+            if self.cb is not None and self.cb.errors:
+                raise RuntimeError("exchange callback failed: %s" % self.cb.errors[0])
+            return
         for k in range(5 if gather else 4):
             self.run_phase(h, k)
             if k < (4 if gather else 3):

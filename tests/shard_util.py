@@ -29,7 +29,7 @@ def local_sharded_decode(lib, pic, refs, nranks, device="cpu", stages=worklist.S
         decs, hs, dsts = [], [], []
         for r, ctx in enumerate(ctxs):
             ctx.set_stages(stages)
-            d = shard.ShardedDecoder(ctx, r, nranks, comm=None, device=device)
+            d = shard.ShardedDecoder(ctx, r, nranks, comm=None, device=device, native=False)   # the phase loop by hand, in lockstep
             sp, dst = _setup_rank(ctx, pic, refs, r, nranks, device)
             decs.append(d); hs.append(d.upload(sp)); dsts.append(dst)
         for _ in range(repeat):

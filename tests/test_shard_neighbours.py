@@ -1,9 +1,11 @@
 """`shard.neighbour_ranks` (who a rank exchanges tile-boundary halos with): symmetric, never the rank itself, and it contains every
 rank that owns a CTB within one CTB (edge or corner) of an own CTB — checked against the CTB owner map for a sweep of tile grids."""
+import ctypes
+
 import numpy as np
 import pytest
 
-from libde265_amd import shard, worklist
+from libde265_amd import capi, shard, worklist
 
 
 def _pp(tc, tr, w_ctbs, h_ctbs):
@@ -36,3 +38,9 @@ def test_neighbour_ranks(tc, tr, nranks):
         assert set(got) == want[r], (r, got, want[r])
         for q in got:
             assert r in shard.neighbour_ranks(pp, q, nranks)
+        # the library's own version (m355_shard_peers: what m355_decode_sharded exchanges with) agrees
+        lib = capi.Library()
+        buf = (ctypes.c_int * 64)()
+        raw = np.array([pp]).tobytes()
+        n = lib.lib.m355_shard_peers(ctypes.c_char_p(raw), r, nranks, buf, 64)
+        assert list(buf[:n]) == got
