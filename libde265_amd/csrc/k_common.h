@@ -113,6 +113,7 @@ struct DevPic {
   const DevIntraWork* intra_work;   /* one descriptor per CTB that holds intra blocks: first the n_intra_free CTBs that wait for no
                                        neighbour (longest first), then the dependent ones in decode order (k_intra's ticket order) */
   int n_intra_work, n_intra_free;
+  int intra_grid;                   /* intra pictures: workgroups of k_intra's launch (persistent: each takes CTB after CTB); 0 = one per CTB */
   const uint8_t* ctb_dep;           /* per CTB: bit n = reads intra output of neighbour n (0 L, 1 TL, 2 T, 3 TR; orders the work list);
                                        bit 4 = a neighbour reads ours; bits 5-6 = the CTB's widest level (0: 1 luma block, 1: 2, 2: 3-4, 3: more) -> waves in k_intra */
   /* tile sharding (k_shard.hip): NULL = this context owns the whole picture */

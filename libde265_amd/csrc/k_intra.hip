@@ -93,7 +93,7 @@ __device__ __forceinline__ m355_granule* d_edge_row(const DevPic& p, int c, int 
 /* A halo sample its CTB has not published yet: poll its granule (relaxed, agent scope: served by the L2 / fabric, never by this
  * CU's L1); every waiting lane has its own word, the wave leaves when all have arrived.  Returns the lane's (possibly updated)
  * value; arrived samples are also stored in the halo words for the blocks that read them later. */
-__device__ __attribute__((noinline)) uint32_t d_poll_halo(const m355_granule* top_row, const m355_granule* left_col, uint32_t* timeout, uint16_t* halo, int hi, uint32_t val, bool pending, int x0c, int y0c, uint32_t epoch)
+__device__ __forceinline__ uint32_t d_poll_halo(const m355_granule* top_row, const m355_granule* left_col, uint32_t* timeout, uint16_t* halo, int hi, uint32_t val, bool pending, int x0c, int y0c, uint32_t epoch)
 {
   const int lane = threadIdx.x & 63;
   const bool is_top = hi < HALO_TOP_N;
@@ -271,12 +271,17 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      loads, record fields live in SGPRs and the per-block branches are scalar */
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 
-  /* work item: the first n_intra_free items are CTBs that wait for no neighbour — any workgroup may take any of them, so they go
-     by workgroup index (no atomic, no barrier); the dependent CTBs behind them are claimed through the ticket, in decode order,
-     so that a workgroup only ever waits on items claimed before its own (free ones, or lower tickets) */
+  /* Work items.  Intra pictures (DENSE): the workgroup is PERSISTENT — it claims CTB after CTB through the ticket, in work-list
+     order (CTBs that wait for no neighbour first, then the dependent ones in wavefront order), until the list is exhausted.  The
+     grid is therefore free to be smaller than the list (runtime.hip: with several pictures in flight each picture gets a share of
+     the GPU's workgroup slots that covers its ACTIVE wavefront, instead of parking a workgroup on every CTB of the picture for
+     the picture's whole duration); a workgroup only ever waits on items claimed before its own, whose workgroups are running.
+     Inter pictures: one workgroup per CTB with intra blocks — the first n_intra_free items (no neighbour to wait for) go by
+     workgroup index (no atomic, no barrier), the dependent ones through the ticket. */
+  for (;;) {
   int item = (int)blockIdx.x;
-  if (item >= p.n_intra_free) {          /* (uniform per workgroup) */
-    if (threadIdx.x == 0) s_ticket = (uint32_t)p.n_intra_free + atomicAdd(p.ticket, 1u);
+  if (DENSE || item >= p.n_intra_free) {          /* (uniform per workgroup) */
+    if (threadIdx.x == 0) s_ticket = (DENSE ? 0u : (uint32_t)p.n_intra_free) + atomicAdd(p.ticket, 1u);
     __syncthreads();
     item = __builtin_amdgcn_readfirstlane((int)s_ticket);
   }
@@ -288,8 +293,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   const int ctb = __builtin_amdgcn_readfirstlane((int)wd0.x);
   struct { uint32_t ib_start, ib_count; } ctbinfo = {(uint32_t)__builtin_amdgcn_readfirstlane((int)wd0.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)wd0.z)};
   const uint32_t plan_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wd1.y), plan_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)wd1.z);
-  /* wave -> (colour component c, sub-wave g of G): GL luma waves, then GC for Cb, GC for Cr; the rest leave at once
-     (finished waves do not take part in later barriers) */
+  /* wave -> (colour component c, sub-wave g of G): GL luma waves, then GC for Cb, GC for Cr; the rest have no part in this CTB:
+     a one-CTB workgroup's leave at once (finished waves do not take part in later barriers), a persistent workgroup's run along
+     as waves of an absent component (they execute the barriers and take the next CTB with the others) */
   int GL, GC;
   {
     const int code = __builtin_amdgcn_readfirstlane((int)(wd1.x & 3u));   /* widest level of the CTB: luma 1 / 2 / 3-4 / more blocks */
@@ -297,20 +303,21 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     GL = min(GLMAX, code == 0 ? 1 : (code == 1 ? 2 : (code == 2 ? 4 : 8)));
     GC = code == 3 ? GCMAX : 1;
   }
-  if (wv >= GL + 2 * GC) return;
-  const int c = wv < GL ? 0 : (wv < GL + GC ? 1 : 2);
-  const int G = c == 0 ? GL : GC, g = c == 0 ? wv : (wv - GL - (c - 1) * GC);
-  const int NWV = GL + 2 * GC;                           /* waves at work on this CTB */
+  const bool spare = wv >= GL + 2 * GC;
+  if (spare && !DENSE) return;
+  const int c = spare ? 3 : (wv < GL ? 0 : (wv < GL + GC ? 1 : 2));
+  const int G = spare ? 1 : (c == 0 ? GL : GC), g = spare ? 0 : (c == 0 ? wv : (wv - GL - (c - 1) * GC));
+  const int NWV = DENSE ? NW : GL + 2 * GC;              /* waves running this CTB's loops */
   const bool multi = GL + GC > 2;                        /* more than one wave per component somewhere: levels end in a barrier */
   const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
   const int l2c = p.pp.log2_ctb_size;
 
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
   const bool comp = c < nc;
-  const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
+  const int csw = (c && comp) ? (p.sw == 2) : 0, csh = (c && comp) ? (p.sh == 2) : 0;
   const int cw = (1 << l2c) >> csw, ch = (1 << l2c) >> csh;
   const int x0c = (ctbX << l2c) >> csw, y0c = (ctbY << l2c) >> csh;
-  const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+  const int bd = (c && comp) ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
   const int cs = comp ? c : 0;
   PIX* plane = (PIX*)p.plane[cs];
   const int stride = p.stride[cs], pw = p.pw[cs], ph = p.ph[cs];
@@ -589,7 +596,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const uint32_t cd = code[q];
         uint32_t val = 0;
         if (e < nEnt) val = body[cd];
-        /* a halo sample its CTB has not published yet: poll its granule (rare: kept out of line, off the block chain's registers) */
+        /* a halo sample its CTB has not published yet: poll its granule */
         const bool pending = e < nEnt && val == HALO_NOT_READY && cd >= (uint32_t)HALO_BASE && cd < (uint32_t)(HALO_BASE + HALO_N);
         if (__any((int)pending))
           val = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)cd - HALO_BASE, val, pending, x0c, y0c, epoch);
@@ -797,6 +804,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       else *(uint32_t*)dst = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y & 0xFF0000u) << 8);
     }
   }
+  if (!DENSE) return;
+  __syncthreads();     /* the LDS tiles (and the ticket word) are free for the workgroup's next CTB */
+  }   /* persistent workgroup: next CTB */
 #undef SYNC_CTB
 }
 
@@ -809,7 +819,7 @@ static void launch_intra_cf(const DevPic& p, hipStream_t st)
   hipMemsetAsync(p.ticket, 0, 4, st);
   /* dense intra pictures: 12 waves (up to 8 luma + 2 + 2 chroma blocks of a level at once); sparse ones: 4 (3 and 6 measured
      slower) */
-  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true>), dim3(p.n_intra_work), dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work);
+  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true>), dim3(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work), dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work);
 }
 

@@ -1367,6 +1367,14 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   }
 #endif
   d.resbuf = c->resbuf; d.edge = c->edge; d.ticket = c->ticket; d.timeout = c->timeout;
+  {
+    /* intra pictures: k_intra's workgroups are persistent (k_intra.hip); with several pictures in flight every picture gets a
+       share of the GPU's workgroup slots (2 per CU for this kernel) — enough for its active wavefront, not a slot per CTB */
+    static const int grid_env = getenv("M355_INTRA_GRID") ? atoi(getenv("M355_INTRA_GRID")) : 0;
+    static int slots = 0;
+    if (!slots) { hipDeviceProp_t prop; slots = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512; }
+    d.intra_grid = grid_env > 0 ? grid_env : std::max(64, slots / std::max(1, c->depth));
+  }
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;
   d_out = d; want_sao_out = want_sao;
