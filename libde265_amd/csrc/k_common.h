@@ -43,9 +43,20 @@ struct DevIntraWork {
 /* Border plans (k_intra_plan -> k_intra): per intra block 4nT + 1 16-bit entries (one LDS source per border entry).
  * The blocks of one component of a CTB are disjoint (runtime.hip intra_schedule rejects lists where they are not), which bounds a
  * CTB's plans by its 4x4-only case, 18 entries per 4x4 block, ... */
-/* DevPic.ib_aux word (runtime.hip intra_schedule): bits 0-15 plan offset, 16-29 dependency level inside the CTB */
-#define M355_IBA_FILT 0x40000000u    /* [1 2 1] border smoothing applies (intrapred.h:195-212: mode, size and component decide) */
-#define M355_IBA_STRONG 0x80000000u  /* ... and the bilinear variant is allowed if the border is flat (intrapred.h:216-234) */
+/* DevPic.ib_aux: one EXEC RECORD of four words per intra block (runtime.hip intra_schedule), everything k_intra's block chain needs
+ * that is not a sample value:
+ *   word 0  bits 0-6 lx, 7-13 ly (position inside the CTB, component samples), 14-16 log2 size, 17-18 component, 19-24 mode, flags:
+ *   word 1  residual buffer offset (int16 units) / pcm[] offset
+ *   word 2  bits 0-7 intraPredAngle (signed), 8-10 mode class (0 planar, 1 DC, 2 pure horizontal / vertical, 3 / 4 angular with a
+ *           positive / negative angle), 16-31 invAngle (signed; 0 unless the angle is negative)   (intrapred.h:313-326)
+ *   word 3  bits 0-15 offset of the block's border plan inside the CTB's plans, 16-29 dependency level inside the CTB */
+#define M355_IBX_HAS_RES 0x02000000u
+#define M355_IBX_PCM     0x04000000u
+#define M355_IBX_FILT    0x08000000u   /* [1 2 1] border smoothing applies (intrapred.h:195-212: mode, size and component decide) */
+#define M355_IBX_STRONG  0x10000000u   /* ... and the bilinear variant is allowed if the border is flat (intrapred.h:216-234) */
+#define M355_IBX_BFILT   0x20000000u   /* luma block < 32x32 whose boundary smoothing applies (DC: always; pure horizontal / vertical: unless disabled) */
+#define M355_IBX_PUB_COL 0x40000000u   /* the block completes a piece of the CTB's right column that the next CTB may read */
+#define M355_IBX_PUB_ROW 0x80000000u   /* ... of its bottom row */
 #define M355_INTRA_PLAN_CAP(cf) ((cf) == 0 ? 4608 : ((cf) == 1 ? 6912 : ((cf) == 2 ? 9216 : 13824)))
 /* ... and the plans of any 64 blocks of a CTB by 2176 / 2496 / 2848 / 3520 entries (+ 7 of alignment) */
 #define M355_INTRA_PLAN_BATCH(cf) ((cf) == 0 ? 2304 : ((cf) == 1 ? 2560 : ((cf) == 2 ? 3072 : 3584)))
@@ -69,7 +80,7 @@ struct DevPic {
   const m355_wt* wts;
   const m355_rb* rb_bin[4];         /* residual blocks of 4x4, 8x8, 16x16, 32x32 (rb_count[] entries each) */
   const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime.hip intra_schedule) */
-  const uint32_t* ib_aux;           /* per ibs[i]: M355_IBA_* (offset of its border plan inside the CTB's plans, dependency level, smoothing) */
+  const uint32_t* ib_aux;           /* per ibs[i]: the block's exec record, 4 words (M355_IBX_*) */
 #ifdef M355_X_PROF
   unsigned long long* prof;         /* timing hooks of experiment builds (tools/variants.sh -DM355_X_PROF=<work item>) */
 #endif

@@ -39,6 +39,7 @@
  *   - the inverse transforms were done up front, in parallel, by k_residual.
  */
 #include <stdlib.h>
+#include <type_traits>
 #include "k_common.h"
 
 #define MAXCTB 64
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
   for (uint32_t k = (uint32_t)(wv + 4 * (int)blockIdx.y); k < ib_count; k += 4 * PLAN_SPLIT) {
     const uint32_t* r = (const uint32_t*)&p.ibs[ib_start + k];
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[0]), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[1]);
-    const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[ib_start + k]);
+    const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[4 * (ib_start + k) + 3]);
     const int c = (int)(w1 & 0xFFu), log2 = (int)((w1 >> 8) & 0xFFu), flags = (int)(w1 >> 24);
     if (flags & M355_IBF_PCM) continue;                      /* raw blocks read no border: no plan entries */
     const int nT = 1 << log2;
@@ -496,29 +497,28 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     }
   }
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
-  /* The CTB's block records (sorted by level, then component) are fetched 64 at a time (one per lane, coalesced) by
-     EVERY wave.  A wave's blocks of the batch — those of its component whose rank inside their (level, component) group
-     falls to it — are one 64-bit mask; it walks them level by level, and all waves meet at the workgroup barrier after
-     every level of the batch (the loop bounds come from the records alone, so the waves of absent components execute the
-     same barriers).  The walk is software-pipelined: a block's record and its plan entries (LDS reads that depend on no
-     sample) are fetched while the block before it is being predicted, so that what stands between two dependent blocks is
-     sample read -> taps -> sample write. */
+  /* The CTB's exec records (runtime.hip intra_schedule: sorted by level, then component; everything about a block that is not a
+     sample value) are fetched 64 at a time (one per lane, 16 bytes, coalesced) by EVERY wave.  A wave's blocks of the batch —
+     those of its component whose rank inside their (level, component) group falls to it — are one 64-bit mask; it walks them
+     level by level, and all waves meet at the workgroup barrier after every level of the batch (the loop bounds come from the
+     records alone, so the waves of absent components execute the same barriers).  What stands between two dependent blocks is
+     kept short: the plan entries of the NEXT block's border (LDS reads that depend on no sample) are requested while the current
+     block is predicted, a 4x4 / 8x8 block's border, smoothing and taps live in registers (cross-lane reads), its arithmetic is
+     specialised by size (compile time) and mode class (one scalar branch). */
   const int thr_strong = 1 << (p.pp.bit_depth_luma - 5);
-  const bool can_pub_col = ctbX + 1 < p.ctbW, can_pub_row = ctbY + 1 < p.ctbH;
+  const int body_s0 = BODY_X0, pix_max = (1 << bd) - 1;
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
-    uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0, rw3 = 0;
+    uint4 ex = make_uint4(0, 0, 0, 0);
     int lv = -1;
     const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
     if (lane < nvalid) {
-      const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
-      rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
-      rw3 = p.ib_aux[ctbinfo.ib_start + kbase + lane];     /* M355_IBA_*: plan offset inside the CTB, level, smoothing flags */
-      lv = (int)((rw3 >> 16) & 0x3FFFu);
+      ex = ((const uint4*)p.ib_aux)[ctbinfo.ib_start + kbase + lane];
+      lv = (int)((ex.w >> 16) & 0x3FFFu);
     }
     if (!DENSE) {
       /* this batch's plan entries: [first block's offset, + PLAN_LDS) — reload when the window in LDS does not hold them */
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)rw3, 0) & 0xFFFFu;
-      const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)rw3, nvalid - 1) & 0xFFFFu;
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)ex.w, 0) & 0xFFFFu;
+      const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)ex.w, nvalid - 1) & 0xFFFFu;
       if (last + 130u > plan_lo + (uint32_t)PLAN_LDS && plan_count > (uint32_t)PLAN_LDS) {
         __syncthreads();                                     /* everybody is done with the previous window */
         const uint32_t lo8 = lo & ~7u;
@@ -533,30 +533,23 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     unsigned long long mine;
     {
       /* the records of one (level, component) group sit in consecutive lanes: rank in the group = lane - first lane of the group */
-      const uint32_t key = lane < nvalid ? (((uint32_t)lv << 2) | (rw1 & 3u)) : 0xFFFFFFFFu;
+      const uint32_t key = lane < nvalid ? (((uint32_t)lv << 2) | ((ex.x >> 17) & 3u)) : 0xFFFFFFFFu;
       const uint32_t prevk = __shfl_up(key, 1u, 64);
       const unsigned long long heads = __ballot((int)(lane == 0 || key != prevk));
       const int start = 63 - __clzll(heads & ((2ull << lane) - 1ull));
-      mine = __ballot((int)(comp && lane < nvalid && (rw1 & 0xFFu) == (uint32_t)c && (((lane - start) & (G - 1)) == g)));
+      mine = __ballot((int)(comp && lane < nvalid && ((ex.x >> 17) & 3u) == (uint32_t)c && (((lane - start) & (G - 1)) == g)));
     }
-    /* the wave's NEXT block: record words + the plan entries of its border (one per lane and 64-entry chunk) */
-    uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, ncode[3] = {0, 0, 0};
-    int nsrc = -1;
+    /* the wave's NEXT block: which record, its level, and (4x4 / 8x8) the plan entries of its border, entry e in lane e */
+    int nsrc = -1, nlevel = -1;
+    uint32_t ncode = 0;
     auto fetch_next = [&]() {
       nsrc = mine ? __ffsll(mine) - 1 : -1;
       mine &= mine - 1;
       if (nsrc < 0) return;
-      nw0 = __builtin_amdgcn_readlane(rw0, nsrc); nw1 = __builtin_amdgcn_readlane(rw1, nsrc);
-      nw2 = __builtin_amdgcn_readlane(rw2, nsrc); nw3 = __builtin_amdgcn_readlane(rw3, nsrc);
-      if ((nw1 >> 24) & M355_IBF_PCM) return;
-      const int nEnt = (4 << ((nw1 >> 8) & 0xFFu)) + 1;
-      const uint16_t* pl = s_plan + ((nw3 & 0xFFFFu) - plan_lo);
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        if (64 * q >= nEnt) continue;
-        const int e = lane + 64 * q;
-        ncode[q] = e < nEnt ? (uint32_t)pl[e] : 0u;
-      }
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)ex.x, nsrc), n3 = (uint32_t)__builtin_amdgcn_readlane((int)ex.w, nsrc);
+      nlevel = (int)((n3 >> 16) & 0x3FFFu);
+      const int nl2 = (int)((n0 >> 14) & 7u);
+      if (nl2 <= 3 && !(n0 & M355_IBX_PCM)) ncode = s_plan[((n3 & 0xFFFFu) - plan_lo) + (uint32_t)min(lane, 4 << nl2)];
     };
     fetch_next();
 #ifdef M355_X_PROF
@@ -569,136 +562,154 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #endif
     for (int L = lv_first; L <= lv_last; L++) {
     PROF_T(0);
-    while (nsrc >= 0 && (int)((nw3 >> 16) & 0x3FFFu) == L) {
-      m355_ib ib;
-      ib.x = (uint16_t)(nw0 & 0xFFFFu); ib.y = (uint16_t)(nw0 >> 16);
-      ib.cidx = (uint8_t)(nw1 & 0xFFu); ib.log2_size = (uint8_t)((nw1 >> 8) & 0xFFu); ib.mode = (uint8_t)((nw1 >> 16) & 0xFFu); ib.flags = (uint8_t)(nw1 >> 24);
-      ib.res_ofs = nw2;
-      const bool f_filt = (nw3 & M355_IBA_FILT) != 0, f_strong = (nw3 & M355_IBA_STRONG) != 0;
-      const uint32_t code[3] = {ncode[0], ncode[1], ncode[2]};
-      fetch_next();                                          /* the block after this one: its LDS reads run beside this block's */
-      const int nT = 1 << ib.log2_size;
-      const int xB = ib.x, yB = ib.y, lx = xB - x0c, ly = yB - y0c;
-      /* does the block complete a piece of the CTB's right column / bottom row that a neighbour CTB may read? */
-      const bool pub_col = lx + nT == cw && can_pub_col, pub_row = ly + nT == ch && can_pub_row;
-      bool published = false;
+    while (nsrc >= 0 && nlevel == L) {
+      const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ex.x, nsrc), e1 = (uint32_t)__builtin_amdgcn_readlane((int)ex.y, nsrc);
+      const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)ex.z, nsrc), e3 = (uint32_t)__builtin_amdgcn_readlane((int)ex.w, nsrc);
+      const uint32_t code0 = ncode;
+      fetch_next();                                          /* the block after this one: its plan reads run beside this block's */
+      const int lx = (int)(e0 & 127u), ly = (int)((e0 >> 7) & 127u), log2 = (int)((e0 >> 14) & 7u), nT = 1 << log2;
+      const int mode = (int)((e0 >> 19) & 63u), cls = (int)((e2 >> 8) & 7u);
+      const int angle = (int)(int8_t)(e2 & 0xFFu), inv = (int)(int16_t)(e2 >> 16);
+      const bool vert = mode >= 18;
+      const bool has_res = (e0 & M355_IBX_HAS_RES) != 0, bfilt = (e0 & M355_IBX_BFILT) != 0;
+      const bool pub_col = (e0 & M355_IBX_PUB_COL) != 0, pub_row = (e0 & M355_IBX_PUB_ROW) != 0;
 
-      if (!(ib.flags & M355_IBF_PCM)) {
-      const int nEnt = 4 * nT + 1;
-      const bool small = nT <= 8;                            /* the whole border (17 / 33 entries) sits in ONE register, entry e in lane e */
-      /* ---- the border (fill_from_image + substitution, intrapred.h:534-665, resolved by k_intra_plan): one entry per lane
-         and chunk, each from the LDS source its plan entry names ---- */
-      uint32_t bv = 0;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        if (64 * q >= nEnt) continue;              /* wave-uniform: 4x4 / 8x8 blocks have 17 / 33 border entries */
-        const int e = lane + 64 * q;
-        const uint32_t cd = code[q];
-        uint32_t val = 0;
-        if (e < nEnt) val = body[cd];
-        /* a halo sample its CTB has not published yet: poll its granule */
-        const bool pending = e < nEnt && val == HALO_NOT_READY && cd >= (uint32_t)HALO_BASE && cd < (uint32_t)(HALO_BASE + HALO_N);
-        if (__any((int)pending))
-          val = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)cd - HALO_BASE, val, pending, x0c, y0c, epoch);
-        if (small) bv = val;
-        else if (e < nEnt) raw[e] = (uint16_t)val;
-      }
-      if (!small) wave_sync();
-      PROF_T(1);
-      /* residual of this block (written by k_residual; its cache lines were requested in the prologue): the loads are issued
-         here, BEHIND the border gather — hipcc drains the vector-memory counter in front of the gather's poll loop, so loads
-         issued before it are waited for at once — and consumed after smoothing, up to 16 samples per lane (32x32) */
-      int16_t rv[16];
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int o = lane + 64 * q;
-        rv[q] = (!DENSE && (ib.flags & M355_IBF_HAS_RESIDUAL) && o < nT * nT) ? p.resbuf[ib.res_ofs + o] : (int16_t)0;
-      }
-      const int mode = ib.mode;
-      const int Z = 2 * nT;
-      const int log2 = ib.log2_size;
-      /* angular modes (intrapred.h:330-433): the projected reference array ref[] of the reference is not built — its entry x is
-         border entry sgn*x for x >= 0 and, left of the corner (negative angles only), -sgn*((x*invAngle+128)>>8): the two taps
-         of a sample are read straight from the border */
-      /* intraPredAngle / invAngle (intrapred.h:313-326) from the distance d of the mode to the pure horizontal (10) / vertical
-         (26) mode, looked up in packed constants (a table in memory would be a dependent vector load per block) */
-      const int d_ang = mode >= 18 ? d_abs(mode - 26) : d_abs(mode - 10);                    /* 0..8 */
-      const int mag = (int)((0x20345488D1214100ull >> (7 * d_ang)) & 0x7Full);                 /* {0,2,5,9,13,17,21,26,32}, 7 bits each */
-      const bool neg = mode >= 18 ? mode < 26 : mode > 10;
-      const int angle = mode < 2 ? 0 : (neg ? -mag : mag);
-      const int sgn = mode >= 18 ? 1 : -1;
-      /* invAngle = -round(8192 / |angle|): {4096,1638,910,630 | 482,390,315,256} for d = 1..8, 16 bits each */
-      const unsigned long long inv_tab = d_ang <= 4 ? 0x0276038E06661000ull : 0x0100013B018601E2ull;
-      const int inv = (mode >= 2 && angle < 0) ? -(int)((inv_tab >> (16 * ((d_ang - 1) & 3))) & 0xFFFFull) : 0;
-      const bool has_res = (ib.flags & M355_IBF_HAS_RESIDUAL) != 0;
-      const bool edge = (c == 0 && nT < 32);
-      const bool bfilt = edge && !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER);
-      /* one sample (x, y) of the block from border taps BRD(i), i = -2nT .. 2nT (intrapred.h:261-433) */
-#define PREDICT_SAMPLE(v, x, y, dcVal)                                                                                              \
-      do {                                                                                                                          \
-        if (mode == 0) {                                                                                                            \
-          v = ((nT - 1 - (x)) * BRD(-1 - (y)) + ((x) + 1) * BRD(1 + nT) + (nT - 1 - (y)) * BRD(1 + (x)) + ((y) + 1) * BRD(-1 - nT) + nT) >> (log2 + 1); \
-        } else if (mode == 1) {                                                                                                     \
-          v = dcVal;                                                                                                                \
-          if (edge) {                                                                                                               \
-            const int e0_ = BRD(-1), e1_ = BRD(1), ex_ = BRD((x) + 1), ey_ = BRD(-(y) - 1);                                         \
-            if ((x) == 0 && (y) == 0) v = (e0_ + 2 * dcVal + e1_ + 2) >> 2;                                                         \
-            else if ((y) == 0) v = (ex_ + 3 * dcVal + 2) >> 2;                                                                      \
-            else if ((x) == 0) v = (ey_ + 3 * dcVal + 2) >> 2;                                                                      \
-          }                                                                                                                         \
-        } else {                                                                                                                    \
-          const int a_ = mode >= 18 ? (y) : (x), b_ = mode >= 18 ? (x) : (y);                                                       \
-          const int iIdx_ = ((a_ + 1) * angle) >> 5, iFact_ = ((a_ + 1) * angle) & 31;                                              \
-          const int x1_ = b_ + iIdx_ + 1, x2_ = b_ + iIdx_ + 2;                                                                     \
-          const int r1_ = BRD(x1_ >= 0 ? sgn * x1_ : -sgn * ((x1_ * inv + 128) >> 8));                                              \
-          const int r2_ = BRD(x2_ >= 0 ? sgn * x2_ : -sgn * ((x2_ * inv + 128) >> 8));                                              \
-          v = iFact_ ? ((32 - iFact_) * r1_ + iFact_ * r2_ + 16) >> 5 : r1_;                                                        \
-          if (bfilt && (mode == 26 || mode == 10)) {                                                                                \
-            const int t0_ = BRD(0), t1_ = BRD(mode == 26 ? 1 : -1), t2_ = BRD(mode == 26 ? -1 - (y) : 1 + (x));                      \
-            if (mode == 26 ? (x) == 0 : (y) == 0) v = d_clip_bd(t1_ + ((t2_ - t0_) >> 1), bd);                                      \
-          }                                                                                                                         \
-        }                                                                                                                           \
-      } while (0)
-      if (small) {
-        /* ---- 4x4 / 8x8: border, smoothing and taps in registers (cross-lane reads), one sample per lane; every lane runs the
-           arithmetic (a cross-lane read needs its source lane active), lanes beyond the block do not store ---- */
-        if (f_filt) {     /* intra_prediction_sample_filtering (intrapred.h:185-258), [1 2 1] only (strong smoothing is 32x32) */
-          const uint32_t up = __shfl_up(bv, 1u, 64), dn = __shfl_down(bv, 1u, 64);
-          if (lane > 0 && lane < nEnt - 1) bv = (dn + 2u * bv + up + 2u) >> 2;
+      /* ---- 4x4 / 8x8 (the chain of an intra picture): border entry e in lane e of ONE register, one sample per lane; every
+         lane runs the arithmetic (a cross-lane read needs its source lane active), lanes beyond the block do not store ---- */
+      auto small_block = [&](auto l2_) {
+        constexpr int LOG2 = decltype(l2_)::value, NT = 1 << LOG2, Z = 2 * NT, NENT = 4 * NT + 1;
+        const int x = lane & (NT - 1), y = lane >> LOG2;
+        const bool inb = lane < NT * NT;
+        uint32_t bv = body[code0];                           /* fill_from_image + substitution (intrapred.h:534-665) resolved by k_intra_plan */
+        int rs = 0;
+        if (has_res) rs = DENSE ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (inb ? (int)p.resbuf[e1 + lane] : 0);
+        if (__any((int)(bv == HALO_NOT_READY))) {
+          /* a halo sample its CTB has not published yet: poll its granule */
+          const bool pending = bv == HALO_NOT_READY && code0 >= (uint32_t)HALO_BASE && code0 < (uint32_t)(HALO_BASE + HALO_N);
+          if (__any((int)pending))
+            bv = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)code0 - HALO_BASE, bv, pending, x0c, y0c, epoch);
         }
-#define BRD(i) ((int)__shfl(bv, ((i) + Z) & 63, 64))
-        int dcVal = 0;
-        if (mode == 1) {
-          const int t1 = BRD(lane + 1), t2 = BRD(-lane - 1);
-          int s_ = lane < nT ? t1 + t2 : 0;
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m, 64);
-          dcVal = (s_ + nT) >> (log2 + 1);
+        PROF_T(1);
+        if (e0 & M355_IBX_FILT) {   /* intra_prediction_sample_filtering (intrapred.h:185-258), [1 2 1] only (strong smoothing is 32x32) */
+          const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv, 0x138, 0xF, 0xF, false) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv, 0x130, 0xF, 0xF, false);
+          if (lane > 0 && lane < NENT - 1) bv = (nb + 2u * bv + 2u) >> 2;
         }
-        const int y = lane >> log2, x = lane & (nT - 1);
+#define BRL(i) ((int)__builtin_amdgcn_readlane((int)bv, (i) + Z))                 /* border entry i, the same for every lane */
+#define BRP(i) ((int)__builtin_amdgcn_ds_bpermute(((i) + Z) << 2, (int)bv))       /* border entry i, per lane */
         int v;
-        PREDICT_SAMPLE(v, x, y, dcVal);
-        const bool inb = lane < nT * nT;
-        if (has_res && inb) v = d_clip_bd(v + (DENSE ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (int)rv[0]), bd);
-        if (inb) body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;
-#undef BRD
+        if (cls == 0) {               /* planar (intrapred.h:261-285) */
+          const int l = BRP(-1 - y), t = BRP(1 + x), tr = BRL(1 + NT), bl = BRL(-1 - NT);
+          v = (__mul24(NT - 1 - x, l) + __mul24(x + 1, tr) + __mul24(NT - 1 - y, t) + __mul24(y + 1, bl) + NT) >> (LOG2 + 1);   /* (24-bit multiplies: full rate) */
+        } else if (cls == 1) {        /* DC (intrapred.h:288-310, 378-392) */
+          int s_ = (lane >= Z - NT && lane <= Z + NT && lane != Z) ? (int)bv : 0;
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0xB1, 0xF, 0xF, false);     /* quad_perm [1,0,3,2] */
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0x4E, 0xF, 0xF, false);     /* quad_perm [2,3,0,1] */
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0x141, 0xF, 0xF, false);    /* row_half_mirror */
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0x140, 0xF, 0xF, false);    /* row_mirror: every lane of a row of 16 holds the row's sum */
+          int sum = __builtin_amdgcn_readlane(s_, 0) + __builtin_amdgcn_readlane(s_, 16);
+          const int dc = (sum + NT) >> (LOG2 + 1);
+          v = dc;
+          if (bfilt) {
+            const int eb = BRP(y == 0 ? x + 1 : -y - 1), e2c = BRL(-1) + BRL(1);
+            if (x == 0 || y == 0) v = (eb + 3 * dc + 2) >> 2;
+            if (lane == 0) v = (e2c + 2 * dc + 2) >> 2;
+          }
+        } else if (cls == 2) {        /* pure horizontal / vertical (intrapred.h:330-433 with intraPredAngle 0) */
+          const int l = BRP(-1 - y), t = BRP(1 + x), corner = BRL(0), first = vert ? BRL(1) : BRL(-1);
+          v = vert ? t : l;
+          if (bfilt && (vert ? x == 0 : y == 0)) v = d_clip3(0, pix_max, first + (((vert ? l : t) - corner) >> 1));
+        } else {                      /* angular: ref[] of the reference is not built — its entry i is border entry sgn*i for i >= 0
+                                         and, left of the corner (negative angles only), -sgn*((i*invAngle+128)>>8) */
+          const int a_ = vert ? y : x, b_ = vert ? x : y;
+          const int tt = __mul24(a_ + 1, angle), iIdx = tt >> 5, iFact = tt & 31;
+          const int x1 = b_ + iIdx + 1, x2 = x1 + 1;
+          const int sgn = vert ? 1 : -1;
+          int i1, i2;
+          if (cls == 3) { i1 = vert ? x1 : -x1; i2 = i1 + sgn; }
+          else {
+            const int p1 = (__mul24(x1, inv) + 128) >> 8, p2 = (__mul24(x2, inv) + 128) >> 8;
+            i1 = x1 >= 0 ? x1 : -p1; i2 = x2 >= 0 ? x2 : -p2;
+            if (!vert) { i1 = -i1; i2 = -i2; }
+          }
+          const int r1 = BRP(i1), r2 = BRP(i2);
+          v = (32 * r1 + __mul24(iFact, r2 - r1) + 16) >> 5;   /* (= r1 when iFact is 0) */
+        }
+#undef BRL
+#undef BRP
+        if (has_res) v = d_clip3(0, pix_max, v + rs);
+        if (inb) body[(ly + y) * BODY_PITCH + lx + x + body_s0] = (uint16_t)v;
         /* ---- publish from the registers: a granule = two samples, the second one comes from the lane below / beside ---- */
         if (pub_col) {
-          const uint32_t v2 = (uint32_t)__shfl(v, (lane + nT) & 63, 64);
-          if (inb && x == nT - 1 && !(y & 1))
+          const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + NT) << 2, v);
+          if (inb && x == NT - 1 && !(y & 1))
             __hip_atomic_store(d_edge_col(p, cs, ctbX, y0c + ly + y), ((m355_granule)epoch << 32) | (v2 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (pub_row) {
-          const uint32_t v2 = (uint32_t)__shfl(v, (lane + 1) & 63, 64);
-          if (inb && y == nT - 1 && !(x & 1))
+          const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, v);
+          if (inb && y == NT - 1 && !(x & 1))
             __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + lx + x), ((m355_granule)epoch << 32) | (v2 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        published = true;
-      } else {
+      };
+
+      if (!(e0 & M355_IBX_PCM) && log2 == 2) small_block(std::integral_constant<int, 2>());
+      else if (!(e0 & M355_IBX_PCM) && log2 == 3) small_block(std::integral_constant<int, 3>());
+      else {
+      if (!(e0 & M355_IBX_PCM)) {
         /* ---- 16x16 / 32x32: the border lives in LDS (65 / 129 entries) ---- */
+        const int nEnt = 4 * nT + 1, Z = 2 * nT;
+        const uint16_t* pl = s_plan + ((e3 & 0xFFFFu) - plan_lo);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          if (64 * q >= nEnt) continue;              /* wave-uniform */
+          const int e = lane + 64 * q;
+          const uint32_t cd = e < nEnt ? (uint32_t)pl[e] : 0u;
+          uint32_t val = 0;
+          if (e < nEnt) val = body[cd];
+          const bool pending = e < nEnt && val == HALO_NOT_READY && cd >= (uint32_t)HALO_BASE && cd < (uint32_t)(HALO_BASE + HALO_N);
+          if (__any((int)pending))
+            val = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)cd - HALO_BASE, val, pending, x0c, y0c, epoch);
+          if (e < nEnt) raw[e] = (uint16_t)val;
+        }
+        wave_sync();
+        PROF_T(1);
+        /* residual of this block (sparse pictures: written by k_residual, its cache lines were requested in the prologue): the loads
+           are issued here, BEHIND the border gather, and consumed after smoothing, up to 16 samples per lane (32x32) */
+        int16_t rv[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int o = lane + 64 * q;
+          rv[q] = (!DENSE && has_res && o < nT * nT) ? p.resbuf[e1 + o] : (int16_t)0;
+        }
+        const int sgn = vert ? 1 : -1;
+        /* one sample (x, y) of the block from border taps BRD(i), i = -2nT .. 2nT (intrapred.h:261-433) */
+#define PREDICT_SAMPLE(v, x, y, dcVal)                                                                                              \
+        do {                                                                                                                        \
+          if (mode == 0) {                                                                                                          \
+            v = ((nT - 1 - (x)) * BRD(-1 - (y)) + ((x) + 1) * BRD(1 + nT) + (nT - 1 - (y)) * BRD(1 + (x)) + ((y) + 1) * BRD(-1 - nT) + nT) >> (log2 + 1); \
+          } else if (mode == 1) {                                                                                                   \
+            v = dcVal;                                                                                                              \
+            if (bfilt) {                                                                                                            \
+              const int e0_ = BRD(-1), e1_ = BRD(1), ex_ = BRD((x) + 1), ey_ = BRD(-(y) - 1);                                       \
+              if ((x) == 0 && (y) == 0) v = (e0_ + 2 * dcVal + e1_ + 2) >> 2;                                                       \
+              else if ((y) == 0) v = (ex_ + 3 * dcVal + 2) >> 2;                                                                    \
+              else if ((x) == 0) v = (ey_ + 3 * dcVal + 2) >> 2;                                                                    \
+            }                                                                                                                       \
+          } else {                                                                                                                  \
+            const int a_ = vert ? (y) : (x), b_ = vert ? (x) : (y);                                                                 \
+            const int iIdx_ = ((a_ + 1) * angle) >> 5, iFact_ = ((a_ + 1) * angle) & 31;                                            \
+            const int x1_ = b_ + iIdx_ + 1, x2_ = b_ + iIdx_ + 2;                                                                   \
+            const int r1_ = BRD(x1_ >= 0 ? sgn * x1_ : -sgn * ((x1_ * inv + 128) >> 8));                                            \
+            const int r2_ = BRD(x2_ >= 0 ? sgn * x2_ : -sgn * ((x2_ * inv + 128) >> 8));                                            \
+            v = iFact_ ? ((32 - iFact_) * r1_ + iFact_ * r2_ + 16) >> 5 : r1_;                                                      \
+            if (bfilt && cls == 2) {                                                                                                \
+              const int t0_ = BRD(0), t1_ = BRD(vert ? 1 : -1), t2_ = BRD(vert ? -1 - (y) : 1 + (x));                               \
+              if (vert ? (x) == 0 : (y) == 0) v = d_clip3(0, pix_max, t1_ + ((t2_ - t0_) >> 1));                                    \
+            }                                                                                                                       \
+          }                                                                                                                         \
+        } while (0)
         uint16_t* P = raw; /* border in use, entry index = i + 2nT */
-        if (f_filt) {     /* intra_prediction_sample_filtering (intrapred.h:185-258) */
-          const bool bi = f_strong && d_abs((int)raw[Z] + raw[Z + 64] - 2 * raw[Z + 32]) < thr_strong && d_abs((int)raw[Z] + raw[Z - 64] - 2 * raw[Z - 32]) < thr_strong;
+        if (e0 & M355_IBX_FILT) {     /* intra_prediction_sample_filtering (intrapred.h:185-258) */
+          const bool bi = (e0 & M355_IBX_STRONG) && d_abs((int)raw[Z] + raw[Z + 64] - 2 * raw[Z + 32]) < thr_strong && d_abs((int)raw[Z] + raw[Z - 64] - 2 * raw[Z - 32]) < thr_strong;
 #pragma unroll
           for (int q = 0; q < 3; q++) {
             if (64 * q >= nEnt) continue;
@@ -734,7 +745,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             const int y = o >> log2, x = o & (nT - 1);
             int v;
             PREDICT_SAMPLE(v, x, y, dcVal);
-            if (has_res) v = d_clip_bd(v + (int)resl[(ly + y) * RES_PITCH + lx + x], bd);
+            if (has_res) v = d_clip3(0, pix_max, v + (int)resl[(ly + y) * RES_PITCH + lx + x]);
             body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders; the picture is written at the end */
           }
         } else {
@@ -745,21 +756,20 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             const int y = o >> log2, x = o & (nT - 1);
             int v;
             PREDICT_SAMPLE(v, x, y, dcVal);
-            if (has_res) v = d_clip_bd(v + (int)rv[q], bd);
+            if (has_res) v = d_clip3(0, pix_max, v + (int)rv[q]);
             body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;
           }
         }
 #undef BRD
-      }
 #undef PREDICT_SAMPLE
       } else { /* raw block (slice.cc:4211-4255) */
         for (int o = lane; o < nT * nT; o += 64) {
-          const int y = o >> ib.log2_size, x = o & (nT - 1);
-          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = p.pcm[ib.res_ofs + o];
+          const int y = o >> log2, x = o & (nT - 1);
+          body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = p.pcm[e1 + o];
         }
       }
       /* ---- publish: the block's share of the CTB's right column / bottom row, two samples per granule ---- */
-      if (!published && (pub_col || pub_row)) {
+      if (pub_col || pub_row) {
         wave_sync();
         if (pub_col && lane < (nT >> 1)) {
           const int y = ly + 2 * lane;
@@ -772,6 +782,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
           __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + x), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      }   /* 16x16 / 32x32 / raw */
       PROF_T(2);
     }   /* this wave's blocks of the level */
     PROF_T(3);

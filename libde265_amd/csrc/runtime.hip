@@ -877,13 +877,14 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
  * of those samples (a superset of what the availability rules of intrapred.h:534-633 let it read); level = 1 + the
  * highest level among them.  Blocks of one level are independent: k_intra runs them concurrently on several waves with
  * a workgroup barrier between levels, instead of walking the CTB's blocks one by one.  `out` receives each CTB's blocks
- * sorted by (level, component), decode order kept inside; `aux` per sorted block: the offset of its border plan inside the
- * CTB's plans (k_intra_plan: 4nT + 1 entries per predicted block, none for a raw block), level, smoothing flags (M355_IBA_*); plan_count[ctb] =
+ * sorted by (level, component), decode order kept inside; `aux` per sorted block: its 4-word exec record (M355_IBX_*: geometry,
+ * mode parameters, smoothing / publish flags, offset of its border plan inside the CTB's plans — k_intra_plan: 4nT + 1 entries per
+ * predicted block, none for a raw block —, level); plan_count[ctb] =
  * the CTB's plan entries; log2_waves[ctb] = how wide the CTB's widest level is in luma blocks (0: 1, 1: 2, 2: 3-4,
  * 3: more) -> how many waves k_intra runs on it; *dense = intra picture (24 or more blocks per intra CTB on average).
  * Returns the first CTB whose intra blocks overlap (they never do in a picture the reference decodes: one
  * decode_intra_prediction per transform block; the LDS budgets of k_intra rest on it), or -1. */
-static int intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint32_t* aux, uint32_t* plan_count, uint8_t* log2_waves, int* dense)
+static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* out, uint32_t* aux, uint32_t* plan_count, uint8_t* log2_waves, int* dense)
 {
   const m355_pic_params& pp = pic->pp;
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
@@ -925,13 +926,38 @@ static int intra_schedule(const m355_picture* pic, int ctbW, m355_ib* out, uint3
       for (uint32_t k = 0; k < ctb.ib_count; k++) {
         const m355_ib& ib = pic->ibs[ctb.ib_start + key[k].second];
         out[ctb.ib_start + k] = ib;
-        uint32_t sm = 0;                                 /* which smoothing intra_prediction_sample_filtering (intrapred.h:185-258) will apply */
+        /* the block's EXEC RECORD for k_intra's chain (k_common.h M355_IBX_*): everything about the block that is not a sample
+           value, precomputed here so that no instruction between two dependent blocks has to derive it */
+        const int csw_ = ib.cidx ? (sw == 2) : 0, csh_ = ib.cidx ? (sh == 2) : 0;
+        const int cwc = (1 << pp.log2_ctb_size) >> csw_, chc = (1 << pp.log2_ctb_size) >> csh_, nT_ = 1 << ib.log2_size;
+        const int lx_ = ib.x - ((cx << pp.log2_ctb_size) >> csw_), ly_ = ib.y - ((cy << pp.log2_ctb_size) >> csh_);
+        uint32_t e0 = (uint32_t)(lx_ & 127) | ((uint32_t)(ly_ & 127) << 7) | ((uint32_t)(ib.log2_size & 7) << 14) | ((uint32_t)(ib.cidx & 3) << 17) | ((uint32_t)(ib.mode & 63) << 19);
+        if (ib.flags & M355_IBF_HAS_RESIDUAL) e0 |= M355_IBX_HAS_RES;
+        if (ib.flags & M355_IBF_PCM) e0 |= M355_IBX_PCM;
+        /* boundary smoothing of luma blocks < 32x32: DC always (intrapred.h:305), pure horizontal / vertical unless disabled (intrapred.h:378, 416, intrapred.cc:306-308) */
+        if (ib.cidx == 0 && ib.log2_size < 5 && (ib.mode == 1 || !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER))) e0 |= M355_IBX_BFILT;
+        if (lx_ + nT_ == cwc && cx + 1 < ctbW) e0 |= M355_IBX_PUB_COL;
+        if (ly_ + nT_ == chc && cy + 1 < ctbH) e0 |= M355_IBX_PUB_ROW;
+        /* which smoothing intra_prediction_sample_filtering (intrapred.h:185-258) will apply */
         if (!(ib.flags & M355_IBF_PCM) && !(pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (ib.cidx == 0 || pp.chroma_format_idc == 3) && ib.mode != 1 && ib.log2_size != 2) {
           const int minDist = std::min(abs((int)ib.mode - 26), abs((int)ib.mode - 10));
           const bool filt = ib.log2_size == 3 ? minDist > 7 : (ib.log2_size == 4 ? minDist > 1 : (ib.log2_size == 5 ? minDist > 0 : false));
-          if (filt) sm = M355_IBA_FILT | (((pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) && ib.cidx == 0 && ib.log2_size == 5) ? M355_IBA_STRONG : 0u);
+          if (filt) e0 |= M355_IBX_FILT | (((pp.flags & M355_PF_STRONG_INTRA_SMOOTHING) && ib.cidx == 0 && ib.log2_size == 5) ? M355_IBX_STRONG : 0u);
         }
-        aux[ctb.ib_start + k] = (rel & 0xFFFFu) | (((key[k].first >> 2) & 0x3FFFu) << 16) | sm;
+        /* intraPredAngle / invAngle of the mode (intrapred.h:313-326, intrapred.cc:268-274) */
+        int angle = 0, inv = 0;
+        if (ib.mode >= 2 && ib.mode <= 34) {
+          static const int8_t mag[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+          static const int16_t invm[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+          const int d = ib.mode >= 18 ? abs((int)ib.mode - 26) : abs((int)ib.mode - 10);
+          const bool neg = ib.mode >= 18 ? ib.mode < 26 : ib.mode > 10;
+          angle = neg ? -mag[d] : mag[d];
+          inv = angle < 0 ? -invm[d] : 0;
+        }
+        uint32_t* ex = aux + 4 * (size_t)(ctb.ib_start + k);
+        const uint32_t cls = ib.mode == 0 ? 0u : (ib.mode == 1 ? 1u : (angle == 0 ? 2u : (angle > 0 ? 3u : 4u)));   /* planar, DC, pure H/V, angular +/- */
+        ex[0] = e0; ex[1] = ib.res_ofs; ex[2] = ((uint32_t)(uint16_t)(int16_t)inv << 16) | (cls << 8) | (uint32_t)(uint8_t)(int8_t)angle;
+        ex[3] = (rel & 0xFFFFu) | (((key[k].first >> 2) & 0x3FFFu) << 16);
         if (!(ib.flags & M355_IBF_PCM) && ib.log2_size >= 2 && ib.log2_size <= 5) rel += (4u << ib.log2_size) + 1u;
         run = (k && key[k].first == key[k - 1].first) ? run + 1 : 1;
         if ((key[k].first & 3) == 0) widest = std::max(widest, run);      /* luma blocks of one level */
@@ -999,7 +1025,7 @@ static void make_layout(const m355_arena_caps& k, int nCtb, int halo_units, bool
   for (int b = 0; b < 4; b++) L.i_rb[b] = add(sizeof(m355_rb) * (size_t)k.n_rbs[b]);
   L.i_ibin = add(with_ib_input ? sizeof(m355_ib) * (size_t)k.n_ibs : 0);   /* in place: the caller's blocks in decode order (host only) */
   L.i_ib = add(sizeof(m355_ib) * (size_t)k.n_ibs);      /* each CTB's blocks sorted by dependency level */
-  L.i_il = add(4 * (size_t)k.n_ibs);                    /* ib_aux: plan offset | level << 16 */
+  L.i_il = add(16 * (size_t)k.n_ibs);                   /* ib_aux: one exec record (4 words) per block */
   L.i_co = add(4 * (size_t)k.n_coeffs);
   L.i_pc = add(2 * (size_t)k.n_pcm);
   L.i_sc = add(k.scaling ? 6 * (16 + 64 + 256 + 1024) : 0);
@@ -1064,7 +1090,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     srcs[i_pb] = pic->pbs; used[i_pb] = sizeof(m355_pb) * (size_t)pic->n_pbs;
     srcs[i_wt] = pic->wts; used[i_wt] = sizeof(m355_wt) * (size_t)pic->n_wts;
     for (int b = 0; b < 4; b++) { srcs[L.i_rb[b]] = pic->rbs + rb_o; used[L.i_rb[b]] = sizeof(m355_rb) * (size_t)pic->rb_count[b]; rb_o += (size_t)pic->rb_count[b]; }
-    used[i_ib] = sizeof(m355_ib) * (size_t)pic->n_ibs; used[i_il] = 4 * (size_t)pic->n_ibs;
+    used[i_ib] = sizeof(m355_ib) * (size_t)pic->n_ibs; used[i_il] = 16 * (size_t)pic->n_ibs;
     srcs[i_co] = pic->coeffs; used[i_co] = 4 * (size_t)pic->n_coeffs;
     srcs[i_pc] = pic->pcm; used[i_pc] = 2 * (size_t)pic->n_pcm;
     srcs[i_sc] = pic->scaling_factors; used[i_sc] = pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0;
@@ -1107,7 +1133,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   int intra_dense = 0;
   std::vector<uint32_t> plan_count((size_t)nCtb, 0);
   {
-    const int bad = intra_schedule(pic, ctbW, (m355_ib*)(r.host + seg[i_ib].ofs), (uint32_t*)(r.host + seg[i_il].ofs), plan_count.data(), log2_waves.data(), &intra_dense);
+    const int bad = intra_schedule(pic, ctbW, ctbH, (m355_ib*)(r.host + seg[i_ib].ofs), (uint32_t*)(r.host + seg[i_il].ofs), plan_count.data(), log2_waves.data(), &intra_dense);
     if (bad >= 0) return fail(M355_ERR_INVALID, "ctb %d: intra blocks overlap", bad);
     const uint32_t cap = (uint32_t)M355_INTRA_PLAN_CAP(pp.chroma_format_idc);
     for (int i = 0; i < nCtb; i++) if (plan_count[(size_t)i] > cap) return fail(M355_ERR_INVALID, "ctb %d: more intra blocks than a CTB holds", i);

@@ -199,6 +199,25 @@ template <class T> static inline T __builtin_amdgcn_readfirstlane(T v)
 
 template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return simt_exchange(v, lane & 63); }
 
+/* ds_bpermute_b32: lane i reads `v` of lane (addr / 4) & 63 */
+static inline int __builtin_amdgcn_ds_bpermute(int addr, int v) { return simt_exchange(v, (addr >> 2) & 63); }
+/* v_mov_b32 dpp (all lanes of the wave active, row / bank masks 0xF): the controls the kernels use */
+static inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+  (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+  const int lane = simt::lane_id();
+  int src = lane;
+  bool valid = true;
+  if (ctrl < 0x100) src = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);        /* quad_perm */
+  else if (ctrl == 0x130) { src = lane + 1; valid = src < 64; }                    /* wave_shl:1 */
+  else if (ctrl == 0x138) { src = lane - 1; valid = src >= 0; }                    /* wave_shr:1 */
+  else if (ctrl == 0x140) src = (lane & ~15) | (15 - (lane & 15));                 /* row_mirror */
+  else if (ctrl == 0x141) src = (lane & ~7) | (7 - (lane & 7));                    /* row_half_mirror */
+  else abort();
+  const int got = simt_exchange(v, valid ? src : lane);
+  return valid ? got : old;
+}
+
 /* atomics: one OS thread, fibers switch only at rendezvous points */
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
