@@ -15,6 +15,10 @@ __device__ __forceinline__ void d_drain_vmem() { asm volatile("s_waitcnt vmcnt(0
 __device__ __forceinline__ void d_st_nt4(void* p, unsigned v) { __builtin_nontemporal_store(v, (unsigned*)p); }
 __device__ __forceinline__ void d_st_nt8(void* p, unsigned v0, unsigned v1) { __builtin_nontemporal_store(v0, (unsigned*)p); __builtin_nontemporal_store(v1, (unsigned*)p + 1); }
 
+/* keep a wave-uniform value in a scalar register, computed HERE (k_intra decodes its next block's record before the level barrier,
+ * not at the first use behind it) */
+#define M355_PIN_S(x) asm volatile("" : "+s"(x))
+
 /* spin bound of k_intra's granule polls: ~2^22 polls x (one L2 round trip + s_sleep) is seconds — far beyond any real wait */
 #define M355_SPIN_LIMIT (1u << 22)
 

@@ -303,6 +303,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     constexpr int GLMAX = NW >= 12 ? 8 : (NW >= 6 ? 4 : 2), GCMAX = (NW - GLMAX) / 2 >= 2 ? 2 : 1;
     GL = min(GLMAX, code == 0 ? 1 : (code == 1 ? 2 : (code == 2 ? 4 : 8)));
     GC = code == 3 ? GCMAX : 1;
+    /* intra pictures: never fewer than two waves per component — a component's blocks go round its waves (below), so that
+       a wave prepares its next block while another one predicts the current level's */
+    if (DENSE) { GL = max(GL, 2); GC = GCMAX; }
   }
   const bool spare = wv >= GL + 2 * GC;
   if (spare && !DENSE) return;
@@ -506,7 +509,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      block is predicted, a 4x4 / 8x8 block's border, smoothing and taps live in registers (cross-lane reads), its arithmetic is
      specialised by size (compile time) and mode class (one scalar branch). */
   const int thr_strong = 1 << (p.pp.bit_depth_luma - 5);
-  const int body_s0 = BODY_X0, pix_max = (1 << bd) - 1;
+  const int pix_max = (1 << bd) - 1;
+  /* a lane's sample of a 4x4 / 8x8 block, relative to the block's first sample in the body / residual tile */
+  const int lofs_b4 = (lane >> 2) * BODY_PITCH + (lane & 3), lofs_b8 = (lane >> 3) * BODY_PITCH + (lane & 7);
+  const int lofs_r4 = (lane >> 2) * RES_PITCH + (lane & 3), lofs_r8 = (lane >> 3) * RES_PITCH + (lane & 7);
+  int taken = 0;                                           /* blocks of this wave's component in earlier batches */
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
     uint4 ex = make_uint4(0, 0, 0, 0);
     int lv = -1;
@@ -532,26 +539,37 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     const int lv_first = __builtin_amdgcn_readlane(lv, 0), lv_last = __builtin_amdgcn_readlane(lv, nvalid - 1);
     unsigned long long mine;
     {
-      /* the records of one (level, component) group sit in consecutive lanes: rank in the group = lane - first lane of the group */
-      const uint32_t key = lane < nvalid ? (((uint32_t)lv << 2) | ((ex.x >> 17) & 3u)) : 0xFFFFFFFFu;
-      const uint32_t prevk = __shfl_up(key, 1u, 64);
-      const unsigned long long heads = __ballot((int)(lane == 0 || key != prevk));
-      const int start = 63 - __clzll(heads & ((2ull << lane) - 1ull));
-      mine = __ballot((int)(comp && lane < nvalid && ((ex.x >> 17) & 3u) == (uint32_t)c && (((lane - start) & (G - 1)) == g)));
+      /* a component's blocks go ROUND ITS WAVES in record order (level by level): consecutive levels of a dependency chain fall
+         to different waves, so the wave that predicts level L is not the one that has to fetch and decode the record of level
+         L + 1 — that wave did so while the others worked (after the barrier of ITS last block), and what is left between two
+         barriers of the chain is border read -> taps -> arithmetic -> sample write */
+      const unsigned long long same = __ballot((int)(comp && lane < nvalid && ((ex.x >> 17) & 3u) == (uint32_t)c));
+      const int rank = taken + __popcll(same & ((1ull << lane) - 1ull));
+      mine = same & __ballot((int)((rank & (G - 1)) == g));
+      taken += __popcll(same);
     }
-    /* the wave's NEXT block: which record, its level, and (4x4 / 8x8) the plan entries of its border, entry e in lane e */
+    /* the wave's NEXT block, decoded: record words, offsets of its first sample in the body / residual tiles, mode parameters,
+       and (4x4 / 8x8) the plan entries of its border, entry e in lane e */
     int nsrc = -1, nlevel = -1;
-    uint32_t ncode = 0;
+    uint32_t e0 = 0, e1 = 0, e3 = 0, ncode = 0;
+    int d_bofs = 0, d_rofs = 0, d_angle = 0, d_inv = 0, d_cls = 0, d_log2 = 0;
     auto fetch_next = [&]() {
       nsrc = mine ? __ffsll(mine) - 1 : -1;
       mine &= mine - 1;
       if (nsrc < 0) return;
-      const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)ex.x, nsrc), n3 = (uint32_t)__builtin_amdgcn_readlane((int)ex.w, nsrc);
-      nlevel = (int)((n3 >> 16) & 0x3FFFu);
-      const int nl2 = (int)((n0 >> 14) & 7u);
-      if (nl2 <= 3 && !(n0 & M355_IBX_PCM)) ncode = s_plan[((n3 & 0xFFFFu) - plan_lo) + (uint32_t)min(lane, 4 << nl2)];
+      e0 = (uint32_t)__builtin_amdgcn_readlane((int)ex.x, nsrc); e1 = (uint32_t)__builtin_amdgcn_readlane((int)ex.y, nsrc);
+      const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)ex.z, nsrc);
+      e3 = (uint32_t)__builtin_amdgcn_readlane((int)ex.w, nsrc);
+      nlevel = (int)((e3 >> 16) & 0x3FFFu);
+      d_log2 = (int)((e0 >> 14) & 7u);
+      const int lx = (int)(e0 & 127u), ly = (int)((e0 >> 7) & 127u);
+      d_bofs = ly * BODY_PITCH + lx + BODY_X0; d_rofs = ly * RES_PITCH + lx;
+      d_cls = (int)((e2 >> 8) & 7u); d_angle = (int)(int8_t)(e2 & 0xFFu); d_inv = (int)(int16_t)(e2 >> 16);
+      if (d_log2 <= 3 && !(e0 & M355_IBX_PCM)) ncode = s_plan[((e3 & 0xFFFFu) - plan_lo) + (uint32_t)min(lane, 4 << d_log2)];
+      M355_PIN_S(d_bofs); M355_PIN_S(d_rofs); M355_PIN_S(d_cls); M355_PIN_S(d_angle); M355_PIN_S(d_inv); M355_PIN_S(d_log2); M355_PIN_S(nlevel);
     };
     fetch_next();
+    bool pend = false;                                       /* the next block is still to be fetched (done behind the barrier) */
 #ifdef M355_X_PROF
 #define PROF_T(k) do { if (prof_on) pt[k] = __builtin_readcyclecounter(); } while (0)
     const bool prof_on = p.prof != nullptr && item == M355_X_PROF && wv == 0;
@@ -562,17 +580,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #endif
     for (int L = lv_first; L <= lv_last; L++) {
     PROF_T(0);
+    if (pend) { fetch_next(); pend = false; }
     while (nsrc >= 0 && nlevel == L) {
-      const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ex.x, nsrc), e1 = (uint32_t)__builtin_amdgcn_readlane((int)ex.y, nsrc);
-      const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)ex.z, nsrc), e3 = (uint32_t)__builtin_amdgcn_readlane((int)ex.w, nsrc);
       const uint32_t code0 = ncode;
-      fetch_next();                                          /* the block after this one: its plan reads run beside this block's */
-      const int lx = (int)(e0 & 127u), ly = (int)((e0 >> 7) & 127u), log2 = (int)((e0 >> 14) & 7u), nT = 1 << log2;
-      const int mode = (int)((e0 >> 19) & 63u), cls = (int)((e2 >> 8) & 7u);
-      const int angle = (int)(int8_t)(e2 & 0xFFu), inv = (int)(int16_t)(e2 >> 16);
+      const int log2 = d_log2, nT = 1 << log2, cls = d_cls, angle = d_angle, inv = d_inv;
+      const int mode = (int)((e0 >> 19) & 63u);
       const bool vert = mode >= 18;
       const bool has_res = (e0 & M355_IBX_HAS_RES) != 0, bfilt = (e0 & M355_IBX_BFILT) != 0;
       const bool pub_col = (e0 & M355_IBX_PUB_COL) != 0, pub_row = (e0 & M355_IBX_PUB_ROW) != 0;
+      const int lx = (int)(e0 & 127u), ly = (int)((e0 >> 7) & 127u);      /* (used by the 16x16 / 32x32 / raw paths and by publishing) */
 
       /* ---- 4x4 / 8x8 (the chain of an intra picture): border entry e in lane e of ONE register, one sample per lane; every
          lane runs the arithmetic (a cross-lane read needs its source lane active), lanes beyond the block do not store ---- */
@@ -582,7 +598,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const bool inb = lane < NT * NT;
         uint32_t bv = body[code0];                           /* fill_from_image + substitution (intrapred.h:534-665) resolved by k_intra_plan */
         int rs = 0;
-        if (has_res) rs = DENSE ? (int)resl[(ly + y) * RES_PITCH + lx + x] : (inb ? (int)p.resbuf[e1 + lane] : 0);
+        if (has_res) rs = DENSE ? (int)resl[d_rofs + (LOG2 == 2 ? lofs_r4 : lofs_r8)] : (inb ? (int)p.resbuf[e1 + lane] : 0);
         if (__any((int)(bv == HALO_NOT_READY))) {
           /* a halo sample its CTB has not published yet: poll its granule */
           const bool pending = bv == HALO_NOT_READY && code0 >= (uint32_t)HALO_BASE && code0 < (uint32_t)(HALO_BASE + HALO_N);
@@ -637,7 +653,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #undef BRL
 #undef BRP
         if (has_res) v = d_clip3(0, pix_max, v + rs);
-        if (inb) body[(ly + y) * BODY_PITCH + lx + x + body_s0] = (uint16_t)v;
+        if (inb) body[d_bofs + (LOG2 == 2 ? lofs_b4 : lofs_b8)] = (uint16_t)v;
         /* ---- publish from the registers: a granule = two samples, the second one comes from the lane below / beside ---- */
         if (pub_col) {
           const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + NT) << 2, v);
@@ -658,17 +674,32 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         /* ---- 16x16 / 32x32: the border lives in LDS (65 / 129 entries) ---- */
         const int nEnt = 4 * nT + 1, Z = 2 * nT;
         const uint16_t* pl = s_plan + ((e3 & 0xFFFFu) - plan_lo);
+        /* (all plan entries, then all samples: two LDS round trips for the whole border, not two per 64-entry chunk) */
+        uint32_t cd[3] = {0, 0, 0}, val[3] = {0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           if (64 * q >= nEnt) continue;              /* wave-uniform */
           const int e = lane + 64 * q;
-          const uint32_t cd = e < nEnt ? (uint32_t)pl[e] : 0u;
-          uint32_t val = 0;
-          if (e < nEnt) val = body[cd];
-          const bool pending = e < nEnt && val == HALO_NOT_READY && cd >= (uint32_t)HALO_BASE && cd < (uint32_t)(HALO_BASE + HALO_N);
-          if (__any((int)pending))
-            val = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)cd - HALO_BASE, val, pending, x0c, y0c, epoch);
-          if (e < nEnt) raw[e] = (uint16_t)val;
+          if (e < nEnt) cd[q] = (uint32_t)pl[e];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          if (64 * q >= nEnt) continue;
+          if (lane + 64 * q < nEnt) val[q] = body[cd[q]];
+        }
+        if (__any((int)(val[0] == HALO_NOT_READY || val[1] == HALO_NOT_READY || val[2] == HALO_NOT_READY))) {
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            if (64 * q >= nEnt) continue;
+            const bool pending = lane + 64 * q < nEnt && val[q] == HALO_NOT_READY && cd[q] >= (uint32_t)HALO_BASE && cd[q] < (uint32_t)(HALO_BASE + HALO_N);
+            if (__any((int)pending))
+              val[q] = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)cd[q] - HALO_BASE, val[q], pending, x0c, y0c, epoch);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          if (64 * q >= nEnt) continue;
+          if (lane + 64 * q < nEnt) raw[lane + 64 * q] = (uint16_t)val[q];
         }
         wave_sync();
         PROF_T(1);
@@ -734,20 +765,74 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         if (mode == 1) {
           int s_ = 0;
           if (lane < nT) s_ = BRD(lane + 1) + BRD(-lane - 1);
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m, 64);
-          dcVal = (s_ + nT) >> (log2 + 1);
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0xB1, 0xF, 0xF, false);     /* sums over rows of 16 lanes, as in the 4x4 / 8x8 path */
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0x4E, 0xF, 0xF, false);
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0x141, 0xF, 0xF, false);
+          s_ += __builtin_amdgcn_update_dpp(0, s_, 0x140, 0xF, 0xF, false);
+          dcVal = (__builtin_amdgcn_readlane(s_, 0) + __builtin_amdgcn_readlane(s_, 16) + nT) >> (log2 + 1);
         }
         if (DENSE) {
-          /* (a loop, not 16 unrolled copies: the chain of an intra picture should sit in the instruction cache) */
-#pragma unroll 1
-          for (int o = lane; o < nT * nT; o += 64) {
-            const int y = o >> log2, x = o & (nT - 1);
-            int v;
-            PREDICT_SAMPLE(v, x, y, dcVal);
-            if (has_res) v = d_clip3(0, pix_max, v + (int)resl[(ly + y) * RES_PITCH + lx + x]);
-            body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;     /* for the next blocks' borders; the picture is written at the end */
-          }
+          /* one loop per mode class, FOUR samples per lane in flight: their border taps and residuals are requested together (one
+             LDS round trip per four samples, not two per sample), then the four are computed and stored */
+          const int xb = lane & (nT - 1), yb = lane >> log2, ystep = 64 >> log2, nIt = (nT * nT) >> 6;
+          const int res_on = has_res ? -1 : 0;
+          auto big_loop = [&](auto cls_) {
+            constexpr int CLS = decltype(cls_)::value;
+            const int x = xb;
+            /* what does not depend on the row */
+            const int t_x = (CLS == 0 || CLS == 2) ? BRD(1 + x) : 0;
+            const int u_tr = CLS == 0 ? BRD(1 + nT) : 0, u_bl = CLS == 0 ? BRD(-1 - nT) : 0;
+            const int u_c = CLS == 2 ? BRD(0) : 0, u_f = CLS == 2 ? (vert ? BRD(1) : BRD(-1)) : 0;
+            const int u_e2 = CLS == 1 ? BRD(-1) + BRD(1) : 0;
+            for (int it0 = 0; it0 < nIt; it0 += 4) {
+              int ta[4], tb[4], fa[4], rs[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int y = yb + (it0 + u) * ystep;
+                fa[u] = 0; tb[u] = 0;
+                if (CLS == 0 || CLS == 2) ta[u] = BRD(-1 - y);
+                else if (CLS == 1) ta[u] = BRD(y == 0 ? x + 1 : -y - 1);
+                else {
+                  const int a_ = vert ? y : x, b_ = vert ? x : y;
+                  const int tt = __mul24(a_ + 1, angle), iIdx = tt >> 5;
+                  fa[u] = tt & 31;
+                  const int x1 = b_ + iIdx + 1, x2 = x1 + 1;
+                  int i1, i2;
+                  if (CLS == 3) { i1 = vert ? x1 : -x1; i2 = vert ? x2 : -x2; }
+                  else {
+                    const int p1 = (__mul24(x1, inv) + 128) >> 8, p2 = (__mul24(x2, inv) + 128) >> 8;
+                    i1 = x1 >= 0 ? x1 : -p1; i2 = x2 >= 0 ? x2 : -p2;
+                    if (!vert) { i1 = -i1; i2 = -i2; }
+                  }
+                  ta[u] = BRD(i1); tb[u] = BRD(fa[u] ? i2 : i1);   /* (no read beyond the border when the second tap has weight 0) */
+                }
+                rs[u] = (int)resl[d_rofs + y * RES_PITCH + x] & res_on;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int y = yb + (it0 + u) * ystep;
+                int v;
+                if (CLS == 0) v = (__mul24(nT - 1 - x, ta[u]) + __mul24(x + 1, u_tr) + __mul24(nT - 1 - y, t_x) + __mul24(y + 1, u_bl) + nT) >> (log2 + 1);
+                else if (CLS == 1) {
+                  v = dcVal;
+                  if (bfilt) {
+                    if (x == 0 || y == 0) v = (ta[u] + 3 * dcVal + 2) >> 2;
+                    if (x == 0 && y == 0) v = (u_e2 + 2 * dcVal + 2) >> 2;
+                  }
+                } else if (CLS == 2) {
+                  v = vert ? t_x : ta[u];
+                  if (bfilt && (vert ? x == 0 : y == 0)) v = d_clip3(0, pix_max, u_f + (((vert ? ta[u] : t_x) - u_c) >> 1));
+                } else v = (32 * ta[u] + __mul24(fa[u], tb[u] - ta[u]) + 16) >> 5;
+                v = d_clip3(0, pix_max, v + rs[u]);          /* (a prediction is inside the sample range: no-op without a residual) */
+                body[d_bofs + y * BODY_PITCH + x] = (uint16_t)v;         /* for the next blocks' borders; the picture is written at the end */
+              }
+            }
+          };
+          if (cls == 0) big_loop(std::integral_constant<int, 0>());
+          else if (cls == 1) big_loop(std::integral_constant<int, 1>());
+          else if (cls == 2) big_loop(std::integral_constant<int, 2>());
+          else if (cls == 3) big_loop(std::integral_constant<int, 3>());
+          else big_loop(std::integral_constant<int, 4>());
         } else {
 #pragma unroll
           for (int q = 0; q < 16; q++) {
@@ -784,6 +869,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       }
       }   /* 16x16 / 32x32 / raw */
       PROF_T(2);
+      /* another block of this level?  Else go to the barrier first: the next record is fetched behind it */
+      const int peek = mine ? __builtin_amdgcn_readlane(lv, __ffsll(mine) - 1) : -1;
+      if (peek != L) { pend = true; break; }
+      fetch_next();
     }   /* this wave's blocks of the level */
     PROF_T(3);
     SYNC_CTB();
