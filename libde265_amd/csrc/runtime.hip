@@ -881,7 +881,8 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
  * mode parameters, smoothing / publish flags, offset of its border plan inside the CTB's plans — k_intra_plan: 4nT + 1 entries per
  * predicted block, none for a raw block —, level); plan_count[ctb] =
  * the CTB's plan entries; log2_waves[ctb] = how wide the CTB's widest level is in luma blocks (0: 1, 1: 2, 2: 3-4,
- * 3: more) -> how many waves k_intra runs on it; *dense = intra picture (24 or more blocks per intra CTB on average).
+ * 3: more) -> how many waves k_intra runs on it; *dense = intra picture (8 or more intra blocks per CTB of the
+ * picture on average: an I picture of 64x64 CUs has 12, the inter pictures of the bench 3.4).
  * Returns the first CTB whose intra blocks overlap (they never do in a picture the reference decodes: one
  * decode_intra_prediction per transform block; the LDS budgets of k_intra rest on it), or -1. */
 static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* out, uint32_t* aux, uint32_t* plan_count, uint8_t* log2_waves, int* dense)
@@ -967,7 +968,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
     }
     n_blocks += my_blocks; n_intra_ctbs += my_ctbs;
   });
-  *dense = (n_intra_ctbs.load() && n_blocks.load() / n_intra_ctbs.load() >= 24) ? 1 : 0;
+  *dense = (n_intra_ctbs.load() && n_blocks.load() >= 8 * (long)ctbW * ctbH) ? 1 : 0;
   return overlap.load();
 }
 
