@@ -201,16 +201,16 @@ static void select_lane(m355_ctx* c, int lane)
 }
 /* The HIP runtime multiplexes its streams onto a few hardware queues PER STREAM PRIORITY (GPU_MAX_HW_QUEUES, default 4), and
  * kernels of different streams that share a hardware queue mostly run one after the other.  Three lanes (six streams) do well on
- * the default priority's queues; every further group of three lanes takes the next priority class, i.e. its own hardware queues
- * (measured, profiles/r03_z_*: all-intra 1080p, depth 4: 1.02 -> 0.66 ms per picture, depth 8: 0.98 -> 0.59; raising
- * GPU_MAX_HW_QUEUES to 16 instead gives 0.41 at depth 8 but slows the inter pictures' short kernels down by 15-75 %, so it is
- * left to the application).  M355_LANE_PRIORITIES=0 keeps every lane at the default priority. */
+ * the default priority's queues.  M355_LANE_PRIORITIES=1 gives every further group of three lanes the next priority class, i.e.
+ * its own hardware queues: measured (profiles/r03_z_*, r03_g_*) it helps all-intra pictures beyond depth 3 (1080p: depth 4 1.02 ->
+ * 0.66 ms per picture, depth 8 0.98 -> 0.59; GPU_MAX_HW_QUEUES=16 without classes: 0.41 at depth 8) and costs inter pictures 7 %
+ * at depth 4 (8K: 0.436 -> 0.466), as every queue beyond the first few does — so it is off unless asked for. */
 static int lane_priority(int index)
 {
   static int lo = 0, hi = 0, probed = 0;
   if (!probed) { probed = 1; if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0; }   /* (least, greatest) */
   const char* e = getenv("M355_LANE_PRIORITIES");
-  if (e && atoi(e) == 0) return 0;
+  if (!e || atoi(e) == 0) return 0;
   const int cls = (index / 3) % 3;
   return cls == 0 ? 0 : (cls == 1 ? hi : lo);
 }
@@ -906,7 +906,8 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
   std::atomic<long long> n_blocks(0), n_intra_ctbs(0);
   std::atomic<int> overlap(-1);
-  parallel_ranges((size_t)pic->n_ctbs, 256, [&](size_t cb, size_t ce) {
+  /* (an intra picture has hundreds of blocks per CTB: smaller shares, so that a 1080p picture's 510 CTBs still use the whole pool) */
+  parallel_ranges((size_t)pic->n_ctbs, (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs ? 16 : 256, [&](size_t cb, size_t ce) {
     std::vector<std::pair<uint32_t, uint32_t>> key;      /* (level << 2 | cidx, index) */
     long long my_blocks = 0, my_ctbs = 0;
     for (size_t c = cb; c < ce; c++) {
