@@ -287,6 +287,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     item = __builtin_amdgcn_readfirstlane((int)s_ticket);
   }
   if (item >= work_n) return;
+#ifdef M355_X_PROF      /* experiment builds (tools/prof_timeline.py): when a CTB was claimed, started its block loop, ended it, was written out */
+#define TL(k) do { if (p.prof && threadIdx.x == 0 && item < 1600) p.prof[8200 + 5 * item + 1 + (k)] = wall_clock64(); } while (0)
+#else
+#define TL(k) do { } while (0)
+#endif
+  TL(0);
   /* the CTB's descriptor (host-prepared, runtime.hip): one scalar 32-byte load */
   const DevIntraWork* wp = p.intra_work + item;
   const uint4 wd0 = *(const uint4*)wp;
@@ -500,6 +506,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     }
   }
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
+  TL(1);
+#ifdef M355_X_PROF
+  if (p.prof && threadIdx.x == 0 && item < 1600) p.prof[8200 + 5 * item] = (unsigned long long)ctb + 1;
+#endif
   /* The CTB's exec records (runtime.hip intra_schedule: sorted by level, then component; everything about a block that is not a
      sample value) are fetched 64 at a time (one per lane, 16 bytes, coalesced) by EVERY wave.  A wave's blocks of the batch —
      those of its component whose rank inside their (level, component) group falls to it — are one 64-bit mask; it walks them
@@ -572,7 +582,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     bool pend = false;                                       /* the next block is still to be fetched (done behind the barrier) */
 #ifdef M355_X_PROF
 #define PROF_T(k) do { if (prof_on) pt[k] = __builtin_readcyclecounter(); } while (0)
-    const bool prof_on = p.prof != nullptr && item == M355_X_PROF && wv == 0;
+#ifndef M355_X_PROF_WAVE
+#define M355_X_PROF_WAVE 0
+#endif
+    const bool prof_on = p.prof != nullptr && item == M355_X_PROF && wv == M355_X_PROF_WAVE;
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
     if (prof_on && kbase == 0 && lane == 0) { p.prof[0] = __builtin_readcyclecounter(); p.prof[1] = wall_clock64(); }
 #else
@@ -890,6 +903,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
        by the wave-level sync; components do not interact) */
     }   /* levels in the batch */
   }   /* 64-record batches */
+  TL(2);
   /* ---- the CTB's intra samples -> the picture: every 4x4 unit some intra block covered (s_cover), one 4-sample row piece per
      lane, neighbouring lanes on neighbouring pieces of a row (the last level's barrier / wave_sync made them all visible) ---- */
   if (comp) {
@@ -904,6 +918,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       else *(uint32_t*)dst = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y & 0xFF0000u) << 8);
     }
   }
+  TL(3);
   if (!DENSE) return;
   __syncthreads();     /* the LDS tiles (and the ticket word) are free for the workgroup's next CTB */
   }   /* persistent workgroup: next CTB */
