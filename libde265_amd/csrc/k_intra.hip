@@ -611,7 +611,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const bool inb = lane < NT * NT;
         uint32_t bv = body[code0];                           /* fill_from_image + substitution (intrapred.h:534-665) resolved by k_intra_plan */
         int rs = 0;
-        if (has_res) rs = DENSE ? (int)resl[d_rofs + (LOG2 == 2 ? lofs_r4 : lofs_r8)] : (inb ? (int)p.resbuf[e1 + lane] : 0);
+        /* (branch-free where it is cheap: a taken branch costs a lone wave more than the few instructions it skips) */
+        if (DENSE) rs = (int)resl[d_rofs + (LOG2 == 2 ? lofs_r4 : lofs_r8)] & (has_res ? -1 : 0);
+        else if (has_res) rs = inb ? (int)p.resbuf[e1 + lane] : 0;
         if (__any((int)(bv == HALO_NOT_READY))) {
           /* a halo sample its CTB has not published yet: poll its granule */
           const bool pending = bv == HALO_NOT_READY && code0 >= (uint32_t)HALO_BASE && code0 < (uint32_t)(HALO_BASE + HALO_N);
@@ -619,9 +621,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             bv = d_poll_halo(d_edge_row(p, cs, ctbY - 1, 0), d_edge_col(p, cs, ctbX - 1, 0), p.timeout, halo, (int)code0 - HALO_BASE, bv, pending, x0c, y0c, epoch);
         }
         PROF_T(1);
-        if (e0 & M355_IBX_FILT) {   /* intra_prediction_sample_filtering (intrapred.h:185-258), [1 2 1] only (strong smoothing is 32x32) */
+        {   /* intra_prediction_sample_filtering (intrapred.h:185-258), [1 2 1] only (strong smoothing is 32x32) */
           const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv, 0x138, 0xF, 0xF, false) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv, 0x130, 0xF, 0xF, false);
-          if (lane > 0 && lane < NENT - 1) bv = (nb + 2u * bv + 2u) >> 2;
+          const uint32_t fbv = (nb + 2u * bv + 2u) >> 2;
+          if ((e0 & M355_IBX_FILT) && lane > 0 && lane < NENT - 1) bv = fbv;
         }
 #define BRL(i) ((int)__builtin_amdgcn_readlane((int)bv, (i) + Z))                 /* border entry i, the same for every lane */
 #define BRP(i) ((int)__builtin_amdgcn_ds_bpermute(((i) + Z) << 2, (int)bv))       /* border entry i, per lane */
@@ -665,9 +668,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
 #undef BRL
 #undef BRP
-        if (has_res) v = d_clip3(0, pix_max, v + rs);
+        if (DENSE || has_res) v = d_clip3(0, pix_max, v + rs);   /* (a prediction is inside the sample range: no-op without a residual) */
         if (inb) body[d_bofs + (LOG2 == 2 ? lofs_b4 : lofs_b8)] = (uint16_t)v;
         /* ---- publish from the registers: a granule = two samples, the second one comes from the lane below / beside ---- */
+        if (e0 & (M355_IBX_PUB_COL | M355_IBX_PUB_ROW)) {
         if (pub_col) {
           const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + NT) << 2, v);
           if (inb && x == NT - 1 && !(y & 1))
@@ -677,6 +681,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
           const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, v);
           if (inb && y == NT - 1 && !(x & 1))
             __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + lx + x), ((m355_granule)epoch << 32) | (v2 << 16) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         }
       };
 
