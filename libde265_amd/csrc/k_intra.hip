@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         /* (branch-free where it is cheap: a taken branch costs a lone wave more than the few instructions it skips) */
         if (DENSE) rs = (int)resl[d_rofs + (LOG2 == 2 ? lofs_r4 : lofs_r8)] & (has_res ? -1 : 0);
         else if (has_res) rs = inb ? (int)p.resbuf[e1 + lane] : 0;
-        if (__any((int)(bv == HALO_NOT_READY))) {
+        if (__builtin_expect(__any((int)(bv == HALO_NOT_READY)), 0)) {
           /* a halo sample its CTB has not published yet: poll its granule */
           const bool pending = bv == HALO_NOT_READY && code0 >= (uint32_t)HALO_BASE && code0 < (uint32_t)(HALO_BASE + HALO_N);
           if (__any((int)pending))
@@ -629,7 +629,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #define BRL(i) ((int)__builtin_amdgcn_readlane((int)bv, (i) + Z))                 /* border entry i, the same for every lane */
 #define BRP(i) ((int)__builtin_amdgcn_ds_bpermute(((i) + Z) << 2, (int)bv))       /* border entry i, per lane */
         int v;
-        if (cls == 0) {               /* planar (intrapred.h:261-285) */
+        if (__builtin_expect(cls >= 3, 1)) {
+          /* angular (33 of the 35 modes; first in line, and one formula for both signs of the angle): ref[] of the reference is not
+             built — its entry i is border entry sgn*i for i >= 0 and, left of the corner (negative angles only), -sgn*((i*invAngle+128)>>8) */
+          const int a_ = vert ? y : x, b_ = vert ? x : y;
+          const int tt = __mul24(a_ + 1, angle), iIdx = tt >> 5, iFact = tt & 31;
+          const int x1 = b_ + iIdx + 1, x2 = x1 + 1;
+          const int p1 = (__mul24(x1, inv) + 128) >> 8, p2 = (__mul24(x2, inv) + 128) >> 8;     /* (invAngle is 0 for a positive angle, whose x1 is never negative) */
+          int i1 = x1 >= 0 ? x1 : -p1, i2 = x2 >= 0 ? x2 : -p2;
+          if (!vert) { i1 = -i1; i2 = -i2; }
+          const int r1 = BRP(i1), r2 = BRP(i2);
+          v = (32 * r1 + __mul24(iFact, r2 - r1) + 16) >> 5;   /* (= r1 when iFact is 0) */
+        } else if (cls == 0) {        /* planar (intrapred.h:261-285) */
           const int l = BRP(-1 - y), t = BRP(1 + x), tr = BRL(1 + NT), bl = BRL(-1 - NT);
           v = (__mul24(NT - 1 - x, l) + __mul24(x + 1, tr) + __mul24(NT - 1 - y, t) + __mul24(y + 1, bl) + NT) >> (LOG2 + 1);   /* (24-bit multiplies: full rate) */
         } else if (cls == 1) {        /* DC (intrapred.h:288-310, 378-392) */
@@ -646,32 +657,17 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             if (x == 0 || y == 0) v = (eb + 3 * dc + 2) >> 2;
             if (lane == 0) v = (e2c + 2 * dc + 2) >> 2;
           }
-        } else if (cls == 2) {        /* pure horizontal / vertical (intrapred.h:330-433 with intraPredAngle 0) */
+        } else {                      /* pure horizontal / vertical (intrapred.h:330-433 with intraPredAngle 0) */
           const int l = BRP(-1 - y), t = BRP(1 + x), corner = BRL(0), first = vert ? BRL(1) : BRL(-1);
           v = vert ? t : l;
           if (bfilt && (vert ? x == 0 : y == 0)) v = d_clip3(0, pix_max, first + (((vert ? l : t) - corner) >> 1));
-        } else {                      /* angular: ref[] of the reference is not built — its entry i is border entry sgn*i for i >= 0
-                                         and, left of the corner (negative angles only), -sgn*((i*invAngle+128)>>8) */
-          const int a_ = vert ? y : x, b_ = vert ? x : y;
-          const int tt = __mul24(a_ + 1, angle), iIdx = tt >> 5, iFact = tt & 31;
-          const int x1 = b_ + iIdx + 1, x2 = x1 + 1;
-          const int sgn = vert ? 1 : -1;
-          int i1, i2;
-          if (cls == 3) { i1 = vert ? x1 : -x1; i2 = i1 + sgn; }
-          else {
-            const int p1 = (__mul24(x1, inv) + 128) >> 8, p2 = (__mul24(x2, inv) + 128) >> 8;
-            i1 = x1 >= 0 ? x1 : -p1; i2 = x2 >= 0 ? x2 : -p2;
-            if (!vert) { i1 = -i1; i2 = -i2; }
-          }
-          const int r1 = BRP(i1), r2 = BRP(i2);
-          v = (32 * r1 + __mul24(iFact, r2 - r1) + 16) >> 5;   /* (= r1 when iFact is 0) */
         }
 #undef BRL
 #undef BRP
         if (DENSE || has_res) v = d_clip3(0, pix_max, v + rs);   /* (a prediction is inside the sample range: no-op without a residual) */
         if (inb) body[d_bofs + (LOG2 == 2 ? lofs_b4 : lofs_b8)] = (uint16_t)v;
         /* ---- publish from the registers: a granule = two samples, the second one comes from the lane below / beside ---- */
-        if (e0 & (M355_IBX_PUB_COL | M355_IBX_PUB_ROW)) {
+        if (__builtin_expect((e0 & (M355_IBX_PUB_COL | M355_IBX_PUB_ROW)) != 0, 0)) {
         if (pub_col) {
           const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + NT) << 2, v);
           if (inb && x == NT - 1 && !(y & 1))
@@ -685,9 +681,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
       };
 
-      if (!(e0 & M355_IBX_PCM) && log2 == 2) small_block(std::integral_constant<int, 2>());
-      else if (!(e0 & M355_IBX_PCM) && log2 == 3) small_block(std::integral_constant<int, 3>());
-      else {
+      if (__builtin_expect(log2 <= 3 && !(e0 & M355_IBX_PCM), 1)) {
+        if (log2 == 2) small_block(std::integral_constant<int, 2>()); else small_block(std::integral_constant<int, 3>());
+      } else {
       if (!(e0 & M355_IBX_PCM)) {
         /* ---- 16x16 / 32x32: the border lives in LDS (65 / 129 entries) ---- */
         const int nEnt = 4 * nT + 1, Z = 2 * nT;
