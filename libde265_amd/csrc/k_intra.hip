@@ -562,7 +562,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
        and (4x4 / 8x8) the plan entries of its border, entry e in lane e */
     int nsrc = -1, nlevel = -1;
     uint32_t e0 = 0, e1 = 0, e3 = 0, ncode = 0;
-    int d_bofs = 0, d_rofs = 0, d_angle = 0, d_inv = 0, d_cls = 0, d_log2 = 0;
+    int d_bofs = 0, d_rofs = 0, d_angle = 0, d_inv = 0, d_cls = 0, d_log2 = 0, d_small = 0;
+    int d_baddr = 0, d_raddr = 0;                           /* (4x4 / 8x8) this lane's sample in the body / residual tiles */
     auto fetch_next = [&]() {
       nsrc = mine ? __ffsll(mine) - 1 : -1;
       mine &= mine - 1;
@@ -575,8 +576,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const int lx = (int)(e0 & 127u), ly = (int)((e0 >> 7) & 127u);
       d_bofs = ly * BODY_PITCH + lx + BODY_X0; d_rofs = ly * RES_PITCH + lx;
       d_cls = (int)((e2 >> 8) & 7u); d_angle = (int)(int8_t)(e2 & 0xFFu); d_inv = (int)(int16_t)(e2 >> 16);
-      if (d_log2 <= 3 && !(e0 & M355_IBX_PCM)) ncode = s_plan[((e3 & 0xFFFFu) - plan_lo) + (uint32_t)min(lane, 4 << d_log2)];
-      M355_PIN_S(d_bofs); M355_PIN_S(d_rofs); M355_PIN_S(d_cls); M355_PIN_S(d_angle); M355_PIN_S(d_inv); M355_PIN_S(d_log2); M355_PIN_S(nlevel);
+      d_small = (d_log2 <= 3 && !(e0 & M355_IBX_PCM)) ? 1 : 0;
+      if (d_small) {
+        ncode = s_plan[((e3 & 0xFFFFu) - plan_lo) + (uint32_t)min(lane, 4 << d_log2)];
+        d_baddr = d_bofs + (d_log2 == 2 ? lofs_b4 : lofs_b8); d_raddr = d_rofs + (d_log2 == 2 ? lofs_r4 : lofs_r8);
+      }
+      M355_PIN_S(d_small); M355_PIN_S(d_bofs); M355_PIN_S(d_rofs); M355_PIN_S(d_cls); M355_PIN_S(d_angle); M355_PIN_S(d_inv); M355_PIN_S(d_log2); M355_PIN_S(nlevel);
     };
     fetch_next();
     bool pend = false;                                       /* the next block is still to be fetched (done behind the barrier) */
@@ -596,6 +601,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     if (pend) { fetch_next(); pend = false; }
     while (nsrc >= 0 && nlevel == L) {
       const uint32_t code0 = ncode;
+      /* first thing behind the barrier: the block's border (fill_from_image + substitution, intrapred.h:534-665, resolved by
+         k_intra_plan: one sample per plan entry) and its residual — everything else of the block is decoded beside these reads */
+      uint32_t bv0 = 0;
+      int rs0 = 0;
+      if (__builtin_expect(d_small, 1)) { bv0 = body[code0]; if (DENSE) rs0 = (int)resl[d_raddr]; }
       const int log2 = d_log2, nT = 1 << log2, cls = d_cls, angle = d_angle, inv = d_inv;
       const int mode = (int)((e0 >> 19) & 63u);
       const bool vert = mode >= 18;
@@ -609,10 +619,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         constexpr int LOG2 = decltype(l2_)::value, NT = 1 << LOG2, Z = 2 * NT, NENT = 4 * NT + 1;
         const int x = lane & (NT - 1), y = lane >> LOG2;
         const bool inb = lane < NT * NT;
-        uint32_t bv = body[code0];                           /* fill_from_image + substitution (intrapred.h:534-665) resolved by k_intra_plan */
+        uint32_t bv = bv0;
         int rs = 0;
         /* (branch-free where it is cheap: a taken branch costs a lone wave more than the few instructions it skips) */
-        if (DENSE) rs = (int)resl[d_rofs + (LOG2 == 2 ? lofs_r4 : lofs_r8)] & (has_res ? -1 : 0);
+        if (DENSE) rs = rs0 & (has_res ? -1 : 0);
         else if (has_res) rs = inb ? (int)p.resbuf[e1 + lane] : 0;
         if (__builtin_expect(__any((int)(bv == HALO_NOT_READY)), 0)) {
           /* a halo sample its CTB has not published yet: poll its granule */
@@ -665,7 +675,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #undef BRL
 #undef BRP
         if (DENSE || has_res) v = d_clip3(0, pix_max, v + rs);   /* (a prediction is inside the sample range: no-op without a residual) */
-        if (inb) body[d_bofs + (LOG2 == 2 ? lofs_b4 : lofs_b8)] = (uint16_t)v;
+        if (inb) body[d_baddr] = (uint16_t)v;
         /* ---- publish from the registers: a granule = two samples, the second one comes from the lane below / beside ---- */
         if (__builtin_expect((e0 & (M355_IBX_PUB_COL | M355_IBX_PUB_ROW)) != 0, 0)) {
         if (pub_col) {
@@ -681,7 +691,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
       };
 
-      if (__builtin_expect(log2 <= 3 && !(e0 & M355_IBX_PCM), 1)) {
+      if (__builtin_expect(d_small, 1)) {
         if (log2 == 2) small_block(std::integral_constant<int, 2>()); else small_block(std::integral_constant<int, 3>());
       } else {
       if (!(e0 & M355_IBX_PCM)) {
