@@ -512,7 +512,10 @@ M355_API int64_t m355_shard_xbuf_bytes(m355_ctx* ctx, int handle, int which);
  * the exchanged contents.  Asynchronous.  With m355_set_pipeline_depth(ctx, n >= 2) consecutive pictures run on n lanes: phase 0
  * takes the next lane, the later phases of a picture follow it there, frame hazards are ordered as for m355_decode_resident —
  * the exchanges and filter phases of one picture overlap the prediction phase of the next.  After every call m355_stream() is
- * the stream of the picture's lane: order the exchange that follows on it. */
+ * the stream of the picture's lane: order the exchange that follows on it.
+ * A REFERENCE picture is complete only after phase 4 (phase 3 marks the destination frame written with the own tiles only): issue
+ * its phase 4 before phase 0 of any picture that reads it — m355_decode_sharded and libde265_amd/shard.py do, they issue a picture's
+ * phases back to back. */
 M355_API int m355_decode_phase(m355_ctx* ctx, int handle, int phase, void* xbuf);
 
 /* The whole sharded picture in ONE call: the five phases with the exchanges between them, issued from the library (C++; no

@@ -26,6 +26,7 @@
 #include <utility>
 #include <vector>
 
+#include <pthread.h>
 #include "k_common.h"
 #include "k_hash.h"
 
@@ -640,10 +641,15 @@ struct HostPool {
     job = nullptr; n_parts = 0;
   }
 };
+static HostPool* g_pool = nullptr;
 static HostPool& host_pool()
 {
-  static HostPool* p = new HostPool(host_threads() - 1);    /* lives until process exit (worker threads must not outlive it) */
-  return *p;
+  /* lives until process exit (worker threads must not outlive it); a fork()ed child has no worker threads: it forgets the parent's
+     pool (its threads do not exist there) and makes its own at the first parallel phase */
+  static std::once_flag once;
+  std::call_once(once, []() { pthread_atfork(nullptr, nullptr, []() { g_pool = nullptr; }); });
+  if (!g_pool) g_pool = new HostPool(host_threads() - 1);
+  return *g_pool;
 }
 static std::mutex g_pool_mu;                                 /* one parallel phase at a time (contexts on several threads share the pool) */
 template <class F> static void parallel_ranges(size_t n, size_t min_per_thread, F f)   /* f(begin, end) */
@@ -653,7 +659,10 @@ template <class F> static void parallel_ranges(size_t n, size_t min_per_thread, 
   else if (n / min_per_thread < (size_t)T) T = (int)(n / min_per_thread);
   if (T <= 1) { f((size_t)0, n); return; }
   const std::function<void(int)> part = [&](int t) { f(n * (size_t)t / T, n * ((size_t)t + 1) / T); };
-  std::lock_guard<std::mutex> g(g_pool_mu);
+  /* one parallel phase at a time on the shared pool; a context that finds it busy (several decoders in one process, each on its own
+     thread) does its phase itself instead of queueing behind the others */
+  std::unique_lock<std::mutex> g(g_pool_mu, std::try_to_lock);
+  if (!g.owns_lock()) { f((size_t)0, n); return; }
   host_pool().run(T, part);
 }
 /* check(i) -> nullptr or a message; the LOWEST failing index is reported as "<what> <i>: <message>" */
