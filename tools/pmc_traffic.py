@@ -12,7 +12,7 @@ import re
 import sys
 from collections import defaultdict
 
-STAGES = {"k_inter": "k_inter", "k_residual": "k_residual", "k_intra": "k_intra", "k_deblock": "k_deblock", "k_sao": "k_sao<",
+STAGES = {"k_inter": "k_inter", "k_residual": "k_residual", "k_intra": "k_intra<", "k_deblock": "k_deblock", "k_sao": "k_sao<",
           "k_meta": "k_meta"}
 
 
