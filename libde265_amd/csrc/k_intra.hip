@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   }
   if (item >= work_n) return;
 #ifdef M355_X_PROF      /* experiment builds (tools/prof_timeline.py): when a CTB was claimed, started its block loop, ended it, was written out */
-#define TL(k) do { if (p.prof && threadIdx.x == 0 && item < 1600) p.prof[8200 + 5 * item + 1 + (k)] = wall_clock64(); } while (0)
+#define TL(k) do { if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item + 1 + (k)] = wall_clock64(); } while (0)
 #else
 #define TL(k) do { } while (0)
 #endif
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
   TL(1);
 #ifdef M355_X_PROF
-  if (p.prof && threadIdx.x == 0 && item < 1600) p.prof[8200 + 5 * item] = (unsigned long long)ctb + 1;
+  if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item] = (unsigned long long)ctb + 1;
 #endif
   /* The CTB's exec records (runtime.hip intra_schedule: sorted by level, then component; everything about a block that is not a
      sample value) are fetched 64 at a time (one per lane, 16 bytes, coalesced) by EVERY wave.  A wave's blocks of the batch —

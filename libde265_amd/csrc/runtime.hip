@@ -1412,8 +1412,8 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
 #ifdef M355_X_PROF
   {
     static unsigned long long* prof = nullptr;
-    if (!prof) { hipMalloc(&prof, 8 * 16384); }
-    hipMemsetAsync(prof, 0, 8 * 16384, c->stream);
+    if (!prof) { hipMalloc(&prof, 8 * 65536); }
+    hipMemsetAsync(prof, 0, 8 * 65536, c->stream);
     d.prof = prof;
     g_prof = prof;
   }
