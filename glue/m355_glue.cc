@@ -77,7 +77,8 @@ namespace {
 #define M355_FUNCS(X) \
   X(m355_last_error) X(m355_device_count) X(m355_create) X(m355_destroy) X(m355_frame_create) X(m355_frame_destroy) \
   X(m355_frame_upload) X(m355_frame_download) X(m355_submit_picture) X(m355_wait) X(m355_set_pipeline_depth) \
-  X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash) X(m355_arena_begin) X(m355_last_serial) X(m355_decode_status)
+  X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash) X(m355_arena_begin) X(m355_last_serial) X(m355_decode_status) \
+  X(m355_frame_download_async) X(m355_frame_download_wait)
 
 struct Api {
   void* handle = nullptr;
@@ -193,6 +194,12 @@ struct Glue {
      lists were rejected, or it was predicted from a damaged frame) */
   unsigned long long pending_serial[M355_MAX_REF_FRAMES];
   bool damaged[M355_MAX_REF_FRAMES];
+  /* picture output: once the application has asked for a picture's planes, every later output picture's download is started right
+     behind its decode (asynchronous, into the image's pinned planes) instead of when the application asks: dl_id = the image whose
+     copy is in flight (or has landed) per slot */
+  uint32_t dl_id[M355_MAX_REF_FRAMES];
+  std::atomic<bool> app_reads{false};
+  long long n_prefetched = 0;
   long long n_rejected = 0;
   PlanePool planes;
   /* The submit step (metadata walk, lists into the arena, m355_submit_picture) of a parsed picture runs on a WORKER thread while
@@ -217,7 +224,7 @@ struct Glue {
   std::string error;
   Glue()
   {
-    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) { frame_of_slot[i] = -1; dev_id[i] = host_id[i] = 0xFFFFFFFFu; pending_serial[i] = 0; damaged[i] = false; }
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) { frame_of_slot[i] = -1; dev_id[i] = host_id[i] = 0xFFFFFFFFu; pending_serial[i] = 0; damaged[i] = false; dl_id[i] = 0xFFFFFFFFu; }
   }
 };
 
@@ -332,6 +339,16 @@ void glue_release_buffer(de265_decoder_context* ctx, de265_image* img, void* use
 {
   Glue* g = (Glue*)userdata;
   wait_submitted(g, img->get_ID());               /* the DPB recycles the image (dpb.cc:206-216): the worker may still be walking its metadata */
+  {
+    /* a download started behind the picture's decode that nobody waited for (the application never looked at the picture): it must
+       have landed before the planes go back to the pool — the next image's parser may write PCM samples into them */
+    std::lock_guard<std::mutex> api_lock(g->api_mu);
+    for (int s = 0; s < M355_MAX_REF_FRAMES; s++)
+      if (g->dl_id[s] == img->get_ID() && g->host_id[s] != img->get_ID() && g->frame_of_slot[s] >= 0) {
+        api()->m355_frame_download_wait(g->mctx, g->frame_of_slot[s]);
+        g->dl_id[s] = 0xFFFFFFFFu;
+      }
+  }
   for (int c = 0; c < 3; c++) {
     void* p = (void*)img->get_image_plane(c);
     if (p) g->planes.put(p);
@@ -410,6 +427,15 @@ void download_if_needed(Glue* g, de265_image* img)
   const auto t0 = std::chrono::steady_clock::now();
   collect_status(g, slot);                         /* this picture's own outcome (waits for its decode) */
   if (g->damaged[slot] && img->integrity == INTEGRITY_CORRECT) img->integrity = INTEGRITY_DERIVED_FROM_FAULTY_REFERENCE;
+  g->app_reads.store(true);
+  if (g->dl_id[slot] == img->get_ID()) {           /* its copy was started behind its decode: wait for that copy only */
+    if (api()->m355_frame_download_wait(g->mctx, g->frame_of_slot[slot]) == M355_OK) {
+      g->host_id[slot] = img->get_ID();
+      g->n_downloads++;
+      g->ms_download += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      return;
+    }
+  }
   const int nc = img->get_chroma_format() == de265_chroma_mono ? 1 : 3;
   for (int c = 0; c < nc; c++)
     if (api()->m355_frame_download(g->mctx, g->frame_of_slot[slot], c, img->get_image_plane(c), img->get_image_stride(c)) != M355_OK) {
@@ -829,6 +855,14 @@ bool submit_picture(Glue* g, Glue::Job& job)
   g->damaged[dslot] = from_damaged;
   if (from_damaged && img->integrity == INTEGRITY_CORRECT) img->integrity = INTEGRITY_DERIVED_FROM_FAULTY_REFERENCE;
   g->n_pictures++;
+  g->dl_id[dslot] = 0xFFFFFFFFu;
+  if (g->app_reads.load() && img->PicOutputFlag && !getenv("M355_GLUE_NO_PREFETCH")) {
+    void* dst[3] = {nullptr, nullptr, nullptr};
+    ptrdiff_t str[3] = {0, 0, 0};
+    const int nc = img->get_chroma_format() == de265_chroma_mono ? 1 : 3;
+    for (int c = 0; c < nc; c++) { dst[c] = img->get_image_plane(c); str[c] = img->get_image_stride(c); }
+    if (A->m355_frame_download_async(g->mctx, g->frame_of_slot[dslot], dst, str) == M355_OK) { g->dl_id[dslot] = img->get_ID(); g->n_prefetched++; }
+  }
   return true;
 }
 

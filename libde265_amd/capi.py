@@ -68,6 +68,8 @@ class Library:
         L.m355_frame_download.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_fill.argtypes = [vp, i, i, i]
         L.m355_arena_begin.argtypes = [vp, vp, vp]
+        L.m355_frame_download_async.argtypes = [vp, i, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ssize_t)]
+        L.m355_frame_download_wait.argtypes = [vp, i]
         L.m355_host_alloc.argtypes = [ctypes.c_size_t]
         L.m355_host_alloc.restype = vp
         L.m355_host_free.argtypes = [vp]
@@ -168,6 +170,33 @@ class Context:
             a = np.zeros((ph, pw), np.uint8 if (bdl if c == 0 else bdc) <= 8 else np.uint16)
             self.L.check(self.L.lib.m355_frame_download(self.h, f, c, a.ctypes.data, pw))
             out.append(a)
+        return out
+
+    def frame_download_async(self, f):
+        """start the download of all planes behind the frame's last writer (into pinned planes); -> token for frame_download_finish"""
+        w, h, cf, bdl, bdc = self._geom[f]
+        dst = (ctypes.c_void_p * 3)(); strides = (ctypes.c_ssize_t * 3)()
+        arrays, bufs = [], []
+        for c, (pw, ph) in enumerate(worklist.plane_dims(w, h, cf)):
+            if pw == 0:
+                continue
+            dt = np.uint8 if (bdl if c == 0 else bdc) <= 8 else np.uint16
+            nbytes = pw * ph * np.dtype(dt).itemsize
+            p = self.L.lib.m355_host_alloc(nbytes)
+            if not p:
+                raise M355Error(5, self.L.error())
+            bufs.append(p)
+            arrays.append(np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), (nbytes,)).view(dt).reshape(ph, pw))
+            dst[c] = p; strides[c] = pw
+        self.L.check(self.L.lib.m355_frame_download_async(self.h, f, dst, strides))
+        return (f, arrays, bufs)
+
+    def frame_download_finish(self, token):
+        f, arrays, bufs = token
+        self.L.check(self.L.lib.m355_frame_download_wait(self.h, f))
+        out = [a.copy() for a in arrays]
+        for p in bufs:
+            self.L.lib.m355_host_free(p)
         return out
 
     def frame_fill(self, f, luma, chroma):

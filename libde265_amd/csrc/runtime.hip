@@ -55,6 +55,9 @@ struct Frame {
   /* pictures in flight on different lanes (m355_set_pipeline_depth): last writer / last readers per lane */
   hipEvent_t ev_wr = nullptr, ev_rd[M355_MAX_LANES] = {};
   bool wr_pending = false, rd_pending[M355_MAX_LANES] = {};
+  /* a download in flight on the context's copy stream (m355_frame_download_async): the next writer of the frame waits for it */
+  hipEvent_t ev_dl = nullptr;
+  bool dl_pending = false;
 };
 
 static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
@@ -91,6 +94,8 @@ static void frame_free(Frame& f)
   if (f.ev_wr) hipEventDestroy(f.ev_wr);
   for (int k = 0; k < M355_MAX_LANES; k++) { if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]); f.ev_rd[k] = nullptr; f.rd_pending[k] = false; }
   f.ev_wr = nullptr; f.wr_pending = false;
+  if (f.ev_dl) hipEventDestroy(f.ev_dl);
+  f.ev_dl = nullptr; f.dl_pending = false;
   f.used = false;
 }
 
@@ -156,6 +161,8 @@ struct m355_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+  hipStream_t dl_stream = nullptr;         /* m355_frame_download_async: copies out beside the decodes */
+  hipEvent_t ev_dl_fork = nullptr;
   std::vector<Frame> frames;
   std::vector<Resident> resident;
   Resident transient[3];       /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes */
@@ -250,6 +257,7 @@ static hipError_t sync_all(m355_ctx* c)
   hipError_t e = hipStreamSynchronize(c->stream);
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].stream) { hipError_t e2 = hipStreamSynchronize(c->lanes[k].stream); if (e == hipSuccess) e = e2; }
+  if (c->dl_stream) { hipError_t e2 = hipStreamSynchronize(c->dl_stream); if (e == hipSuccess) e = e2; }
   return e;
 }
 
@@ -404,6 +412,8 @@ void m355_destroy(m355_ctx* c)
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& st_ : c->status) if (st_.ev) hipEventDestroy(st_.ev);
   if (c->status_words) hipHostFree(c->status_words);
+  if (c->dl_stream) hipStreamDestroy(c->dl_stream);
+  if (c->ev_dl_fork) hipEventDestroy(c->ev_dl_fork);
   {
     /* the active lane lives in the context's own fields: collect it into a Lane and destroy both */
     Lane a;
@@ -489,6 +499,45 @@ int m355_frame_download(m355_ctx* c, int h, int cidx, void* dst, ptrdiff_t strid
   HIPCHK(sync_all(c));
   HIPCHK(hipMemcpy2D(dst, (size_t)stride * f->bpp[cidx], f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx],
                      (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyDeviceToHost));
+  return M355_OK;
+}
+/* The download of a whole frame, asynchronous: the copies run on the context's own copy stream, behind the frame's last writer and
+ * beside the decodes of later pictures; the next picture written into the frame waits for them.  dst planes should be pinned
+ * (m355_host_alloc), else the copies are staged by the runtime and block. */
+int m355_frame_download_async(m355_ctx* c, int h, void* const dst[3], const ptrdiff_t stride[3])
+{
+  Frame* f = get_frame(c, h);
+  if (!f || !dst || !stride) return fail(M355_ERR_INVALID, "bad frame / destination");
+  hipSetDevice(c->device);
+  if (!c->dl_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_dl_fork, hipEventDisableTiming));
+  }
+  if (f->wr_pending) HIPCHK(hipStreamWaitEvent(c->dl_stream, f->ev_wr, 0));     /* pictures in flight: the frame's writer */
+  else if (c->depth < 2) {                                                      /* one lane: whatever that stream holds so far */
+    HIPCHK(hipEventRecord(c->ev_dl_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->dl_stream, c->ev_dl_fork, 0));
+  }                                                                             /* (else: nothing pending writes it — m355_wait cleared the mark) */
+  for (int cc = 0; cc < 3; cc++) {
+    if (!f->pw[cc]) continue;
+    if (!dst[cc]) return fail(M355_ERR_INVALID, "no destination for plane %d", cc);
+    HIPCHK(hipMemcpy2DAsync(dst[cc], (size_t)stride[cc] * f->bpp[cc], f->plane[cc], (size_t)f->stride[cc] * f->bpp[cc],
+                            (size_t)f->pw[cc] * f->bpp[cc], f->ph[cc], hipMemcpyDeviceToHost, c->dl_stream));
+  }
+  if (!f->ev_dl) HIPCHK(hipEventCreateWithFlags(&f->ev_dl, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(f->ev_dl, c->dl_stream));
+  f->dl_pending = true;
+  return M355_OK;
+}
+/* wait (this frame's download only) until the planes handed to m355_frame_download_async hold the picture */
+int m355_frame_download_wait(m355_ctx* c, int h)
+{
+  Frame* f = get_frame(c, h);
+  if (!f) return fail(M355_ERR_INVALID, "bad frame handle %d", h);
+  if (!f->dl_pending) return M355_OK;
+  hipSetDevice(c->device);
+  HIPCHK(hipEventSynchronize(f->ev_dl));
+  f->dl_pending = false;
   return M355_OK;
 }
 int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
@@ -1494,6 +1543,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   /* write-after-write / write-after-read on the destination: waited for right before the first kernel that writes
      it — the SAO stage when SAO runs (everything before writes this lane's working planes), else the first stage */
   auto dst_hazards = [&]() {
+    if (dstf->dl_pending) hipStreamWaitEvent(c->stream, dstf->ev_dl, 0);     /* (stays pending for the HOST until m355_frame_download_wait / m355_wait) */
     if (!piped) return;
     if (dstf->wr_pending) hipStreamWaitEvent(c->stream, dstf->ev_wr, 0);
     for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(c->stream, dstf->ev_rd[k], 0);
@@ -1639,6 +1689,7 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   const bool deblock = (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED);
   Frame* dstf = get_frame(c, r.hdr.dst_frame);
   auto dst_hazards = [&]() {     /* as in decode(): right before the first write of the destination frame */
+    if (dstf->dl_pending) hipStreamWaitEvent(st, dstf->ev_dl, 0);
     if (!piped) return;
     if (dstf->wr_pending) hipStreamWaitEvent(st, dstf->ev_wr, 0);
     for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(st, dstf->ev_rd[k], 0);
@@ -1925,7 +1976,7 @@ int m355_wait(m355_ctx* c)
 {
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-  for (auto& f : c->frames) { f.wr_pending = false; for (int k = 0; k < M355_MAX_LANES; k++) f.rd_pending[k] = false; }   /* everything is complete */
+  for (auto& f : c->frames) { f.wr_pending = false; f.dl_pending = false; for (int k = 0; k < M355_MAX_LANES; k++) f.rd_pending[k] = false; }   /* everything is complete */
   uint32_t t = 0;
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
   for (int k = 0; k < M355_MAX_LANES; k++)

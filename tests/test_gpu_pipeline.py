@@ -69,3 +69,47 @@ def test_dependent_pictures_pipelined(oracle, cfg, depth):
         assert_planes_equal(ctx.frame_download(pool[(n - 1) % 3]), want[n - 1], "replayed")
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_async_download_beside_later_decodes(oracle, depth):
+    """m355_frame_download_async: the copy of picture k is started right behind its decode and runs beside the decodes of k+1, k+2
+    (which reference k and then RECYCLE its frame: the writer must wait for the copy); what lands in the pinned planes is picture k."""
+    o = Oracle(oracle)
+    cfg = dict(width=832, height=480, bit_depth=10, seed=311, n_refs=2, tile_cols=2, tile_rows=1)
+    n = 7
+    pics, ref0 = chain_case(n, **cfg)
+    pp = pics[0].pp[0]
+    of0 = o.frame_new(pp); o.frame_set_planes(of0, ref0)
+    oprev, want = of0, []
+    for pic in pics:
+        od = o.frame_new(pp)
+        pic.ref_frames = [0, 1] + [-1] * (worklist.MAX_REF_FRAMES - 2)
+        assert o.decode(pic, od, {0: of0, 1: oprev}) == 0
+        want.append(o.frame_planes(od))
+        oprev = od
+    lib = capi.Library()
+    ctx = capi.Context(lib, 0)
+    try:
+        ctx.set_pipeline_depth(depth)
+        g0 = ctx.frame_create_for(pp); ctx.frame_upload(g0, ref0)
+        pool = [ctx.frame_create_for(pp) for _ in range(2)]        # two destination frames: picture k+2 overwrites picture k's
+        handles, prev = [], g0
+        for k, pic in enumerate(pics):
+            pic.dst_frame = pool[k % 2]
+            pic.ref_frames = [g0, prev] + [-1] * (worklist.MAX_REF_FRAMES - 2)
+            handles.append(ctx.upload(pic))
+            prev = pic.dst_frame
+        tokens = []
+        for k in range(n):                                          # no host synchronisation anywhere in this loop
+            ctx.decode_resident(handles[k])
+            tokens.append(ctx.frame_download_async(pool[k % 2]))
+        for k in (n - 1, 0, 3):                                     # any order
+            assert_planes_equal(ctx.frame_download_finish(tokens[k]), want[k], "picture %d (async, out of order)" % k)
+            tokens[k] = None
+        ctx.wait()                                                  # m355_wait covers the copies too
+        for k in range(n):
+            if tokens[k] is not None:
+                assert_planes_equal(ctx.frame_download_finish(tokens[k]), want[k], "picture %d (async)" % k)
+    finally:
+        ctx.close()
