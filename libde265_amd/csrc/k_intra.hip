@@ -127,7 +127,9 @@ template <int CF> struct IntraGeo {
  * k_intra_plan: PLAN_SPLIT workgroups of 4 waves per CTB with intra blocks; a wave takes every (4 * PLAN_SPLIT)-th block, one
  * border entry per lane (up to three passes for the 129 entries of a 32x32 block).
  * ---------------------------------------------------------------------------------------------------------------- */
-#define PLAN_SPLIT 4
+#ifndef PLAN_SPLIT
+#define PLAN_SPLIT 8   /* (4 -> 8: C2 waits 15 us less for its plans, profiles/r03_u_*) */
+#endif
 template <int CF>
 __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
 {
