@@ -1495,10 +1495,16 @@ static hipError_t frame_event(hipEvent_t* e)
 static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev)
 {
   hipStream_t st = c->stream;
-  hipEventRecord(c->ev_fork, st);
-  hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-  m355_launch_meta_planes(d, c->stream2);
-  if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, c->stream2);   /* reads the CU plane (constrained intra prediction) */
+  /* an intra picture keeps to its lane's main stream (M355_DENSE_SINGLE_STREAM=0: forks like the others): its side work (metadata
+     planes, border plans: 0.07 ms) is nothing beside k_intra, and half as many streams compete for the runtime's hardware queues when
+     many such pictures are in flight — with M355_LANE_PRIORITIES=1 nine lanes are nine queues: C2 0.340 ms per picture = 1.50 M
+     CTB64/s at depth 9 (profiles/r03_v_*; forked: 0.59 at depth 8) */
+  static const bool single_env = !(getenv("M355_DENSE_SINGLE_STREAM") && atoi(getenv("M355_DENSE_SINGLE_STREAM")) == 0);
+  const bool single = single_env && d.intra_dense;
+  hipStream_t s2 = single ? st : c->stream2;
+  if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
+  m355_launch_meta_planes(d, s2);
+  if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, s2);   /* reads the CU plane (constrained intra prediction) */
   m355_launch_meta_jobs(d, st);
   if (ev) hipEventRecord(ev[1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
@@ -1512,13 +1518,11 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   if (ev) hipEventRecord(ev[2], st);
   if (c->stages & M355_STAGE_RESIDUAL) {
-    hipEventRecord(c->ev_fork2, st);                   /* inter residuals are added to the prediction samples */
-    hipStreamWaitEvent(c->stream2, c->ev_fork2, 0);
-    m355_launch_residual(d, hbd, false, c->stream2);
+    if (!single) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }   /* inter residuals are added to the prediction samples */
+    m355_launch_residual(d, hbd, false, s2);
     m355_launch_residual(d, hbd, true, st);
   }
-  hipEventRecord(c->ev_join, c->stream2);
-  hipStreamWaitEvent(st, c->ev_join, 0);     /* join */
+  if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
   if (ev) hipEventRecord(ev[3], st);
   if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
   if (ev) hipEventRecord(ev[4], st);
