@@ -19,8 +19,12 @@ EMU_SO = os.path.join(ROOT, "tests", "simt_emu", "_build", "libde265_mi355x_emu.
 
 @pytest.fixture(scope="session")
 def emu_lib():
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "libde265_amd", "csrc"), "-j8", "emu"], check=True,
-                   stdout=subprocess.DEVNULL)
+    # (pytest-xdist: every worker process has its own session — one build at a time, the others find it up to date)
+    import fcntl
+    with open(os.path.join(ROOT, "tests", "simt_emu", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "libde265_amd", "csrc"), "-j8", "emu"], check=True,
+                       stdout=subprocess.DEVNULL)
     return capi.Library(EMU_SO)
 
 
