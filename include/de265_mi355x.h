@@ -404,8 +404,8 @@ M355_API int m355_frame_destroy(m355_ctx* ctx, int frame);
 M355_API int m355_frame_upload(m355_ctx* ctx, int frame, int cidx, const void* src, ptrdiff_t stride);
 M355_API int m355_frame_download(m355_ctx* ctx, int frame, int cidx, void* dst, ptrdiff_t stride);
 /* The same for all planes of the frame, asynchronous (picture output, de265_get_next_picture / de265_get_image_plane: image.h's planes
- * are the destination): the copies are ordered behind the decode that writes the frame and run beside later pictures' decodes on
- * the context's copy stream; a later picture decoded into the frame waits for them.  dst[c] / stride[c] (in samples) per plane
+ * are the destination): the copies are queued right behind the decode that writes the frame, on that lane's stream — beside the
+ * host and the other lanes' decodes; a later picture decoded into the frame waits for them.  dst[c] / stride[c] (in samples) per plane
  * (unused planes of a monochrome frame are ignored); use m355_host_alloc'ed planes.  m355_frame_download_wait blocks until THIS
  * frame's copy has landed (m355_wait also waits for every copy). */
 M355_API int m355_frame_download_async(m355_ctx* ctx, int frame, void* const dst[3], const ptrdiff_t stride[3]);

@@ -58,6 +58,7 @@ struct Frame {
   /* a download in flight on the context's copy stream (m355_frame_download_async): the next writer of the frame waits for it */
   hipEvent_t ev_dl = nullptr;
   bool dl_pending = false;
+  int wr_lane = -1;                        /* the lane whose stream last wrote the frame (its downloads are queued on that stream) */
 };
 
 static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
@@ -94,7 +95,6 @@ static void frame_free(Frame& f)
   if (f.ev_wr) hipEventDestroy(f.ev_wr);
   for (int k = 0; k < M355_MAX_LANES; k++) { if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]); f.ev_rd[k] = nullptr; f.rd_pending[k] = false; }
   f.ev_wr = nullptr; f.wr_pending = false;
-  if (f.ev_dl) hipEventDestroy(f.ev_dl);
   f.ev_dl = nullptr; f.dl_pending = false;
   f.used = false;
 }
@@ -161,8 +161,8 @@ struct m355_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
-  hipStream_t dl_stream = nullptr;         /* m355_frame_download_async: copies out beside the decodes */
-  hipEvent_t ev_dl_fork = nullptr;
+  std::vector<hipEvent_t> dl_evs;          /* m355_frame_download_async: ring of completion events */
+  int dl_ev_next = 0;
   std::vector<Frame> frames;
   std::vector<Resident> resident;
   Resident transient[3];       /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes */
@@ -257,7 +257,6 @@ static hipError_t sync_all(m355_ctx* c)
   hipError_t e = hipStreamSynchronize(c->stream);
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].stream) { hipError_t e2 = hipStreamSynchronize(c->lanes[k].stream); if (e == hipSuccess) e = e2; }
-  if (c->dl_stream) { hipError_t e2 = hipStreamSynchronize(c->dl_stream); if (e == hipSuccess) e = e2; }
   return e;
 }
 
@@ -412,8 +411,7 @@ void m355_destroy(m355_ctx* c)
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& st_ : c->status) if (st_.ev) hipEventDestroy(st_.ev);
   if (c->status_words) hipHostFree(c->status_words);
-  if (c->dl_stream) hipStreamDestroy(c->dl_stream);
-  if (c->ev_dl_fork) hipEventDestroy(c->ev_dl_fork);
+  for (hipEvent_t e : c->dl_evs) if (e) hipEventDestroy(e);
   {
     /* the active lane lives in the context's own fields: collect it into a Lane and destroy both */
     Lane a;
@@ -501,6 +499,7 @@ int m355_frame_download(m355_ctx* c, int h, int cidx, void* dst, ptrdiff_t strid
                      (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyDeviceToHost));
   return M355_OK;
 }
+static hipError_t frame_event(hipEvent_t* e);
 /* The download of a whole frame, asynchronous: the copies run on the context's own copy stream, behind the frame's last writer and
  * beside the decodes of later pictures; the next picture written into the frame waits for them.  dst planes should be pinned
  * (m355_host_alloc), else the copies are staged by the runtime and block. */
@@ -509,23 +508,28 @@ int m355_frame_download_async(m355_ctx* c, int h, void* const dst[3], const ptrd
   Frame* f = get_frame(c, h);
   if (!f || !dst || !stride) return fail(M355_ERR_INVALID, "bad frame / destination");
   hipSetDevice(c->device);
-  if (!c->dl_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_dl_fork, hipEventDisableTiming));
+  /* The copies go on the stream of the lane that wrote the frame, right behind the decode: measured (tests/test_gpu_pipeline.py,
+     profiles/r03_y_*) a copy on a stream of its own, ordered behind the writer by an event (even with the host waiting for that event
+     first), now and then read a half-written picture — the writer's last stores were not yet visible to the copy engine; queued on
+     the writer's own stream it never did.  They still run beside the host and beside the other lanes' decodes; the lane's next
+     picture waits for them. */
+  if (c->dl_evs.empty()) {
+    c->dl_evs.resize(128, nullptr);
+    for (auto& e : c->dl_evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  if (f->wr_pending) HIPCHK(hipStreamWaitEvent(c->dl_stream, f->ev_wr, 0));     /* pictures in flight: the frame's writer */
-  else if (c->depth < 2) {                                                      /* one lane: whatever that stream holds so far */
-    HIPCHK(hipEventRecord(c->ev_dl_fork, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->dl_stream, c->ev_dl_fork, 0));
-  }                                                                             /* (else: nothing pending writes it — m355_wait cleared the mark) */
+  hipEvent_t ev_done = c->dl_evs[c->dl_ev_next];            /* (a ring: never re-recorded while an earlier record may still be waited for) */
+  c->dl_ev_next = (c->dl_ev_next + 1) % (int)c->dl_evs.size();
+  const bool known = f->wr_lane >= 0 && f->wr_lane < c->depth && (f->wr_lane == c->active || c->lanes[f->wr_lane].stream);
+  hipStream_t cs = known ? (f->wr_lane == c->active ? c->stream : c->lanes[f->wr_lane].stream) : c->stream;
+  if (!known && f->wr_pending) HIPCHK(hipStreamWaitEvent(cs, f->ev_wr, 0));     /* (a frame no decode of this context wrote: uploads and fills are synchronous) */
   for (int cc = 0; cc < 3; cc++) {
     if (!f->pw[cc]) continue;
     if (!dst[cc]) return fail(M355_ERR_INVALID, "no destination for plane %d", cc);
     HIPCHK(hipMemcpy2DAsync(dst[cc], (size_t)stride[cc] * f->bpp[cc], f->plane[cc], (size_t)f->stride[cc] * f->bpp[cc],
-                            (size_t)f->pw[cc] * f->bpp[cc], f->ph[cc], hipMemcpyDeviceToHost, c->dl_stream));
+                            (size_t)f->pw[cc] * f->bpp[cc], f->ph[cc], hipMemcpyDeviceToHost, cs));
   }
-  if (!f->ev_dl) HIPCHK(hipEventCreateWithFlags(&f->ev_dl, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(f->ev_dl, c->dl_stream));
+  HIPCHK(hipEventRecord(ev_done, cs));
+  f->ev_dl = ev_done;                                                           /* (the ring's: not the frame's to destroy) */
   f->dl_pending = true;
   return M355_OK;
 }
@@ -1574,6 +1578,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   hipEventRecord(ev[6], st);
   if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
   hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
+  dstf->wr_lane = c->active;
   if (piped) {
     if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
@@ -1701,6 +1706,7 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   auto dst_written = [&]() -> int {
     if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
+    dstf->wr_lane = c->active;
     if (!piped) return M355_OK;
     if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
