@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   int GL, GC;
   {
     const int code = __builtin_amdgcn_readfirstlane((int)(wd1.x & 3u));   /* widest level of the CTB: luma 1 / 2 / 3-4 / more blocks */
-    constexpr int GLMAX = NW >= 12 ? 8 : (NW >= 6 ? 4 : 2), GCMAX = (NW - GLMAX) / 2 >= 2 ? 2 : 1;
+    constexpr int GLMAX = NW >= 12 ? 8 : (NW >= 6 ? 4 : 2), GCMAX = (NW - GLMAX) / 2 >= 4 ? 4 : ((NW - GLMAX) / 2 >= 2 ? 2 : 1);
     GL = min(GLMAX, code == 0 ? 1 : (code == 1 ? 2 : (code == 2 ? 4 : 8)));
     GC = code == 3 ? GCMAX : 1;
     /* intra pictures: never fewer than two waves per component — a component's blocks go round its waves (below), so that
