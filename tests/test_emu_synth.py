@@ -27,6 +27,15 @@ CASES = [
     dict(width=128, height=128, bit_depth=10, seed=42, features=64 + 128 + 2, chroma_format=3, intra_pct=50, cbf_pct=90, fixed_cu_log2=3),
     dict(width=192, height=128, bit_depth=8, seed=43, features=256, intra_pct=5, weighted_pct=30),
     dict(width=128, height=128, bit_depth=10, seed=44, features=512 + 64 + 128, intra_pct=40, cbf_pct=90, chroma_format=2),
+    # intra pictures (k_intra's 12-wave kernel: persistent workgroups, exec records, register-resident 4x4 / 8x8 path, batched
+    # 16x16 / 32x32 loops) in every chroma format, with raw / bypass / constrained-intra blocks, one CU size at a time and mixed
+    dict(width=128, height=128, bit_depth=8, seed=51, intra_pct=100, n_refs=0, chroma_format=3, features=31),
+    dict(width=192, height=128, bit_depth=12, seed=52, intra_pct=100, n_refs=0, chroma_format=2, features=31, tile_cols=2),
+    dict(width=128, height=128, bit_depth=10, seed=53, intra_pct=100, n_refs=0, chroma_format=4),
+    dict(width=128, height=128, bit_depth=8, seed=54, intra_pct=100, n_refs=0, fixed_cu_log2=6),
+    dict(width=128, height=128, bit_depth=10, seed=55, intra_pct=100, n_refs=0, fixed_cu_log2=5, chroma_format=3),
+    dict(width=136, height=72, bit_depth=8, seed=56, intra_pct=100, n_refs=0, fixed_cu_log2=4, n_slices=2),
+    dict(width=128, height=128, bit_depth=8, seed=57, intra_pct=100, n_refs=0, fixed_cu_log2=3, cbf_pct=0),
 ]
 
 
