@@ -58,7 +58,7 @@ struct Frame {
   /* a download in flight on the context's copy stream (m355_frame_download_async): the next writer of the frame waits for it */
   hipEvent_t ev_dl = nullptr;
   bool dl_pending = false;
-  int wr_lane = -1;                        /* the lane whose stream last wrote the frame (its downloads are queued on that stream) */
+  hipStream_t wr_stream = nullptr;         /* the stream that last wrote the frame (its downloads are queued on that stream) */
 };
 
 static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
@@ -95,7 +95,7 @@ static void frame_free(Frame& f)
   if (f.ev_wr) hipEventDestroy(f.ev_wr);
   for (int k = 0; k < M355_MAX_LANES; k++) { if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]); f.ev_rd[k] = nullptr; f.rd_pending[k] = false; }
   f.ev_wr = nullptr; f.wr_pending = false;
-  f.ev_dl = nullptr; f.dl_pending = false;
+  f.ev_dl = nullptr; f.dl_pending = false; f.wr_stream = nullptr;
   f.used = false;
 }
 
@@ -143,6 +143,10 @@ struct Resident {
 struct Lane {
   hipStream_t stream = nullptr, stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+  /* intra pictures on lanes 3.. run on a stream of the lane's priority class (own hardware queues, lane_class below); the lane's
+     scratch is shared by both streams: a decode waits for the lane's previous one when that ran on the other stream */
+  hipStream_t stream_hi = nullptr, last_stream = nullptr;
+  hipEvent_t ev_last = nullptr;
   Frame work;
   uint32_t *pb_of = nullptr, *ticket = nullptr, *timeout = nullptr;
   unsigned long long* edge = nullptr;   /* k_intra halo granules */
@@ -161,6 +165,8 @@ struct m355_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+  hipStream_t stream_hi = nullptr, last_stream = nullptr;   /* (of the active lane, as in Lane) */
+  hipEvent_t ev_last = nullptr;
   std::vector<hipEvent_t> dl_evs;          /* m355_frame_download_async: ring of completion events */
   int dl_ev_next = 0;
   std::vector<Frame> frames;
@@ -194,7 +200,7 @@ struct m355_ctx {
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
 };
 
-#define LANE_FIELDS(X) X(stream) X(stream2) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
+#define LANE_FIELDS(X) X(stream) X(stream2) X(stream_hi) X(last_stream) X(ev_last) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
   X(resbuf) X(jobs) X(sao_nb) X(iplan) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
 static void select_lane(m355_ctx* c, int lane)
 {
@@ -209,19 +215,26 @@ static void select_lane(m355_ctx* c, int lane)
 }
 /* The HIP runtime multiplexes its streams onto a few hardware queues PER STREAM PRIORITY (GPU_MAX_HW_QUEUES, default 4), and
  * kernels of different streams that share a hardware queue mostly run one after the other.  Three lanes (six streams) do well on
- * the default priority's queues.  M355_LANE_PRIORITIES=1 gives every further group of three lanes the next priority class, i.e.
- * its own hardware queues: measured (profiles/r03_z_*, r03_g_*) it helps all-intra pictures beyond depth 3 (1080p: depth 4 1.02 ->
- * 0.66 ms per picture, depth 8 0.98 -> 0.59; GPU_MAX_HW_QUEUES=16 without classes: 0.41 at depth 8) and costs inter pictures 7 %
- * at depth 4 (8K: 0.436 -> 0.466), as every queue beyond the first few does — so it is off unless asked for. */
-static int lane_priority(int index)
+ * the default priority's queues.  Every further group of three lanes belongs to the next priority class, whose streams have
+ * hardware queues of their own — used by INTRA PICTURES only (they keep to one stream, launch_prediction, and their k_intra is
+ * what gains from more pictures in flight: 1080p, nine lanes 0.84 -> 0.334 ms per picture, profiles/r03_v_*, r03_x_c2_in_flight):
+ * such a picture runs on its lane's stream_hi.  Inter pictures stay on the default-priority streams: every queue beyond the first
+ * few slows their short kernels down (8K at depth 4: 0.436 -> 0.466 ms with all streams in classes).
+ * M355_LANE_PRIORITIES=0: no classes at all; =1: ALL streams of lanes 3.. in their class (the measurement above). */
+static int lane_class_priority(int index)
 {
   static int lo = 0, hi = 0, probed = 0;
   if (!probed) { probed = 1; if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0; }   /* (least, greatest) */
-  const char* e = getenv("M355_LANE_PRIORITIES");
-  if (!e || atoi(e) == 0) return 0;
   const int cls = (index / 3) % 3;
   return cls == 0 ? 0 : (cls == 1 ? hi : lo);
 }
+static int lane_priorities_mode()                            /* 0 off, 1 every stream, 2 (default) intra pictures only */
+{
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("M355_LANE_PRIORITIES"); mode = !e ? 2 : (atoi(e) == 0 ? 0 : 1); }
+  return mode;
+}
+static int lane_priority(int index) { return lane_priorities_mode() == 1 ? lane_class_priority(index) : 0; }
 static int lane_create(m355_ctx* c, Lane& l, int index)
 {
   HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, lane_priority(index)));
@@ -247,6 +260,8 @@ static void lane_destroy(Lane& l)
   if (l.ev_fork) hipEventDestroy(l.ev_fork);
   if (l.ev_fork2) hipEventDestroy(l.ev_fork2);
   if (l.ev_join) hipEventDestroy(l.ev_join);
+  if (l.stream_hi) { hipStreamSynchronize(l.stream_hi); hipStreamDestroy(l.stream_hi); }
+  if (l.ev_last) hipEventDestroy(l.ev_last);
   if (l.stream2) hipStreamDestroy(l.stream2);
   if (l.stream) hipStreamDestroy(l.stream);
   l = Lane();
@@ -257,6 +272,9 @@ static hipError_t sync_all(m355_ctx* c)
   hipError_t e = hipStreamSynchronize(c->stream);
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].stream) { hipError_t e2 = hipStreamSynchronize(c->lanes[k].stream); if (e == hipSuccess) e = e2; }
+  if (c->stream_hi) { hipError_t e2 = hipStreamSynchronize(c->stream_hi); if (e == hipSuccess) e = e2; }
+  for (int k = 0; k < M355_MAX_LANES; k++)
+    if (k != c->active && c->lanes[k].stream_hi) { hipError_t e2 = hipStreamSynchronize(c->lanes[k].stream_hi); if (e == hipSuccess) e = e2; }
   return e;
 }
 
@@ -519,9 +537,8 @@ int m355_frame_download_async(m355_ctx* c, int h, void* const dst[3], const ptrd
   }
   hipEvent_t ev_done = c->dl_evs[c->dl_ev_next];            /* (a ring: never re-recorded while an earlier record may still be waited for) */
   c->dl_ev_next = (c->dl_ev_next + 1) % (int)c->dl_evs.size();
-  const bool known = f->wr_lane >= 0 && f->wr_lane < c->depth && (f->wr_lane == c->active || c->lanes[f->wr_lane].stream);
-  hipStream_t cs = known ? (f->wr_lane == c->active ? c->stream : c->lanes[f->wr_lane].stream) : c->stream;
-  if (!known && f->wr_pending) HIPCHK(hipStreamWaitEvent(cs, f->ev_wr, 0));     /* (a frame no decode of this context wrote: uploads and fills are synchronous) */
+  hipStream_t cs = f->wr_stream ? f->wr_stream : c->stream;                     /* (no decode of this context wrote it: uploads and fills are synchronous) */
+  if (!f->wr_stream && f->wr_pending) HIPCHK(hipStreamWaitEvent(cs, f->ev_wr, 0));
   for (int cc = 0; cc < 3; cc++) {
     if (!f->pw[cc]) continue;
     if (!dst[cc]) return fail(M355_ERR_INVALID, "no destination for plane %d", cc);
@@ -1536,6 +1553,18 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
 {
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
   if (rotate && c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);   /* consecutive pictures go round the lanes */
+  /* which stream: an intra picture on lane 3.. takes the lane's class stream (lane_class_priority); the whole decode below addresses
+     c->stream, which is that stream until this function returns */
+  struct StreamSwap { hipStream_t& ref; hipStream_t saved; ~StreamSwap() { ref = saved; } } swap_back{c->stream, c->stream};
+  {
+    hipStream_t run = c->stream;
+    if (r.dp.intra_dense && c->active >= 3 && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
+      if (!c->stream_hi) HIPCHK(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, lane_class_priority(c->active)));
+      run = c->stream_hi;
+    }
+    if (c->last_stream && c->last_stream != run) hipStreamWaitEvent(run, c->ev_last, 0);   /* the lane's scratch and working planes */
+    c->stream = run;
+  }
   DevPic d;
   bool want_sao;
   int rc = prepare(c, r, d, want_sao);
@@ -1578,7 +1607,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   hipEventRecord(ev[6], st);
   if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
   hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
-  dstf->wr_lane = c->active;
+  dstf->wr_stream = st;
   if (piped) {
     if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
@@ -1602,6 +1631,8 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
     }
     hipEventRecord(s.ev, st);
   }
+  if (!c->ev_last && hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+  hipEventRecord(c->ev_last, st); c->last_stream = st;        /* (the lane's next decode may run on the lane's other stream) */
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return M355_OK;
@@ -1706,7 +1737,7 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   auto dst_written = [&]() -> int {
     if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
-    dstf->wr_lane = c->active;
+    dstf->wr_stream = st;
     if (!piped) return M355_OK;
     if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;

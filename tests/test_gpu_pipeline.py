@@ -117,3 +117,58 @@ def test_async_download_beside_later_decodes(oracle, depth):
                 check(k, "async")
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("depth", [4, 9])
+def test_intra_and_inter_pictures_alternate_on_deep_pipelines(oracle, depth):
+    """Lanes 3.. decode intra pictures on a stream of another priority class (own hardware queues) and inter pictures on the lane's
+    ordinary streams: a lane's scratch is shared by both, frames are recycled across lanes, inter pictures reference the picture
+    decoded right before them (an intra one, on another stream) — everything must still equal the oracle's sequential decode."""
+    o = Oracle(oracle)
+    base = dict(width=416, height=240, bit_depth=8, n_refs=1)
+    n = 2 * depth + 3
+    pics = []
+    for k in range(n):
+        intra = (k % 2 == 0) or (k % 5 == 0)
+        pics.append(synth.picture(**dict(base, seed=500 + 7 * k, intra_pct=100 if intra else 15, n_refs=0 if intra else 1)))
+    pp = pics[0].pp[0]
+    ref0 = synth.ref_planes(77, int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"]))
+    of0 = o.frame_new(pp); o.frame_set_planes(of0, ref0)
+    oprev, want = of0, []
+    for pic in pics:
+        od = o.frame_new(pp)
+        pic.ref_frames = [0] + [-1] * (worklist.MAX_REF_FRAMES - 1)
+        assert o.decode(pic, od, {0: oprev}) == 0
+        want.append(o.frame_planes(od))
+        oprev = od
+    lib = capi.Library()
+    ctx = capi.Context(lib, 0)
+    try:
+        ctx.set_pipeline_depth(depth)
+        g0 = ctx.frame_create_for(pp); ctx.frame_upload(g0, ref0)
+        npool = 4
+        pool = [ctx.frame_create_for(pp) for _ in range(npool)]
+        handles, prev = [], g0
+        for k, pic in enumerate(pics):
+            pic.dst_frame = pool[k % npool]
+            pic.ref_frames = [prev] + [-1] * (worklist.MAX_REF_FRAMES - 1)
+            handles.append(ctx.upload(pic))
+            prev = pic.dst_frame
+        got = []
+        for k0 in range(0, n, npool - 1):          # frames are recycled: take the finished ones out before their next writer is issued
+            ks = list(range(k0, min(n, k0 + npool - 1)))
+            for k in ks:
+                ctx.decode_resident(handles[k])
+            ctx.wait()
+            got += [ctx.frame_download(pool[k % npool]) for k in ks]
+        for k in range(n):
+            assert_planes_equal(got[k], want[k], "picture %d" % k)
+        # and without any host synchronisation in between: the last npool pictures are still in their frames afterwards
+        for _ in range(3):
+            for k in range(n):
+                ctx.decode_resident(handles[k])
+        ctx.wait()
+        for k in range(n - npool + 1, n):
+            assert_planes_equal(ctx.frame_download(pool[k % npool]), want[k], "picture %d after three unsynchronised rounds" % k)
+    finally:
+        ctx.close()

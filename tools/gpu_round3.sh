@@ -28,9 +28,9 @@ cp $REPO/profiles/pmc_traffic.json $OUT/pmc_traffic.json
 cd $REPO
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --force-tile-shard --no-cpu-baseline --no-with-upload --no-dependent-chain --no-end-to-end > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; tail -c 900 $OUT/bench_dist1.json; tail -2 $OUT/bench_dist1.err
 # all-intra pictures in flight: the default (4 hardware queues per stream priority) and the tuned setting for intra-only streams
-for cfg in "4 3 0" "4 8 0" "16 8 0" "4 9 1"; do set -- $cfg; M355_LANE_PRIORITIES=$3 GPU_MAX_HW_QUEUES=$1 timeout 300 python bench.py --workload c2_1080p_intra --steps 200 --warmup 10 --pipeline-depth $2 --no-cpu-baseline --no-with-upload --no-dependent-chain --no-end-to-end 2>>$OUT/bench.err | python -c "
+for cfg in "4 3" "4 9" "16 8"; do set -- $cfg; GPU_MAX_HW_QUEUES=$1 timeout 300 python bench.py --workload c2_1080p_intra --steps 200 --warmup 10 --pipeline-depth $2 --no-cpu-baseline --no-with-upload --no-dependent-chain --no-end-to-end 2>>$OUT/bench.err | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2 GPU_MAX_HW_QUEUES=$1 M355_LANE_PRIORITIES=$3 depth $2: %.4f ms/pic = %.3f M CTB64/s (one at a time %.4f)' % (d['ms_per_step'], 510/d['ms_per_step']/1e3, d['ms_per_step_one_in_flight']))" | tee -a $OUT/c2_in_flight.txt; done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2 GPU_MAX_HW_QUEUES=$1 depth $2: %.4f ms/pic = %.3f M CTB64/s (one at a time %.4f)' % (d['ms_per_step'], 510/d['ms_per_step']/1e3, d['ms_per_step_one_in_flight']))" | tee -a $OUT/c2_in_flight.txt; done
 timeout 300 python tools/diag_intra.py 1 3 2>>$OUT/bench.err | tee $OUT/diag_intra.txt
 bash tools/e2e.sh $OUT > /dev/null 2>&1; grep -A1 "t 8\|md5" $OUT/e2e.txt | grep -v "^--"
 find $OUT -name "*.db" -size +10M -delete; find $OUT -name "*counter_collection.csv" -size +10M -delete; find $OUT -name "*kernel_trace.csv" -size +10M -delete
