@@ -479,7 +479,9 @@ M355_API int m355_set_stages(m355_ctx* ctx, int stage_mask);
  * round n lanes (own streams, working planes, scratch) and overlap wherever the frames they touch allow: a decode
  * waits for the last writer of each reference frame it reads and, right before its own first write, for the last writer
  * and the readers of its destination frame.  (The reference decodes independent pictures concurrently too: frame-parallel
- * image units, decctx.cc:605-630.) */
+ * image units, decctx.cc:605-630.)  Three is the sweet spot for inter pictures; an all-intra stream (dependency-bound k_intra,
+ * a fraction of the GPU per picture) gains up to nine: intra pictures on lanes 3.. run on streams of other priority classes, which
+ * the HIP runtime gives hardware queues of their own (M355_LANE_PRIORITIES=0 turns that off). */
 M355_API int m355_set_pipeline_depth(m355_ctx* ctx, int depth);
 
 /* ------------------------------------------------------------------------------------------------
