@@ -1251,6 +1251,8 @@ LIBDE265_API int m355_glue_feature_counts(long long* out, int n)
   for (int k = 0; k < n && k < M355_GLUE_N_FEATURES; k++) out[k] = g_feat[k].load();
   return M355_GLUE_N_FEATURES;
 }
+/* output pictures whose download was started behind their decode (before the application asked) */
+LIBDE265_API long long m355_glue_prefetched_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); if (g) wait_submitted(g, 0xFFFFFFFFu); return g ? g->n_prefetched : -1; }
 LIBDE265_API long long m355_glue_hashed_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); if (g) wait_submitted(g, 0xFFFFFFFFu); return g ? g->n_hashed : -1; }
 LIBDE265_API long long m355_glue_rejected_pictures(de265_decoder_context* c) { Glue* g = glue_of((decoder_context*)c); if (g) wait_submitted(g, 0xFFFFFFFFu); return g ? g->n_rejected : -1; }
 LIBDE265_API int m355_glue_stats(de265_decoder_context* c, long long* pictures, long long* uploads, long long* downloads)

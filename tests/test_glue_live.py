@@ -39,15 +39,22 @@ def glue_lib():
     return lib
 
 
-def run(variant, threads, scalar=False, backend=None):
+def run(variant, threads, scalar=False, backend=None, prefetch=True):
     lib = glue_lib()
+    lib.m355_glue_prefetched_pictures.restype = ctypes.c_longlong
+    lib.m355_glue_prefetched_pictures.argtypes = [ctypes.c_void_p]
     stats = {}
 
     def grab(ctx):
         stats["ctx"] = ctx
 
+    def count(ctx):
+        stats["prefetched"] = lib.m355_glue_prefetched_pictures(ctx)
+
     data = open(STREAM, "rb").read()
-    md5, n, warnings = de265_py.decode_stream(lib, data, threads=threads, scalar=scalar, after_create=grab, **VARIANT[variant])
+    md5, n, warnings = de265_py.decode_stream(lib, data, threads=threads, scalar=scalar, after_create=grab, before_free=count, **VARIANT[variant])
+    # the application takes every picture: once the first one has been read, the downloads of the pictures submitted after that are started behind their decodes (unless switched off)
+    assert (stats["prefetched"] >= 20) if prefetch else (stats["prefetched"] == 0), stats
     assert n == 75 and not warnings
     assert md5 == MD5[variant], "live decode (%s, %d threads) differs from the reference's golden MD5" % (variant, threads)
     assert lib.m355_glue_cpu_pixel_calls() == 0, "the decoder called into its CPU pixel table"
@@ -60,6 +67,12 @@ def run(variant, threads, scalar=False, backend=None):
 def test_live_decode_emulated_backend(emu_lib, variant, threads, monkeypatch):  # noqa: F811
     monkeypatch.setenv("M355_LIB", EMU_SO)
     run(variant, threads, backend=EMU_SO)
+
+
+def test_live_decode_emulated_backend_without_download_prefetch(emu_lib, monkeypatch):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    monkeypatch.setenv("M355_GLUE_NO_PREFETCH", "1")
+    run("nolf", 2, backend=EMU_SO, prefetch=False)
 
 
 # ---- GPU tier ----
