@@ -220,7 +220,12 @@ struct Glue {
   double ms_main = 0;
   /* statistics (m355_glue_stats) */
   long long n_pictures = 0, n_uploads = 0, n_downloads = 0, n_hashed = 0;
+  std::vector<std::vector<m355_cu>> w_bcu;   /* scratch of the worker's metadata walk (submit_picture) */
+  std::vector<std::vector<m355_tu>> w_btu;
+  std::vector<m355_cu> w_cus;
+  std::vector<m355_tu> w_tus;
   double ms_walk = 0, ms_submit = 0, ms_download = 0;
+  double ms_phase[6] = {0, 0, 0, 0, 0, 0};   /* of ms_walk: headers + CTBs, CU / TU walk, merge + sort, PCM / intra reorder, copies into the arena, final copies */
   std::string error;
   Glue()
   {
@@ -486,16 +491,64 @@ int glue_threads()
   }
   return n;
 }
+/* persistent helper threads: a thread created per parallel phase costs this process 0.3-0.5 ms each while the parser's threads are
+   busy (stack mmap / clone against their page faults) — sixteen of them made the 8K metadata walk take 10 ms against 4 ms on one
+   thread (profiles/r03_z11_*) */
+struct TaskPool {
+  std::vector<std::thread> th;
+  std::mutex mu, run_mu;
+  std::condition_variable cv_go, cv_done;
+  const std::function<void(size_t)>* job = nullptr;
+  size_t n_tasks = 0;
+  std::atomic<size_t> next{0};
+  size_t done = 0;
+  int active = 0;                                              /* workers that hold the current job's function */
+  unsigned long long gen = 0;
+  bool stop = false;
+  explicit TaskPool(int workers) { for (int i = 0; i < workers; i++) th.emplace_back([this]() { work(); }); }
+  ~TaskPool() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
+  void drain(const std::function<void(size_t)>& f, size_t n)
+  {
+    size_t mine = 0;
+    for (;;) { const size_t i = next.fetch_add(1); if (i >= n) break; f(i); mine++; }
+    if (mine) { std::lock_guard<std::mutex> g(mu); done += mine; if (done >= n) cv_done.notify_all(); }
+  }
+  void work()
+  {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(size_t)>* f; size_t n;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&]() { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen; f = job; n = n_tasks;
+        if (f) active++;
+      }
+      if (f) {
+        drain(*f, n);
+        std::lock_guard<std::mutex> g(mu);
+        if (--active == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void run(size_t n, const std::function<void(size_t)>& f)
+  {
+    std::lock_guard<std::mutex> one(run_mu);                   /* one parallel phase at a time */
+    { std::lock_guard<std::mutex> g(mu); job = &f; n_tasks = n; next.store(0); done = 0; gen++; }
+    cv_go.notify_all();
+    drain(f, n);
+    std::unique_lock<std::mutex> lk(mu);
+    job = nullptr;                                             /* a worker that wakes up from here on takes nothing ... */
+    cv_done.wait(lk, [&]() { return done >= n && active == 0; });   /* ... and none still holds `f` when this returns */
+  }
+};
 void parallel_tasks(size_t n_tasks, const std::function<void(size_t)>& f)
 {
   const int T = (int)std::min<size_t>((size_t)glue_threads(), n_tasks);
   if (T <= 1) { for (size_t i = 0; i < n_tasks; i++) f(i); return; }
-  std::atomic<size_t> next(0);
-  auto work = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n_tasks) return; f(i); } };
-  std::vector<std::thread> th;
-  for (int t = 1; t < T; t++) th.emplace_back(work);
-  work();
-  for (auto& t : th) t.join();
+  static TaskPool* pool = new TaskPool(glue_threads() - 1);    /* lives until process exit */
+  pool->run(n_tasks, f);
 }
 
 bool submit_picture(Glue* g, Glue::Job& job)
@@ -504,6 +557,8 @@ bool submit_picture(Glue* g, Glue::Job& job)
   Api* A = api();
   decoder_context* d = g->dctx;
   const auto t0 = std::chrono::steady_clock::now();
+  auto tp = t0;
+  auto lap = [&](int k) { const auto n = std::chrono::steady_clock::now(); g->ms_phase[k] += std::chrono::duration<double, std::milli>(n - tp).count(); tp = n; };
   const seq_parameter_set& sps = img->get_sps();
   const pic_parameter_set& pps = img->get_pps();
 
@@ -562,9 +617,13 @@ bool submit_picture(Glue* g, Glue::Job& job)
       if (img->get_CTB_has_pcm_or_cu_transquant_bypass(x, y)) c.flags |= M355_CTBF_HAS_PCM_OR_BYPASS;
     }
 
+  lap(0);
   /* ---- coding units + transform-tree leaves (image.h:173-195, deblock.cc:33-63) ---- */
-  std::vector<m355_cu> cus;
-  std::vector<m355_tu> tus;
+  /* (the walk's vectors live in the Glue and keep their capacity from picture to picture: growing sixty vectors on sixteen
+     threads at once made the parallel walk slower than a serial one — 10 ms against 5 ms per 8K picture, the allocator and the
+     kernel's page-table lock serialise it —, profiles/r03_z11_*) */
+  std::vector<m355_cu>& cus = g->w_cus; cus.clear();
+  std::vector<m355_tu>& tus = g->w_tus; tus.clear();
   std::vector<uint32_t> pcm_cus;
   const int minCb = sps.MinCbSizeY;
   long long covered = 0;
@@ -572,12 +631,14 @@ bool submit_picture(Glue* g, Glue::Job& job)
     /* bands of min-CB rows, walked in parallel, concatenated in raster order */
     const int rows = sps.PicHeightInMinCbsY, per = std::max(1, (rows + 4 * glue_threads() - 1) / (4 * glue_threads()));
     const size_t nb = (size_t)((rows + per - 1) / per);
-    std::vector<std::vector<m355_cu>> bcu(nb);
-    std::vector<std::vector<m355_tu>> btu(nb);
+    std::vector<std::vector<m355_cu>>& bcu = g->w_bcu;
+    std::vector<std::vector<m355_tu>>& btu = g->w_btu;
+    if (bcu.size() < nb) { bcu.resize(nb); btu.resize(nb); }
     std::vector<long long> bcov(nb, 0);
     parallel_tasks(nb, [&](size_t b) {
-      std::vector<m355_cu>& vc = bcu[b];
-      std::vector<m355_tu>& vt = btu[b];
+      std::vector<m355_cu>& vc = bcu[b]; vc.clear();
+      std::vector<m355_tu>& vt = btu[b]; vt.clear();
+      long long cov = 0;
       for (int cy = (int)b * per; cy < rows && cy < ((int)b + 1) * per; cy++)
         for (int cx = 0; cx < sps.PicWidthInMinCbsY; cx++) {
           const int l2 = img->get_log2CbSize_cbUnits(cx, cy);
@@ -591,9 +652,10 @@ bool submit_picture(Glue* g, Glue::Job& job)
           if (img->get_pcm_flag(x0, y0)) cu.flags |= M355_CUF_PCM;
           if (img->get_cu_transquant_bypass(x0, y0)) cu.flags |= M355_CUF_TRANSQUANT_BYPASS;
           vc.push_back(cu);
-          bcov[b] += 1ll << (2 * l2);
+          cov += 1ll << (2 * l2);
           walk_tu(img, x0, y0, l2, 0, vt);
         }
+      bcov[b] = cov;
     });
     size_t ncu = 0, ntu = 0;
     for (size_t b = 0; b < nb; b++) { ncu += bcu[b].size(); ntu += btu[b].size(); covered += bcov[b]; }
@@ -602,6 +664,7 @@ bool submit_picture(Glue* g, Glue::Job& job)
     for (size_t i = 0; i < cus.size(); i++) if (cus[i].flags & M355_CUF_PCM) { pcm_cus.push_back((uint32_t)i); any_pcm = true; }
   }
 
+  lap(1);
   /* ---- concatenate the threads' lists ---- */
   const std::vector<ThreadRec*>& recs = job.recs;          /* (empty: a picture without a single coded block) */
   size_t n_pb = 0, n_ib = 0, n_co = 0, n_rb[4] = {0, 0, 0, 0};
@@ -642,6 +705,7 @@ bool submit_picture(Glue* g, Glue::Job& job)
     }
   }
 
+  lap(2);
   /* Where the lists go.  Normally straight into the backend's pinned arena (m355_arena_begin: the submit then copies nothing
      and checks the records on the device); pictures with PCM units (their raw blocks are merged into the intra lists below)
      and M355_GLUE_COPY=1 take the copying m355_submit_picture through host vectors. */
@@ -711,6 +775,7 @@ bool submit_picture(Glue* g, Glue::Job& job)
       }
     });
   }
+  lap(3);
   if (any_pcm) {
     /* PCM coding units (slice.cc:4211-4255): the parser has stored the raw samples in the host planes (bitstream reading,
        not arithmetic); lift them into pcm[] and list one raw block per component at the unit's place in decode order */
@@ -781,6 +846,7 @@ bool submit_picture(Glue* g, Glue::Job& job)
     }
   }
 
+  lap(4);
   /* ---- frames: destination + every DPB slot a prediction block reads ---- */
   if (!api_lock.owns_lock()) api_lock.lock();
   const int dslot = job.dslot;
@@ -843,6 +909,7 @@ bool submit_picture(Glue* g, Glue::Job& job)
     pic.wts = wts.data(); pic.rbs = rbs.data(); pic.ibs = ibs.data(); pic.coeffs = coeffs.data(); pic.pcm = pcm.data();
   }
 
+  lap(5);
   const auto t1 = std::chrono::steady_clock::now();
   const int rc = A->m355_submit_picture(g->mctx, &pic);
   const auto t2 = std::chrono::steady_clock::now();
@@ -1217,6 +1284,9 @@ LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)
     fprintf(stderr, "m355 glue: %lld pictures submitted, %lld uploaded, %lld downloaded; host ms per picture: on the decoder's thread %.3f, on the worker: lists %.3f, submit %.3f; download %.3f ms each; cpu pixel calls %lld\n",
             g->n_pictures, g->n_uploads, g->n_downloads, g->n_pictures ? g->ms_main / g->n_pictures : 0.0, g->n_pictures ? g->ms_walk / g->n_pictures : 0.0, g->n_pictures ? g->ms_submit / g->n_pictures : 0.0,
             g->n_downloads ? g->ms_download / g->n_downloads : 0.0, g_cpu_pixel_calls.load());
+  if (g && getenv("M355_GLUE_STATS") && atoi(getenv("M355_GLUE_STATS")) >= 2 && g->n_pictures)
+    fprintf(stderr, "m355 glue: lists per picture: headers + CTBs %.3f, CU / TU walk %.3f, merge + sort %.3f, arena + block lists %.3f, PCM + weights %.3f, frames + small lists %.3f ms\n",
+            g->ms_phase[0] / g->n_pictures, g->ms_phase[1] / g->n_pictures, g->ms_phase[2] / g->n_pictures, g->ms_phase[3] / g->n_pictures, g->ms_phase[4] / g->n_pictures, g->ms_phase[5] / g->n_pictures);
   const de265_error e = m355ref_de265_free_decoder(c);      /* releases the images into the pool */
   if (g) {
     { std::lock_guard<std::mutex> lk(g->job_mu); g->stop = true; }
