@@ -2007,10 +2007,16 @@ int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
   /* the lists travel on the stream of the lane that decodes them: the copy of picture k runs beside the kernels of
      picture k-1 on the previous lane (uploading on the lane that is still active would queue it BEHIND those kernels) */
   if (c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);
+  static const bool prof = getenv("M355_PROFILE_UPLOAD") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = upload(c, t, pic);
   t.arena = false;                                          /* pointers handed out by m355_arena_begin are spent */
   if (rc) return rc;
-  return decode(c, t, false);
+  const auto t1 = std::chrono::steady_clock::now();
+  rc = decode(c, t, false);
+  if (prof) fprintf(stderr, "m355 submit: upload (host phases + copy enqueue) %.3f ms, decode enqueue %.3f ms\n",
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  return rc;
 }
 
 int m355_wait(m355_ctx* c)
