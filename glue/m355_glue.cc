@@ -68,6 +68,8 @@ extern "C" {
 de265_decoder_context* m355ref_de265_new_decoder(void);
 de265_error m355ref_de265_free_decoder(de265_decoder_context*);
 const uint8_t* m355ref_de265_get_image_plane(const struct de265_image*, int, int*);
+void m355ref_de265_set_parameter_bool(de265_decoder_context*, enum de265_param, int);
+int m355ref_de265_get_parameter_bool(de265_decoder_context*, enum de265_param);
 }
 
 namespace {
@@ -215,6 +217,12 @@ struct Glue {
   std::deque<Job> jobs;
   bool busy = false, stop = false, sync_submit = false;
   uint32_t busy_id = 0xFFFFFFFFu;
+  uint32_t busy_dpb_id[M355_MAX_REF_FRAMES];    /* the DPB snapshot of the job the worker is running */
+  /* DE265_DECODER_PARAM_DISABLE_SAO as the application set it.  The decoder's own param_disable_sao is kept TRUE: that is what
+     makes decctx.cc:1928 allocate every picture through de265_set_image_allocation_functions (pinned planes, and the release hook
+     below that keeps the DPB from recycling an image the worker still reads) — with SAO on, the reference decodes into a private
+     image and lets apply_sample_adaptive_offset write the output one; here SAO runs on the device and there is only one. */
+  bool user_disable_sao = false;
   std::thread worker;
   std::vector<int> deferred_warnings;       /* raised by the worker, handed to the decoder on its own thread */
   double ms_main = 0;
@@ -250,7 +258,7 @@ Glue* glue_of(const decoder_context* d)
 }
 
 void install_traps(acceleration_functions& a);
-void wait_submitted(Glue* g, uint32_t id);
+void wait_submitted(Glue* g, uint32_t id, bool also_as_reference = false);
 void flush_warnings(Glue* g);
 
 /* the calling thread's lists for the picture `img` */
@@ -343,7 +351,8 @@ int glue_get_buffer(de265_decoder_context* ctx, de265_image_spec* spec, de265_im
 void glue_release_buffer(de265_decoder_context* ctx, de265_image* img, void* userdata)
 {
   Glue* g = (Glue*)userdata;
-  wait_submitted(g, img->get_ID());               /* the DPB recycles the image (dpb.cc:206-216): the worker may still be walking its metadata */
+  wait_submitted(g, img->get_ID(), true);         /* the DPB recycles the image (dpb.cc:206-216): the worker may still be walking its metadata,
+                                                     or reading it as a reference of a later picture's job */
   {
     /* a download started behind the picture's decode that nobody waited for (the application never looked at the picture): it must
        have landed before the planes go back to the pool — the next image's parser may write PCM samples into them */
@@ -556,6 +565,8 @@ bool submit_picture(Glue* g, Glue::Job& job)
   de265_image* img = job.img;
   Api* A = api();
   decoder_context* d = g->dctx;
+  /* (the release hook keeps the DPB from recycling an image with a job in the queue: glue_release_buffer) */
+  if (img->get_ID() != job.id) { g->error = "the picture's image was recycled before its submit step ran"; return false; }
   const auto t0 = std::chrono::steady_clock::now();
   auto tp = t0;
   auto lap = [&](int k) { const auto n = std::chrono::steady_clock::now(); g->ms_phase[k] += std::chrono::duration<double, std::milli>(n - tp).count(); tp = n; };
@@ -574,7 +585,7 @@ bool submit_picture(Glue* g, Glue::Job& job)
   if (sps.strong_intra_smoothing_enable_flag) pp.flags |= M355_PF_STRONG_INTRA_SMOOTHING;
   if (sps.pcm_loop_filter_disable_flag) pp.flags |= M355_PF_PCM_LOOP_FILTER_DISABLE;
   if (pps.loop_filter_across_tiles_enabled_flag) pp.flags |= M355_PF_LF_ACROSS_TILES;
-  if (sps.sample_adaptive_offset_enabled_flag && !d->param_disable_sao) pp.flags |= M355_PF_SAO_ENABLED;
+  if (sps.sample_adaptive_offset_enabled_flag && !g->user_disable_sao) pp.flags |= M355_PF_SAO_ENABLED;
   if (sps.range_extension.intra_smoothing_disabled_flag) pp.flags |= M355_PF_INTRA_SMOOTHING_DISABLED;
   if (sps.range_extension.implicit_rdpcm_enabled_flag) pp.flags |= M355_PF_IMPLICIT_RDPCM;
   if (sps.range_extension.transform_skip_rotation_enabled_flag) pp.flags |= M355_PF_TRANSFORM_SKIP_ROTATION;
@@ -956,6 +967,7 @@ void worker_main(Glue* g)
     Glue::Job job = std::move(g->jobs.front());
     g->jobs.pop_front();
     g->busy = true; g->busy_id = job.id;
+    memcpy(g->busy_dpb_id, job.dpb_id, sizeof(g->busy_dpb_id));
     lk.unlock();
     run_job(g, job);
     lk.lock();
@@ -966,13 +978,19 @@ void worker_main(Glue* g)
 
 /* wait until the worker is done with picture `id` (0xFFFFFFFF: with everything): whoever is about to touch the picture's device
    frame, its host planes or its metadata arrays (application, SEI check, the DPB recycling the image) comes through here */
-void wait_submitted(Glue* g, uint32_t id)
+void wait_submitted(Glue* g, uint32_t id, bool also_as_reference)
 {
   std::unique_lock<std::mutex> lk(g->job_mu);
   g->idle_cv.wait(lk, [&]() {
     if (id == 0xFFFFFFFFu) return g->jobs.empty() && !g->busy;
     if (g->busy && g->busy_id == id) return false;
     for (const Glue::Job& j : g->jobs) if (j.id == id) return false;
+    if (also_as_reference) {
+      /* the submit step of a LATER picture reads this one through its DPB snapshot (integrity, host planes of a picture that
+         has to be re-uploaded): the image must outlive those jobs too */
+      if (g->busy) for (int s = 0; s < M355_MAX_REF_FRAMES; s++) if (g->busy_dpb_id[s] == id) return false;
+      for (const Glue::Job& j : g->jobs) for (int s = 0; s < M355_MAX_REF_FRAMES; s++) if (j.dpb_id[s] == id) return false;
+    }
     return true;
   });
 }
@@ -1242,6 +1260,7 @@ LIBDE265_API de265_decoder_context* de265_new_decoder()
   if (!c) return nullptr;
   Glue* g = new Glue;
   g->dctx = (decoder_context*)c;
+  g->dctx->param_disable_sao = true;              /* (Glue::user_disable_sao holds the application's setting) */
   int dev = 0;
   if (const char* e = getenv("M355_DEVICE")) dev = atoi(e);
   if (A->m355_create(dev, &g->mctx) != M355_OK) {
@@ -1261,6 +1280,20 @@ LIBDE265_API de265_decoder_context* de265_new_decoder()
   g_glues.push_back(g);
   g_reg_gen++;
   return c;
+}
+
+/* de265.cc:515-560 / 589-620, with DISABLE_SAO kept in the glue (see Glue::user_disable_sao) */
+LIBDE265_API void de265_set_parameter_bool(de265_decoder_context* c, enum de265_param param, int value)
+{
+  Glue* g = glue_of((decoder_context*)c);
+  if (g && param == DE265_DECODER_PARAM_DISABLE_SAO) { g->user_disable_sao = !!value; return; }
+  m355ref_de265_set_parameter_bool(c, param, value);
+}
+LIBDE265_API int de265_get_parameter_bool(de265_decoder_context* c, enum de265_param param)
+{
+  Glue* g = glue_of((decoder_context*)c);
+  if (g && param == DE265_DECODER_PARAM_DISABLE_SAO) return g->user_disable_sao;
+  return m355ref_de265_get_parameter_bool(c, param);
 }
 
 LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)

@@ -600,6 +600,26 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
   const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
 
+  /* fused residual (k_common.h res_map): the map entries of the job's two luma units and of its chroma piece are requested
+     here, beside the PB record's dependants; the residual rows themselves behind the last list's filter */
+  uint32_t e0 = 0, e1 = 0, ec1 = 0, ec2 = 0, ec1b = 0, ec2b = 0;
+  if (p.res_map) {
+    const uint32_t* m = p.res_map + (size_t)(y0 >> 2) * p.res_map_w[0] + (x0 >> 2);
+    e0 = m[0];
+    if (rows > 4) e1 = m[p.res_map_w[0]];
+    if (nc == 3) {
+      /* 4:2:0: the 2 x (rows / 2) chroma piece lies in unit (x0 >> 3, y0 >> 3); a job that starts on an odd multiple of 4
+         (PBs of asymmetric partitions) reaches two rows into the unit below */
+      const size_t cu = (size_t)(y0 >> 3) * p.res_map_w[1] + (x0 >> 3);
+      ec1 = p.res_map[p.res_map_ofs[1] + cu];
+      ec2 = p.res_map[p.res_map_ofs[2] + cu];
+      if (((y0 >> 1) & 3) + (rows >> 1) > 4) {
+        ec1b = p.res_map[p.res_map_ofs[1] + cu + p.res_map_w[1]];
+        ec2b = p.res_map[p.res_map_ofs[2] + cu + p.res_map_w[1]];
+      }
+    }
+  }
+
   /* weights of the job's component c (WtSel above); the two records are fetched once per job */
   m355_wt wa, wb;
   if (weighted) { wa = p.wts[wtA]; wb = p.wts[wtB]; }
@@ -645,6 +665,24 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
         continue;
       }
+      /* residual rows of the two units (4 int16 each; tile pitch nT), clip(pred + res) as add_residual (fallback-dct.h:65-73) */
+      unsigned rs[8][2];
+#pragma unroll
+      for (int y = 0; y < 8; y++) { rs[y][0] = 0; rs[y][1] = 0; }
+      if ((e0 | e1) >> 31) {
+        if (e0 >> 31) {
+          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e0 & 0x0FFFFFFFu) << 2);
+          const int nt = 4 << ((e0 >> 28) & 3);
+#pragma unroll
+          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[y]);
+        }
+        if (e1 >> 31) {
+          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e1 & 0x0FFFFFFFu) << 2);
+          const int nt = 4 << ((e1 >> 28) & 3);
+#pragma unroll
+          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[4 + y]);
+        }
+      }
 #pragma unroll
       for (int y = 0; y < 8; y++) {
         if (y >= rows) break;
@@ -653,6 +691,7 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         for (int x = 0; x < 4; x++) {
           const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
           o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
+          o[x] = (unsigned)d_clip_bd((int)o[x] + ((x & 1) ? d_hi16s(rs[y][x >> 1]) : d_lo16s(rs[y][x >> 1])), bd);
         }
         /* streaming stores (k_asm.h): -4 % kernel time, -10 % fabric fetch (profiles/r02_b_inter_variants.txt) */
         if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0] | (o[1] << 16), o[2] | (o[3] << 16));
@@ -692,18 +731,39 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
         continue;
       }
+      /* residual: the job's 2 x crows piece of each plane (unit-local position (xc & 3, yc & 3), see the map lookup above) */
+      unsigned rc1[4], rc2[4];
+#pragma unroll
+      for (int y = 0; y < 4; y++) { rc1[y] = 0; rc2[y] = 0; }
+      if ((ec1 | ec2 | ec1b | ec2b) >> 31) {
+        const int ly = yc & 3;
+        auto piece = [&](uint32_t ea, uint32_t eb, unsigned* rc) {
+          const int nta = 4 << ((ea >> 28) & 3), ntb = 4 << ((eb >> 28) & 3);
+          const M355_GLOBAL int16_t* ra = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(ea & 0x0FFFFFFFu) << 2) + (xc & 3);
+          const M355_GLOBAL int16_t* rb = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(eb & 0x0FFFFFFFu) << 2) + (xc & 3);
+#pragma unroll
+          for (int y = 0; y < 4; y++) {
+            if (y >= crows) break;
+            const int l = ly + y;
+            if (l < 4) { if (ea >> 31) rc[y] = d_ldg4(ra + l * nta); }
+            else if (eb >> 31) rc[y] = d_ldg4(rb + (l - 4) * ntb);
+          }
+        };
+        piece(ec1, ec1b, rc1);
+        piece(ec2, ec2b, rc2);
+      }
 #pragma unroll
       for (int y = 0; y < 4; y++) {
         if (y >= crows) break;
         {
           const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
-          const unsigned o0 = (unsigned)d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd);
+          const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc1[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc1[y]), bd);
           if (sizeof(PIX) == 2) d_st_nt4(d1 + (size_t)y * p.stride[1], o0 | (o1 << 16));
           else *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)(o0 | (o1 << 8));
         }
         {
           const unsigned a = bi ? pa2[y] : cur2[y], b = cur2[y];
-          const unsigned o0 = (unsigned)d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd);
+          const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc2[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc2[y]), bd);
           if (sizeof(PIX) == 2) d_st_nt4(d2 + (size_t)y * p.stride[2], o0 | (o1 << 16));
           else *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)(o0 | (o1 << 8));
         }

@@ -217,7 +217,7 @@ __device__ __forceinline__ m355_rb d_rb_idle(int log2)
   return rb;
 }
 
-template <int LOG2, class PIX>
+template <int LOG2, class PIX, bool FUSED>
 __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb* rbs, int rb_n, int group, uint32_t* smem)
 {
   constexpr int NT = 1 << LOG2;
@@ -243,8 +243,16 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   uint32_t w[NVP];
 #pragma unroll
   for (int i = 0; i < NVP; i++) w[i] = 0;
-  const bool rmw = active && !(rb.flags & M355_RBF_DEFERRED);
+  const bool rmw = !FUSED && active && !(rb.flags & M355_RBF_DEFERRED);
   PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
+  /* FUSED: a block of an inter CU is handed to k_inter_jobs' write-back as a compact int16 tile (k_common.h, res_map); the lane
+     of every fourth row marks the row of 4x4 units it starts — fire and forget, ahead of the coefficient fetch */
+  const uint32_t fused_ofs = FUSED ? p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT : 0u;
+  if (FUSED && active && !(rb.flags & M355_RBF_DEFERRED) && (c & 3) == 0) {
+    uint32_t* m = p.res_map + p.res_map_ofs[rb.cidx] + (size_t)((rb.y + c) >> 2) * p.res_map_w[rb.cidx] + (rb.x >> 2);
+#pragma unroll
+    for (int u = 0; u < NT / 4; u++) m[u] = 0x80000000u | ((uint32_t)(LOG2 - 2) << 28) | ((fused_ofs >> 2) + u);
+  }
   if (rmw) {
     if (sizeof(PIX) == 2) {
       if (NT >= 8) {
@@ -290,8 +298,8 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
 
   if (!active) return;
   const int y = c;
-  if (rb.flags & M355_RBF_DEFERRED) {
-    int16_t* out = p.resbuf + rb.res_ofs + y * NT;
+  if (FUSED || (rb.flags & M355_RBF_DEFERRED)) {
+    int16_t* out = p.resbuf + ((FUSED && !(rb.flags & M355_RBF_DEFERRED)) ? fused_ofs : rb.res_ofs + y * NT);
 #pragma unroll
     for (int i = 0; i < NT; i += 2) *(uint32_t*)(out + i) = res_pack(d_clip3(-32768, 32767, res[i]), d_clip3(-32768, 32767, res[i + 1]));
   } else {
@@ -326,19 +334,27 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
  * 3 the 32-point transform's registers would impose on every size).  The stage is a chain of dependent round trips per wave —
  * record, coefficient pairs, destination rows — so resident waves are what hides it.  Larger size first within each launch. */
 #define RES_LDS_DWORDS_SMALL (8 * RES_WPG * (4 * 8 + 8 * 5))   /* 8x8: 8 blocks per wave (4x4: 16 x 20 dwords fit too) */
-template <class PIX, bool BIG>
+template <class PIX, bool BIG, bool FUSED>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual(DevPic p, int ng_hi)
 {
   M355_GATE(p);
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
   const int g = blockIdx.x;
   if (BIG) {
-    if (g < ng_hi) d_residual_group<5, PIX>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
-    else d_residual_group<4, PIX>(p, p.rb_bin[2], p.rb_count[2], g - ng_hi, s_buf);
+    if (g < ng_hi) d_residual_group<5, PIX, FUSED>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
+    else d_residual_group<4, PIX, FUSED>(p, p.rb_bin[2], p.rb_count[2], g - ng_hi, s_buf);
   } else {
-    if (g < ng_hi) d_residual_group<3, PIX>(p, p.rb_bin[1], p.rb_count[1], g, s_buf);
-    else d_residual_group<2, PIX>(p, p.rb_bin[0], p.rb_count[0], g - ng_hi, s_buf);
+    if (g < ng_hi) d_residual_group<3, PIX, FUSED>(p, p.rb_bin[1], p.rb_count[1], g, s_buf);
+    else d_residual_group<2, PIX, FUSED>(p, p.rb_bin[0], p.rb_count[0], g - ng_hi, s_buf);
   }
+}
+
+template <class PIX, bool BIG>
+static void launch_res(const DevPic& p, int n, int ng_hi, hipStream_t st)
+{
+  const dim3 blk(64 * RES_WPG);
+  if (p.res_map) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, true>), dim3(n), blk, 0, st, p, ng_hi);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, false>), dim3(n), blk, 0, st, p, ng_hi);
 }
 
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)
@@ -346,13 +362,12 @@ void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)
   /* blocks per workgroup: RES_WPG waves * 64/nT */
   auto groups = [](int n, int per_wave) { return (n + per_wave * RES_WPG - 1) / (per_wave * RES_WPG); };
   const int ng2 = groups(p.rb_count[0], 16), ng3 = groups(p.rb_count[1], 8), ng4 = groups(p.rb_count[2], 4), ng5 = groups(p.rb_count[3], 2);
-  const dim3 blk(64 * RES_WPG);
   if (big && ng5 + ng4) {
-    if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint16_t, true>), dim3(ng5 + ng4), blk, 0, st, p, ng5);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint8_t, true>), dim3(ng5 + ng4), blk, 0, st, p, ng5);
+    if (hbd) launch_res<uint16_t, true>(p, ng5 + ng4, ng5, st);
+    else launch_res<uint8_t, true>(p, ng5 + ng4, ng5, st);
   }
   if (!big && ng3 + ng2) {
-    if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint16_t, false>), dim3(ng3 + ng2), blk, 0, st, p, ng3);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<uint8_t, false>), dim3(ng3 + ng2), blk, 0, st, p, ng3);
+    if (hbd) launch_res<uint16_t, false>(p, ng3 + ng2, ng3, st);
+    else launch_res<uint8_t, false>(p, ng3 + ng2, ng3, st);
   }
 }

@@ -155,7 +155,8 @@ struct Lane {
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;   /* border plans of the picture's intra blocks */
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0;
+  uint32_t* res_map = nullptr; /* fused inter residuals: per component 4x4 unit -> tile piece (k_common.h) */
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0;
 };
 
 struct m355_ctx {
@@ -182,7 +183,8 @@ struct m355_ctx {
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0;
+  uint32_t* res_map = nullptr;
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0;
   uint32_t epoch = 0;
   /* per-decode status (m355_decode_status): the last M355_STATUS_RING decodes; a device-validated decode copies its lane's gate
      words into `words` (pinned) behind its last kernel */
@@ -195,13 +197,14 @@ struct m355_ctx {
   m355_comm comm = {nullptr, nullptr, nullptr};   /* exchanges of m355_decode_sharded */
   void* rccl = nullptr;              /* built-in RCCL communicator (m355_shard_rccl_init) */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
+  std::vector<uint8_t> ev_fused;   /* per timed decode: the residual stage ran first (launch_prediction) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
 };
 
 #define LANE_FIELDS(X) X(stream) X(stream2) X(stream_hi) X(last_stream) X(ev_last) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
-  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
+  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(res_map) X(cap_resmap) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
 static void select_lane(m355_ctx* c, int lane)
 {
   if (lane == c->active) return;
@@ -255,7 +258,7 @@ static void lane_destroy(Lane& l)
   if (l.stream) hipStreamSynchronize(l.stream);
   if (l.stream2) hipStreamSynchronize(l.stream2);
   if (l.work.used) frame_free(l.work);
-  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb, l.iplan};
+  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb, l.iplan, l.res_map};
   for (void* b : bufs) if (b) hipFree(b);
   if (l.ev_fork) hipEventDestroy(l.ev_fork);
   if (l.ev_fork2) hipEventDestroy(l.ev_fork2);
@@ -1453,7 +1456,31 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
     if ((rc = grow(&c->edge, &c->cap_edge, n + 1, c->stream, true))) return rc;
   }
   if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + (size_t)r.halo.n_units + 1, c->stream, false))) return rc;
-  if ((rc = grow(&c->resbuf, &c->cap_res, (size_t)pic.res_len + 1, c->stream, false))) return rc;
+  /* Fused inter residuals (k_common.h res_map): whenever k_inter_jobs runs, k_residual hands the blocks of inter CUs over as int16
+     tiles behind the deferred (intra) ones instead of read-modify-writing the picture.  Not for 16-bit samples (a residual of
+     transform_idct_add, fallback-dct.cc:550-691, needs 18 bits there), not for the generic kernel's chroma formats, not when a
+     stage is isolated. */
+  static const bool fused_env = !(getenv("M355_RES_FUSED") && atoi(getenv("M355_RES_FUSED")) == 0);
+  const bool fused = fused_env && pic.n_pbs > 0 && pp.chroma_format_idc <= 1 && pp.bit_depth_luma < 16 && pp.bit_depth_chroma < 16 &&
+                     (c->stages & M355_STAGE_INTER) && (c->stages & M355_STAGE_RESIDUAL) &&
+                     (pic.rb_count[0] | pic.rb_count[1] | pic.rb_count[2] | pic.rb_count[3]);
+  size_t res_need = (size_t)pic.res_len + 1;
+  d.res_map = nullptr;
+  if (fused) {
+    size_t base = ((size_t)pic.res_len + 15) & ~(size_t)15;
+    for (int s = 0; s < 4; s++) { d.res_fused_base[s] = (uint32_t)base; base += (size_t)pic.rb_count[s] << (2 * (s + 2)); }
+    if (base >= ((size_t)1 << 30)) return fail(M355_ERR_INVALID, "residual blocks exceed the fused residual buffer");
+    res_need = base + 1;
+    size_t n = 0;
+    for (int cc = 0; cc < (pp.chroma_format_idc ? 3 : 1); cc++) {
+      d.res_map_ofs[cc] = (uint32_t)n; d.res_map_w[cc] = (dst->pw[cc] + 3) >> 2;
+      n += (size_t)d.res_map_w[cc] * ((dst->ph[cc] + 3) >> 2);
+    }
+    if ((rc = grow(&c->res_map, &c->cap_resmap, n + 1, c->stream, false))) return rc;
+    d.res_map = c->res_map;
+    d.res_map_words = (uint32_t)n;
+  }
+  if ((rc = grow(&c->resbuf, &c->cap_res, res_need, c->stream, false))) return rc;
   if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
   if ((rc = grow(&c->jobs, &c->cap_jobs, (size_t)r.n_jobs + 1, c->stream, false))) return rc;
   if ((rc = grow(&c->iplan, &c->cap_iplan, (size_t)r.n_iplan + 8, c->stream, false))) return rc;
@@ -1522,29 +1549,40 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
      CTB64/s at depth 9 (profiles/r03_v_*; forked: 0.59 at depth 8) */
   static const bool single_env = !(getenv("M355_DENSE_SINGLE_STREAM") && atoi(getenv("M355_DENSE_SINGLE_STREAM")) == 0);
   const bool single = single_env && d.intra_dense;
+  const bool fused = d.res_map != nullptr;   /* prepare(): the residuals of inter CUs are added in k_inter_jobs' write-back */
   hipStream_t s2 = single ? st : c->stream2;
+  if (fused) hipMemsetAsync(d.res_map, 0, (size_t)d.res_map_words * 4, st);
   if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
+  if (fused) {
+    /* the residual stage reads nothing but the lists: it runs FIRST, side by side on the lane's two streams, beside the tail of
+       the previous picture; its event order is [residual, meta, inter] (m355_timing_collect) */
+    m355_launch_residual(d, hbd, false, s2);
+    if (!single) hipEventRecord(c->ev_fork2, s2);
+    m355_launch_residual(d, hbd, true, st);
+    if (ev) hipEventRecord(ev[1], st);
+  }
   m355_launch_meta_planes(d, s2);
   if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, s2);   /* reads the CU plane (constrained intra prediction) */
   m355_launch_meta_jobs(d, st);
-  if (ev) hipEventRecord(ev[1], st);
+  if (ev) hipEventRecord(ev[fused ? 2 : 1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
-     reference — the list copy, validation, metadata planes and job list of a picture run beside the tail (filters) of the picture
-     it references */
+     reference — the list copy, validation, metadata planes, job list (and fused residuals) of a picture run beside the tail
+     (filters) of the picture it references */
   if (c->depth >= 2)
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
       if (f && f->wr_pending) hipStreamWaitEvent(st, f->ev_wr, 0);
     }
+  if (fused && !single) hipStreamWaitEvent(st, c->ev_fork2, 0);   /* the 8x8 + 4x4 tiles */
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
-  if (ev) hipEventRecord(ev[2], st);
-  if (c->stages & M355_STAGE_RESIDUAL) {
+  if (ev) hipEventRecord(ev[fused ? 3 : 2], st);
+  if (!fused && (c->stages & M355_STAGE_RESIDUAL)) {
     if (!single) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }   /* inter residuals are added to the prediction samples */
     m355_launch_residual(d, hbd, false, s2);
     m355_launch_residual(d, hbd, true, st);
   }
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
-  if (ev) hipEventRecord(ev[3], st);
+  if (!fused && ev) hipEventRecord(ev[3], st);
   if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
   if (ev) hipEventRecord(ev[4], st);
 }
@@ -1589,6 +1627,8 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
   while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
   hipEvent_t* ev = &c->evs[c->ev_used * 7];
+  if ((int)c->ev_fused.size() <= c->ev_used) c->ev_fused.resize(c->ev_used + 1);
+  c->ev_fused[c->ev_used] = d.res_map != nullptr;
   c->ev_used++;
   hipEventRecord(ev[0], st);
   if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
@@ -1635,6 +1675,16 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   hipEventRecord(c->ev_last, st); c->last_stream = st;        /* (the lane's next decode may run on the lane's other stream) */
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  {
+    /* M355_DEBUG_TIMEOUT=1: name the decode whose intra stage gave up a wait (diagnostic: serialises the pipeline) */
+    static const bool dbg = getenv("M355_DEBUG_TIMEOUT") && atoi(getenv("M355_DEBUG_TIMEOUT"));
+    if (dbg) {
+      hipStreamSynchronize(st);
+      uint32_t t = 0;
+      hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost);
+      if (t) fprintf(stderr, "m355: decode %llu (epoch %u, %d pbs, %d ibs, %d cus, lane %d): intra wait gave up\n", c->serial, d.epoch, d.n_pbs, d.n_ibs, d.n_cus, c->active);
+    }
+  }
   return M355_OK;
 }
 
@@ -2082,7 +2132,10 @@ int m355_timing_collect(m355_ctx* c, int* n_decodes, float* total_ms, float stag
     hipEvent_t* ev = &c->evs[k * 7];
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[6])); tot += ms;
-    for (int i = 0; i < 6; i++) { HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); st[i] += ms; }
+    /* stage order of the events: [meta, inter, residual, intra, deblock, sao], or with fused residuals [residual, meta, inter, ...] */
+    static const int order[2][6] = {{0, 1, 2, 3, 4, 5}, {2, 0, 1, 3, 4, 5}};
+    const int* o = order[k < (int)c->ev_fused.size() && c->ev_fused[k] ? 1 : 0];
+    for (int i = 0; i < 6; i++) { HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); st[o[i]] += ms; }
   }
   if (n_decodes) *n_decodes = c->ev_used;
   if (total_ms) *total_ms = (float)(tot / c->ev_used);

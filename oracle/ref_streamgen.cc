@@ -37,6 +37,19 @@
  *               slice.cc:3940-3960, chroma prediction modes slice.cc:4537-4575)
  *   slices      slice segments per picture, each with its own deblocking override (disable flag, beta / tc offsets),
  *               SAO flags, loop-filter-across-slices flag and QP (slice.cc:750-826)
+ *   F_RA        a random-access stream shape (the offline stand-in for the ra_main conformance streams): hierarchical-B groups of
+ *               8 pictures coded in the order 8 4 2 1 3 6 5 7 (output order != decoding order, sps_max_num_reorder_pics 3:
+ *               decctx.cc:1885-2035, dpb.cc:194-281), every picture's reference picture set written in its slice header
+ *               (st_ref_pic_set, refpic.cc:85-260: pictures before AND after the current one, some kept but not used), four
+ *               active references per list out of 1..6 pictures (cyclic list construction, decctx.cc:1550-1700), odd pictures
+ *               are sub-layer non-reference pictures (TRAIL_N)
+ *   F_LT        (with F_RA) the IDR picture becomes a long-term reference from the third group on (slice.cc:517-598, lt_idx /
+ *               poc_lsb_lt / used_by_curr_pic_lt_flag in the slice header)
+ *   F_TMVP      sps_temporal_mvp_enabled_flag: slice_temporal_mvp_enabled_flag, collocated_from_l0_flag, collocated_ref_idx
+ *               (slice.cc:705-728) — the decoder derives the temporal merge / AMVP candidates (motion.cc:1210-1560)
+ *   F_SDH       sign_data_hiding_enabled_flag (slice.cc:3317-3440; the reference's residual writer implements the hidden sign)
+ *   F_WPP       entropy_coding_sync_enabled_flag: one substream per CTB row with the context models of the row above's second
+ *               CTB (decode_substream, slice.cc:4732-4900; what decode_slice_unit_WPP threads parse, decctx.cc:840-1061)
  *
  * usage: streamgen out.h265 W H bit_depth tile_cols tile_rows n_frames seed [intra_pct=5] [b_frames=1] [sao=1]
  *                  [features=0] [chroma=1] [slices=1]
@@ -71,7 +84,8 @@ void encode_mvd(encoder_context* ectx, CABAC_encoder* cabac, const int16_t mvd[2
 
 namespace {
 
-enum { F_WP = 1, F_TSKIP = 2, F_BYPASS = 4, F_QPDELTA = 8, F_PCM = 16, F_SCALING = 32, F_SCALING_PPS = 64, F_REXT = 256, F_CIP = 512, F_DEPSLICE = 1024 };
+enum { F_WP = 1, F_TSKIP = 2, F_BYPASS = 4, F_QPDELTA = 8, F_PCM = 16, F_SCALING = 32, F_SCALING_PPS = 64, F_REXT = 256, F_CIP = 512, F_DEPSLICE = 1024,
+       F_RA = 2048, F_WPP = 4096, F_TMVP = 8192, F_SDH = 16384, F_LT = 32768 };
 struct Cfg { int W, H, bd, tc, tr, frames; uint32_t seed; int intra_pct, b_frames, sao, features, chroma, slices; };
 
 struct Gen {
@@ -90,6 +104,10 @@ struct Gen {
   int slice_index = 0;                        /* index of shdr in img.slices */
   bool qg_coded = true, cqo_coded = true;     /* IsCuQpDeltaCoded / IsCuChromaQpOffsetCoded of the parser (slice.cc:4671-4685) */
   bool cu_bypass = false;                     /* cu_transquant_bypass_flag of the coding unit being written */
+  /* the picture being written (F_RA / F_LT / F_TMVP): its reference picture set as the slice header codes it */
+  std::vector<int> rps_neg, rps_neg_used, rps_pos, rps_pos_used;   /* POC distances (> 0), nearest first */
+  std::vector<int> lt_lsb, lt_used;
+  int col_from_l0 = 1, col_ref_idx = 0;
 
   uint32_t rnd() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
   int below(int n) { return (int)(rnd() % (uint32_t)n); }
@@ -248,6 +266,21 @@ struct Gen {
     if (intra) {
       tb.intra_mode = (enum IntraPredMode)img.get_IntraPredMode(x0, y0);
       tb.intra_mode_chroma = (enum IntraPredMode)img.get_IntraPredModeC(x0, y0);
+    }
+    if (pps->sign_data_hiding_flag) {
+      /* the residual writer leaves out the sign of a sub-block's first coefficient in scan order when it is hidden and asserts
+         that it was positive (encoder-syntax.cc:1074-1090); the decoder infers it from the parity of the level sum
+         (slice.cc:3426-3440) — whichever of the three scans applies, the first coefficient is made positive here */
+      cb.cu_transquant_bypass_flag = cu_bypass;
+      for (int sy = 0; sy < n; sy += 4)
+        for (int sx = 0; sx < n; sx += 4) {
+          int first[3] = {-1, -1, -1};
+          for (int d = 0; d < 7 && first[0] < 0; d++)                             /* up-right diagonal: anti-diagonals from the top left */
+            for (int yy = std::min(d, 3); yy >= 0 && first[0] < 0; yy--) { const int xx = d - yy; if (xx < 4 && c[sx + xx + (sy + yy) * n]) first[0] = sx + xx + (sy + yy) * n; }
+          for (int i = 0; i < 16 && first[1] < 0; i++) if (c[sx + (i & 3) + (sy + (i >> 2)) * n]) first[1] = sx + (i & 3) + (sy + (i >> 2)) * n;    /* horizontal */
+          for (int i = 0; i < 16 && first[2] < 0; i++) if (c[sx + (i >> 2) + (sy + (i & 3)) * n]) first[2] = sx + (i >> 2) + (sy + (i & 3)) * n;    /* vertical */
+          for (int k = 0; k < 3; k++) if (first[k] >= 0 && c[first[k]] < 0) c[first[k]] = (int16_t)-c[first[k]];
+        }
     }
     encode_residual(&ectx, cabac, &tb, &cb, x0, y0, log2, cIdx);
   }
@@ -516,6 +549,8 @@ struct Gen {
     const int start = enc.size();
     substream_end.clear();
     qg_coded = cqo_coded = true;
+    const bool wpp = pps->entropy_coding_sync_enabled_flag;
+    context_model_table row_ctx;                                               /* WPP: the models after the second CTB of the row above */
     for (int ts = ts0; ts < ts1; ts++) {
       const int rs = pps->scan->CtbAddrTStoRS[ts], xCtb = rs % W, yCtb = rs / W;
       img.set_SliceAddrRS(xCtb, yCtb, shdr->SliceAddrRS);
@@ -523,15 +558,19 @@ struct Gen {
       if (shdr->slice_sao_luma_flag || shdr->slice_sao_chroma_flag) write_sao(xCtb, yCtb, rs);
       const int target = 3 + below(S.Log2CtbSizeY - 2);
       coding_quadtree(xCtb << S.Log2CtbSizeY, yCtb << S.Log2CtbSizeY, S.Log2CtbSizeY, 0, target);
+      if (wpp && xCtb == 1) row_ctx = ctx.copy();                               /* storage process (9.3.2.2 end; slice.cc:4806-4822) */
       const bool last = ts == ts1 - 1;
       enc.write_CABAC_term_bit(last);                                          /* end_of_slice_segment_flag */
-      if (!last && pps->scan->TileId[ts + 1] != pps->scan->TileId[ts]) {
+      const bool next_row = wpp && !last && pps->scan->CtbAddrTStoRS[ts + 1] / W != yCtb;
+      if (!last && (next_row || pps->scan->TileId[ts + 1] != pps->scan->TileId[ts])) {
         enc.write_CABAC_term_bit(1);                                           /* end_of_subset_one_bit */
         enc.flush_CABAC();
         enc.add_trailing_bits();                                               /* byte_alignment() */
         enc.flush_VLC();
         substream_end.push_back(enc.size() - start);
-        ctx.init(shdr->initType, shdr->SliceQPY);
+        /* a new tile starts from fresh models; a new CTB row under WPP from the stored ones when the picture is more than one
+           CTB wide (slice.cc:4745-4775) */
+        if (next_row && W > 1) ctx = row_ctx.copy(); else ctx.init(shdr->initType, shdr->SliceQPY);
         enc.init_CABAC();
       }
     }
@@ -576,9 +615,23 @@ struct Gen {
       out.write_uvlc(sh->slice_type);
       if (nal_type != NAL_UNIT_IDR_W_RADL && nal_type != NAL_UNIT_IDR_N_LP) {
         out.write_bits(sh->slice_pic_order_cnt_lsb, S.log2_max_pic_order_cnt_lsb);
-        out.write_bit(1);                                                       /* short_term_ref_pic_set_sps_flag */
-        const int nb = ceil_log2(S.num_short_term_ref_pic_sets());
-        if (nb > 0) out.write_bits(sh->short_term_ref_pic_set_idx, nb);
+        if (has(F_RA)) {
+          /* st_ref_pic_set(num_short_term_ref_pic_sets) in the slice header (read_short_term_ref_pic_set, refpic.cc:85-260) */
+          out.write_bit(0);                                                     /* short_term_ref_pic_set_sps_flag */
+          if (S.num_short_term_ref_pic_sets() != 0) out.write_bit(0);           /* inter_ref_pic_set_prediction_flag */
+          out.write_uvlc((int)rps_neg.size()); out.write_uvlc((int)rps_pos.size());
+          for (size_t i = 0; i < rps_neg.size(); i++) { out.write_uvlc(rps_neg[i] - (i ? rps_neg[i - 1] : 0) - 1); out.write_bit(rps_neg_used[i]); }
+          for (size_t i = 0; i < rps_pos.size(); i++) { out.write_uvlc(rps_pos[i] - (i ? rps_pos[i - 1] : 0) - 1); out.write_bit(rps_pos_used[i]); }
+        } else {
+          out.write_bit(1);                                                     /* short_term_ref_pic_set_sps_flag */
+          const int nb = ceil_log2(S.num_short_term_ref_pic_sets());
+          if (nb > 0) out.write_bits(sh->short_term_ref_pic_set_idx, nb);
+        }
+        if (S.long_term_ref_pics_present_flag) {                                /* slice.cc:517-598; no candidates in the SPS */
+          out.write_uvlc((int)lt_lsb.size());
+          for (size_t i = 0; i < lt_lsb.size(); i++) { out.write_bits(lt_lsb[i], S.log2_max_pic_order_cnt_lsb); out.write_bit(lt_used[i]); out.write_bit(0); }   /* delta_poc_msb_present_flag */
+        }
+        if (S.sps_temporal_mvp_enabled_flag) out.write_bit(sh->slice_temporal_mvp_enabled_flag);
       }
       if (S.sample_adaptive_offset_enabled_flag) {
         out.write_bit(sh->slice_sao_luma_flag);
@@ -588,6 +641,10 @@ struct Gen {
         out.write_bit(1);                                                       /* num_ref_idx_active_override_flag */
         out.write_uvlc(nref[0] - 1);
         if (sh->slice_type == SLICE_TYPE_B) { out.write_uvlc(nref[1] - 1); out.write_bit(0); }   /* mvd_l1_zero_flag */
+        if (sh->slice_temporal_mvp_enabled_flag) {                              /* slice.cc:705-728 */
+          if (sh->slice_type == SLICE_TYPE_B) out.write_bit(col_from_l0);
+          if (nref[col_from_l0 ? 0 : 1] > 1) out.write_uvlc(col_ref_idx);
+        }
         if ((P.weighted_pred_flag && sh->slice_type == SLICE_TYPE_P) || (P.weighted_bipred_flag && sh->slice_type == SLICE_TYPE_B)) write_pred_weight_table(out, sh);
         out.write_uvlc(sh->five_minus_max_num_merge_cand);
       }
@@ -642,7 +699,7 @@ struct Gen {
     out.write_bit(P.dependent_slice_segments_enabled_flag);
     out.write_bit(0);                                                           /* output_flag_present_flag */
     out.write_bits(0, 3);                                                       /* num_extra_slice_header_bits */
-    out.write_bit(0);                                                           /* sign_data_hiding_enabled_flag */
+    out.write_bit(P.sign_data_hiding_flag);
     out.write_bit(0);                                                           /* cabac_init_present_flag */
     out.write_uvlc(P.num_ref_idx_l0_default_active - 1); out.write_uvlc(P.num_ref_idx_l1_default_active - 1);
     out.write_svlc(P.pic_init_qp - 26);
@@ -655,7 +712,7 @@ struct Gen {
     out.write_bit(P.weighted_pred_flag); out.write_bit(P.weighted_bipred_flag);
     out.write_bit(P.transquant_bypass_enable_flag);
     out.write_bit(P.tiles_enabled_flag);
-    out.write_bit(0);                                                           /* entropy_coding_sync_enabled_flag */
+    out.write_bit(P.entropy_coding_sync_enabled_flag);
     if (P.tiles_enabled_flag) {
       out.write_uvlc(P.num_tile_columns - 1); out.write_uvlc(P.num_tile_rows - 1);
       out.write_bit(1);                                                         /* uniform_spacing_flag */
@@ -711,6 +768,7 @@ int run(const Cfg& cfg, const char* out_name)
   S.bit_depth_luma = S.bit_depth_chroma = cfg.bd;
   S.log2_max_pic_order_cnt_lsb = 8;
   S.sps_max_dec_pic_buffering[0] = 4; S.sps_max_num_reorder_pics[0] = 0; S.sps_max_latency_increase_plus1[0] = 0;
+  if (g.has(F_RA)) { S.sps_max_dec_pic_buffering[0] = 8; S.sps_max_num_reorder_pics[0] = 3; }   /* up to 6 reference pictures + the current one; 8 4 2 precede picture 1 */
   S.max_transform_hierarchy_depth_inter = 2;
   S.max_transform_hierarchy_depth_intra = 2;
   S.amp_enabled_flag = 1;
@@ -723,8 +781,9 @@ int run(const Cfg& cfg, const char* out_name)
     S.pcm_loop_filter_disable_flag = (cfg.seed >> 1) & 1;
   }
   if (g.has(F_SCALING) || g.has(F_SCALING_PPS)) { S.scaling_list_enable_flag = 1; S.sps_scaling_list_data_present_flag = 0; }   /* the SPS carries the default lists */
-  S.long_term_ref_pics_present_flag = 0;
-  S.sps_temporal_mvp_enabled_flag = 0;
+  S.long_term_ref_pics_present_flag = g.has(F_LT) ? 1 : 0;
+  S.num_long_term_ref_pics_sps = 0;
+  S.sps_temporal_mvp_enabled_flag = g.has(F_TMVP) ? 1 : 0;
   S.strong_intra_smoothing_enable_flag = 1;
   if (rext) {
     S.sps_extension_present_flag = 1; S.sps_range_extension_flag = 1;
@@ -755,6 +814,8 @@ int run(const Cfg& cfg, const char* out_name)
   P.pps_loop_filter_across_slices_enabled_flag = 1;
   P.deblocking_filter_control_present_flag = 0;
   P.pic_cb_qp_offset = 1; P.pic_cr_qp_offset = -1;
+  P.sign_data_hiding_flag = g.has(F_SDH);
+  P.entropy_coding_sync_enabled_flag = g.has(F_WPP);
   if (!plain) {
     P.constrained_intra_pred_flag = g.has(F_CIP);
     P.transform_skip_enabled_flag = g.has(F_TSKIP);
@@ -808,11 +869,61 @@ int run(const Cfg& cfg, const char* out_name)
   fwrite(out.data(), 1, out.size(), f);
 
   const int nCtb = S.PicSizeInCtbsY;
-  for (int fr = 0; fr < cfg.frames; fr++) {
-    const int type = fr == 0 ? SLICE_TYPE_I : ((cfg.b_frames && (fr & 1) == 0) ? SLICE_TYPE_B : SLICE_TYPE_P);
-    const int nal_type = fr == 0 ? NAL_UNIT_IDR_W_RADL : NAL_UNIT_TRAIL_R;
-    const int nrefs = fr >= 2 ? 2 : fr;
+  /* coding order.  Plain: POC = picture index, I then P / B pictures on the one or two pictures before (RPS from the SPS).
+     F_RA: groups of 8 in the order 8 4 2 1 3 6 5 7; a picture keeps, as short-term references, the two anchors around it, the
+     even pictures of its group decoded so far and (an anchor only) the anchor before the last; odd pictures are never referenced.
+     F_LT: from the second group's inner pictures on the IDR picture is listed as a long-term reference instead of being dropped. */
+  struct Plan { int poc, nal, type, nrefs; std::vector<int> neg, neg_used, pos, pos_used, lt_lsb, lt_used; };
+  std::vector<Plan> plans;
+  if (!g.has(F_RA)) {
+    for (int fr = 0; fr < cfg.frames; fr++) {
+      Plan pl;
+      pl.poc = fr; pl.nal = fr == 0 ? NAL_UNIT_IDR_W_RADL : NAL_UNIT_TRAIL_R;
+      pl.type = fr == 0 ? SLICE_TYPE_I : ((cfg.b_frames && (fr & 1) == 0) ? SLICE_TYPE_B : SLICE_TYPE_P);
+      pl.nrefs = fr >= 2 ? 2 : fr;
+      plans.push_back(pl);
+    }
+  } else {
+    static const int gop[8] = {8, 4, 2, 1, 3, 6, 5, 7};
+    std::vector<int> order(1, 0);
+    for (int base = 0; (int)order.size() < cfg.frames; base += 8)
+      for (int k = 0; k < 8 && (int)order.size() < cfg.frames; k++) order.push_back(base + gop[k]);
+    std::vector<int> alive;                                                     /* POCs of the short-term reference pictures in the DPB */
+    bool lt0 = false;                                                           /* POC 0 has become a long-term picture */
+    uint32_t pr = cfg.seed * 69069u + 12345u;
+    auto r = [&]() { pr ^= pr << 13; pr ^= pr >> 17; pr ^= pr << 5; return pr; };
+    for (int p : order) {
+      Plan pl;
+      pl.poc = p;
+      if (p == 0) { pl.nal = NAL_UNIT_IDR_W_RADL; pl.type = SLICE_TYPE_I; pl.nrefs = 0; alive.assign(1, 0); plans.push_back(pl); continue; }
+      pl.nal = (p & 1) ? NAL_UNIT_TRAIL_N : NAL_UNIT_TRAIL_R;
+      pl.type = SLICE_TYPE_B;
+      const int a1 = (p + 7) / 8 * 8, a0 = a1 - 8;
+      std::vector<int> keep;
+      bool had0 = false;
+      for (int q : alive) {
+        const bool k = q == a1 || q == a0 || (q > a0 && q < a1) || (p == a1 && q == a0 - 8);
+        if (k) keep.push_back(q); else if (q == 0) had0 = true;
+      }
+      if (g.has(F_LT) && (had0 || lt0)) { lt0 = true; pl.lt_lsb.push_back(0); pl.lt_used.push_back(r() % 10 < 7); }
+      std::sort(keep.begin(), keep.end());
+      for (int i = (int)keep.size() - 1; i >= 0; i--) if (keep[i] < p) { pl.neg.push_back(p - keep[i]); pl.neg_used.push_back(1); }
+      for (size_t i = 0; i < keep.size(); i++) if (keep[i] > p) { pl.pos.push_back(keep[i] - p); pl.pos_used.push_back(1); }
+      /* some pictures are kept for later pictures only (RefPicSetStFoll): the farthest one before, now and then */
+      if (pl.neg.size() + pl.pos.size() >= 3 && pl.neg.size() >= 2 && r() % 3 == 0) pl.neg_used.back() = 0;
+      pl.nrefs = 4;                                                              /* lists longer than the set repeat its pictures (decctx.cc:1580-1640) */
+      alive = keep;
+      if (!(p & 1)) alive.push_back(p);
+      plans.push_back(pl);
+    }
+  }
+  for (size_t pi = 0; pi < plans.size(); pi++) {
+    const Plan& plan = plans[pi];
+    const int fr = (int)pi;                                                     /* coding index: seeds */
+    const int type = plan.type, nal_type = plan.nal, nrefs = plan.nrefs;
     g.slice_type = type; g.nref[0] = g.nref[1] = nrefs;
+    g.rps_neg = plan.neg; g.rps_neg_used = plan.neg_used; g.rps_pos = plan.pos; g.rps_pos_used = plan.pos_used;
+    g.lt_lsb = plan.lt_lsb; g.lt_used = plan.lt_used;
     /* slice segments: [cut[k], cut[k+1]) in tile-scan order; with tiles a segment holds whole tiles (7.4.7.1) */
     std::vector<int> cut;
     cut.push_back(0);
@@ -849,9 +960,12 @@ int run(const Cfg& cfg, const char* out_name)
         indep_addr = sh->slice_segment_address;
         sh->slice_type = type;
         sh->pic_output_flag = 1;
-        sh->slice_pic_order_cnt_lsb = fr & 0xFF;
-        sh->short_term_ref_pic_set_sps_flag = 1;
+        sh->slice_pic_order_cnt_lsb = plan.poc & 0xFF;
+        sh->short_term_ref_pic_set_sps_flag = g.has(F_RA) ? 0 : 1;
         sh->short_term_ref_pic_set_idx = nrefs >= 2 ? 1 : 0;
+        sh->slice_temporal_mvp_enabled_flag = (g.has(F_TMVP) && type != SLICE_TYPE_I) ? (r() % 8 != 0) : 0;
+        g.col_from_l0 = type == SLICE_TYPE_B ? (int)(r() % 2) : 1;
+        g.col_ref_idx = nrefs > 1 ? (int)(r() % (uint32_t)nrefs) : 0;
         sh->slice_sao_luma_flag = sh->slice_sao_chroma_flag = cfg.sao ? 1 : 0;
         sh->num_ref_idx_active_override_flag = type != SLICE_TYPE_I;
         sh->num_ref_idx_l0_active = nrefs; sh->num_ref_idx_l1_active = nrefs;
@@ -934,5 +1048,9 @@ int main(int argc, char** argv)
   c.features = argc > 12 ? (int)strtol(argv[12], nullptr, 0) : 0; c.chroma = argc > 13 ? atoi(argv[13]) : 1; c.slices = argc > 14 ? atoi(argv[14]) : 1;
   if (c.W % 8 || c.H % 8 || c.W < 16 || c.H < 16 || c.bd < 8 || c.bd > 12 || c.tc < 1 || c.tr < 1 || c.frames < 1 || c.chroma < 0 || c.chroma > 3 || c.slices < 1 || c.slices > 32) { fprintf(stderr, "streamgen: bad arguments\n"); return 2; }
   if ((c.features & F_PCM) && c.bd - 2 < 1) { fprintf(stderr, "streamgen: bad arguments\n"); return 2; }
+  /* WPP: one slice, no tiles (the reference refuses tiles + WPP with threads, decctx.cc:813-817); the reference picture set and the
+     collocated picture are per picture: one slice; the residual writer knows the hidden sign only outside the range extensions */
+  if (((c.features & F_WPP) && (c.tc > 1 || c.tr > 1 || c.slices > 1)) || ((c.features & (F_RA | F_TMVP)) && c.slices > 1) || ((c.features & F_LT) && !(c.features & F_RA)) ||
+      ((c.features & F_SDH) && (c.features & F_REXT)) || ((c.features & F_RA) && c.frames > 200)) { fprintf(stderr, "streamgen: bad feature combination\n"); return 2; }
   return run(c, argv[1]);
 }

@@ -29,6 +29,10 @@ STREAMGEN = os.path.join(ROOT, "oracle", "_ref", "streamgen")
 
 # feature bits of oracle/ref_streamgen.cc (what the reference's own writers cannot express: written by OUR writers there)
 F_WP, F_TSKIP, F_BYPASS, F_QPDELTA, F_PCM, F_SCALING, F_SCALING_PPS, F_REXT, F_CIP, F_DEPSLICE = 1, 2, 4, 8, 16, 32, 64, 256, 512, 1024
+# random-access shape (the offline stand-in for the ra_main conformance streams): hierarchical-B groups of 8 decoded out of output
+# order, slice-header reference picture sets with up to 6 pictures and 4 active references per list, a long-term picture,
+# temporal motion vector prediction, sign data hiding, and WPP substreams (one per CTB row, parsed by the reference's WPP threads)
+F_RA, F_WPP, F_TMVP, F_SDH, F_LT = 2048, 4096, 8192, 16384, 32768
 # coverage counters of the glue's recorder (glue/m355_glue.cc FEAT_*): a stream that carries a feature must drive its branch
 FEATS = ["pcm_cu", "weighted_pb", "bypass_rb", "skip_rb", "rdpcm_rb", "rotate_rb", "scaling_rb", "cross_comp_rb", "multi_slice_pic",
          "weighted_pb_later_slice", "no_boundary_filter_ib", "fill_pb", "chroma_422_rb", "chroma_444_rb", "mono_pic", "deblock_off_slice"]
@@ -66,6 +70,19 @@ def check(ref, data, frames, threads, backend, expect=()):
     after = feature_counts(lib)
     for name in expect:                         # the stream really drove the recorder branch it is there for
         assert after[name] > before[name], "the stream did not exercise '%s' (%r)" % (name, {k: after[k] - before[k] for k in FEATS})
+    return want
+
+
+def check_random_access(ref, data, frames, threads, backend):
+    """A random-access stream: as check(), plus the decode an application makes that never looks at the samples (dec265 -q
+    without -o: pictures are taken in output order and dropped, frames recycle while the submit worker is still behind)."""
+    want = check(ref, data, frames, threads, backend)
+    lib = glue_lib()
+    got = de265_py.decode_stream(lib, data, threads=threads, touch_planes=False)
+    assert got[1] == frames and set(got[2]) <= {1000}, got
+    assert lib.m355_glue_cpu_pixel_calls() == 0
+    # and once more with the samples, single-threaded: the glue's frame bookkeeping must not depend on the parser's threads
+    assert de265_py.decode_stream(lib, data, threads=0)[:2] == want[:2]
 
 
 CPU_CASES = [(416, 240, 8, 1, 1, 4, 21), (448, 256, 10, 2, 2, 4, 22)]
@@ -92,6 +109,31 @@ FEATURE_CPU_CASES = [
 def test_feature_streams_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, w, h, bd, tc, tr, frames, seed, intra, feat, chroma, slices, expect):  # noqa: F811
     monkeypatch.setenv("M355_LIB", EMU_SO)
     check(ref, make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra, 1, 1, feat, chroma, slices), frames, 3, EMU_SO, expect)
+
+
+# (w, h, bit depth, frames, seed, features, parser threads)
+RA_CPU_CASES = [(256, 128, 8, 14, 5, F_RA | F_LT | F_TMVP | F_SDH, 3), (256, 192, 8, 10, 6, F_RA | F_WPP | F_TMVP | F_SDH, 4)]
+
+
+@pytest.mark.parametrize("w,h,bd,frames,seed,feat,threads", RA_CPU_CASES)
+def test_random_access_streams_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, w, h, bd, frames, seed, feat, threads):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    check_random_access(ref, make_stream(tmp_path, w, h, bd, 1, 1, frames, seed, 5, 1, 1, feat), frames, threads, EMU_SO)
+
+
+RA_GPU_CASES = [
+    (3840, 2160, 8, 17, 81, F_RA | F_LT | F_TMVP | F_SDH, 8),              # the C3 stand-in: 4K, two groups of pictures + the IDR
+    (3840, 2160, 8, 17, 82, F_RA | F_LT | F_TMVP | F_SDH | F_WPP, 8),      # ... WPP-only, CTB rows on 8 parser threads
+    (1920, 1080, 10, 33, 83, F_RA | F_LT | F_TMVP | F_SDH | F_WPP | F_WP, 8),   # four groups: the long-term picture outlives three of them
+    (832, 480, 8, 41, 84, F_RA | F_TMVP, 0),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bd,frames,seed,feat,threads", RA_GPU_CASES)
+def test_random_access_streams_gpu(ref, tmp_path, monkeypatch, w, h, bd, frames, seed, feat, threads):
+    monkeypatch.delenv("M355_LIB", raising=False)
+    check_random_access(ref, make_stream(tmp_path, w, h, bd, 1, 1, frames, seed, 5, 1, 1, feat), frames, threads, capi.DEFAULT_LIB)
 
 
 FEATURE_GPU_CASES = [
