@@ -446,13 +446,18 @@ def end_to_end(cfg):
     if not all(os.path.exists(p) for p in (gen, ref, glue)):
         return None
     try:
-        frames = 16
+        # a workload without tiles (C3, the stand-in for the 4K ra_main conformance stream) gets the random-access stream shape:
+        # hierarchical-B groups of 8 decoded out of output order, slice-header reference picture sets, 4 active references per
+        # list, a long-term picture, temporal MVP, sign data hiding, and WPP substreams parsed by 8 threads (oracle/ref_streamgen.cc)
+        ra = cfg["tile_cols"] * cfg["tile_rows"] == 1
+        frames = 17 if ra else 16
+        features = (2048 | 4096 | 8192 | 16384 | 32768) if ra else 0
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "s.h265")
             subprocess.run([gen, path, str(cfg["width"]), str(cfg["height"]), str(cfg["bit_depth"]), str(cfg["tile_cols"]), str(cfg["tile_rows"]),
-                            str(frames), "77", "5", "1", "1"], check=True, timeout=300)
+                            str(frames), "77", "5", "1", "1", str(features)], check=True, timeout=300)
             size = os.path.getsize(path)
-            threads = max(1, min(32, cfg["tile_cols"] * cfg["tile_rows"]))   # the parser runs one thread per tile
+            threads = 8 if ra else max(1, min(32, cfg["tile_cols"] * cfg["tile_rows"]))   # the parser runs one thread per tile / per CTB row in flight
 
             def run(exe, output=False):
                 env = dict(os.environ, M355_PIPELINE_DEPTH="3")
@@ -469,8 +474,9 @@ def end_to_end(cfg):
             nro, fro = run(ref, True)
             ngo, fgo = run(glue, True)
         ctbs = ((cfg["width"] + 63) // 64) * ((cfg["height"] + 63) // 64)
-        return {"stream": "%dx%d %d-bit, %dx%d tiles, %d pictures (I + P/B, 2 references), %d bytes; dec265 -q -t %d" %
-                          (cfg["width"], cfg["height"], cfg["bit_depth"], cfg["tile_cols"], cfg["tile_rows"], frames, size, threads),
+        return {"stream": "%dx%d %d-bit, %dx%d tiles, %d pictures (%s), %d bytes; dec265 -q -t %d" %
+                          (cfg["width"], cfg["height"], cfg["bit_depth"], cfg["tile_cols"], cfg["tile_rows"], frames,
+                           "random access: hierarchical-B groups of 8, 4 references per list, long-term picture, TMVP, SDH, WPP" if ra else "I + P/B, 2 references", size, threads),
                 "reference_fps": fr, "reference_ctb64_per_s": fr * ctbs, "mi355x_fps": fg, "mi355x_ctb64_per_s": fg * ctbs,
                 "pictures": [nr, ng], "speedup": (fg / fr) if fr > 0 else None,
                 "with_output": {"reference_fps": fro, "mi355x_fps": fgo, "pictures": [nro, ngo], "speedup": (fgo / fro) if fro > 0 else None,

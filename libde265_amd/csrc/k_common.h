@@ -188,6 +188,7 @@ enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
 /* ---- launchers (each in its stage's .hip); all asynchronous on `st` ---- */
 void m355_launch_validate(const DevPic& p, hipStream_t st);   /* device-side validation of the work lists (k_meta.hip) */
 void m355_launch_meta(const DevPic& p, hipStream_t st);
+void m355_launch_clear_gated(const DevPic& p, void* ptr, size_t bytes, hipStream_t st);   /* zero fill behind the decode's gate (bytes: a multiple of 16) */
 void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for k_inter */
 void m355_launch_meta_planes(const DevPic& p, hipStream_t st);   /* planes for intra / deblock / SAO */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);

@@ -5,6 +5,7 @@
  * and derive_edgeFlags_CTBRow + markTransformBlockBoundary + markPredictionBlockBoundary
  * (deblock.cc:33-227).  Pure scatter kernels: HBM-write bound, a few bytes per 4x4 unit.
  */
+#include <algorithm>
 #include "k_common.h"
 
 /* one thread per CU: CU-index plane, per-CU edge decisions (deblock.cc:172-210), PB edges */
@@ -222,6 +223,20 @@ void m355_launch_meta_planes(const DevPic& p, hipStream_t st)
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
   if (p.pp.flags & M355_PF_SAO_ENABLED) hipLaunchKernelGGL(k_meta_sao, dim3((p.nCtb * 3 + 255) / 256), dim3(256), 0, st, p);
+}
+
+/* zero fill that a rejected decode (k_validate) does not perform: planes are 128-byte-pitched allocations with a 256-byte tail */
+__global__ void __launch_bounds__(256) k_clear_gated(DevPic p, uint4* q, size_t n16)
+{
+  M355_GATE(p);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) q[i] = make_uint4(0, 0, 0, 0);
+}
+void m355_launch_clear_gated(const DevPic& p, void* ptr, size_t bytes, hipStream_t st)
+{
+  const size_t n16 = (bytes + 15) / 16;
+  if (!n16) return;
+  const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_clear_gated, dim3(grid), dim3(256), 0, st, p, (uint4*)ptr, n16);
 }
 
 void m355_launch_meta(const DevPic& p, hipStream_t st)

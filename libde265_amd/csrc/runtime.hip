@@ -192,6 +192,9 @@ struct m355_ctx {
   Status status[M355_STATUS_RING];
   uint32_t* status_words = nullptr;   /* pinned: 4 words per ring slot = the lane's timeout[0..3] at the end of the decode */
   unsigned long long serial = 0;
+  /* rejected decodes that left the status ring unreported (more than M355_STATUS_RING submits between two waits): latched when
+     their slot is reused, reported by the next m355_wait */
+  unsigned long long lost_first = 0; int lost_count = 0;
   int stages = M355_STAGE_ALL;
   int shard_rank = 0, shard_n = 0;   /* shard_n == 0: sharding off */
   m355_comm comm = {nullptr, nullptr, nullptr};   /* exchanges of m355_decode_sharded */
@@ -464,7 +467,8 @@ int m355_set_pipeline_depth(m355_ctx* c, int depth)
   return M355_OK;
 }
 
-void* m355_stream(m355_ctx* c) { return (void*)c->stream; }
+/* the stream the active lane's last decode / phase ran on (an intra picture on lane 3.. runs on the lane's class stream, decode()) */
+void* m355_stream(m355_ctx* c) { return (void*)(c->last_stream ? c->last_stream : c->stream); }
 
 /* ------------------------------------------------------------------------------ frames -------- */
 
@@ -535,8 +539,13 @@ int m355_frame_download_async(m355_ctx* c, int h, void* const dst[3], const ptrd
      the writer's own stream it never did.  They still run beside the host and beside the other lanes' decodes; the lane's next
      picture waits for them. */
   if (c->dl_evs.empty()) {
-    c->dl_evs.resize(128, nullptr);
-    for (auto& e : c->dl_evs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    std::vector<hipEvent_t> evs(128, nullptr);              /* swapped in only when every event exists */
+    for (auto& e : evs)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        for (hipEvent_t x : evs) if (x) hipEventDestroy(x);
+        return fail(M355_ERR_HIP, "hipEventCreate failed");
+      }
+    c->dl_evs.swap(evs);
   }
   hipEvent_t ev_done = c->dl_evs[c->dl_ev_next];            /* (a ring: never re-recorded while an earlier record may still be waited for) */
   c->dl_ev_next = (c->dl_ev_next + 1) % (int)c->dl_evs.size();
@@ -1540,6 +1549,20 @@ static hipError_t frame_event(hipEvent_t* e)
  * stream while the main stream runs job list -> inter prediction, which do not read them; the residual stage then runs in two
  * launches side by side — 32x32 + 16x16 blocks on the main stream, 8x8 + 4x4 on the side stream — and k_intra follows the join.
  * ev: the decode's timing events [1..4] (after meta jobs / inter / residual / intra) or nullptr. */
+/* M355_PF_CLEAR_DST: a new picture starts from zero in the reference (image.cc:164); the planes being reconstructed are this
+ * lane's working planes (SAO rewrites every sample of the destination) or the destination itself — then, for lists checked on
+ * the device, by a kernel behind the decode's gate: a rejected picture must leave its destination frame untouched
+ * (de265_mi355x.h, m355_decode_status). */
+static void clear_target(m355_ctx* c, const DevPic& d, Frame* tgt, bool gated, hipStream_t st)
+{
+  for (int cc = 0; cc < 3; cc++) {
+    if (!tgt->pw[cc]) continue;
+    const size_t bytes = (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc];
+    if (gated) m355_launch_clear_gated(d, tgt->plane[cc], bytes, st);
+    else hipMemsetAsync(tgt->plane[cc], 0, bytes, st);
+  }
+}
+
 static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev)
 {
   hipStream_t st = c->stream;
@@ -1633,13 +1656,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
   hipEventRecord(ev[0], st);
   if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
   if (!want_sao) dst_hazards();
-  if (pp.flags & M355_PF_CLEAR_DST) {
-    /* a new picture starts from zero in the reference (image.cc:164); the planes being reconstructed are this lane's
-       working planes (SAO rewrites every sample of the destination) or the destination itself */
-    Frame* tgt = want_sao ? &c->work : dstf;
-    for (int cc = 0; cc < 3; cc++)
-      if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
-  }
+  if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, want_sao ? &c->work : dstf, r.device_validate && !want_sao, st);
   launch_prediction(c, r, d, hbd, ev);
   if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
   hipEventRecord(ev[5], st);
@@ -1663,6 +1680,12 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
     /* this decode's status slot: completion event; a device-validated decode also brings its lane's gate words back (behind the
        events the dependent decodes wait on: nobody waits for this copy but m355_decode_status / m355_wait) */
     m355_ctx::Status& s = c->status[++c->serial % M355_STATUS_RING];
+    if (s.serial && s.validated && !s.reported && s.ev) {
+      /* the slot's previous decode (M355_STATUS_RING submits ago) was never asked about: resolve it before its words are
+         overwritten — a rejection must not get lost (m355_wait promises to report it) */
+      hipEventSynchronize(s.ev);
+      if (c->status_words[4 * (s.serial % M355_STATUS_RING) + 1] == s.epoch) { if (!c->lost_count++) c->lost_first = s.serial; }
+    }
     s.serial = c->serial; s.epoch = d.epoch; s.validated = r.device_validate; s.reported = false;
     if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     if (r.device_validate) {
@@ -1708,7 +1731,7 @@ int m355_decode_status(m355_ctx* c, unsigned long long serial)
 {
   if (serial == 0 || serial > c->serial) return fail(M355_ERR_INVALID, "no decode with serial %llu", serial);
   m355_ctx::Status& s = c->status[serial % M355_STATUS_RING];
-  if (s.serial != serial) return M355_OK;                     /* older than the ring: reported by an m355_wait since */
+  if (s.serial != serial) return fail(M355_ERR_INVALID, "decode %llu is older than the last %d decodes: its status is no longer kept (m355_wait reports rejections)", serial, M355_STATUS_RING);
   hipSetDevice(c->device);
   const hipError_t q = hipEventQuery(s.ev);
   if (q == hipErrorNotReady) return M355_ERR_BUSY;
@@ -1788,6 +1811,8 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
     if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
     dstf->wr_stream = st;
+    if (!c->ev_last && hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+    hipEventRecord(c->ev_last, st); c->last_stream = st;
     if (!piped) return M355_OK;
     if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
     hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
@@ -1795,16 +1820,16 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   };
   switch (phase) {
     case 0: {
+      if (c->last_stream && c->last_stream != st && c->ev_last) hipStreamWaitEvent(st, c->ev_last, 0);   /* the lane's scratch and working planes (decode()) */
+      /* the exchange buffers of m355_decode_sharded belong to the handle, not to a lane: a second decode of the same lists
+         starts behind the last unpack of the one before */
+      if (r.xb[0] && r.done_pending && r.ev_done) hipStreamWaitEvent(st, r.ev_done, 0);
       if (piped) {
         if (r.ev_up) hipStreamWaitEvent(st, r.ev_up, 0);
       }
       if (r.device_validate) m355_launch_validate(d, st);
       if (!r.live_sao) dst_hazards();
-      if (pp.flags & M355_PF_CLEAR_DST) {
-        Frame* tgt = r.live_sao ? &c->work : dstf;
-        for (int cc = 0; cc < 3; cc++)
-          if (tgt->pw[cc]) hipMemsetAsync(tgt->plane[cc], 0, (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc], st);
-      }
+      if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, r.live_sao ? &c->work : dstf, r.device_validate && !r.live_sao, st);
       launch_prediction(c, r, d, hbd, nullptr);
       if (piped)      /* the reference frames are not read after this phase */
         for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
@@ -1957,13 +1982,16 @@ int m355_shard_time_exchange(m355_ctx* c, int h, int which, int iters, float* ms
 static int rccl_load(Rccl& R)
 {
   if (R.so) return M355_OK;
-  R.so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!R.so) R.so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!R.so) return fail(M355_ERR_HIP, "cannot load librccl.so: %s", dlerror());
-#define RSYM(field, name) R.field = (decltype(R.field))dlsym(R.so, name); if (!R.field) return fail(M355_ERR_HIP, "librccl lacks %s", name);
+  /* resolved into a local copy and committed only when every symbol is there: a partial table must never look loaded */
+  Rccl L;
+  L.so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!L.so) L.so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!L.so) return fail(M355_ERR_HIP, "cannot load librccl.so: %s", dlerror());
+#define RSYM(field, name) L.field = (decltype(L.field))dlsym(L.so, name); if (!L.field) { dlclose(L.so); return fail(M355_ERR_HIP, "librccl lacks %s", name); }
   RSYM(GetUniqueId, "ncclGetUniqueId") RSYM(CommInitRank, "ncclCommInitRank") RSYM(CommDestroy, "ncclCommDestroy") RSYM(GroupStart, "ncclGroupStart")
   RSYM(GroupEnd, "ncclGroupEnd") RSYM(Send, "ncclSend") RSYM(Recv, "ncclRecv") RSYM(AllGather, "ncclAllGather")
 #undef RSYM
+  R = L;
   return M355_OK;
 }
 static int rccl_halo_sum(void* user, void* buf, size_t bytes, const int* peers, int n_peers, void* scratch, void* stream)
@@ -2083,6 +2111,12 @@ int m355_wait(m355_ctx* c)
     m355_ctx::Status* first = nullptr;
     for (m355_ctx::Status& st_ : c->status)
       if (st_.serial && st_.validated && !st_.reported && c->status_words[4 * (st_.serial % M355_STATUS_RING) + 1] == st_.epoch && (!first || st_.serial < first->serial)) first = &st_;
+    if (c->lost_count) {
+      const unsigned long long f = c->lost_first; const int n = c->lost_count;
+      c->lost_first = 0; c->lost_count = 0;
+      return fail(M355_ERR_INVALID, "picture %llu%s rejected by the device-side list validation (not decoded; its status had left the %d-entry ring: %d such picture%s)",
+                  f, n > 1 ? " and later ones" : "", M355_STATUS_RING, n, n > 1 ? "s" : "");
+    }
     if (first) return status_of(c, *first);
   }
   if (t) {

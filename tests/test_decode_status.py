@@ -19,7 +19,7 @@ CORRUPTIONS = [("cus", "pred_mode", 7, "cu"), ("tus", "log2_size", 9, "tu"), ("r
                ("pbs", "ref_slot", 31, "pb"), ("rbs", "kind", 9, "rb")]
 
 
-def run(lib, oracle, depth):
+def run(lib, oracle, depth, ring=True):
     pic, refs = make_case(**CASE)
     pp = pic.pp[0]
     want = oracle_decode(Oracle(oracle), pic, refs)
@@ -79,13 +79,34 @@ def run(lib, oracle, depth):
             ctx.wait()
         assert e.value.code == 3 and "picture %d:" % (serials[-1] + 1) in str(e.value)
         ctx.wait()                                          # reported once
+        # a rejection nobody asks about must survive more submits than the status ring holds (64); the fillers are tiny pictures
+        if ring:
+            bad.dst_frame = dsts[1]
+            ctx.submit_in_place(bad, fill_threads=1)
+            lost = ctx.last_serial()
+            small, srefs = make_case(width=64, height=64, bit_depth=8, seed=72, intra_pct=30)
+            spp = small.pp[0]
+            sh = []
+            for planes in srefs:
+                f = ctx.frame_create_for(spp)
+                ctx.frame_upload(f, planes)
+                sh.append(f)
+            small.ref_frames = [sh[i] if i < len(sh) else -1 for i in range(worklist.MAX_REF_FRAMES)]
+            small.dst_frame = ctx.frame_create_for(spp)
+            for _ in range(70):
+                ctx.submit_in_place(small, fill_threads=1)
+            assert ctx.decode_status(lost) == 3 and "no longer kept" in lib.error()
+            with pytest.raises(capi.M355Error) as e:
+                ctx.wait()
+            assert e.value.code == 3 and "picture %d" % lost in str(e.value) and "ring" in str(e.value)
+            ctx.wait()
     finally:
         ctx.close()
 
 
 @pytest.mark.parametrize("depth", [1, 3])
 def test_decode_status_emulated(emu_lib, oracle, depth):  # noqa: F811
-    run(emu_lib, oracle, depth)
+    run(emu_lib, oracle, depth, ring=depth == 3)
 
 
 @pytest.mark.gpu
