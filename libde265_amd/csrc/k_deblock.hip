@@ -35,22 +35,18 @@ __device__ __forceinline__ CuInfo d_cu_info(const DevPic& p, int xl, int yl)
   return r;
 }
 
-/* derive_boundaryStrength for one edge unit (deblock.cc:243-383) */
-__device__ int d_boundary_strength(const DevPic& p, int x4, int y4, bool vertical, const CuInfo& P, const CuInfo& Q)
+/* derive_boundaryStrength for one edge unit (deblock.cc:243-383) on values the caller has fetched: ef = the unit's edge flags
+   (TU | PB), efo = the TU flags of the unit across the edge, A / B = the prediction blocks across / on this side (pb_ok: both
+   exist in this picture's records) */
+__device__ __forceinline__ int d_boundary_strength(int ef, int efo, bool vertical, const CuInfo& P, const CuInfo& Q, bool pb_ok, const m355_pb& A, const m355_pb& B)
 {
-  const int u = y4 * p.w4 + x4;
-  const int ef = p.edge_tu[u] | p.edge_pb[u];
   const int edgeMask = vertical ? (E_TU_V | E_PB_V) : (E_TU_H | E_PB_H);
   if (!(ef & edgeMask)) return 0;
   if (P.pred_mode == 0 || Q.pred_mode == 0) return 2;
-  const int uo = vertical ? u - 1 : u - p.w4;
-  if ((ef & (vertical ? E_TU_V : E_TU_H)) && ((ef & E_NONZERO) || (p.edge_tu[uo] & E_NONZERO))) return 1;
-  const uint32_t ip = p.pb_of[uo], iq = p.pb_of[u];
-  if (!ip || !iq) return 0;
+  if ((ef & (vertical ? E_TU_V : E_TU_H)) && ((ef & E_NONZERO) || (efo & E_NONZERO))) return 1;
   /* pb_of is not cleared between pictures (k_meta.hip): an inter CU whose units no PB of THIS picture covers (a list that
-     validation cannot fully check) leaves a stale index — never follow it past this picture's records */
-  if (ip > (uint32_t)p.n_pb_records || iq > (uint32_t)p.n_pb_records) return 0;
-  const m355_pb A = p.pbs[ip - 1], B = p.pbs[iq - 1];
+     validation cannot fully check) leaves a stale index — never followed past this picture's records (pb_ok) */
+  if (!pb_ok) return 0;
   const bool pf0 = A.flags & M355_PBF_PRED_L0, pf1 = A.flags & M355_PBF_PRED_L1;
   const bool qf0 = B.flags & M355_PBF_PRED_L0, qf1 = B.flags & M355_PBF_PRED_L1;
   const int rP0 = pf0 ? A.ref_slot[0] : -1, rP1 = pf1 ? A.ref_slot[1] : -1;
@@ -65,6 +61,33 @@ __device__ int d_boundary_strength(const DevPic& p, int x4, int y4, bool vertica
   }
   return ((FAR(p0x, p0y, q0x, q0y) || FAR(p1x, p1y, q1x, q1y)) && (FAR(p0x, p0y, q1x, q1y) || FAR(p1x, p1y, q0x, q0y))) ? 1 : 0;
 #undef FAR
+}
+
+/* Four adjacent samples = one aligned vector (8 bytes of uint16, 4 bytes of uint8), kept RAW in registers: the segment's
+   4 x 8 samples are 16 (8) dwords instead of 32 unpacked ones, a sample is a bit-field extract / insert at a compile-time
+   position (all loops below are unrolled) — 8 waves per SIMD for both directions. */
+template <class PIX> struct Raw4 { uint32_t w[sizeof(PIX) == 2 ? 2 : 1]; };
+template <class PIX> __device__ __forceinline__ Raw4<PIX> d_ld4(const PIX* q)
+{
+  Raw4<PIX> r;
+  if (sizeof(PIX) == 2) { const uint2 v = *(const uint2*)q; r.w[0] = v.x; r.w[sizeof(PIX) == 2 ? 1 : 0] = v.y; }
+  else r.w[0] = *(const uint32_t*)q;
+  return r;
+}
+template <class PIX> __device__ __forceinline__ void d_st4(PIX* q, const Raw4<PIX>& r)
+{
+  if (sizeof(PIX) == 2) *(uint2*)q = make_uint2(r.w[0], r.w[sizeof(PIX) == 2 ? 1 : 0]);
+  else *(uint32_t*)q = r.w[0];
+}
+template <class PIX> __device__ __forceinline__ int d_get(const Raw4<PIX>& r, int s)
+{
+  if (sizeof(PIX) == 2) return (int)((r.w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu);
+  return (int)((r.w[0] >> (8 * s)) & 0xFFu);
+}
+template <class PIX> __device__ __forceinline__ void d_set(Raw4<PIX>& r, int s, int v)
+{
+  if (sizeof(PIX) == 2) { const uint32_t m = 0xFFFFu << (16 * (s & 1)); r.w[s >> 1] = (r.w[s >> 1] & ~m) | ((uint32_t)v << (16 * (s & 1))); }
+  else { const uint32_t m = 0xFFu << (8 * s); r.w[0] = (r.w[0] & ~m) | ((uint32_t)v << (8 * s)); }
 }
 
 template <class PIX, bool VERTICAL>
@@ -86,11 +109,41 @@ __global__ void __launch_bounds__(256) k_deblock(DevPic p)
     ownQ = p.ctb_owner[d_ctb_of(p, xDi, yDi)] != 0; ownP = p.ctb_owner[d_ctb_of(p, xp, yp)] != 0;
     if (!ownP && !ownQ) return;
   }
-  const CuInfo Q = d_cu_info(p, xDi, yDi), P = d_cu_info(p, xp, yp);
-  const int bS = d_boundary_strength(p, x4, y4, VERTICAL, P, Q);
+
+  /* ---- memory round trip 1, everything at once and before any decision: the edge flags, the CU / PB indices of both sides,
+     the CTB's slice index AND the luma samples of the segment (nearly every segment of an inter picture is filtered or at
+     least examined; 32 + 32 bytes as aligned 4-sample vectors: the segment's 4 x 8 samples belong to this thread alone in
+     this pass).  The pass used to be a chain of five dependent round trips with 32 scalar sample loads at its end. ---- */
+  const int u = y4 * p.w4 + x4, uo = VERTICAL ? u - 1 : u - p.w4;
+  const uint32_t ciQ = d_cu_index_at(p, xDi, yDi), ciP = d_cu_index_at(p, xp, yp);
+  const int ef = p.edge_tu[u] | p.edge_pb[u], efo = p.edge_tu[uo];
+  const uint32_t ip = p.pb_of[uo], iq = p.pb_of[u];
+  const int slice_idx = p.ctbs[d_ctb_of(p, xDi, yDi)].slice_idx;
+  const int stride = p.stride[0];
+  PIX* const ptr = (PIX*)p.plane[0] + yDi * stride + xDi;
+  /* VERTICAL: rp[k] / rq[k] = line k (samples xDi-4 .. xDi-1 / xDi .. xDi+3); horizontal: rp[i] / rq[i] = the row at distance i
+     from the edge (its four samples are the four lines) */
+  Raw4<PIX> rp[4], rq[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    rp[j] = d_ld4<PIX>(VERTICAL ? ptr + j * stride - 4 : ptr - (j + 1) * stride);
+    rq[j] = d_ld4<PIX>(VERTICAL ? ptr + j * stride : ptr + j * stride);
+  }
+#define PV(k, i) (VERTICAL ? d_get<PIX>(rp[k], 3 - (i)) : d_get<PIX>(rp[i], k))     /* line k, distance i */
+#define QV(k, i) (VERTICAL ? d_get<PIX>(rq[k], i) : d_get<PIX>(rq[i], k))
+#define SETP(k, i, v) do { if (VERTICAL) d_set<PIX>(rp[k], 3 - (i), v); else d_set<PIX>(rp[i], k, v); } while (0)
+#define SETQ(k, i, v) do { if (VERTICAL) d_set<PIX>(rq[k], i, v); else d_set<PIX>(rq[i], k, v); } while (0)
+  /* ---- round trip 2: the records the indices name (an absent one reads the CTB table instead: always there, never used) ---- */
+  const bool pb_ok = ip && iq && ip <= (uint32_t)p.n_pb_records && iq <= (uint32_t)p.n_pb_records;
+  const m355_cu cuQ = *(ciQ ? p.cus + (ciQ - 1) : (const m355_cu*)p.ctbs), cuP = *(ciP ? p.cus + (ciP - 1) : (const m355_cu*)p.ctbs);
+  const m355_pb A = *(pb_ok ? p.pbs + (ip - 1) : (const m355_pb*)p.ctbs), B = *(pb_ok ? p.pbs + (iq - 1) : (const m355_pb*)p.ctbs);
+  const m355_slice sh = p.slices[slice_idx];
+  CuInfo Q = {0, 0, 0, 0}, P = {0, 0, 0, 0};
+  if (ciQ) { Q.pred_mode = cuQ.pred_mode; Q.qp = cuQ.qp_y; Q.pcm = (cuQ.flags & M355_CUF_PCM) != 0; Q.bypass = (cuQ.flags & M355_CUF_TRANSQUANT_BYPASS) != 0; }
+  if (ciP) { P.pred_mode = cuP.pred_mode; P.qp = cuP.qp_y; P.pcm = (cuP.flags & M355_CUF_PCM) != 0; P.bypass = (cuP.flags & M355_CUF_TRANSQUANT_BYPASS) != 0; }
+  const int bS = d_boundary_strength(ef, efo, VERTICAL, P, Q, pb_ok, A, B);
   if (bS == 0) return;
 
-  const m355_slice sh = d_slice_at(p, xDi, yDi);
   const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
   const bool filterP = ownP && !((plf && P.pcm) || P.bypass), filterQ = ownQ && !((plf && Q.pcm) || Q.bypass);
   const int qP_L = (Q.qp + P.qp + 1) >> 1;
@@ -98,55 +151,60 @@ __global__ void __launch_bounds__(256) k_deblock(DevPic p)
   /* ---- luma (deblock.cc:480-601, fallback-deblk.h:33-100) ---- */
   {
     const int bd = p.pp.bit_depth_luma;
-    const int stride = p.stride[0];
-    PIX* ptr = (PIX*)p.plane[0] + yDi * stride + xDi;
-    const int across = VERTICAL ? 1 : stride, along = VERTICAL ? stride : 1;
     const int beta = c_tab_beta[d_clip3(0, 51, qP_L + sh.beta_offset)] * (1 << (bd - 8));
     const int tc = c_tab_tc[d_clip3(0, 53, qP_L + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
-    int pv[4][4], qv[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) { qv[k][i] = ptr[k * along + i * across]; pv[k][i] = ptr[k * along - (i + 1) * across]; }
-    const int dp0 = d_abs(pv[0][2] - 2 * pv[0][1] + pv[0][0]), dp3 = d_abs(pv[3][2] - 2 * pv[3][1] + pv[3][0]);
-    const int dq0 = d_abs(qv[0][2] - 2 * qv[0][1] + qv[0][0]), dq3 = d_abs(qv[3][2] - 2 * qv[3][1] + qv[3][0]);
+    const int dp0 = d_abs(PV(0, 2) - 2 * PV(0, 1) + PV(0, 0)), dp3 = d_abs(PV(3, 2) - 2 * PV(3, 1) + PV(3, 0));
+    const int dq0 = d_abs(QV(0, 2) - 2 * QV(0, 1) + QV(0, 0)), dq3 = d_abs(QV(3, 2) - 2 * QV(3, 1) + QV(3, 0));
     const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
     if (d < beta) {
-      const bool dSam0 = 2 * dpq0 < (beta >> 2) && d_abs(pv[0][3] - pv[0][0]) + d_abs(qv[0][0] - qv[0][3]) < (beta >> 3) &&
-                         d_abs(pv[0][0] - qv[0][0]) < ((5 * tc + 1) >> 1);
-      const bool dSam3 = 2 * dpq3 < (beta >> 2) && d_abs(pv[3][3] - pv[3][0]) + d_abs(qv[3][0] - qv[3][3]) < (beta >> 3) &&
-                         d_abs(pv[3][0] - qv[3][0]) < ((5 * tc + 1) >> 1);
+      const bool dSam0 = 2 * dpq0 < (beta >> 2) && d_abs(PV(0, 3) - PV(0, 0)) + d_abs(QV(0, 0) - QV(0, 3)) < (beta >> 3) &&
+                         d_abs(PV(0, 0) - QV(0, 0)) < ((5 * tc + 1) >> 1);
+      const bool dSam3 = 2 * dpq3 < (beta >> 2) && d_abs(PV(3, 3) - PV(3, 0)) + d_abs(QV(3, 0) - QV(3, 3)) < (beta >> 3) &&
+                         d_abs(PV(3, 0) - QV(3, 0)) < ((5 * tc + 1) >> 1);
       const bool strong = dSam0 && dSam3;
       const bool dEp = dp < ((beta + (beta >> 1)) >> 3), dEq = dq < ((beta + (beta >> 1)) >> 3);
+      /* the filtered samples replace the loaded ones; np / nq = how far from the edge a side was modified (0: not at all) */
+      int np = 0, nq = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int p0 = pv[k][0], p1 = pv[k][1], p2 = pv[k][2], p3 = pv[k][3];
-        const int q0 = qv[k][0], q1 = qv[k][1], q2 = qv[k][2], q3 = qv[k][3];
-        PIX* o = ptr + k * along;
+        const int p0 = PV(k, 0), p1 = PV(k, 1), p2 = PV(k, 2), p3 = PV(k, 3);
+        const int q0 = QV(k, 0), q1 = QV(k, 1), q2 = QV(k, 2), q3 = QV(k, 3);
         if (strong) {
           if (filterP) {
-            o[-1 * across] = (PIX)d_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
-            o[-2 * across] = (PIX)d_clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
-            o[-3 * across] = (PIX)d_clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+            SETP(k, 0, d_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3));
+            SETP(k, 1, d_clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2));
+            SETP(k, 2, d_clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3));
+            np = 3;
           }
           if (filterQ) {
-            o[0] = (PIX)d_clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
-            o[across] = (PIX)d_clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
-            o[2 * across] = (PIX)d_clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+            SETQ(k, 0, d_clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3));
+            SETQ(k, 1, d_clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2));
+            SETQ(k, 2, d_clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
+            nq = 3;
           }
         } else {
           int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
           if (d_abs(delta) < tc * 10) {
             delta = d_clip3(-tc, tc, delta);
-            if (filterP) o[-across] = (PIX)d_clip_bd(p0 + delta, bd);
-            if (filterQ) o[0] = (PIX)d_clip_bd(q0 - delta, bd);
-            if (dEp && filterP) o[-2 * across] = (PIX)d_clip_bd(p1 + d_clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1), bd);
-            if (dEq && filterQ) o[across] = (PIX)d_clip_bd(q1 + d_clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1), bd);
+            if (filterP) { SETP(k, 0, d_clip_bd(p0 + delta, bd)); np = max(np, 1); }
+            if (filterQ) { SETQ(k, 0, d_clip_bd(q0 - delta, bd)); nq = max(nq, 1); }
+            if (dEp && filterP) { SETP(k, 1, d_clip_bd(p1 + d_clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1), bd)); np = max(np, 2); }
+            if (dEq && filterQ) { SETQ(k, 1, d_clip_bd(q1 + d_clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1), bd)); nq = max(nq, 2); }
           }
         }
       }
+      /* write back whole vectors of the sides / rows that changed (nobody else touches this segment's samples in this pass) */
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (VERTICAL ? np > 0 : j < np) d_st4<PIX>(VERTICAL ? ptr + j * stride - 4 : ptr - (j + 1) * stride, rp[j]);
+        if (VERTICAL ? nq > 0 : j < nq) d_st4<PIX>(ptr + j * stride, rq[j]);
+      }
     }
   }
+#undef PV
+#undef QV
+#undef SETP
+#undef SETQ
 
   /* ---- chroma (deblock.cc:635-761): bS == 2 only, on the 8-sample chroma grid ---- */
   if (bS > 1 && p.pp.chroma_format_idc != 0) {

@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint3
   return d_pk_add16(d_pk_add16(s1, s2), 0x00020002u);
 }
 
-template <class PIX>
+template <class PIX, bool PACKED>
 __global__ void __launch_bounds__(256) k_sao(DevPic p)
 {
   M355_GATE(p);
@@ -125,78 +125,93 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
   /* tile sharding: only own CTBs are filtered / written; waves without any own sample leave at once */
   const bool owned = !p.ctb_owner || p.ctb_owner[yCtb * p.ctbW + xCtb] != 0;
   if (!__any(owned)) return;
+
+  /* ---- memory round trip 1: the CTB record, its neighbour mask and the thread's own four rows, all requested together and
+     from CLAMPED addresses (no per-lane branch in front of a load: a branch makes hipcc wait for everything in flight — the
+     kernel used to be a chain of up to 17 dependent round trips per wave, and it is latency x occupancy that bounds it, not
+     bandwidth) ---- */
+  constexpr int NW = (int)sizeof(V4) / 4;
+  const int xs = max(0, min(x0, width - 4));                      /* (planes are at least 4 wide) */
   const m355_ctb ctb = p.ctbs[yCtb * p.ctbW + xCtb];
-  const m355_slice csl = p.slices[ctb.slice_idx];
+  const uint32_t nbmask_raw = p.sao_nb[c * p.nCtb + yCtb * p.ctbW + xCtb];
+  uint32_t rw[6][NW];
+#pragma unroll
+  for (int r = 1; r <= 4; r++) d_sao_load4<PIX>(in + (size_t)min(y0 + r - 1, height - 1) * is + xs, rw[r]);
   /* this component's parameters, selected without indexing the record dynamically */
   const int band_pos = c == 0 ? ctb.sao_band_pos[0] : (c == 1 ? ctb.sao_band_pos[1] : ctb.sao_band_pos[2]);
   const int so0 = c == 0 ? ctb.sao_offset[0][0] : (c == 1 ? ctb.sao_offset[1][0] : ctb.sao_offset[2][0]);
   const int so1 = c == 0 ? ctb.sao_offset[0][1] : (c == 1 ? ctb.sao_offset[1][1] : ctb.sao_offset[2][1]);
   const int so2 = c == 0 ? ctb.sao_offset[0][2] : (c == 1 ? ctb.sao_offset[1][2] : ctb.sao_offset[2][2]);
   const int so3 = c == 0 ? ctb.sao_offset[0][3] : (c == 1 ? ctb.sao_offset[1][3] : ctb.sao_offset[2][3]);
+  const int type_raw = valid ? ((ctb.sao_type >> (2 * c)) & 3) : 0;
+  /* ---- round trip 2: the slice record and — where the CTB asks for an edge class — the wave tile's rim: the row above the
+     top lanes and below the bottom lanes, and the sample left / right of the outer lanes for the six rows.  The rim columns
+     are 48 samples per wave: lane i fetches sample i (ONE load instruction), the outer lanes pick theirs up with cross-lane reads. ---- */
+  const m355_slice csl = p.slices[ctb.slice_idx];
+  const bool any_edge = __any(type_raw == 2);
+  uint32_t rim_up[NW], rim_dn[NW];
+  uint32_t rim_col = 0;
+  if (any_edge) {
+    d_sao_load4<PIX>(in + (size_t)(ly == 0 ? max(y0 - 1, 0) : min(y0, height - 1)) * is + xs, rim_up);
+    d_sao_load4<PIX>(in + (size_t)(ly == 3 ? min(y0 + 4, height - 1) : min(y0 + 3, height - 1)) * is + xs, rim_dn);
+    /* lane i < 48: group g = i / 12 (the lanes with ly == g), side = (i % 12) / 6 (0 left, 1 right), row r = i % 6 */
+    const int g = lane / 12, k12 = lane - g * 12, side = k12 >= 6 ? 1 : 0, r = k12 - 6 * side;
+    const int yy = min(max(yt + 4 * min(g, 3) - 1 + r, 0), height - 1);
+    const int xx = side ? min(xt + 64, width - 1) : max(xt - 1, 0);
+    rim_col = in[(size_t)yy * is + xx];
+  }
   const bool enabled = c == 0 ? (csl.flags & M355_SF_SAO_LUMA) : (csl.flags & M355_SF_SAO_CHROMA);
-  const int type = (enabled && valid) ? ((ctb.sao_type >> (2 * c)) & 3) : 0;
+  const int type = enabled ? type_raw : 0;
   const bool edge = type == 2;
-
-  /* ---- the 6x6 neighbourhood; rows are kept as raw 32-bit words (NW per 4 samples) ---- */
-  constexpr int NW = (int)sizeof(V4) / 4;
-  int nb[6][6];
-  uint32_t rw[6][NW];
-#pragma unroll
-  for (int r = 0; r < 6; r++)
-#pragma unroll
-    for (int k = 0; k < NW; k++) rw[r][k] = 0;
 #pragma unroll
   for (int r = 1; r <= 4; r++)
-    if (r - 1 < rows) d_sao_load4<PIX>(in + (size_t)(y0 + r - 1) * is + x0, rw[r]);
-  const bool any_edge = __any(edge);
+    if (r - 1 >= rows) {
+#pragma unroll
+      for (int k = 0; k < NW; k++) rw[r][k] = 0;
+    }
+#pragma unroll
+  for (int k = 0; k < NW; k++) { rw[0][k] = 0; rw[5][k] = 0; }
   if (any_edge) {
-    /* rows y0-1 and y0+4: the lanes 16 up / down hold them as their last / first own row */
+    /* rows y0-1 and y0+4: the lanes 16 up / down hold them as their last / first own row; the wave tile's rim came from memory */
 #pragma unroll
     for (int k = 0; k < NW; k++) {
       const uint32_t up = __shfl_up(rw[4][k], 16, 64), dn = __shfl_down(rw[1][k], 16, 64);
-      if (ly > 0) rw[0][k] = up;
-      if (ly < 3) rw[5][k] = dn;
+      rw[0][k] = ly > 0 ? up : ((valid && y0 > 0) ? rim_up[k] : 0u);
+      rw[5][k] = ly < 3 ? dn : ((valid && y0 + 4 < height) ? rim_dn[k] : 0u);
     }
-    if (valid && ly == 0 && y0 > 0) d_sao_load4<PIX>(in + (size_t)(y0 - 1) * is + x0, rw[0]);
-    if (valid && ly == 3 && y0 + 4 < height) d_sao_load4<PIX>(in + (size_t)(y0 + 4) * is + x0, rw[5]);
   }
   const int bd = c ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma, maxv = (1 << bd) - 1;
-  const bool packed = bd <= 15;      /* uniform: 16-bit lane differences need |c - a| < 32768 */
+  constexpr bool packed = PACKED;    /* bit depth <= 15 (the launcher decides): 16-bit lane differences need |c - a| < 32768 */
   /* rows as packed 16-bit pairs (s0,s1)(s2,s3) + the sample left / right of the block */
   uint32_t P[6][2];
   int Ls[6], Rs[6];
+  int nb[6][6];
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     if (sizeof(PIX) == 2) { P[r][0] = rw[r][0]; P[r][1] = rw[r][NW - 1]; }
     else { P[r][0] = d_perm(0u, rw[r][0], 0x0c010c00u); P[r][1] = d_perm(0u, rw[r][0], 0x0c030c02u); }
     Ls[r] = Rs[r] = 0;
   }
-  if (packed) {
-    if (any_edge) {
+  if (any_edge) {
 #pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const int yy = y0 - 1 + r;
-        const bool yok = valid && yy >= 0 && yy < height;
-        int l = __shfl_up((int)(P[r][1] >> 16), 1, 64), rg = __shfl_down((int)(P[r][0] & 0xFFFFu), 1, 64);
-        if (lx == 0) l = (edge && yok && x0 > 0) ? (int)in[(size_t)yy * is + x0 - 1] : 0;
-        if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? (int)in[(size_t)yy * is + x0 + 4] : 0;
-        Ls[r] = l; Rs[r] = rg;
-      }
+    for (int r = 0; r < 6; r++) {
+      const int yy = y0 - 1 + r;
+      const bool yok = valid && yy >= 0 && yy < height;
+      /* the wave tile's left / right rim sample of this lane's row group: fetched by lane ly * 12 + r (left) / + 6 + r (right);
+         the tile lies at x = xt .. xt + 63, so x0 > 0 for an outer-left lane means xt > 0 */
+      const int rimv = __shfl((int)rim_col, ly * 12 + (lx == 15 ? 6 : 0) + r, 64);
+      int l = __shfl_up((int)(P[r][1] >> 16), 1, 64), rg = __shfl_down((int)(P[r][0] & 0xFFFFu), 1, 64);
+      if (lx == 0) l = (edge && yok && x0 > 0) ? rimv : 0;
+      if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? rimv : 0;
+      Ls[r] = l; Rs[r] = rg;
     }
-  } else {
+  }
+  if (!packed) {
 #pragma unroll
     for (int r = 0; r < 6; r++) {
 #pragma unroll
       for (int k = 0; k < 4; k++) nb[r][1 + k] = d_sao_sample<PIX>(rw[r], k);
-      nb[r][0] = nb[r][5] = 0;
-      if (any_edge) {
-        const int yy = y0 - 1 + r;
-        const bool yok = valid && yy >= 0 && yy < height;
-        int l = __shfl_up(nb[r][4], 1, 64), rg = __shfl_down(nb[r][1], 1, 64);
-        if (lx == 0) l = (edge && yok && x0 > 0) ? (int)in[(size_t)yy * is + x0 - 1] : 0;
-        if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? (int)in[(size_t)yy * is + x0 + 4] : 0;
-        nb[r][0] = l; nb[r][5] = rg;
-      }
+      nb[r][0] = Ls[r]; nb[r][5] = Rs[r];
     }
   }
   /* pcm (with pcm_loop_filter_disable) / transquant-bypass samples are left alone (sao.cc:103-120); and is any
@@ -213,7 +228,7 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
         }
       }
   }
-  const uint32_t nbmask = (valid && edge) ? p.sao_nb[c * p.nCtb + yCtb * p.ctbW + xCtb] : 0u;
+  const uint32_t nbmask = (valid && edge) ? nbmask_raw : 0u;
   const bool slow = __any(skipmask != 0 || nbmask != 0);
   if (!valid || !owned) return;
 
@@ -345,6 +360,7 @@ void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st)
   /* one launch for all components: grid.z = component; chroma blocks beyond the chroma plane exit at once */
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
   const dim3 grid((p.pw[0] + 255) / 256, (p.ph[0] + 15) / 16, nc), block(256);   /* 4 waves side by side: 256 x 16 samples */
-  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t>), grid, block, 0, st, p);
+  if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p);
+  else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p);
 }
