@@ -548,6 +548,9 @@ M355_API int m355_shard_set_comm(m355_ctx* ctx, const m355_comm* comm);
 M355_API int m355_decode_sharded(m355_ctx* ctx, int handle, int gather);
 M355_API int m355_rccl_unique_id(void* out128);                                  /* rank 0: ncclGetUniqueId (128 bytes) */
 M355_API int m355_shard_rccl_init(m355_ctx* ctx, const void* id128, int rank, int nranks);   /* m355_shard_set + an RCCL communicator on the context's device */
+/* collective self-test of that transport: `words` 32-bit words through the halo exchange (every other rank as peer; a lone rank
+ * sends to itself) and the all-gather, verified on the host */
+M355_API int m355_shard_rccl_selftest(m355_ctx* ctx, size_t words);
 /* device time (ms) of exchange `which` (0..3) of a sharded picture's buffers over the installed transport, averaged over `iters` runs;
  * collective: every rank calls it alike, after at least one m355_decode_sharded of the picture */
 M355_API int m355_shard_time_exchange(m355_ctx* ctx, int handle, int which, int iters, float* ms_each);

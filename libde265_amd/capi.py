@@ -97,6 +97,7 @@ class Library:
         L.m355_shard_set_comm.argtypes = [vp, vp]
         L.m355_rccl_unique_id.argtypes = [vp]
         L.m355_shard_rccl_init.argtypes = [vp, vp, i, i]
+        L.m355_shard_rccl_selftest.argtypes = [vp, ctypes.c_size_t]
         L.m355_shard_peers.argtypes = [vp, i, i, ctypes.POINTER(i), i]
         L.m355_shard_time_exchange.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_float)]
         L.init_acceleration_functions_mi355x.argtypes = [vp]
@@ -270,6 +271,10 @@ class Context:
     def shard_set_comm(self, comm_struct):
         """comm_struct: a ctypes m355_comm (kept alive by the caller) or None"""
         self.L.check(self.L.lib.m355_shard_set_comm(self.h, ctypes.addressof(comm_struct) if comm_struct is not None else None))
+
+    def shard_rccl_selftest(self, words=1 << 16):
+        """collective: real bytes through ncclSend / ncclRecv / ncclAllGather of this context's communicator, checked on the host"""
+        self.L.check(self.L.lib.m355_shard_rccl_selftest(self.h, words))
 
     def shard_rccl_init(self, unique_id, rank, nranks):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)

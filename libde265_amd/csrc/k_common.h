@@ -113,10 +113,12 @@ struct DevPic {
   uint32_t res_fused_base[4];
   uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
-  const uint32_t* job_base;         /* [256-PB chunk][3]: first job index of the chunk per range (uni, bi, edge), from the host's upload pass */
+  uint32_t* job_base;               /* [256-PB chunk][3]: first job index of the chunk per range (uni, bi, edge): k_job_count leaves the chunk's
+                                       counts here, k_job_scan turns them into the prefix sums k_meta_pb reads (lane scratch) */
+  uint32_t* job_tot;                /* [0] one-list jobs, [1] + bi-predicted = where the EDGE range starts, [2] all jobs (k_job_scan; clamped to jobs_cap) */
+  uint32_t jobs_cap;                /* entries of jobs[]: >= what any list of disjoint prediction blocks produces (runtime.hip prepare) */
   int fill_pb_of_in_meta;           /* 1: k_meta_pb fills pb_of (inter stage off); 0: k_inter_jobs does, two units per job */
-  int n_jobs;                       /* sum over PBs of (w/4) * ceil(h/8), computed at upload */
-  int n_jobs_uni, n_jobs_main;      /* jobs [0, n_jobs_uni): one list; [n_jobs_uni, n_jobs_main): bi-predicted; [n_jobs_main, n_jobs): EDGE (clamped loads) */
+  /* (jobs [0, job_tot[0]): one list; [job_tot[0], job_tot[1]): bi-predicted; [job_tot[1], job_tot[2]): EDGE = clamped loads) */
   /* intra wavefront state */
   unsigned long long* edge;         /* k_intra's halo exchange: 8-byte granules (epoch << 32 | two samples), per component the right
                                        columns of all CTB columns [ctbX][row >> 1], then the bottom rows of all CTB rows [ctbY][col >> 1] */

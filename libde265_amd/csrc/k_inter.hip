@@ -508,9 +508,14 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
 #define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
 #endif
 template <class PIX, bool BIAS>
-__global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jobs(DevPic p, int nblk_edge8, int nblk_bi8)
+__global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jobs(DevPic p)
 {
   M355_GATE(p);
+  /* the job counts live on the device (k_job_scan); the grid is an upper bound: surplus workgroups leave here */
+  const int n_jobs_uni = (int)p.job_tot[0], n_jobs_main = (int)p.job_tot[1], n_jobs = (int)p.job_tot[2];
+  auto blocks8 = [](int jobs) { return (((jobs + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK + 7) / 8) * 8; };
+  const int nblk_uni8 = blocks8(n_jobs_uni), nblk_bi8 = blocks8(n_jobs_main - n_jobs_uni), nblk_edge8 = blocks8(n_jobs - n_jobs_main);
+  if ((int)blockIdx.x >= nblk_edge8 + nblk_bi8 + nblk_uni8) return;
   __shared__ unsigned s_qt[4 * QT_STRIDE];
   __shared__ unsigned s_et[8 * ET_STRIDE];
   /* the reference-frame table (plane pointers / pitches per DPB slot) in LDS: a job looks its references up
@@ -544,12 +549,12 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
      each range (= compact regions of the picture) so reference-window overlap hits that XCD's own L2. */
   const int b = blockIdx.x;
   if (b < nblk_edge8) {
-    const int ji = p.n_jobs_main + b * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < p.n_jobs) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et, s_refs);
+    const int ji = n_jobs_main + b * M355_INTER_BLOCK + threadIdx.x;
+    if (ji < n_jobs) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et, s_refs);
     return;
   }
   const int bm = b - nblk_edge8, xcd = bm & 7, slot = bm >> 3;
-  const int per_bi = nblk_bi8 >> 3, per_uni = (gridDim.x - nblk_edge8 - nblk_bi8) >> 3;
+  const int per_bi = nblk_bi8 >> 3, per_uni = nblk_uni8 >> 3;
 #ifndef M355_INTER_NO_INTERLEAVE
   /* Within an XCD the bi-predicted and the one-list blocks are interleaved in proportion (both lists are in
      PB order, so block i/per_bi of one and block i/per_uni of the other cover the same part of the picture):
@@ -558,19 +563,19 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
   const int per = per_bi + per_uni;
   const int bi_before = (int)(((long long)slot * per_bi) / per), bi_after = (int)(((long long)(slot + 1) * per_bi) / per);
   if (bi_after != bi_before) {
-    const int ji = p.n_jobs_uni + (xcd * per_bi + bi_before) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
+    const int ji = n_jobs_uni + (xcd * per_bi + bi_before) * M355_INTER_BLOCK + threadIdx.x;
+    if (ji < n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   } else {
     const int ji = (xcd * per_uni + slot - bi_before) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
+    if (ji < n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   }
 #else
   if (slot < per_bi) {
-    const int ji = p.n_jobs_uni + (xcd * per_bi + slot) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < p.n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
+    const int ji = n_jobs_uni + (xcd * per_bi + slot) * M355_INTER_BLOCK + threadIdx.x;
+    if (ji < n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   } else {
     const int ji = (xcd * per_uni + slot - per_bi) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < p.n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
+    if (ji < n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
   }
 #endif
 }
@@ -775,11 +780,10 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
 template <class PIX, bool BIAS>
 static void launch_jobs(const DevPic& p, hipStream_t st)
 {
-  /* grid padded to a multiple of 8 blocks for the XCD-contiguous block order */
-  auto blocks8 = [](int jobs) { return (((jobs + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK + 7) / 8) * 8; };
-  const int nblk_uni8 = blocks8(p.n_jobs_uni), nblk_bi8 = blocks8(p.n_jobs_main - p.n_jobs_uni), nblk_edge8 = blocks8(p.n_jobs - p.n_jobs_main);
-  if (!(nblk_uni8 + nblk_bi8 + nblk_edge8)) return;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(nblk_edge8 + nblk_bi8 + nblk_uni8), dim3(M355_INTER_BLOCK), 0, st, p, nblk_edge8, nblk_bi8);
+  /* each range's blocks are padded to a multiple of 8 for the XCD-contiguous block order; the counts are on the device, so the
+     grid covers the most jobs the list can hold */
+  const unsigned grid = (unsigned)((p.jobs_cap + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK) + 3 * 8;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(grid), dim3(M355_INTER_BLOCK), 0, st, p);
 }
 
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)

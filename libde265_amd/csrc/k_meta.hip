@@ -102,6 +102,71 @@ __global__ void __launch_bounds__(256) k_meta_tu(DevPic p)
   }
 }
 
+/* ---- job counts on the device (the host no longer reads the PB list of a picture recorded in place) ----
+ * k_job_count: one workgroup per 256-PB chunk (= one k_meta_pb workgroup): the chunk's jobs per range -> job_base[chunk][3].
+ * k_job_scan : ONE workgroup turns the counts into the chunks' first job indices (ranges one after the other: one list, two
+ *              lists, picture edge) and leaves the range ends in job_tot[0..2].  A malformed record counts nothing here (k_validate
+ *              rejects the picture); lists whose blocks overlap can exceed jobs[]: the ends are clamped and k_meta_pb drops what
+ *              does not fit (memory-safe, the picture is garbage either way). */
+__device__ __forceinline__ int d_pb_jobs(const m355_pb& pb)
+{
+  if (pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3)) return 0;
+  return (pb.w >> 2) * ((pb.h + 7) >> 3);
+}
+__global__ void __launch_bounds__(256) k_job_count(DevPic p)
+{
+  M355_GATE(p);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int cnt[3] = {0, 0, 0};
+  if (i < p.n_pbs) {
+    const m355_pb pb = p.pbs[i];
+    const int cls = m355_pb_is_edge(pb, p.pp.width, p.pp.chroma_format_idc) ? 2 : (((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0);
+    const int n = d_pb_jobs(pb);
+    cnt[0] = cls == 0 ? n : 0; cnt[1] = cls == 1 ? n : 0; cnt[2] = cls == 2 ? n : 0;
+  }
+  __shared__ int s_w[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt[k] += __shfl_xor(cnt[k], d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6][0] = cnt[0]; s_w[threadIdx.x >> 6][1] = cnt[1]; s_w[threadIdx.x >> 6][2] = cnt[2]; }
+  __syncthreads();
+  if (threadIdx.x < 3) p.job_base[blockIdx.x * 3 + threadIdx.x] = (uint32_t)(s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(1024) k_job_scan(DevPic p, int n_chunks)
+{
+  M355_GATE(p);
+  __shared__ uint32_t s_sum[3][1024];
+  const int t = threadIdx.x;
+  const int per = (n_chunks + 1023) / 1024, c0 = t * per, c1 = min(n_chunks, c0 + per);
+  uint32_t mine[3] = {0, 0, 0};
+  for (int c = c0; c < c1; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) mine[k] += p.job_base[c * 3 + k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) s_sum[k][t] = mine[k];
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {        /* inclusive scan over the threads' sums */
+    uint32_t v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) v[k] = t >= d ? s_sum[k][t - d] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) s_sum[k][t] += v[k];
+    __syncthreads();
+  }
+  const uint32_t nu = s_sum[0][1023], nb = s_sum[1][1023], ne = s_sum[2][1023];
+  uint32_t run[3] = {s_sum[0][t] - mine[0], nu + s_sum[1][t] - mine[1], nu + nb + s_sum[2][t] - mine[2]};
+  for (int c = c0; c < c1; c++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const uint32_t n = p.job_base[c * 3 + k]; p.job_base[c * 3 + k] = run[k]; run[k] += n; }
+  if (t == 0) {
+    const uint32_t cap = p.jobs_cap;
+    p.job_tot[0] = min(nu, cap); p.job_tot[1] = min(nu + nb, cap); p.job_tot[2] = min(nu + nb + ne, cap);
+  }
+}
+
 /* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) and the job list of
  * k_inter_jobs: (w/4) x ceil(h/8) jobs per PB, row block major so consecutive jobs are horizontally
  * adjacent; three ranges (one-list, bi-predicted, picture-edge jobs), each in PB order. */
@@ -113,8 +178,8 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   const bool active = i < p.n_pbs;
   m355_pb pb;
   if (active) pb = p.pbs[i]; else { pb.x = pb.y = 0; pb.w = pb.h = 0; pb.flags = 0; }
-  const int ns = pb.w >> 2, nr = (pb.h + 7) >> 3;
-  const int njobs = active ? ns * nr : 0;
+  const int ns = pb.w >> 2;
+  const int njobs = active ? d_pb_jobs(pb) : 0;              /* (as k_job_count counted it) */
   /* three ranges: one-list jobs, bi-predicted jobs (so a wave never idles through a second pass it does
      not need), edge jobs; wave-level exclusive scans, one atomic per wave and range */
   const bool edge = active && m355_pb_is_edge(pb, p.pp.width, p.pp.chroma_format_idc);
@@ -163,7 +228,7 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
     const int ns_k = __shfl(ns, k, 64);
     const uint32_t dst = __shfl(dst0, k, 64) + (uint32_t)local;
     const uint32_t pbi = (uint32_t)__shfl(i, k, 64);
-    if (t < total) {
+    if (t < total && dst < p.jobs_cap) {
       const int r = local / ns_k, s = local - r * ns_k;
       p.jobs[dst] = pbi | ((uint32_t)s << 25) | ((uint32_t)r << 29);
     }
@@ -211,7 +276,11 @@ __global__ void __launch_bounds__(256) k_meta_sao(DevPic p)
 /* the inter stage needs only the job list (+ pb_of when the inter stage is off) */
 void m355_launch_meta_jobs(const DevPic& p, hipStream_t st)
 {
-  if (p.n_pbs) hipLaunchKernelGGL(k_meta_pb, dim3((p.n_pbs + 255) / 256), dim3(256), 0, st, p);
+  if (!p.n_pbs) return;
+  const int n_chunks = (p.n_pbs + 255) / 256;
+  hipLaunchKernelGGL(k_job_count, dim3(n_chunks), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_job_scan, dim3(1), dim3(1024), 0, st, p, n_chunks);
+  hipLaunchKernelGGL(k_meta_pb, dim3(n_chunks), dim3(256), 0, st, p);
 }
 
 /* metadata planes for intra availability, deblocking and SAO (not read by k_inter / k_residual) */

@@ -112,7 +112,6 @@ struct Resident {
   bool refs_valid = false;
   int n_intra_work = 0;
   uint32_t n_iplan = 0;        /* border-plan entries of the picture's intra blocks (k_intra_plan -> k_intra) */
-  int n_jobs = 0, n_jobs_main = 0, n_jobs_uni = 0;   /* inter jobs (k_inter_jobs), from the PB geometry */
   /* tile sharding (m355_decode_phase) */
   bool sharded = false;
   int shard_rank = 0, shard_n = 1;
@@ -131,8 +130,9 @@ struct Resident {
   bool fresh = false;          /* uploaded and not decoded since: nothing in flight reads its reference table */
   bool arena = false;          /* m355_arena_begin handed out list pointers into `host`: the next upload of lists that sit there copies nothing */
   m355_arena_caps caps;        /* ... with room for this many entries */
-  std::vector<uint32_t> job_cnt;   /* per 256-PB chunk and range: inter jobs (filled by the validation sweep) */
   bool device_validate = false;    /* the record checks of these lists run on the device (k_validate) */
+  std::vector<uint8_t> sched_u8;   /* upload(): per-CTB scratch of the intra schedule */
+  std::vector<uint32_t> sched_u32;
 };
 
 /* Everything ONE picture in flight writes: streams, working planes, metadata / job / residual scratch.  The context's
@@ -156,7 +156,8 @@ struct Lane {
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;   /* border plans of the picture's intra blocks */
   uint32_t* res_map = nullptr; /* fused inter residuals: per component 4x4 unit -> tile piece (k_common.h) */
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0;
+  uint32_t* job_base = nullptr; /* per 256-PB chunk the first job of each range + the three range ends (k_job_count / k_job_scan) */
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0, cap_jobbase = 0;
 };
 
 struct m355_ctx {
@@ -184,7 +185,8 @@ struct m355_ctx {
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;
   uint32_t* res_map = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0;
+  uint32_t* job_base = nullptr;
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0, cap_jobbase = 0;
   uint32_t epoch = 0;
   /* per-decode status (m355_decode_status): the last M355_STATUS_RING decodes; a device-validated decode copies its lane's gate
      words into `words` (pinned) behind its last kernel */
@@ -204,10 +206,13 @@ struct m355_ctx {
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
+  /* CtbAddrRStoTS / TStoRS / TileIdRS of the last tile structure seen (pps.cc:589-606), upload() */
+  struct ScanCache { int ctbW = 0, ctbH = 0, ntc = 0, ntr = 0; decltype(m355_pic_params::col_bd) col_bd; decltype(m355_pic_params::row_bd) row_bd;
+                     std::vector<uint32_t> ctb_ts, ts2rs; std::vector<uint16_t> tile_id; } scan;
 };
 
 #define LANE_FIELDS(X) X(stream) X(stream2) X(stream_hi) X(last_stream) X(ev_last) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
-  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(res_map) X(cap_resmap) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
+  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(res_map) X(cap_resmap) X(job_base) X(cap_jobbase) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
 static void select_lane(m355_ctx* c, int lane)
 {
   if (lane == c->active) return;
@@ -261,7 +266,7 @@ static void lane_destroy(Lane& l)
   if (l.stream) hipStreamSynchronize(l.stream);
   if (l.stream2) hipStreamSynchronize(l.stream2);
   if (l.work.used) frame_free(l.work);
-  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb, l.iplan, l.res_map};
+  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb, l.iplan, l.res_map, l.job_base};
   for (void* b : bufs) if (b) hipFree(b);
   if (l.ev_fork) hipEventDestroy(l.ev_fork);
   if (l.ev_fork2) hipEventDestroy(l.ev_fork2);
@@ -768,7 +773,7 @@ static void parallel_memcpy(void* dst, const void* src, size_t bytes)
 }
 } /* extern "C++" */
 
-static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, uint32_t* job_cnt, bool records_on_device, int* ctbW_out, int* ctbH_out)
+static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, bool records_on_device, int* ctbW_out, int* ctbH_out)
 {
   const m355_pic_params& pp = pic->pp;
   if (pp.width <= 0 || pp.height <= 0 || pp.chroma_format_idc > 3) return fail(M355_ERR_INVALID, "bad picture size / chroma format");
@@ -866,9 +871,10 @@ static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, ui
     return nullptr;
   };
   const char* const names[7] = {"ctb", "cu", "tu", "pb", "weight", "rb", "ib"};
-  /* records_on_device: only what the host's own schedules index by is checked here — the CTB table with each CTB's intra blocks,
-     and the PB sizes the job counts are made of; every record check runs in k_validate before any kernel acts on the lists */
-  const size_t cnts[7] = {(size_t)pic->n_ctbs, records_on_device ? 0 : (size_t)pic->n_cus, records_on_device ? 0 : (size_t)pic->n_tus, (size_t)pic->n_pbs,
+  /* records_on_device: only what the host's own schedules index by is checked here — the CTB table with each CTB's intra blocks;
+     every record check runs in k_validate before any kernel acts on the lists, and the inter job counts are made on the device
+     (k_job_count / k_job_scan): the host does not read the PB list at all */
+  const size_t cnts[7] = {(size_t)pic->n_ctbs, records_on_device ? 0 : (size_t)pic->n_cus, records_on_device ? 0 : (size_t)pic->n_tus, records_on_device ? 0 : (size_t)pic->n_pbs,
                           records_on_device ? 0 : (size_t)pic->n_wts, records_on_device ? 0 : nrb, records_on_device ? 0 : (size_t)pic->n_ibs};
   size_t ofs[8];
   ofs[0] = 0;
@@ -889,24 +895,7 @@ static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, ui
         case 0: SWEEP(chk_ctb) break;
         case 1: SWEEP(chk_cu) break;
         case 2: SWEEP(chk_tu) break;
-        case 3: {
-          /* with each record in the cache: its share of the inter job counts, per 256-PB chunk (= one k_meta_pb workgroup) and
-             range (one list / two lists / picture-edge windows); a thread's partial sums are flushed once per chunk */
-          uint32_t acc[3] = {0, 0, 0};
-          size_t chunk = (lo - base) >> 8;
-          auto flush = [&]() { for (int k = 0; k < 3; k++) if (acc[k]) { __atomic_fetch_add(&job_cnt[chunk * 3 + k], acc[k], __ATOMIC_RELAXED); acc[k] = 0; } };
-          for (size_t g = lo; g < hi; g++) {
-            const size_t i = g - base;
-            if ((m = chk_pb(i)) != nullptr) { bad = g; break; }
-            if ((i >> 8) != chunk) { flush(); chunk = i >> 8; }
-            const m355_pb& pb = pic->pbs[i];
-            int cls = 2;
-            if (!m355_pb_is_edge(pb, pp.width, pp.chroma_format_idc)) cls = ((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0;
-            acc[cls] += (uint32_t)(pb.w >> 2) * ((pb.h + 7) >> 3);
-          }
-          flush();
-          break;
-        }
+        case 3: SWEEP(chk_pb) break;
         case 4: SWEEP(chk_wt) break;
         case 5: SWEEP(chk_rb) break;
         default: SWEEP(chk_ib) break;
@@ -930,35 +919,10 @@ static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, ui
 /* Which neighbour CTBs must the intra wavefront wait for?  (k_intra.hip reads this mask.)
  * touch bits per CTB: an intra block reaches its right column (1), bottom row (2), both (4);
  * need bits: an intra block reads across the left (L), top (T), top-left (TL), top-right (TR) border. */
-static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, const uint16_t* tile_id, uint8_t* dep)
+static void intra_dependencies(int ctbW, int ctbH, const uint16_t* tile_id, const uint8_t* touch, const uint8_t* need, uint8_t* dep)
 {
-  const m355_pic_params& pp = pic->pp;
   const int nCtb = ctbW * ctbH;
-  std::vector<uint8_t> touch(nCtb, 0), need(nCtb, 0);
-  const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
-  parallel_ranges((size_t)nCtb, 512, [&](size_t cb, size_t ce) {
-    for (size_t c = cb; c < ce; c++) {
-      const m355_ctb& ctb = pic->ctbs[c];
-      const int cx = (int)c % ctbW, cy = (int)c / ctbW;
-      uint8_t t = 0, n_ = 0;
-      for (uint32_t k = 0; k < ctb.ib_count; k++) {
-        const m355_ib& ib = pic->ibs[ctb.ib_start + k];
-        const int csw = ib.cidx ? (sw == 2) : 0, csh = ib.cidx ? (sh == 2) : 0;
-        const int cw = (1 << pp.log2_ctb_size) >> csw, ch = (1 << pp.log2_ctb_size) >> csh;
-        const int lx = ib.x - ((cx << pp.log2_ctb_size) >> csw), ly = ib.y - ((cy << pp.log2_ctb_size) >> csh);
-        const int n = 1 << ib.log2_size;
-        if (lx + n == cw) t |= 1;
-        if (ly + n == ch) t |= 2;
-        if (lx + n == cw && ly + n == ch) t |= 4;
-        if (ib.flags & M355_IBF_PCM) continue;              /* raw blocks read no neighbours */
-        if (lx == 0) n_ |= 1;                                /* L  */
-        if (lx == 0 && ly == 0) n_ |= 2;                     /* TL */
-        if (ly == 0) n_ |= 4;                                /* T  */
-        if (ly == 0 && lx + 2 * n > cw) n_ |= 8;             /* TR */
-      }
-      touch[c] = t; need[c] = n_; dep[c] = 0;
-    }
-  });
+  memset(dep, 0, (size_t)nCtb);
   /* serial and short: one pass over the CTBs (the "somebody reads ours" bit lands on a neighbour) */
   for (int c = 0; c < nCtb; c++) {
     if (!need[c]) continue;
@@ -991,7 +955,7 @@ static void intra_dependencies(const m355_picture* pic, int ctbW, int ctbH, cons
  * picture on average: an I picture of 64x64 CUs has 12, the inter pictures of the bench 3.4).
  * Returns the first CTB whose intra blocks overlap (they never do in a picture the reference decodes: one
  * decode_intra_prediction per transform block; the LDS budgets of k_intra rest on it), or -1. */
-static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* out, uint32_t* aux, uint32_t* plan_count, uint8_t* log2_waves, int* dense)
+static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* out, uint32_t* aux, uint32_t* plan_count, uint8_t* log2_waves, uint8_t* touch, uint8_t* need, int* dense)
 {
   const m355_pic_params& pp = pic->pp;
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
@@ -1003,7 +967,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
     long long my_blocks = 0, my_ctbs = 0;
     for (size_t c = cb; c < ce; c++) {
       const m355_ctb& ctb = pic->ctbs[c];
-      log2_waves[c] = 0; plan_count[c] = 0;
+      log2_waves[c] = 0; plan_count[c] = 0; touch[c] = 0; need[c] = 0;
       if (!ctb.ib_count) continue;
       my_ctbs++; my_blocks += ctb.ib_count;
       const int cx = (int)c % ctbW, cy = (int)c / ctbW;
@@ -1017,6 +981,23 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
         const int ux = (ib.x - ((cx << pp.log2_ctb_size) >> csw)) >> 2, uy = (ib.y - ((cy << pp.log2_ctb_size) >> csh)) >> 2;
         const int n4 = (1 << ib.log2_size) >> 2;
         int level = 0;
+        {
+          /* what the CTB-to-CTB dependencies are made of (intra_dependencies): does a block reach the CTB's right column (1) /
+             bottom row (2) / both (4), and does a predicted block read across the left (1), top-left (2), top (4), top-right (8) border */
+          const int cw = (1 << pp.log2_ctb_size) >> csw, ch = (1 << pp.log2_ctb_size) >> csh, n = 1 << ib.log2_size;
+          const int lx = ib.x - ((cx << pp.log2_ctb_size) >> csw), ly = ib.y - ((cy << pp.log2_ctb_size) >> csh);
+          uint8_t t = 0, n_ = 0;
+          if (lx + n == cw) t |= 1;
+          if (ly + n == ch) t |= 2;
+          if (lx + n == cw && ly + n == ch) t |= 4;
+          if (!(ib.flags & M355_IBF_PCM)) {                /* raw blocks read no neighbours */
+            if (lx == 0) n_ |= 1;
+            if (lx == 0 && ly == 0) n_ |= 2;
+            if (ly == 0) n_ |= 4;
+            if (ly == 0 && lx + 2 * n > cw) n_ |= 8;
+          }
+          touch[c] |= t; need[c] |= n_;
+        }
         if (ux < 0 || uy < 0 || ux >= 16 || uy >= 16) { key.push_back(std::make_pair((uint32_t)ib.cidx, k)); continue; }   /* rejected by validate() */
         if (!(ib.flags & M355_IBF_PCM)) {                /* raw blocks read nothing */
           for (int t = -1; t < 2 * n4; t++) {
@@ -1142,7 +1123,7 @@ static void make_layout(const m355_arena_caps& k, int nCtb, int halo_units, bool
   L.i_ti = add(2 * (size_t)nCtb);   /* tile_id  */
   L.i_iw = add(sizeof(DevIntraWork) * (size_t)nCtb);   /* intra_work */
   L.i_dp = add((size_t)nCtb);       /* ctb_dep */
-  L.i_jb = add(12 * (size_t)(((size_t)k.n_pbs + 255) / 256 + 1));   /* job_base */
+  L.i_jb = add(0);                  /* (job_base: lane scratch since the job counts are made on the device) */
   L.i_ow = add(sharded ? (size_t)nCtb : 0);                          /* ctb_owner */
 }
 
@@ -1155,11 +1136,9 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const m355_pic_params& pp = pic->pp;
   const bool in_place = r.arena && r.host && pic->n_ctbs > 0 && (const char*)pic->ctbs >= r.host && (const char*)pic->ctbs < r.host + r.cap;
   int ctbW, ctbH;
-  const int n_chunks = (pic->n_pbs > 0 ? pic->n_pbs + 255 : 0) / 256;
-  r.job_cnt.assign((size_t)n_chunks * 3 + 3, 0);
   static const bool host_only = getenv("M355_HOST_VALIDATION") != nullptr;     /* diagnostics: all record checks on the host */
   r.device_validate = in_place && !host_only;
-  int rc = validate(pic, in_place ? (const m355_rb* const*)r.caps.rb_bin : nullptr, r.job_cnt.data(), r.device_validate, &ctbW, &ctbH);
+  int rc = validate(pic, in_place ? (const m355_rb* const*)r.caps.rb_bin : nullptr, r.device_validate, &ctbW, &ctbH);
   if (rc) return rc;
   const auto t_valid = now();
   const int nCtb = ctbW * ctbH;
@@ -1203,7 +1182,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     srcs[i_pc] = pic->pcm; used[i_pc] = 2 * (size_t)pic->n_pcm;
     srcs[i_sc] = pic->scaling_factors; used[i_sc] = pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0;
     used[i_ts] = used[i_rs] = 4 * (size_t)nCtb; used[i_iw] = sizeof(DevIntraWork) * (size_t)nCtb;   /* (cut down to the items in use below) */ used[i_ti] = 2 * (size_t)nCtb; used[i_dp] = (size_t)nCtb;
-    used[i_jb] = 12 * (size_t)(n_chunks ? n_chunks : 1); used[i_ow] = sharded ? (size_t)nCtb : 0;
+    used[i_jb] = 0; used[i_ow] = sharded ? (size_t)nCtb : 0;
     for (int i = 0; i < ns; i++) { seg[i].src = srcs[i]; seg[i].bytes = used[i]; }
     if (in_place) {
       /* every list must sit where the arena put it (the four size bins of rbs[] in their own regions: m355_arena_begin
@@ -1237,11 +1216,13 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   for (int i = 0; i < ns; i++)
     if (seg[i].src && seg[i].bytes) parallel_memcpy(r.host + seg[i].ofs, seg[i].src, seg[i].bytes);
   const auto t_copy = now();
-  std::vector<uint8_t> log2_waves((size_t)nCtb, 0);
+  /* (per-CTB scratch of the schedules: kept in the Resident, no allocation per picture) */
+  r.sched_u8.resize((size_t)nCtb * 3); r.sched_u32.resize((size_t)nCtb);
+  uint8_t* const log2_waves = r.sched_u8.data(); uint8_t* const ctb_touch = log2_waves + nCtb; uint8_t* const ctb_need = ctb_touch + nCtb;
+  uint32_t* const plan_count = r.sched_u32.data();
   int intra_dense = 0;
-  std::vector<uint32_t> plan_count((size_t)nCtb, 0);
   {
-    const int bad = intra_schedule(pic, ctbW, ctbH, (m355_ib*)(r.host + seg[i_ib].ofs), (uint32_t*)(r.host + seg[i_il].ofs), plan_count.data(), log2_waves.data(), &intra_dense);
+    const int bad = intra_schedule(pic, ctbW, ctbH, (m355_ib*)(r.host + seg[i_ib].ofs), (uint32_t*)(r.host + seg[i_il].ofs), plan_count, log2_waves, ctb_touch, ctb_need, &intra_dense);
     if (bad >= 0) return fail(M355_ERR_INVALID, "ctb %d: intra blocks overlap", bad);
     const uint32_t cap = (uint32_t)M355_INTRA_PLAN_CAP(pp.chroma_format_idc);
     for (int i = 0; i < nCtb; i++) if (plan_count[(size_t)i] > cap) return fail(M355_ERR_INVALID, "ctb %d: more intra blocks than a CTB holds", i);
@@ -1252,21 +1233,33 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   uint32_t* ts2rs = (uint32_t*)(r.host + seg[i_rs].ofs);
   uint16_t* tile_id = (uint16_t*)(r.host + seg[i_ti].ofs);
   DevIntraWork* iw = (DevIntraWork*)(r.host + seg[i_iw].ofs);
-  uint32_t ts = 0; int tidx = 0;
-  for (int ty = 0; ty < pp.num_tile_rows; ty++)
-    for (int tx = 0; tx < pp.num_tile_cols; tx++) {
-      for (int y = pp.row_bd[ty]; y < pp.row_bd[ty + 1]; y++)
-        for (int x = pp.col_bd[tx]; x < pp.col_bd[tx + 1]; x++) {
-          ctb_ts[y * ctbW + x] = ts; ts2rs[ts] = (uint32_t)(y * ctbW + x); tile_id[y * ctbW + x] = (uint16_t)tidx; ts++;
+  {
+    /* the tables depend on the tile structure only: kept from picture to picture (a stream changes it with its PPS) */
+    m355_ctx::ScanCache& sc = c->scan;
+    const bool same = sc.ctbW == ctbW && sc.ctbH == ctbH && sc.ntc == pp.num_tile_cols && sc.ntr == pp.num_tile_rows &&
+                      !memcmp(sc.col_bd, pp.col_bd, sizeof(pp.col_bd)) && !memcmp(sc.row_bd, pp.row_bd, sizeof(pp.row_bd));
+    if (!same) {
+      sc.ctbW = ctbW; sc.ctbH = ctbH; sc.ntc = pp.num_tile_cols; sc.ntr = pp.num_tile_rows;
+      memcpy(sc.col_bd, pp.col_bd, sizeof(pp.col_bd)); memcpy(sc.row_bd, pp.row_bd, sizeof(pp.row_bd));
+      sc.ctb_ts.assign((size_t)nCtb, 0); sc.ts2rs.assign((size_t)nCtb, 0); sc.tile_id.assign((size_t)nCtb, 0);
+      uint32_t ts = 0; int tidx = 0;
+      for (int ty = 0; ty < pp.num_tile_rows; ty++)
+        for (int tx = 0; tx < pp.num_tile_cols; tx++) {
+          for (int y = pp.row_bd[ty]; y < pp.row_bd[ty + 1]; y++)
+            for (int x = pp.col_bd[tx]; x < pp.col_bd[tx + 1]; x++) {
+              sc.ctb_ts[y * ctbW + x] = ts; sc.ts2rs[ts] = (uint32_t)(y * ctbW + x); sc.tile_id[y * ctbW + x] = (uint16_t)tidx; ts++;
+            }
+          tidx++;
         }
-      tidx++;
     }
+    memcpy(ctb_ts, sc.ctb_ts.data(), 4 * (size_t)nCtb); memcpy(ts2rs, sc.ts2rs.data(), 4 * (size_t)nCtb); memcpy(tile_id, sc.tile_id.data(), 2 * (size_t)nCtb);
+  }
   /* intra work list (claimed in this order through k_intra's ticket): first the CTBs that wait for no neighbour,
      LONGEST FIRST (a CTB's blocks are a serial chain, so the CTB with the most blocks is the stage's critical path:
      it must start at once, not at a random point of the launch), then the dependent ones in decode order.  A
      workgroup still only ever waits on lower tickets: free CTBs never wait, dependent ones wait on free ones (all
      earlier) or on dependent ones earlier in decode order. */
-  intra_dependencies(pic, ctbW, ctbH, tile_id, (uint8_t*)(r.host + seg[i_dp].ofs));
+  intra_dependencies(ctbW, ctbH, tile_id, ctb_touch, ctb_need, (uint8_t*)(r.host + seg[i_dp].ofs));
   for (int i = 0; i < nCtb; i++) ((uint8_t*)(r.host + seg[i_dp].ofs))[i] |= (uint8_t)(log2_waves[i] << 5);
   const auto t_deps = now();
   int nw = 0, n_free = 0;
@@ -1320,20 +1313,6 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   }
   seg[i_iw].bytes = sizeof(DevIntraWork) * (size_t)(nw ? nw : 1);
   r.n_intra_work = nw; r.n_iplan = n_iplan;
-  {
-    /* job counts per range (k_inter_jobs) and, per 256-PB chunk (= one k_meta_pb workgroup), the first job
-       index of the chunk in each range */
-    long long nj = 0, nm = 0, nu = 0;
-    uint32_t* jb = (uint32_t*)(r.host + seg[i_jb].ofs);
-    const std::vector<uint32_t>& cnt = r.job_cnt;          /* counted by the validation sweep */
-    for (int k = 0; k < n_chunks; k++) { nu += cnt[(size_t)k * 3]; nm += (long long)cnt[(size_t)k * 3] + cnt[(size_t)k * 3 + 1]; nj += (long long)cnt[(size_t)k * 3] + cnt[(size_t)k * 3 + 1] + cnt[(size_t)k * 3 + 2]; }
-    {
-      uint32_t run[3] = {0, (uint32_t)nu, (uint32_t)nm};
-      for (int k = 0; k < n_chunks; k++)
-        for (int q = 0; q < 3; q++) { jb[k * 3 + q] = run[q]; run[q] += cnt[(size_t)k * 3 + q]; }
-    }
-    r.n_jobs = (int)nj; r.n_jobs_main = (int)nm; r.n_jobs_uni = (int)nu;
-  }
   if (sharded) {
     uint8_t* ow = (uint8_t*)(r.host + seg[i_ow].ofs);
     const int n_tiles = pp.num_tile_cols * pp.num_tile_rows;
@@ -1394,9 +1373,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
   d.intra_work = (const DevIntraWork*)(r.dev + seg[i_iw].ofs);
   d.n_intra_work = nw; d.n_intra_free = n_free;
-  d.n_jobs = r.n_jobs; d.n_jobs_main = r.n_jobs_main; d.n_jobs_uni = r.n_jobs_uni;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
-  d.job_base = (const uint32_t*)(r.dev + seg[i_jb].ofs);
   d.ctb_owner = sharded ? (const uint8_t*)(r.dev + seg[i_ow].ofs) : nullptr;
   d.halo_cu_base = pic->n_cus; d.halo_pb_base = pic->n_pbs;
   d.n_pb_records = pic->n_pbs + halo.n_units;
@@ -1491,7 +1468,16 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
   }
   if ((rc = grow(&c->resbuf, &c->cap_res, res_need, c->stream, false))) return rc;
   if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
-  if ((rc = grow(&c->jobs, &c->cap_jobs, (size_t)r.n_jobs + 1, c->stream, false))) return rc;
+  {
+    /* inter jobs of 4 x 8 luma samples: a list of disjoint prediction blocks makes at most one per 16 luma samples (8x4 blocks),
+       and at most one per 32 plus eight per block; the counts themselves are made on the device (k_job_count / k_job_scan) */
+    const size_t area = (size_t)pp.width * pp.height;
+    const size_t cap = pic.n_pbs > 0 ? std::min(area / 16, area / 32 + 8 * (size_t)pic.n_pbs) + 256 : 1;
+    const size_t n_chunks = ((size_t)(pic.n_pbs > 0 ? pic.n_pbs : 0) + 255) / 256;
+    if ((rc = grow(&c->jobs, &c->cap_jobs, cap, c->stream, false))) return rc;
+    if ((rc = grow(&c->job_base, &c->cap_jobbase, n_chunks * 3 + 8, c->stream, true))) return rc;
+    d.jobs_cap = (uint32_t)cap; d.job_base = c->job_base; d.job_tot = c->job_base + n_chunks * 3;
+  }
   if ((rc = grow(&c->iplan, &c->cap_iplan, (size_t)r.n_iplan + 8, c->stream, false))) return rc;
 
   const bool want_sao = (c->stages & M355_STAGE_SAO) && (pp.flags & M355_PF_SAO_ENABLED);
@@ -2035,6 +2021,49 @@ int m355_shard_rccl_init(m355_ctx* c, const void* id128, int rank, int nranks)
   if (g_rccl.CommInitRank(&c->rccl, nranks, id, rank)) return fail(M355_ERR_HIP, "ncclCommInitRank failed");
   m355_comm cm = {c, rccl_halo_sum, rccl_all_gather};
   return m355_shard_set_comm(c, &cm);
+}
+
+/* Moves real bytes through the built-in RCCL transport on this context's communicator and checks them on the host: the halo
+ * exchange (ncclSend / ncclRecv grouped per peer + k_halo_add) with every OTHER rank as peer — or, in a communicator of one
+ * rank, with itself (a grouped self-send) — and the in-place all-gather.  Every rank calls it alike.  What each rank sends is
+ * a function of (rank, word index), so the sums and the gathered slots are known everywhere. */
+int m355_shard_rccl_selftest(m355_ctx* c, size_t words)
+{
+  if (!c->rccl || c->shard_n < 1) return fail(M355_ERR_INVALID, "no RCCL communicator (m355_shard_rccl_init)");
+  if (words < 1 || words > (1u << 24)) return fail(M355_ERR_INVALID, "bad size");
+  hipSetDevice(c->device);
+  const int N = c->shard_n, me = c->shard_rank;
+  std::vector<int> peers;
+  for (int q = 0; q < N; q++) if (q != me) peers.push_back(q);
+  if (peers.empty()) peers.push_back(me);                   /* one rank: send to / receive from itself */
+  const size_t bytes = words * 4, pitch = (bytes + 255) & ~(size_t)255;
+  auto val = [](int rank, size_t i) { return (uint32_t)(rank + 1) * 0x01000193u + (uint32_t)i * 2654435761u; };
+  uint32_t *buf = nullptr, *scratch = nullptr, *gat = nullptr;
+  HIPCHK(hipMalloc(&buf, bytes + 256));
+  HIPCHK(hipMalloc(&scratch, pitch * peers.size() + 256));
+  HIPCHK(hipMalloc(&gat, bytes * (size_t)N + 256));
+  std::vector<uint32_t> h(words), back(words * (size_t)N);
+  for (size_t i = 0; i < words; i++) h[i] = val(me, i);
+  int rc = M355_OK;
+  do {
+    if (hipMemcpy(buf, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(gat + words * (size_t)me, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(M355_ERR_HIP, "copy failed"); break; }
+    int e = rccl_halo_sum(c, buf, bytes, peers.data(), (int)peers.size(), scratch, (void*)c->stream);
+    if (e) { rc = fail(M355_ERR_HIP, "halo exchange over RCCL failed (%d)", e); break; }
+    e = rccl_all_gather(c, gat, bytes, me, N, (void*)c->stream);
+    if (e) { rc = fail(M355_ERR_HIP, "ncclAllGather failed (%d)", e); break; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(M355_ERR_HIP, "the exchange did not complete: %s", hipGetErrorString(hipGetLastError())); break; }
+    if (hipMemcpy(h.data(), buf, bytes, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(back.data(), gat, bytes * (size_t)N, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(M355_ERR_HIP, "copy failed"); break; }
+    for (size_t i = 0; i < words && !rc; i++) {
+      uint32_t want = val(me, i);
+      for (int q : peers) want += val(q, i);
+      if (h[i] != want) rc = fail(M355_ERR_HIP, "halo sum: word %zu is %08x, expected %08x", i, h[i], want);
+    }
+    for (int q = 0; q < N && !rc; q++)
+      for (size_t i = 0; i < words && !rc; i++)
+        if (back[(size_t)q * words + i] != val(q, i)) rc = fail(M355_ERR_HIP, "all-gather: slot %d word %zu is %08x, expected %08x", q, i, back[(size_t)q * words + i], val(q, i));
+  } while (0);
+  hipFree(buf); hipFree(scratch); hipFree(gat);
+  return rc;
 }
 
 int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)
