@@ -15,6 +15,9 @@ __device__ __forceinline__ void d_drain_vmem() { asm volatile("s_waitcnt vmcnt(0
 __device__ __forceinline__ void d_st_nt4(void* p, unsigned v) { __builtin_nontemporal_store(v, (unsigned*)p); }
 __device__ __forceinline__ void d_st_nt8(void* p, unsigned v0, unsigned v1) { __builtin_nontemporal_store(v0, (unsigned*)p); __builtin_nontemporal_store(v1, (unsigned*)p + 1); }
 
+/* no memory operation moves across this point (compiler only; costs no instruction) */
+#define M355_COMPILER_FENCE() asm volatile("" ::: "memory")
+
 /* keep a wave-uniform value in a scalar register, computed HERE (k_intra decodes its next block's record before the level barrier,
  * not at the first use behind it) */
 #define M355_PIN_S(x) asm volatile("" : "+s"(x))

@@ -605,31 +605,41 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
   const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
 
-  /* fused residual (k_common.h res_map): the map entries of the job's two luma units and of its chroma piece are requested
-     here, beside the PB record's dependants; the residual rows themselves behind the last list's filter */
+  /* fused residual (k_common.h res_map): where the map entries of the job's two luma units and of its chroma piece are requested
+     decides the register pressure of the filter loops (M355_RES_MAP_WHEN: 0 = at the start, beside the PB record's dependants;
+     1 = luma at the start, chroma between the luma and the chroma filter; 2 = each right before its residual rows) */
+#ifndef M355_RES_MAP_WHEN
+#define M355_RES_MAP_WHEN 2
+#endif
   uint32_t e0 = 0, e1 = 0, ec1 = 0, ec2 = 0, ec1b = 0, ec2b = 0;
-  if (p.res_map) {
+  auto map_luma = [&]() {
+    if (!p.res_map) return;
     const uint32_t* m = p.res_map + (size_t)(y0 >> 2) * p.res_map_w[0] + (x0 >> 2);
     e0 = m[0];
     if (rows > 4) e1 = m[p.res_map_w[0]];
-    if (nc == 3) {
-      /* 4:2:0: the 2 x (rows / 2) chroma piece lies in unit (x0 >> 3, y0 >> 3); a job that starts on an odd multiple of 4
-         (PBs of asymmetric partitions) reaches two rows into the unit below */
-      const size_t cu = (size_t)(y0 >> 3) * p.res_map_w[1] + (x0 >> 3);
-      ec1 = p.res_map[p.res_map_ofs[1] + cu];
-      ec2 = p.res_map[p.res_map_ofs[2] + cu];
-      if (((y0 >> 1) & 3) + (rows >> 1) > 4) {
-        ec1b = p.res_map[p.res_map_ofs[1] + cu + p.res_map_w[1]];
-        ec2b = p.res_map[p.res_map_ofs[2] + cu + p.res_map_w[1]];
-      }
+  };
+  auto map_chroma = [&]() {
+    if (!p.res_map || nc != 3) return;
+    /* 4:2:0: the 2 x (rows / 2) chroma piece lies in unit (x0 >> 3, y0 >> 3); a job that starts on an odd multiple of 4
+       (PBs of asymmetric partitions) reaches two rows into the unit below */
+    const size_t cu = (size_t)(y0 >> 3) * p.res_map_w[1] + (x0 >> 3);
+    ec1 = p.res_map[p.res_map_ofs[1] + cu];
+    ec2 = p.res_map[p.res_map_ofs[2] + cu];
+    if (((y0 >> 1) & 3) + (rows >> 1) > 4) {
+      ec1b = p.res_map[p.res_map_ofs[1] + cu + p.res_map_w[1]];
+      ec2b = p.res_map[p.res_map_ofs[2] + cu + p.res_map_w[1]];
     }
-  }
+  };
+  if (M355_RES_MAP_WHEN <= 1) map_luma();
+  if (M355_RES_MAP_WHEN == 0) map_chroma();
 
-  /* weights of the job's component c (WtSel above); the two records are fetched once per job */
-  m355_wt wa, wb;
-  if (weighted) { wa = p.wts[wtA]; wb = p.wts[wtB]; }
+  /* weights of the job's component c (WtSel above).  Called in the write-back, behind the filter loops: the two weight records
+     (8 registers) and the selection (5) are not carried through them — registers are what the loops are short of, and a
+     spilled one is scratch traffic on the same memory path the kernel is bound by */
   auto make_ws = [&](int c, int bd) {
     WtSel ws;
+    m355_wt wa, wb;
+    if (weighted) { wa = p.wts[wtA]; wb = p.wts[wtB]; }
     const int shift3 = max(2, 14 - bd), shift2 = max(3, 15 - bd);
     ws.w0 = 1; ws.w1 = bi ? 1 : 0; ws.o = 0;
     ws.sh = bi ? shift2 : shift3; ws.rnd = 1 << (ws.sh - 1);
@@ -648,12 +658,10 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
   /* ---- luma ---- */
   {
     const int bd = p.pp.bit_depth_luma;
-    const WtSel ws = make_ws(0, bd);
     const int pw = p.pw[0], ph = p.ph[0];
     unsigned pa[8][2];
 #pragma unroll
     for (int y = 0; y < 8; y++) { pa[y][0] = 0; pa[y][1] = 0; }
-    PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
 #pragma unroll 1
     for (int pass = 0; pass < npass; pass++) {
       unsigned cur[8][2];
@@ -671,6 +679,10 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         continue;
       }
       /* residual rows of the two units (4 int16 each; tile pitch nT), clip(pred + res) as add_residual (fallback-dct.h:65-73) */
+      M355_COMPILER_FENCE();          /* the residual / weight loads must not be hoisted into the filter loops */
+      const WtSel ws = make_ws(0, bd);
+      PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
+      if (M355_RES_MAP_WHEN == 2) map_luma();
       unsigned rs[8][2];
 #pragma unroll
       for (int y = 0; y < 8; y++) { rs[y][0] = 0; rs[y][1] = 0; }
@@ -705,20 +717,18 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
     }
   }
   if (nc == 1) return;
+  if (M355_RES_MAP_WHEN == 1) map_chroma();
 
   /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are
      in flight together (one memory latency per list instead of two); chroma mv = luma mv in 1/8 pel
      (motion.cc:196-203) ---- */
   {
     const int bd = p.pp.bit_depth_chroma;
-    const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
     const int pw = p.pw[1], ph = p.ph[1];
     const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
     unsigned pa1[4], pa2[4];
 #pragma unroll
     for (int y = 0; y < 4; y++) { pa1[y] = 0; pa2[y] = 0; }
-    PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
-    PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
 #pragma unroll 1
     for (int pass = 0; pass < npass; pass++) {
       unsigned cur1[4], cur2[4];
@@ -737,6 +747,11 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         continue;
       }
       /* residual: the job's 2 x crows piece of each plane (unit-local position (xc & 3, yc & 3), see the map lookup above) */
+      M355_COMPILER_FENCE();
+      const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
+      PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
+      PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
+      if (M355_RES_MAP_WHEN == 2) map_chroma();
       unsigned rc1[4], rc2[4];
 #pragma unroll
       for (int y = 0; y < 4; y++) { rc1[y] = 0; rc2[y] = 0; }

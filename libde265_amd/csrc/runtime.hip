@@ -1446,8 +1446,13 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
      tiles behind the deferred (intra) ones instead of read-modify-writing the picture.  Not for 16-bit samples (a residual of
      transform_idct_add, fallback-dct.cc:550-691, needs 18 bits there), not for the generic kernel's chroma formats, not when a
      stage is isolated. */
-  static const bool fused_env = !(getenv("M355_RES_FUSED") && atoi(getenv("M355_RES_FUSED")) == 0);
-  const bool fused = fused_env && pic.n_pbs > 0 && pp.chroma_format_idc <= 1 && pp.bit_depth_luma < 16 && pp.bit_depth_chroma < 16 &&
+  /* When: with ONE picture in flight (the residual stage then runs beside the job list instead of behind k_inter_jobs: 0.505 vs
+     0.52 ms per C5 picture).  With pictures in flight the read-modify-write order is the faster one although it moves 80 MB more
+     per picture: k_inter_jobs is the stage everything else queues behind, the 20 us the residual rows add to it cost more than the
+     35 us k_residual saves beside the other pictures' kernels (0.379 vs 0.395 ms, profiles/r04_g_*).  M355_RES_FUSED=0 / 1 forces it. */
+  static const int fused_env = getenv("M355_RES_FUSED") ? atoi(getenv("M355_RES_FUSED")) : -1;
+  const bool fused_on = fused_env >= 0 ? fused_env != 0 : c->depth == 1;
+  const bool fused = fused_on && pic.n_pbs > 0 && pp.chroma_format_idc <= 1 && pp.bit_depth_luma < 16 && pp.bit_depth_chroma < 16 &&
                      (c->stages & M355_STAGE_INTER) && (c->stages & M355_STAGE_RESIDUAL) &&
                      (pic.rb_count[0] | pic.rb_count[1] | pic.rb_count[2] | pic.rb_count[3]);
   size_t res_need = (size_t)pic.res_len + 1;

@@ -31,7 +31,7 @@ def main():
         else:
             t0 = time.time()
             while not os.path.exists(idfile):
-                if time.time() - t0 > 120:
+                if time.time() - t0 > 45:
                     raise RuntimeError("no unique id from rank 0")
                 time.sleep(0.05)
             uid = open(idfile, "rb").read()

