@@ -57,6 +57,11 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # The residual order of the library follows the pictures in flight (fused into k_inter_jobs' write-back at depth 1, read-modify-
+    # write behind it otherwise, runtime.hip prepare()).  The headline runs with pictures in flight; the legs that time the stages one
+    # picture at a time (stage_ms, roofline, the rocprofv3 traces under profiles/) must see the SAME kernels, so this process pins the
+    # order of the headline unless told otherwise.
+    os.environ.setdefault("M355_RES_FUSED", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,7 +258,10 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "k_" + dom),
-                         "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": ab[dom] / max(1, launches[dom])},
+                         "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": ab[dom] / max(1, launches[dom]),
+                         "pictures_in_flight": 1,     # launch_ms / stage_ms: one picture at a time; `value`: args.pipeline_depth in flight
+                         "traffic_total": pmc_traffic_total(args.workload),
+                         "residual_order": "fused" if os.environ.get("M355_RES_FUSED") == "1" else "read-modify-write"},
         }
         if sharded is not None:
             out["tile_sharded"] = sharded
@@ -290,6 +298,27 @@ def main():
     ctx.close()
     if dist:
         dist.destroy_process_group()
+
+
+def pmc_traffic_total(workload):
+    """HBM bytes per PICTURE over all kernels of the pipeline: the sum of profiles/pmc_traffic.json (per-launch figures x launches
+    per picture as recorded there); null when no PMC passes of this workload are committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
+    except Exception:  # noqa: BLE001
+        return None
+    tot_f = tot_w = 0
+    n = max((v.get("launches_sampled", 0) for k, v in d.items() if isinstance(v, dict) and k == "k_inter"), default=0) or \
+        max((v.get("launches_sampled", 0) for k, v in d.items() if isinstance(v, dict)), default=0)
+    if not n:
+        return None
+    for k, v in d.items():
+        if not isinstance(v, dict) or "fetch_bytes" not in v:
+            continue
+        per_pic = v.get("launches_sampled", n) / n        # launches of this kernel group per picture
+        tot_f += v["fetch_bytes"] * per_pic
+        tot_w += v["write_bytes"] * per_pic
+    return {"bytes_per_picture": int(tot_f + tot_w), "fetch_bytes": int(tot_f), "write_bytes": int(tot_w), "source": d.get("_source")}
 
 
 def pmc_traffic(workload, kernel):
