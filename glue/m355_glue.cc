@@ -80,7 +80,8 @@ namespace {
   X(m355_last_error) X(m355_device_count) X(m355_create) X(m355_destroy) X(m355_frame_create) X(m355_frame_destroy) \
   X(m355_frame_upload) X(m355_frame_download) X(m355_submit_picture) X(m355_wait) X(m355_set_pipeline_depth) \
   X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash) X(m355_arena_begin) X(m355_last_serial) X(m355_decode_status) \
-  X(m355_frame_download_async) X(m355_frame_download_wait)
+  X(m355_frame_download_async) X(m355_frame_download_wait) \
+  X(m355_group_create) X(m355_group_destroy) X(m355_group_decode) X(m355_picture_upload) X(m355_picture_replace) X(m355_shard_owner_of_tile)
 
 struct Api {
   void* handle = nullptr;
@@ -234,6 +235,16 @@ struct Glue {
   std::vector<m355_tu> w_tus;
   double ms_walk = 0, ms_submit = 0, ms_download = 0;
   double ms_phase[6] = {0, 0, 0, 0, 0, 0};   /* of ms_walk: headers + CTBs, CU / TU walk, merge + sort, PCM / intra reorder, copies into the arena, final copies */
+  /* M355_GLUE_RANKS=N > 1: ONE bitstream across N backend contexts (device r % device count; all on one device where there is
+     only one) — the picture's tiles are split over the ranks (m355_shard_owner_of_tile), every rank reconstructs its tiles and the
+     library's in-process group (m355_group_*: copies between the contexts, ordered by events) carries the deblocking / SAO halos and
+     the finished tiles.  Rank 0 is `mctx` (pictures are downloaded / hashed there); rframe[r - 1][slot] = the other ranks' frames. */
+  int n_ranks = 1;
+  std::vector<m355_ctx*> rctx;              /* [0] = mctx */
+  std::vector<std::vector<int>> rframe;     /* ranks 1.. */
+  m355_group* group = nullptr;
+  std::vector<std::vector<int>> rhandle;    /* [ring position][rank]: uploaded pictures, cycled (m355_picture_replace) */
+  size_t rhandle_next = 0;
   std::string error;
   Glue()
   {
@@ -388,6 +399,12 @@ bool ensure_frame(Glue* g, int slot, const de265_image* img)
   g->frame_of_slot[slot] = api()->m355_frame_create(g->mctx, geo[0], geo[1], geo[2], geo[3], geo[4]);
   g->dev_id[slot] = 0xFFFFFFFFu;
   if (g->frame_of_slot[slot] < 0) { g->error = api()->m355_last_error(); return false; }
+  for (int r = 1; r < g->n_ranks; r++) {
+    int& f = g->rframe[(size_t)r - 1][(size_t)slot];
+    if (f >= 0) api()->m355_frame_destroy(g->rctx[(size_t)r], f);
+    f = api()->m355_frame_create(g->rctx[(size_t)r], geo[0], geo[1], geo[2], geo[3], geo[4]);
+    if (f < 0) { g->error = api()->m355_last_error(); return false; }
+  }
   memcpy(g->geom[slot], geo, sizeof(geo));
   return true;
 }
@@ -398,7 +415,8 @@ bool upload_host_planes(Glue* g, int slot, const de265_image* img)
   if (!ensure_frame(g, slot, img)) return false;
   const int nc = img->get_chroma_format() == de265_chroma_mono ? 1 : 3;
   for (int c = 0; c < nc; c++)
-    if (api()->m355_frame_upload(g->mctx, g->frame_of_slot[slot], c, img->get_image_plane(c), img->get_image_stride(c)) != M355_OK) { g->error = api()->m355_last_error(); return false; }
+    for (int r = 0; r < g->n_ranks; r++)
+      if (api()->m355_frame_upload(g->rctx[(size_t)r], r ? g->rframe[(size_t)r - 1][(size_t)slot] : g->frame_of_slot[slot], c, img->get_image_plane(c), img->get_image_stride(c)) != M355_OK) { g->error = api()->m355_last_error(); return false; }
   g->dev_id[slot] = img->get_ID();
   g->host_id[slot] = img->get_ID();
   g->n_uploads++;
@@ -559,6 +577,70 @@ void parallel_tasks(size_t n_tasks, const std::function<void(size_t)>& f)
   if (T <= 1) { for (size_t i = 0; i < n_tasks; i++) f(i); return; }
   static TaskPool* pool = new TaskPool(glue_threads() - 1);    /* lives until process exit */
   pool->run(n_tasks, f);
+}
+
+/* One picture over the ranks of the glue's group.  `pic` = the whole picture's lists in host memory (copying mode).  Rank r gets
+ * the coding units, transform leaves, prediction blocks, residual and intra blocks of ITS tiles (the owner of a block is the owner
+ * of its CTB's tile); slices, CTB table (SAO parameters, slice indices), weights, PCM samples, coefficients and the residual
+ * numbering stay picture-wide — what libde265_amd/shard.py shard_picture does for the Python harness. */
+int submit_sharded(Glue* g, const m355_picture& pic, int dslot)
+{
+  Api* A = api();
+  const m355_pic_params& pp = pic.pp;
+  const int N = g->n_ranks, l2 = pp.log2_ctb_size, cs = 1 << l2;
+  const int ctbW = (pp.width + cs - 1) >> l2, ctbH = (pp.height + cs - 1) >> l2, n_tiles = pp.num_tile_cols * pp.num_tile_rows;
+  std::vector<uint8_t> owner((size_t)ctbW * ctbH, 0);
+  for (int ty = 0, t = 0; ty < pp.num_tile_rows; ty++)
+    for (int tx = 0; tx < pp.num_tile_cols; tx++, t++) {
+      const uint8_t o = (uint8_t)A->m355_shard_owner_of_tile(t, n_tiles, N);
+      for (int y = pp.row_bd[ty]; y < pp.row_bd[ty + 1] && y < ctbH; y++)
+        for (int x = pp.col_bd[tx]; x < pp.col_bd[tx + 1] && x < ctbW; x++) owner[(size_t)y * ctbW + x] = o;
+    }
+  const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
+  auto own = [&](int x, int y) { return owner[(size_t)(y >> l2) * ctbW + (x >> l2)]; };
+  if (g->rhandle.size() < 4) g->rhandle.resize(4);
+  std::vector<int>& hs = g->rhandle[g->rhandle_next];
+  g->rhandle_next = (g->rhandle_next + 1) % g->rhandle.size();
+  const bool fresh = hs.empty();
+  if (fresh) hs.assign((size_t)N, -1);
+  std::vector<m355_cu> cus; std::vector<m355_tu> tus; std::vector<m355_pb> pbs; std::vector<m355_rb> rbs; std::vector<m355_ib> ibs; std::vector<m355_ctb> ctbs;
+  for (int r = 0; r < N; r++) {
+    cus.clear(); tus.clear(); pbs.clear(); rbs.clear(); ibs.clear();
+    for (int i = 0; i < pic.n_cus; i++) if (own(pic.cus[i].x, pic.cus[i].y) == r) cus.push_back(pic.cus[i]);
+    for (int i = 0; i < pic.n_tus; i++) if (own(pic.tus[i].x, pic.tus[i].y) == r) tus.push_back(pic.tus[i]);
+    for (int i = 0; i < pic.n_pbs; i++) if (own(pic.pbs[i].x, pic.pbs[i].y) == r) pbs.push_back(pic.pbs[i]);
+    m355_picture rp = pic;
+    const m355_rb* src = pic.rbs;
+    for (int s = 0; s < 4; s++) {
+      int kept = 0;
+      for (int i = 0; i < pic.rb_count[s]; i++, src++)
+        if (own(src->cidx ? src->x * sw : src->x, src->cidx ? src->y * sh : src->y) == r) { rbs.push_back(*src); kept++; }
+      rp.rb_count[s] = kept;
+    }
+    /* intra blocks: whole CTBs are kept or dropped; the kept CTBs' runs are renumbered (ascending ib_start = the order they lie in) */
+    ctbs.assign(pic.ctbs, pic.ctbs + pic.n_ctbs);
+    std::vector<uint32_t> order((size_t)pic.n_ctbs);
+    for (int i = 0; i < pic.n_ctbs; i++) order[(size_t)i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pic.ctbs[a].ib_start < pic.ctbs[b].ib_start; });
+    for (uint32_t ci : order) {
+      m355_ctb& c = ctbs[ci];
+      if (owner[ci] != r || !c.ib_count) { c.ib_start = 0; c.ib_count = 0; continue; }
+      const uint32_t start = (uint32_t)ibs.size();
+      ibs.insert(ibs.end(), pic.ibs + c.ib_start, pic.ibs + c.ib_start + c.ib_count);
+      c.ib_start = start;
+    }
+    rp.cus = cus.data(); rp.n_cus = (int32_t)cus.size(); rp.tus = tus.data(); rp.n_tus = (int32_t)tus.size();
+    rp.pbs = pbs.data(); rp.n_pbs = (int32_t)pbs.size(); rp.rbs = rbs.data(); rp.ibs = ibs.data(); rp.n_ibs = (int32_t)ibs.size();
+    rp.ctbs = ctbs.data();
+    if (r) {
+      rp.dst_frame = g->rframe[(size_t)r - 1][(size_t)dslot];
+      for (int i = 0; i < M355_MAX_REF_FRAMES; i++) if (pic.ref_frames[i] >= 0) rp.ref_frames[i] = g->rframe[(size_t)r - 1][(size_t)i];
+    }
+    const int h = fresh ? A->m355_picture_upload(g->rctx[(size_t)r], &rp) : A->m355_picture_replace(g->rctx[(size_t)r], hs[(size_t)r], &rp);
+    if (fresh) { if (h < 0) return -h; hs[(size_t)r] = h; }
+    else if (h != M355_OK) return h;
+  }
+  return A->m355_group_decode(g->group, hs.data(), 1);      /* (every rank ends up with the whole picture: it is a reference everywhere) */
 }
 
 bool submit_picture(Glue* g, Glue::Job& job)
@@ -722,7 +804,7 @@ bool submit_picture(Glue* g, Glue::Job& job)
      and checks the records on the device); pictures with PCM units (their raw blocks are merged into the intra lists below)
      and M355_GLUE_COPY=1 take the copying m355_submit_picture through host vectors. */
   static const bool force_copy = getenv("M355_GLUE_COPY") != nullptr;
-  const bool in_place = !any_pcm && !force_copy;
+  const bool in_place = !any_pcm && !force_copy && g->n_ranks == 1;   /* (a tile-sharded context takes whole lists: submit_sharded) */
   std::unique_lock<std::mutex> api_lock(g->api_mu, std::defer_lock);
   std::vector<m355_pb> pbs;
   std::vector<uint32_t> coeffs;
@@ -923,14 +1005,17 @@ bool submit_picture(Glue* g, Glue::Job& job)
 
   lap(5);
   const auto t1 = std::chrono::steady_clock::now();
-  const int rc = A->m355_submit_picture(g->mctx, &pic);
+  /* M355_GLUE_ATTRIB (time attribution only — pictures are NOT decoded; profiles/r04_e2e_attribution.txt): 2 = everything but the submit */
+  static const int attrib = getenv("M355_GLUE_ATTRIB") ? atoi(getenv("M355_GLUE_ATTRIB")) : 0;
+  if (attrib == 2) { g->ms_walk += std::chrono::duration<double, std::milli>(t1 - t0).count(); g->n_pictures++; g->dev_id[dslot] = img->get_ID(); g->host_id[dslot] = 0xFFFFFFFFu; return true; }
+  const int rc = g->n_ranks > 1 ? submit_sharded(g, pic, dslot) : A->m355_submit_picture(g->mctx, &pic);
   const auto t2 = std::chrono::steady_clock::now();
   g->ms_walk += std::chrono::duration<double, std::milli>(t1 - t0).count();
   g->ms_submit += std::chrono::duration<double, std::milli>(t2 - t1).count();
   if (rc != M355_OK) { g->error = A->m355_last_error(); return false; }
   g->dev_id[dslot] = img->get_ID();
   g->host_id[dslot] = 0xFFFFFFFFu;
-  g->pending_serial[dslot] = A->m355_last_serial(g->mctx);
+  g->pending_serial[dslot] = g->n_ranks > 1 ? 0 : A->m355_last_serial(g->mctx);   /* (sharded: the lists were checked on the host, at the upload) */
   g->damaged[dslot] = from_damaged;
   if (from_damaged && img->integrity == INTEGRITY_CORRECT) img->integrity = INTEGRITY_DERIVED_FROM_FAULTY_REFERENCE;
   g->n_pictures++;
@@ -1022,6 +1107,13 @@ void picture_complete(decoder_context* d, de265_image* img)
     if (g->cur_id == img->get_ID()) { job.recs.swap(g->recs); g->cur_id = 0xFFFFFFFFu; }   /* else: a picture without a single coded block */
   }
   flush_warnings(g);
+  static const int attrib = getenv("M355_GLUE_ATTRIB") ? atoi(getenv("M355_GLUE_ATTRIB")) : 0;
+  if (attrib == 1) {                              /* 1 = parser + recorders only: the picture's lists are dropped here */
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (ThreadRec* r : job.recs) { r->clear(); g->pool.push_back(r); }
+    g->n_pictures++;
+    return;
+  }
   if (g->sync_submit) run_job(g, job);
   else {
     { std::lock_guard<std::mutex> lk(g->job_mu); g->jobs.push_back(std::move(job)); }
@@ -1269,9 +1361,27 @@ LIBDE265_API de265_decoder_context* de265_new_decoder()
     delete g; m355ref_de265_free_decoder(c);
     return nullptr;
   }
+  g->rctx.push_back(g->mctx);
+  if (const char* e = getenv("M355_GLUE_RANKS")) {
+    const int n = atoi(e), ndev = A->m355_device_count();
+    if (n >= 2 && n <= 64) {
+      for (int r = 1; r < n; r++) {
+        m355_ctx* x = nullptr;
+        if (A->m355_create((dev + r) % ndev, &x) != M355_OK) { fprintf(stderr, "libde265 (MI355X glue): rank %d: %s\n", r, A->m355_last_error()); break; }
+        g->rctx.push_back(x);
+        g->rframe.push_back(std::vector<int>(M355_MAX_REF_FRAMES, -1));
+      }
+      if ((int)g->rctx.size() == n && A->m355_group_create(g->rctx.data(), n, &g->group) == M355_OK) g->n_ranks = n;
+      else {
+        fprintf(stderr, "libde265 (MI355X glue): M355_GLUE_RANKS=%d could not be set up (%s): one context\n", n, A->m355_last_error());
+        for (size_t r = 1; r < g->rctx.size(); r++) A->m355_destroy(g->rctx[r]);
+        g->rctx.resize(1); g->rframe.clear();
+      }
+    }
+  }
   int depth = 2;
   if (const char* e = getenv("M355_PIPELINE_DEPTH")) depth = atoi(e);
-  if (depth >= 1 && depth <= 16) A->m355_set_pipeline_depth(g->mctx, depth);
+  if (depth >= 1 && depth <= 16) for (m355_ctx* x : g->rctx) A->m355_set_pipeline_depth(x, g->n_ranks > 1 ? std::min(depth, 3) : depth);
   g->sync_submit = getenv("M355_GLUE_SYNC") != nullptr;
   if (!g->sync_submit) g->worker = std::thread(worker_main, g);
   install_traps(g->dctx->acceleration);
@@ -1309,6 +1419,7 @@ LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)
     wait_submitted(g, 0xFFFFFFFFu);
     std::lock_guard<std::mutex> api_lock(g->api_mu);
     collect_status(g, -1);
+    for (size_t r = 1; r < g->rctx.size(); r++) api()->m355_wait(g->rctx[r]);
     while (api()->m355_wait(g->mctx) != M355_OK) {           /* (one rejected picture per call) */
       fprintf(stderr, "libde265 (MI355X glue): at shutdown: %s\n", api()->m355_last_error());
       if (++g->n_rejected > 1000) break;
@@ -1326,6 +1437,8 @@ LIBDE265_API de265_error de265_free_decoder(de265_decoder_context* c)
     { std::lock_guard<std::mutex> lk(g->job_mu); g->stop = true; }
     g->job_cv.notify_all();
     if (g->worker.joinable()) g->worker.join();
+    if (g->group) api()->m355_group_destroy(g->group);
+    for (size_t r = 1; r < g->rctx.size(); r++) api()->m355_destroy(g->rctx[r]);
     api()->m355_destroy(g->mctx);
     g->planes.drain();
     for (ThreadRec* r : g->recs) { r->clear(); }

@@ -470,6 +470,8 @@ M355_API int m355_decode_status(m355_ctx* ctx, unsigned long long serial);
 /* Resident work lists (benchmarks, replay): upload once, decode many times. */
 M355_API int m355_picture_upload(m355_ctx* ctx, const m355_picture* pic);   /* -> handle >= 0 */
 M355_API int m355_picture_release(m355_ctx* ctx, int handle);
+/* other lists into an uploaded picture's arenas: waits for that handle's last decode only (no allocation when they fit) */
+M355_API int m355_picture_replace(m355_ctx* ctx, int handle, const m355_picture* pic);
 M355_API int m355_decode_resident(m355_ctx* ctx, int handle);
 /* stage mask for m355_set_stages: run only part of the chain (stage-isolated parity, like
  * DE265_DECODER_PARAM_DISABLE_DEBLOCKING / _DISABLE_SAO, de265.h:409-410) */
@@ -551,6 +553,17 @@ M355_API int m355_shard_rccl_init(m355_ctx* ctx, const void* id128, int rank, in
 /* collective self-test of that transport: `words` 32-bit words through the halo exchange (every other rank as peer; a lone rank
  * sends to itself) and the all-gather, verified on the host */
 M355_API int m355_shard_rccl_selftest(m355_ctx* ctx, size_t words);
+/* Tile sharding inside ONE process (no collective library): a group of contexts — one per device, or several on one device —
+ * decodes one picture; rank r = position in `ctxs`.  Each context gets its share of the picture with m355_picture_upload (after
+ * m355_group_create, which calls m355_shard_set(ctx, r, n)); m355_group_decode(handles[r]) issues every rank's phases and moves
+ * the halo buffers / finished tiles between the contexts with hipMemcpyPeerAsync ordered by events on their own streams.
+ * Asynchronous like m355_decode_sharded; m355_wait on every context to finish.  This is what a decoder that parses one
+ * bitstream with a thread per tile uses to spread the tiles over the GPUs of a node (deblock.cc:191-209, sao.cc:158-163 are
+ * the couplings the exchanges carry). */
+typedef struct m355_group m355_group;
+M355_API int m355_group_create(m355_ctx* const* ctxs, int n, m355_group** out);
+M355_API void m355_group_destroy(m355_group* group);
+M355_API int m355_group_decode(m355_group* group, const int* handles, int gather);
 /* device time (ms) of exchange `which` (0..3) of a sharded picture's buffers over the installed transport, averaged over `iters` runs;
  * collective: every rank calls it alike, after at least one m355_decode_sharded of the picture */
 M355_API int m355_shard_time_exchange(m355_ctx* ctx, int handle, int which, int iters, float* ms_each);

@@ -98,6 +98,10 @@ class Library:
         L.m355_rccl_unique_id.argtypes = [vp]
         L.m355_shard_rccl_init.argtypes = [vp, vp, i, i]
         L.m355_shard_rccl_selftest.argtypes = [vp, ctypes.c_size_t]
+        L.m355_group_create.argtypes = [ctypes.POINTER(vp), i, ctypes.POINTER(vp)]
+        L.m355_group_destroy.argtypes = [vp]
+        L.m355_group_destroy.restype = None
+        L.m355_group_decode.argtypes = [vp, ctypes.POINTER(i), i]
         L.m355_shard_peers.argtypes = [vp, i, i, ctypes.POINTER(i), i]
         L.m355_shard_time_exchange.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_float)]
         L.init_acceleration_functions_mi355x.argtypes = [vp]
@@ -394,3 +398,28 @@ def acceleration_functions(lib=None):
     if rc != 0:
         raise M355Error(rc, "init_acceleration_functions_mi355x: no HIP device (there is no CPU fallback)")
     return t
+
+
+class Group:
+    """Tile sharding inside one process (m355_group_*): rank r = ctxs[r]; each context uploads its share of the picture
+    (shard.shard_picture) and decode() issues every rank's phases with the exchanges as copies between the contexts."""
+
+    def __init__(self, lib, ctxs):
+        self.L, self.ctxs = lib, list(ctxs)
+        arr = (ctypes.c_void_p * len(self.ctxs))(*[c.h for c in self.ctxs])
+        self.h = ctypes.c_void_p()
+        lib.check(lib.lib.m355_group_create(arr, len(self.ctxs), ctypes.byref(self.h)))
+
+    def decode(self, handles, gather=True):
+        arr = (ctypes.c_int * len(handles))(*handles)
+        self.L.check(self.L.lib.m355_group_decode(self.h, arr, 1 if gather else 0))
+
+    def wait(self):
+        for c in self.ctxs:
+            c.wait()
+
+    def close(self):
+        if self.h:
+            self.L.lib.m355_group_destroy(self.h)
+            self.h = None
+

@@ -131,6 +131,7 @@ struct Resident {
   bool arena = false;          /* m355_arena_begin handed out list pointers into `host`: the next upload of lists that sit there copies nothing */
   m355_arena_caps caps;        /* ... with room for this many entries */
   bool device_validate = false;    /* the record checks of these lists run on the device (k_validate) */
+  size_t xscratch_pitch = 0;       /* m355_decode_sharded / m355_group_decode: bytes between the peers' slots of xscratch */
   std::vector<uint8_t> sched_u8;   /* upload(): per-CTB scratch of the intra schedule */
   std::vector<uint32_t> sched_u32;
 };
@@ -1898,6 +1899,31 @@ int m355_shard_set_comm(m355_ctx* c, const m355_comm* comm)
   return M355_OK;
 }
 
+/* first sharded decode of these lists: the exchange buffers (zeroed once: a rank's pack kernels write only its own elements, the
+   unpack kernels read what the exchange completed), the peers, and one scratch slot per peer */
+static int shard_buffers(m355_ctx* c, int h)
+{
+  Resident& r = c->resident[h];
+  if (r.xb[0]) return M355_OK;
+  size_t mx = 0;
+  for (int k = 0; k < 4; k++) {
+    const int64_t b = m355_shard_xbuf_bytes(c, h, k);
+    if (b < 0) return M355_ERR_INVALID;
+    r.xb_bytes[k] = (size_t)b;
+    HIPCHK(hipMalloc(&r.xb[k], (size_t)b + 256));
+    HIPCHK(hipMemsetAsync(r.xb[k], 0, (size_t)b + 256, c->stream));
+    if (k < 3) mx = std::max(mx, (size_t)b);
+  }
+  int peers[256];
+  const int np = m355_shard_peers(&r.hdr.pp, r.shard_rank, r.shard_n, peers, 256);
+  if (np < 0) return M355_ERR_INVALID;
+  r.peers.assign(peers, peers + np);
+  r.xscratch_pitch = (mx + 255) & ~(size_t)255;
+  if (np) HIPCHK(hipMalloc(&r.xscratch, (r.xscratch_pitch + 256) * (size_t)np));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return M355_OK;
+}
+
 int m355_decode_sharded(m355_ctx* c, int h, int gather)
 {
   if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded) return fail(M355_ERR_INVALID, "not a sharded picture handle");
@@ -1905,24 +1931,9 @@ int m355_decode_sharded(m355_ctx* c, int h, int gather)
   const int N = r.shard_n;
   if (N > 1 && (!c->comm.halo_sum || !c->comm.all_gather)) return fail(M355_ERR_INVALID, "m355_decode_sharded: no exchange callbacks (m355_shard_set_comm / m355_shard_rccl_init)");
   hipSetDevice(c->device);
-  if (!r.xb[0]) {
-    /* first decode of these lists: the exchange buffers (zeroed once: a rank's pack kernels write only its own elements, the
-       unpack kernels read what the exchange completed) and the peers */
-    size_t mx = 0;
-    for (int k = 0; k < 4; k++) {
-      const int64_t b = m355_shard_xbuf_bytes(c, h, k);
-      if (b < 0) return M355_ERR_INVALID;
-      r.xb_bytes[k] = (size_t)b;
-      HIPCHK(hipMalloc(&r.xb[k], (size_t)b + 256));
-      HIPCHK(hipMemsetAsync(r.xb[k], 0, (size_t)b + 256, c->stream));
-      if (k < 3) mx = std::max(mx, (size_t)b);
-    }
-    int peers[256];
-    const int np = m355_shard_peers(&r.hdr.pp, r.shard_rank, N, peers, 256);
-    if (np < 0) return M355_ERR_INVALID;
-    r.peers.assign(peers, peers + np);
-    if (np) HIPCHK(hipMalloc(&r.xscratch, (mx + 256) * (size_t)np));
-    HIPCHK(hipStreamSynchronize(c->stream));
+  {
+    const int rc0 = shard_buffers(c, h);
+    if (rc0) return rc0;
   }
   const int last = gather ? 4 : 3;
   for (int k = 0; k <= last; k++) {
@@ -1966,6 +1977,117 @@ int m355_shard_time_exchange(m355_ctx* c, int h, int which, int iters, float* ms
   hipEventDestroy(e0); hipEventDestroy(e1);
   if (rc || he != hipSuccess) return fail(M355_ERR_HIP, "exchange %d failed", which);
   *ms_each = ms / (float)iters;
+  return M355_OK;
+}
+
+/* ---- tile sharding inside ONE process: a group of contexts (one per device, or several on one device) decodes one picture.
+ * The exchanges between the phases are copies between the contexts' buffers — hipMemcpyPeerAsync, ordered by events on the
+ * contexts' own streams — instead of a collective library: rank r reads what its neighbours packed (their X buffers are untouched
+ * until everybody has read them), then adds.  X3: every rank copies the other ranks' finished-tile slots into its gather buffer. ---- */
+struct m355_group {
+  std::vector<m355_ctx*> ctx;
+  std::vector<hipEvent_t> ev_pack, ev_copied;     /* per rank */
+};
+
+int m355_group_create(m355_ctx* const* ctxs, int n, m355_group** out)
+{
+  if (!ctxs || n < 1 || n > 256 || !out) return fail(M355_ERR_INVALID, "bad group");
+  m355_group* g = new m355_group;
+  for (int r = 0; r < n; r++) {
+    if (!ctxs[r]) { delete g; return fail(M355_ERR_INVALID, "null context in group"); }
+    g->ctx.push_back(ctxs[r]);
+    int rc = m355_shard_set(ctxs[r], r, n);
+    if (rc) { delete g; return rc; }
+    m355_shard_set_comm(ctxs[r], nullptr);
+  }
+  g->ev_pack.assign((size_t)n, nullptr); g->ev_copied.assign((size_t)n, nullptr);
+  for (int r = 0; r < n; r++) {
+    hipSetDevice(ctxs[r]->device);
+    if (hipEventCreateWithFlags(&g->ev_pack[(size_t)r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev_copied[(size_t)r], hipEventDisableTiming) != hipSuccess) {
+      m355_group_destroy(g);
+      return fail(M355_ERR_HIP, "hipEventCreate failed");
+    }
+  }
+  *out = g;
+  return M355_OK;
+}
+
+void m355_group_destroy(m355_group* g)
+{
+  if (!g) return;
+  for (size_t r = 0; r < g->ctx.size(); r++) {
+    hipSetDevice(g->ctx[r]->device);
+    if (r < g->ev_pack.size() && g->ev_pack[r]) hipEventDestroy(g->ev_pack[r]);
+    if (r < g->ev_copied.size() && g->ev_copied[r]) hipEventDestroy(g->ev_copied[r]);
+  }
+  delete g;
+}
+
+int m355_group_decode(m355_group* g, const int* handles, int gather)
+{
+  if (!g || !handles) return fail(M355_ERR_INVALID, "bad arguments");
+  const int N = (int)g->ctx.size();
+  std::vector<Resident*> R((size_t)N);
+  for (int r = 0; r < N; r++) {
+    m355_ctx* c = g->ctx[(size_t)r];
+    const int h = handles[r];
+    if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded) return fail(M355_ERR_INVALID, "rank %d: not a sharded picture handle", r);
+    if (c->resident[h].shard_n != N || c->resident[h].shard_rank != r) return fail(M355_ERR_INVALID, "rank %d: the picture was uploaded for another group layout", r);
+    hipSetDevice(c->device);
+    const int rc = shard_buffers(c, h);
+    if (rc) return rc;
+    R[(size_t)r] = &c->resident[h];
+  }
+  const int last = gather ? 4 : 3;
+  for (int k = 0; k <= last; k++) {
+    for (int r = 0; r < N; r++) {
+      m355_ctx* c = g->ctx[(size_t)r];
+      hipSetDevice(c->device);
+      const int rc = m355_decode_phase(c, handles[r], k, k < 4 ? R[(size_t)r]->xb[k] : nullptr);
+      if (rc) return rc;
+      if (N > 1 && k < last) hipEventRecord(g->ev_pack[(size_t)r], (hipStream_t)m355_stream(c));
+    }
+    if (N <= 1 || k >= last) continue;
+    if (k < 3) {
+      /* step 1: every rank fetches its neighbours' buffers (as they packed them) into its scratch slots */
+      for (int r = 0; r < N; r++) {
+        m355_ctx* c = g->ctx[(size_t)r];
+        Resident& me = *R[(size_t)r];
+        hipSetDevice(c->device);
+        hipStream_t st = (hipStream_t)m355_stream(c);
+        for (size_t i = 0; i < me.peers.size(); i++) {
+          const int q = me.peers[i];
+          hipStreamWaitEvent(st, g->ev_pack[(size_t)q], 0);
+          HIPCHK(hipMemcpyPeerAsync((char*)me.xscratch + me.xscratch_pitch * i, c->device, R[(size_t)q]->xb[k], g->ctx[(size_t)q]->device, me.xb_bytes[k], st));
+        }
+        hipEventRecord(g->ev_copied[(size_t)r], st);
+      }
+      /* step 2: ... and adds them once its own buffer has been read by all of them */
+      for (int r = 0; r < N; r++) {
+        m355_ctx* c = g->ctx[(size_t)r];
+        Resident& me = *R[(size_t)r];
+        if (me.peers.empty()) continue;
+        hipSetDevice(c->device);
+        hipStream_t st = (hipStream_t)m355_stream(c);
+        for (int q : me.peers) hipStreamWaitEvent(st, g->ev_copied[(size_t)q], 0);
+        m355_launch_halo_add((uint32_t*)me.xb[k], (const uint32_t*)me.xscratch, (uint32_t)(me.xscratch_pitch / 4), (int)me.peers.size(), (uint32_t)((me.xb_bytes[k] + 3) / 4), st);
+      }
+    } else {
+      /* X3: the other ranks' finished tiles, slot by slot, straight out of their gather buffers */
+      for (int r = 0; r < N; r++) {
+        m355_ctx* c = g->ctx[(size_t)r];
+        Resident& me = *R[(size_t)r];
+        hipSetDevice(c->device);
+        hipStream_t st = (hipStream_t)m355_stream(c);
+        const size_t slot = me.xb_bytes[3] / (size_t)N;
+        for (int q = 0; q < N; q++) {
+          if (q == r) continue;
+          hipStreamWaitEvent(st, g->ev_pack[(size_t)q], 0);
+          HIPCHK(hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)R[(size_t)q]->xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st));
+        }
+      }
+    }
+  }
   return M355_OK;
 }
 
@@ -2172,6 +2294,23 @@ int m355_picture_upload(m355_ctx* c, const m355_picture* pic)
   if (rc) { resident_free(c->resident[idx]); return -rc; }
   return idx;
 }
+/* new lists into the arenas of an uploaded picture (waits for the last decode of the old ones only — no allocation when they
+   fit, no synchronisation of the context): how a caller cycles a few handles through a stream of pictures */
+int m355_picture_replace(m355_ctx* c, int h, const m355_picture* pic)
+{
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !pic) return fail(M355_ERR_INVALID, "bad picture handle");
+  Resident& r = c->resident[h];
+  hipSetDevice(c->device);
+  if (r.done_pending && r.ev_done) { HIPCHK(hipEventSynchronize(r.ev_done)); r.done_pending = false; }
+  if (r.xb[0] && (memcmp(&r.hdr.pp, &pic->pp, sizeof(pic->pp)) != 0 || r.shard_n != c->shard_n || r.shard_rank != c->shard_rank)) {
+    /* the exchange buffers of a sharded picture are sized by its geometry and tile structure */
+    for (void*& b : r.xb) { if (b) hipFree(b); b = nullptr; }
+    if (r.xscratch) { hipFree(r.xscratch); r.xscratch = nullptr; }
+    r.peers.clear();
+  }
+  return upload(c, r, pic);
+}
+
 int m355_picture_release(m355_ctx* c, int h)
 {
   if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");

@@ -84,3 +84,39 @@ def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL,
         return out[0]
     finally:
         ctx.close()
+
+
+def group_sharded_decode(lib, pic, refs, nranks, depth=1, gather=True, repeat=1):
+    """The in-process group (m355_group_*): nranks contexts on device 0 decode one picture, the exchanges are copies between the
+    contexts' buffers.  -> per rank the downloaded destination planes (gather: every rank holds the whole picture; else only its
+    own tiles are meaningful).  depth > 1: `depth` copies of the lists / destination frames in flight."""
+    ctxs = [capi.Context(lib, 0) for _ in range(nranks)]
+    grp = capi.Group(lib, ctxs)
+    try:
+        hs, dsts = [], []
+        for r, ctx in enumerate(ctxs):
+            ctx.set_pipeline_depth(depth)
+            per_h, per_d = [], []
+            sp, dst = _setup_rank(ctx, pic, refs, r, nranks, "cpu")
+            per_h.append(ctx.upload(sp)); per_d.append(dst)
+            for _ in range(depth - 1):
+                sp.dst_frame = ctx.frame_create_for(pic.pp[0])
+                per_d.append(sp.dst_frame)
+                per_h.append(ctx.upload(sp))
+            hs.append(per_h); dsts.append(per_d)
+        for _ in range(repeat):
+            for k in range(depth):
+                grp.decode([hs[r][k] for r in range(nranks)], gather)
+        grp.wait()
+        out = []
+        for r, ctx in enumerate(ctxs):
+            frames = [ctx.frame_download(f) for f in dsts[r]]
+            for o in frames[1:]:
+                for a, b in zip(frames[0], o):
+                    assert np.array_equal(a, b), "pictures in flight: destination frames differ"
+            out.append(frames[0])
+        return out
+    finally:
+        grp.close()
+        for ctx in ctxs:
+            ctx.close()

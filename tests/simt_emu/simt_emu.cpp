@@ -180,6 +180,7 @@ hipError_t hipMemcpy2D(void* d, size_t dp, const void* s, size_t sp, size_t w, s
   return hipSuccess;
 }
 hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t) { return hipMemcpy2D(d, dp, s, sp, w, h, k); }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { return hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); }
 hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
 hipError_t hipStreamCreate(hipStream_t* s) { *s = new simt_stream; return hipSuccess; }

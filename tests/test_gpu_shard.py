@@ -10,7 +10,7 @@ import sys
 import pytest
 
 from oracle_py import Oracle
-from shard_util import local_sharded_decode
+from shard_util import group_sharded_decode, local_sharded_decode
 from synth_util import assert_planes_equal, make_case, oracle_decode
 from test_shard_emu import CASES
 from test_shard_gloo import free_port
@@ -59,3 +59,28 @@ def test_rccl_path_world_size_1(lib, oracle, depth):
            os.path.join(ROOT, "tests", "shard_worker.py"), "nccl", "default", json.dumps(cases), str(depth)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARD_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("name,nranks,depth", [("c4_4k_4tiles", 4, 1), ("c5_8k10_8tiles", 8, 1), ("c5_8k10_8tiles", 4, 3), ("c3_4k_inter", 1, 2)])
+def test_group_in_one_process_baseline_configs(lib, oracle, name, nranks, depth):
+    """m355_group_*: one process, one context per rank (here all on the one GPU), exchanges = hipMemcpyPeerAsync between the
+    contexts ordered by events; C4 / C5 at full size, also with three pictures in flight per rank"""
+    o = Oracle(oracle)
+    pic, refs = make_case(**synth.CONFIGS[name])
+    want = oracle_decode(o, pic, refs)
+    for r, got in enumerate(group_sharded_decode(lib, pic, refs, nranks, depth=depth, repeat=2)):
+        assert_planes_equal(got, want, "%s group rank %d of %d" % (name, r, nranks))
+
+
+@pytest.mark.parametrize("case,nranks", [(CASES[1][0], 4), (CASES[3][0], 3), (CASES[5][0], 3)],
+                         ids=lambda v: ("%dx%d_seed%d" % (v["width"], v["height"], v["seed"])) if isinstance(v, dict) else "r%d" % v)
+def test_group_in_one_process_small(lib, oracle, case, nranks):
+    o = Oracle(oracle)
+    pic, refs = make_case(**case)
+    want = oracle_decode(o, pic, refs)
+    for gather in (True, False):
+        got_all = group_sharded_decode(lib, pic, refs, nranks, depth=2, gather=gather, repeat=2)
+        if gather:
+            for r, got in enumerate(got_all):
+                assert_planes_equal(got, want, "group rank %d of %d" % (r, nranks))
+

@@ -5,7 +5,7 @@ ranks, ranks without tiles, 10-bit and all-intra pictures."""
 import pytest
 
 from oracle_py import Oracle
-from shard_util import local_sharded_decode
+from shard_util import group_sharded_decode, local_sharded_decode
 from synth_util import assert_planes_equal, make_case, oracle_decode
 from test_emu_picture import emu_lib  # noqa: F401  (fixture)
 from libde265_amd import worklist
@@ -38,3 +38,17 @@ def test_sharded_stage_isolation(emu_lib, oracle):  # noqa: F811
         want = oracle_decode(o, pic, refs, st)
         for r, got in enumerate(local_sharded_decode(emu_lib, pic, refs, 2, stages=st)):
             assert_planes_equal(got, want, "stages %d rank %d" % (st, r))
+
+
+GROUP_CASES = [(CASES[0][0], 2), (CASES[1][0], 4), (CASES[3][0], 3), (CASES[6][0], 4), (CASES[2][0], 1)]
+
+
+@pytest.mark.parametrize("case,nranks", GROUP_CASES, ids=lambda v: ("%dx%d_seed%d" % (v["width"], v["height"], v["seed"])) if isinstance(v, dict) else "r%d" % v)
+def test_group_in_one_process_matches_oracle(emu_lib, oracle, case, nranks):  # noqa: F811
+    """m355_group_*: the ranks are contexts of ONE process, the exchanges copies between their buffers (no callbacks, no
+    collective library) — what a decoder with a parser thread per tile uses to spread one bitstream over the GPUs of a node"""
+    o = Oracle(oracle)
+    pic, refs = make_case(**case)
+    want = oracle_decode(o, pic, refs)
+    for r, got in enumerate(group_sharded_decode(emu_lib, pic, refs, nranks, repeat=2)):
+        assert_planes_equal(got, want, "group rank %d of %d" % (r, nranks))

@@ -136,6 +136,33 @@ def test_random_access_streams_gpu(ref, tmp_path, monkeypatch, w, h, bd, frames,
     check_random_access(ref, make_stream(tmp_path, w, h, bd, 1, 1, frames, seed, 5, 1, 1, feat), frames, threads, capi.DEFAULT_LIB)
 
 
+# One bitstream across several backend contexts of ONE process (M355_GLUE_RANKS: the glue splits every picture's lists by tile
+# owner, the library's m355_group_* carries the halos and the finished tiles between the contexts; glue/m355_glue.cc submit_sharded):
+# (w, h, bit depth, tile cols, tile rows, frames, seed, features, ranks)
+RANKS_CPU_CASES = [(448, 256, 10, 2, 2, 4, 22, 0, 2), (320, 192, 8, 3, 2, 4, 23, F_WP | F_QPDELTA | F_PCM, 3)]
+
+
+@pytest.mark.parametrize("w,h,bd,tc,tr,frames,seed,feat,ranks", RANKS_CPU_CASES)
+def test_one_stream_across_ranks_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, w, h, bd, tc, tr, frames, seed, feat, ranks):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    monkeypatch.setenv("M355_GLUE_RANKS", str(ranks))
+    check(ref, make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, 10, 1, 1, feat), frames, 4, EMU_SO)
+
+
+RANKS_GPU_CASES = [(3840, 2160, 10, 2, 2, 5, 85, 0, 4), (1920, 1080, 8, 4, 2, 6, 86, F_WP | F_QPDELTA | F_PCM | F_CIP, 8),
+                   (1920, 1080, 8, 3, 2, 17, 87, F_RA | F_LT | F_TMVP | F_SDH, 3), (7680, 4320, 10, 4, 2, 3, 88, 0, 8)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bd,tc,tr,frames,seed,feat,ranks", RANKS_GPU_CASES)
+def test_one_stream_across_ranks_gpu(ref, tmp_path, monkeypatch, w, h, bd, tc, tr, frames, seed, feat, ranks):
+    """all ranks share the one GPU of the test box (contexts are per rank, the device index wraps): the control flow, the list
+    split and the exchanges are those of a node with one GPU per rank"""
+    monkeypatch.delenv("M355_LIB", raising=False)
+    monkeypatch.setenv("M355_GLUE_RANKS", str(ranks))
+    check(ref, make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, 10, 1, 1, feat), frames, 8, capi.DEFAULT_LIB)
+
+
 FEATURE_GPU_CASES = [
     (832, 480, 8, 1, 1, 6, 51, 5, F_WP, 1, 1, ("weighted_pb",)),
     (832, 480, 10, 2, 2, 6, 52, 10, F_WP | F_QPDELTA, 1, 4, ("weighted_pb", "weighted_pb_later_slice", "multi_slice_pic")),
