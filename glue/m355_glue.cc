@@ -603,35 +603,51 @@ int submit_sharded(Glue* g, const m355_picture& pic, int dslot)
   g->rhandle_next = (g->rhandle_next + 1) % g->rhandle.size();
   const bool fresh = hs.empty();
   if (fresh) hs.assign((size_t)N, -1);
-  std::vector<m355_cu> cus; std::vector<m355_tu> tus; std::vector<m355_pb> pbs; std::vector<m355_rb> rbs; std::vector<m355_ib> ibs; std::vector<m355_ctb> ctbs;
-  for (int r = 0; r < N; r++) {
-    cus.clear(); tus.clear(); pbs.clear(); rbs.clear(); ibs.clear();
-    for (int i = 0; i < pic.n_cus; i++) if (own(pic.cus[i].x, pic.cus[i].y) == r) cus.push_back(pic.cus[i]);
-    for (int i = 0; i < pic.n_tus; i++) if (own(pic.tus[i].x, pic.tus[i].y) == r) tus.push_back(pic.tus[i]);
-    for (int i = 0; i < pic.n_pbs; i++) if (own(pic.pbs[i].x, pic.pbs[i].y) == r) pbs.push_back(pic.pbs[i]);
-    m355_picture rp = pic;
+  /* the ranks' lists are cut out side by side (each task reads the whole picture's lists once and keeps its rank's records; the
+     coefficients of the kept residual blocks are compacted), then uploaded one context after the other */
+  struct RankLists { std::vector<m355_cu> cus; std::vector<m355_tu> tus; std::vector<m355_pb> pbs; std::vector<m355_rb> rbs; std::vector<m355_ib> ibs;
+                     std::vector<m355_ctb> ctbs; std::vector<uint32_t> coeffs; int rb_count[4]; };
+  static std::vector<RankLists> L;                          /* (kept between pictures: one worker thread submits) */
+  if ((int)L.size() < N) L.resize((size_t)N);
+  std::vector<uint32_t> order((size_t)pic.n_ctbs);
+  for (int i = 0; i < pic.n_ctbs; i++) order[(size_t)i] = (uint32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pic.ctbs[a].ib_start < pic.ctbs[b].ib_start; });
+  parallel_tasks((size_t)N, [&](size_t rr) {
+    const int r = (int)rr;
+    RankLists& l = L[rr];
+    l.cus.clear(); l.tus.clear(); l.pbs.clear(); l.rbs.clear(); l.ibs.clear(); l.coeffs.clear();
+    for (int i = 0; i < pic.n_cus; i++) if (own(pic.cus[i].x, pic.cus[i].y) == r) l.cus.push_back(pic.cus[i]);
+    for (int i = 0; i < pic.n_tus; i++) if (own(pic.tus[i].x, pic.tus[i].y) == r) l.tus.push_back(pic.tus[i]);
+    for (int i = 0; i < pic.n_pbs; i++) if (own(pic.pbs[i].x, pic.pbs[i].y) == r) l.pbs.push_back(pic.pbs[i]);
     const m355_rb* src = pic.rbs;
     for (int s = 0; s < 4; s++) {
       int kept = 0;
       for (int i = 0; i < pic.rb_count[s]; i++, src++)
-        if (own(src->cidx ? src->x * sw : src->x, src->cidx ? src->y * sh : src->y) == r) { rbs.push_back(*src); kept++; }
-      rp.rb_count[s] = kept;
+        if (own(src->cidx ? src->x * sw : src->x, src->cidx ? src->y * sh : src->y) == r) {
+          m355_rb rb = *src;
+          rb.coeff_ofs = (uint32_t)l.coeffs.size();
+          l.coeffs.insert(l.coeffs.end(), pic.coeffs + src->coeff_ofs, pic.coeffs + src->coeff_ofs + src->ncoeff);
+          l.rbs.push_back(rb); kept++;
+        }
+      l.rb_count[s] = kept;
     }
     /* intra blocks: whole CTBs are kept or dropped; the kept CTBs' runs are renumbered (ascending ib_start = the order they lie in) */
-    ctbs.assign(pic.ctbs, pic.ctbs + pic.n_ctbs);
-    std::vector<uint32_t> order((size_t)pic.n_ctbs);
-    for (int i = 0; i < pic.n_ctbs; i++) order[(size_t)i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pic.ctbs[a].ib_start < pic.ctbs[b].ib_start; });
+    l.ctbs.assign(pic.ctbs, pic.ctbs + pic.n_ctbs);
     for (uint32_t ci : order) {
-      m355_ctb& c = ctbs[ci];
+      m355_ctb& c = l.ctbs[ci];
       if (owner[ci] != r || !c.ib_count) { c.ib_start = 0; c.ib_count = 0; continue; }
-      const uint32_t start = (uint32_t)ibs.size();
-      ibs.insert(ibs.end(), pic.ibs + c.ib_start, pic.ibs + c.ib_start + c.ib_count);
+      const uint32_t start = (uint32_t)l.ibs.size();
+      l.ibs.insert(l.ibs.end(), pic.ibs + c.ib_start, pic.ibs + c.ib_start + c.ib_count);
       c.ib_start = start;
     }
-    rp.cus = cus.data(); rp.n_cus = (int32_t)cus.size(); rp.tus = tus.data(); rp.n_tus = (int32_t)tus.size();
-    rp.pbs = pbs.data(); rp.n_pbs = (int32_t)pbs.size(); rp.rbs = rbs.data(); rp.ibs = ibs.data(); rp.n_ibs = (int32_t)ibs.size();
-    rp.ctbs = ctbs.data();
+  });
+  for (int r = 0; r < N; r++) {
+    RankLists& l = L[(size_t)r];
+    m355_picture rp = pic;
+    for (int s = 0; s < 4; s++) rp.rb_count[s] = l.rb_count[s];
+    rp.cus = l.cus.data(); rp.n_cus = (int32_t)l.cus.size(); rp.tus = l.tus.data(); rp.n_tus = (int32_t)l.tus.size();
+    rp.pbs = l.pbs.data(); rp.n_pbs = (int32_t)l.pbs.size(); rp.rbs = l.rbs.data(); rp.ibs = l.ibs.data(); rp.n_ibs = (int32_t)l.ibs.size();
+    rp.ctbs = l.ctbs.data(); rp.coeffs = l.coeffs.data(); rp.n_coeffs = (uint32_t)l.coeffs.size();
     if (r) {
       rp.dst_frame = g->rframe[(size_t)r - 1][(size_t)dslot];
       for (int i = 0; i < M355_MAX_REF_FRAMES; i++) if (pic.ref_frames[i] >= 0) rp.ref_frames[i] = g->rframe[(size_t)r - 1][(size_t)i];
