@@ -110,15 +110,17 @@ __global__ void __launch_bounds__(256) k_deblock(DevPic p)
     if (!ownP && !ownQ) return;
   }
 
-  /* ---- memory round trip 1, everything at once and before any decision: the edge flags, the CU / PB indices of both sides,
-     the CTB's slice index AND the luma samples of the segment (nearly every segment of an inter picture is filtered or at
-     least examined; 32 + 32 bytes as aligned 4-sample vectors: the segment's 4 x 8 samples belong to this thread alone in
-     this pass).  The pass used to be a chain of five dependent round trips with 32 scalar sample loads at its end. ---- */
+  /* ---- memory round trip 1: the edge flags, the CU / PB indices of both sides and the CTB's slice index.  Segments that are no
+     transform / prediction edge leave here (half of the 8x8 grid of a picture of mixed CU sizes). ---- */
   const int u = y4 * p.w4 + x4, uo = VERTICAL ? u - 1 : u - p.w4;
   const uint32_t ciQ = d_cu_index_at(p, xDi, yDi), ciP = d_cu_index_at(p, xp, yp);
   const int ef = p.edge_tu[u] | p.edge_pb[u], efo = p.edge_tu[uo];
   const uint32_t ip = p.pb_of[uo], iq = p.pb_of[u];
   const int slice_idx = p.ctbs[d_ctb_of(p, xDi, yDi)].slice_idx;
+  if (!(ef & (VERTICAL ? (E_TU_V | E_PB_V) : (E_TU_H | E_PB_H)))) return;
+  /* ---- round trip 2: the records the indices name AND the segment's luma samples, requested together (the pass used to be a
+     chain of five dependent round trips with 32 scalar sample loads at its end): 32 + 32 bytes as aligned 4-sample vectors — the
+     segment's 4 x 8 samples belong to this thread alone in this pass ---- */
   const int stride = p.stride[0];
   PIX* const ptr = (PIX*)p.plane[0] + yDi * stride + xDi;
   /* VERTICAL: rp[k] / rq[k] = line k (samples xDi-4 .. xDi-1 / xDi .. xDi+3); horizontal: rp[i] / rq[i] = the row at distance i
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(256) k_deblock(DevPic p)
 #define QV(k, i) (VERTICAL ? d_get<PIX>(rq[k], i) : d_get<PIX>(rq[i], k))
 #define SETP(k, i, v) do { if (VERTICAL) d_set<PIX>(rp[k], 3 - (i), v); else d_set<PIX>(rp[i], k, v); } while (0)
 #define SETQ(k, i, v) do { if (VERTICAL) d_set<PIX>(rq[k], i, v); else d_set<PIX>(rq[i], k, v); } while (0)
-  /* ---- round trip 2: the records the indices name (an absent one reads the CTB table instead: always there, never used) ---- */
+  /* (an absent record reads the CTB table instead: always there, never used) */
   const bool pb_ok = ip && iq && ip <= (uint32_t)p.n_pb_records && iq <= (uint32_t)p.n_pb_records;
   const m355_cu cuQ = *(ciQ ? p.cus + (ciQ - 1) : (const m355_cu*)p.ctbs), cuP = *(ciP ? p.cus + (ciP - 1) : (const m355_cu*)p.ctbs);
   const m355_pb A = *(pb_ok ? p.pbs + (ip - 1) : (const m355_pb*)p.ctbs), B = *(pb_ok ? p.pbs + (iq - 1) : (const m355_pb*)p.ctbs);
