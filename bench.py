@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the bitstream-level leg (synthetic 8K stream through the reference CLI on the reference library and on the glue library)")
     ap.add_argument("--no-dependent-chain", action="store_true", help="skip the leg in which every picture references the two decoded before it")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
+    ap.add_argument("--group-ranks", type=int, default=0, help="N=1 only, diagnostic: additionally decode the picture tile-sharded over this many contexts of THIS process (m355_group_*), all on the one GPU")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
     args = ap.parse_args()
     # stdout carries exactly ONE line (rank 0's JSON): the libraries underneath are chatty on fd 1 (RCCL's version banner at
@@ -267,6 +268,10 @@ def main():
             out["tile_sharded"] = sharded
         if with_upload is not None:
             out["with_upload"] = with_upload
+        if world == 1 and args.group_ranks:
+            grp_leg = in_process_group_leg(args, lib, cfg, pic, synth, worklist, 1e3 * dt / args.steps)
+            if grp_leg is not None:
+                out["tile_sharded_in_process"] = grp_leg
         if chain is not None:
             out["dependent_chain"] = chain
         if not args.no_cpu_baseline and world == 1:
@@ -457,6 +462,66 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
                 "exchange_ms": ex_ms, "halo_exchange": dec.halo, "transport": transport,
                 "tiles_per_rank": (cfg["tile_cols"] * cfg["tile_rows"]) / world, "frames_identical_on_all_ranks": bool(same),
                 "exchange": {"halo_allreduce_bytes": xb[:3], "tile_allgather_bytes": xb[3]}}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
+def in_process_group_leg(args, lib, cfg, pic, synth, worklist, ms_unsharded):
+    """One picture tile-sharded over the contexts of ONE process (m355_group_*: exchanges = event-ordered peer copies, no collective
+    library).  On the one GPU of a bench box all ranks share the device, so this measures what sharding COSTS (cutting the picture,
+    the pack / unpack kernels, the exchanges as device-to-device copies) — per-GPU work does not shrink; on a node, rank r = GPU r."""
+    try:
+        from libde265_amd import capi, shard
+        n_tiles = cfg["tile_cols"] * cfg["tile_rows"]
+        ranks = max(2, min(args.group_ranks, n_tiles))
+        if n_tiles < 2:
+            return None
+        pp = pic.pp[0]
+        depth = 3
+        ctxs = [capi.Context(lib, 0) for _ in range(ranks)]
+        grp = capi.Group(lib, ctxs)
+        try:
+            hs = []
+            for r, ctx in enumerate(ctxs):
+                ctx.set_pipeline_depth(depth)
+                refs = []
+                for i in range(cfg["n_refs"]):
+                    f = ctx.frame_create_for(pp)
+                    ctx.frame_upload(f, synth.ref_planes(cfg["seed"] + 17 * i, int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
+                    refs.append(f)
+                sp = shard.shard_picture(pic, r, ranks)
+                sp.ref_frames = [refs[i] if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
+                per = []
+                for _ in range(depth):
+                    sp.dst_frame = ctx.frame_create_for(pp)
+                    per.append(ctx.upload(sp))
+                hs.append(per)
+            steps = max(30, min(args.steps, 200))
+
+            def timed(gather, in_flight):
+                for k in range(6):
+                    grp.decode([hs[r][k % depth] for r in range(ranks)], gather)
+                grp.wait()
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    grp.decode([hs[r][k % depth] for r in range(ranks)], gather)
+                    if not in_flight:
+                        grp.wait()
+                grp.wait()
+                return 1e3 * (time.perf_counter() - t0) / steps
+            ms_ref = timed(True, True)
+            ms_nonref = timed(False, True)
+            ms_one = timed(True, False)
+        finally:
+            grp.close()
+            for ctx in ctxs:
+                ctx.close()
+        return {"ranks": ranks, "all_ranks_on_one_gpu": True, "pictures_in_flight": depth, "ms_per_picture": ms_ref,
+                "ms_per_picture_non_reference": ms_nonref, "ms_per_picture_one_at_a_time": ms_one,
+                "tile_gather_ms": max(0.0, ms_ref - ms_nonref), "overhead_vs_unsharded": (ms_ref / ms_unsharded) if ms_unsharded > 0 else None,
+                "note": "one process, one context per rank, exchanges = hipMemcpyPeerAsync between the contexts ordered by events (m355_group_decode); "
+                        "PLUMBING figure: the ranks share this box's one GPU and their 6 streams each the HIP runtime's 4 hardware queues, so the "
+                        "kernels of different ranks mostly serialise (profiles/r04_m_group_one_gpu.txt) — on a node rank r has GPU r to itself"}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
 

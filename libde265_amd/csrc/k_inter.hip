@@ -27,6 +27,7 @@
  * Roofline: HBM/L2-bound; algorithmic bytes per PB and list = [(w+7)(h+7)+2(w/2+3)(h/2+3)]*B read,
  * w*h*1.5*B written.
  */
+#include <stdlib.h>
 #include "k_common.h"
 
 __constant__ int8_t c_qpel_taps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0},
@@ -798,7 +799,10 @@ static void launch_jobs(const DevPic& p, hipStream_t st)
   /* each range's blocks are padded to a multiple of 8 for the XCD-contiguous block order; the counts are on the device, so the
      grid covers the most jobs the list can hold */
   const unsigned grid = (unsigned)((p.jobs_cap + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK) + 3 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(grid), dim3(M355_INTER_BLOCK), 0, st, p);
+  /* M355_INTER_LDS_PAD=<bytes> (experiment): dynamic LDS nobody uses, to cap the workgroups per CU — k_inter_jobs fills the register
+     file of every SIMD it runs on (3 waves x 168 VGPRs), so kernels of the other pictures in flight only get what it leaves */
+  static const unsigned pad = getenv("M355_INTER_LDS_PAD") ? (unsigned)atoi(getenv("M355_INTER_LDS_PAD")) : 0u;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(grid), dim3(M355_INTER_BLOCK), pad, st, p);
 }
 
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)

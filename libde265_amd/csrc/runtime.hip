@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1986,8 +1987,104 @@ int m355_shard_time_exchange(m355_ctx* c, int h, int which, int iters, float* ms
  * until everybody has read them), then adds.  X3: every rank copies the other ranks' finished-tile slots into its gather buffer. ---- */
 struct m355_group {
   std::vector<m355_ctx*> ctx;
-  std::vector<hipEvent_t> ev_pack, ev_copied;     /* per rank */
+  /* [rank][exchange 0..3]: recorded behind the rank's pack of that phase / behind its fetch of the neighbours' buffers */
+  std::vector<std::array<hipEvent_t, 4>> ev_pack, ev_copied;
+  /* One host thread per rank enqueues that rank's phases and exchanges (a single thread issuing every rank's ≈60 calls per picture
+     is what bounds a group of 4: 1.46 ms per 8K picture against 0.4 unsharded, profiles/r04_m_*).  The threads meet only where one
+     needs an event another has to have RECORDED first: seq_* = (picture number * 8 + exchange + 1) once the event of that exchange is on
+     its stream; a reader spins until its peer got there.  Every event is recorded once per picture, and m355_group_decode returns
+     only when every rank has enqueued the whole picture, so the next picture's record never overtakes a wait of this one. */
+  std::vector<std::thread> th;
+  std::vector<std::atomic<unsigned long long>> seq_pack, seq_copied;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  unsigned long long job = 0;          /* picture number (1, 2, ...) the threads are to enqueue */
+  int pending = 0;
+  bool stop = false;
+  const int* handles = nullptr;
+  int gather = 0;
+  std::vector<int> rc;
+  std::vector<std::string> err;
 };
+
+/* rank r's share of one picture: phases 0..last with the exchanges between them */
+static int group_rank_decode(m355_group* g, int r, unsigned long long n, const int* handles, int gather)
+{
+  const int N = (int)g->ctx.size();
+  m355_ctx* c = g->ctx[(size_t)r];
+  hipSetDevice(c->device);
+  const int h = handles[r];
+  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded) return fail(M355_ERR_INVALID, "rank %d: not a sharded picture handle", r);
+  if (c->resident[h].shard_n != N || c->resident[h].shard_rank != r) return fail(M355_ERR_INVALID, "rank %d: the picture was uploaded for another group layout", r);
+  const int rc0 = shard_buffers(c, h);
+  Resident& me = c->resident[h];
+  auto published = [&](std::atomic<unsigned long long>& a, int k) { a.store(n * 8 + (unsigned long long)k + 1, std::memory_order_release); };
+  auto await = [&](std::atomic<unsigned long long>& a, int k) {
+    const unsigned long long want = n * 8 + (unsigned long long)k + 1;
+    while (a.load(std::memory_order_acquire) < want) std::this_thread::yield();
+  };
+  const int last = gather ? 4 : 3;
+  int rc = rc0;
+  for (int k = 0; k <= last; k++) {
+    /* (a rank that failed keeps publishing its steps: the others must not wait for it forever) */
+    if (!rc) rc = m355_decode_phase(c, h, k, k < 4 ? me.xb[k] : nullptr);
+    if (N <= 1 || k >= last) continue;
+    hipStream_t st = (hipStream_t)m355_stream(c);
+    if (!rc) hipEventRecord(g->ev_pack[(size_t)r][(size_t)k], st);
+    published(g->seq_pack[(size_t)r], k);
+    if (k < 3) {
+      /* step 1: fetch the neighbours' buffers as they packed them into this rank's scratch slots */
+      for (size_t i = 0; i < me.peers.size() && !rc; i++) {
+        const int q = me.peers[i];
+        await(g->seq_pack[(size_t)q], k);
+        Resident& other = g->ctx[(size_t)q]->resident[handles[q]];
+        if (!other.xb[k]) { rc = fail(M355_ERR_INVALID, "rank %d has no exchange buffers", q); break; }
+        hipStreamWaitEvent(st, g->ev_pack[(size_t)q][(size_t)k], 0);
+        if (hipMemcpyPeerAsync((char*)me.xscratch + me.xscratch_pitch * i, c->device, other.xb[k], g->ctx[(size_t)q]->device, me.xb_bytes[k], st) != hipSuccess) rc = fail(M355_ERR_HIP, "hipMemcpyPeerAsync failed");
+      }
+      if (!rc) hipEventRecord(g->ev_copied[(size_t)r][(size_t)k], st);
+      published(g->seq_copied[(size_t)r], k);
+      /* step 2: add them once this rank's own buffer has been read by all of them */
+      if (!rc && !me.peers.empty()) {
+        for (int q : me.peers) { await(g->seq_copied[(size_t)q], k); hipStreamWaitEvent(st, g->ev_copied[(size_t)q][(size_t)k], 0); }
+        m355_launch_halo_add((uint32_t*)me.xb[k], (const uint32_t*)me.xscratch, (uint32_t)(me.xscratch_pitch / 4), (int)me.peers.size(), (uint32_t)((me.xb_bytes[k] + 3) / 4), st);
+      }
+    } else {
+      /* X3: the other ranks' finished tiles, slot by slot, straight out of their gather buffers */
+      const size_t slot = me.xb_bytes[3] / (size_t)N;
+      for (int q = 0; q < N && !rc; q++) {
+        if (q == r) continue;
+        await(g->seq_pack[(size_t)q], 3);
+        Resident& other = g->ctx[(size_t)q]->resident[handles[q]];
+        if (!other.xb[3]) { rc = fail(M355_ERR_INVALID, "rank %d has no exchange buffers", q); break; }
+        hipStreamWaitEvent(st, g->ev_pack[(size_t)q][3], 0);
+        if (hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)other.xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st) != hipSuccess) rc = fail(M355_ERR_HIP, "hipMemcpyPeerAsync failed");
+      }
+    }
+  }
+  return rc;
+}
+
+static void group_thread(m355_group* g, int r)
+{
+  unsigned long long seen = 0;
+  for (;;) {
+    const int* handles; int gather; unsigned long long n;
+    {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv_go.wait(lk, [&]() { return g->stop || g->job != seen; });
+      if (g->stop) return;
+      n = seen = g->job; handles = g->handles; gather = g->gather;
+    }
+    const int rc = group_rank_decode(g, r, n, handles, gather);
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->rc[(size_t)r] = rc;
+      if (rc) g->err[(size_t)r] = g_err;
+      if (--g->pending == 0) g->cv_done.notify_all();
+    }
+  }
+}
 
 int m355_group_create(m355_ctx* const* ctxs, int n, m355_group** out)
 {
@@ -2000,14 +2097,25 @@ int m355_group_create(m355_ctx* const* ctxs, int n, m355_group** out)
     if (rc) { delete g; return rc; }
     m355_shard_set_comm(ctxs[r], nullptr);
   }
-  g->ev_pack.assign((size_t)n, nullptr); g->ev_copied.assign((size_t)n, nullptr);
+  g->ev_pack.resize((size_t)n); g->ev_copied.resize((size_t)n);
+  for (int r = 0; r < n; r++) for (int k = 0; k < 4; k++) { g->ev_pack[(size_t)r][(size_t)k] = nullptr; g->ev_copied[(size_t)r][(size_t)k] = nullptr; }
+  g->seq_pack = std::vector<std::atomic<unsigned long long>>((size_t)n);
+  g->seq_copied = std::vector<std::atomic<unsigned long long>>((size_t)n);
+  for (int r = 0; r < n; r++) { g->seq_pack[(size_t)r].store(0); g->seq_copied[(size_t)r].store(0); }
+  g->rc.assign((size_t)n, 0); g->err.assign((size_t)n, std::string());
   for (int r = 0; r < n; r++) {
     hipSetDevice(ctxs[r]->device);
-    if (hipEventCreateWithFlags(&g->ev_pack[(size_t)r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev_copied[(size_t)r], hipEventDisableTiming) != hipSuccess) {
-      m355_group_destroy(g);
-      return fail(M355_ERR_HIP, "hipEventCreate failed");
-    }
+    for (int k = 0; k < 4; k++)
+      if (hipEventCreateWithFlags(&g->ev_pack[(size_t)r][(size_t)k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev_copied[(size_t)r][(size_t)k], hipEventDisableTiming) != hipSuccess) {
+        m355_group_destroy(g);
+        return fail(M355_ERR_HIP, "hipEventCreate failed");
+      }
   }
+  bool threads = n > 1 && !(getenv("M355_GROUP_THREADS") && atoi(getenv("M355_GROUP_THREADS")) == 0);
+#ifdef SIMT_EMU
+  threads = false;
+#endif
+  if (threads) for (int r = 0; r < n; r++) g->th.emplace_back(group_thread, g, r);
   *out = g;
   return M355_OK;
 }
@@ -2015,17 +2123,23 @@ int m355_group_create(m355_ctx* const* ctxs, int n, m355_group** out)
 void m355_group_destroy(m355_group* g)
 {
   if (!g) return;
-  for (size_t r = 0; r < g->ctx.size(); r++) {
+  { std::lock_guard<std::mutex> lk(g->mu); g->stop = true; }
+  g->cv_go.notify_all();
+  for (auto& t : g->th) t.join();
+  for (size_t r = 0; r < g->ctx.size() && r < g->ev_pack.size(); r++) {
     hipSetDevice(g->ctx[r]->device);
-    if (r < g->ev_pack.size() && g->ev_pack[r]) hipEventDestroy(g->ev_pack[r]);
-    if (r < g->ev_copied.size() && g->ev_copied[r]) hipEventDestroy(g->ev_copied[r]);
+    for (int k = 0; k < 4; k++) {
+      if (g->ev_pack[r][(size_t)k]) hipEventDestroy(g->ev_pack[r][(size_t)k]);
+      if (g->ev_copied[r][(size_t)k]) hipEventDestroy(g->ev_copied[r][(size_t)k]);
+    }
   }
   delete g;
 }
 
-int m355_group_decode(m355_group* g, const int* handles, int gather)
+/* the same picture enqueued by ONE thread, rank after rank in lockstep (M355_GROUP_THREADS=0, and the SIMT interpreter of the CPU
+   test tier, whose launches are not thread-safe) */
+static int group_decode_lockstep(m355_group* g, const int* handles, int gather)
 {
-  if (!g || !handles) return fail(M355_ERR_INVALID, "bad arguments");
   const int N = (int)g->ctx.size();
   std::vector<Resident*> R((size_t)N);
   for (int r = 0; r < N; r++) {
@@ -2045,49 +2159,50 @@ int m355_group_decode(m355_group* g, const int* handles, int gather)
       hipSetDevice(c->device);
       const int rc = m355_decode_phase(c, handles[r], k, k < 4 ? R[(size_t)r]->xb[k] : nullptr);
       if (rc) return rc;
-      if (N > 1 && k < last) hipEventRecord(g->ev_pack[(size_t)r], (hipStream_t)m355_stream(c));
+      if (N > 1 && k < last) hipEventRecord(g->ev_pack[(size_t)r][(size_t)k], (hipStream_t)m355_stream(c));
     }
     if (N <= 1 || k >= last) continue;
-    if (k < 3) {
-      /* step 1: every rank fetches its neighbours' buffers (as they packed them) into its scratch slots */
+    for (int step = 0; step < (k < 3 ? 2 : 1); step++)
       for (int r = 0; r < N; r++) {
         m355_ctx* c = g->ctx[(size_t)r];
         Resident& me = *R[(size_t)r];
         hipSetDevice(c->device);
         hipStream_t st = (hipStream_t)m355_stream(c);
-        for (size_t i = 0; i < me.peers.size(); i++) {
-          const int q = me.peers[i];
-          hipStreamWaitEvent(st, g->ev_pack[(size_t)q], 0);
-          HIPCHK(hipMemcpyPeerAsync((char*)me.xscratch + me.xscratch_pitch * i, c->device, R[(size_t)q]->xb[k], g->ctx[(size_t)q]->device, me.xb_bytes[k], st));
-        }
-        hipEventRecord(g->ev_copied[(size_t)r], st);
-      }
-      /* step 2: ... and adds them once its own buffer has been read by all of them */
-      for (int r = 0; r < N; r++) {
-        m355_ctx* c = g->ctx[(size_t)r];
-        Resident& me = *R[(size_t)r];
-        if (me.peers.empty()) continue;
-        hipSetDevice(c->device);
-        hipStream_t st = (hipStream_t)m355_stream(c);
-        for (int q : me.peers) hipStreamWaitEvent(st, g->ev_copied[(size_t)q], 0);
-        m355_launch_halo_add((uint32_t*)me.xb[k], (const uint32_t*)me.xscratch, (uint32_t)(me.xscratch_pitch / 4), (int)me.peers.size(), (uint32_t)((me.xb_bytes[k] + 3) / 4), st);
-      }
-    } else {
-      /* X3: the other ranks' finished tiles, slot by slot, straight out of their gather buffers */
-      for (int r = 0; r < N; r++) {
-        m355_ctx* c = g->ctx[(size_t)r];
-        Resident& me = *R[(size_t)r];
-        hipSetDevice(c->device);
-        hipStream_t st = (hipStream_t)m355_stream(c);
-        const size_t slot = me.xb_bytes[3] / (size_t)N;
-        for (int q = 0; q < N; q++) {
-          if (q == r) continue;
-          hipStreamWaitEvent(st, g->ev_pack[(size_t)q], 0);
-          HIPCHK(hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)R[(size_t)q]->xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st));
+        if (k < 3 && step == 0) {
+          for (size_t i = 0; i < me.peers.size(); i++) {
+            const int q = me.peers[i];
+            hipStreamWaitEvent(st, g->ev_pack[(size_t)q][(size_t)k], 0);
+            HIPCHK(hipMemcpyPeerAsync((char*)me.xscratch + me.xscratch_pitch * i, c->device, R[(size_t)q]->xb[k], g->ctx[(size_t)q]->device, me.xb_bytes[k], st));
+          }
+          hipEventRecord(g->ev_copied[(size_t)r][(size_t)k], st);
+        } else if (k < 3) {
+          if (me.peers.empty()) continue;
+          for (int q : me.peers) hipStreamWaitEvent(st, g->ev_copied[(size_t)q][(size_t)k], 0);
+          m355_launch_halo_add((uint32_t*)me.xb[k], (const uint32_t*)me.xscratch, (uint32_t)(me.xscratch_pitch / 4), (int)me.peers.size(), (uint32_t)((me.xb_bytes[k] + 3) / 4), st);
+        } else {
+          const size_t slot = me.xb_bytes[3] / (size_t)N;
+          for (int q = 0; q < N; q++) {
+            if (q == r) continue;
+            hipStreamWaitEvent(st, g->ev_pack[(size_t)q][3], 0);
+            HIPCHK(hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)R[(size_t)q]->xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st));
+          }
         }
       }
-    }
   }
+  return M355_OK;
+}
+
+int m355_group_decode(m355_group* g, const int* handles, int gather)
+{
+  if (!g || !handles) return fail(M355_ERR_INVALID, "bad arguments");
+  const int N = (int)g->ctx.size();
+  if (g->th.empty()) return group_decode_lockstep(g, handles, gather);
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->handles = handles; g->gather = gather; g->pending = N; g->job++;
+  g->cv_go.notify_all();
+  g->cv_done.wait(lk, [&]() { return g->pending == 0; });
+  for (int r = 0; r < N; r++)
+    if (g->rc[(size_t)r]) { g_err = g->err[(size_t)r]; return g->rc[(size_t)r]; }
   return M355_OK;
 }
 
