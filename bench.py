@@ -42,6 +42,8 @@ def main():
                     "synchronisation; ms_per_step / value are the MEDIAN region, ms_per_step_spread the min / max (default: 25 for <= 200 steps, else 5)")
     ap.add_argument("--workload", default="c5_8k10_8tiles")
     ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1..16)")
+    ap.add_argument("--intra-batch", type=int, default=0, help="intra workloads: the timed region's steps go out in groups of this many pictures with ONE intra stage "
+                    "(m355_decode_batch; needs --pipeline-depth >= the group); a step is still one whole picture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", type=int, default=31, help="DIAGNOSTIC ONLY: M355_STAGE_* mask (anything but 31 is not a valid benchmark)")
     ap.add_argument("--no-with-upload", action="store_true", help="skip the PCIe-inclusive legs (lists recorded into the pinned arena -> validation -> H2D -> decode, per step)")
@@ -126,8 +128,21 @@ def main():
     # go round the lanes; every step still runs the whole chain for one picture, into the next of `depth` destination frames —
     # reusing a frame waits for its previous decode through the frame events)
     ctx.set_pipeline_depth(args.pipeline_depth)
-    for i in range(args.warmup):
-        ctx.decode_resident(handles[i % len(handles)])
+    batch = args.intra_batch if args.intra_batch > 1 else 0
+    if batch and (batch > len(handles) or cfg.get("intra_pct", 0) != 100):
+        raise SystemExit("--intra-batch needs an intra workload and --pipeline-depth >= the batch")
+
+    def run_steps(n):
+        if not batch:
+            for i in range(n):
+                ctx.decode_resident(handles[i % len(handles)])
+            return
+        i = 0
+        while i < n:                          # groups of `batch` pictures, one shared k_intra launch each
+            b = min(batch, n - i)
+            ctx.decode_batch([handles[(i + j) % len(handles)] for j in range(b)])
+            i += b
+    run_steps(args.warmup)
     ctx.wait()
     repeats = args.repeats if args.repeats > 0 else (25 if args.steps <= 200 else 5)
     regions, enq = [], []
@@ -136,8 +151,7 @@ def main():
             import torch
             dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            ctx.decode_resident(handles[i % len(handles)])
+        run_steps(args.steps)
         enq.append(time.perf_counter() - t0)  # host time to enqueue the K steps (launches are asynchronous)
         ctx.wait()
         if dist:
@@ -246,7 +260,7 @@ def main():
             "metric": "decoded CTBs/s", "value": world * args.steps * n_ctbs / dt, "unit": "CTB64/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "repeats": repeats, "ms_per_step_spread": spread,
-            "ms_per_step_one_in_flight": 1e3 * dt_serial / args.steps, "pictures_in_flight": args.pipeline_depth,
+            "ms_per_step_one_in_flight": 1e3 * dt_serial / args.steps, "pictures_in_flight": args.pipeline_depth, "intra_batch": batch,
             "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if pp["bit_depth_luma"] <= 8 else "u16", "data": "synthetic",

@@ -473,6 +473,13 @@ M355_API int m355_picture_release(m355_ctx* ctx, int handle);
 /* other lists into an uploaded picture's arenas: waits for that handle's last decode only (no allocation when they fit) */
 M355_API int m355_picture_replace(m355_ctx* ctx, int handle, const m355_picture* pic);
 M355_API int m355_decode_resident(m355_ctx* ctx, int handle);
+/* n independent INTRA pictures (n <= pipeline depth, distinct destination frames, one chroma format and sample type) with ONE intra
+ * stage: each picture's residuals / border plans and its filters run on a lane of its own as for n m355_decode_resident calls, the
+ * CTB wavefronts of all n run interleaved inside one k_intra launch — the way all-intra material (the reference's decode_CTB loop
+ * over intra slices, slice.cc:4375 read_coding_tree_unit -> intrapred.cc:279 decode_intra_prediction, one picture at a time) fills
+ * the GPU without one hardware queue per picture.  The pictures get consecutive serials (m355_last_serial = the last one's);
+ * results are those of n single decodes, bit for bit.  Not stage-timed (m355_timing_collect sees single decodes only). */
+M355_API int m355_decode_batch(m355_ctx* ctx, const int* handles, int n);
 /* stage mask for m355_set_stages: run only part of the chain (stage-isolated parity, like
  * DE265_DECODER_PARAM_DISABLE_DEBLOCKING / _DISABLE_SAO, de265.h:409-410) */
 enum { M355_STAGE_INTER = 1, M355_STAGE_RESIDUAL = 2, M355_STAGE_INTRA = 4, M355_STAGE_DEBLOCK = 8,

@@ -82,6 +82,7 @@ class Library:
         L.m355_picture_upload.argtypes = [vp, vp]
         L.m355_picture_release.argtypes = [vp, i]
         L.m355_decode_resident.argtypes = [vp, i]
+        L.m355_decode_batch.argtypes = [vp, ctypes.POINTER(i), i]
         L.m355_set_stages.argtypes = [vp, i]
         L.m355_set_pipeline_depth.argtypes = [vp, i]
         L.m355_timing_reset.argtypes = [vp]
@@ -305,6 +306,11 @@ class Context:
 
     def decode_resident(self, handle):
         self.L.check(self.L.lib.m355_decode_resident(self.h, handle))
+
+    def decode_batch(self, handles):
+        """several independent intra pictures with one intra stage (m355_decode_batch)"""
+        a = (ctypes.c_int * len(handles))(*handles)
+        self.L.check(self.L.lib.m355_decode_batch(self.h, a, len(handles)))
 
     def set_stages(self, mask):
         self.L.check(self.L.lib.m355_set_stages(self.h, mask))

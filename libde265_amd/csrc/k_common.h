@@ -197,6 +197,7 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pics, int n, int max_work, uint32_t* ticket, int grid, hipStream_t st);   /* intra pictures of one geometry in ONE launch */
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st);   /* one direction (tile sharding) */
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st);

@@ -244,10 +244,14 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
  * blocks per CTB: up to 1-2 + 1 + 1 waves, residual cache lines requested in the prologue and loaded per block behind its
  * border gather, the plan of 64 blocks at a time; the smaller footprint keeps more CTBs in flight).  The CTB's own wave
  * counts come from DevIntraWork.waves_code (runtime.hip intra_schedule). */
-template <class PIX, int CF, int NW, bool DENSE>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p, int work_n)
+/* BATCH (intra pictures only): SEVERAL pictures' CTBs in one launch — pics[0 .. n_pics) in device memory, one shared ticket; ticket t
+ * is item t / n_pics of picture t % n_pics (the pictures' wavefronts interleaved: a workgroup still only waits on items claimed
+ * before its own, now of its own picture).  Independent intra pictures then overlap CTB by CTB inside one kernel instead of through
+ * the runtime's hardware queues (m355_decode_batch, runtime.hip). */
+template <class PIX, int CF, int NW, bool DENSE, bool BATCH>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
 {
-  M355_GATE(p);
+  if (!BATCH) M355_GATE(p0);
   constexpr int CW_C = IntraGeo<CF>::CW_C, CH_C = IntraGeo<CF>::CH_C;
   constexpr int BODY_L = IntraGeo<CF>::BODY_L, BODY_C = IntraGeo<CF>::BODY_C;
   constexpr int SAMP_L = IntraGeo<CF>::SAMP_L, SAMP_C = IntraGeo<CF>::SAMP_C;
@@ -282,13 +286,23 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      Inter pictures: one workgroup per CTB with intra blocks — the first n_intra_free items (no neighbour to wait for) go by
      workgroup index (no atomic, no barrier), the dependent ones through the ticket. */
   for (;;) {
-  int item = (int)blockIdx.x;
-  if (DENSE || item >= p.n_intra_free) {          /* (uniform per workgroup) */
-    if (threadIdx.x == 0) s_ticket = (DENSE ? 0u : (uint32_t)p.n_intra_free) + atomicAdd(p.ticket, 1u);
+  int item = (int)blockIdx.x, pk = 0;
+  if (BATCH) {
+    if (threadIdx.x == 0) s_ticket = atomicAdd(batch_ticket, 1u);
+    __syncthreads();
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
+    if (t >= (uint32_t)work_n * (uint32_t)n_pics) return;       /* work_n = the longest picture's list */
+    pk = (int)(t % (uint32_t)n_pics); item = (int)(t / (uint32_t)n_pics);
+  } else if (DENSE || item >= p0.n_intra_free) {          /* (uniform per workgroup) */
+    if (threadIdx.x == 0) s_ticket = (DENSE ? 0u : (uint32_t)p0.n_intra_free) + atomicAdd(p0.ticket, 1u);
     __syncthreads();
     item = __builtin_amdgcn_readfirstlane((int)s_ticket);
   }
-  if (item >= work_n) return;
+  const DevPic& p = *(BATCH ? pics + pk : &p0);
+  if (BATCH) {
+    /* a shorter picture's list is exhausted, or its lists were rejected (k_validate): nothing to do for this ticket */
+    if (item >= p.n_intra_work || p.timeout[1] == p.epoch) { __syncthreads(); continue; }
+  } else if (item >= work_n) return;
 #ifdef M355_X_PROF      /* experiment builds (tools/prof_timeline.py): when a CTB was claimed, started its block loop, ended it, was written out */
 #define TL(k) do { if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item + 1 + (k)] = wall_clock64(); } while (0)
 #else
@@ -947,8 +961,8 @@ static void launch_intra_cf(const DevPic& p, hipStream_t st)
   hipMemsetAsync(p.ticket, 0, 4, st);
   /* dense intra pictures: 12 waves (up to 8 luma + 2 + 2 chroma blocks of a level at once); sparse ones: 4 (3 and 6 measured
      slower) */
-  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true>), dim3(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work), dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work);
+  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, false>), dim3(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work), dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
 }
 
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)
@@ -959,6 +973,24 @@ void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)
     case 1: if (hbd) launch_intra_cf<uint16_t, 1>(p, st); else launch_intra_cf<uint8_t, 1>(p, st); break;
     case 2: if (hbd) launch_intra_cf<uint16_t, 2>(p, st); else launch_intra_cf<uint8_t, 2>(p, st); break;
     default: if (hbd) launch_intra_cf<uint16_t, 3>(p, st); else launch_intra_cf<uint8_t, 3>(p, st); break;
+  }
+}
+
+/* several intra pictures of one geometry in ONE launch (k_intra<BATCH>): first = the pictures' common parameters, dev_pics = their
+   DevPic records in device memory, ticket = a zeroed word of its own, grid = persistent workgroups */
+template <class PIX, int CF>
+static void launch_intra_batch_cf(const DevPic& first, const DevPic* dev_pics, int n, int max_work, uint32_t* ticket, int grid, hipStream_t st)
+{
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, true>), dim3(grid), dim3(64 * M355_INTRA_DENSE_NW), 0, st, first, max_work, dev_pics, n, ticket);
+}
+void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pics, int n, int max_work, uint32_t* ticket, int grid, hipStream_t st)
+{
+  if (max_work <= 0 || n <= 0) return;
+  switch (first.pp.chroma_format_idc) {
+    case 0: if (hbd) launch_intra_batch_cf<uint16_t, 0>(first, dev_pics, n, max_work, ticket, grid, st); else launch_intra_batch_cf<uint8_t, 0>(first, dev_pics, n, max_work, ticket, grid, st); break;
+    case 1: if (hbd) launch_intra_batch_cf<uint16_t, 1>(first, dev_pics, n, max_work, ticket, grid, st); else launch_intra_batch_cf<uint8_t, 1>(first, dev_pics, n, max_work, ticket, grid, st); break;
+    case 2: if (hbd) launch_intra_batch_cf<uint16_t, 2>(first, dev_pics, n, max_work, ticket, grid, st); else launch_intra_batch_cf<uint8_t, 2>(first, dev_pics, n, max_work, ticket, grid, st); break;
+    default: if (hbd) launch_intra_batch_cf<uint16_t, 3>(first, dev_pics, n, max_work, ticket, grid, st); else launch_intra_batch_cf<uint8_t, 3>(first, dev_pics, n, max_work, ticket, grid, st); break;
   }
 }
 

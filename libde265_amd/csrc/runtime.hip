@@ -208,6 +208,16 @@ struct m355_ctx {
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
+  /* m355_decode_batch: ring of picture-record arrays (pinned staging + device copy + the batch's ticket word); a slot's event is
+     recorded behind the batch's k_intra — what the pictures' filter stages wait for, and what guards the slot's reuse */
+  struct BatchSlot { DevPic* host = nullptr; DevPic* dev = nullptr; uint32_t* ticket = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+  BatchSlot batch[4];
+  int batch_next = 0;
+  hipStream_t batch_stream[2] = {nullptr, nullptr};   /* consecutive batches' k_intra launches alternate between two streams of priority
+                                                         classes of their own (own hardware queues): the tail of one batch's wavefronts
+                                                         overlaps the head of the next batch's when they run on different lanes */
+  unsigned batch_count = 0;
+  hipEvent_t batch_ev_pre[M355_MAX_LANES] = {};   /* the front part of picture k of the current batch is enqueued */
   /* CtbAddrRStoTS / TStoRS / TileIdRS of the last tile structure seen (pps.cc:589-606), upload() */
   struct ScanCache { int ctbW = 0, ctbH = 0, ntc = 0, ntr = 0; decltype(m355_pic_params::col_bd) col_bd; decltype(m355_pic_params::row_bd) row_bd;
                      std::vector<uint32_t> ctb_ts, ts2rs; std::vector<uint16_t> tile_id; } scan;
@@ -286,6 +296,7 @@ static hipError_t sync_all(m355_ctx* c)
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].stream) { hipError_t e2 = hipStreamSynchronize(c->lanes[k].stream); if (e == hipSuccess) e = e2; }
   if (c->stream_hi) { hipError_t e2 = hipStreamSynchronize(c->stream_hi); if (e == hipSuccess) e = e2; }
+  for (hipStream_t bs : c->batch_stream) if (bs) { hipError_t e2 = hipStreamSynchronize(bs); if (e == hipSuccess) e = e2; }
   for (int k = 0; k < M355_MAX_LANES; k++)
     if (k != c->active && c->lanes[k].stream_hi) { hipError_t e2 = hipStreamSynchronize(c->lanes[k].stream_hi); if (e == hipSuccess) e = e2; }
   return e;
@@ -439,6 +450,9 @@ void m355_destroy(m355_ctx* c)
   for (auto& t : c->transient) resident_free(t);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   if (c->hash_acc) hipFree(c->hash_acc);
+  for (auto& b : c->batch) { if (b.host) hipHostFree(b.host); if (b.dev) hipFree(b.dev); if (b.ev) hipEventDestroy(b.ev); }
+  for (hipEvent_t e : c->batch_ev_pre) if (e) hipEventDestroy(e);
+  for (hipStream_t bs : c->batch_stream) if (bs) hipStreamDestroy(bs);
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& st_ : c->status) if (st_.ev) hipEventDestroy(st_.ev);
   if (c->status_words) hipHostFree(c->status_words);
@@ -1556,7 +1570,7 @@ static void clear_target(m355_ctx* c, const DevPic& d, Frame* tgt, bool gated, h
   }
 }
 
-static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev)
+static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra = true)
 {
   hipStream_t st = c->stream;
   /* an intra picture keeps to its lane's main stream (M355_DENSE_SINGLE_STREAM=0: forks like the others): its side work (metadata
@@ -1599,30 +1613,46 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   }
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
   if (!fused && ev) hipEventRecord(ev[3], st);
-  if (c->stages & M355_STAGE_INTRA) m355_launch_intra(d, hbd, st);
+  if (with_intra && (c->stages & M355_STAGE_INTRA)) m355_launch_intra(d, hbd, st);   /* (m355_decode_batch launches several pictures' intra stage as one kernel) */
   if (ev) hipEventRecord(ev[4], st);
 }
 
-static int decode(m355_ctx* c, Resident& r, bool rotate = true)
+/* write-after-write / write-after-read on the destination: waited for right before the first kernel that writes it — the SAO
+   stage when SAO runs (everything before writes this lane's working planes), else the first stage */
+static void dst_hazards(m355_ctx* c, Frame* dstf, bool piped)
+{
+  if (dstf->dl_pending) hipStreamWaitEvent(c->stream, dstf->ev_dl, 0);     /* (stays pending for the HOST until m355_frame_download_wait / m355_wait) */
+  if (!piped) return;
+  if (dstf->wr_pending) hipStreamWaitEvent(c->stream, dstf->ev_wr, 0);
+  for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(c->stream, dstf->ev_rd[k], 0);
+}
+
+/* One decode = decode_pre (lane, hazards, validation, every stage in front of the intra stage [and, with_intra, that stage]) +
+ * decode_post (in-loop filters, events, status slot).  m355_decode_batch runs the pre part of several intra pictures on their lanes,
+ * ONE k_intra launch for all of them, then their post parts. */
+struct DecodeState { DevPic d; bool want_sao = false; hipEvent_t* ev = nullptr; hipStream_t saved_stream = nullptr; bool swapped = false; };
+
+static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, bool with_intra)
 {
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
   if (rotate && c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);   /* consecutive pictures go round the lanes */
-  /* which stream: an intra picture on lane 3.. takes the lane's class stream (lane_class_priority); the whole decode below addresses
-     c->stream, which is that stream until this function returns */
-  struct StreamSwap { hipStream_t& ref; hipStream_t saved; ~StreamSwap() { ref = saved; } } swap_back{c->stream, c->stream};
+  /* which stream: an intra picture on lane 3.. takes the lane's class stream (lane_class_priority); the whole decode addresses
+     c->stream, which is that stream until decode_post returns (a batch keeps to the lanes' ordinary streams: its pictures overlap
+     inside one kernel, not through hardware queues) */
   {
     hipStream_t run = c->stream;
-    if (r.dp.intra_dense && c->active >= 3 && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
+    if (with_intra && r.dp.intra_dense && c->active >= 3 && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
       if (!c->stream_hi) HIPCHK(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, lane_class_priority(c->active)));
       run = c->stream_hi;
     }
     if (c->last_stream && c->last_stream != run) hipStreamWaitEvent(run, c->ev_last, 0);   /* the lane's scratch and working planes */
+    S.saved_stream = c->stream; S.swapped = run != c->stream;
     c->stream = run;
   }
-  DevPic d;
-  bool want_sao;
-  int rc = prepare(c, r, d, want_sao);
+  DevPic& d = S.d;
+  int rc = prepare(c, r, d, S.want_sao);
   if (rc) return rc;
+  const bool want_sao = S.want_sao;
   const m355_pic_params& pp = r.hdr.pp;
   const bool hbd = pp.bit_depth_luma > 8;
   const bool piped = c->depth >= 2;
@@ -1631,30 +1661,40 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
     /* read-after-write: the lists (uploaded on whichever lane was active); the reference frames' last writers: launch_prediction */
     if (r.ev_up) hipStreamWaitEvent(c->stream, r.ev_up, 0);
   }
-  /* write-after-write / write-after-read on the destination: waited for right before the first kernel that writes
-     it — the SAO stage when SAO runs (everything before writes this lane's working planes), else the first stage */
-  auto dst_hazards = [&]() {
-    if (dstf->dl_pending) hipStreamWaitEvent(c->stream, dstf->ev_dl, 0);     /* (stays pending for the HOST until m355_frame_download_wait / m355_wait) */
-    if (!piped) return;
-    if (dstf->wr_pending) hipStreamWaitEvent(c->stream, dstf->ev_wr, 0);
-    for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(c->stream, dstf->ev_rd[k], 0);
-  };
   hipStream_t st = c->stream;
-  if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
-  while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
-  hipEvent_t* ev = &c->evs[c->ev_used * 7];
-  if ((int)c->ev_fused.size() <= c->ev_used) c->ev_fused.resize(c->ev_used + 1);
-  c->ev_fused[c->ev_used] = d.res_map != nullptr;
-  c->ev_used++;
-  hipEventRecord(ev[0], st);
+  hipEvent_t* ev = nullptr;
+  if (with_intra) {                                        /* (a batch's decodes are not stage-timed: their intra stage is shared) */
+    if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
+    while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
+    ev = &c->evs[c->ev_used * 7];
+    if ((int)c->ev_fused.size() <= c->ev_used) c->ev_fused.resize(c->ev_used + 1);
+    c->ev_fused[c->ev_used] = d.res_map != nullptr;
+    c->ev_used++;
+    hipEventRecord(ev[0], st);
+  }
+  S.ev = ev;
   if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
-  if (!want_sao) dst_hazards();
+  if (!want_sao) dst_hazards(c, dstf, piped);
   if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, want_sao ? &c->work : dstf, r.device_validate && !want_sao, st);
-  launch_prediction(c, r, d, hbd, ev);
+  launch_prediction(c, r, d, hbd, ev, with_intra);
+  return M355_OK;
+}
+
+static int decode_post(m355_ctx* c, Resident& r, DecodeState& S)
+{
+  struct StreamRestore { m355_ctx* c; DecodeState& S; ~StreamRestore() { if (S.swapped) c->stream = S.saved_stream; } } restore{c, S};
+  const DevPic& d = S.d;
+  const bool want_sao = S.want_sao;
+  hipEvent_t* ev = S.ev;
+  const m355_pic_params& pp = r.hdr.pp;
+  const bool hbd = pp.bit_depth_luma > 8;
+  const bool piped = c->depth >= 2;
+  Frame* dstf = get_frame(c, r.hdr.dst_frame);
+  hipStream_t st = c->stream;
   if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
-  hipEventRecord(ev[5], st);
-  if (want_sao) { dst_hazards(); m355_launch_sao(d, hbd, st); }
-  hipEventRecord(ev[6], st);
+  if (ev) hipEventRecord(ev[5], st);
+  if (want_sao) { dst_hazards(c, dstf, piped); m355_launch_sao(d, hbd, st); }
+  if (ev) hipEventRecord(ev[6], st);
   if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
   hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
   dstf->wr_stream = st;
@@ -1668,7 +1708,7 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
       hipEventRecord(f->ev_rd[c->active], st); f->rd_pending[c->active] = true;
     }
   }
-  c->timed = true;
+  if (ev) c->timed = true;
   {
     /* this decode's status slot: completion event; a device-validated decode also brings its lane's gate words back (behind the
        events the dependent decodes wait on: nobody waits for this copy but m355_decode_status / m355_wait) */
@@ -1702,6 +1742,14 @@ static int decode(m355_ctx* c, Resident& r, bool rotate = true)
     }
   }
   return M355_OK;
+}
+
+static int decode(m355_ctx* c, Resident& r, bool rotate = true)
+{
+  DecodeState S;
+  int rc = decode_pre(c, r, rotate, S, true);
+  if (rc) { if (S.swapped) c->stream = S.saved_stream; return rc; }
+  return decode_post(c, r, S);
 }
 
 /* status of one finished decode from its ring slot: M355_OK, or M355_ERR_INVALID with the rejected record in the message */
@@ -2438,6 +2486,90 @@ int m355_decode_resident(m355_ctx* c, int h)
 {
   if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");
   return decode(c, c->resident[h]);
+}
+/* Several independent intra pictures as ONE intra stage: every picture's front part (validation, residuals, border plans) on its own
+ * lane, then one k_intra<BATCH> launch over all their CTB wavefronts, then every picture's filters on its lane again.  What more
+ * lanes buy an intra picture — other pictures' CTBs filling the GPU while its own wavefront is narrow — without one hardware queue per
+ * picture. */
+int m355_decode_batch(m355_ctx* c, const int* handles, int n)
+{
+  if (n < 1 || !handles) return fail(M355_ERR_INVALID, "m355_decode_batch: no pictures");
+  if (n > std::max(1, c->depth)) return fail(M355_ERR_INVALID, "m355_decode_batch: %d pictures on %d lanes (m355_set_pipeline_depth)", n, c->depth);
+  for (int k = 0; k < n; k++) {
+    const int h = handles[k];
+    if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");
+    for (int j = 0; j < k; j++) if (handles[j] == h) return fail(M355_ERR_INVALID, "m355_decode_batch: picture %d twice in one batch", h);
+    const Resident& r = c->resident[h];
+    const m355_pic_params &a = r.hdr.pp, &b = c->resident[handles[0]].hdr.pp;
+    if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
+    /* (pictures of a batch must not reference one another: their frames' writer events are recorded behind the shared launch) */
+    if (!r.dp.intra_dense || r.dp.n_pbs > 0) return fail(M355_ERR_INVALID, "m355_decode_batch: picture %d is not an intra picture", h);
+    if (a.chroma_format_idc != b.chroma_format_idc || (a.bit_depth_luma > 8) != (b.bit_depth_luma > 8))
+      return fail(M355_ERR_INVALID, "m355_decode_batch: the pictures differ in chroma format or sample type");
+    for (int j = 0; j < k; j++)
+      if (c->resident[handles[j]].hdr.dst_frame == r.hdr.dst_frame) return fail(M355_ERR_INVALID, "m355_decode_batch: two pictures into frame %d", r.hdr.dst_frame);
+  }
+  hipSetDevice(c->device);
+  if (n == 1 || !(c->stages & M355_STAGE_INTRA)) {
+    for (int k = 0; k < n; k++) { int rc = decode(c, c->resident[handles[k]]); if (rc) return rc; }
+    return M355_OK;
+  }
+  DecodeState S[M355_MAX_LANES];
+  int lane[M355_MAX_LANES];
+  int rc_late = M355_OK, n_ok = 0;
+  for (int k = 0; k < n; k++) {
+    Resident& r = c->resident[handles[k]];
+    const int rc = decode_pre(c, r, true, S[k], false);
+    if (rc) { rc_late = rc; break; }                 /* the pictures in front of it are finished as a shorter batch */
+    lane[k] = c->active;
+    if (!c->batch_ev_pre[k] && hipEventCreateWithFlags(&c->batch_ev_pre[k], hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+    hipEventRecord(c->batch_ev_pre[k], c->stream);
+    n_ok++;
+  }
+  if (!n_ok) return rc_late;
+  m355_ctx::BatchSlot& b = c->batch[c->batch_next];
+  c->batch_next = (c->batch_next + 1) % 4;
+  if (!b.dev) {
+    HIPCHK(hipHostMalloc((void**)&b.host, sizeof(DevPic) * M355_MAX_LANES, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&b.dev, sizeof(DevPic) * M355_MAX_LANES + 64));
+    b.ticket = (uint32_t*)((uint8_t*)b.dev + sizeof(DevPic) * M355_MAX_LANES);
+    HIPCHK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+  }
+  if (b.pending) { hipEventSynchronize(b.ev); b.pending = false; }     /* (four batches ago) */
+  select_lane(c, lane[0]);
+  /* M355_BATCH_STREAMS=0: the shared launch goes on the first picture's lane */
+  static const int own_streams = getenv("M355_BATCH_STREAMS") ? atoi(getenv("M355_BATCH_STREAMS")) : 0;
+  hipStream_t st0 = c->stream;
+  static const bool own_prio = !getenv("M355_BATCH_STREAM_PRIO") || atoi(getenv("M355_BATCH_STREAM_PRIO"));
+  if (own_streams > 0) {
+    const int j = own_streams >= 2 ? (int)(c->batch_count++ & 1) : 0;
+    if (!c->batch_stream[j]) HIPCHK(hipStreamCreateWithPriority(&c->batch_stream[j], hipStreamNonBlocking, own_prio ? lane_class_priority(3 * (j + 1)) : 0));
+    st0 = c->batch_stream[j];
+  }
+  const bool own = st0 != c->stream;
+  int max_work = 0; long total = 0;
+  for (int k = 0; k < n_ok; k++) {
+    b.host[k] = S[k].d;
+    max_work = std::max(max_work, S[k].d.n_intra_work); total += S[k].d.n_intra_work;
+    if (k || own) hipStreamWaitEvent(st0, c->batch_ev_pre[k], 0);
+  }
+  hipMemcpyAsync(b.dev, b.host, sizeof(DevPic) * n_ok, hipMemcpyHostToDevice, st0);
+  hipMemsetAsync(b.ticket, 0, 4, st0);
+  {
+    static const int grid_env = getenv("M355_INTRA_GRID") ? atoi(getenv("M355_INTRA_GRID")) : 0;
+    static int slots = 0;
+    if (!slots) { hipDeviceProp_t prop; slots = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512; }
+    const int grid = (int)std::min<long>(std::max<long>(total, 1), grid_env > 0 ? grid_env : slots);
+    m355_launch_intra_batch(S[0].d, c->resident[handles[0]].hdr.pp.bit_depth_luma > 8, b.dev, n_ok, max_work, b.ticket, grid, st0);
+  }
+  hipEventRecord(b.ev, st0); b.pending = true;
+  for (int k = 0; k < n_ok; k++) {
+    select_lane(c, lane[k]);
+    if (k || own) hipStreamWaitEvent(c->stream, b.ev, 0);
+    const int rc = decode_post(c, c->resident[handles[k]], S[k]);
+    if (rc && !rc_late) rc_late = rc;
+  }
+  return rc_late;
 }
 int m355_set_stages(m355_ctx* c, int mask) { c->stages = mask & M355_STAGE_ALL; return M355_OK; }
 
