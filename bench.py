@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="the timed region of --steps steps is run this many times back to back, each bracketed by a "
                     "synchronisation; ms_per_step / value are the MEDIAN region, ms_per_step_spread the min / max (default: 25 for <= 200 steps, else 5)")
     ap.add_argument("--workload", default="c5_8k10_8tiles")
-    ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1..16)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, help="pictures in flight per GPU in the timed region (1..32)")
     ap.add_argument("--intra-batch", type=int, default=0, help="intra workloads: the timed region's steps go out in groups of this many pictures with ONE intra stage "
                     "(m355_decode_batch; needs --pipeline-depth >= the group); a step is still one whole picture")
     ap.add_argument("--no-cpu-baseline", action="store_true")

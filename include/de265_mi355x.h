@@ -485,7 +485,7 @@ M355_API int m355_decode_batch(m355_ctx* ctx, const int* handles, int n);
 enum { M355_STAGE_INTER = 1, M355_STAGE_RESIDUAL = 2, M355_STAGE_INTRA = 4, M355_STAGE_DEBLOCK = 8,
        M355_STAGE_SAO = 16, M355_STAGE_ALL = 31 };
 M355_API int m355_set_stages(m355_ctx* ctx, int stage_mask);
-/* Pictures in flight (1..16): 1 (default) = one after the other on the context's stream; n = consecutive decodes go
+/* Pictures in flight (1..32): 1 (default) = one after the other on the context's stream; n = consecutive decodes go
  * round n lanes (own streams, working planes, scratch) and overlap wherever the frames they touch allow: a decode
  * waits for the last writer of each reference frame it reads and, right before its own first write, for the last writer
  * and the readers of its destination frame.  (The reference decodes independent pictures concurrently too: frame-parallel

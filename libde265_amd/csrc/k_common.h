@@ -187,6 +187,15 @@ void m355_launch_tiles_copy(const TileCopyArgs& a, int n, void* xbuf, bool to_sl
 
 enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };
 
+/* Batch launches (m355_decode_batch): one launch of a stage over SEVERAL pictures — a grid plane (blockIdx.z) per picture, the
+ * picture records in device memory, `on` = the pictures that run this stage.  Every such stage is a body function over
+ * `const DevPic&` with two kernels around it: k_x(DevPic) for one picture (record in the kernel arguments) and k_x_batch(DevBatch). */
+struct DevBatch { const DevPic* pics; uint32_t on; };
+#define M355_BATCH_PIC_AT(b, k) if (!(((b).on >> (k)) & 1u)) return; const DevPic& p = (b).pics[(k)]
+#define M355_BATCH_PIC(b) M355_BATCH_PIC_AT(b, blockIdx.z)
+/* what the host needs for a batched launch: the pictures' own records (grid sizes), their device copies, how many, who takes part */
+struct HostBatch { const DevPic* host; const DevPic* dev; int n; uint32_t on; };
+
 /* ---- launchers (each in its stage's .hip); all asynchronous on `st` ---- */
 void m355_launch_validate(const DevPic& p, hipStream_t st);   /* device-side validation of the work lists (k_meta.hip) */
 void m355_launch_meta(const DevPic& p, hipStream_t st);
@@ -197,6 +206,11 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_meta_planes_batch(const HostBatch& b, hipStream_t st);              /* the batch forms: pictures of one sample type and chroma format */
+void m355_launch_residual_batch(const HostBatch& b, bool hbd, bool big, hipStream_t st);
+void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st);
+void m355_launch_deblock_batch(const HostBatch& b, bool hbd, hipStream_t st);
+void m355_launch_sao_batch(const HostBatch& b, bool hbd, hipStream_t st);
 void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pics, int n, int max_work, uint32_t* ticket, int grid, hipStream_t st);   /* intra pictures of one geometry in ONE launch */
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st);   /* one direction (tile sharding) */

@@ -12,6 +12,7 @@
  * the luma segment plus (every second segment, 4:2:0) the two chroma segments.
  * Roofline: HBM-bound — picture read + write once per direction plus ~1.3 B of metadata per 4x4.
  */
+#include <algorithm>
 #include "k_common.h"
 
 __constant__ uint8_t c_tab_beta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,
@@ -91,7 +92,7 @@ template <class PIX> __device__ __forceinline__ void d_set(Raw4<PIX>& r, int s, 
 }
 
 template <class PIX, bool VERTICAL>
-__global__ void __launch_bounds__(256) k_deblock(DevPic p)
+__device__ __forceinline__ void k_deblock_body(const DevPic& p)
 {
   M355_GATE(p);
   /* thread -> edge unit on the 8x8 luma grid: vertical edges at even x4, horizontal at even y4 */
@@ -238,6 +239,24 @@ __global__ void __launch_bounds__(256) k_deblock(DevPic p)
       }
     }
   }
+}
+
+template <class PIX, bool VERTICAL> __global__ void __launch_bounds__(256) k_deblock(DevPic p) { k_deblock_body<PIX, VERTICAL>(p); }
+template <class PIX, bool VERTICAL> __global__ void __launch_bounds__(256) k_deblock_batch(DevBatch b) { M355_BATCH_PIC(b); k_deblock_body<PIX, VERTICAL>(p); }
+
+template <class PIX>
+static void launch_pass_batch(const HostBatch& b, bool vertical, hipStream_t st)
+{
+  int w4 = 0, h4 = 0;
+  for (int k = 0; k < b.n; k++) if ((b.on >> k) & 1u) { w4 = std::max(w4, b.host[k].w4); h4 = std::max(h4, b.host[k].h4); }
+  if (!w4) return;
+  const DevBatch d{b.dev, b.on};
+  if (vertical) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deblock_batch<PIX, true>), dim3(((w4 + 1) / 2 + 63) / 64, (h4 + 3) / 4, b.n), dim3(256), 0, st, d);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deblock_batch<PIX, false>), dim3((w4 + 63) / 64, ((h4 + 1) / 2 + 3) / 4, b.n), dim3(256), 0, st, d);
+}
+void m355_launch_deblock_batch(const HostBatch& b, bool hbd, hipStream_t st)
+{
+  for (int v = 1; v >= 0; v--) { if (hbd) launch_pass_batch<uint16_t>(b, v != 0, st); else launch_pass_batch<uint8_t>(b, v != 0, st); }
 }
 
 template <class PIX>

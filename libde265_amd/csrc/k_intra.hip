@@ -131,7 +131,7 @@ template <int CF> struct IntraGeo {
 #define PLAN_SPLIT 8   /* (4 -> 8: C2 waits 15 us less for its plans, profiles/r03_u_*) */
 #endif
 template <int CF>
-__global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
+__device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n)
 {
   M355_GATE(p);
   __shared__ uint16_t s_code[4][4 * 32 + 8];
@@ -238,6 +238,8 @@ __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n)
     wave_sync();                                             /* codes[] is reused by the wave's next block */
   }
 }
+template <int CF> __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n) { k_intra_plan_body<CF>(p, work_n); }
+template <int CF> __global__ void __launch_bounds__(256) k_intra_plan_batch(DevBatch b) { M355_BATCH_PIC(b); k_intra_plan_body<CF>(p, p.n_intra_work); }
 
 /* NW = waves per workgroup: 12 for intra pictures (CTBs with hundreds of blocks: up to 8 luma + 2 + 2 chroma waves share a
  * level, the CTB's residuals and its whole plan are fetched into LDS up front), 4 for inter pictures (a handful of intra
@@ -991,6 +993,21 @@ void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pi
     case 1: if (hbd) launch_intra_batch_cf<uint16_t, 1>(first, dev_pics, n, max_work, ticket, grid, st); else launch_intra_batch_cf<uint8_t, 1>(first, dev_pics, n, max_work, ticket, grid, st); break;
     case 2: if (hbd) launch_intra_batch_cf<uint16_t, 2>(first, dev_pics, n, max_work, ticket, grid, st); else launch_intra_batch_cf<uint8_t, 2>(first, dev_pics, n, max_work, ticket, grid, st); break;
     default: if (hbd) launch_intra_batch_cf<uint16_t, 3>(first, dev_pics, n, max_work, ticket, grid, st); else launch_intra_batch_cf<uint8_t, 3>(first, dev_pics, n, max_work, ticket, grid, st); break;
+  }
+}
+
+void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
+{
+  int work = 0, cf = 1;
+  for (int k = 0; k < b.n; k++) if ((b.on >> k) & 1u) { work = std::max(work, b.host[k].n_intra_work); cf = b.host[k].pp.chroma_format_idc; }
+  if (!work) return;
+  const DevBatch d{b.dev, b.on};
+  const dim3 grid(work, PLAN_SPLIT, b.n);
+  switch (cf) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan_batch<0>), grid, dim3(256), 0, st, d); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan_batch<1>), grid, dim3(256), 0, st, d); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan_batch<2>), grid, dim3(256), 0, st, d); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan_batch<3>), grid, dim3(256), 0, st, d); break;
   }
 }
 

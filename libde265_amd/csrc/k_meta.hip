@@ -9,7 +9,7 @@
 #include "k_common.h"
 
 /* one thread per CU: CU-index plane, per-CU edge decisions (deblock.cc:172-210), PB edges */
-__global__ void __launch_bounds__(256) k_meta_cu(DevPic p)
+__device__ __forceinline__ void k_meta_cu_body(const DevPic& p)
 {
   M355_GATE(p);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_meta_cu(DevPic p)
 }
 
 /* one thread per transform-tree leaf: transform edges + cbf_luma (deblock.cc:33-63, slice.cc:2958) */
-__global__ void __launch_bounds__(256) k_meta_tu(DevPic p)
+__device__ __forceinline__ void k_meta_tu_body(const DevPic& p)
 {
   M355_GATE(p);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
  * another tile with loop_filter_across_tiles off.  Reproduces the reference's quirk of looking up the
  * CTB's own slice address with COMPONENT coordinates used as luma coordinates (sao.cc:56), which is
  * why the centre CTB has a bit too.  k_sao then needs no dependent global loads per border sample. */
-__global__ void __launch_bounds__(256) k_meta_sao(DevPic p)
+__device__ __forceinline__ void k_meta_sao_body(const DevPic& p)
 {
   M355_GATE(p);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,6 +283,23 @@ void m355_launch_meta_jobs(const DevPic& p, hipStream_t st)
   hipLaunchKernelGGL(k_meta_pb, dim3(n_chunks), dim3(256), 0, st, p);
 }
 
+/* 16-byte units of edge_tu | edge_pb | cb_cu (prepare() in runtime.hip: cb_cu starts at the next multiple of 64, 64 spare bytes behind) */
+__host__ __device__ static inline size_t d_meta_fill16(const DevPic& p) { return ((((size_t)2 * p.w4 * p.h4 + 63) & ~(size_t)63) + (size_t)p.wcb * p.hcb * 4 + 15) / 16; }
+__global__ void __launch_bounds__(256) k_meta_cu(DevPic p) { k_meta_cu_body(p); }
+__global__ void __launch_bounds__(256) k_meta_tu(DevPic p) { k_meta_tu_body(p); }
+__global__ void __launch_bounds__(256) k_meta_sao(DevPic p) { k_meta_sao_body(p); }
+__global__ void __launch_bounds__(256) k_meta_cu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_cu_body(p); }
+__global__ void __launch_bounds__(256) k_meta_tu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_tu_body(p); }
+__global__ void __launch_bounds__(256) k_meta_sao_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_sao_body(p); }
+/* the zero fill in front of them (one plane of the grid per picture; the region is 16-byte aligned and padded, as below) */
+__global__ void __launch_bounds__(256) k_meta_fill_batch(DevBatch b)
+{
+  M355_BATCH_PIC(b);
+  const size_t n16 = d_meta_fill16(p);
+  uint4* q = (uint4*)p.edge_tu;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) q[i] = make_uint4(0, 0, 0, 0);
+}
+
 /* metadata planes for intra availability, deblocking and SAO (not read by k_inter / k_residual) */
 void m355_launch_meta_planes(const DevPic& p, hipStream_t st)
 {
@@ -292,6 +309,23 @@ void m355_launch_meta_planes(const DevPic& p, hipStream_t st)
   if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
   if (p.pp.flags & M355_PF_SAO_ENABLED) hipLaunchKernelGGL(k_meta_sao, dim3((p.nCtb * 3 + 255) / 256), dim3(256), 0, st, p);
+}
+
+void m355_launch_meta_planes_batch(const HostBatch& b, hipStream_t st)
+{
+  int n_cus = 0, n_tus = 0, n_sao = 0; size_t fill = 0; uint32_t sao_on = 0;
+  for (int k = 0; k < b.n; k++) {
+    if (!((b.on >> k) & 1u)) continue;
+    const DevPic& p = b.host[k];
+    n_cus = std::max(n_cus, p.n_cus); n_tus = std::max(n_tus, p.n_tus);
+    fill = std::max(fill, d_meta_fill16(p));
+    if (p.pp.flags & M355_PF_SAO_ENABLED) { sao_on |= 1u << k; n_sao = std::max(n_sao, p.nCtb * 3); }
+  }
+  const DevBatch d{b.dev, b.on};
+  if (fill) hipLaunchKernelGGL(k_meta_fill_batch, dim3((unsigned)std::min<size_t>((fill + 255) / 256, 1024), 1, b.n), dim3(256), 0, st, d);
+  if (n_cus) hipLaunchKernelGGL(k_meta_cu_batch, dim3((n_cus + 255) / 256, 1, b.n), dim3(256), 0, st, d);
+  if (n_tus) hipLaunchKernelGGL(k_meta_tu_batch, dim3((n_tus + 255) / 256, 1, b.n), dim3(256), 0, st, d);
+  if (n_sao) hipLaunchKernelGGL(k_meta_sao_batch, dim3((n_sao + 255) / 256, 1, b.n), dim3(256), 0, st, DevBatch{b.dev, sao_on});
 }
 
 /* zero fill that a rejected decode (k_validate) does not perform: planes are 128-byte-pitched allocations with a 256-byte tail */

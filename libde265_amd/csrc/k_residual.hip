@@ -22,6 +22,7 @@
  * Roofline: HBM-bound on paper (4 B per nonzero coefficient in, nT^2 samples read-modify-write); in
  * practice VALU/latency-bound on dense blocks, see DESIGN.md.
  */
+#include <algorithm>
 #include "k_common.h"
 
 __constant__ int8_t c_level_scale[6] = {40, 45, 51, 57, 64, 72};
@@ -335,10 +336,9 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
  * record, coefficient pairs, destination rows — so resident waves are what hides it.  Larger size first within each launch. */
 #define RES_LDS_DWORDS_SMALL (8 * RES_WPG * (4 * 8 + 8 * 5))   /* 8x8: 8 blocks per wave (4x4: 16 x 20 dwords fit too) */
 template <class PIX, bool BIG, bool FUSED>
-__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual(DevPic p, int ng_hi)
+__device__ __forceinline__ void k_residual_body(const DevPic& p, int ng_hi, uint32_t* s_buf)
 {
   M355_GATE(p);
-  __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
   const int g = blockIdx.x;
   if (BIG) {
     if (g < ng_hi) d_residual_group<5, PIX, FUSED>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
@@ -347,6 +347,39 @@ __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_
     if (g < ng_hi) d_residual_group<3, PIX, FUSED>(p, p.rb_bin[1], p.rb_count[1], g, s_buf);
     else d_residual_group<2, PIX, FUSED>(p, p.rb_bin[0], p.rb_count[0], g - ng_hi, s_buf);
   }
+}
+
+template <class PIX, bool BIG, bool FUSED>
+__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual(DevPic p, int ng_hi)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
+  k_residual_body<PIX, BIG, FUSED>(p, ng_hi, s_buf);
+}
+/* blocks per workgroup: RES_WPG waves * 64/nT */
+__host__ __device__ static inline int res_groups(int n, int per_wave) { return (n + per_wave * RES_WPG - 1) / (per_wave * RES_WPG); }
+/* batch form (intra pictures: never the fused order) */
+template <class PIX, bool BIG>
+__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_batch(DevBatch b)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
+  M355_BATCH_PIC(b);
+  k_residual_body<PIX, BIG, false>(p, BIG ? res_groups(p.rb_count[3], 2) : res_groups(p.rb_count[1], 8), s_buf);
+}
+
+template <class PIX, bool BIG>
+static void launch_res_batch(const HostBatch& b, hipStream_t st)
+{
+  int n = 0;
+  for (int k = 0; k < b.n; k++) if ((b.on >> k) & 1u) {
+    const DevPic& p = b.host[k];
+    n = std::max(n, BIG ? res_groups(p.rb_count[3], 2) + res_groups(p.rb_count[2], 4) : res_groups(p.rb_count[1], 8) + res_groups(p.rb_count[0], 16));
+  }
+  if (n) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_batch<PIX, BIG>), dim3(n, 1, b.n), dim3(64 * RES_WPG), 0, st, DevBatch{b.dev, b.on});
+}
+void m355_launch_residual_batch(const HostBatch& b, bool hbd, bool big, hipStream_t st)
+{
+  if (big) { if (hbd) launch_res_batch<uint16_t, true>(b, st); else launch_res_batch<uint8_t, true>(b, st); }
+  else { if (hbd) launch_res_batch<uint16_t, false>(b, st); else launch_res_batch<uint8_t, false>(b, st); }
 }
 
 template <class PIX, bool BIG>
@@ -359,8 +392,7 @@ static void launch_res(const DevPic& p, int n, int ng_hi, hipStream_t st)
 
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)
 {
-  /* blocks per workgroup: RES_WPG waves * 64/nT */
-  auto groups = [](int n, int per_wave) { return (n + per_wave * RES_WPG - 1) / (per_wave * RES_WPG); };
+  auto groups = res_groups;
   const int ng2 = groups(p.rb_count[0], 16), ng3 = groups(p.rb_count[1], 8), ng4 = groups(p.rb_count[2], 4), ng5 = groups(p.rb_count[3], 2);
   if (big && ng5 + ng4) {
     if (hbd) launch_res<uint16_t, true>(p, ng5 + ng4, ng5, st);

@@ -13,6 +13,7 @@
  * border neighbours suppress the edge offset.
  * Roofline: HBM-bound, 2*S*B bytes per CTB + 28 B of parameters.
  */
+#include <algorithm>
 #include "k_common.h"
 
 template <class PIX> struct Vec4;
@@ -97,7 +98,7 @@ __device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint3
 }
 
 template <class PIX, bool PACKED>
-__global__ void __launch_bounds__(256) k_sao(DevPic p)
+__device__ __forceinline__ void k_sao_body(const DevPic& p, const int c)
 {
   M355_GATE(p);
   /* one thread = a 4x4 sample block (always inside one CTB: component CTB sizes are >= 8 and planes are
@@ -107,7 +108,6 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
      above/below come from the lanes 16 up/down and the columns left/right from the neighbouring lanes
      (cross-lane shuffles) — memory is touched again only on the wave tile's rim. */
   typedef typename Vec4<PIX>::T V4;
-  const int c = blockIdx.z;
   const int lane = threadIdx.x & 63, lx = lane & 15, ly = lane >> 4;
   const int width = p.pw[c], height = p.ph[c];
   const int xt = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 64, yt = (int)blockIdx.y * 16;
@@ -353,6 +353,32 @@ __global__ void __launch_bounds__(256) k_sao(DevPic p)
     if (sizeof(PIX) == 2) d_st_nt8(q, (uint32_t)res[j][0] | ((uint32_t)res[j][1] << 16), (uint32_t)res[j][2] | ((uint32_t)res[j][3] << 16));
     else d_st_nt4(q, (uint32_t)res[j][0] | ((uint32_t)res[j][1] << 8) | ((uint32_t)res[j][2] << 16) | ((uint32_t)res[j][3] << 24));
   }
+}
+
+template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p) { k_sao_body<PIX, PACKED>(p, (int)blockIdx.z); }
+/* batch form: grid.z = 3 * picture + component */
+template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao_batch(DevBatch b)
+{
+  const int k = (int)blockIdx.z / 3, c = (int)blockIdx.z - 3 * k;
+  M355_BATCH_PIC_AT(b, k);
+  if (c && !p.pp.chroma_format_idc) return;
+  k_sao_body<PIX, PACKED>(p, c);
+}
+
+void m355_launch_sao_batch(const HostBatch& b, bool hbd, hipStream_t st)
+{
+  int w = 0, h = 0; bool packed = true;
+  for (int k = 0; k < b.n; k++) if ((b.on >> k) & 1u) {
+    const DevPic& p = b.host[k];
+    w = std::max(w, p.pw[0]); h = std::max(h, p.ph[0]);
+    if (p.pp.bit_depth_luma > 15 || p.pp.bit_depth_chroma > 15) packed = false;
+  }
+  if (!w) return;
+  const DevBatch d{b.dev, b.on};
+  const dim3 grid((w + 255) / 256, (h + 15) / 16, 3 * b.n), block(256);
+  if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao_batch<uint8_t, true>), grid, block, 0, st, d);
+  else if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao_batch<uint16_t, true>), grid, block, 0, st, d);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao_batch<uint16_t, false>), grid, block, 0, st, d);
 }
 
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st)

@@ -46,7 +46,8 @@ static int fail(int code, const char* fmt, ...)
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(M355_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
 #define M355_STATUS_RING 64
-#define M355_MAX_LANES 16  /* pictures in flight per context (m355_set_pipeline_depth) */
+#define M355_BATCH_RING 16 /* m355_decode_batch: picture-record arrays in flight (the host runs this many batches ahead) */
+#define M355_MAX_LANES 32  /* pictures in flight per context (m355_set_pipeline_depth) */
 
 struct Frame {
   bool used = false;
@@ -211,9 +212,9 @@ struct m355_ctx {
   /* m355_decode_batch: ring of picture-record arrays (pinned staging + device copy + the batch's ticket word); a slot's event is
      recorded behind the batch's k_intra — what the pictures' filter stages wait for, and what guards the slot's reuse */
   struct BatchSlot { DevPic* host = nullptr; DevPic* dev = nullptr; uint32_t* ticket = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
-  BatchSlot batch[4];
+  BatchSlot batch[M355_BATCH_RING];
   int batch_next = 0;
-  hipStream_t batch_stream[2] = {nullptr, nullptr};   /* consecutive batches' k_intra launches alternate between two streams of priority
+  hipStream_t batch_stream[4] = {nullptr, nullptr, nullptr, nullptr};   /* consecutive batches' k_intra launches alternate between two streams of priority
                                                          classes of their own (own hardware queues): the tail of one batch's wavefronts
                                                          overlaps the head of the next batch's when they run on different lanes */
   unsigned batch_count = 0;
@@ -1632,16 +1633,20 @@ static void dst_hazards(m355_ctx* c, Frame* dstf, bool piped)
  * ONE k_intra launch for all of them, then their post parts. */
 struct DecodeState { DevPic d; bool want_sao = false; hipEvent_t* ev = nullptr; hipStream_t saved_stream = nullptr; bool swapped = false; };
 
-static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, bool with_intra)
+/* front: PRE_ALL = everything up to and including the intra stage; PRE_NO_INTRA = without k_intra; PRE_HAZARDS = lane, hazards, validation and
+   clearing only (m355_decode_batch launches the stages itself, one launch per stage for all its pictures) */
+enum { PRE_ALL = 0, PRE_NO_INTRA = 1, PRE_HAZARDS = 2 };
+static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int mode, hipStream_t on_stream = nullptr)
 {
+  const bool with_intra = mode == PRE_ALL;
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
   if (rotate && c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);   /* consecutive pictures go round the lanes */
   /* which stream: an intra picture on lane 3.. takes the lane's class stream (lane_class_priority); the whole decode addresses
      c->stream, which is that stream until decode_post returns (a batch keeps to the lanes' ordinary streams: its pictures overlap
      inside one kernel, not through hardware queues) */
   {
-    hipStream_t run = c->stream;
-    if (with_intra && r.dp.intra_dense && c->active >= 3 && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
+    hipStream_t run = on_stream ? on_stream : c->stream;   /* (a batch on a stream of its own: its lanes lend their scratch only) */
+    if (!on_stream && with_intra && r.dp.intra_dense && c->active >= 3 && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
       if (!c->stream_hi) HIPCHK(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, lane_class_priority(c->active)));
       run = c->stream_hi;
     }
@@ -1676,11 +1681,11 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, boo
   if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
   if (!want_sao) dst_hazards(c, dstf, piped);
   if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, want_sao ? &c->work : dstf, r.device_validate && !want_sao, st);
-  launch_prediction(c, r, d, hbd, ev, with_intra);
+  if (mode != PRE_HAZARDS) launch_prediction(c, r, d, hbd, ev, with_intra);
   return M355_OK;
 }
 
-static int decode_post(m355_ctx* c, Resident& r, DecodeState& S)
+static int decode_post(m355_ctx* c, Resident& r, DecodeState& S, bool filters = true)
 {
   struct StreamRestore { m355_ctx* c; DecodeState& S; ~StreamRestore() { if (S.swapped) c->stream = S.saved_stream; } } restore{c, S};
   const DevPic& d = S.d;
@@ -1691,9 +1696,9 @@ static int decode_post(m355_ctx* c, Resident& r, DecodeState& S)
   const bool piped = c->depth >= 2;
   Frame* dstf = get_frame(c, r.hdr.dst_frame);
   hipStream_t st = c->stream;
-  if ((c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
+  if (filters && (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
   if (ev) hipEventRecord(ev[5], st);
-  if (want_sao) { dst_hazards(c, dstf, piped); m355_launch_sao(d, hbd, st); }
+  if (filters && want_sao) { dst_hazards(c, dstf, piped); m355_launch_sao(d, hbd, st); }
   if (ev) hipEventRecord(ev[6], st);
   if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
   hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
@@ -1747,7 +1752,7 @@ static int decode_post(m355_ctx* c, Resident& r, DecodeState& S)
 static int decode(m355_ctx* c, Resident& r, bool rotate = true)
 {
   DecodeState S;
-  int rc = decode_pre(c, r, rotate, S, true);
+  int rc = decode_pre(c, r, rotate, S, PRE_ALL);
   if (rc) { if (S.swapped) c->stream = S.saved_stream; return rc; }
   return decode_post(c, r, S);
 }
@@ -2517,56 +2522,96 @@ int m355_decode_batch(m355_ctx* c, const int* handles, int n)
   DecodeState S[M355_MAX_LANES];
   int lane[M355_MAX_LANES];
   int rc_late = M355_OK, n_ok = 0;
+  /* Where the batch runs.  M355_BATCH_STREAMS=N (default 4): whole batches go round N streams of their own — front parts, the shared
+     launch and the filters of ONE batch are one stream's worth of work (they depend on one another anyway), consecutive batches on
+     different lanes overlap on different hardware queues; the lanes lend their scratch and working planes.  =0: every picture's front
+     part and filters on its own lane's stream, the shared launch on the first lane's (measured slower: 16 lanes' small kernels
+     serialise on the runtime's four hardware queues AND with the batch, profiles/r04_n_c2_batch.txt). */
+  static const int streams_env = getenv("M355_BATCH_STREAMS") ? std::min(4, std::max(0, atoi(getenv("M355_BATCH_STREAMS")))) : -1;
+  /* as many streams as batches of this size fit the lanes side by side (batches that share lanes run one after the other anyway) */
+  const int n_streams = streams_env >= 0 ? streams_env : std::min(4, std::max(1, c->depth / n));
+  hipStream_t bs = nullptr;
+  if (n_streams > 0) {
+    const int j = (int)(c->batch_count++ % (unsigned)n_streams);
+    if (!c->batch_stream[j]) HIPCHK(hipStreamCreateWithFlags(&c->batch_stream[j], hipStreamNonBlocking));
+    bs = c->batch_stream[j];
+  }
   for (int k = 0; k < n; k++) {
     Resident& r = c->resident[handles[k]];
-    const int rc = decode_pre(c, r, true, S[k], false);
+    const int rc = decode_pre(c, r, true, S[k], bs ? PRE_HAZARDS : PRE_NO_INTRA, bs);
+    if (S[k].swapped) { c->stream = S[k].saved_stream; S[k].swapped = false; }   /* (select_lane parks c->stream with the lane) */
     if (rc) { rc_late = rc; break; }                 /* the pictures in front of it are finished as a shorter batch */
     lane[k] = c->active;
-    if (!c->batch_ev_pre[k] && hipEventCreateWithFlags(&c->batch_ev_pre[k], hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-    hipEventRecord(c->batch_ev_pre[k], c->stream);
+    if (!bs) {
+      if (!c->batch_ev_pre[k] && hipEventCreateWithFlags(&c->batch_ev_pre[k], hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+      hipEventRecord(c->batch_ev_pre[k], c->stream);
+    }
     n_ok++;
   }
   if (!n_ok) return rc_late;
   m355_ctx::BatchSlot& b = c->batch[c->batch_next];
-  c->batch_next = (c->batch_next + 1) % 4;
+  c->batch_next = (c->batch_next + 1) % M355_BATCH_RING;
   if (!b.dev) {
     HIPCHK(hipHostMalloc((void**)&b.host, sizeof(DevPic) * M355_MAX_LANES, hipHostMallocDefault));
     HIPCHK(hipMalloc((void**)&b.dev, sizeof(DevPic) * M355_MAX_LANES + 64));
     b.ticket = (uint32_t*)((uint8_t*)b.dev + sizeof(DevPic) * M355_MAX_LANES);
     HIPCHK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
   }
-  if (b.pending) { hipEventSynchronize(b.ev); b.pending = false; }     /* (four batches ago) */
+  if (b.pending) { hipEventSynchronize(b.ev); b.pending = false; }     /* (M355_BATCH_RING batches ago) */
   select_lane(c, lane[0]);
-  /* M355_BATCH_STREAMS=0: the shared launch goes on the first picture's lane */
-  static const int own_streams = getenv("M355_BATCH_STREAMS") ? atoi(getenv("M355_BATCH_STREAMS")) : 0;
-  hipStream_t st0 = c->stream;
-  static const bool own_prio = !getenv("M355_BATCH_STREAM_PRIO") || atoi(getenv("M355_BATCH_STREAM_PRIO"));
-  if (own_streams > 0) {
-    const int j = own_streams >= 2 ? (int)(c->batch_count++ & 1) : 0;
-    if (!c->batch_stream[j]) HIPCHK(hipStreamCreateWithPriority(&c->batch_stream[j], hipStreamNonBlocking, own_prio ? lane_class_priority(3 * (j + 1)) : 0));
-    st0 = c->batch_stream[j];
-  }
-  const bool own = st0 != c->stream;
+  hipStream_t st0 = bs ? bs : c->stream;
   int max_work = 0; long total = 0;
   for (int k = 0; k < n_ok; k++) {
     b.host[k] = S[k].d;
     max_work = std::max(max_work, S[k].d.n_intra_work); total += S[k].d.n_intra_work;
-    if (k || own) hipStreamWaitEvent(st0, c->batch_ev_pre[k], 0);
+    if (k && !bs) hipStreamWaitEvent(st0, c->batch_ev_pre[k], 0);
   }
   hipMemcpyAsync(b.dev, b.host, sizeof(DevPic) * n_ok, hipMemcpyHostToDevice, st0);
   hipMemsetAsync(b.ticket, 0, 4, st0);
+  const bool hbd = c->resident[handles[0]].hdr.pp.bit_depth_luma > 8;
+  const HostBatch hb{b.host, b.dev, n_ok, n_ok >= 32 ? 0xFFFFFFFFu : (1u << n_ok) - 1u};
+  if (bs) {
+    /* the stages in front of the intra stage, each ONE launch over the batch's pictures (launch_prediction's order for an intra
+       picture: metadata planes, border plans, 8x8 + 4x4 residuals, 32x32 + 16x16 residuals) */
+    m355_launch_meta_planes_batch(hb, st0);
+    if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan_batch(hb, st0);
+    if (c->stages & M355_STAGE_RESIDUAL) { m355_launch_residual_batch(hb, hbd, false, st0); m355_launch_residual_batch(hb, hbd, true, st0); }
+  }
   {
     static const int grid_env = getenv("M355_INTRA_GRID") ? atoi(getenv("M355_INTRA_GRID")) : 0;
     static int slots = 0;
     if (!slots) { hipDeviceProp_t prop; slots = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512; }
-    const int grid = (int)std::min<long>(std::max<long>(total, 1), grid_env > 0 ? grid_env : slots);
-    m355_launch_intra_batch(S[0].d, c->resident[handles[0]].hdr.pp.bit_depth_luma > 8, b.dev, n_ok, max_work, b.ticket, grid, st0);
+    /* persistent workgroups of the shared launch: a batch on its own takes every slot of the GPU (4 pictures, 64 -> 512 workgroups:
+       0.573 -> 0.484 ms per picture); batches side by side take what covers their pictures' widest wavefronts (CTB (x, y) runs at
+       step x + 2y: 16 for 1080p) or half their share of the slots — more only spin and crowd the other batches' kernels (32 pictures
+       as 4 x 8, 512 -> 128 workgroups each: 0.161 -> 0.126; 16 as 4 x 4, 128 -> 64: 0.181 -> 0.160; profiles/r04_n_c2_batch.txt) */
+    int widest = 0;
+    for (int k = 0; k < n_ok; k++) widest += std::min(S[k].d.ctbH, (S[k].d.ctbW + 1) / 2) + 1;
+    const int grid = (int)std::min<long>(std::max<long>(total, 1), grid_env > 0 ? grid_env : std::min(slots, n_streams <= 1 ? slots : std::max(widest, slots / (2 * n_streams))));
+    m355_launch_intra_batch(S[0].d, hbd, b.dev, n_ok, max_work, b.ticket, grid, st0);
   }
   hipEventRecord(b.ev, st0); b.pending = true;
+  if (bs) {
+    /* the in-loop filters of the whole batch: two deblocking launches, one SAO launch (its pictures' destination hazards in front) */
+    uint32_t dbk = 0, sao = 0;
+    for (int k = 0; k < n_ok; k++) {
+      if ((c->stages & M355_STAGE_DEBLOCK) && (c->resident[handles[k]].hdr.pp.flags & M355_PF_DEBLOCK_ENABLED)) dbk |= 1u << k;
+      if (S[k].want_sao) sao |= 1u << k;
+    }
+    if (dbk) m355_launch_deblock_batch(HostBatch{b.host, b.dev, n_ok, dbk}, hbd, st0);
+    if (sao) {
+      hipStream_t keep = c->stream;
+      c->stream = bs;
+      for (int k = 0; k < n_ok; k++) if ((sao >> k) & 1u) dst_hazards(c, get_frame(c, c->resident[handles[k]].hdr.dst_frame), c->depth >= 2);
+      c->stream = keep;
+      m355_launch_sao_batch(HostBatch{b.host, b.dev, n_ok, sao}, hbd, st0);
+    }
+  }
   for (int k = 0; k < n_ok; k++) {
     select_lane(c, lane[k]);
-    if (k || own) hipStreamWaitEvent(c->stream, b.ev, 0);
-    const int rc = decode_post(c, c->resident[handles[k]], S[k]);
+    if (bs) { S[k].saved_stream = c->stream; c->stream = bs; S[k].swapped = true; }      /* (decode_post puts the lane's stream back) */
+    else if (k) hipStreamWaitEvent(c->stream, b.ev, 0);
+    const int rc = decode_post(c, c->resident[handles[k]], S[k], !bs);
     if (rc && !rc_late) rc_late = rc;
   }
   return rc_late;
