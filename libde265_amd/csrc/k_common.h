@@ -24,7 +24,28 @@ struct DevRef {            /* one reference frame (indexed by m355_pb.ref_slot) 
   int stride[3];
   int valid;
   int pad;
+#ifdef M355_X_TILED
+  /* EXPERIMENT (tools/variants.sh -DM355_X_TILED): a second copy of the frame in tiles of 32 x 8 samples, every tile row followed by
+     an apron of the next columns (a window row never straddles a tile: the kernel's two vector loads per row stay two), read by
+     k_inter_jobs' FAST path only.  tile = 8 rows of M355_TILE_ROW(plane) samples; trs = samples per row of tiles. */
+  const void* tiled[3];
+  int trs[3];
+  int pad2;
+#endif
 };
+#ifdef M355_X_TILED
+#ifndef M355_TILE_LW
+#define M355_TILE_LW 5       /* log2 tile width (samples) */
+#endif
+#ifndef M355_TILE_LH
+#define M355_TILE_LH 3       /* log2 tile height (rows) */
+#endif
+#define M355_TILE_W (1 << M355_TILE_LW)
+#define M355_TILE_H (1 << M355_TILE_LH)
+#define M355_TILE_ROW_L (M355_TILE_W + 16)   /* luma: + 16 (8-bit rows are fetched as 16 bytes from the dword below the window, 16-bit as 12 samples) */
+#define M355_TILE_ROW_C (M355_TILE_W + 8)    /* chroma: + 8 */
+void m355_launch_tile_convert(const void* src, int stride, int pw, int ph, int bpp, bool chroma, void* dst, int tiles_w, hipStream_t st);
+#endif
 
 /* k_intra's work item: everything a workgroup needs to know about its CTB in ONE 32-byte record (one scalar load behind the
  * ticket instead of a chain of dependent lookups: work list -> CTB record -> neighbours' slices / tiles / scan positions) */

@@ -325,13 +325,25 @@ __device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int 
 /* luma 4x8 block of one list -> packed 14-bit predictions (int16 pairs), fallback-motion.cc:492-636.
  * (xi,yi) = integer position of the block's top-left sample in the reference plane. */
 template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rstride, int pw, int ph, int xi, int yi, int xf, int yf, int bd,
+__device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rstride,
+#ifdef M355_X_TILED
+                                              const M355_GLOBAL PIX* tp, int trs,
+#endif
+                                              int pw, int ph, int xi, int yi, int xf, int yf, int bd,
                                               const unsigned* qt, unsigned pred[8][2])
 {
   const unsigned* tx = qt + xf * QT_STRIDE;
   const unsigned* ty = qt + yf * QT_STRIDE;
   const int shift1 = bd - 8, shift3 = max(2, 14 - bd);
   const int xa = xi - 3;
+#ifdef M355_X_TILED
+  /* the tile column of the window's first loaded sample is the same for all 15 rows: fold it into the base */
+  const int txl = (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3)) >> M355_TILE_LW;
+  const M355_GLOBAL PIX* tpl = tp + txl * (M355_TILE_H * M355_TILE_ROW_L - M355_TILE_W);
+#define LROW(yc) (FAST ? tpl + __mul24((yc) >> M355_TILE_LH, trs) + ((yc) & (M355_TILE_H - 1)) * M355_TILE_ROW_L : rp + __mul24((yc), rstride))
+#else
+#define LROW(yc) (rp + __mul24((yc), rstride))
+#endif
   const unsigned xmask = xf == 0 ? ~0u : 0u, ymask = yf == 0 ? ~0u : 0u, xymask = xmask & ymask;
   unsigned Q[8][4];
   {
@@ -348,18 +360,18 @@ __device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rst
     unsigned S[2][2][6];
 #pragma unroll
     for (int i = 0; i < 6; i++) S[1][1][i] = 0;
-    d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi - 3), rstride), xa, pw, S[0][0]);
-    d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi - 2), rstride), xa, pw, S[0][1]);
+    d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi - 3)), xa, pw, S[0][0]);
+    d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi - 2)), xa, pw, S[0][1]);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       if (FAST) {
         if (k < 7) {
-          d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k - 1), rstride), xa, pw, S[(k + 1) & 1][0]);
-          if (k < 6) d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k), rstride), xa, pw, S[(k + 1) & 1][1]);
+          d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k - 1)), xa, pw, S[(k + 1) & 1][0]);
+          if (k < 6) d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k)), xa, pw, S[(k + 1) & 1][1]);
         }
       } else if (k > 0) {   /* edge jobs: 24 clamped sample loads per pair, no prefetch (register pressure) */
-        d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k - 3), rstride), xa, pw, S[k & 1][0]);
-        if (k < 7) d_load12<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + 2 * k - 2), rstride), xa, pw, S[k & 1][1]);
+        d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k - 3)), xa, pw, S[k & 1][0]);
+        if (k < 7) d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k - 2)), xa, pw, S[k & 1][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       /* both rows of the pair, then one v_perm per column packs the (row 2k, row 2k+1) int16 pair —
@@ -418,15 +430,27 @@ __device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rst
   }
 }
 
+#undef LROW
 /* chroma 2x4 block of one list and plane, fallback-motion.cc:305-415 / 262-302 */
 template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int rstride, int pw, int ph, int xi, int yi, int xf, int yf, int bd,
+__device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int rstride,
+#ifdef M355_X_TILED
+                                                const M355_GLOBAL PIX* tp, int trs,
+#endif
+                                                int pw, int ph, int xi, int yi, int xf, int yf, int bd,
                                                 const unsigned* et, unsigned pred[4])
 {
   const unsigned* tx = et + xf * ET_STRIDE;
   const unsigned* ty = et + yf * ET_STRIDE;
   const int shift1 = bd - 8, shift3 = max(2, 14 - bd);
   const int xa = xi - 1;
+#ifdef M355_X_TILED
+  const int txc = (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3)) >> M355_TILE_LW;
+  const M355_GLOBAL PIX* tpc = tp + txc * (M355_TILE_H * M355_TILE_ROW_C - M355_TILE_W);
+#define CROW(yc) (FAST ? tpc + __mul24((yc) >> M355_TILE_LH, trs) + ((yc) & (M355_TILE_H - 1)) * M355_TILE_ROW_C : rp + __mul24((yc), rstride))
+#else
+#define CROW(yc) (rp + __mul24((yc), rstride))
+#endif
   const unsigned xmask = xf == 0 ? ~0u : 0u, ymask = yf == 0 ? ~0u : 0u, xymask = xmask & ymask;
   unsigned Q[4][2];
   {
@@ -440,13 +464,13 @@ __device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int r
     unsigned S[7][3];
     if (FAST) {   /* all seven rows in flight at once; the edge path loads row by row (register pressure) */
 #pragma unroll
-      for (int r = 0; r < 7; r++) d_load6<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + r - 1), rstride), xa, pw, S[r]);
+      for (int r = 0; r < 7; r++) d_load6<PIX, FAST>(CROW(d_clip3(0, ph - 1, yi + r - 1)), xa, pw, S[r]);
     }
     int h[8][2];
 #pragma unroll
     for (int r = 0; r < 7; r++) {
       if (!FAST) {
-        d_load6<PIX, FAST>(rp + __mul24(d_clip3(0, ph - 1, yi + r - 1), rstride), xa, pw, S[r]);
+        d_load6<PIX, FAST>(CROW(d_clip3(0, ph - 1, yi + r - 1)), xa, pw, S[r]);
         __builtin_amdgcn_sched_barrier(0);
       }
       const unsigned B0 = S[r][0] ^ bias, B1 = S[r][1] ^ bias, B2 = S[r][2] ^ bias;
@@ -496,6 +520,7 @@ __device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
   return d_clip_bd(((__mul24(a, s.w0) + __mul24(b, s.w1) + s.rnd) >> s.sh) + s.o, bd);
 }
 
+#undef CROW
 /* One job.  FAST: the PB's reference windows lie inside the picture horizontally (k_meta_pb sorts the
  * others into the EDGE job range, handled with clamped per-sample loads). */
 template <class PIX, bool BIAS, bool FAST>
@@ -672,7 +697,11 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
       } else {
         const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
         const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-        d_mc_luma_4x8<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], pw, ph, x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, bd, s_qt, cur);
+        d_mc_luma_4x8<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0],
+#ifdef M355_X_TILED
+                                       (const M355_GLOBAL PIX*)ref->tiled[0], ref->trs[0],
+#endif
+                                       pw, ph, x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, bd, s_qt, cur);
       }
       if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
 #pragma unroll
@@ -739,8 +768,16 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
       } else {
         const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
         const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur1);
-        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur2);
+        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1],
+#ifdef M355_X_TILED
+                                         (const M355_GLOBAL PIX*)ref->tiled[1], ref->trs[1],
+#endif
+                                         pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur1);
+        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2],
+#ifdef M355_X_TILED
+                                         (const M355_GLOBAL PIX*)ref->tiled[2], ref->trs[2],
+#endif
+                                         pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur2);
       }
       if (pass + 1 < npass) {
 #pragma unroll
@@ -818,3 +855,27 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
   if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_generic<uint16_t>), grid, block, 0, st, p);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_generic<uint8_t>), grid, block, 0, st, p);
 }
+
+#ifdef M355_X_TILED
+/* EXPERIMENT: linear plane -> tiled copy with aprons (k_common.h DevRef).  One thread per sample pair of the tiled copy; columns
+   beyond the picture repeat its last sample (never used with a non-zero tap). */
+template <class PIX>
+__global__ void __launch_bounds__(256) k_tile_convert(const PIX* __restrict__ src, int stride, int pw, int ph, int row_len, PIX* __restrict__ dst, int tiles_w)
+{
+  const int per_row = tiles_w * row_len;                       /* samples of one picture row in the tiled copy */
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
+  if (i >= per_row || y >= ph) return;
+  const int tx = i / row_len, e = i - tx * row_len;
+  const PIX* r = src + (size_t)y * stride;
+  PIX* o = dst + ((size_t)((y >> M355_TILE_LH) * tiles_w + tx) * M355_TILE_H + (y & (M355_TILE_H - 1))) * row_len + e;
+  o[0] = r[min(tx * M355_TILE_W + e, pw - 1)];
+  o[1] = r[min(tx * M355_TILE_W + e + 1, pw - 1)];
+}
+void m355_launch_tile_convert(const void* src, int stride, int pw, int ph, int bpp, bool chroma, void* dst, int tiles_w, hipStream_t st)
+{
+  const int row_len = chroma ? M355_TILE_ROW_C : M355_TILE_ROW_L;
+  const dim3 grid((tiles_w * row_len / 2 + 255) / 256, ph);
+  if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_convert<uint16_t>), grid, dim3(256), 0, st, (const uint16_t*)src, stride, pw, ph, row_len, (uint16_t*)dst, tiles_w);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_convert<uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)src, stride, pw, ph, row_len, (uint8_t*)dst, tiles_w);
+}
+#endif

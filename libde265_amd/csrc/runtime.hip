@@ -61,6 +61,12 @@ struct Frame {
   hipEvent_t ev_dl = nullptr;
   bool dl_pending = false;
   hipStream_t wr_stream = nullptr;         /* the stream that last wrote the frame (its downloads are queued on that stream) */
+#ifdef M355_X_TILED
+  void* tiled[3] = {nullptr, nullptr, nullptr};   /* EXPERIMENT: tiled copy read by k_inter_jobs (k_common.h DevRef) */
+  int tiles_w[3] = {0, 0, 0};
+  bool tiled_valid = false;
+  hipEvent_t ev_tiled = nullptr;
+#endif
 };
 
 static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
@@ -94,6 +100,11 @@ static int frame_alloc(Frame& f, hipStream_t st)
 static void frame_free(Frame& f)
 {
   for (int c = 0; c < 3; c++) { if (f.plane[c]) hipFree(f.plane[c]); f.plane[c] = nullptr; }
+#ifdef M355_X_TILED
+  for (int c = 0; c < 3; c++) { if (f.tiled[c]) hipFree(f.tiled[c]); f.tiled[c] = nullptr; }
+  if (f.ev_tiled) hipEventDestroy(f.ev_tiled);
+  f.ev_tiled = nullptr; f.tiled_valid = false;
+#endif
   if (f.ev_wr) hipEventDestroy(f.ev_wr);
   for (int k = 0; k < M355_MAX_LANES; k++) { if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]); f.ev_rd[k] = nullptr; f.rd_pending[k] = false; }
   f.ev_wr = nullptr; f.wr_pending = false;
@@ -532,6 +543,9 @@ int m355_frame_upload(m355_ctx* c, int h, int cidx, const void* src, ptrdiff_t s
   if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
+#ifdef M355_X_TILED
+  f->tiled_valid = false;
+#endif
   HIPCHK(hipMemcpy2D(f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx], src, (size_t)stride * f->bpp[cidx],
                      (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyHostToDevice));
   return M355_OK;
@@ -601,6 +615,9 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
   if (!f) return fail(M355_ERR_INVALID, "bad frame handle %d", h);
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
+#ifdef M355_X_TILED
+  f->tiled_valid = false;
+#endif
   for (int cc = 0; cc < 3; cc++) {
     if (!f->pw[cc]) continue;
     const size_t n = (size_t)f->stride[cc] * f->ph[cc];
@@ -1424,6 +1441,19 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
       return fail(M355_ERR_INVALID, "reference frame %d geometry differs (motion.cc:377-398 would conceal; record FILL instead)", i);
     if (f == dst) return fail(M355_ERR_INVALID, "a picture cannot reference itself");
     for (int cc = 0; cc < 3; cc++) { refs[i].plane[cc] = f->plane[cc]; refs[i].stride[cc] = f->stride[cc]; }
+#ifdef M355_X_TILED
+    for (int cc = 0; cc < 3; cc++) {
+      if (!f->pw[cc]) continue;
+      const int row_len = cc ? M355_TILE_ROW_C : M355_TILE_ROW_L;
+      if (!f->tiled[cc]) {
+        f->tiles_w[cc] = (f->pw[cc] + M355_TILE_W - 1) / M355_TILE_W;
+        const size_t bytes = (size_t)((f->ph[cc] + M355_TILE_H - 1) / M355_TILE_H) * f->tiles_w[cc] * M355_TILE_H * row_len * f->bpp[cc] + 256;
+        HIPCHK(hipMalloc(&f->tiled[cc], bytes));
+        f->tiled_valid = false;
+      }
+      refs[i].tiled[cc] = f->tiled[cc]; refs[i].trs[cc] = f->tiles_w[cc] * M355_TILE_H * row_len;
+    }
+#endif
     refs[i].valid = 1;
     d.ref_valid |= 1u << i;
   }
@@ -1605,6 +1635,19 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
       if (f && f->wr_pending) hipStreamWaitEvent(st, f->ev_wr, 0);
     }
   if (fused && !single) hipStreamWaitEvent(st, c->ev_fork2, 0);   /* the 8x8 + 4x4 tiles */
+#ifdef M355_X_TILED
+  if ((c->stages & M355_STAGE_INTER) && d.n_pbs)
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+      if (!f || !f->tiled[0]) continue;
+      if (!f->tiled_valid) {                 /* the conversion pass (its time is the experiment's cost side: k_tile_convert in the kernel trace) */
+        for (int cc = 0; cc < 3; cc++) if (f->pw[cc]) m355_launch_tile_convert(f->plane[cc], f->stride[cc], f->pw[cc], f->ph[cc], f->bpp[cc], cc != 0, f->tiled[cc], f->tiles_w[cc], st);
+        if (!f->ev_tiled) hipEventCreateWithFlags(&f->ev_tiled, hipEventDisableTiming);
+        hipEventRecord(f->ev_tiled, st);
+        f->tiled_valid = true;
+      } else if (f->ev_tiled) hipStreamWaitEvent(st, f->ev_tiled, 0);
+    }
+#endif
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   if (ev) hipEventRecord(ev[fused ? 3 : 2], st);
   if (!fused && (c->stages & M355_STAGE_RESIDUAL)) {
@@ -1702,6 +1745,9 @@ static int decode_post(m355_ctx* c, Resident& r, DecodeState& S, bool filters = 
   if (ev) hipEventRecord(ev[6], st);
   if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
   hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
+#ifdef M355_X_TILED
+  dstf->tiled_valid = false;
+#endif
   dstf->wr_stream = st;
   if (piped) {
     if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
