@@ -1,5 +1,9 @@
 """CPU tier of m355_decode_batch (k_intra<BATCH> through the SIMT-interpreter build): several intra pictures in one launch give the
 oracle's planes of each picture; ragged batches, batches back to back on recycled lanes, and what the call refuses."""
+import os
+import subprocess
+import sys
+
 import pytest
 
 from oracle_py import Oracle
@@ -34,3 +38,14 @@ def test_ragged_batch_and_prediction_only(emu_lib, oracle):  # noqa: F811
 
 def test_batch_refusals(emu_lib, oracle):  # noqa: F811
     check_rejections(emu_lib, Oracle(oracle), dict(width=128, height=64, bit_depth=8, seed=621))
+
+
+@pytest.mark.parametrize("streams", ["0", "2"])
+def test_batch_stream_modes(emu_lib, oracle, streams):  # noqa: F811
+    """M355_BATCH_STREAMS=0 (every picture's own stages on its lane, only k_intra shared) and a fixed number of batch streams: the
+    setting is read once per process, so each runs in a process of its own"""
+    from test_emu_picture import EMU_SO
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "batch_worker.py"), EMU_SO, oracle._name], env=dict(os.environ, M355_BATCH_STREAMS=streams),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

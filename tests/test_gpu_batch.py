@@ -1,5 +1,9 @@
 """m355_decode_batch on the GPU: several independent intra pictures through ONE k_intra launch (k_intra<BATCH>) are, picture by
 picture, the oracle's decode; batches back to back without host synchronisation on recycled lanes; ragged batches; refusals."""
+import os
+import subprocess
+import sys
+
 import pytest
 
 from oracle_py import Oracle
@@ -51,3 +55,13 @@ def test_batches_and_single_decodes_interleaved(oracle):
 
 def test_batch_refusals(oracle):
     check_rejections(capi.Library(), Oracle(oracle), dict(width=416, height=240, bit_depth=8, seed=731))
+
+
+@pytest.mark.parametrize("streams", ["0", "1", "4"])
+def test_batch_stream_modes(oracle, streams):
+    """M355_BATCH_STREAMS (read once per process): 0 = the pictures' own stages on their lanes' streams, k_intra shared; 1 / 4 = whole
+    batches on that many streams of their own"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "batch_worker.py"), "default", oracle._name], env=dict(os.environ, M355_BATCH_STREAMS=streams),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
