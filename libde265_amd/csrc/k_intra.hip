@@ -274,6 +274,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint32_t s_cover[3][MAXCTB / 4];    /* per component and row of 4x4 units, which units an intra block of this CTB writes */
   __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
   __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
+#ifdef M355_X_INTRA_LDS_PAD      /* experiment (tools/variants.sh): what does a workgroup less per CU cost the sparse kernel? */
+  __shared__ uint32_t s_pad[DENSE ? 1 : M355_X_INTRA_LDS_PAD / 4];
+  if (threadIdx.x == 0 && work_n < 0) s_pad[work_n & 1] = 1;
+#endif
 
   /* everything derived from the wave index or from a block record is wave-uniform: say so (readfirstlane / readlane), so that
      the component's plane pointers, pitches and granule offsets are scalar loads from the kernel arguments instead of vector
