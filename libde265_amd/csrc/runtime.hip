@@ -2652,6 +2652,7 @@ int m355_decode_batch(m355_ctx* c, const int* handles, int n)
       c->stream = keep;
       m355_launch_sao_batch(HostBatch{b.host, b.dev, n_ok, sao}, hbd, st0);
     }
+    hipEventRecord(b.ev, st0);     /* the filter launches read the slot's records too: the slot is free behind THEM */
   }
   for (int k = 0; k < n_ok; k++) {
     select_lane(c, lane[k]);
