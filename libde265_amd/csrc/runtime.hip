@@ -216,6 +216,7 @@ struct m355_ctx {
   m355_comm comm = {nullptr, nullptr, nullptr};   /* exchanges of m355_decode_sharded */
   void* rccl = nullptr;              /* built-in RCCL communicator (m355_shard_rccl_init) */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
+  std::vector<hipStream_t> pad_streams;   /* (M355_X_STREAM_PAD) */
   std::vector<uint8_t> ev_fused;   /* per timed decode: the residual stage ran first (launch_prediction) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
@@ -272,6 +273,11 @@ static int lane_priorities_mode()                            /* 0 off, 1 every s
 static int lane_priority(int index) { return lane_priorities_mode() == 1 ? lane_class_priority(index) : 0; }
 static int lane_create(m355_ctx* c, Lane& l, int index)
 {
+  /* M355_X_STREAM_PAD=n (experiment): n idle streams in front of every second lane's streams — shifts which hardware queue the
+     runtime gives the lanes' main streams (created main, side, main, side ... they land on every other queue) */
+  static const int pad = getenv("M355_X_STREAM_PAD") ? atoi(getenv("M355_X_STREAM_PAD")) : 0;
+  if (pad > 0 && index >= 2 && (index & 1) == 0)
+    for (int k = 0; k < pad; k++) { hipStream_t dummy; if (hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking) == hipSuccess) c->pad_streams.push_back(dummy); }
   HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, lane_priority(index)));
   HIPCHK(hipStreamCreateWithPriority(&l.stream2, hipStreamNonBlocking, lane_priority(index)));
   HIPCHK(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
@@ -465,6 +471,7 @@ void m355_destroy(m355_ctx* c)
   for (auto& b : c->batch) { if (b.host) hipHostFree(b.host); if (b.dev) hipFree(b.dev); if (b.ev) hipEventDestroy(b.ev); }
   for (hipEvent_t e : c->batch_ev_pre) if (e) hipEventDestroy(e);
   for (hipStream_t bs : c->batch_stream) if (bs) hipStreamDestroy(bs);
+  for (hipStream_t ps : c->pad_streams) hipStreamDestroy(ps);
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& st_ : c->status) if (st_.ev) hipEventDestroy(st_.ev);
   if (c->status_words) hipHostFree(c->status_words);
@@ -1609,7 +1616,10 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
      many such pictures are in flight — with M355_LANE_PRIORITIES=1 nine lanes are nine queues: C2 0.340 ms per picture = 1.50 M
      CTB64/s at depth 9 (profiles/r03_v_*; forked: 0.59 at depth 8) */
   static const bool single_env = !(getenv("M355_DENSE_SINGLE_STREAM") && atoi(getenv("M355_DENSE_SINGLE_STREAM")) == 0);
-  const bool single = single_env && d.intra_dense;
+  /* M355_SINGLE_STREAM=1 (experiment): every picture on its lane's main stream only — a lane is then ONE stream for the runtime's
+     hardware queues */
+  static const bool single_all = getenv("M355_SINGLE_STREAM") && atoi(getenv("M355_SINGLE_STREAM"));
+  const bool single = (single_env && d.intra_dense) || single_all;
   const bool fused = d.res_map != nullptr;   /* prepare(): the residuals of inter CUs are added in k_inter_jobs' write-back */
   hipStream_t s2 = single ? st : c->stream2;
   if (fused) hipMemsetAsync(d.res_map, 0, (size_t)d.res_map_words * 4, st);
