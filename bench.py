@@ -208,12 +208,12 @@ def main():
 
     # (4) PCIe-inclusive: the lists are written into the library's pinned arena (m355_arena_begin; libm355synth copies them
     # there with 16 threads, standing in for the parser's recorder threads), then validated, scheduled, copied to the device
-    # and decoded, every step.  "submit_only": the same with the lists already lying in the arenas (three rotate).
+    # and decoded, every step.  "submit_only": the same with the lists already lying in the arenas (depth + 3 rotate).
     with_upload = None
     if not args.no_with_upload and rank == 0:
         ctx.set_pipeline_depth(args.pipeline_depth)
         st = {}
-        for _ in range(4):                   # the three rotating arenas are allocated on first use
+        for _ in range(args.pipeline_depth + 4):   # the rotating arenas (pipeline depth + 3) are allocated on first use
             ctx.submit_in_place(pic, state=st)
         ctx.wait()
         up_steps = max(side_steps, 100)      # (a host-side rate: 20 steps are 20 ms of wall clock, too few to be stable)

@@ -228,7 +228,7 @@ class Context:
         """The in-place path: m355_arena_begin (capacities = the picture's counts x slack) -> the lists are written into the
         pinned arena by libm355synth's m355_synth_fill_arena (standing in for recorder threads) -> m355_submit_picture on
         those pointers (no host copy inside the library).  refill=False re-submits what the arena still holds from an
-        earlier call with the same capacities (the three arenas rotate): the library's own share of the work alone.
+        earlier call with the same capacities (pipeline depth + 3 arenas rotate, at most 12): the library's own share of the work alone.
         `state` caches the marshalled source picture between calls."""
         from . import synth
         state = state if state is not None else {}
@@ -249,7 +249,7 @@ class Context:
         rc = self.L.lib.m355_arena_begin(self.h, state["a_caps"], state["a_dst"])
         if rc:
             self.L.check(rc)
-        if refill or not state.get("filled", 0) >= 3:
+        if refill or not state.get("filled", 0) >= 12:      # (every arena of the ring holds the lists)
             lib.m355_synth_fill_arena(state["a_src"], state["a_caps"], state["a_dst"], fill_threads)
             state["filled"] = state.get("filled", 0) + 1
         else:

@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint3
 }
 
 template <class PIX, bool PACKED>
-__device__ __forceinline__ void k_sao_body(const DevPic& p, const int c)
+__device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const int bx, const int by)
 {
   M355_GATE(p);
   /* one thread = a 4x4 sample block (always inside one CTB: component CTB sizes are >= 8 and planes are
@@ -110,7 +110,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c)
   typedef typename Vec4<PIX>::T V4;
   const int lane = threadIdx.x & 63, lx = lane & 15, ly = lane >> 4;
   const int width = p.pw[c], height = p.ph[c];
-  const int xt = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 64, yt = (int)blockIdx.y * 16;
+  const int xt = (bx * 4 + (int)(threadIdx.x >> 6)) * 64, yt = by * 16;
   if (yt >= height || xt >= width) return;        /* wave-uniform (chroma planes are smaller than the grid) */
   const int x0 = xt + lx * 4, y0 = yt + ly * 4;
   const bool valid = x0 < width && y0 < height;
@@ -355,14 +355,33 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c)
   }
 }
 
-template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p) { k_sao_body<PIX, PACKED>(p, (int)blockIdx.z); }
+#ifdef M355_X_SAO_XCD
+/* EXPERIMENT (tools/variants.sh saoxcd "-DM355_X_SAO_XCD=2"): a 1-D grid whose blocks are dealt to the XCDs in runs of M355_X_SAO_XCD whole
+   block ROWS (block b runs on XCD b % 8): the 256-sample blocks of a row — and the rows of a run — then share one L2, so a row's rim lines
+   (the 128-byte line left and right of every block: 6 lines touched for 4 used) are fetched from the fabric once instead of once per
+   neighbour, while the eight XCDs still stream 8 x M355_X_SAO_XCD neighbouring rows of the picture at a time (a band of rows per XCD was
+   25 % slower: profiles/r02_b_inter_variants.txt).  Rows = luma rows, then the Cb rows, then the Cr rows (chroma rows are narrower: their
+   surplus blocks leave at once). */
+template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p, int gx, int gy0, int gy1)
+{
+  constexpr int RP = M355_X_SAO_XCD;
+  const int b = (int)blockIdx.x, xcd = b & 7, i = b >> 3;
+  const int x = i % gx, rr = i / gx;                       /* rr-th row this XCD takes */
+  const int R = (rr / RP) * (8 * RP) + xcd * RP + rr % RP;
+  if (R >= gy0 + 2 * gy1) return;
+  const int c = R < gy0 ? 0 : (R < gy0 + gy1 ? 1 : 2), y = R - (c == 0 ? 0 : (c == 1 ? gy0 : gy0 + gy1));
+  k_sao_body<PIX, PACKED>(p, c, x, y);
+}
+#else
+template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p) { k_sao_body<PIX, PACKED>(p, (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y); }
+#endif
 /* batch form: grid.z = 3 * picture + component */
 template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao_batch(DevBatch b)
 {
   const int k = (int)blockIdx.z / 3, c = (int)blockIdx.z - 3 * k;
   M355_BATCH_PIC_AT(b, k);
   if (c && !p.pp.chroma_format_idc) return;
-  k_sao_body<PIX, PACKED>(p, c);
+  k_sao_body<PIX, PACKED>(p, c, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 void m355_launch_sao_batch(const HostBatch& b, bool hbd, hipStream_t st)
@@ -385,8 +404,17 @@ void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st)
 {
   /* one launch for all components: grid.z = component; chroma blocks beyond the chroma plane exit at once */
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
+#ifdef M355_X_SAO_XCD
+  const int gx = (p.pw[0] + 255) / 256, gy0 = (p.ph[0] + 15) / 16, gy1 = nc == 3 ? (p.ph[1] + 15) / 16 : 0;
+  const int rows = gy0 + 2 * gy1, rows_pad = (rows + 8 * M355_X_SAO_XCD - 1) / (8 * M355_X_SAO_XCD) * (8 * M355_X_SAO_XCD);
+  const dim3 grid((unsigned)(gx * rows_pad)), block(256);
+  if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p, gx, gy0, gy1);
+  else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p, gx, gy0, gy1);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p, gx, gy0, gy1);
+#else
   const dim3 grid((p.pw[0] + 255) / 256, (p.ph[0] + 15) / 16, nc), block(256);   /* 4 waves side by side: 256 x 16 samples */
   if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p);
   else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p);
+#endif
 }

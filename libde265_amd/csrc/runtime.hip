@@ -48,6 +48,7 @@ static int fail(int code, const char* fmt, ...)
 #define M355_STATUS_RING 64
 #define M355_BATCH_RING 16 /* m355_decode_batch: picture-record arrays in flight (the host runs this many batches ahead) */
 #define M355_MAX_LANES 32  /* pictures in flight per context (m355_set_pipeline_depth) */
+#define M355_TRANSIENT_MAX 12 /* staging arenas of m355_submit_picture (m355_ctx::transient_ring) */
 
 struct Frame {
   bool used = false;
@@ -147,6 +148,7 @@ struct Resident {
   size_t xscratch_pitch = 0;       /* m355_decode_sharded / m355_group_decode: bytes between the peers' slots of xscratch */
   std::vector<uint8_t> sched_u8;   /* upload(): per-CTB scratch of the intra schedule */
   std::vector<uint32_t> sched_u32;
+  std::vector<uint32_t> sched_order, sched_cand, sched_bucket, sched_u32b;   /* ... and of the work list (order, counting-sort buckets, plan bases) */
 };
 
 /* Everything ONE picture in flight writes: streams, working planes, metadata / job / residual scratch.  The context's
@@ -187,8 +189,19 @@ struct m355_ctx {
   int dl_ev_next = 0;
   std::vector<Frame> frames;
   std::vector<Resident> resident;
-  Resident transient[3];       /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes */
+  /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes.  A slot is free again when
+     the decode of the lists it held has FINISHED, and with `depth` pictures in flight a picture finishes about (host phases + list
+     copy + depth decode times) after its m355_arena_begin: three slots made the ring, not PCIe or the GPU, the bound of a
+     submit-every-picture decoder (C5: 2.1 ms of latency / 3 = 0.7 ms per picture against 0.57 ms of list copy).  The ring in use is
+     depth + 3 slots (M355_TRANSIENT_RING=<n> overrides, 2..M355_TRANSIENT_MAX); slots allocate on first use. */
+  Resident transient[M355_TRANSIENT_MAX];
   int next_transient = 0;
+  int transient_ring() const
+  {
+    static const int env = getenv("M355_TRANSIENT_RING") ? atoi(getenv("M355_TRANSIENT_RING")) : 0;
+    const int n = env > 0 ? env : depth + 3;
+    return n < 2 ? 2 : (n > M355_TRANSIENT_MAX ? M355_TRANSIENT_MAX : n);
+  }
   Frame work;                  /* pre-SAO working planes */
   /* scratch */
   uint32_t *pb_of = nullptr, *ticket = nullptr, *timeout = nullptr;
@@ -724,6 +737,11 @@ struct HostPool {
   const std::function<void(int)>* job = nullptr;
   int n_parts = 0, next = 0, pending = 0;
   unsigned long long gen = 0;
+  /* a submit runs its phases back to back (validation's checks, the intra schedule, the work list): a worker that has just finished
+     a part polls this copy of `gen` for a few tens of microseconds before it blocks — the next phase then starts without a futex
+     wake-up per worker (about what a short phase itself takes); an idle process still sleeps */
+  std::atomic<unsigned long long> gen_hint{0};
+  std::atomic<int> pending_hint{0};
   bool stop = false;
   explicit HostPool(int workers)
   {
@@ -735,11 +753,24 @@ struct HostPool {
     cv_go.notify_all();
     for (auto& t : th) t.join();
   }
+  static void cpu_relax()
+  {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+  }
   void work()
   {
     unsigned long long seen = 0;
+    bool warm = false;                                   /* finished a part a moment ago */
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
+      if (warm && !stop && !(gen != seen && next < n_parts)) {
+        lk.unlock();
+        for (int spin = 0; spin < 4000 && gen_hint.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
+        lk.lock();
+      }
+      warm = false;
       cv_go.wait(lk, [&]() { return stop || (gen != seen && next < n_parts); });
       if (stop) return;
       while (next < n_parts) {
@@ -748,7 +779,9 @@ struct HostPool {
         lk.unlock();
         (*f)(part);
         lk.lock();
-        if (--pending == 0) cv_done.notify_all();
+        warm = true;
+        pending_hint.store(--pending, std::memory_order_release);
+        if (pending == 0) cv_done.notify_all();
       }
       seen = gen;
     }
@@ -757,13 +790,20 @@ struct HostPool {
   {
     std::unique_lock<std::mutex> lk(mu);
     job = &f; n_parts = parts; next = 0; pending = parts; gen++;
+    pending_hint.store(parts, std::memory_order_relaxed);
+    gen_hint.store(gen, std::memory_order_release);
     cv_go.notify_all();
     while (next < n_parts) {
       const int part = next++;
       lk.unlock();
       f(part);
       lk.lock();
-      --pending;
+      pending_hint.store(--pending, std::memory_order_release);
+    }
+    if (pending) {                                       /* the last parts are about to finish on the workers: poll before sleeping */
+      lk.unlock();
+      for (int spin = 0; spin < 4000 && pending_hint.load(std::memory_order_acquire) != 0; spin++) cpu_relax();
+      lk.lock();
     }
     cv_done.wait(lk, [&]() { return pending == 0; });
     job = nullptr; n_parts = 0;
@@ -1004,7 +1044,8 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
   std::atomic<int> overlap(-1);
   /* (an intra picture has hundreds of blocks per CTB: smaller shares, so that a 1080p picture's 510 CTBs still use the whole pool) */
   parallel_ranges((size_t)pic->n_ctbs, (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs ? 16 : 256, [&](size_t cb, size_t ce) {
-    std::vector<std::pair<uint32_t, uint32_t>> key;      /* (level << 2 | cidx, index) */
+    std::vector<std::pair<uint32_t, uint32_t>> key, sorted;      /* (level << 2 | cidx, index) */
+    uint32_t hist[4 * 128 + 1];                          /* stable counting sort of a CTB's keys (no allocation per CTB) */
     long long my_blocks = 0, my_ctbs = 0;
     for (size_t c = cb; c < ce; c++) {
       const m355_ctb& ctb = pic->ctbs[c];
@@ -1012,7 +1053,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
       if (!ctb.ib_count) continue;
       my_ctbs++; my_blocks += ctb.ib_count;
       const int cx = (int)c % ctbW, cy = (int)c / ctbW;
-      int16_t grid[3][16][16];
+      int8_t grid[3][16][16];                            /* level of the block covering each 4x4 unit (a chain in a CTB is < 64 long) */
       memset(grid, 0xFF, sizeof(grid));                  /* -1: no intra block of this CTB there (yet) */
       key.clear();
       bool clash = false;
@@ -1046,12 +1087,22 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
             if (uy - 1 >= 0 && ux + t >= 0 && ux + t < 16) level = std::max(level, grid[ib.cidx][uy - 1][ux + t] + 1);
           }
         }
+        level = std::min(level, 126);                    /* (only overlapping blocks — rejected below — could get there) */
         for (int y = uy; y < uy + n4 && y < 16; y++)
-          for (int x = ux; x < ux + n4 && x < 16; x++) { if (grid[ib.cidx][y][x] >= 0) clash = true; grid[ib.cidx][y][x] = (int16_t)level; }
+          for (int x = ux; x < ux + n4 && x < 16; x++) { if (grid[ib.cidx][y][x] >= 0) clash = true; grid[ib.cidx][y][x] = (int8_t)level; }
         key.push_back(std::make_pair(((uint32_t)level << 2) | ib.cidx, k));
       }
       if (clash) { int e = -1; overlap.compare_exchange_strong(e, (int)c); }
-      std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+      {
+        uint32_t kmax = 0;
+        for (const auto& e : key) kmax = std::max(kmax, e.first);
+        for (uint32_t i = 0; i <= kmax + 1; i++) hist[i] = 0;
+        for (const auto& e : key) hist[e.first + 1]++;
+        for (uint32_t i = 1; i <= kmax; i++) hist[i] += hist[i - 1];
+        sorted.resize(key.size());
+        for (const auto& e : key) sorted[hist[e.first]++] = e;
+        key.swap(sorted);
+      }
       uint32_t widest = 1, run = 0, rel = 0;
       for (uint32_t k = 0; k < ctb.ib_count; k++) {
         const m355_ib& ib = pic->ibs[ctb.ib_start + key[k].second];
@@ -1307,50 +1358,72 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   uint32_t n_iplan = 0;                                     /* border-plan entries of the picture (k_intra_plan) */
   {
     const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
-    std::vector<std::pair<uint32_t, uint32_t>> freec;     /* (block count, raster address) */
-    for (int t = 0; t < nCtb; t++)
-      if (pic->ctbs[ts2rs[t]].ib_count && !(dep[ts2rs[t]] & 15)) freec.push_back(std::make_pair(pic->ctbs[ts2rs[t]].ib_count, ts2rs[t]));
-    std::stable_sort(freec.begin(), freec.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
-    /* a work item = the CTB's descriptor: block range, wave count code, and the 3x3 neighbourhood facts every availability
-       test of intrapred.h:486-508 / :534-633 needs (picture, slice, tile, decode order across CTBs) */
-    auto item = [&](uint32_t rs) {
-      DevIntraWork w;
-      memset(&w, 0, sizeof(w));
-      w.ctb = rs; w.ib_start = pic->ctbs[rs].ib_start; w.ib_count = pic->ctbs[rs].ib_count;
-      w.waves_code = (uint8_t)(log2_waves[rs] & 3);
-      w.plan_base = n_iplan; w.plan_count = plan_count[rs];
-      n_iplan += (plan_count[rs] + 7u) & ~7u;
-      const int cx = (int)rs % ctbW, cy = (int)rs / ctbW;
-      const uint32_t my_sa = pic->slices[pic->ctbs[rs].slice_idx].slice_addr_rs;
-      for (int k = 0; k < 9; k++) {
-        const int nx = cx + k % 3 - 1, ny = cy + k / 3 - 1;
-        if (nx < 0 || ny < 0 || nx >= ctbW || ny >= ctbH) continue;
-        const int n = ny * ctbW + nx;
-        if (pic->slices[pic->ctbs[n].slice_idx].slice_addr_rs == my_sa && tile_id[n] == tile_id[rs]) w.nb_same |= (uint16_t)(1u << k);
-        if (ctb_ts[n] < ctb_ts[rs]) w.nb_earlier |= (uint16_t)(1u << k);
-      }
-      iw[nw++] = w;
-    };
-    for (const auto& e : freec) item(e.second);
-    n_free = nw;
-    /* the dependent CTBs in WAVEFRONT order of their tile (x + 2y, the time at which the CTB's neighbours L / TL / T / TR — all
-       of smaller x + 2y — can have delivered): workgroups are dispatched in this order, so with more CTBs than the GPU holds
-       at once (large pictures, several pictures in flight) the resident ones are those that can run, not the rest of a CTB row
-       whose turn comes much later; any order in which a CTB follows its four neighbours keeps the ticket protocol deadlock-free */
-    std::vector<std::pair<uint32_t, uint32_t>> depc;      /* (x + 2y inside the tile, decode position) */
+    /* the order first — two stable COUNTING sorts over the CTBs in decode order (keys are small: blocks per CTB, x + 2y inside a
+       tile), a comparison sort of the 8K picture's 2800 intra CTBs cost more than everything else here —, then the items, in parallel */
+    std::vector<uint32_t>& order = r.sched_order;          /* raster address of work item k */
+    std::vector<uint32_t>& cand = r.sched_cand;            /* the CTBs with intra blocks in decode order: raster address, blocks | free << 31 */
+    cand.clear();
+    uint32_t max_cnt = 0;
+    size_t n_dep = 0;
+    for (int t = 0; t < nCtb; t++) {
+      const uint32_t rs = ts2rs[t], cnt = pic->ctbs[rs].ib_count;
+      if (!cnt) continue;
+      const bool free_ctb = !(dep[rs] & 15);
+      cand.push_back(rs); cand.push_back(cnt | (free_ctb ? 0x80000000u : 0u));
+      if (free_ctb) max_cnt = std::max(max_cnt, cnt); else n_dep++;
+    }
+    const size_t n_cand = cand.size() / 2;
+    n_free = (int)(n_cand - n_dep);
+    order.resize(n_cand);
+    std::vector<uint32_t>& bucket = r.sched_bucket;
     {
+      /* free CTBs, LONGEST first (bucket = max - count), decode order inside a bucket */
+      bucket.assign((size_t)max_cnt + 2, 0);
+      for (size_t i = 0; i < n_cand; i++) if (cand[2 * i + 1] >> 31) bucket[(size_t)(max_cnt - (cand[2 * i + 1] & 0x7FFFFFFFu)) + 1]++;
+      for (size_t i = 1; i < bucket.size(); i++) bucket[i] += bucket[i - 1];
+      for (size_t i = 0; i < n_cand; i++) if (cand[2 * i + 1] >> 31) order[bucket[max_cnt - (cand[2 * i + 1] & 0x7FFFFFFFu)]++] = cand[2 * i];
+    }
+    if (n_dep) {
+      /* the dependent CTBs in WAVEFRONT order of their tile (x + 2y, the time at which the CTB's neighbours L / TL / T / TR — all
+         of smaller x + 2y — can have delivered): workgroups are dispatched in this order, so with more CTBs than the GPU holds
+         at once (large pictures, several pictures in flight) the resident ones are those that can run, not the rest of a CTB row
+         whose turn comes much later; any order in which a CTB follows its four neighbours keeps the ticket protocol deadlock-free */
       std::vector<int> tx0((size_t)pp.num_tile_cols * pp.num_tile_rows), ty0(tx0.size());
       for (int ty = 0, t = 0; ty < pp.num_tile_rows; ty++)
         for (int tx = 0; tx < pp.num_tile_cols; tx++, t++) { tx0[t] = pp.col_bd[tx]; ty0[t] = pp.row_bd[ty]; }
-      for (int t = 0; t < nCtb; t++) {
-        const uint32_t rs = ts2rs[t];
-        if (!pic->ctbs[rs].ib_count || !(dep[rs] & 15)) continue;
-        const int cx = (int)rs % ctbW, cy = (int)rs / ctbW, ti = tile_id[rs];
-        depc.push_back(std::make_pair((uint32_t)((cx - tx0[ti]) + 2 * (cy - ty0[ti])), (uint32_t)t));
-      }
+      auto wkey = [&](uint32_t rs) { const int cx = (int)rs % ctbW, cy = (int)rs / ctbW, ti = tile_id[rs]; return (uint32_t)((cx - tx0[ti]) + 2 * (cy - ty0[ti])); };
+      bucket.assign((size_t)ctbW + 2 * (size_t)ctbH + 2, 0);
+      for (size_t i = 0; i < n_cand; i++) if (!(cand[2 * i + 1] >> 31)) bucket[(size_t)wkey(cand[2 * i]) + 1]++;
+      for (size_t i = 1; i < bucket.size(); i++) bucket[i] += bucket[i - 1];
+      for (size_t i = 0; i < n_cand; i++) if (!(cand[2 * i + 1] >> 31)) order[(size_t)n_free + bucket[wkey(cand[2 * i])]++] = cand[2 * i];
     }
-    std::stable_sort(depc.begin(), depc.end());
-    for (const auto& e : depc) item(ts2rs[e.second]);
+    nw = (int)order.size();
+    /* where each item's border plans start (a running sum in work order) */
+    std::vector<uint32_t>& pbase = r.sched_u32b;
+    pbase.resize((size_t)nw + 1);
+    for (int k = 0; k < nw; k++) { pbase[(size_t)k] = n_iplan; n_iplan += (plan_count[order[(size_t)k]] + 7u) & ~7u; }
+    /* a work item = the CTB's descriptor: block range, wave count code, and the 3x3 neighbourhood facts every availability
+       test of intrapred.h:486-508 / :534-633 needs (picture, slice, tile, decode order across CTBs) */
+    parallel_ranges((size_t)nw, 512, [&](size_t kb, size_t ke) {
+      for (size_t k = kb; k < ke; k++) {
+        const uint32_t rs = order[k];
+        DevIntraWork w;
+        memset(&w, 0, sizeof(w));
+        w.ctb = rs; w.ib_start = pic->ctbs[rs].ib_start; w.ib_count = pic->ctbs[rs].ib_count;
+        w.waves_code = (uint8_t)(log2_waves[rs] & 3);
+        w.plan_base = pbase[k]; w.plan_count = plan_count[rs];
+        const int cx = (int)rs % ctbW, cy = (int)rs / ctbW;
+        const uint32_t my_sa = pic->slices[pic->ctbs[rs].slice_idx].slice_addr_rs;
+        for (int q = 0; q < 9; q++) {
+          const int nx = cx + q % 3 - 1, ny = cy + q / 3 - 1;
+          if (nx < 0 || ny < 0 || nx >= ctbW || ny >= ctbH) continue;
+          const int n = ny * ctbW + nx;
+          if (pic->slices[pic->ctbs[n].slice_idx].slice_addr_rs == my_sa && tile_id[n] == tile_id[rs]) w.nb_same |= (uint16_t)(1u << q);
+          if (ctb_ts[n] < ctb_ts[rs]) w.nb_earlier |= (uint16_t)(1u << q);
+        }
+        iw[k] = w;
+      }
+    });
   }
   seg[i_iw].bytes = sizeof(DevIntraWork) * (size_t)(nw ? nw : 1);
   r.n_intra_work = nw; r.n_iplan = n_iplan;
@@ -2461,7 +2534,7 @@ int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)
 int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
 {
   Resident& t = c->transient[c->next_transient];
-  c->next_transient = (c->next_transient + 1) % 3;
+  c->next_transient = (c->next_transient + 1) % c->transient_ring();
   /* the lists travel on the stream of the lane that decodes them: the copy of picture k runs beside the kernels of
      picture k-1 on the previous lane (uploading on the lane that is still active would queue it BEHIND those kernels) */
   if (c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);

@@ -1,6 +1,6 @@
 """Lists recorded IN PLACE (m355_arena_begin -> the caller writes into the pinned arena -> m355_submit_picture copies nothing on
 the host): same picture as the copying submit, bit for bit; capacities larger than the lists; several pictures through the
-three rotating arenas; lists that do not sit in the arena, or exceed its capacities, are refused."""
+rotating arenas (pipeline depth + 3); lists that do not sit in the arena, or exceed its capacities, are refused."""
 import ctypes
 
 import pytest
@@ -29,9 +29,9 @@ def run(lib, oracle, case):
         dsts = [ctx.frame_create_for(pp) for _ in range(4)]
         pic.ref_frames = [handles[i] if i < len(handles) else -1 for i in range(worklist.MAX_REF_FRAMES)]
         ctx.set_pipeline_depth(2)
-        for k, d in enumerate(dsts):                       # four pictures: every arena is used, one of them twice
-            pic.dst_frame = d
-            ctx.submit_in_place(pic, slack=1.0 + 0.4 * k, fill_threads=2)
+        for k in range(7):                                 # depth + 3 = five arenas: every one is used, two of them twice
+            pic.dst_frame = dsts[k % 4]
+            ctx.submit_in_place(pic, slack=1.0 + 0.4 * (k % 4), fill_threads=2)
         ctx.wait()
         for d in dsts:
             assert_planes_equal(ctx.frame_download(d), want, "in-place submit")
