@@ -393,6 +393,8 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         # (one lane more than the unsharded line: a sharded picture is a longer chain — nine small pack / unpack kernels and the
         # exchanges between its phases — and needs one more picture beside it to keep the GPU full; measured 0.43 vs 0.47 ms at world 1)
         depth = min(4, max(1, args.pipeline_depth) + 1) if args.pipeline_depth >= 2 else 1
+        if os.environ.get("M355_BENCH_SHARD_DEPTH"):      # (A/B of the sharded leg's pictures in flight)
+            depth = max(1, int(os.environ["M355_BENCH_SHARD_DEPTH"]))
         ctx.set_pipeline_depth(depth)
         sp = shard.shard_picture(pic, rank, world)
         sp.ref_frames = [refs[i] if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]

@@ -22,6 +22,7 @@
  * Roofline: HBM-bound on paper (4 B per nonzero coefficient in, nT^2 samples read-modify-write); in
  * practice VALU/latency-bound on dense blocks, see DESIGN.md.
  */
+#include <stdlib.h>
 #include <algorithm>
 #include "k_common.h"
 
@@ -65,8 +66,9 @@ __device__ __forceinline__ uint32_t d_sel_u(uint32_t mask, uint32_t a, uint32_t 
 
 /* Residual of one block per lane group (all lanes of the wave call this together): res[] = row `c` of the block,
  * NT adjacent samples, before it is added to the picture / stored.  smem pointers are the lane group's tile. */
-template <int LOG2>
-__device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb, bool active, int c, uint32_t* cfp, int* res)
+#define RES_GB 8   /* (pos, level) pairs a lane fetches per batch */
+template <int LOG2, bool PRE = false>
+__device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb, bool active, int c, uint32_t* cfp, int* res, const uint32_t* eb0 = nullptr)
 {
   constexpr int NT = 1 << LOG2, N2 = NT * NT;
   constexpr int QN = NT / 2;             /* int16 pairs per column / row */
@@ -97,14 +99,8 @@ __device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb,
     }
     /* the (pos, level) pairs are fetched eight per lane at a time: a dense 32x32 block holds 1024 of them, and one
        dependent load -> scatter step per pair (32 memory round trips per lane) was what the whole launch waited for */
-    constexpr int GB = 8;
-    for (int k0 = c; k0 < rb.ncoeff; k0 += NT * GB) {
-      uint32_t eb[GB];
-#pragma unroll
-      for (int j = 0; j < GB; j++) {
-        const int k = k0 + j * NT;
-        eb[j] = k < rb.ncoeff ? p.coeffs[rb.coeff_ofs + k] : 0xFFFFFFFFu;   /* pos 65535: skipped below */
-      }
+    constexpr int GB = RES_GB;
+    auto scatter = [&](const uint32_t* eb) {
 #pragma unroll
       for (int j = 0; j < GB; j++) {
         const uint32_t e = eb[j];
@@ -123,6 +119,16 @@ __device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb,
         cf16[((row >> 1) * NT + col) * 2 + (row & 1)] = (int16_t)v;
         if (v != 0) { maxrow = max(maxrow, row); maxcol = max(maxcol, col); }
       }
+    };
+    if (PRE) scatter(eb0);       /* the first batch was requested an iteration ago (d_res_issue) */
+    for (int k0 = c + (PRE ? NT * GB : 0); k0 < rb.ncoeff; k0 += NT * GB) {
+      uint32_t eb[GB];
+#pragma unroll
+      for (int j = 0; j < GB; j++) {
+        const int k = k0 + j * NT;
+        eb[j] = k < rb.ncoeff ? p.coeffs[rb.coeff_ofs + k] : 0xFFFFFFFFu;   /* pos 65535: skipped below */
+      }
+      scatter(eb);
     }
   }
   /* occupied extent: over the block's lanes for the skip/bypass test below, over the WAVE for the loop
@@ -218,38 +224,37 @@ __device__ __forceinline__ m355_rb d_rb_idle(int log2)
   return rb;
 }
 
-template <int LOG2, class PIX, bool FUSED>
-__device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb* rbs, int rb_n, int group, uint32_t* smem)
+/* One group = the 64 / nT blocks a wave handles together, in three steps so that the steps of consecutive groups can overlap
+ * (d_residual_loop): the record (d_res_record), the loads that depend on it (d_res_issue: the lane's destination row and — for the
+ * loop — its first batch of coefficient pairs), and everything else (d_res_finish: scatter, transform, add / store). */
+template <int LOG2, class PIX> struct ResGeom {
+  static constexpr int NT = 1 << LOG2, BPW = 64 / NT, QN = NT / 2, GP = QN + 1, BLK_DW = QN * NT + NT * GP;
+  static constexpr int NVP = sizeof(PIX) == 2 ? NT / 2 : (NT >= 4 ? NT / 4 : 1);     /* dwords of a destination row */
+};
+
+template <int LOG2>
+__device__ __forceinline__ m355_rb d_res_record(const m355_rb* rbs, int rb_n, int tbi)
 {
-  constexpr int NT = 1 << LOG2;
-  constexpr int BPW = 64 / NT;           /* blocks per wave */
-  constexpr int QN = NT / 2;
-  constexpr int GP = QN + 1;
-  constexpr int BLK_DW = QN * NT + NT * GP;
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = lane & (NT - 1), b = lane >> LOG2;
-  const int tbi = (group * RES_WPG + wave) * BPW + b;
-  const bool active = tbi < rb_n;
-  uint32_t* cfp = smem + (wave * BPW + b) * BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
-
   m355_rb rb = d_rb_idle(LOG2);
-  if (active) rb = rbs[tbi];
-  const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+  if (tbi < rb_n) rb = rbs[tbi];
+  return rb;
+}
 
+template <int LOG2, class PIX, bool FUSED, bool PRE>
+__device__ __forceinline__ void d_res_issue(const DevPic& p, const m355_rb& rb, bool active, int c, int tbi, uint32_t* w, uint32_t* eb)
+{
+  constexpr int NT = ResGeom<LOG2, PIX>::NT, NVP = ResGeom<LOG2, PIX>::NVP;
   /* the lane's destination row (prediction samples the residual is added to) is requested BEFORE the transform: its
      memory round trip then overlaps the coefficient fetch and the two filter passes instead of following them (the
      launch is a chain of dependent round trips per workgroup, not bandwidth: 0.03-0.045 ms for any ONE block size alone) */
-  constexpr int NVP = sizeof(PIX) == 2 ? NT / 2 : (NT >= 4 ? NT / 4 : 1);
-  uint32_t w[NVP];
 #pragma unroll
   for (int i = 0; i < NVP; i++) w[i] = 0;
   const bool rmw = !FUSED && active && !(rb.flags & M355_RBF_DEFERRED);
-  PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
+  const PIX* d = (const PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
   /* FUSED: a block of an inter CU is handed to k_inter_jobs' write-back as a compact int16 tile (k_common.h, res_map); the lane
      of every fourth row marks the row of 4x4 units it starts — fire and forget, ahead of the coefficient fetch */
-  const uint32_t fused_ofs = FUSED ? p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT : 0u;
   if (FUSED && active && !(rb.flags & M355_RBF_DEFERRED) && (c & 3) == 0) {
+    const uint32_t fused_ofs = p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT;
     uint32_t* m = p.res_map + p.res_map_ofs[rb.cidx] + (size_t)((rb.y + c) >> 2) * p.res_map_w[rb.cidx] + (rb.x >> 2);
 #pragma unroll
     for (int u = 0; u < NT / 4; u++) m[u] = 0x80000000u | ((uint32_t)(LOG2 - 2) << 28) | ((fused_ofs >> 2) + u);
@@ -268,9 +273,25 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
       else w[0] = *(const uint32_t*)d;
     }
   }
+  if (PRE) {
+#pragma unroll
+    for (int j = 0; j < RES_GB; j++) {
+      const int k = c + j * NT;
+      eb[j] = k < rb.ncoeff ? p.coeffs[rb.coeff_ofs + k] : 0xFFFFFFFFu;
+    }
+  }
+}
+
+template <int LOG2, class PIX, bool FUSED, bool PRE>
+__device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs, const m355_rb& rb, bool active, int c, int tbi, uint32_t* cfp, uint32_t* w, const uint32_t* eb)
+{
+  constexpr int NT = ResGeom<LOG2, PIX>::NT;
+  const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+  PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
+  const uint32_t fused_ofs = FUSED ? p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT : 0u;
 
   int res[NT];      /* one row (lane's `c` is the row index here), NT adjacent samples */
-  d_rb_compute<LOG2>(p, rb, active, c, cfp, res);
+  d_rb_compute<LOG2, PRE>(p, rb, active, c, cfp, res, eb);
 
   /* cross-component prediction (4:4:4 range extension; transform.cc:244-260, slice.cc:3721-3760): the chroma block
      adds (ResScaleVal * ((rY << BitDepthC) >> BitDepthY)) >> 3 of its transform unit's LUMA residual, which this lane
@@ -330,6 +351,78 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   }
 }
 
+template <int LOG2, class PIX, bool FUSED>
+__device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb* rbs, int rb_n, int group, uint32_t* smem)
+{
+  typedef ResGeom<LOG2, PIX> G;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & (G::NT - 1), b = lane >> LOG2;
+  const int tbi = (group * RES_WPG + wave) * G::BPW + b;
+  const bool active = tbi < rb_n;
+  uint32_t* cfp = smem + (wave * G::BPW + b) * G::BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
+  const m355_rb rb = d_res_record<LOG2>(rbs, rb_n, tbi);
+  uint32_t w[G::NVP];
+  d_res_issue<LOG2, PIX, FUSED, false>(p, rb, active, c, tbi, w, nullptr);
+  d_res_finish<LOG2, PIX, FUSED, false>(p, rbs, rb, active, c, tbi, cfp, w, nullptr);
+}
+
+/* EXPERIMENT (M355_X_RES_PIPE): the groups g0, g0 + gs, g0 + 2 gs, ... < ng by ONE wave.  A wave that handles one group and ends goes
+ * through four dependent memory round trips — kernel arguments, the gate word, the record, then the coefficient pairs and the
+ * destination row — with about 1 us of arithmetic behind them; in the walk only the last one is left per group:
+ *   DEPTH 1: the record of group i + 1 is requested before group i is worked on (5 more registers);
+ *   DEPTH 2: while group i is transformed, the loads of group i + 1 that depend on its record (destination row, first coefficient
+ *            batch) and the record of group i + 2 are in flight (about 40 more registers: 126 instead of 66, 4 waves per SIMD). */
+#ifndef M355_X_RES_PIPE_DEPTH
+#define M355_X_RES_PIPE_DEPTH 1
+#endif
+template <int LOG2, class PIX, bool FUSED>
+__device__ __forceinline__ void d_residual_loop(const DevPic& p, const m355_rb* rbs, int rb_n, int g0, int gs, int ng, uint32_t* smem)
+{
+  typedef ResGeom<LOG2, PIX> G;
+  if (g0 >= ng) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & (G::NT - 1), b = lane >> LOG2;
+  uint32_t* cfp = smem + (wave * G::BPW + b) * G::BLK_DW;
+  auto tbi_of = [&](int g) { return (g * RES_WPG + wave) * G::BPW + b; };
+  int g = g0;
+  m355_rb rbA = d_res_record<LOG2>(rbs, rb_n, tbi_of(g));
+  if (M355_X_RES_PIPE_DEPTH <= 1) {
+    for (;;) {
+      const bool more = g + gs < ng;                       /* wave-uniform */
+      const int tA = tbi_of(g);
+      const m355_rb rbB = d_res_record<LOG2>(rbs, more ? rb_n : 0, tbi_of(g + gs));
+      uint32_t wA[G::NVP];
+      d_res_issue<LOG2, PIX, FUSED, false>(p, rbA, tA < rb_n, c, tA, wA, nullptr);
+      d_res_finish<LOG2, PIX, FUSED, false>(p, rbs, rbA, tA < rb_n, c, tA, cfp, wA, nullptr);
+      if (!more) break;
+      rbA = rbB;
+      g += gs;
+    }
+    return;
+  }
+  m355_rb rbB = d_res_record<LOG2>(rbs, g + gs < ng ? rb_n : 0, tbi_of(g + gs));
+  uint32_t wA[G::NVP], ebA[RES_GB];
+  d_res_issue<LOG2, PIX, FUSED, true>(p, rbA, tbi_of(g) < rb_n, c, tbi_of(g), wA, ebA);
+  for (;;) {
+    const bool more = g + gs < ng;                         /* wave-uniform */
+    const int tA = tbi_of(g), tB = tbi_of(g + gs);
+    uint32_t wB[G::NVP], ebB[RES_GB];
+    m355_rb rbC = d_rb_idle(LOG2);
+    if (more) {
+      d_res_issue<LOG2, PIX, FUSED, true>(p, rbB, tB < rb_n, c, tB, wB, ebB);
+      rbC = d_res_record<LOG2>(rbs, g + 2 * gs < ng ? rb_n : 0, tbi_of(g + 2 * gs));
+    }
+    d_res_finish<LOG2, PIX, FUSED, true>(p, rbs, rbA, tA < rb_n, c, tA, cfp, wA, ebA);
+    if (!more) break;
+    rbA = rbB; rbB = rbC;
+#pragma unroll
+    for (int i = 0; i < G::NVP; i++) wA[i] = wB[i];
+#pragma unroll
+    for (int i = 0; i < RES_GB; i++) ebA[i] = ebB[i];
+    g += gs;
+  }
+}
+
 /* Two launches, issued side by side on the lane's two streams (runtime.hip, launch_prediction): 32x32 + 16x16 blocks (2 / 4 per
  * wave; 128 VGPRs, 8 KB of LDS tiles per wave) and 8x8 + 4x4 blocks (8 / 16 per wave; 66 VGPRs -> 7 waves per SIMD instead of the
  * 3 the 32-point transform's registers would impose on every size).  The stage is a chain of dependent round trips per wave —
@@ -379,6 +472,48 @@ __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
   k_residual_body<PIX, BIG, FUSED, RES_XCD_ORDER>(p, ng_hi, s_buf);
 }
+#ifdef M355_X_RES_PIPE
+/* EXPERIMENT (tools/variants.sh respipe "-DM355_X_RES_PIPE=<workgroups per launch>"): a persistent grid; workgroup b walks the groups
+   b, b + G, b + 2G, ... of the launch's larger size, then those of the smaller one (continuing the round so that every workgroup gets
+   the same number of groups +- 1), each walk software-pipelined (d_residual_loop).  With M355_X_RES_XCD the walk of a workgroup stays
+   inside its XCD's contiguous eighth of the bin (block b runs on XCD b % 8; G is a multiple of 8). */
+#ifndef M355_X_RES_PIPE_WAVES
+#define M355_X_RES_PIPE_WAVES 4   /* register budget: waves per SIMD the walking 8x8 / 4x4 kernel is compiled for (at least) */
+#endif
+template <class PIX, bool BIG, bool FUSED>
+__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(M355_X_RES_PIPE_WAVES))) k_residual_pipe(DevPic p, int ng_hi, int ng_lo)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
+  M355_GATE(p);
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  const m355_rb* rb_hi = BIG ? p.rb_bin[3] : p.rb_bin[1];
+  const m355_rb* rb_lo = BIG ? p.rb_bin[2] : p.rb_bin[0];
+  const int n_hi = BIG ? p.rb_count[3] : p.rb_count[1], n_lo = BIG ? p.rb_count[2] : p.rb_count[0];
+  if (RES_XCD_ORDER) {
+    /* bin -> eight contiguous chunks, chunk x walked by the G / 8 workgroups of XCD x */
+    const int x = b & 7, j = b >> 3, Gx = G >> 3;
+    const int per_hi = (ng_hi + 7) >> 3, per_lo = (ng_lo + 7) >> 3;
+    const int e_hi = min(ng_hi, (x + 1) * per_hi), e_lo = min(ng_lo, (x + 1) * per_lo);
+    const int r = per_hi % Gx;                          /* (the chunk's last round is partial: the smaller size starts where it ends) */
+    if (BIG) {
+      d_residual_loop<5, PIX, FUSED>(p, rb_hi, n_hi, x * per_hi + j, Gx, e_hi, s_buf);
+      d_residual_loop<4, PIX, FUSED>(p, rb_lo, n_lo, x * per_lo + (j - r + Gx) % Gx, Gx, e_lo, s_buf);
+    } else {
+      d_residual_loop<3, PIX, FUSED>(p, rb_hi, n_hi, x * per_hi + j, Gx, e_hi, s_buf);
+      d_residual_loop<2, PIX, FUSED>(p, rb_lo, n_lo, x * per_lo + (j - r + Gx) % Gx, Gx, e_lo, s_buf);
+    }
+  } else {
+    const int r = ng_hi % G;
+    if (BIG) {
+      d_residual_loop<5, PIX, FUSED>(p, rb_hi, n_hi, b, G, ng_hi, s_buf);
+      d_residual_loop<4, PIX, FUSED>(p, rb_lo, n_lo, (b - r + G) % G, G, ng_lo, s_buf);
+    } else {
+      d_residual_loop<3, PIX, FUSED>(p, rb_hi, n_hi, b, G, ng_hi, s_buf);
+      d_residual_loop<2, PIX, FUSED>(p, rb_lo, n_lo, (b - r + G) % G, G, ng_lo, s_buf);
+    }
+  }
+}
+#endif
 /* batch form (intra pictures: never the fused order) */
 template <class PIX, bool BIG>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_batch(DevBatch b)
@@ -408,6 +543,17 @@ template <class PIX, bool BIG>
 static void launch_res(const DevPic& p, int n, int ng_hi, hipStream_t st)
 {
   const dim3 blk(64 * RES_WPG);
+#ifdef M355_X_RES_PIPE
+  if (!BIG) {      /* (the 32x32 / 16x16 launch is bound by its arithmetic, and two groups' state does not fit its 128 registers: 250-400 bytes of scratch per lane) */
+    const int ng_lo = BIG ? res_groups(p.rb_count[2], 4) : res_groups(p.rb_count[0], 16);
+    static const int g_env = getenv("M355_RES_PIPE_GRID") ? atoi(getenv("M355_RES_PIPE_GRID")) : 0;
+    int G = g_env > 0 ? g_env : M355_X_RES_PIPE;
+    G = std::max(8, std::min(G, ng_hi + ng_lo) & ~7);
+    if (p.res_map) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_pipe<PIX, BIG, true>), dim3(G), blk, 0, st, p, ng_hi, ng_lo);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_pipe<PIX, BIG, false>), dim3(G), blk, 0, st, p, ng_hi, ng_lo);
+    return;
+  }
+#endif
   if (p.res_map) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, true>), dim3(n), blk, 0, st, p, ng_hi);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, false>), dim3(n), blk, 0, st, p, ng_hi);
 }
