@@ -473,6 +473,13 @@ M355_API int m355_picture_upload(m355_ctx* ctx, const m355_picture* pic);   /* -
 M355_API int m355_picture_release(m355_ctx* ctx, int handle);
 /* other lists into an uploaded picture's arenas: waits for that handle's last decode only (no allocation when they fit) */
 M355_API int m355_picture_replace(m355_ctx* ctx, int handle, const m355_picture* pic);
+/* m355_arena_begin for the arenas of a RESIDENT picture: list pointers into the pinned arena of `handle` (-1: a new handle) with room
+ * for `caps` entries; returns the handle (>= 0) or -error.  The recorder threads write the lists there and
+ * m355_picture_replace(ctx, handle, pic) takes them over without copying a byte on the host (same rules as m355_submit_picture on
+ * in-place lists).  This is the in-place path of a TILE-SHARDED context (m355_shard_set / m355_group_*), whose pictures are decoded
+ * from handles; there `pp` — the picture's parameters, known before its lists are recorded — sizes the room for the border units
+ * of the other ranks behind cus[] / pbs[] (unsharded contexts ignore it; the lists of a sharded picture are checked on the host). */
+M355_API int m355_picture_arena_begin(m355_ctx* ctx, int handle, m355_arena_caps* caps, const m355_pic_params* pp, m355_picture* pic);
 M355_API int m355_decode_resident(m355_ctx* ctx, int handle);
 /* n independent INTRA pictures (n <= pipeline depth, distinct destination frames, one chroma format and sample type) with ONE intra
  * stage: each picture's residuals / border plans and its filters run on a lane of its own as for n m355_decode_resident calls, the

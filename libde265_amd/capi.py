@@ -68,6 +68,8 @@ class Library:
         L.m355_frame_download.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_fill.argtypes = [vp, i, i, i]
         L.m355_arena_begin.argtypes = [vp, vp, vp]
+        if hasattr(L, "m355_picture_arena_begin"):      # (absent from older builds loaded through M355_LIB for an A/B)
+            L.m355_picture_arena_begin.argtypes = [vp, i, vp, vp, vp]
         L.m355_frame_download_async.argtypes = [vp, i, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ssize_t)]
         L.m355_frame_download_wait.argtypes = [vp, i]
         L.m355_host_alloc.argtypes = [ctypes.c_size_t]
@@ -300,6 +302,31 @@ class Context:
         if r < 0:
             raise M355Error(-r, self.L.error())
         return r
+
+    def upload_in_place(self, src_pic, handle=-1, slack=1.0, fill_threads=4):
+        """The in-place path of a RESIDENT picture (m355_picture_arena_begin -> the lists are written into the handle's pinned arena
+        by libm355synth, standing in for recorder threads -> m355_picture_replace copies nothing on the host); what a tile-sharded
+        context offers instead of m355_arena_begin.  -> handle"""
+        from . import synth
+        src, keep = src_pic.to_c()
+        caps = ArenaCaps()
+        for n in ("n_slices", "n_ctbs", "n_cus", "n_tus", "n_pbs", "n_wts", "n_ibs"):
+            setattr(caps, n, int(getattr(src, n)) if n in ("n_slices", "n_ctbs") else int(getattr(src, n) * slack) + 1)
+        for b in range(4):
+            caps.n_rbs[b] = int(src.rb_count[b] * slack) + 1
+        caps.n_coeffs = int(src.n_coeffs * slack) + 1
+        caps.n_pcm = int(src.n_pcm * slack) + 1
+        caps.scaling = 1 if src.scaling_factors else 0
+        dst = worklist.CPicture()
+        h = self.L.lib.m355_picture_arena_begin(self.h, handle, ctypes.addressof(caps), ctypes.addressof(src) + worklist.CPicture.pp.offset, ctypes.addressof(dst))
+        if h < 0:
+            raise M355Error(-h, self.L.error())
+        synth._lib().m355_synth_fill_arena(ctypes.addressof(src), ctypes.addressof(caps), ctypes.addressof(dst), fill_threads)
+        dst.dst_frame = src.dst_frame
+        ctypes.memmove(dst.ref_frames, src.ref_frames, 4 * worklist.MAX_REF_FRAMES)
+        self.L.check(self.L.lib.m355_picture_replace(self.h, h, ctypes.addressof(dst)))
+        del keep
+        return h
 
     def release(self, handle):
         self.L.check(self.L.lib.m355_picture_release(self.h, handle))

@@ -21,6 +21,9 @@ __device__ __forceinline__ void d_st_nt8(void* p, unsigned v0, unsigned v1) { __
 /* keep a wave-uniform value in a scalar register, computed HERE (k_intra decodes its next block's record before the level barrier,
  * not at the first use behind it) */
 #define M355_PIN_S(x) asm volatile("" : "+s"(x))
+/* make a value opaque to the optimiser where it stands (any register): e.g. two record fields that must both be LOADED before a select
+ * between them — hipcc otherwise selects the ADDRESS and loads one of them later, behind whatever is in flight */
+#define M355_PIN_V(x) asm volatile("" : "+v"(x))
 
 /* spin bound of k_intra's granule polls: ~2^22 polls x (one L2 round trip + s_sleep) is seconds — far beyond any real wait */
 #define M355_SPIN_LIMIT (1u << 22)
@@ -50,6 +53,10 @@ __device__ __forceinline__ void d_ldg12(const M355_GLOBAL void* p, unsigned* o) 
 __device__ __forceinline__ void d_ldg8(const M355_GLOBAL void* p, unsigned* o) { const m355_u2 v = *(const M355_GLOBAL m355_u2*)p; o[0] = v.x; o[1] = v.y; }
 __device__ __forceinline__ unsigned d_ldg4(const M355_GLOBAL void* p) { return *(const M355_GLOBAL m355_u1*)p; }
 __device__ __forceinline__ unsigned d_ldg2(const M355_GLOBAL void* p) { return *(const M355_GLOBAL m355_h1*)p; }
+/* the matching stores (plain: the line stays in the L2 for whoever reads the samples next) */
+__device__ __forceinline__ void d_stg16(M355_GLOBAL void* p, const unsigned* v) { m355_u4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *(M355_GLOBAL m355_u4*)p = t; }
+__device__ __forceinline__ void d_stg8(M355_GLOBAL void* p, const unsigned* v) { m355_u2 t; t.x = v[0]; t.y = v[1]; *(M355_GLOBAL m355_u2*)p = t; }
+__device__ __forceinline__ void d_stg4(M355_GLOBAL void* p, unsigned v) { *(M355_GLOBAL m355_u1*)p = v; }
 
 /* v_perm_b32: byte permute of {hi:lo}; the two selectors used here gather the LOW resp. HIGH 16-bit halves
  * of two registers into one packed pair (lo -> bits 0..15, hi -> bits 16..31) in a single VALU issue */

@@ -82,8 +82,35 @@ struct DevIntraWork {
 /* ... and the plans of any 64 blocks of a CTB by 2176 / 2496 / 2848 / 3520 entries (+ 7 of alignment) */
 #define M355_INTRA_PLAN_BATCH(cf) ((cf) == 0 ? 2304 : ((cf) == 1 ? 2560 : ((cf) == 2 ? 3072 : 3584)))
 
+/* m355_pic_params as the KERNELS see it: every field a whole dword.  A DevPic travels in the kernel argument segment, and a field
+ * narrower than a dword there is not a scalar load (gfx950 has none below 32 bits): hipcc fetches it with a VECTOR memory load from
+ * the argument segment and waits for everything in flight where it needs it — k_deblock started with such a round trip before its
+ * first real load, k_sao had one behind its sample loads (bit depth of the launch's component).  Same field names, so the kernels
+ * read p.pp.<field> as before; dev_pic_params() widens. */
+struct DevPicParams {
+  int32_t  width, height;
+  int32_t  chroma_format_idc, bit_depth_luma, bit_depth_chroma, log2_ctb_size, log2_min_tb_size, log2_min_cb_size;
+  int32_t  pic_cb_qp_offset, pic_cr_qp_offset;
+  uint32_t flags;
+  int32_t  num_tile_cols, num_tile_rows;
+  uint16_t col_bd[M355_MAX_TILE_COLS + 1];
+  uint16_t row_bd[M355_MAX_TILE_ROWS + 1];
+};
+static inline DevPicParams dev_pic_params(const m355_pic_params& q)
+{
+  DevPicParams d;
+  d.width = q.width; d.height = q.height;
+  d.chroma_format_idc = q.chroma_format_idc; d.bit_depth_luma = q.bit_depth_luma; d.bit_depth_chroma = q.bit_depth_chroma;
+  d.log2_ctb_size = q.log2_ctb_size; d.log2_min_tb_size = q.log2_min_tb_size; d.log2_min_cb_size = q.log2_min_cb_size;
+  d.pic_cb_qp_offset = q.pic_cb_qp_offset; d.pic_cr_qp_offset = q.pic_cr_qp_offset;
+  d.flags = q.flags; d.num_tile_cols = q.num_tile_cols; d.num_tile_rows = q.num_tile_rows;
+  for (int i = 0; i <= M355_MAX_TILE_COLS; i++) d.col_bd[i] = q.col_bd[i];
+  for (int i = 0; i <= M355_MAX_TILE_ROWS; i++) d.row_bd[i] = q.row_bd[i];
+  return d;
+}
+
 struct DevPic {
-  m355_pic_params pp;
+  DevPicParams pp;
   int sw, sh;                       /* SubWidthC, SubHeightC */
   int ctbW, ctbH, nCtb, w4, h4, wcb, hcb;
   int pw[3], ph[3];                 /* plane dimensions */
@@ -132,7 +159,7 @@ struct DevPic {
   int res_map_w[3];                 /* units per row */
   uint32_t res_map_words;           /* all components */
   uint32_t res_fused_base[4];
-  uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable (k_meta_sao) */
+  uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable; bit 15 = the CTB's slice has SAO on for the component (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
   uint32_t* job_base;               /* [256-PB chunk][3]: first job index of the chunk per range (uni, bi, edge): k_job_count leaves the chunk's
                                        counts here, k_job_scan turns them into the prefix sums k_meta_pb reads (lane scratch) */
@@ -204,6 +231,17 @@ struct TileCopyArgs { char* plane[3]; size_t pitch[3]; TileCopyRect r[M355_TILE_
 void m355_launch_tiles_copy(const TileCopyArgs& a, int n, void* xbuf, bool to_slot, hipStream_t st);
 
 /* first statement of every kernel of a decode: a picture whose lists k_validate rejected is never acted upon */
+/* Element `c` (0..2, per lane) of a three-entry table of the kernel arguments (plane pointers, pitches, ...): all three entries are
+ * read as scalars and the lane selects — indexing the argument segment with a per-lane value is a VECTOR memory load from it, i.e. one
+ * more dependent round trip between a record and the loads its component decides (k_residual: record -> plane pointer -> row).  The
+ * pins keep hipcc from folding the selection back into an address. */
+template <class T> __device__ __forceinline__ T d_sel3(int c, T a0, T a1, T a2)
+{
+  M355_PIN_V(a0); M355_PIN_V(a1); M355_PIN_V(a2);
+  return c == 0 ? a0 : (c == 1 ? a1 : a2);
+}
+#define M355_SEL3(arr, c) d_sel3((c), (arr)[0], (arr)[1], (arr)[2])
+
 #define M355_GATE(p) do { if ((p).timeout[1] == (p).epoch) return; } while (0)
 
 enum { E_TU_V = 1, E_TU_H = 2, E_PB_V = 4, E_PB_H = 8, E_NONZERO = 16 };

@@ -118,6 +118,9 @@ __device__ __forceinline__ void k_deblock_body(const DevPic& p)
   const int ef = p.edge_tu[u] | p.edge_pb[u], efo = p.edge_tu[uo];
   const uint32_t ip = p.pb_of[uo], iq = p.pb_of[u];
   const int slice_idx = p.ctbs[d_ctb_of(p, xDi, yDi)].slice_idx;
+  /* all of the above is requested HERE: without the fence hipcc sinks every load but the edge flags below the exit — three dependent
+     round trips (flags, indices, records) instead of two */
+  M355_COMPILER_FENCE();
   if (!(ef & (VERTICAL ? (E_TU_V | E_PB_V) : (E_TU_H | E_PB_H)))) return;
   /* ---- round trip 2: the records the indices name AND the segment's luma samples, requested together (the pass used to be a
      chain of five dependent round trips with 32 scalar sample loads at its end): 32 + 32 bytes as aligned 4-sample vectors — the

@@ -270,6 +270,8 @@ __device__ __forceinline__ void k_meta_sao_body(const DevPic& p)
     }
     if (blocked) mask |= 1u << k;
   }
+  /* bit 15: the CTB's slice runs SAO on this component (slice_sao_luma / chroma_flag) — k_sao then needs no slice record at all */
+  if (curFlags & (c == 0 ? M355_SF_SAO_LUMA : M355_SF_SAO_CHROMA)) mask |= 0x8000u;
   p.sao_nb[i] = (uint16_t)mask;
 }
 
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256) k_validate(DevPic p, uint32_t n_total)
 {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
   if (g >= n_total) return;
-  const m355_pic_params& pp = p.pp;
+  const DevPicParams& pp = p.pp;
   const uint32_t cnt[9] = {(uint32_t)p.n_cus, (uint32_t)p.n_tus, (uint32_t)p.n_pbs, (uint32_t)p.n_wts, (uint32_t)p.rb_count[0], (uint32_t)p.rb_count[1],
                            (uint32_t)p.rb_count[2], (uint32_t)p.rb_count[3], (uint32_t)p.n_ibs};
   uint32_t i = g;

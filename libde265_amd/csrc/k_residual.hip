@@ -26,7 +26,6 @@
 #include <algorithm>
 #include "k_common.h"
 
-__constant__ int8_t c_level_scale[6] = {40, 45, 51, 57, 64, 72};
 
 /* ---- compile-time tables: M[k][n] = c(k(2n+1)), c = quarter wave of the HEVC core transform
  * (the matrix of fallback-dct.cc:512-545), stored as int16 pairs (M[F*2q][i], M[F*(2q+1)][i]), F = 32/nT ---- */
@@ -91,7 +90,8 @@ __device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb,
     int bdShift = bd + LOG2 - 5;
     if (!sclist) bdShift -= 4;
     const long long offset = 1ll << (bdShift - 1);
-    const int ls = c_level_scale[rb.qp % 6], qs = rb.qp / 6;
+    /* levelScale[qP % 6] = {40, 45, 51, 57, 64, 72} (transform.cc:436) as a byte permute: the table in constant memory was a vector load per lane */
+    const int ls = (int)d_byte_lookup(0x00004840u, 0x39332D28u, (unsigned)(rb.qp % 6)), qs = rb.qp / 6;
     const uint8_t* scl = nullptr;
     if (sclist && p.scaling) {
       const int sz_ofs = LOG2 == 2 ? 0 : LOG2 == 3 ? 6 * 16 : LOG2 == 4 ? 6 * 16 + 6 * 64 : 6 * 16 + 6 * 64 + 6 * 256;
@@ -126,7 +126,8 @@ __device__ __forceinline__ void d_rb_compute(const DevPic& p, const m355_rb& rb,
 #pragma unroll
       for (int j = 0; j < GB; j++) {
         const int k = k0 + j * NT;
-        eb[j] = k < rb.ncoeff ? p.coeffs[rb.coeff_ofs + k] : 0xFFFFFFFFu;   /* pos 65535: skipped below */
+        const uint32_t v = p.coeffs[rb.coeff_ofs + (uint32_t)min(k, max((int)rb.ncoeff - 1, 0))];   /* (clamped: no branch in front of a load) */
+        eb[j] = k < rb.ncoeff ? v : 0xFFFFFFFFu;   /* pos 65535: skipped below */
       }
       scatter(eb);
     }
@@ -249,35 +250,40 @@ __device__ __forceinline__ void d_res_issue(const DevPic& p, const m355_rb& rb, 
      launch is a chain of dependent round trips per workgroup, not bandwidth: 0.03-0.045 ms for any ONE block size alone) */
 #pragma unroll
   for (int i = 0; i < NVP; i++) w[i] = 0;
-  const bool rmw = !FUSED && active && !(rb.flags & M355_RBF_DEFERRED);
-  const PIX* d = (const PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
+  const M355_GLOBAL PIX* d = (const M355_GLOBAL PIX*)M355_SEL3(p.plane, rb.cidx) + (size_t)(rb.y + c) * M355_SEL3(p.stride, rb.cidx) + rb.x;
   /* FUSED: a block of an inter CU is handed to k_inter_jobs' write-back as a compact int16 tile (k_common.h, res_map); the lane
      of every fourth row marks the row of 4x4 units it starts — fire and forget, ahead of the coefficient fetch */
   if (FUSED && active && !(rb.flags & M355_RBF_DEFERRED) && (c & 3) == 0) {
     const uint32_t fused_ofs = p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT;
-    uint32_t* m = p.res_map + p.res_map_ofs[rb.cidx] + (size_t)((rb.y + c) >> 2) * p.res_map_w[rb.cidx] + (rb.x >> 2);
+    M355_GLOBAL uint32_t* m = (M355_GLOBAL uint32_t*)p.res_map + M355_SEL3(p.res_map_ofs, rb.cidx) + (size_t)((rb.y + c) >> 2) * M355_SEL3(p.res_map_w, rb.cidx) + (rb.x >> 2);
 #pragma unroll
     for (int u = 0; u < NT / 4; u++) m[u] = 0x80000000u | ((uint32_t)(LOG2 - 2) << 28) | ((fused_ofs >> 2) + u);
   }
-  if (rmw) {
+  /* (requested by every lane, also where the row is not used — blocks of intra CUs, idle lanes; their address is a valid row of the
+     plane all the same: a load under a per-lane condition leaves hipcc unsure of what is in flight behind it, and it then drains
+     everything before the next load) */
+  if (!FUSED) {
     if (sizeof(PIX) == 2) {
       if (NT >= 8) {
 #pragma unroll
-        for (int i = 0; i < NVP; i += 4) { const uint4 v = *(const uint4*)(d + 2 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
-      } else { const uint2 v = *(const uint2*)d; w[0] = v.x; w[1] = v.y; }
+        for (int i = 0; i < NVP; i += 4) d_ldg16(d + 2 * i, w + i);
+      } else d_ldg8(d, w);
     } else {
       if (NT >= 16) {
 #pragma unroll
-        for (int i = 0; i < NVP; i += 4) { const uint4 v = *(const uint4*)(d + 4 * i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
-      } else if (NT == 8) { const uint2 v = *(const uint2*)d; w[0] = v.x; w[NVP - 1] = v.y; }
-      else w[0] = *(const uint32_t*)d;
+        for (int i = 0; i < NVP; i += 4) d_ldg16(d + 4 * i, w + i);
+      } else if (NT == 8) d_ldg8(d, w);
+      else w[0] = d_ldg4(d);
     }
   }
   if (PRE) {
 #pragma unroll
     for (int j = 0; j < RES_GB; j++) {
+      /* from a CLAMPED index, selected afterwards: a load under a per-lane condition is a branch and a wait of its own (eight
+         dependent round trips instead of one) */
       const int k = c + j * NT;
-      eb[j] = k < rb.ncoeff ? p.coeffs[rb.coeff_ofs + k] : 0xFFFFFFFFu;
+      const uint32_t v = p.coeffs[rb.coeff_ofs + (uint32_t)min(k, max((int)rb.ncoeff - 1, 0))];
+      eb[j] = k < rb.ncoeff ? v : 0xFFFFFFFFu;
     }
   }
 }
@@ -287,7 +293,7 @@ __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs
 {
   constexpr int NT = ResGeom<LOG2, PIX>::NT;
   const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
-  PIX* d = (PIX*)p.plane[rb.cidx] + (size_t)(rb.y + c) * p.stride[rb.cidx] + rb.x;
+  M355_GLOBAL PIX* d = (M355_GLOBAL PIX*)M355_SEL3(p.plane, rb.cidx) + (size_t)(rb.y + c) * M355_SEL3(p.stride, rb.cidx) + rb.x;
   const uint32_t fused_ofs = FUSED ? p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT : 0u;
 
   int res[NT];      /* one row (lane's `c` is the row index here), NT adjacent samples */
@@ -334,8 +340,8 @@ __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs
         w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFFFu) + res[2 * i], bd) | ((uint32_t)d_clip_bd((int)(w[i] >> 16) + res[2 * i + 1], bd) << 16);
       if (NT >= 8) {
 #pragma unroll
-        for (int i = 0; i < NV; i += 4) *(uint4*)(d + 2 * i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
-      } else *(uint2*)d = make_uint2(w[0], w[1]);
+        for (int i = 0; i < NV; i += 4) d_stg16(d + 2 * i, w + i);
+      } else d_stg8(d, w);
     } else {
       constexpr int NV = NT / 4;
 #pragma unroll
@@ -344,9 +350,9 @@ __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs
                ((uint32_t)d_clip_bd((int)((w[i] >> 16) & 0xFFu) + res[4 * i + 2], bd) << 16) | ((uint32_t)d_clip_bd((int)(w[i] >> 24) + res[4 * i + 3], bd) << 24);
       if (NT >= 16) {
 #pragma unroll
-        for (int i = 0; i < NV; i += 4) *(uint4*)(d + 4 * i) = make_uint4(w[i], w[i + 1], w[i + 2], w[i + 3]);
-      } else if (NT == 8) *(uint2*)d = make_uint2(w[0], w[NV - 1]);
-      else *(uint32_t*)d = w[0];
+        for (int i = 0; i < NV; i += 4) d_stg16(d + 4 * i, w + i);
+      } else if (NT == 8) d_stg8(d, w);
+      else d_stg4(d, w[0]);
     }
   }
 }
@@ -361,9 +367,12 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   const bool active = tbi < rb_n;
   uint32_t* cfp = smem + (wave * G::BPW + b) * G::BLK_DW;   /* cfp[q * NT + col] = (coef[2q][col], coef[2q+1][col]) */
   const m355_rb rb = d_res_record<LOG2>(rbs, rb_n, tbi);
-  uint32_t w[G::NVP];
-  d_res_issue<LOG2, PIX, FUSED, false>(p, rb, active, c, tbi, w, nullptr);
-  d_res_finish<LOG2, PIX, FUSED, false>(p, rbs, rb, active, c, tbi, cfp, w, nullptr);
+  /* the destination row and the first batch of coefficient pairs in ONE straight line of loads behind the record (a block of up to
+     8 nT pairs has no other batch): requested inside the batch loop, the pairs waited for the row first — hipcc drains every load in
+     flight at a loop header */
+  uint32_t w[G::NVP], eb[RES_GB];
+  d_res_issue<LOG2, PIX, FUSED, true>(p, rb, active, c, tbi, w, eb);
+  d_res_finish<LOG2, PIX, FUSED, true>(p, rbs, rb, active, c, tbi, cfp, w, eb);
 }
 
 /* EXPERIMENT (M355_X_RES_PIPE): the groups g0, g0 + gs, g0 + 2 gs, ... < ng by ONE wave.  A wave that handles one group and ends goes

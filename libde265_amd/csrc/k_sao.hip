@@ -144,14 +144,20 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   const int so2 = c == 0 ? ctb.sao_offset[0][2] : (c == 1 ? ctb.sao_offset[1][2] : ctb.sao_offset[2][2]);
   const int so3 = c == 0 ? ctb.sao_offset[0][3] : (c == 1 ? ctb.sao_offset[1][3] : ctb.sao_offset[2][3]);
   const int type_raw = valid ? ((ctb.sao_type >> (2 * c)) & 3) : 0;
-  /* ---- round trip 2: the slice record and — where the CTB asks for an edge class — the wave tile's rim: the row above the
-     top lanes and below the bottom lanes, and the sample left / right of the outer lanes for the six rows.  The rim columns
-     are 48 samples per wave: lane i fetches sample i (ONE load instruction), the outer lanes pick theirs up with cross-lane reads. ---- */
-  const m355_slice csl = p.slices[ctb.slice_idx];
-  const bool any_edge = __any(type_raw == 2);
+  /* ---- (still round trip 1) the wave tile's rim: the row above the top lanes and below the bottom lanes, and the sample left / right
+     of the outer lanes for the six rows — requested whether or not a CTB of the wave asks for an edge class: the kernel is bound by
+     dependent round trips per wave at full occupancy, not by bytes (profiles/r04_af_*: 31 % less fabric fetch moved nothing), and the
+     rim behind the CTB record was a second trip.  The slice's SAO switch comes with the neighbour mask (k_meta_sao, bit 15): no slice
+     record either.  The rim columns are 48 samples per wave: lane i fetches sample i (ONE load instruction), the outer lanes pick
+     theirs up with cross-lane reads. ---- */
   uint32_t rim_up[NW], rim_dn[NW];
   uint32_t rim_col = 0;
-  if (any_edge) {
+#ifndef M355_X_SAO_TWO_TRIPS
+  {
+#else
+  const bool any_edge_early = __any(type_raw == 2);
+  if (any_edge_early) {
+#endif
     d_sao_load4<PIX>(in + (size_t)(ly == 0 ? max(y0 - 1, 0) : min(y0, height - 1)) * is + xs, rim_up);
     d_sao_load4<PIX>(in + (size_t)(ly == 3 ? min(y0 + 4, height - 1) : min(y0 + 3, height - 1)) * is + xs, rim_dn);
     /* lane i < 48: group g = i / 12 (the lanes with ly == g), side = (i % 12) / 6 (0 left, 1 right), row r = i % 6 */
@@ -160,7 +166,8 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
     const int xx = side ? min(xt + 64, width - 1) : max(xt - 1, 0);
     rim_col = in[(size_t)yy * is + xx];
   }
-  const bool enabled = c == 0 ? (csl.flags & M355_SF_SAO_LUMA) : (csl.flags & M355_SF_SAO_CHROMA);
+  const bool any_edge = __any(type_raw == 2);
+  const bool enabled = (nbmask_raw & 0x8000u) != 0;
   const int type = enabled ? type_raw : 0;
   const bool edge = type == 2;
 #pragma unroll
@@ -228,7 +235,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
         }
       }
   }
-  const uint32_t nbmask = (valid && edge) ? nbmask_raw : 0u;
+  const uint32_t nbmask = (valid && edge) ? (nbmask_raw & 0x1FFu) : 0u;
   const bool slow = __any(skipmask != 0 || nbmask != 0);
   if (!valid || !owned) return;
 

@@ -144,6 +144,8 @@ struct Resident {
   bool fresh = false;          /* uploaded and not decoded since: nothing in flight reads its reference table */
   bool arena = false;          /* m355_arena_begin handed out list pointers into `host`: the next upload of lists that sit there copies nothing */
   m355_arena_caps caps;        /* ... with room for this many entries */
+  int arena_halo_units = 0;    /* ... and, on a tile-sharded context, for this many foreign border units behind cus[] / pbs[] */
+  bool reserved = false;       /* m355_picture_arena_begin made this handle; no lists yet (m355_picture_replace brings them) */
   bool device_validate = false;    /* the record checks of these lists run on the device (k_validate) */
   size_t xscratch_pitch = 0;       /* m355_decode_sharded / m355_group_decode: bytes between the peers' slots of xscratch */
   std::vector<uint8_t> sched_u8;   /* upload(): per-CTB scratch of the intra schedule */
@@ -1229,7 +1231,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const bool in_place = r.arena && r.host && pic->n_ctbs > 0 && (const char*)pic->ctbs >= r.host && (const char*)pic->ctbs < r.host + r.cap;
   int ctbW, ctbH;
   static const bool host_only = getenv("M355_HOST_VALIDATION") != nullptr;     /* diagnostics: all record checks on the host */
-  r.device_validate = in_place && !host_only;
+  r.device_validate = in_place && !host_only && c->shard_n < 1;   /* (a sharded picture's phases have no status slot: its lists are checked here) */
   int rc = validate(pic, in_place ? (const m355_rb* const*)r.caps.rb_bin : nullptr, r.device_validate, &ctbW, &ctbH);
   if (rc) return rc;
   const auto t_valid = now();
@@ -1244,6 +1246,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   caps_of(pic, cp);
   if (in_place) {
     const m355_arena_caps& k = r.caps;
+    if (halo.n_units != r.arena_halo_units) return fail(M355_ERR_INVALID, "in-place submit: the arena was laid out for another tile structure (m355_picture_arena_begin's pp)");
     if (cp.n_slices > k.n_slices || cp.n_ctbs > k.n_ctbs || cp.n_cus > k.n_cus || cp.n_tus > k.n_tus || cp.n_pbs > k.n_pbs || cp.n_wts > k.n_wts ||
         cp.n_rbs[0] > k.n_rbs[0] || cp.n_rbs[1] > k.n_rbs[1] || cp.n_rbs[2] > k.n_rbs[2] || cp.n_rbs[3] > k.n_rbs[3] || cp.n_ibs > k.n_ibs ||
         cp.n_coeffs > k.n_coeffs || cp.n_pcm > k.n_pcm || (cp.scaling && !k.scaling))
@@ -1460,7 +1463,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   r.hdr = *pic;
   DevPic& d = r.dp;
   memset(&d, 0, sizeof(d));
-  d.pp = pp;
+  d.pp = dev_pic_params(pp);
   d.sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1;
   d.sh = pp.chroma_format_idc == 1 ? 2 : 1;
   d.ctbW = ctbW; d.ctbH = ctbH; d.nCtb = nCtb;
@@ -2490,16 +2493,11 @@ int m355_shard_rccl_selftest(m355_ctx* c, size_t words)
   return rc;
 }
 
-int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)
+/* room for `k` entries per list in the arenas of `r` (grown when it does not fit), list pointers into its pinned half */
+static int arena_into(m355_ctx* c, Resident& r, m355_arena_caps* k, int halo_units, bool sharded, m355_picture* pic)
 {
-  if (!k || !pic || k->n_ctbs <= 0 || k->n_slices <= 0 || k->n_cus < 0 || k->n_tus < 0 || k->n_pbs < 0 || k->n_wts < 0 || k->n_ibs < 0 ||
-      k->n_rbs[0] < 0 || k->n_rbs[1] < 0 || k->n_rbs[2] < 0 || k->n_rbs[3] < 0)
-    return fail(M355_ERR_INVALID, "bad arena capacities");
-  if (c->shard_n >= 1) return fail(M355_ERR_INVALID, "m355_arena_begin is not available on a tile-sharded context");
-  hipSetDevice(c->device);
-  Resident& r = c->transient[c->next_transient];         /* the arena the next m355_submit_picture uses */
   Lay L;
-  make_layout(*k, k->n_ctbs, 0, false, true, L);
+  make_layout(*k, k->n_ctbs, halo_units, sharded, true, L);
   if (L.total > r.cap) {
     if (r.dev || r.host) HIPCHK(sync_all(c));
     if (r.dev) hipFree(r.dev);
@@ -2521,7 +2519,7 @@ int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)
   pic->wts = (const m355_wt*)(r.host + L.seg[L.i_wt].ofs);
   pic->rbs = (const m355_rb*)(r.host + L.seg[L.i_rb[0]].ofs);
   for (int b = 0; b < 4; b++) k->rb_bin[b] = (m355_rb*)(r.host + L.seg[L.i_rb[b]].ofs);
-  r.arena = true; r.caps = *k;
+  r.arena = true; r.caps = *k; r.arena_halo_units = halo_units;
   pic->ibs = (const m355_ib*)(r.host + L.seg[L.i_ibin].ofs);
   pic->coeffs = (const uint32_t*)(r.host + L.seg[L.i_co].ofs);
   pic->pcm = (const uint16_t*)(r.host + L.seg[L.i_pc].ofs);
@@ -2529,6 +2527,43 @@ int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)
   pic->dst_frame = -1;
   for (int i = 0; i < M355_MAX_REF_FRAMES; i++) pic->ref_frames[i] = -1;
   return M355_OK;
+}
+static bool caps_ok(const m355_arena_caps* k, const m355_picture* pic)
+{
+  return k && pic && k->n_ctbs > 0 && k->n_slices > 0 && k->n_cus >= 0 && k->n_tus >= 0 && k->n_pbs >= 0 && k->n_wts >= 0 && k->n_ibs >= 0 &&
+         k->n_rbs[0] >= 0 && k->n_rbs[1] >= 0 && k->n_rbs[2] >= 0 && k->n_rbs[3] >= 0;
+}
+
+int m355_arena_begin(m355_ctx* c, m355_arena_caps* k, m355_picture* pic)
+{
+  if (!caps_ok(k, pic)) return fail(M355_ERR_INVALID, "bad arena capacities");
+  if (c->shard_n >= 1) return fail(M355_ERR_INVALID, "m355_arena_begin is not available on a tile-sharded context (its pictures are decoded from handles: m355_picture_arena_begin)");
+  hipSetDevice(c->device);
+  return arena_into(c, c->transient[c->next_transient], k, 0, false, pic);   /* the arena the next m355_submit_picture uses */
+}
+
+/* the same for the arenas of a RESIDENT picture (tile-sharded contexts decode from handles): handle -1 makes one */
+int m355_picture_arena_begin(m355_ctx* c, int h, m355_arena_caps* k, const m355_pic_params* pp, m355_picture* pic)
+{
+  if (!caps_ok(k, pic)) return -fail(M355_ERR_INVALID, "bad arena capacities");
+  const bool sharded = c->shard_n >= 1;
+  if (sharded && !pp) return -fail(M355_ERR_INVALID, "m355_picture_arena_begin: a tile-sharded context needs the picture parameters (room for the border units of other ranks)");
+  int halo_units = 0;
+  if (sharded) {
+    if (pp->num_tile_cols < 1 || pp->num_tile_rows < 1 || pp->num_tile_cols > M355_MAX_TILE_COLS || pp->num_tile_rows > M355_MAX_TILE_ROWS || pp->width < 8 || pp->height < 8)
+      return -fail(M355_ERR_INVALID, "m355_picture_arena_begin: bad picture parameters");
+    HaloLayout halo;
+    halo_layout(*pp, halo);
+    halo_units = halo.n_units;
+  }
+  hipSetDevice(c->device);
+  if (h < 0) {
+    for (size_t i = 0; i < c->resident.size(); i++) if (!c->resident[i].used && !c->resident[i].reserved) { h = (int)i; break; }
+    if (h < 0) { c->resident.push_back(Resident()); h = (int)c->resident.size() - 1; }
+    c->resident[h].reserved = true;
+  } else if (h >= (int)c->resident.size() || !(c->resident[h].used || c->resident[h].reserved)) return -fail(M355_ERR_INVALID, "bad picture handle");
+  const int rc = arena_into(c, c->resident[h], k, halo_units, sharded, pic);
+  return rc ? -rc : h;
 }
 
 int m355_submit_picture(m355_ctx* c, const m355_picture* pic)
@@ -2585,7 +2620,7 @@ int m355_wait(m355_ctx* c)
 int m355_picture_upload(m355_ctx* c, const m355_picture* pic)
 {
   int idx = -1;
-  for (size_t i = 0; i < c->resident.size(); i++) if (!c->resident[i].used) { idx = (int)i; break; }
+  for (size_t i = 0; i < c->resident.size(); i++) if (!c->resident[i].used && !c->resident[i].reserved) { idx = (int)i; break; }
   if (idx < 0) { c->resident.push_back(Resident()); idx = (int)c->resident.size() - 1; }
   int rc = upload(c, c->resident[idx], pic);
   if (rc) { resident_free(c->resident[idx]); return -rc; }
@@ -2595,7 +2630,7 @@ int m355_picture_upload(m355_ctx* c, const m355_picture* pic)
    fit, no synchronisation of the context): how a caller cycles a few handles through a stream of pictures */
 int m355_picture_replace(m355_ctx* c, int h, const m355_picture* pic)
 {
-  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !pic) return fail(M355_ERR_INVALID, "bad picture handle");
+  if (h < 0 || h >= (int)c->resident.size() || !(c->resident[h].used || c->resident[h].reserved) || !pic) return fail(M355_ERR_INVALID, "bad picture handle");
   Resident& r = c->resident[h];
   hipSetDevice(c->device);
   if (r.done_pending && r.ev_done) { HIPCHK(hipEventSynchronize(r.ev_done)); r.done_pending = false; }
@@ -2605,12 +2640,15 @@ int m355_picture_replace(m355_ctx* c, int h, const m355_picture* pic)
     if (r.xscratch) { hipFree(r.xscratch); r.xscratch = nullptr; }
     r.peers.clear();
   }
-  return upload(c, r, pic);
+  const int rc = upload(c, r, pic);
+  r.arena = false;                                          /* pointers handed out by m355_picture_arena_begin are spent */
+  if (!rc) r.reserved = false;
+  return rc;
 }
 
 int m355_picture_release(m355_ctx* c, int h)
 {
-  if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");
+  if (h < 0 || h >= (int)c->resident.size() || !(c->resident[h].used || c->resident[h].reserved)) return fail(M355_ERR_INVALID, "bad picture handle");
   hipSetDevice(c->device);
   sync_all(c);
   resident_free(c->resident[h]);

@@ -8,6 +8,7 @@ static inline void d_touch(const void*, unsigned*) {}
 static inline void d_st_nt4(void* p, unsigned v) { *(unsigned*)p = v; }
 static inline void d_st_nt8(void* p, unsigned v0, unsigned v1) { ((unsigned*)p)[0] = v0; ((unsigned*)p)[1] = v1; }
 #define M355_PIN_S(x) ((void)0)
+#define M355_PIN_V(x) ((void)0)
 #define M355_COMPILER_FENCE() ((void)0)
 
 #define M355_SPIN_LIMIT 4u
@@ -17,6 +18,9 @@ static inline void d_ldg12(const void* p, unsigned* o) { memcpy(o, p, 12); }
 static inline void d_ldg8(const void* p, unsigned* o) { memcpy(o, p, 8); }
 static inline unsigned d_ldg4(const void* p) { unsigned v; memcpy(&v, p, 4); return v; }
 static inline unsigned d_ldg2(const void* p) { unsigned short v; memcpy(&v, p, 2); return v; }
+static inline void d_stg16(void* p, const unsigned* v) { memcpy(p, v, 16); }
+static inline void d_stg8(void* p, const unsigned* v) { memcpy(p, v, 8); }
+static inline void d_stg4(void* p, unsigned v) { memcpy(p, &v, 4); }
 static inline unsigned d_pack_lo16(unsigned lo, unsigned hi) { return (lo & 0xFFFFu) | (hi << 16); }
 static inline unsigned d_pack_hi16(unsigned lo, unsigned hi) { return (lo >> 16) | (hi & 0xFFFF0000u); }
 static inline unsigned d_pk_shl16(unsigned v, int s) { return ((v << s) & 0xFFFFu) | ((((v >> 16) << s) & 0xFFFFu) << 16); }
