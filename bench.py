@@ -208,12 +208,12 @@ def main():
 
     # (4) PCIe-inclusive: the lists are written into the library's pinned arena (m355_arena_begin; libm355synth copies them
     # there with 16 threads, standing in for the parser's recorder threads), then validated, scheduled, copied to the device
-    # and decoded, every step.  "submit_only": the same with the lists already lying in the arenas (depth + 3 rotate).
+    # and decoded, every step.  "submit_only": the same with the lists already lying in the arenas (three rotate).
     with_upload = None
     if not args.no_with_upload and rank == 0:
         ctx.set_pipeline_depth(args.pipeline_depth)
         st = {}
-        for _ in range(args.pipeline_depth + 4):   # the rotating arenas (pipeline depth + 3) are allocated on first use
+        for _ in range(13):                  # the rotating arenas (three; M355_TRANSIENT_RING up to 12) are allocated on first use
             ctx.submit_in_place(pic, state=st)
         ctx.wait()
         up_steps = max(side_steps, 100)      # (a host-side rate: 20 steps are 20 ms of wall clock, too few to be stable)
@@ -390,9 +390,10 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
                                                  int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
             refs.append(f)
         # pictures in flight, like the main line: `depth` copies of the picture's lists with their own destination frames go round the lanes
-        # (one lane more than the unsharded line: a sharded picture is a longer chain — nine small pack / unpack kernels and the
-        # exchanges between its phases — and needs one more picture beside it to keep the GPU full; measured 0.43 vs 0.47 ms at world 1)
-        depth = min(4, max(1, args.pipeline_depth) + 1) if args.pipeline_depth >= 2 else 1
+        # (as many as the unsharded line.  Round 2 gave the sharded picture — a longer chain: nine small pack / unpack kernels and the
+        # exchanges between its phases — one lane more, 0.43 vs 0.47 ms at world 1 then; with today's kernels the fourth lane costs what it
+        # costs the unsharded line: 0.489 ms with 4 in flight, 0.445 ms with 3, profiles/r04_af_variants_ring_sharded.txt)
+        depth = max(1, args.pipeline_depth)
         if os.environ.get("M355_BENCH_SHARD_DEPTH"):      # (A/B of the sharded leg's pictures in flight)
             depth = max(1, int(os.environ["M355_BENCH_SHARD_DEPTH"]))
         ctx.set_pipeline_depth(depth)

@@ -443,9 +443,8 @@ M355_API int m355_submit_picture(m355_ctx* ctx, const m355_picture* pic);
  * picture, say).  The parser's recorder threads write the lists there; the submitted m355_picture carries exactly those
  * pointers (pic->rbs = the 4x4 bin's region; the four size bins live in their own regions caps->rb_bin[0..3], filled in by
  * the call) and its real counts (<= the capacities): the submit then validates, derives its schedules and starts the
- * host-to-device copy without copying a byte on the host.  It waits for the picture that used this arena last (pipeline depth + 3
- * arenas rotate, so that a decoder that submits every picture is bound by the list copy, not by the ring; M355_TRANSIENT_RING=<n>
- * overrides).  dst_frame / ref_frames / pp / counts are the caller's to fill in. */
+ * host-to-device copy without copying a byte on the host.  It waits for the picture that used this arena last (three arenas
+ * rotate; M355_TRANSIENT_RING=<n> makes the ring longer — measured: no gain, the submitting thread is the bound).  dst_frame / ref_frames / pp / counts are the caller's to fill in. */
 typedef struct m355_arena_caps {
   int32_t n_slices, n_ctbs, n_cus, n_tus, n_pbs, n_wts, n_ibs;
   int32_t n_rbs[4];

@@ -191,17 +191,18 @@ struct m355_ctx {
   int dl_ev_next = 0;
   std::vector<Frame> frames;
   std::vector<Resident> resident;
-  /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes.  A slot is free again when
-     the decode of the lists it held has FINISHED, and with `depth` pictures in flight a picture finishes about (host phases + list
-     copy + depth decode times) after its m355_arena_begin: three slots made the ring, not PCIe or the GPU, the bound of a
-     submit-every-picture decoder (C5: 2.1 ms of latency / 3 = 0.7 ms per picture against 0.57 ms of list copy).  The ring in use is
-     depth + 3 slots (M355_TRANSIENT_RING=<n> overrides, 2..M355_TRANSIENT_MAX); slots allocate on first use. */
+  /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes; a slot is free again when the
+     decode of the lists it held has finished.  THREE slots: a longer ring (M355_TRANSIENT_RING=<n>, 2..M355_TRANSIENT_MAX; slots
+     allocate on first use) was measured and buys nothing — the submitting thread's own work per picture (list checks, schedules,
+     ~20 launches: 0.45 ms at 8K) is what bounds a submit-every-picture decoder, and with more slots it runs further ahead of the
+     three lanes, which costs more than it hides (C5 submit_only 0.74-0.79 ms with 3 slots, 0.80-0.94 with 4, 0.81-0.92 with 6:
+     profiles/r04_ai_submit_ring.txt). */
   Resident transient[M355_TRANSIENT_MAX];
   int next_transient = 0;
   int transient_ring() const
   {
     static const int env = getenv("M355_TRANSIENT_RING") ? atoi(getenv("M355_TRANSIENT_RING")) : 0;
-    const int n = env > 0 ? env : depth + 3;
+    const int n = env > 0 ? env : 3;
     return n < 2 ? 2 : (n > M355_TRANSIENT_MAX ? M355_TRANSIENT_MAX : n);
   }
   Frame work;                  /* pre-SAO working planes */

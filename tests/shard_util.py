@@ -86,26 +86,34 @@ def dist_sharded_decode(lib, pic, refs, device="cpu", stages=worklist.STAGE_ALL,
         ctx.close()
 
 
-def group_sharded_decode(lib, pic, refs, nranks, depth=1, gather=True, repeat=1):
+def group_sharded_decode(lib, pic, refs, nranks, depth=1, gather=True, repeat=1, in_place=False):
     """The in-process group (m355_group_*): nranks contexts on device 0 decode one picture, the exchanges are copies between the
     contexts' buffers.  -> per rank the downloaded destination planes (gather: every rank holds the whole picture; else only its
-    own tiles are meaningful).  depth > 1: `depth` copies of the lists / destination frames in flight."""
+    own tiles are meaningful).  depth > 1: `depth` copies of the lists / destination frames in flight.  in_place: every rank's lists
+    are recorded into its handle's pinned arena (m355_picture_arena_begin -> m355_picture_replace: no host copy in the library), and
+    recorded again into the same handle before every further round."""
     ctxs = [capi.Context(lib, 0) for _ in range(nranks)]
     grp = capi.Group(lib, ctxs)
     try:
         hs, dsts = [], []
+        up = (lambda c, s_: c.upload_in_place(s_, slack=1.3)) if in_place else (lambda c, s_: c.upload(s_))
+        shards = []
         for r, ctx in enumerate(ctxs):
             ctx.set_pipeline_depth(depth)
             per_h, per_d = [], []
             sp, dst = _setup_rank(ctx, pic, refs, r, nranks, "cpu")
-            per_h.append(ctx.upload(sp)); per_d.append(dst)
+            per_h.append(up(ctx, sp)); per_d.append(dst)
             for _ in range(depth - 1):
                 sp.dst_frame = ctx.frame_create_for(pic.pp[0])
                 per_d.append(sp.dst_frame)
-                per_h.append(ctx.upload(sp))
-            hs.append(per_h); dsts.append(per_d)
-        for _ in range(repeat):
+                per_h.append(up(ctx, sp))
+            hs.append(per_h); dsts.append(per_d); shards.append(sp)
+        for it in range(repeat):
             for k in range(depth):
+                if in_place and it:        # the handle's arena is recorded again (waits for its last decode only)
+                    for r, ctx in enumerate(ctxs):
+                        shards[r].dst_frame = dsts[r][k]
+                        assert ctx.upload_in_place(shards[r], handle=hs[r][k], slack=1.0 + 0.2 * it) == hs[r][k]
                 grp.decode([hs[r][k] for r in range(nranks)], gather)
         grp.wait()
         out = []

@@ -52,3 +52,18 @@ def test_group_in_one_process_matches_oracle(emu_lib, oracle, case, nranks):  # 
     want = oracle_decode(o, pic, refs)
     for r, got in enumerate(group_sharded_decode(emu_lib, pic, refs, nranks, repeat=2)):
         assert_planes_equal(got, want, "group rank %d of %d" % (r, nranks))
+
+
+IN_PLACE_CASES = [(CASES[1][0], 4, 1), (CASES[2][0], 2, 2), (CASES[6][0], 4, 1), (CASES[0][0], 1, 1)]
+
+
+@pytest.mark.parametrize("case,nranks,depth", IN_PLACE_CASES, ids=lambda v: ("%dx%d_seed%d" % (v["width"], v["height"], v["seed"])) if isinstance(v, dict) else "n%d" % v)
+def test_group_lists_recorded_in_place(emu_lib, oracle, case, nranks, depth):  # noqa: F811
+    """m355_picture_arena_begin: the in-place path of a tile-sharded context — every rank's lists are written into its handle's
+    pinned arena (room for the other ranks' border units behind cus[] / pbs[] sized from the picture parameters) and taken over by
+    m355_picture_replace without a host copy; the handles are recorded again before the second round"""
+    o = Oracle(oracle)
+    pic, refs = make_case(**case)
+    want = oracle_decode(o, pic, refs)
+    for r, got in enumerate(group_sharded_decode(emu_lib, pic, refs, nranks, depth=depth, repeat=2, in_place=True)):
+        assert_planes_equal(got, want, "in-place group rank %d of %d" % (r, nranks))
