@@ -81,7 +81,8 @@ namespace {
   X(m355_frame_upload) X(m355_frame_download) X(m355_submit_picture) X(m355_wait) X(m355_set_pipeline_depth) \
   X(m355_host_alloc) X(m355_host_free) X(m355_frame_hash) X(m355_arena_begin) X(m355_last_serial) X(m355_decode_status) \
   X(m355_frame_download_async) X(m355_frame_download_wait) \
-  X(m355_group_create) X(m355_group_destroy) X(m355_group_decode) X(m355_picture_upload) X(m355_picture_replace) X(m355_shard_owner_of_tile)
+  X(m355_group_create) X(m355_group_destroy) X(m355_group_decode) X(m355_picture_upload) X(m355_picture_replace) X(m355_shard_owner_of_tile) \
+  X(m355_picture_arena_begin)
 
 struct Api {
   void* handle = nullptr;
@@ -603,8 +604,12 @@ int submit_sharded(Glue* g, const m355_picture& pic, int dslot)
   g->rhandle_next = (g->rhandle_next + 1) % g->rhandle.size();
   const bool fresh = hs.empty();
   if (fresh) hs.assign((size_t)N, -1);
-  /* the ranks' lists are cut out side by side (each task reads the whole picture's lists once and keeps its rank's records; the
-     coefficients of the kept residual blocks are compacted), then uploaded one context after the other */
+  /* The ranks' lists are cut out side by side, IN PLACE: a counting pass per rank, then m355_picture_arena_begin hands out room in
+     the pinned arena of the rank's handle (with the border units of the other ranks behind cus[] / pbs[], sized from the picture
+     parameters) and the cut writes there — m355_picture_replace then copies nothing on the host (what the per-rank vectors and the
+     library's staging copy cost before: one more pass over every list).  Each task reads the whole picture's lists and keeps its
+     rank's records; the coefficients of the kept residual blocks are compacted.  M355_GLUE_RANKS_COPY=1: the vectors again. */
+  static const bool ranks_copy = getenv("M355_GLUE_RANKS_COPY") != nullptr;
   struct RankLists { std::vector<m355_cu> cus; std::vector<m355_tu> tus; std::vector<m355_pb> pbs; std::vector<m355_rb> rbs; std::vector<m355_ib> ibs;
                      std::vector<m355_ctb> ctbs; std::vector<uint32_t> coeffs; int rb_count[4]; };
   static std::vector<RankLists> L;                          /* (kept between pictures: one worker thread submits) */
@@ -612,6 +617,91 @@ int submit_sharded(Glue* g, const m355_picture& pic, int dslot)
   std::vector<uint32_t> order((size_t)pic.n_ctbs);
   for (int i = 0; i < pic.n_ctbs; i++) order[(size_t)i] = (uint32_t)i;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pic.ctbs[a].ib_start < pic.ctbs[b].ib_start; });
+  auto own_rb = [&](const m355_rb& rb) { return own(rb.cidx ? rb.x * sw : rb.x, rb.cidx ? rb.y * sh : rb.y); };
+  if (!ranks_copy) {
+    struct Cnt { int cus = 0, tus = 0, pbs = 0, rbs[4] = {0, 0, 0, 0}, ibs = 0; uint32_t coeffs = 0; };
+    std::vector<Cnt> cnt((size_t)N);
+    parallel_tasks((size_t)N, [&](size_t rr) {
+      const int r = (int)rr; Cnt& c = cnt[rr];
+      for (int i = 0; i < pic.n_cus; i++) c.cus += own(pic.cus[i].x, pic.cus[i].y) == r;
+      for (int i = 0; i < pic.n_tus; i++) c.tus += own(pic.tus[i].x, pic.tus[i].y) == r;
+      for (int i = 0; i < pic.n_pbs; i++) c.pbs += own(pic.pbs[i].x, pic.pbs[i].y) == r;
+      const m355_rb* src = pic.rbs;
+      for (int s = 0; s < 4; s++)
+        for (int i = 0; i < pic.rb_count[s]; i++, src++) if (own_rb(*src) == r) { c.rbs[s]++; c.coeffs += src->ncoeff; }
+      for (int ci = 0; ci < pic.n_ctbs; ci++) if (owner[(size_t)ci] == r) c.ibs += (int)pic.ctbs[ci].ib_count;
+    });
+    std::vector<m355_picture> rp((size_t)N);
+    std::vector<m355_arena_caps> caps((size_t)N);
+    for (int r = 0; r < N; r++) {                           /* (one context after the other: the arenas may have to grow) */
+      m355_arena_caps& k = caps[(size_t)r]; memset(&k, 0, sizeof(k));
+      const Cnt& c = cnt[(size_t)r];
+      k.n_slices = pic.n_slices; k.n_ctbs = pic.n_ctbs; k.n_cus = c.cus + 1; k.n_tus = c.tus + 1; k.n_pbs = c.pbs + 1; k.n_wts = pic.n_wts + 1; k.n_ibs = c.ibs + 1;
+      for (int s = 0; s < 4; s++) k.n_rbs[s] = c.rbs[s] + 1;
+      k.n_coeffs = c.coeffs + 1; k.n_pcm = pic.n_pcm + 1; k.scaling = pic.scaling_factors ? 1 : 0;
+      const int h = A->m355_picture_arena_begin(g->rctx[(size_t)r], fresh ? -1 : hs[(size_t)r], &k, &pic.pp, &rp[(size_t)r]);
+      if (h < 0) return -h;
+      hs[(size_t)r] = h;
+    }
+    parallel_tasks((size_t)N, [&](size_t rr) {
+      const int r = (int)rr;
+      m355_picture& q = rp[rr];
+      const m355_arena_caps& k = caps[rr];
+      /* picture-wide lists: slices, the CTB table (renumbered below), weights, PCM samples, scaling factors */
+      memcpy((void*)q.slices, pic.slices, sizeof(m355_slice) * (size_t)pic.n_slices);
+      if (pic.n_wts) memcpy((void*)q.wts, pic.wts, sizeof(m355_wt) * (size_t)pic.n_wts);
+      if (pic.n_pcm) memcpy((void*)q.pcm, pic.pcm, 2 * (size_t)pic.n_pcm);
+      if (pic.scaling_factors) memcpy((void*)q.scaling_factors, pic.scaling_factors, 6 * (16 + 64 + 256 + 1024));
+      m355_cu* cu = (m355_cu*)q.cus; m355_tu* tu = (m355_tu*)q.tus; m355_pb* pb = (m355_pb*)q.pbs; uint32_t* co = (uint32_t*)q.coeffs;
+      int n = 0;
+      for (int i = 0; i < pic.n_cus; i++) if (own(pic.cus[i].x, pic.cus[i].y) == r) cu[n++] = pic.cus[i];
+      q.n_cus = n; n = 0;
+      for (int i = 0; i < pic.n_tus; i++) if (own(pic.tus[i].x, pic.tus[i].y) == r) tu[n++] = pic.tus[i];
+      q.n_tus = n; n = 0;
+      for (int i = 0; i < pic.n_pbs; i++) if (own(pic.pbs[i].x, pic.pbs[i].y) == r) pb[n++] = pic.pbs[i];
+      q.n_pbs = n;
+      const m355_rb* src = pic.rbs;
+      uint32_t nco = 0;
+      for (int s = 0; s < 4; s++) {
+        m355_rb* dst = k.rb_bin[s];
+        int kept = 0;
+        for (int i = 0; i < pic.rb_count[s]; i++, src++)
+          if (own_rb(*src) == r) {
+            m355_rb rb = *src;
+            rb.coeff_ofs = nco;
+            memcpy(co + nco, pic.coeffs + src->coeff_ofs, 4 * (size_t)src->ncoeff);
+            nco += src->ncoeff;
+            dst[kept++] = rb;
+          }
+        q.rb_count[s] = kept;
+      }
+      q.n_coeffs = nco;
+      /* intra blocks: whole CTBs are kept or dropped; the kept CTBs' runs are renumbered (ascending ib_start = the order they lie in) */
+      m355_ctb* ct = (m355_ctb*)q.ctbs; m355_ib* ib = (m355_ib*)q.ibs;
+      memcpy(ct, pic.ctbs, sizeof(m355_ctb) * (size_t)pic.n_ctbs);
+      uint32_t nib = 0;
+      for (uint32_t ci : order) {
+        m355_ctb& c = ct[ci];
+        if (owner[ci] != r || !c.ib_count) { c.ib_start = 0; c.ib_count = 0; continue; }
+        memcpy(ib + nib, pic.ibs + c.ib_start, sizeof(m355_ib) * (size_t)c.ib_count);
+        c.ib_start = nib; nib += c.ib_count;
+      }
+      q.n_ibs = (int32_t)nib;
+      q.pp = pic.pp; q.n_slices = pic.n_slices; q.n_ctbs = pic.n_ctbs; q.n_wts = pic.n_wts; q.n_pcm = pic.n_pcm; q.res_len = pic.res_len;
+      if (!pic.scaling_factors) q.scaling_factors = nullptr;
+      q.dst_frame = pic.dst_frame;
+      for (int i = 0; i < M355_MAX_REF_FRAMES; i++) q.ref_frames[i] = pic.ref_frames[i];
+      if (r) {
+        q.dst_frame = g->rframe[(size_t)r - 1][(size_t)dslot];
+        for (int i = 0; i < M355_MAX_REF_FRAMES; i++) if (pic.ref_frames[i] >= 0) q.ref_frames[i] = g->rframe[(size_t)r - 1][(size_t)i];
+      }
+    });
+    for (int r = 0; r < N; r++) {
+      const int rc = A->m355_picture_replace(g->rctx[(size_t)r], hs[(size_t)r], &rp[(size_t)r]);
+      if (rc != M355_OK) return rc;
+    }
+    return A->m355_group_decode(g->group, hs.data(), 1);    /* (every rank ends up with the whole picture: it is a reference everywhere) */
+  }
   parallel_tasks((size_t)N, [&](size_t rr) {
     const int r = (int)rr;
     RankLists& l = L[rr];
@@ -623,7 +713,7 @@ int submit_sharded(Glue* g, const m355_picture& pic, int dslot)
     for (int s = 0; s < 4; s++) {
       int kept = 0;
       for (int i = 0; i < pic.rb_count[s]; i++, src++)
-        if (own(src->cidx ? src->x * sw : src->x, src->cidx ? src->y * sh : src->y) == r) {
+        if (own_rb(*src) == r) {
           m355_rb rb = *src;
           rb.coeff_ofs = (uint32_t)l.coeffs.size();
           l.coeffs.insert(l.coeffs.end(), pic.coeffs + src->coeff_ofs, pic.coeffs + src->coeff_ofs + src->ncoeff);

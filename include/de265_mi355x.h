@@ -585,8 +585,9 @@ M355_API int m355_shard_time_exchange(m355_ctx* ctx, int handle, int which, int 
 M355_API int m355_shard_peers(const m355_pic_params* pp, int rank, int nranks, int* peers, int max_peers);
 
 /* Per-stage device timing from HIP events recorded on the context's OWN stream around every decode
- * enqueued since m355_timing_reset(): averages in milliseconds, stage order
- * [meta, inter, residual, intra, deblock, sao]. m355_timing_collect() waits for the work. */
+ * enqueued between m355_timing_reset() and m355_timing_collect(): averages in milliseconds, stage order
+ * [meta, inter, residual, intra, deblock, sao]. m355_timing_collect() waits for the work and ends the window: decodes outside a
+ * window record no stage events (seven event packets per picture are a diagnostic, not part of the decode). */
 M355_API int m355_timing_reset(m355_ctx* ctx);
 M355_API int m355_timing_collect(m355_ctx* ctx, int* n_decodes, float* total_ms, float stage_ms[6]);
 M355_API void* m355_stream(m355_ctx* ctx);   /* hipStream_t of the context's active lane (the lane of the last decode / phase call) */

@@ -236,6 +236,7 @@ struct m355_ctx {
   std::vector<uint8_t> ev_fused;   /* per timed decode: the residual stage ran first (launch_prediction) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
+  bool timing_on = false;      /* between m355_timing_reset and m355_timing_collect: decodes record their seven stage events */
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
   /* m355_decode_batch: ring of picture-record arrays (pinned staging + device copy + the batch's ticket word); a slot's event is
      recorded behind the batch's k_intra — what the pictures' filter stages wait for, and what guards the slot's reuse */
@@ -1798,7 +1799,8 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
   }
   hipStream_t st = c->stream;
   hipEvent_t* ev = nullptr;
-  if (with_intra) {                                        /* (a batch's decodes are not stage-timed: their intra stage is shared) */
+  static const bool always_time = getenv("M355_ALWAYS_TIME") && atoi(getenv("M355_ALWAYS_TIME"));   /* (A/B: the stage events on every decode, as before round 4) */
+  if (with_intra && (c->timing_on || always_time)) {                        /* (a batch's decodes are not stage-timed: their intra stage is shared) */
     if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
     while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
     ev = &c->evs[c->ev_used * 7];
@@ -2787,11 +2789,12 @@ int m355_decode_batch(m355_ctx* c, const int* handles, int n)
 }
 int m355_set_stages(m355_ctx* c, int mask) { c->stages = mask & M355_STAGE_ALL; return M355_OK; }
 
-int m355_timing_reset(m355_ctx* c) { c->ev_used = 0; return M355_OK; }
+int m355_timing_reset(m355_ctx* c) { c->ev_used = 0; c->timing_on = true; return M355_OK; }
 
 /* averages over every decode enqueued since m355_timing_reset(); waits for them to finish */
 int m355_timing_collect(m355_ctx* c, int* n_decodes, float* total_ms, float stage_ms[6])
 {
+  c->timing_on = false;
   if (c->ev_used == 0) return fail(M355_ERR_INVALID, "nothing decoded since the last timing reset");
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
