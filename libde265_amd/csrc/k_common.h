@@ -161,9 +161,9 @@ struct DevPic {
   uint32_t res_fused_base[4];
   uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable; bit 15 = the CTB's slice has SAO on for the component (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
-  uint32_t* job_base;               /* [256-PB chunk][3]: first job index of the chunk per range (uni, bi, edge): k_job_count leaves the chunk's
-                                       counts here, k_job_scan turns them into the prefix sums k_meta_pb reads (lane scratch) */
-  uint32_t* job_tot;                /* [0] one-list jobs, [1] + bi-predicted = where the EDGE range starts, [2] all jobs (k_job_scan; clamped to jobs_cap) */
+  uint32_t* job_base;               /* [256-PB chunk][3]: the chunk's jobs per range (uni, bi, edge): k_job_count leaves the counts here, every
+                                       workgroup of k_meta_pb sums the ones in front of its chunk (lane scratch) */
+  uint32_t* job_tot;                /* [0] one-list jobs, [1] + bi-predicted = where the EDGE range starts, [2] all jobs (k_meta_pb's workgroup 0; clamped to jobs_cap) */
   uint32_t jobs_cap;                /* entries of jobs[]: >= what any list of disjoint prediction blocks produces (runtime.hip prepare) */
   int fill_pb_of_in_meta;           /* 1: k_meta_pb fills pb_of (inter stage off); 0: k_inter_jobs does, two units per job */
   /* (jobs [0, job_tot[0]): one list; [job_tot[0], job_tot[1]): bi-predicted; [job_tot[1], job_tot[2]): EDGE = clamped loads) */
@@ -259,8 +259,10 @@ struct HostBatch { const DevPic* host; const DevPic* dev; int n; uint32_t on; };
 void m355_launch_validate(const DevPic& p, hipStream_t st);   /* device-side validation of the work lists (k_meta.hip) */
 void m355_launch_meta(const DevPic& p, hipStream_t st);
 void m355_launch_clear_gated(const DevPic& p, void* ptr, size_t bytes, hipStream_t st);   /* zero fill behind the decode's gate (bytes: a multiple of 16) */
-void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for k_inter */
-void m355_launch_meta_planes(const DevPic& p, hipStream_t st);   /* planes for intra / deblock / SAO */
+void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for k_inter (= the two below) */
+void m355_launch_job_count(const DevPic& p, bool clear_planes, hipStream_t st);   /* ... its first launch, optionally with the zero fill of the metadata planes */
+void m355_launch_job_list(const DevPic& p, hipStream_t st);      /* ... the rest */
+void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared);   /* planes for intra / deblock / SAO (cleared: k_job_count filled them) */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */

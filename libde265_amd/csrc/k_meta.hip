@@ -9,10 +9,10 @@
 #include "k_common.h"
 
 /* one thread per CU: CU-index plane, per-CU edge decisions (deblock.cc:172-210), PB edges */
-__device__ __forceinline__ void k_meta_cu_body(const DevPic& p)
+__device__ __forceinline__ void k_meta_cu_body(const DevPic& p, const int blk)
 {
   M355_GATE(p);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blk * blockDim.x + threadIdx.x;
   if (i >= p.n_cus) return;
   const m355_cu cu = p.cus[i];
   const int x0 = cu.x, y0 = cu.y;
@@ -70,10 +70,10 @@ __device__ __forceinline__ void k_meta_cu_body(const DevPic& p)
 }
 
 /* one thread per transform-tree leaf: transform edges + cbf_luma (deblock.cc:33-63, slice.cc:2958) */
-__device__ __forceinline__ void k_meta_tu_body(const DevPic& p)
+__device__ __forceinline__ void k_meta_tu_body(const DevPic& p, const int blk)
 {
   M355_GATE(p);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blk * blockDim.x + threadIdx.x;
   if (i >= p.n_tus) return;
   const m355_tu tu = p.tus[i];
   const int n4 = (1 << tu.log2_size) >> 2;
@@ -104,8 +104,9 @@ __device__ __forceinline__ void k_meta_tu_body(const DevPic& p)
 
 /* ---- job counts on the device (the host no longer reads the PB list of a picture recorded in place) ----
  * k_job_count: one workgroup per 256-PB chunk (= one k_meta_pb workgroup): the chunk's jobs per range -> job_base[chunk][3].
- * k_job_scan : ONE workgroup turns the counts into the chunks' first job indices (ranges one after the other: one list, two
- *              lists, picture edge) and leaves the range ends in job_tot[0..2].  A malformed record counts nothing here (k_validate
+ * k_meta_pb  : every workgroup sums the counts of the chunks in front of its own (and all of them, for the range starts: one list, two
+ *              lists, picture edge — one after the other) itself: 3 x n_chunks words out of the L2 per workgroup instead of a
+ *              one-workgroup scan launch on the picture's critical path; workgroup 0 leaves the range ends in job_tot[0..2].  A malformed record counts nothing here (k_validate
  *              rejects the picture); lists whose blocks overlap can exceed jobs[]: the ends are clamped and k_meta_pb drops what
  *              does not fit (memory-safe, the picture is garbage either way). */
 __device__ __forceinline__ int d_pb_jobs(const m355_pb& pb)
@@ -113,9 +114,19 @@ __device__ __forceinline__ int d_pb_jobs(const m355_pb& pb)
   if (pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3)) return 0;
   return (pb.w >> 2) * ((pb.h + 7) >> 3);
 }
-__global__ void __launch_bounds__(256) k_job_count(DevPic p)
+/* 16-byte units of edge_tu | edge_pb | cb_cu (prepare() in runtime.hip: cb_cu starts at the next multiple of 64, 64 spare bytes behind) */
+__host__ __device__ static inline size_t d_meta_fill16(const DevPic& p) { return ((((size_t)2 * p.w4 * p.h4 + 63) & ~(size_t)63) + (size_t)p.wcb * p.hcb * 4 + 15) / 16; }
+/* clear_planes: the launch also zero-fills the metadata planes (edge_tu | edge_pb | cb_cu) that k_meta_planes scatters into — it is the
+   first kernel of an inter picture on its lane's main stream, in FRONT of the fork of the side stream: one launch less per picture
+   than a fill of its own (a packet costs about 2 us of pipeline time, profiles/r04_aj_*) */
+__global__ void __launch_bounds__(256) k_job_count(DevPic p, int clear_planes)
 {
   M355_GATE(p);
+  if (clear_planes) {
+    const size_t n16 = d_meta_fill16(p);
+    uint4* q = (uint4*)p.edge_tu;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) q[k] = make_uint4(0, 0, 0, 0);
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   int cnt[3] = {0, 0, 0};
   if (i < p.n_pbs) {
@@ -134,39 +145,6 @@ __global__ void __launch_bounds__(256) k_job_count(DevPic p)
   __syncthreads();
   if (threadIdx.x < 3) p.job_base[blockIdx.x * 3 + threadIdx.x] = (uint32_t)(s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x]);
 }
-__global__ void __launch_bounds__(1024) k_job_scan(DevPic p, int n_chunks)
-{
-  M355_GATE(p);
-  __shared__ uint32_t s_sum[3][1024];
-  const int t = threadIdx.x;
-  const int per = (n_chunks + 1023) / 1024, c0 = t * per, c1 = min(n_chunks, c0 + per);
-  uint32_t mine[3] = {0, 0, 0};
-  for (int c = c0; c < c1; c++)
-#pragma unroll
-    for (int k = 0; k < 3; k++) mine[k] += p.job_base[c * 3 + k];
-#pragma unroll
-  for (int k = 0; k < 3; k++) s_sum[k][t] = mine[k];
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {        /* inclusive scan over the threads' sums */
-    uint32_t v[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) v[k] = t >= d ? s_sum[k][t - d] : 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 3; k++) s_sum[k][t] += v[k];
-    __syncthreads();
-  }
-  const uint32_t nu = s_sum[0][1023], nb = s_sum[1][1023], ne = s_sum[2][1023];
-  uint32_t run[3] = {s_sum[0][t] - mine[0], nu + s_sum[1][t] - mine[1], nu + nb + s_sum[2][t] - mine[2]};
-  for (int c = c0; c < c1; c++)
-#pragma unroll
-    for (int k = 0; k < 3; k++) { const uint32_t n = p.job_base[c * 3 + k]; p.job_base[c * 3 + k] = run[k]; run[k] += n; }
-  if (t == 0) {
-    const uint32_t cap = p.jobs_cap;
-    p.job_tot[0] = min(nu, cap); p.job_tot[1] = min(nu + nb, cap); p.job_tot[2] = min(nu + nb + ne, cap);
-  }
-}
-
 /* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) and the job list of
  * k_inter_jobs: (w/4) x ceil(h/8) jobs per PB, row block major so consecutive jobs are horizontally
  * adjacent; three ranges (one-list, bi-predicted, picture-edge jobs), each in PB order. */
@@ -198,12 +176,43 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   const int wave = threadIdx.x >> 6;
   if (lane == 63) { s_wtot[wave][0] = incl[0]; s_wtot[wave][1] = incl[1]; s_wtot[wave][2] = incl[2]; }
   __syncthreads();
-  uint32_t base[3];
+  /* the chunk's first job per range: sum of the counts (k_job_count) of the chunks before it + where the range starts */
+  __shared__ uint32_t s_red[4][6];
+  {
+    uint32_t acc[6] = {0, 0, 0, 0, 0, 0};                    /* [0..2] all chunks, [3..5] the chunks in front of this one */
+    for (int ch = (int)threadIdx.x; ch < (int)gridDim.x; ch += 256) {
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    uint32_t bsum = p.job_base[blockIdx.x * 3 + k];
-    for (int w = 0; w < wave; w++) bsum += (uint32_t)s_wtot[w][k];
-    base[k] = bsum;
+      for (int k = 0; k < 3; k++) {
+        const uint32_t n = p.job_base[ch * 3 + k];
+        acc[k] += n;
+        acc[3 + k] += ch < (int)blockIdx.x ? n : 0u;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) acc[k] += (uint32_t)__shfl_xor((int)acc[k], d, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) s_red[wave][k] = acc[k];
+    }
+  }
+  __syncthreads();
+  uint32_t base[3];
+  {
+    uint32_t tot[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) tot[k] = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
+    const uint32_t nu = tot[0], nb = tot[1], ne = tot[2];
+    base[0] = tot[3]; base[1] = nu + tot[4]; base[2] = nu + nb + tot[5];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const uint32_t cap = p.jobs_cap;
+      p.job_tot[0] = min(nu, cap); p.job_tot[1] = min(nu + nb, cap); p.job_tot[2] = min(nu + nb + ne, cap);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      for (int w = 0; w < wave; w++) base[k] += (uint32_t)s_wtot[w][k];
   }
   /* emit the wave's jobs cooperatively: slot t of the wave's total belongs to the PB found by a binary
      search over the wave's exclusive scan (shuffles), so a 64x64 PB (128 jobs) costs the wave two
@@ -243,10 +252,10 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
  * another tile with loop_filter_across_tiles off.  Reproduces the reference's quirk of looking up the
  * CTB's own slice address with COMPONENT coordinates used as luma coordinates (sao.cc:56), which is
  * why the centre CTB has a bit too.  k_sao then needs no dependent global loads per border sample. */
-__device__ __forceinline__ void k_meta_sao_body(const DevPic& p)
+__device__ __forceinline__ void k_meta_sao_body(const DevPic& p, const int blk)
 {
   M355_GATE(p);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blk * blockDim.x + threadIdx.x;
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
   if (i >= p.nCtb * nc) return;
   const int c = i / p.nCtb, ctb = i - c * p.nCtb;
@@ -276,23 +285,35 @@ __device__ __forceinline__ void k_meta_sao_body(const DevPic& p)
 }
 
 /* the inter stage needs only the job list (+ pb_of when the inter stage is off) */
-void m355_launch_meta_jobs(const DevPic& p, hipStream_t st)
+void m355_launch_job_count(const DevPic& p, bool clear_planes, hipStream_t st)
+{
+  if (!p.n_pbs) return;
+  hipLaunchKernelGGL(k_job_count, dim3((p.n_pbs + 255) / 256), dim3(256), 0, st, p, clear_planes ? 1 : 0);
+}
+void m355_launch_job_list(const DevPic& p, hipStream_t st)       /* behind m355_launch_job_count */
 {
   if (!p.n_pbs) return;
   const int n_chunks = (p.n_pbs + 255) / 256;
-  hipLaunchKernelGGL(k_job_count, dim3(n_chunks), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(k_job_scan, dim3(1), dim3(1024), 0, st, p, n_chunks);
   hipLaunchKernelGGL(k_meta_pb, dim3(n_chunks), dim3(256), 0, st, p);
 }
+void m355_launch_meta_jobs(const DevPic& p, hipStream_t st)
+{
+  m355_launch_job_count(p, false, st);
+  m355_launch_job_list(p, st);
+}
 
-/* 16-byte units of edge_tu | edge_pb | cb_cu (prepare() in runtime.hip: cb_cu starts at the next multiple of 64, 64 spare bytes behind) */
-__host__ __device__ static inline size_t d_meta_fill16(const DevPic& p) { return ((((size_t)2 * p.w4 * p.h4 + 63) & ~(size_t)63) + (size_t)p.wcb * p.hcb * 4 + 15) / 16; }
-__global__ void __launch_bounds__(256) k_meta_cu(DevPic p) { k_meta_cu_body(p); }
-__global__ void __launch_bounds__(256) k_meta_tu(DevPic p) { k_meta_tu_body(p); }
-__global__ void __launch_bounds__(256) k_meta_sao(DevPic p) { k_meta_sao_body(p); }
-__global__ void __launch_bounds__(256) k_meta_cu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_cu_body(p); }
-__global__ void __launch_bounds__(256) k_meta_tu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_tu_body(p); }
-__global__ void __launch_bounds__(256) k_meta_sao_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_sao_body(p); }
+/* the CU plane + PB edges and the SAO neighbour masks as ONE launch (independent scatters: blocks [0, nb_cu) walk the CUs, the rest
+   the CTBs); the transform edges follow in a launch of their own — a leaf looks its CU up in the plane the first launch wrote */
+__global__ void __launch_bounds__(256) k_meta_planes(DevPic p, int nb_cu)
+{
+  const int b = (int)blockIdx.x;
+  if (b < nb_cu) k_meta_cu_body(p, b);
+  else k_meta_sao_body(p, b - nb_cu);
+}
+__global__ void __launch_bounds__(256) k_meta_tu(DevPic p) { k_meta_tu_body(p, (int)blockIdx.x); }
+__global__ void __launch_bounds__(256) k_meta_cu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_cu_body(p, (int)blockIdx.x); }
+__global__ void __launch_bounds__(256) k_meta_tu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_tu_body(p, (int)blockIdx.x); }
+__global__ void __launch_bounds__(256) k_meta_sao_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_sao_body(p, (int)blockIdx.x); }
 /* the zero fill in front of them (one plane of the grid per picture; the region is 16-byte aligned and padded, as below) */
 __global__ void __launch_bounds__(256) k_meta_fill_batch(DevBatch b)
 {
@@ -303,14 +324,14 @@ __global__ void __launch_bounds__(256) k_meta_fill_batch(DevBatch b)
 }
 
 /* metadata planes for intra availability, deblocking and SAO (not read by k_inter / k_residual) */
-void m355_launch_meta_planes(const DevPic& p, hipStream_t st)
+void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared)
 {
   /* edge_tu, edge_pb (sparse writers) and cb_cu (robustness against uncovered areas) live in ONE allocation: one
-     fill.  pb_of needs none: it is only read where both sides are inter-coded, i.e. covered by a PB. */
-  hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4 * 2 + (size_t)p.wcb * p.hcb * 4 + 64, st);
-  if (p.n_cus) hipLaunchKernelGGL(k_meta_cu, dim3((p.n_cus + 255) / 256), dim3(256), 0, st, p);
+     fill (`cleared`: k_job_count did it).  pb_of needs none: it is only read where both sides are inter-coded, i.e. covered by a PB. */
+  if (!cleared) hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4 * 2 + (size_t)p.wcb * p.hcb * 4 + 64, st);
+  const int nb_cu = (p.n_cus + 255) / 256, nb_sao = (p.pp.flags & M355_PF_SAO_ENABLED) ? (p.nCtb * 3 + 255) / 256 : 0;
+  if (nb_cu + nb_sao) hipLaunchKernelGGL(k_meta_planes, dim3(nb_cu + nb_sao), dim3(256), 0, st, p, nb_cu);
   if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
-  if (p.pp.flags & M355_PF_SAO_ENABLED) hipLaunchKernelGGL(k_meta_sao, dim3((p.nCtb * 3 + 255) / 256), dim3(256), 0, st, p);
 }
 
 void m355_launch_meta_planes_batch(const HostBatch& b, hipStream_t st)
@@ -346,7 +367,7 @@ void m355_launch_clear_gated(const DevPic& p, void* ptr, size_t bytes, hipStream
 
 void m355_launch_meta(const DevPic& p, hipStream_t st)
 {
-  m355_launch_meta_planes(p, st);
+  m355_launch_meta_planes(p, st, false);
   m355_launch_meta_jobs(p, st);
 }
 

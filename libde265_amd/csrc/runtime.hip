@@ -50,14 +50,20 @@ static int fail(int code, const char* fmt, ...)
 #define M355_MAX_LANES 32  /* pictures in flight per context (m355_set_pipeline_depth) */
 #define M355_TRANSIENT_MAX 12 /* staging arenas of m355_submit_picture (m355_ctx::transient_ring) */
 
+/* A MARK = "everything enqueued on `stream` up to here", one event of the context's ring (ev_mark / ev_wait / ev_sync below).  The
+ * objects a decode touches — destination and reference frames, its lists, its lane, its status slot — all remember the SAME mark
+ * behind its last kernel: one event packet per decode instead of one per object (each costs about 2 us of pipeline time on this
+ * runtime, profiles/r04_aj_stage_events_ab.txt). */
+struct EvRef { unsigned long long ticket = 0; hipStream_t stream = nullptr; };
+#define M355_EV_RING 256
+
 struct Frame {
   bool used = false;
   int w = 0, h = 0, cf = 0, bdl = 0, bdc = 0;
   int pw[3] = {0, 0, 0}, ph[3] = {0, 0, 0}, stride[3] = {0, 0, 0}, bpp[3] = {1, 1, 1};
   void* plane[3] = {nullptr, nullptr, nullptr};
   /* pictures in flight on different lanes (m355_set_pipeline_depth): last writer / last readers per lane */
-  hipEvent_t ev_wr = nullptr, ev_rd[M355_MAX_LANES] = {};
-  bool wr_pending = false, rd_pending[M355_MAX_LANES] = {};
+  EvRef wr, rd[M355_MAX_LANES];
   /* a download in flight on the context's copy stream (m355_frame_download_async): the next writer of the frame waits for it */
   hipEvent_t ev_dl = nullptr;
   bool dl_pending = false;
@@ -106,9 +112,8 @@ static void frame_free(Frame& f)
   if (f.ev_tiled) hipEventDestroy(f.ev_tiled);
   f.ev_tiled = nullptr; f.tiled_valid = false;
 #endif
-  if (f.ev_wr) hipEventDestroy(f.ev_wr);
-  for (int k = 0; k < M355_MAX_LANES; k++) { if (f.ev_rd[k]) hipEventDestroy(f.ev_rd[k]); f.ev_rd[k] = nullptr; f.rd_pending[k] = false; }
-  f.ev_wr = nullptr; f.wr_pending = false;
+  f.wr = EvRef();
+  for (int k = 0; k < M355_MAX_LANES; k++) f.rd[k] = EvRef();
   f.ev_dl = nullptr; f.dl_pending = false; f.wr_stream = nullptr;
   f.used = false;
 }
@@ -138,9 +143,8 @@ struct Resident {
   size_t xb_bytes[4] = {0, 0, 0, 0};
   void* xscratch = nullptr;
   std::vector<int> peers;      /* ranks this rank exchanges halos with */
-  hipEvent_t ev_up = nullptr;  /* lists copied to the device (decodes on the other lane wait for it) */
-  hipEvent_t ev_done = nullptr; /* last decode of these lists finished: the arenas may be overwritten */
-  bool done_pending = false;
+  EvRef up;                    /* lists copied to the device (decodes on another lane continue behind it) */
+  EvRef done;                  /* last decode of these lists: behind it the arenas may be overwritten */
   bool fresh = false;          /* uploaded and not decoded since: nothing in flight reads its reference table */
   bool arena = false;          /* m355_arena_begin handed out list pointers into `host`: the next upload of lists that sit there copies nothing */
   m355_arena_caps caps;        /* ... with room for this many entries */
@@ -164,7 +168,7 @@ struct Lane {
   /* intra pictures on lanes 3.. run on a stream of the lane's priority class (own hardware queues, lane_class below); the lane's
      scratch is shared by both streams: a decode waits for the lane's previous one when that ran on the other stream */
   hipStream_t stream_hi = nullptr, last_stream = nullptr;
-  hipEvent_t ev_last = nullptr;
+  EvRef last;                  /* behind the lane's last decode */
   Frame work;
   uint32_t *pb_of = nullptr, *ticket = nullptr, *timeout = nullptr;
   unsigned long long* edge = nullptr;   /* k_intra halo granules */
@@ -186,7 +190,12 @@ struct m355_ctx {
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
   hipStream_t stream_hi = nullptr, last_stream = nullptr;   /* (of the active lane, as in Lane) */
-  hipEvent_t ev_last = nullptr;
+  EvRef last;
+  /* the ring of marks (EvRef): a slot is taken over M355_EV_RING marks later, behind a host wait for its old mark — so "the slot
+     carries another ticket" means "that mark has passed" */
+  struct EvSlot { hipEvent_t ev = nullptr; unsigned long long ticket = 0; };
+  EvSlot evring[M355_EV_RING];
+  unsigned long long ev_ticket = 0;
   std::vector<hipEvent_t> dl_evs;          /* m355_frame_download_async: ring of completion events */
   int dl_ev_next = 0;
   std::vector<Frame> frames;
@@ -220,7 +229,7 @@ struct m355_ctx {
   uint32_t epoch = 0;
   /* per-decode status (m355_decode_status): the last M355_STATUS_RING decodes; a device-validated decode copies its lane's gate
      words into `words` (pinned) behind its last kernel */
-  struct Status { unsigned long long serial = 0; uint32_t epoch = 0; bool validated = false, reported = false; hipEvent_t ev = nullptr; };
+  struct Status { unsigned long long serial = 0; uint32_t epoch = 0; bool validated = false, reported = false; EvRef done; };
   Status status[M355_STATUS_RING];
   uint32_t* status_words = nullptr;   /* pinned: 4 words per ring slot = the lane's timeout[0..3] at the end of the decode */
   unsigned long long serial = 0;
@@ -253,8 +262,41 @@ struct m355_ctx {
                      std::vector<uint32_t> ctb_ts, ts2rs; std::vector<uint16_t> tile_id; } scan;
 };
 
-#define LANE_FIELDS(X) X(stream) X(stream2) X(stream_hi) X(last_stream) X(ev_last) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
+#define LANE_FIELDS(X) X(stream) X(stream2) X(stream_hi) X(last_stream) X(last) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
   X(resbuf) X(jobs) X(sao_nb) X(iplan) X(res_map) X(cap_resmap) X(job_base) X(cap_jobbase) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
+/* mark the point the stream has reached (one event packet); -> *out */
+static int ev_mark(m355_ctx* c, hipStream_t st, EvRef* out)
+{
+  const unsigned long long t = ++c->ev_ticket;
+  m355_ctx::EvSlot& e = c->evring[t % M355_EV_RING];
+  if (!e.ev) { if (hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed"); }
+  else if (e.ticket) hipEventSynchronize(e.ev);            /* the slot's old mark, M355_EV_RING marks ago (passed long since: this is the ring's invariant, not a wait) */
+  if (hipEventRecord(e.ev, st) != hipSuccess) return fail(M355_ERR_HIP, "hipEventRecord failed");
+  e.ticket = t;
+  out->ticket = t; out->stream = st;
+  return M355_OK;
+}
+/* `st` continues behind the mark: nothing to enqueue when the mark has passed or lies on `st` itself (stream order) */
+static void ev_wait(m355_ctx* c, hipStream_t st, const EvRef& r)
+{
+  if (!r.ticket || r.stream == st) return;
+  const m355_ctx::EvSlot& e = c->evring[r.ticket % M355_EV_RING];
+  if (e.ticket == r.ticket) hipStreamWaitEvent(st, e.ev, 0);
+}
+/* the host waits for the mark / asks whether it has passed */
+static hipError_t ev_sync(m355_ctx* c, const EvRef& r)
+{
+  if (!r.ticket) return hipSuccess;
+  const m355_ctx::EvSlot& e = c->evring[r.ticket % M355_EV_RING];
+  return e.ticket == r.ticket ? hipEventSynchronize(e.ev) : hipSuccess;
+}
+static hipError_t ev_query(m355_ctx* c, const EvRef& r)
+{
+  if (!r.ticket) return hipSuccess;
+  const m355_ctx::EvSlot& e = c->evring[r.ticket % M355_EV_RING];
+  return e.ticket == r.ticket ? hipEventQuery(e.ev) : hipSuccess;
+}
+
 static void select_lane(m355_ctx* c, int lane)
 {
   if (lane == c->active) return;
@@ -319,7 +361,6 @@ static void lane_destroy(Lane& l)
   if (l.ev_fork2) hipEventDestroy(l.ev_fork2);
   if (l.ev_join) hipEventDestroy(l.ev_join);
   if (l.stream_hi) { hipStreamSynchronize(l.stream_hi); hipStreamDestroy(l.stream_hi); }
-  if (l.ev_last) hipEventDestroy(l.ev_last);
   if (l.stream2) hipStreamDestroy(l.stream2);
   if (l.stream) hipStreamDestroy(l.stream);
   l = Lane();
@@ -470,8 +511,6 @@ static void resident_free(Resident& r)
   if (r.host) hipHostFree(r.host);
   if (r.refs_dev) hipFree(r.refs_dev);
   if (r.refs_host) hipHostFree(r.refs_host);
-  if (r.ev_up) hipEventDestroy(r.ev_up);
-  if (r.ev_done) hipEventDestroy(r.ev_done);
   r = Resident();
 }
 
@@ -490,7 +529,7 @@ void m355_destroy(m355_ctx* c)
   for (hipStream_t bs : c->batch_stream) if (bs) hipStreamDestroy(bs);
   for (hipStream_t ps : c->pad_streams) hipStreamDestroy(ps);
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
-  for (auto& st_ : c->status) if (st_.ev) hipEventDestroy(st_.ev);
+  for (auto& e_ : c->evring) if (e_.ev) hipEventDestroy(e_.ev);
   if (c->status_words) hipHostFree(c->status_words);
   for (hipEvent_t e : c->dl_evs) if (e) hipEventDestroy(e);
   {
@@ -544,7 +583,7 @@ int m355_frame_create(m355_ctx* c, int width, int height, int cf, int bdl, int b
   int rc = frame_alloc(f, c->stream);
   if (rc) { frame_free(f); return -rc; }
   /* the zero fill is this frame's first write: whichever lane touches the frame next orders itself after it */
-  if (hipEventCreateWithFlags(&f.ev_wr, hipEventDisableTiming) == hipSuccess) { hipEventRecord(f.ev_wr, c->stream); f.wr_pending = true; }
+  ev_mark(c, c->stream, &f.wr);
   return idx;
 }
 static Frame* get_frame(m355_ctx* c, int h)
@@ -610,7 +649,7 @@ int m355_frame_download_async(m355_ctx* c, int h, void* const dst[3], const ptrd
   hipEvent_t ev_done = c->dl_evs[c->dl_ev_next];            /* (a ring: never re-recorded while an earlier record may still be waited for) */
   c->dl_ev_next = (c->dl_ev_next + 1) % (int)c->dl_evs.size();
   hipStream_t cs = f->wr_stream ? f->wr_stream : c->stream;                     /* (no decode of this context wrote it: uploads and fills are synchronous) */
-  if (!f->wr_stream && f->wr_pending) HIPCHK(hipStreamWaitEvent(cs, f->ev_wr, 0));
+  if (!f->wr_stream) ev_wait(c, cs, f->wr);
   for (int cc = 0; cc < 3; cc++) {
     if (!f->pw[cc]) continue;
     if (!dst[cc]) return fail(M355_ERR_INVALID, "no destination for plane %d", cc);
@@ -1304,10 +1343,10 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     r.cap = total + total / 4;
     HIPCHK(hipMalloc(&r.dev, r.cap));
     HIPCHK(hipHostMalloc(&r.host, r.cap, hipHostMallocDefault));
-  } else if (r.done_pending) {
+  } else if (r.done.ticket) {
     /* the arenas may still be in use by the last decode of these lists */
-    HIPCHK(hipEventSynchronize(r.ev_done));
-    r.done_pending = false;
+    HIPCHK(ev_sync(c, r.done));
+    r.done = EvRef();
   }
   const auto t_wait = now();
   for (int i = 0; i < ns; i++)
@@ -1459,8 +1498,10 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
       run_b = b; run_e = e;
     }
   }
-  if (!r.ev_up) HIPCHK(hipEventCreateWithFlags(&r.ev_up, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(r.ev_up, c->stream));      /* a decode on the other lane waits for the lists */
+  {
+    const int rcm = ev_mark(c, c->stream, &r.up);  /* a decode on another lane continues behind the copy of the lists */
+    if (rcm) return rcm;
+  }
 
   r.hdr = *pic;
   DevPic& d = r.dp;
@@ -1696,10 +1737,20 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   static const bool single_env = !(getenv("M355_DENSE_SINGLE_STREAM") && atoi(getenv("M355_DENSE_SINGLE_STREAM")) == 0);
   /* M355_SINGLE_STREAM=1 (experiment): every picture on its lane's main stream only — a lane is then ONE stream for the runtime's
      hardware queues */
-  static const bool single_all = getenv("M355_SINGLE_STREAM") && atoi(getenv("M355_SINGLE_STREAM"));
-  const bool single = (single_env && d.intra_dense) || single_all;
+  static const int single_mode = getenv("M355_SINGLE_STREAM") ? atoi(getenv("M355_SINGLE_STREAM")) : -1;   /* 1 always, 0 never, unset: by picture size */
+  /* ... and so does a picture of up to 4K: the fork / join of the side stream is six packets (three event records, three waits) at
+     about 2 us of pipeline time each, and what they buy — the metadata scatters and the second residual launch beside the main
+     stream — is worth less than that once the kernels are short (three in flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms
+     on one stream, C5 0.347 -> 0.351) */
+  const bool single_small = single_mode < 0 && (long long)d.pp.width * d.pp.height <= 16ll << 20;
+  const bool single = (single_env && d.intra_dense) || single_mode > 0 || single_small;
   const bool fused = d.res_map != nullptr;   /* prepare(): the residuals of inter CUs are added in k_inter_jobs' write-back */
   hipStream_t s2 = single ? st : c->stream2;
+  /* the zero fill of the metadata planes rides in the picture's first main-stream launch (k_job_count), in FRONT of the fork: the
+     side stream's scatters then start behind it — one launch less per inter picture (not with fused residuals: there the side
+     stream starts with the residual stage, and the job count comes later) */
+  const bool clear_in_count = !fused && d.n_pbs > 0;
+  if (clear_in_count) m355_launch_job_count(d, true, st);
   if (fused) hipMemsetAsync(d.res_map, 0, (size_t)d.res_map_words * 4, st);
   if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
   if (fused) {
@@ -1710,9 +1761,9 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
     m355_launch_residual(d, hbd, true, st);
     if (ev) hipEventRecord(ev[1], st);
   }
-  m355_launch_meta_planes(d, s2);
+  m355_launch_meta_planes(d, s2, clear_in_count);
   if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, s2);   /* reads the CU plane (constrained intra prediction) */
-  m355_launch_meta_jobs(d, st);
+  if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
   if (ev) hipEventRecord(ev[fused ? 2 : 1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
      reference — the list copy, validation, metadata planes, job list (and fused residuals) of a picture run beside the tail
@@ -1720,7 +1771,7 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   if (c->depth >= 2)
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
-      if (f && f->wr_pending) hipStreamWaitEvent(st, f->ev_wr, 0);
+      if (f) ev_wait(c, st, f->wr);
     }
   if (fused && !single) hipStreamWaitEvent(st, c->ev_fork2, 0);   /* the 8x8 + 4x4 tiles */
 #ifdef M355_X_TILED
@@ -1755,8 +1806,8 @@ static void dst_hazards(m355_ctx* c, Frame* dstf, bool piped)
 {
   if (dstf->dl_pending) hipStreamWaitEvent(c->stream, dstf->ev_dl, 0);     /* (stays pending for the HOST until m355_frame_download_wait / m355_wait) */
   if (!piped) return;
-  if (dstf->wr_pending) hipStreamWaitEvent(c->stream, dstf->ev_wr, 0);
-  for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(c->stream, dstf->ev_rd[k], 0);
+  ev_wait(c, c->stream, dstf->wr);
+  for (int k = 0; k < M355_MAX_LANES; k++) ev_wait(c, c->stream, dstf->rd[k]);
 }
 
 /* One decode = decode_pre (lane, hazards, validation, every stage in front of the intra stage [and, with_intra, that stage]) +
@@ -1781,7 +1832,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
       if (!c->stream_hi) HIPCHK(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, lane_class_priority(c->active)));
       run = c->stream_hi;
     }
-    if (c->last_stream && c->last_stream != run) hipStreamWaitEvent(run, c->ev_last, 0);   /* the lane's scratch and working planes */
+    ev_wait(c, run, c->last);                              /* the lane's scratch and working planes (when its last decode ran on its other stream) */
     S.saved_stream = c->stream; S.swapped = run != c->stream;
     c->stream = run;
   }
@@ -1795,7 +1846,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
   Frame* dstf = get_frame(c, r.hdr.dst_frame);
   if (piped) {
     /* read-after-write: the lists (uploaded on whichever lane was active); the reference frames' last writers: launch_prediction */
-    if (r.ev_up) hipStreamWaitEvent(c->stream, r.ev_up, 0);
+    ev_wait(c, c->stream, r.up);
   }
   hipStream_t st = c->stream;
   hipEvent_t* ev = nullptr;
@@ -1832,43 +1883,44 @@ static int decode_post(m355_ctx* c, Resident& r, DecodeState& S, bool filters = 
   if (ev) hipEventRecord(ev[5], st);
   if (filters && want_sao) { dst_hazards(c, dstf, piped); m355_launch_sao(d, hbd, st); }
   if (ev) hipEventRecord(ev[6], st);
-  if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-  hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
+  /* ONE mark behind the decode's last kernel for everything that has to know when it is over: the lists' arenas, the destination
+     frame's next reader / writer, the reference frames' next writer, the lane's next decode, the status slot */
+  EvRef done;
+  {
+    const int rcm = ev_mark(c, st, &done);
+    if (rcm) return rcm;
+  }
+  r.done = done; r.fresh = false;
 #ifdef M355_X_TILED
   dstf->tiled_valid = false;
 #endif
   dstf->wr_stream = st;
-  if (piped) {
-    if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-    hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
-    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
-      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
-      if (!f) continue;
-      if (frame_event(&f->ev_rd[c->active]) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-      hipEventRecord(f->ev_rd[c->active], st); f->rd_pending[c->active] = true;
-    }
+  dstf->wr = done;
+  for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+    Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+    if (f) f->rd[c->active] = done;
   }
   if (ev) c->timed = true;
   {
-    /* this decode's status slot: completion event; a device-validated decode also brings its lane's gate words back (behind the
-       events the dependent decodes wait on: nobody waits for this copy but m355_decode_status / m355_wait) */
+    /* this decode's status slot; a device-validated decode also brings its lane's gate words back — behind the mark the dependent
+       decodes wait on, with a mark of its own: nobody waits for this copy but m355_decode_status / m355_wait */
     m355_ctx::Status& s = c->status[++c->serial % M355_STATUS_RING];
-    if (s.serial && s.validated && !s.reported && s.ev) {
+    if (s.serial && s.validated && !s.reported) {
       /* the slot's previous decode (M355_STATUS_RING submits ago) was never asked about: resolve it before its words are
          overwritten — a rejection must not get lost (m355_wait promises to report it) */
-      hipEventSynchronize(s.ev);
+      ev_sync(c, s.done);
       if (c->status_words[4 * (s.serial % M355_STATUS_RING) + 1] == s.epoch) { if (!c->lost_count++) c->lost_first = s.serial; }
     }
     s.serial = c->serial; s.epoch = d.epoch; s.validated = r.device_validate; s.reported = false;
-    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+    s.done = done;
     if (r.device_validate) {
       if (!c->status_words) HIPCHK(hipHostMalloc(&c->status_words, 16 * M355_STATUS_RING, hipHostMallocDefault));
       hipMemcpyAsync(c->status_words + 4 * (c->serial % M355_STATUS_RING), c->timeout, 16, hipMemcpyDeviceToHost, st);
+      const int rcm = ev_mark(c, st, &s.done);
+      if (rcm) return rcm;
     }
-    hipEventRecord(s.ev, st);
   }
-  if (!c->ev_last && hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-  hipEventRecord(c->ev_last, st); c->last_stream = st;        /* (the lane's next decode may run on the lane's other stream) */
+  c->last = done; c->last_stream = st;                       /* (the lane's next decode may run on the lane's other stream) */
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   {
@@ -1914,7 +1966,7 @@ int m355_decode_status(m355_ctx* c, unsigned long long serial)
   m355_ctx::Status& s = c->status[serial % M355_STATUS_RING];
   if (s.serial != serial) return fail(M355_ERR_INVALID, "decode %llu is older than the last %d decodes: its status is no longer kept (m355_wait reports rejections)", serial, M355_STATUS_RING);
   hipSetDevice(c->device);
-  const hipError_t q = hipEventQuery(s.ev);
+  const hipError_t q = ev_query(c, s.done);
   if (q == hipErrorNotReady) return M355_ERR_BUSY;
   if (q != hipSuccess) return fail(M355_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
   return status_of(c, s);
@@ -1985,40 +2037,42 @@ int m355_decode_phase(m355_ctx* c, int h, int phase, void* xbuf)
   auto dst_hazards = [&]() {     /* as in decode(): right before the first write of the destination frame */
     if (dstf->dl_pending) hipStreamWaitEvent(st, dstf->ev_dl, 0);
     if (!piped) return;
-    if (dstf->wr_pending) hipStreamWaitEvent(st, dstf->ev_wr, 0);
-    for (int k = 0; k < M355_MAX_LANES; k++) if (dstf->rd_pending[k]) hipStreamWaitEvent(st, dstf->ev_rd[k], 0);
+    ev_wait(c, st, dstf->wr);
+    for (int k = 0; k < M355_MAX_LANES; k++) ev_wait(c, st, dstf->rd[k]);
   };
   auto dst_written = [&]() -> int {
-    if (!r.ev_done && hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-    hipEventRecord(r.ev_done, st); r.done_pending = true; r.fresh = false;
+    EvRef done;
+    const int rcm = ev_mark(c, st, &done);                   /* one mark: the lists, the lane, the destination frame */
+    if (rcm) return rcm;
+    r.done = done; r.fresh = false;
     dstf->wr_stream = st;
-    if (!c->ev_last && hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-    hipEventRecord(c->ev_last, st); c->last_stream = st;
-    if (!piped) return M355_OK;
-    if (frame_event(&dstf->ev_wr) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-    hipEventRecord(dstf->ev_wr, st); dstf->wr_pending = true;
+    c->last = done; c->last_stream = st;
+    dstf->wr = done;
     return M355_OK;
   };
   switch (phase) {
     case 0: {
-      if (c->last_stream && c->last_stream != st && c->ev_last) hipStreamWaitEvent(st, c->ev_last, 0);   /* the lane's scratch and working planes (decode()) */
+      ev_wait(c, st, c->last);                               /* the lane's scratch and working planes (decode()) */
       /* the exchange buffers of m355_decode_sharded belong to the handle, not to a lane: a second decode of the same lists
          starts behind the last unpack of the one before */
-      if (r.xb[0] && r.done_pending && r.ev_done) hipStreamWaitEvent(st, r.ev_done, 0);
+      if (r.xb[0]) ev_wait(c, st, r.done);
       if (piped) {
-        if (r.ev_up) hipStreamWaitEvent(st, r.ev_up, 0);
+        ev_wait(c, st, r.up);
       }
       if (r.device_validate) m355_launch_validate(d, st);
       if (!r.live_sao) dst_hazards();
       if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, r.live_sao ? &c->work : dstf, r.device_validate && !r.live_sao, st);
       launch_prediction(c, r, d, hbd, nullptr);
-      if (piped)      /* the reference frames are not read after this phase */
+      if (piped) {    /* the reference frames are not read after this phase */
+        EvRef read;
+        bool marked = false;
         for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
           Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
           if (!f) continue;
-          if (frame_event(&f->ev_rd[c->active]) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
-          hipEventRecord(f->ev_rd[c->active], st); f->rd_pending[c->active] = true;
+          if (!marked) { const int rcm = ev_mark(c, st, &read); if (rcm) return rcm; marked = true; }
+          f->rd[c->active] = read;
         }
+      }
       m355_launch_halo_pack(d, r.halo, hbd, 1, (char*)xbuf + meta_bytes, (uint32_t*)xbuf, st);
       break;
     }
@@ -2509,9 +2563,9 @@ static int arena_into(m355_ctx* c, Resident& r, m355_arena_caps* k, int halo_uni
     r.cap = L.total + L.total / 4;
     HIPCHK(hipMalloc(&r.dev, r.cap));
     HIPCHK(hipHostMalloc(&r.host, r.cap, hipHostMallocDefault));
-  } else if (r.done_pending) {
-    HIPCHK(hipEventSynchronize(r.ev_done));                /* the last decode of the lists that lived here */
-    r.done_pending = false;
+  } else if (r.done.ticket) {
+    HIPCHK(ev_sync(c, r.done));                            /* the last decode of the lists that lived here */
+    r.done = EvRef();
   }
   memset(pic, 0, sizeof(*pic));
   pic->slices = (const m355_slice*)(r.host + L.seg[L.i_sl].ofs);
@@ -2592,7 +2646,7 @@ int m355_wait(m355_ctx* c)
 {
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-  for (auto& f : c->frames) { f.wr_pending = false; f.dl_pending = false; for (int k = 0; k < M355_MAX_LANES; k++) f.rd_pending[k] = false; }   /* everything is complete */
+  for (auto& f : c->frames) { f.wr = EvRef(); f.dl_pending = false; for (int k = 0; k < M355_MAX_LANES; k++) f.rd[k] = EvRef(); }   /* everything is complete */
   uint32_t t = 0;
   HIPCHK(hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost));
   for (int k = 0; k < M355_MAX_LANES; k++)
@@ -2636,7 +2690,7 @@ int m355_picture_replace(m355_ctx* c, int h, const m355_picture* pic)
   if (h < 0 || h >= (int)c->resident.size() || !(c->resident[h].used || c->resident[h].reserved) || !pic) return fail(M355_ERR_INVALID, "bad picture handle");
   Resident& r = c->resident[h];
   hipSetDevice(c->device);
-  if (r.done_pending && r.ev_done) { HIPCHK(hipEventSynchronize(r.ev_done)); r.done_pending = false; }
+  if (r.done.ticket) { HIPCHK(ev_sync(c, r.done)); r.done = EvRef(); }
   if (r.xb[0] && (memcmp(&r.hdr.pp, &pic->pp, sizeof(pic->pp)) != 0 || r.shard_n != c->shard_n || r.shard_rank != c->shard_rank)) {
     /* the exchange buffers of a sharded picture are sized by its geometry and tile structure */
     for (void*& b : r.xb) { if (b) hipFree(b); b = nullptr; }
