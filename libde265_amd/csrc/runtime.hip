@@ -1790,8 +1790,13 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   if (ev) hipEventRecord(ev[fused ? 3 : 2], st);
   if (!fused && (c->stages & M355_STAGE_RESIDUAL)) {
-    if (!single) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }   /* inter residuals are added to the prediction samples */
-    m355_launch_residual(d, hbd, false, s2);
+    /* inter residuals are added to the prediction samples: behind k_inter_jobs; the two launches side by side on the lane's two
+       streams (M355_RES_SIDE=0: one after the other on the main stream, no second fork — measured 1 % slower at C5 with three
+       pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
+    static const bool res_side = !(getenv("M355_RES_SIDE") && atoi(getenv("M355_RES_SIDE")) == 0);
+    hipStream_t sr = (res_side && !single) ? s2 : st;
+    if (sr != st) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }
+    m355_launch_residual(d, hbd, false, sr);
     m355_launch_residual(d, hbd, true, st);
   }
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
