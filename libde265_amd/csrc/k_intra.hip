@@ -962,23 +962,23 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #define M355_INTRA_DENSE_NW 12
 #endif
 template <class PIX, int CF>
-static void launch_intra_cf(const DevPic& p, hipStream_t st)
+static void launch_intra_cf(const DevPic& p, bool ticket_zero, hipStream_t st)
 {
-  hipMemsetAsync(p.ticket, 0, 4, st);
+  if (!ticket_zero) hipMemsetAsync(p.ticket, 0, 4, st);      /* (an inter picture's k_job_count zeroes it: one packet less) */
   /* dense intra pictures: 12 waves (up to 8 luma + 2 + 2 chroma blocks of a level at once); sparse ones: 4 (3 and 6 measured
      slower) */
   if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, false>), dim3(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work), dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
 }
 
-void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st)
+void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st, bool ticket_zero)
 {
   if (!p.n_intra_work) return;
   switch (p.pp.chroma_format_idc) {
-    case 0: if (hbd) launch_intra_cf<uint16_t, 0>(p, st); else launch_intra_cf<uint8_t, 0>(p, st); break;
-    case 1: if (hbd) launch_intra_cf<uint16_t, 1>(p, st); else launch_intra_cf<uint8_t, 1>(p, st); break;
-    case 2: if (hbd) launch_intra_cf<uint16_t, 2>(p, st); else launch_intra_cf<uint8_t, 2>(p, st); break;
-    default: if (hbd) launch_intra_cf<uint16_t, 3>(p, st); else launch_intra_cf<uint8_t, 3>(p, st); break;
+    case 0: if (hbd) launch_intra_cf<uint16_t, 0>(p, ticket_zero, st); else launch_intra_cf<uint8_t, 0>(p, ticket_zero, st); break;
+    case 1: if (hbd) launch_intra_cf<uint16_t, 1>(p, ticket_zero, st); else launch_intra_cf<uint8_t, 1>(p, ticket_zero, st); break;
+    case 2: if (hbd) launch_intra_cf<uint16_t, 2>(p, ticket_zero, st); else launch_intra_cf<uint8_t, 2>(p, ticket_zero, st); break;
+    default: if (hbd) launch_intra_cf<uint16_t, 3>(p, ticket_zero, st); else launch_intra_cf<uint8_t, 3>(p, ticket_zero, st); break;
   }
 }
 

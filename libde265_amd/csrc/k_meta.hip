@@ -118,11 +118,12 @@ __device__ __forceinline__ int d_pb_jobs(const m355_pb& pb)
 __host__ __device__ static inline size_t d_meta_fill16(const DevPic& p) { return ((((size_t)2 * p.w4 * p.h4 + 63) & ~(size_t)63) + (size_t)p.wcb * p.hcb * 4 + 15) / 16; }
 /* clear_planes: the launch also zero-fills the metadata planes (edge_tu | edge_pb | cb_cu) that k_meta_planes scatters into — it is the
    first kernel of an inter picture on its lane's main stream, in FRONT of the fork of the side stream: one launch less per picture
-   than a fill of its own (a packet costs about 2 us of pipeline time, profiles/r04_aj_*) */
+   than a fill of its own — and resets the ticket word of k_intra, another 4-byte fill packet (a packet costs about 2 us of pipeline time, profiles/r04_aj_*) */
 __global__ void __launch_bounds__(256) k_job_count(DevPic p, int clear_planes)
 {
   M355_GATE(p);
   if (clear_planes) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.ticket = 0;   /* k_intra's claim counter (the lane's previous k_intra is over: stream order) */
     const size_t n16 = d_meta_fill16(p);
     uint4* q = (uint4*)p.edge_tu;
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) q[k] = make_uint4(0, 0, 0, 0);

@@ -1801,7 +1801,7 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   }
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
   if (!fused && ev) hipEventRecord(ev[3], st);
-  if (with_intra && (c->stages & M355_STAGE_INTRA)) m355_launch_intra(d, hbd, st);   /* (m355_decode_batch launches several pictures' intra stage as one kernel) */
+  if (with_intra && (c->stages & M355_STAGE_INTRA)) m355_launch_intra(d, hbd, st, clear_in_count);   /* (m355_decode_batch launches several pictures' intra stage as one kernel) */
   if (ev) hipEventRecord(ev[4], st);
 }
 
