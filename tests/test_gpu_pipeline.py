@@ -172,3 +172,51 @@ def test_intra_and_inter_pictures_alternate_on_deep_pipelines(oracle, depth):
             assert_planes_equal(ctx.frame_download(pool[k % npool]), want[k], "picture %d after three unsynchronised rounds" % k)
     finally:
         ctx.close()
+
+
+def long_chain(lib, oracle, cfg, depth, n_decodes):
+    """More decodes than the context's ring of completion marks holds (runtime.hip EvRef: 256), none of them waited for by the host:
+    every picture references the output of the one before it (read-after-write across lanes), four destination frames go round
+    (write-after-read / write-after-write against marks that have long been taken over), six lists go round their handles."""
+    o = Oracle(oracle)
+    pics, ref0 = chain_case(6, **cfg)
+    pp = pics[0].pp[0]
+    of0 = o.frame_new(pp); o.frame_set_planes(of0, ref0)
+    opool = [o.frame_new(pp) for _ in range(4)]
+    oprev = of0
+    for k in range(n_decodes):
+        pic = pics[k % 6]
+        pic.ref_frames = [0, 1] + [-1] * (worklist.MAX_REF_FRAMES - 2)
+        assert o.decode(pic, opool[k % 4], {0: of0, 1: oprev}) == 0
+        oprev = opool[k % 4]
+    want = [o.frame_planes(f) for f in opool]
+    ctx = capi.Context(lib, 0)
+    try:
+        ctx.set_pipeline_depth(depth)
+        g0 = ctx.frame_create_for(pp); ctx.frame_upload(g0, ref0)
+        pool = [ctx.frame_create_for(pp) for _ in range(4)]
+        handles = [None] * 6
+        prev = g0
+        for k in range(n_decodes):
+            pic = pics[k % 6]
+            pic.dst_frame = pool[k % 4]
+            pic.ref_frames = [g0, prev] + [-1] * (worklist.MAX_REF_FRAMES - 2)
+            # the lists go back into their handle with the new frames (m355_picture_replace waits for that handle's last decode only)
+            if handles[k % 6] is None:
+                handles[k % 6] = ctx.upload(pic)
+            else:
+                c, keep = pic.to_c()
+                import ctypes
+                ctx.L.check(ctx.L.lib.m355_picture_replace(ctx.h, handles[k % 6], ctypes.addressof(c)))
+            ctx.decode_resident(handles[k % 6])
+            prev = pic.dst_frame
+        ctx.wait()
+        for k in range(4):
+            assert_planes_equal(ctx.frame_download(pool[k]), want[k], "frame %d after %d decodes" % (k, n_decodes))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+def test_long_unsynchronised_chain(oracle, depth):
+    long_chain(capi.Library(), oracle, dict(width=416, height=240, bit_depth=8, seed=211, n_refs=2), depth, 700)
