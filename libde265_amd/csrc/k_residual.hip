@@ -250,7 +250,8 @@ __device__ __forceinline__ void d_res_issue(const DevPic& p, const m355_rb& rb, 
      launch is a chain of dependent round trips per workgroup, not bandwidth: 0.03-0.045 ms for any ONE block size alone) */
 #pragma unroll
   for (int i = 0; i < NVP; i++) w[i] = 0;
-  const M355_GLOBAL PIX* d = (const M355_GLOBAL PIX*)M355_SEL3(p.plane, rb.cidx) + (size_t)(rb.y + c) * M355_SEL3(p.stride, rb.cidx) + rb.x;
+  /* (an idle lane — no block — reads row 0: row c of a picture lower than the transform size does not exist) */
+  const M355_GLOBAL PIX* d = (const M355_GLOBAL PIX*)M355_SEL3(p.plane, rb.cidx) + (size_t)(active ? rb.y + c : 0) * M355_SEL3(p.stride, rb.cidx) + rb.x;
   /* FUSED: a block of an inter CU is handed to k_inter_jobs' write-back as a compact int16 tile (k_common.h, res_map); the lane
      of every fourth row marks the row of 4x4 units it starts — fire and forget, ahead of the coefficient fetch */
   if (FUSED && active && !(rb.flags & M355_RBF_DEFERRED) && (c & 3) == 0) {
