@@ -146,7 +146,7 @@ __device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n)
   const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
   const int l2c = p.pp.log2_ctb_size;
   uint16_t* codes = s_code[wv];
-  for (uint32_t k = (uint32_t)(wv + 4 * (int)blockIdx.y); k < ib_count; k += 4 * PLAN_SPLIT) {
+  for (uint32_t k = (uint32_t)(wv + 4 * (int)blockIdx.y); k < ib_count; k += 4 * (uint32_t)gridDim.y) {
     const uint32_t* r = (const uint32_t*)&p.ibs[ib_start + k];
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[0]), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[1]);
     const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[4 * (ib_start + k) + 3]);
@@ -1020,10 +1020,13 @@ void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st)
 {
   if (!p.n_intra_work) return;
+  /* workgroups per CTB: PLAN_SPLIT for an intra picture (hundreds of blocks per CTB); ONE for the handful of intra blocks a CTB of an
+     inter picture holds (3.4 on average at C5: with eight workgroups 90 000 waves were launched for 28 000 blocks) */
+  const int split = p.intra_dense ? PLAN_SPLIT : 1;
   switch (p.pp.chroma_format_idc) {
-    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<0>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
-    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<1>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<2>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<3>), dim3(p.n_intra_work, PLAN_SPLIT), dim3(256), 0, st, p, p.n_intra_work); break;
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<0>), dim3(p.n_intra_work, split), dim3(256), 0, st, p, p.n_intra_work); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<1>), dim3(p.n_intra_work, split), dim3(256), 0, st, p, p.n_intra_work); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<2>), dim3(p.n_intra_work, split), dim3(256), 0, st, p, p.n_intra_work); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra_plan<3>), dim3(p.n_intra_work, split), dim3(256), 0, st, p, p.n_intra_work); break;
   }
 }
