@@ -226,7 +226,7 @@ __device__ __forceinline__ m355_rb d_rb_idle(int log2)
 }
 
 /* One group = the 64 / nT blocks a wave handles together, in three steps so that the steps of consecutive groups can overlap
- * (d_residual_loop): the record (d_res_record), the loads that depend on it (d_res_issue: the lane's destination row and — for the
+ * (tools/experiments/residual_sao_xcd_order_and_walk.patch): the record (d_res_record), the loads that depend on it (d_res_issue: the lane's destination row and — for the
  * loop — its first batch of coefficient pairs), and everything else (d_res_finish: scatter, transform, add / store). */
 template <int LOG2, class PIX> struct ResGeom {
   static constexpr int NT = 1 << LOG2, BPW = 64 / NT, QN = NT / 2, GP = QN + 1, BLK_DW = QN * NT + NT * GP;
@@ -376,63 +376,6 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   d_res_finish<LOG2, PIX, FUSED, true>(p, rbs, rb, active, c, tbi, cfp, w, eb);
 }
 
-/* EXPERIMENT (M355_X_RES_PIPE): the groups g0, g0 + gs, g0 + 2 gs, ... < ng by ONE wave.  A wave that handles one group and ends goes
- * through four dependent memory round trips — kernel arguments, the gate word, the record, then the coefficient pairs and the
- * destination row — with about 1 us of arithmetic behind them; in the walk only the last one is left per group:
- *   DEPTH 1: the record of group i + 1 is requested before group i is worked on (5 more registers);
- *   DEPTH 2: while group i is transformed, the loads of group i + 1 that depend on its record (destination row, first coefficient
- *            batch) and the record of group i + 2 are in flight (about 40 more registers: 126 instead of 66, 4 waves per SIMD). */
-#ifndef M355_X_RES_PIPE_DEPTH
-#define M355_X_RES_PIPE_DEPTH 1
-#endif
-template <int LOG2, class PIX, bool FUSED>
-__device__ __forceinline__ void d_residual_loop(const DevPic& p, const m355_rb* rbs, int rb_n, int g0, int gs, int ng, uint32_t* smem)
-{
-  typedef ResGeom<LOG2, PIX> G;
-  if (g0 >= ng) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = lane & (G::NT - 1), b = lane >> LOG2;
-  uint32_t* cfp = smem + (wave * G::BPW + b) * G::BLK_DW;
-  auto tbi_of = [&](int g) { return (g * RES_WPG + wave) * G::BPW + b; };
-  int g = g0;
-  m355_rb rbA = d_res_record<LOG2>(rbs, rb_n, tbi_of(g));
-  if (M355_X_RES_PIPE_DEPTH <= 1) {
-    for (;;) {
-      const bool more = g + gs < ng;                       /* wave-uniform */
-      const int tA = tbi_of(g);
-      const m355_rb rbB = d_res_record<LOG2>(rbs, more ? rb_n : 0, tbi_of(g + gs));
-      uint32_t wA[G::NVP];
-      d_res_issue<LOG2, PIX, FUSED, false>(p, rbA, tA < rb_n, c, tA, wA, nullptr);
-      d_res_finish<LOG2, PIX, FUSED, false>(p, rbs, rbA, tA < rb_n, c, tA, cfp, wA, nullptr);
-      if (!more) break;
-      rbA = rbB;
-      g += gs;
-    }
-    return;
-  }
-  m355_rb rbB = d_res_record<LOG2>(rbs, g + gs < ng ? rb_n : 0, tbi_of(g + gs));
-  uint32_t wA[G::NVP], ebA[RES_GB];
-  d_res_issue<LOG2, PIX, FUSED, true>(p, rbA, tbi_of(g) < rb_n, c, tbi_of(g), wA, ebA);
-  for (;;) {
-    const bool more = g + gs < ng;                         /* wave-uniform */
-    const int tA = tbi_of(g), tB = tbi_of(g + gs);
-    uint32_t wB[G::NVP], ebB[RES_GB];
-    m355_rb rbC = d_rb_idle(LOG2);
-    if (more) {
-      d_res_issue<LOG2, PIX, FUSED, true>(p, rbB, tB < rb_n, c, tB, wB, ebB);
-      rbC = d_res_record<LOG2>(rbs, g + 2 * gs < ng ? rb_n : 0, tbi_of(g + 2 * gs));
-    }
-    d_res_finish<LOG2, PIX, FUSED, true>(p, rbs, rbA, tA < rb_n, c, tA, cfp, wA, ebA);
-    if (!more) break;
-    rbA = rbB; rbB = rbC;
-#pragma unroll
-    for (int i = 0; i < G::NVP; i++) wA[i] = wB[i];
-#pragma unroll
-    for (int i = 0; i < RES_GB; i++) ebA[i] = ebB[i];
-    g += gs;
-  }
-}
-
 /* Two launches, issued side by side on the lane's two streams (runtime.hip, launch_prediction): 32x32 + 16x16 blocks (2 / 4 per
  * wave; 128 VGPRs, 8 KB of LDS tiles per wave) and 8x8 + 4x4 blocks (8 / 16 per wave; 66 VGPRs -> 7 waves per SIMD instead of the
  * 3 the 32-point transform's registers would impose on every size).  The stage is a chain of dependent round trips per wave —
@@ -440,33 +383,11 @@ __device__ __forceinline__ void d_residual_loop(const DevPic& p, const m355_rb* 
 #define RES_LDS_DWORDS_SMALL (8 * RES_WPG * (4 * 8 + 8 * 5))   /* 8x8: 8 blocks per wave (4x4: 16 x 20 dwords fit too) */
 /* blocks per workgroup: RES_WPG waves * 64/nT */
 __host__ __device__ static inline int res_groups(int n, int per_wave) { return (n + per_wave * RES_WPG - 1) / (per_wave * RES_WPG); }
-#ifdef M355_X_RES_XCD
-#define RES_XCD_ORDER true
-#else
-#define RES_XCD_ORDER false
-#endif
-template <class PIX, bool BIG, bool FUSED, bool XCD = false>
+template <class PIX, bool BIG, bool FUSED>
 __device__ __forceinline__ void k_residual_body(const DevPic& p, int ng_hi, uint32_t* s_buf)
 {
   M355_GATE(p);
-  int g = (int)blockIdx.x;
-  if (XCD) {
-  /* EXPERIMENT (tools/variants.sh resxcd "-DM355_X_RES_XCD"): block b runs on XCD b % 8; each of the launch's two size bins is dealt to the
-     XCDs as eight CONTIGUOUS runs of groups (= compact regions of the picture in decode order), both bins padded to a multiple of eight
-     workgroups, so that the 128-byte lines a group's 8- / 16- / 32-byte rows lie in are fetched by ONE L2 — with the round-robin order
-     the four 16x16 groups of 4x4 blocks that share a line sit on four XCDs and each fetches it (PMC: 173 MB read per picture for
-     62 MB algorithmic).  Unlike the round-2 trial (profiles/r02_b_inter_variants.txt: one split over both bins, the 32x32 groups all on
-     the first XCDs), every XCD gets an eighth of EACH bin. */
-  const int n_hi = BIG ? res_groups(p.rb_count[3], 2) : res_groups(p.rb_count[1], 8), n_lo = BIG ? res_groups(p.rb_count[2], 4) : res_groups(p.rb_count[0], 16);
-  const int n_hi8 = (n_hi + 7) & ~7;
-  {
-    const bool hi = g < n_hi8;
-    const int b = hi ? g : g - n_hi8, per = (hi ? n_hi8 : ((n_lo + 7) & ~7)) >> 3;
-    const int gg = (b & 7) * per + (b >> 3);
-    if (gg >= (hi ? n_hi : n_lo)) return;
-    g = hi ? gg : ng_hi + gg;
-  }
-  }
+  const int g = (int)blockIdx.x;
   if (BIG) {
     if (g < ng_hi) d_residual_group<5, PIX, FUSED>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
     else d_residual_group<4, PIX, FUSED>(p, p.rb_bin[2], p.rb_count[2], g - ng_hi, s_buf);
@@ -480,50 +401,8 @@ template <class PIX, bool BIG, bool FUSED>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual(DevPic p, int ng_hi)
 {
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
-  k_residual_body<PIX, BIG, FUSED, RES_XCD_ORDER>(p, ng_hi, s_buf);
+  k_residual_body<PIX, BIG, FUSED>(p, ng_hi, s_buf);
 }
-#ifdef M355_X_RES_PIPE
-/* EXPERIMENT (tools/variants.sh respipe "-DM355_X_RES_PIPE=<workgroups per launch>"): a persistent grid; workgroup b walks the groups
-   b, b + G, b + 2G, ... of the launch's larger size, then those of the smaller one (continuing the round so that every workgroup gets
-   the same number of groups +- 1), each walk software-pipelined (d_residual_loop).  With M355_X_RES_XCD the walk of a workgroup stays
-   inside its XCD's contiguous eighth of the bin (block b runs on XCD b % 8; G is a multiple of 8). */
-#ifndef M355_X_RES_PIPE_WAVES
-#define M355_X_RES_PIPE_WAVES 4   /* register budget: waves per SIMD the walking 8x8 / 4x4 kernel is compiled for (at least) */
-#endif
-template <class PIX, bool BIG, bool FUSED>
-__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(M355_X_RES_PIPE_WAVES))) k_residual_pipe(DevPic p, int ng_hi, int ng_lo)
-{
-  __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
-  M355_GATE(p);
-  const int G = (int)gridDim.x, b = (int)blockIdx.x;
-  const m355_rb* rb_hi = BIG ? p.rb_bin[3] : p.rb_bin[1];
-  const m355_rb* rb_lo = BIG ? p.rb_bin[2] : p.rb_bin[0];
-  const int n_hi = BIG ? p.rb_count[3] : p.rb_count[1], n_lo = BIG ? p.rb_count[2] : p.rb_count[0];
-  if (RES_XCD_ORDER) {
-    /* bin -> eight contiguous chunks, chunk x walked by the G / 8 workgroups of XCD x */
-    const int x = b & 7, j = b >> 3, Gx = G >> 3;
-    const int per_hi = (ng_hi + 7) >> 3, per_lo = (ng_lo + 7) >> 3;
-    const int e_hi = min(ng_hi, (x + 1) * per_hi), e_lo = min(ng_lo, (x + 1) * per_lo);
-    const int r = per_hi % Gx;                          /* (the chunk's last round is partial: the smaller size starts where it ends) */
-    if (BIG) {
-      d_residual_loop<5, PIX, FUSED>(p, rb_hi, n_hi, x * per_hi + j, Gx, e_hi, s_buf);
-      d_residual_loop<4, PIX, FUSED>(p, rb_lo, n_lo, x * per_lo + (j - r + Gx) % Gx, Gx, e_lo, s_buf);
-    } else {
-      d_residual_loop<3, PIX, FUSED>(p, rb_hi, n_hi, x * per_hi + j, Gx, e_hi, s_buf);
-      d_residual_loop<2, PIX, FUSED>(p, rb_lo, n_lo, x * per_lo + (j - r + Gx) % Gx, Gx, e_lo, s_buf);
-    }
-  } else {
-    const int r = ng_hi % G;
-    if (BIG) {
-      d_residual_loop<5, PIX, FUSED>(p, rb_hi, n_hi, b, G, ng_hi, s_buf);
-      d_residual_loop<4, PIX, FUSED>(p, rb_lo, n_lo, (b - r + G) % G, G, ng_lo, s_buf);
-    } else {
-      d_residual_loop<3, PIX, FUSED>(p, rb_hi, n_hi, b, G, ng_hi, s_buf);
-      d_residual_loop<2, PIX, FUSED>(p, rb_lo, n_lo, (b - r + G) % G, G, ng_lo, s_buf);
-    }
-  }
-}
-#endif
 /* batch form (intra pictures: never the fused order) */
 template <class PIX, bool BIG>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_batch(DevBatch b)
@@ -553,17 +432,6 @@ template <class PIX, bool BIG>
 static void launch_res(const DevPic& p, int n, int ng_hi, hipStream_t st)
 {
   const dim3 blk(64 * RES_WPG);
-#ifdef M355_X_RES_PIPE
-  if (!BIG) {      /* (the 32x32 / 16x16 launch is bound by its arithmetic, and two groups' state does not fit its 128 registers: 250-400 bytes of scratch per lane) */
-    const int ng_lo = BIG ? res_groups(p.rb_count[2], 4) : res_groups(p.rb_count[0], 16);
-    static const int g_env = getenv("M355_RES_PIPE_GRID") ? atoi(getenv("M355_RES_PIPE_GRID")) : 0;
-    int G = g_env > 0 ? g_env : M355_X_RES_PIPE;
-    G = std::max(8, std::min(G, ng_hi + ng_lo) & ~7);
-    if (p.res_map) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_pipe<PIX, BIG, true>), dim3(G), blk, 0, st, p, ng_hi, ng_lo);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_pipe<PIX, BIG, false>), dim3(G), blk, 0, st, p, ng_hi, ng_lo);
-    return;
-  }
-#endif
   if (p.res_map) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, true>), dim3(n), blk, 0, st, p, ng_hi);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, false>), dim3(n), blk, 0, st, p, ng_hi);
 }
@@ -572,17 +440,12 @@ void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)
 {
   auto groups = res_groups;
   const int ng2 = groups(p.rb_count[0], 16), ng3 = groups(p.rb_count[1], 8), ng4 = groups(p.rb_count[2], 4), ng5 = groups(p.rb_count[3], 2);
-#ifdef M355_X_RES_XCD
-  auto pad8 = [](int n) { return (n + 7) & ~7; };
-#else
-  auto pad8 = [](int n) { return n; };
-#endif
   if (big && ng5 + ng4) {
-    if (hbd) launch_res<uint16_t, true>(p, pad8(ng5) + pad8(ng4), ng5, st);
-    else launch_res<uint8_t, true>(p, pad8(ng5) + pad8(ng4), ng5, st);
+    if (hbd) launch_res<uint16_t, true>(p, ng5 + ng4, ng5, st);
+    else launch_res<uint8_t, true>(p, ng5 + ng4, ng5, st);
   }
   if (!big && ng3 + ng2) {
-    if (hbd) launch_res<uint16_t, false>(p, pad8(ng3) + pad8(ng2), ng3, st);
-    else launch_res<uint8_t, false>(p, pad8(ng3) + pad8(ng2), ng3, st);
+    if (hbd) launch_res<uint16_t, false>(p, ng3 + ng2, ng3, st);
+    else launch_res<uint8_t, false>(p, ng3 + ng2, ng3, st);
   }
 }

@@ -152,12 +152,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
      theirs up with cross-lane reads. ---- */
   uint32_t rim_up[NW], rim_dn[NW];
   uint32_t rim_col = 0;
-#ifndef M355_X_SAO_TWO_TRIPS
   {
-#else
-  const bool any_edge_early = __any(type_raw == 2);
-  if (any_edge_early) {
-#endif
     d_sao_load4<PIX>(in + (size_t)(ly == 0 ? max(y0 - 1, 0) : min(y0, height - 1)) * is + xs, rim_up);
     d_sao_load4<PIX>(in + (size_t)(ly == 3 ? min(y0 + 4, height - 1) : min(y0 + 3, height - 1)) * is + xs, rim_dn);
     /* lane i < 48: group g = i / 12 (the lanes with ly == g), side = (i % 12) / 6 (0 left, 1 right), row r = i % 6 */
@@ -362,26 +357,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   }
 }
 
-#ifdef M355_X_SAO_XCD
-/* EXPERIMENT (tools/variants.sh saoxcd "-DM355_X_SAO_XCD=2"): a 1-D grid whose blocks are dealt to the XCDs in runs of M355_X_SAO_XCD whole
-   block ROWS (block b runs on XCD b % 8): the 256-sample blocks of a row — and the rows of a run — then share one L2, so a row's rim lines
-   (the 128-byte line left and right of every block: 6 lines touched for 4 used) are fetched from the fabric once instead of once per
-   neighbour, while the eight XCDs still stream 8 x M355_X_SAO_XCD neighbouring rows of the picture at a time (a band of rows per XCD was
-   25 % slower: profiles/r02_b_inter_variants.txt).  Rows = luma rows, then the Cb rows, then the Cr rows (chroma rows are narrower: their
-   surplus blocks leave at once). */
-template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p, int gx, int gy0, int gy1)
-{
-  constexpr int RP = M355_X_SAO_XCD;
-  const int b = (int)blockIdx.x, xcd = b & 7, i = b >> 3;
-  const int x = i % gx, rr = i / gx;                       /* rr-th row this XCD takes */
-  const int R = (rr / RP) * (8 * RP) + xcd * RP + rr % RP;
-  if (R >= gy0 + 2 * gy1) return;
-  const int c = R < gy0 ? 0 : (R < gy0 + gy1 ? 1 : 2), y = R - (c == 0 ? 0 : (c == 1 ? gy0 : gy0 + gy1));
-  k_sao_body<PIX, PACKED>(p, c, x, y);
-}
-#else
 template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p) { k_sao_body<PIX, PACKED>(p, (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y); }
-#endif
 /* batch form: grid.z = 3 * picture + component */
 template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao_batch(DevBatch b)
 {
@@ -411,17 +387,8 @@ void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st)
 {
   /* one launch for all components: grid.z = component; chroma blocks beyond the chroma plane exit at once */
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
-#ifdef M355_X_SAO_XCD
-  const int gx = (p.pw[0] + 255) / 256, gy0 = (p.ph[0] + 15) / 16, gy1 = nc == 3 ? (p.ph[1] + 15) / 16 : 0;
-  const int rows = gy0 + 2 * gy1, rows_pad = (rows + 8 * M355_X_SAO_XCD - 1) / (8 * M355_X_SAO_XCD) * (8 * M355_X_SAO_XCD);
-  const dim3 grid((unsigned)(gx * rows_pad)), block(256);
-  if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p, gx, gy0, gy1);
-  else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p, gx, gy0, gy1);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p, gx, gy0, gy1);
-#else
   const dim3 grid((p.pw[0] + 255) / 256, (p.ph[0] + 15) / 16, nc), block(256);   /* 4 waves side by side: 256 x 16 samples */
   if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p);
   else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p);
-#endif
 }
