@@ -1006,7 +1006,9 @@ static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, bo
   std::atomic<size_t> first(ofs[7]);
   std::atomic<const char*> first_msg(nullptr);
   std::mutex mu;
-  parallel_ranges(ofs[7], 8192, [&](size_t b, size_t e) {
+  /* (records_on_device: the CTB table alone — 8 160 entries at 8K, each with a walk over its intra blocks: smaller shares, or the
+     whole check runs on the calling thread) */
+  parallel_ranges(ofs[7], records_on_device ? 512 : 8192, [&](size_t b, size_t e) {
     /* the range cut by list: one tight loop per list (the compiler sees ONE check function per loop) */
     for (int q = 0; q < 7; q++) {
       const size_t lo = std::max(b, ofs[q]), hi = std::min(e, ofs[q + 1]);

@@ -204,3 +204,32 @@ GPU_CASES = [(416, 240, 8, 1, 1, 8, 31, 5, 1, 1), (832, 480, 10, 3, 2, 8, 32, 10
 def test_generated_streams_gpu(ref, tmp_path, monkeypatch, w, h, bd, tc, tr, frames, seed, intra, b, sao):
     monkeypatch.delenv("M355_LIB", raising=False)
     check(ref, make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra, b, sao), frames, 8, capi.DEFAULT_LIB)
+
+
+# New coded video sequences inside one bitstream: every segment starts with its own VPS / SPS / PPS and an IDR picture — other
+# picture size, bit depth, chroma format and tile structure than the one before.  The decoder (decctx.cc:1303-1356 process_sps /
+# image allocation dpb.cc:239-281) re-creates its images; the glue's frames, the lanes' working planes and scratch, the scan-table
+# cache and the pinned picture allocator have to follow.
+def segments(tmp_path, specs):
+    return b"".join(make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, 10, 1, 1, feat, chroma) for (w, h, bd, tc, tr, frames, seed, feat, chroma) in specs)
+
+
+SEGMENTS_CPU = [(256, 128, 8, 1, 1, 3, 71, 0, 1), (192, 192, 10, 2, 1, 3, 72, 0, 1), (128, 64, 8, 1, 1, 2, 73, 0, 3), (256, 128, 8, 1, 1, 3, 71, F_WP, 1)]
+SEGMENTS_GPU = [(1920, 1080, 8, 2, 2, 4, 91, 0, 1), (3840, 2160, 10, 4, 2, 3, 92, 0, 1), (832, 480, 8, 1, 1, 4, 93, F_TSKIP, 3),
+                (1280, 720, 12, 1, 1, 3, 94, 0, 2), (1920, 1080, 8, 2, 2, 4, 91, F_WP | F_QPDELTA, 1)]
+
+
+def test_parameter_sets_change_mid_stream_emulated_backend(ref, emu_lib, tmp_path, monkeypatch):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    check(ref, segments(tmp_path, SEGMENTS_CPU), sum(s[5] for s in SEGMENTS_CPU), 2, EMU_SO)
+
+
+@pytest.mark.gpu
+def test_parameter_sets_change_mid_stream_gpu(ref, tmp_path, monkeypatch):
+    monkeypatch.delenv("M355_LIB", raising=False)
+    data = segments(tmp_path, SEGMENTS_GPU)
+    n = sum(s[5] for s in SEGMENTS_GPU)
+    check(ref, data, n, 8, capi.DEFAULT_LIB)
+    # ... and with every picture taken without a look at its samples (frames of the old size are released while decodes of the new size run)
+    got = de265_py.decode_stream(glue_lib(), data, threads=8, touch_planes=False)
+    assert got[1] == n and set(got[2]) <= {1000}, got
