@@ -1796,7 +1796,10 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   /* the zero fill of the metadata planes rides in the picture's first main-stream launch (k_job_count), in FRONT of the fork: the
      side stream's scatters then start behind it — one launch less per inter picture (not with fused residuals: there the side
      stream starts with the residual stage, and the job count comes later) */
-  const bool clear_in_count = !fused && d.n_pbs > 0;
+  /* (the fill is shared out over the launch's workgroups, one per 256 PBs: with a handful of them a fill of its own is faster;
+     M355_CLEAR_IN_COUNT_MIN=<PBs> moves the threshold — the CPU tier's small pictures take the path with 1) */
+  static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
+  const bool clear_in_count = !fused && d.n_pbs >= std::max(1, clear_min);
   if (clear_in_count) m355_launch_job_count(d, true, st);
   if (fused) hipMemsetAsync(d.res_map, 0, (size_t)d.res_map_words * 4, st);
   if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
