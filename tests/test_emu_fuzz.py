@@ -41,17 +41,19 @@ def corrupt(pic, rng):
     return "%s[%d].%s=%d" % (name, i, f, val)
 
 
-@pytest.mark.parametrize("in_place", [False, True], ids=["copying_submit", "in_place_submit"])
+@pytest.mark.parametrize("in_place", [False, True, "resident"], ids=["copying_submit", "in_place_submit", "in_place_resident"])
 @pytest.mark.parametrize("seed", range(8))
 def test_corrupted_lists_never_crash(emu_lib, seed, in_place):  # noqa: F811
     """in_place: the lists are recorded into the pinned arena and their records are checked ON THE DEVICE (k_validate) — a rejected
-    picture is never acted upon and the error surfaces at m355_wait"""
+    picture is never acted upon and the error surfaces at m355_wait.  "resident": recorded into a HANDLE's arena
+    (m355_picture_arena_begin -> m355_picture_replace -> m355_decode_resident), the same handle for every picture."""
     rng = np.random.default_rng(1000 + seed)
     cfg = [dict(width=128, height=64, bit_depth=8, seed=301, tile_cols=2), dict(width=96, height=96, bit_depth=10, seed=302, intra_pct=60, features=31),
            dict(width=128, height=64, bit_depth=8, seed=303, chroma_format=3, features=32)][seed % 3]
     ctx = capi.Context(emu_lib, 0)
     try:
         accepted = rejected = 0
+        handle = -1
         for _ in range(25):
             pic, refs = make_case(**cfg)
             pp = pic.pp[0].copy()
@@ -62,7 +64,10 @@ def test_corrupted_lists_never_crash(emu_lib, seed, in_place):  # noqa: F811
             pic.dst_frame = ctx.frame_create_for(pp)
             pic.ref_frames = [handles[i] if i < len(handles) else -1 for i in range(worklist.MAX_REF_FRAMES)]
             try:
-                if in_place:
+                if in_place == "resident":
+                    handle = ctx.upload_in_place(pic, handle=handle, fill_threads=1)
+                    ctx.decode_resident(handle)
+                elif in_place:
                     ctx.submit_in_place(pic, fill_threads=1)
                 else:
                     ctx.submit(pic)
