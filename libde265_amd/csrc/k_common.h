@@ -262,7 +262,8 @@ void m355_launch_clear_gated(const DevPic& p, void* ptr, size_t bytes, hipStream
 void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for k_inter (= the two below) */
 void m355_launch_job_count(const DevPic& p, bool clear_planes, hipStream_t st);   /* ... its first launch, optionally with the zero fill of the metadata planes */
 void m355_launch_job_list(const DevPic& p, hipStream_t st);      /* ... the rest */
-void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared);   /* planes for intra / deblock / SAO (cleared: k_job_count filled them) */
+void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared, bool with_tu = true);   /* planes for intra / deblock / SAO (cleared: k_job_count filled them; !with_tu: the transform edges come with m355_launch_tu_plan) */
+void m355_launch_tu_plan(const DevPic& p, hipStream_t st);         /* transform edges + border plans in ONE launch (M355_MERGE_TU_PLAN) */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */

@@ -41,6 +41,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "k_common.h"
+#include "k_meta_tu.h"
 
 #define MAXCTB 64
 /* body rows of a component: CTB width + 8 samples — sample x lives at column x + 8 (16-byte aligned 8-sample vectors).
@@ -131,12 +132,11 @@ template <int CF> struct IntraGeo {
 #define PLAN_SPLIT 8   /* (4 -> 8: C2 waits 15 us less for its plans, profiles/r03_u_*) */
 #endif
 template <int CF>
-__device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n)
+__device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n, const int item, const int part, const int n_parts)
 {
   M355_GATE(p);
   __shared__ uint16_t s_code[4][4 * 32 + 8];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  const int item = (int)blockIdx.x;
   if (item >= work_n) return;
   const DevIntraWork* wp = p.intra_work + item;
   const int ctb = __builtin_amdgcn_readfirstlane((int)wp->ctb);
@@ -146,7 +146,7 @@ __device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n)
   const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
   const int l2c = p.pp.log2_ctb_size;
   uint16_t* codes = s_code[wv];
-  for (uint32_t k = (uint32_t)(wv + 4 * (int)blockIdx.y); k < ib_count; k += 4 * (uint32_t)gridDim.y) {
+  for (uint32_t k = (uint32_t)(wv + 4 * part); k < ib_count; k += 4 * (uint32_t)n_parts) {
     const uint32_t* r = (const uint32_t*)&p.ibs[ib_start + k];
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[0]), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[1]);
     const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[4 * (ib_start + k) + 3]);
@@ -238,8 +238,18 @@ __device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n)
     wave_sync();                                             /* codes[] is reused by the wave's next block */
   }
 }
-template <int CF> __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n) { k_intra_plan_body<CF>(p, work_n); }
-template <int CF> __global__ void __launch_bounds__(256) k_intra_plan_batch(DevBatch b) { M355_BATCH_PIC(b); k_intra_plan_body<CF>(p, p.n_intra_work); }
+template <int CF> __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n) { k_intra_plan_body<CF>(p, work_n, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y); }
+template <int CF> __global__ void __launch_bounds__(256) k_intra_plan_batch(DevBatch b) { M355_BATCH_PIC(b); k_intra_plan_body<CF>(p, p.n_intra_work, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y); }
+/* EXPERIMENT (M355_MERGE_TU_PLAN=1, emulator-verified only): the transform-edge scatter (k_meta_tu.h) and the border plans as ONE launch —
+   both only read what k_meta_planes wrote, and a launch costs about 2 us of pipeline time (profiles/r04_aj_*): blocks [0, nb_tu) walk the
+   transform leaves, block nb_tu + item * n_parts + part plans part `part` of work item `item` */
+template <int CF> __global__ void __launch_bounds__(256) k_tu_plan(DevPic p, int nb_tu, int work_n, int n_parts)
+{
+  const int b = (int)blockIdx.x;
+  if (b < nb_tu) { k_meta_tu_body(p, b); return; }
+  const int q = b - nb_tu;
+  k_intra_plan_body<CF>(p, work_n, q / n_parts, q % n_parts, n_parts);
+}
 
 /* NW = waves per workgroup: 12 for intra pictures (CTBs with hundreds of blocks: up to 8 luma + 2 + 2 chroma waves share a
  * level, the CTB's residuals and its whole plan are fetched into LDS up front), 4 for inter pictures (a handful of intra
@@ -1101,6 +1111,18 @@ void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
 
 /* the plans of all intra blocks of the picture (needs the CU plane only under constrained intra prediction: launched behind
    the metadata planes on the side stream, beside k_inter / k_residual) */
+void m355_launch_tu_plan(const DevPic& p, hipStream_t st)
+{
+  const int nb_tu = (p.n_tus + 255) / 256, split = p.intra_dense ? PLAN_SPLIT : 1, nb = nb_tu + p.n_intra_work * split;
+  if (!nb) return;
+  switch (p.pp.chroma_format_idc) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<0>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<1>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<2>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<3>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
+  }
+}
+
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st)
 {
   if (!p.n_intra_work) return;

@@ -7,6 +7,7 @@
  */
 #include <algorithm>
 #include "k_common.h"
+#include "k_meta_tu.h"
 
 /* one thread per CU: CU-index plane, per-CU edge decisions (deblock.cc:172-210), PB edges */
 __device__ __forceinline__ void k_meta_cu_body(const DevPic& p, const int blk)
@@ -66,39 +67,6 @@ __device__ __forceinline__ void k_meta_cu_body(const DevPic& p, const int blk)
         const int ux = (x0 + k) >> 2;
         if (ux < p.w4) p.edge_pb[uy * p.w4 + ux] |= E_PB_H;
       }
-  }
-}
-
-/* one thread per transform-tree leaf: transform edges + cbf_luma (deblock.cc:33-63, slice.cc:2958) */
-__device__ __forceinline__ void k_meta_tu_body(const DevPic& p, const int blk)
-{
-  M355_GATE(p);
-  const int i = blk * blockDim.x + threadIdx.x;
-  if (i >= p.n_tus) return;
-  const m355_tu tu = p.tus[i];
-  const int n4 = (1 << tu.log2_size) >> 2;
-  const int ux0 = tu.x >> 2, uy0 = tu.y >> 2;
-  const uint32_t ci = d_cu_index_at(p, tu.x, tu.y);
-  int left = 0, top = 0;
-  if (ci) {
-    const m355_cu cu = p.cus[ci - 1];
-    const uint8_t f = p.cuf[ci - 1];
-    if (f & 4) {
-      left = (tu.x == cu.x) ? (f & 1) : 1;
-      top = (tu.y == cu.y) ? ((f >> 1) & 1) : 1;
-    }
-  }
-  const int nz = (tu.flags & M355_TUF_NONZERO_COEFF) ? E_NONZERO : 0;
-  if (nz) {
-    for (int y = 0; y < n4 && uy0 + y < p.h4; y++)
-      for (int x = 0; x < n4 && ux0 + x < p.w4; x++)
-        p.edge_tu[(uy0 + y) * p.w4 + ux0 + x] = (uint8_t)(nz | ((x == 0 && left) ? E_TU_V : 0) | ((y == 0 && top) ? E_TU_H : 0));
-  } else {
-    if (left)
-      for (int y = 0; y < n4 && uy0 + y < p.h4; y++)
-        p.edge_tu[(uy0 + y) * p.w4 + ux0] = (uint8_t)(E_TU_V | ((y == 0 && top) ? E_TU_H : 0));
-    if (top)
-      for (int x = (left ? 1 : 0); x < n4 && ux0 + x < p.w4; x++) p.edge_tu[uy0 * p.w4 + ux0 + x] = E_TU_H;
   }
 }
 
@@ -325,14 +293,14 @@ __global__ void __launch_bounds__(256) k_meta_fill_batch(DevBatch b)
 }
 
 /* metadata planes for intra availability, deblocking and SAO (not read by k_inter / k_residual) */
-void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared)
+void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared, bool with_tu)
 {
   /* edge_tu, edge_pb (sparse writers) and cb_cu (robustness against uncovered areas) live in ONE allocation: one
      fill (`cleared`: k_job_count did it).  pb_of needs none: it is only read where both sides are inter-coded, i.e. covered by a PB. */
   if (!cleared) hipMemsetAsync(p.edge_tu, 0, (size_t)p.w4 * p.h4 * 2 + (size_t)p.wcb * p.hcb * 4 + 64, st);
   const int nb_cu = (p.n_cus + 255) / 256, nb_sao = (p.pp.flags & M355_PF_SAO_ENABLED) ? (p.nCtb * 3 + 255) / 256 : 0;
   if (nb_cu + nb_sao) hipLaunchKernelGGL(k_meta_planes, dim3(nb_cu + nb_sao), dim3(256), 0, st, p, nb_cu);
-  if (p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);
+  if (with_tu && p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);   /* (else: k_tu_plan, k_intra.hip) */
 }
 
 void m355_launch_meta_planes_batch(const HostBatch& b, hipStream_t st)
@@ -368,7 +336,7 @@ void m355_launch_clear_gated(const DevPic& p, void* ptr, size_t bytes, hipStream
 
 void m355_launch_meta(const DevPic& p, hipStream_t st)
 {
-  m355_launch_meta_planes(p, st, false);
+  m355_launch_meta_planes(p, st, false, true);
   m355_launch_meta_jobs(p, st);
 }
 

@@ -1811,8 +1811,15 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
     m355_launch_residual(d, hbd, true, st);
     if (ev) hipEventRecord(ev[1], st);
   }
-  m355_launch_meta_planes(d, s2, clear_in_count);
-  if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, s2);   /* reads the CU plane (constrained intra prediction) */
+  /* M355_MERGE_TU_PLAN=1 (EXPERIMENT, emulator-verified only): transform edges and border plans in one launch */
+  static const bool merge_tu_plan = getenv("M355_MERGE_TU_PLAN") && atoi(getenv("M355_MERGE_TU_PLAN"));
+  if (merge_tu_plan && (c->stages & M355_STAGE_INTRA)) {
+    m355_launch_meta_planes(d, s2, clear_in_count, false);
+    m355_launch_tu_plan(d, s2);
+  } else {
+    m355_launch_meta_planes(d, s2, clear_in_count);
+    if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, s2);   /* reads the CU plane (constrained intra prediction) */
+  }
   if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
   if (ev) hipEventRecord(ev[fused ? 2 : 1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a

@@ -14,3 +14,12 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); u=d['with_upload']
 print('M355_DEVICE_WORKLIST=$m: with_upload %.4f ms  submit_only %.4f ms  copying %.4f ms  (resident lists %.4f ms)' % (u['ms_per_step'], u['submit_only']['ms_per_step'], u['copying_submit']['ms_per_step'], d['ms_per_step']))" | tee -a $O/submit.txt
 done; done
 M355_DEVICE_WORKLIST=1 M355_PROFILE_UPLOAD=1 timeout 120 python tools/prof_submit.py 2>&1 | tail -6 | tee $O/submit_host_phases.txt
+# second prepared experiment: transform edges + border plans in one launch (M355_MERGE_TU_PLAN=1): parity, then C5 / C3 three in flight, alternating
+M355_MERGE_TU_PLAN=1 timeout 600 python -m pytest tests/test_gpu_random.py tests/test_gpu_synth.py tests/test_gpu_girlshy.py tests/test_gpu_encintra.py -m gpu -x -q 2>&1 | tail -1 | sed "s/^/M355_MERGE_TU_PLAN=1: /" | tee -a $O/parity.txt
+for rep in 1 2 3; do for m in 0 1; do for w in c5_8k10_8tiles c3_4k_inter; do
+  M355_MERGE_TU_PLAN=$m timeout 200 python bench.py --no-cpu-baseline --no-end-to-end --no-with-upload --no-dependent-chain --workload $w --steps 200 --warmup 10 --pipeline-depth 3 2>>$O/bench.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('M355_MERGE_TU_PLAN=$m %-16s %.4f ms/pic (p10 %.4f p90 %.4f)' % ('$w', d['ms_per_step'], d['ms_per_step_spread']['p10'], d['ms_per_step_spread']['p90']))" | tee -a $O/merge.txt
+done; done; done
+# third: tools/experiments/inter_prologue_overlap.patch (apply, tools/variants.sh prologue "", tools/bench_variants.sh base prologue)
