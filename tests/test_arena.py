@@ -109,7 +109,7 @@ def test_in_place_submit_emulated(emu_lib, oracle, case):  # noqa: F811
     run(emu_lib, oracle, case)
 
 
-@pytest.mark.parametrize("case", CASES[:2], ids=lambda c: "seed%d" % c["seed"])
+@pytest.mark.parametrize("case", CASES[1:2], ids=lambda c: "seed%d" % c["seed"])
 def test_in_place_resident_emulated(emu_lib, oracle, case):  # noqa: F811
     run_resident(emu_lib, oracle, case)
 

@@ -28,16 +28,10 @@ def test_device_work_list_gpu(oracle, mode):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_small_pictures_through_the_large_picture_launch_order_emulated(emu_lib, oracle):  # noqa: F811
-    """pictures of 16 384 prediction blocks and more zero-fill their metadata planes and reset k_intra's ticket inside k_job_count
-    (launch_prediction, runtime.hip); M355_CLEAR_IN_COUNT_MIN=1 sends the CPU tier's small pictures down the same path"""
-    r = subprocess.run([sys.executable, os.path.join(HERE, "worklist_worker.py"), EMU_SO, oracle._name], env=dict(os.environ, M355_CLEAR_IN_COUNT_MIN="1"),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-
-
 def test_transform_edges_and_border_plans_in_one_launch_emulated(emu_lib, oracle):  # noqa: F811
-    """M355_MERGE_TU_PLAN=1 (experiment, off by default): k_meta_tu's scatter and k_intra_plan's plans as one launch (k_tu_plan)"""
+    """M355_MERGE_TU_PLAN=1 (experiment, off by default): k_meta_tu's scatter and k_intra_plan's plans as one launch (k_tu_plan) — with
+    M355_CLEAR_IN_COUNT_MIN=1, which sends the CPU tier's small pictures down the launch order of pictures of 16 384 prediction blocks and
+    more (metadata-plane fill and k_intra's ticket reset inside k_job_count, launch_prediction in runtime.hip)"""
     r = subprocess.run([sys.executable, os.path.join(HERE, "worklist_worker.py"), EMU_SO, oracle._name],
                        env=dict(os.environ, M355_MERGE_TU_PLAN="1", M355_CLEAR_IN_COUNT_MIN="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -54,7 +54,7 @@ def test_group_in_one_process_matches_oracle(emu_lib, oracle, case, nranks):  # 
         assert_planes_equal(got, want, "group rank %d of %d" % (r, nranks))
 
 
-IN_PLACE_CASES = [(CASES[1][0], 4, 1), (CASES[2][0], 2, 2), (CASES[6][0], 4, 1), (CASES[0][0], 1, 1)]
+IN_PLACE_CASES = [(CASES[1][0], 4, 1), (CASES[2][0], 2, 2), (CASES[6][0], 4, 1)]
 
 
 @pytest.mark.parametrize("case,nranks,depth", IN_PLACE_CASES, ids=lambda v: ("%dx%d_seed%d" % (v["width"], v["height"], v["seed"])) if isinstance(v, dict) else "n%d" % v)
