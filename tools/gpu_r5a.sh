@@ -22,4 +22,5 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('M355_MERGE_TU_PLAN=$m %-16s %.4f ms/pic (p10 %.4f p90 %.4f)' % ('$w', d['ms_per_step'], d['ms_per_step_spread']['p10'], d['ms_per_step_spread']['p90']))" | tee -a $O/merge.txt
 done; done; done
-# third: tools/experiments/inter_prologue_overlap.patch (apply, tools/variants.sh prologue "", tools/bench_variants.sh base prologue)
+# third: the prepared patches — apply each to a copy of the tree, tools/variants.sh <name> "", then tools/bench_variants.sh base <name> (C5) and the same for c3_4k_inter:
+#   tools/experiments/inter_prologue_overlap.patch, sao_saddr_offsets.patch, meta_sao_batched_neighbour_loads.patch
