@@ -3,7 +3,8 @@
  *
  * A single-threaded, fiber-based SIMT interpreter that lets the CPU test tier compile the product's
  * .hip sources UNCHANGED with g++ (this directory shadows <hip/hip_runtime.h>) and execute the
- * kernels block by block: every HIP thread is a ucontext fiber, __syncthreads() and the wave-level
+ * kernels block by block: every HIP thread is a fiber (simt_emu.cpp: a six-register switch on x86-64,
+ * ucontext elsewhere and under AddressSanitizer), __syncthreads() and the wave-level
  * collectives (__shfl*, __ballot, wave barrier) are real rendezvous points, LDS is the kernels'
  * own static __shared__ storage, global memory is host memory.  It exists because the build
  * container has no GPU: indexing, LDS staging, barrier placement and divergence bugs are caught

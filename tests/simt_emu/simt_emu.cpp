@@ -9,8 +9,50 @@ namespace {
 
 enum State { RUNNABLE, AT_BLOCK_BARRIER, AT_WAVE_BARRIER, DONE };
 
+/* Context switch.  glibc's swapcontext / getcontext make one rt_sigprocmask system call each, which was a third of the
+ * CPU tier's run time; on x86-64 the switch is six callee-saved registers and the stack pointer, so it is written out here.
+ * Other hosts, and builds with -DSIMT_EMU_UCONTEXT (the AddressSanitizer build of tools/fuzz_asan.py: ASan follows
+ * swapcontext, not a hand-made switch), use ucontext. */
+#if defined(__x86_64__) && !defined(SIMT_EMU_UCONTEXT) && !defined(__SANITIZE_ADDRESS__)
+#define SIMT_EMU_ASM_SWITCH 1
+extern "C" void simt_emu_switch(void** save_sp, void* load_sp);
+asm(".text\n"
+    ".globl simt_emu_switch\n"
+    ".type simt_emu_switch,@function\n"
+    "simt_emu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size simt_emu_switch,.-simt_emu_switch\n");
+struct Context { void* sp = nullptr; };
+inline void ctx_switch(Context& from, Context& to) { simt_emu_switch(&from.sp, to.sp); }
+inline void ctx_make(Context& c, char* stack, size_t size, void (*entry)())
+{
+  /* what simt_emu_switch pops: r15 r14 r13 r12 rbx rbp, then `ret` into entry with rsp = 8 (mod 16) as after a call */
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 64);
+  for (int i = 0; i < 6; i++) sp[i] = nullptr;
+  sp[6] = (void*)entry;
+  sp[7] = nullptr;                 /* entry never returns */
+  c.sp = sp;
+}
+#else
+struct Context { ucontext_t uc; };
+inline void ctx_switch(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+inline void ctx_make(Context& c, char* stack, size_t size, void (*entry)())
+{
+  getcontext(&c.uc);
+  c.uc.uc_stack.ss_sp = stack;
+  c.uc.uc_stack.ss_size = size;
+  c.uc.uc_link = nullptr;
+  makecontext(&c.uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-  ucontext_t ctx;
+  Context ctx;
   char* stack = nullptr;
   State state = RUNNABLE;
   uint3 tid;
@@ -20,13 +62,20 @@ struct Fiber {
 struct Block {
   std::vector<Fiber> fibers;
   std::vector<unsigned long long> slots;   /* 64 per wave */
-  ucontext_t sched;
+  Context sched;
   int current = -1;
   const std::function<void()>* body = nullptr;
 };
 
 Block* g_blk = nullptr;
 const size_t kStack = 256 * 1024;
+/* fiber stacks live as long as the launching host thread: a fresh 256 KB allocation per fiber and launch is an mmap /
+ * page-fault / munmap cycle */
+struct Stacks {
+  std::vector<char*> v;
+  ~Stacks() { for (char* p : v) free(p); }
+};
+thread_local Stacks g_stacks;
 hipError_t g_last = hipSuccess;
 
 void fiber_entry()
@@ -34,14 +83,14 @@ void fiber_entry()
   Block* b = g_blk;
   (*b->body)();
   b->fibers[b->current].state = DONE;
-  swapcontext(&b->fibers[b->current].ctx, &b->sched);
+  ctx_switch(b->fibers[b->current].ctx, b->sched);
 }
 
 void yield_to_scheduler()
 {
   Block* b = g_blk;
   Fiber& f = b->fibers[b->current];
-  swapcontext(&f.ctx, &b->sched);
+  ctx_switch(f.ctx, b->sched);
   /* resumed: restore the thread's built-ins */
   threadIdx = f.tid;
 }
@@ -59,7 +108,7 @@ void run_block(Block& b)
       if (f.state != RUNNABLE) continue;
       b.current = i;
       threadIdx = f.tid;
-      swapcontext(&b.sched, &f.ctx);
+      ctx_switch(b.sched, f.ctx);
       progressed = true;
     }
     if (done == n) break;
@@ -114,7 +163,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
   b.body = &body;
   b.fibers.resize(n);
   b.slots.assign(((n + 63) / 64) * 64, 0);
-  for (int i = 0; i < n; i++) b.fibers[i].stack = (char*)malloc(kStack);
+  while ((int)g_stacks.v.size() < n) g_stacks.v.push_back((char*)malloc(kStack));
+  for (int i = 0; i < n; i++) b.fibers[i].stack = g_stacks.v[i];
   for (unsigned bz = 0; bz < grid.z; bz++)
     for (unsigned by = 0; by < grid.y; by++)
       for (unsigned bx = 0; bx < grid.x; bx++) {
@@ -124,15 +174,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
           f.state = RUNNABLE;
           f.tid.x = i % block.x; f.tid.y = (i / block.x) % block.y; f.tid.z = i / (block.x * block.y);
           f.wave = i / 64; f.lane = i % 64;
-          getcontext(&f.ctx);
-          f.ctx.uc_stack.ss_sp = f.stack;
-          f.ctx.uc_stack.ss_size = kStack;
-          f.ctx.uc_link = nullptr;
-          makecontext(&f.ctx, fiber_entry, 0);
+          ctx_make(f.ctx, f.stack, kStack, fiber_entry);
         }
         run_block(b);
       }
-  for (int i = 0; i < n; i++) free(b.fibers[i].stack);
 }
 
 void sync_threads()
