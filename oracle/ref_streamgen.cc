@@ -51,8 +51,16 @@
  *   F_WPP       entropy_coding_sync_enabled_flag: one substream per CTB row with the context models of the row above's second
  *               CTB (decode_substream, slice.cc:4732-4900; what decode_slice_unit_WPP threads parse, decctx.cc:840-1061)
  *
+ *   geom        picture / block geometry other than the default (CTB 64, CBs 8..64, TBs 4..32, uniform tiles): bits 0-1 CTB 32 (1) or
+ *               16 (2); G_MINCB16 coding blocks of at least 16x16 (no 8x8 CUs, so no intra NxN below 8x8 PUs and no 8x4 / 4x8 PBs);
+ *               G_TILES uniform_spacing_flag = 0 with explicit column widths / row heights (pps.cc:392-421); G_NOTILEFILTER
+ *               loop_filter_across_tiles_enabled_flag = 0 (deblock.cc:191-209, sao.cc:158-163); G_PARMERGE
+ *               log2_parallel_merge_level = 4 (shared merge candidates, motion.cc:1630-1680); G_TB16 TBs 4..16 and
+ *               strong_intra_smoothing off; G_CONFWIN a conformance window (sps.cc:228-262: what the application sees is
+ *               a cropped picture, image.cc:434-470 pixels_confwin)
+ *
  * usage: streamgen out.h265 W H bit_depth tile_cols tile_rows n_frames seed [intra_pct=5] [b_frames=1] [sao=1]
- *                  [features=0] [chroma=1] [slices=1]
+ *                  [features=0] [chroma=1] [slices=1] [geom=0]
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -86,7 +94,8 @@ namespace {
 
 enum { F_WP = 1, F_TSKIP = 2, F_BYPASS = 4, F_QPDELTA = 8, F_PCM = 16, F_SCALING = 32, F_SCALING_PPS = 64, F_REXT = 256, F_CIP = 512, F_DEPSLICE = 1024,
        F_RA = 2048, F_WPP = 4096, F_TMVP = 8192, F_SDH = 16384, F_LT = 32768 };
-struct Cfg { int W, H, bd, tc, tr, frames; uint32_t seed; int intra_pct, b_frames, sao, features, chroma, slices; };
+enum { G_CTB = 3, G_MINCB16 = 4, G_TILES = 8, G_NOTILEFILTER = 16, G_PARMERGE = 32, G_TB16 = 64, G_CONFWIN = 128 };
+struct Cfg { int W, H, bd, tc, tr, frames; uint32_t seed; int intra_pct, b_frames, sao, features, chroma, slices, geom; };
 
 struct Gen {
   Cfg cfg;
@@ -434,6 +443,8 @@ struct Gen {
       const int r = below(10);
       const bool amp_ok = S.amp_enabled_flag && log2 > S.Log2MinCbSizeY;
       part = r < 5 ? PART_2Nx2N : (r < 7 ? PART_2NxN : (r < 9 ? PART_Nx2N : (amp_ok ? PART_2NxnU + below(4) : PART_2NxN)));
+      const bool nxn_ok = log2 == S.Log2MinCbSizeY && log2 > 3;                  /* four square PBs: only the smallest CB, and not 8x8 */
+      if (nxn_ok && r == 9) part = PART_NxN;
       bit(CONTEXT_MODEL_PART_MODE + 0, part == PART_2Nx2N);
       if (part != PART_2Nx2N) {
         const bool horiz = part == PART_2NxN || part == PART_2NxnU || part == PART_2NxnD;
@@ -442,8 +453,8 @@ struct Gen {
           const bool plain = part == PART_2NxN || part == PART_Nx2N;
           bit(CONTEXT_MODEL_PART_MODE + 3, plain);
           if (!plain) bypass(part == PART_2NxnD || part == PART_nRx2N);
-        }
-        /* log2 == min (8): bit1 = 1 -> 2NxN, 0 -> Nx2N, nothing else to code (slice.cc:1788-1800) */
+        } else if (nxn_ok && !horiz) bit(CONTEXT_MODEL_PART_MODE + 2, part == PART_Nx2N);
+        /* log2 == min: bit1 = 1 -> 2NxN; 0 -> Nx2N at 8x8, one more bin (Nx2N / NxN) above (slice.cc:1773-1791) */
       }
     }
     img.set_PartMode(x0, y0, (enum PartMode)part);
@@ -521,6 +532,7 @@ struct Gen {
         case PART_2NxnU: prediction_unit(nCbS, q, ctDepth); prediction_unit(nCbS, nCbS - q, ctDepth); break;
         case PART_2NxnD: prediction_unit(nCbS, nCbS - q, ctDepth); prediction_unit(nCbS, q, ctDepth); break;
         case PART_nLx2N: prediction_unit(q, nCbS, ctDepth); prediction_unit(nCbS - q, nCbS, ctDepth); break;
+        case PART_NxN: for (int k = 0; k < 4; k++) prediction_unit(h, h, ctDepth); break;
         default: prediction_unit(nCbS - q, nCbS, ctDepth); prediction_unit(q, nCbS, ctDepth); break;
       }
     }
@@ -715,7 +727,11 @@ struct Gen {
     out.write_bit(P.entropy_coding_sync_enabled_flag);
     if (P.tiles_enabled_flag) {
       out.write_uvlc(P.num_tile_columns - 1); out.write_uvlc(P.num_tile_rows - 1);
-      out.write_bit(1);                                                         /* uniform_spacing_flag */
+      out.write_bit(P.uniform_spacing_flag);
+      if (!P.uniform_spacing_flag) {                                            /* the last column / row is what is left (pps.cc:392-421) */
+        for (int i = 0; i < P.num_tile_columns - 1; i++) out.write_uvlc(P.colWidth[i] - 1);
+        for (int i = 0; i < P.num_tile_rows - 1; i++) out.write_uvlc(P.rowHeight[i] - 1);
+      }
       out.write_bit(P.loop_filter_across_tiles_enabled_flag);
     }
     out.write_bit(P.pps_loop_filter_across_slices_enabled_flag);
@@ -728,7 +744,7 @@ struct Gen {
     out.write_bit(P.pic_scaling_list_data_present_flag);
     if (P.pic_scaling_list_data_present_flag) write_scaling_list_data(out);
     out.write_bit(0);                                                           /* lists_modification_present_flag */
-    out.write_uvlc(0);                                                          /* log2_parallel_merge_level_minus2 */
+    out.write_uvlc(P.log2_parallel_merge_level - 2);
     out.write_bit(0);                                                           /* slice_segment_header_extension_present_flag */
     out.write_bit(P.pps_range_extension_flag);                                  /* pps_extension_present_flag */
     if (P.pps_range_extension_flag) {
@@ -753,7 +769,7 @@ int run(const Cfg& cfg, const char* out_name)
   std::unique_ptr<Gen> G(new Gen);
   Gen& g = *G;
   g.cfg = cfg;
-  const bool plain = cfg.features == 0 && cfg.chroma == 1 && cfg.slices == 1;  /* then every header comes from the reference's own writers */
+  const bool plain = cfg.features == 0 && cfg.chroma == 1 && cfg.slices == 1 && cfg.geom == 0;  /* then every header comes from the reference's own writers */
   const bool rext = g.has(F_REXT);
   g.vps = std::make_shared<video_parameter_set>();
   g.sps = std::make_shared<seq_parameter_set>();
@@ -761,9 +777,16 @@ int run(const Cfg& cfg, const char* out_name)
   g.vps->set_defaults(Profile_Main, 6, 2);
   seq_parameter_set& S = *g.sps;
   S.set_defaults();
-  S.set_CB_log2size_range(3, 6);
-  S.set_TB_log2size_range(2, 5);
+  const int ctbLog2 = 6 - (cfg.geom & G_CTB);
+  const int maxTbLog2 = std::min((cfg.geom & G_TB16) ? 4 : 5, ctbLog2);
+  S.set_CB_log2size_range((cfg.geom & G_MINCB16) ? 4 : 3, ctbLog2);
+  S.set_TB_log2size_range(2, maxTbLog2);
   S.set_resolution(cfg.W, cfg.H);
+  if (cfg.geom & G_CONFWIN) {                                                   /* offsets count chroma samples (sps.cc:228-262) */
+    S.conformance_window_flag = 1;
+    const int sw = cfg.chroma == 1 || cfg.chroma == 2 ? 2 : 1, sh = cfg.chroma == 1 ? 2 : 1;
+    S.conf_win_left_offset = 4 / sw; S.conf_win_right_offset = 8 / sw; S.conf_win_top_offset = 2 / sh; S.conf_win_bottom_offset = 6 / sh;
+  }
   S.chroma_format_idc = cfg.chroma;
   S.bit_depth_luma = S.bit_depth_chroma = cfg.bd;
   S.log2_max_pic_order_cnt_lsb = 8;
@@ -777,14 +800,15 @@ int run(const Cfg& cfg, const char* out_name)
   if (g.has(F_PCM)) {
     S.pcm_enabled_flag = 1;
     S.pcm_sample_bit_depth_luma = cfg.bd - 1; S.pcm_sample_bit_depth_chroma = cfg.bd - 2;     /* samples are shifted up to the bit depth (slice.cc:4243-4253) */
-    S.log2_min_pcm_luma_coding_block_size = 3; S.log2_diff_max_min_pcm_luma_coding_block_size = 2;
+    S.log2_min_pcm_luma_coding_block_size = (cfg.geom & G_MINCB16) ? 4 : 3;      /* >= the smallest coding block, <= min(CTB, 32) */
+    S.log2_diff_max_min_pcm_luma_coding_block_size = std::min(5, ctbLog2) - S.log2_min_pcm_luma_coding_block_size;
     S.pcm_loop_filter_disable_flag = (cfg.seed >> 1) & 1;
   }
   if (g.has(F_SCALING) || g.has(F_SCALING_PPS)) { S.scaling_list_enable_flag = 1; S.sps_scaling_list_data_present_flag = 0; }   /* the SPS carries the default lists */
   S.long_term_ref_pics_present_flag = g.has(F_LT) ? 1 : 0;
   S.num_long_term_ref_pics_sps = 0;
   S.sps_temporal_mvp_enabled_flag = g.has(F_TMVP) ? 1 : 0;
-  S.strong_intra_smoothing_enable_flag = 1;
+  S.strong_intra_smoothing_enable_flag = (cfg.geom & G_TB16) ? 0 : 1;
   if (rext) {
     S.sps_extension_present_flag = 1; S.sps_range_extension_flag = 1;
     S.range_extension.transform_skip_rotation_enabled_flag = 1;
@@ -810,7 +834,20 @@ int run(const Cfg& cfg, const char* out_name)
   P.tiles_enabled_flag = (cfg.tc > 1 || cfg.tr > 1);
   P.num_tile_columns = cfg.tc; P.num_tile_rows = cfg.tr;
   P.uniform_spacing_flag = 1;
-  P.loop_filter_across_tiles_enabled_flag = 1;
+  if ((cfg.geom & G_TILES) && P.tiles_enabled_flag) {
+    /* random cuts: every column / row at least one CTB (set_derived_values takes colWidth / rowHeight as they are then, pps.cc:696-731) */
+    P.uniform_spacing_flag = 0;
+    uint32_t tr = cfg.seed * 747796405u + 2891336453u;
+    auto r = [&]() { tr ^= tr << 13; tr ^= tr >> 17; tr ^= tr << 5; return tr; };
+    auto cutup = [&](int total, int parts, uint16_t* size) {
+      for (int i = 0; i < parts; i++) size[i] = 1;
+      for (int left = total - parts; left > 0; left--) size[r() % parts]++;
+    };
+    cutup(S.PicWidthInCtbsY, cfg.tc, P.colWidth);
+    cutup(S.PicHeightInCtbsY, cfg.tr, P.rowHeight);
+  }
+  P.loop_filter_across_tiles_enabled_flag = (cfg.geom & G_NOTILEFILTER) ? 0 : 1;
+  if (cfg.geom & G_PARMERGE) P.log2_parallel_merge_level = std::min(4, ctbLog2);
   P.pps_loop_filter_across_slices_enabled_flag = 1;
   P.deblocking_filter_control_present_flag = 0;
   P.pic_cb_qp_offset = 1; P.pic_cr_qp_offset = -1;
@@ -820,7 +857,7 @@ int run(const Cfg& cfg, const char* out_name)
     P.constrained_intra_pred_flag = g.has(F_CIP);
     P.transform_skip_enabled_flag = g.has(F_TSKIP);
     P.transquant_bypass_enable_flag = g.has(F_BYPASS);
-    P.cu_qp_delta_enabled_flag = g.has(F_QPDELTA); P.diff_cu_qp_delta_depth = g.has(F_QPDELTA) ? 1 + (int)(cfg.seed & 1) : 0;
+    P.cu_qp_delta_enabled_flag = g.has(F_QPDELTA); P.diff_cu_qp_delta_depth = g.has(F_QPDELTA) ? std::min(1 + (int)(cfg.seed & 1), (int)S.log2_diff_max_min_luma_coding_block_size) : 0;
     P.pps_slice_chroma_qp_offsets_present_flag = g.has(F_QPDELTA) && cfg.chroma != 0;
     P.weighted_pred_flag = P.weighted_bipred_flag = g.has(F_WP);
     P.dependent_slice_segments_enabled_flag = g.has(F_DEPSLICE);
@@ -828,11 +865,11 @@ int run(const Cfg& cfg, const char* out_name)
     P.pic_scaling_list_data_present_flag = g.has(F_SCALING_PPS);
     if (rext) {
       P.pps_extension_flag = 1; P.pps_range_extension_flag = 1;
-      P.range_extension.log2_max_transform_skip_block_size = g.has(F_TSKIP) ? 5 : 2;
+      P.range_extension.log2_max_transform_skip_block_size = g.has(F_TSKIP) ? maxTbLog2 : 2;
       P.range_extension.cross_component_prediction_enabled_flag = cfg.chroma == 3;
       if (cfg.chroma != 0) {
         P.range_extension.chroma_qp_offset_list_enabled_flag = 1;
-        P.range_extension.diff_cu_chroma_qp_offset_depth = 1;
+        P.range_extension.diff_cu_chroma_qp_offset_depth = std::min(1, (int)S.log2_diff_max_min_luma_coding_block_size);
         P.range_extension.chroma_qp_offset_list_len = 2;
         P.range_extension.cb_qp_offset_list[0] = 3; P.range_extension.cr_qp_offset_list[0] = -4;
         P.range_extension.cb_qp_offset_list[1] = -6; P.range_extension.cr_qp_offset_list[1] = 5;
@@ -1040,12 +1077,16 @@ int run(const Cfg& cfg, const char* out_name)
 
 int main(int argc, char** argv)
 {
-  if (argc < 9) { fprintf(stderr, "usage: %s out.h265 W H bit_depth tile_cols tile_rows n_frames seed [intra_pct=5] [b_frames=1] [sao=1] [features=0] [chroma=1] [slices=1]\n", argv[0]); return 2; }
+  if (argc < 9) { fprintf(stderr, "usage: %s out.h265 W H bit_depth tile_cols tile_rows n_frames seed [intra_pct=5] [b_frames=1] [sao=1] [features=0] [chroma=1] [slices=1] [geom=0]\n", argv[0]); return 2; }
   Cfg c;
   c.W = atoi(argv[2]); c.H = atoi(argv[3]); c.bd = atoi(argv[4]); c.tc = atoi(argv[5]); c.tr = atoi(argv[6]); c.frames = atoi(argv[7]);
   c.seed = (uint32_t)strtoul(argv[8], nullptr, 0);
   c.intra_pct = argc > 9 ? atoi(argv[9]) : 5; c.b_frames = argc > 10 ? atoi(argv[10]) : 1; c.sao = argc > 11 ? atoi(argv[11]) : 1;
   c.features = argc > 12 ? (int)strtol(argv[12], nullptr, 0) : 0; c.chroma = argc > 13 ? atoi(argv[13]) : 1; c.slices = argc > 14 ? atoi(argv[14]) : 1;
+  c.geom = argc > 15 ? (int)strtol(argv[15], nullptr, 0) : 0;
+  const int min_cb = (c.geom & G_MINCB16) ? 16 : 8;
+  if ((c.geom & G_CTB) == 3 || c.W % min_cb || c.H % min_cb || c.geom < 0 || c.geom > 255) { fprintf(stderr, "streamgen: bad geometry\n"); return 2; }
+  if (c.tc > (c.W + (64 >> (c.geom & G_CTB)) - 1) / (64 >> (c.geom & G_CTB)) || c.tr > (c.H + (64 >> (c.geom & G_CTB)) - 1) / (64 >> (c.geom & G_CTB))) { fprintf(stderr, "streamgen: more tiles than CTBs\n"); return 2; }
   if (c.W % 8 || c.H % 8 || c.W < 16 || c.H < 16 || c.bd < 8 || c.bd > 12 || c.tc < 1 || c.tr < 1 || c.frames < 1 || c.chroma < 0 || c.chroma > 3 || c.slices < 1 || c.slices > 32) { fprintf(stderr, "streamgen: bad arguments\n"); return 2; }
   if ((c.features & F_PCM) && c.bd - 2 < 1) { fprintf(stderr, "streamgen: bad arguments\n"); return 2; }
   /* WPP: one slice, no tiles (the reference refuses tiles + WPP with threads, decctx.cc:813-817); the reference picture set and the

@@ -213,9 +213,21 @@ hipError_t hipGetLastError(void) { hipError_t e = g_last; g_last = hipSuccess; r
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "simt_emu"); strcpy(p->gcnArchName, "simt_emu"); p->multiProcessorCount = 1; return hipSuccess; }
-hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+/* Device (and pinned) memory is NOT zero on the GPU, so it is not zero here: every allocation is filled with 0xA5 — a kernel or a
+ * host path that relies on fresh memory being zero fails in the CPU tier.  SIMT_EMU_POISON=<byte> picks another fill (0 = zeros). */
+static int poison_byte()
+{
+  static const int v = [] { const char* e = getenv("SIMT_EMU_POISON"); return e && *e ? (int)strtol(e, nullptr, 0) & 255 : 0xA5; }();
+  return v;
+}
+hipError_t hipMalloc(void** p, size_t n)
+{
+  *p = malloc(n ? n : 1);
+  if (*p) memset(*p, poison_byte(), n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }   /* pinned memory is not zero either */
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }

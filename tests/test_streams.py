@@ -7,7 +7,8 @@ slices with merge / skip / AMVP motion the DECODER derives, two reference pictur
 generator's own writers (feature streams below), explicit weighted prediction, transform skip, RDPCM, transform_skip_rotation,
 cu_transquant_bypass, cu_qp_delta / slice QP and chroma QP offsets, PCM units, default and explicit scaling lists, constrained
 intra prediction, several (dependent) slice segments per picture with their own deblocking / SAO parameters, monochrome /
-4:2:2 / 4:4:4 with cross-component prediction.  Each feature case also asserts, through the glue's coverage counters, that the
+4:2:2 / 4:4:4 with cross-component prediction; CTBs of 32 and 16, coding blocks from 16x16 (inter NxN), non-uniform tiles, no filtering
+across tile boundaries, parallel merge level, a conformance window (geometry cases).  Each feature case also asserts, through the glue's coverage counters, that the
 recorder branch which maps the feature really ran.
 
 CPU tier: small streams, backend = SIMT-interpreter build.  GPU tier: up to 4K tiled 10-bit."""
@@ -33,19 +34,23 @@ F_WP, F_TSKIP, F_BYPASS, F_QPDELTA, F_PCM, F_SCALING, F_SCALING_PPS, F_REXT, F_C
 # order, slice-header reference picture sets with up to 6 pictures and 4 active references per list, a long-term picture,
 # temporal motion vector prediction, sign data hiding, and WPP substreams (one per CTB row, parsed by the reference's WPP threads)
 F_RA, F_WPP, F_TMVP, F_SDH, F_LT = 2048, 4096, 8192, 16384, 32768
+# geometry bits of oracle/ref_streamgen.cc (`geom`): CTB 32 / 16 instead of 64, coding blocks of at least 16x16 (inter NxN), explicit
+# (non-uniform) tile column widths / row heights, no in-loop filtering across tile boundaries, log2_parallel_merge_level 4, TBs of at
+# most 16x16 + strong intra smoothing off, a conformance window (the application sees a cropped picture)
+G_CTB32, G_CTB16, G_MINCB16, G_TILES, G_NOTILEFILTER, G_PARMERGE, G_TB16, G_CONFWIN = 1, 2, 4, 8, 16, 32, 64, 128
 # coverage counters of the glue's recorder (glue/m355_glue.cc FEAT_*): a stream that carries a feature must drive its branch
 FEATS = ["pcm_cu", "weighted_pb", "bypass_rb", "skip_rb", "rdpcm_rb", "rotate_rb", "scaling_rb", "cross_comp_rb", "multi_slice_pic",
          "weighted_pb_later_slice", "no_boundary_filter_ib", "fill_pb", "chroma_422_rb", "chroma_444_rb", "mono_pic", "deblock_off_slice"]
 
 
-def make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra_pct=5, b_frames=1, sao=1, features=0, chroma=1, slices=1):
+def make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra_pct=5, b_frames=1, sao=1, features=0, chroma=1, slices=1, geom=0):
     if not os.path.exists(STREAMGEN):
         if not os.path.isdir("/root/reference"):
             pytest.skip("oracle/_ref/streamgen not available here")
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-j8", "gen"], check=True, stdout=subprocess.DEVNULL)
-    out = os.path.join(str(tmp_path), "s_%dx%d_%d_%dx%d_%d.h265" % (w, h, bd, tc, tr, seed))
+    out = os.path.join(str(tmp_path), "s_%dx%d_%d_%dx%d_%d_%d.h265" % (w, h, bd, tc, tr, seed, geom))
     subprocess.run([STREAMGEN, out, str(w), str(h), str(bd), str(tc), str(tr), str(frames), str(seed), str(intra_pct), str(b_frames), str(sao),
-                    str(features), str(chroma), str(slices)], check=True)
+                    str(features), str(chroma), str(slices), str(geom)], check=True)
     return open(out, "rb").read()
 
 
@@ -134,6 +139,51 @@ RA_GPU_CASES = [
 def test_random_access_streams_gpu(ref, tmp_path, monkeypatch, w, h, bd, frames, seed, feat, threads):
     monkeypatch.delenv("M355_LIB", raising=False)
     check_random_access(ref, make_stream(tmp_path, w, h, bd, 1, 1, frames, seed, 5, 1, 1, feat), frames, threads, capi.DEFAULT_LIB)
+
+
+# Picture / block geometry away from the generator's default (CTB 64, CBs from 8x8, uniform tiles, whole picture shown): what real
+# streams vary and the cases above do not.
+# (w, h, bit depth, tile cols, tile rows, frames, seed, intra %, features, chroma format, slices, geometry, parser threads, ranks)
+GEOM_CPU_CASES = [
+    (256, 128, 8, 1, 1, 3, 101, 10, 0, 1, 1, G_CTB32, 2, 0),
+    (256, 128, 8, 2, 2, 3, 104, 10, 0, 1, 1, G_CTB16 | G_TILES | G_NOTILEFILTER, 4, 0),
+    (256, 128, 8, 1, 1, 3, 106, 10, 0, 1, 1, G_CTB32 | G_MINCB16 | G_PARMERGE, 2, 0),
+    (192, 128, 8, 1, 1, 3, 110, 10, 0, 3, 2, G_CTB16 | G_TB16 | G_CONFWIN, 2, 0),
+    (192, 128, 10, 2, 1, 4, 115, 20, F_WP | F_TSKIP | F_QPDELTA | F_PCM | F_REXT, 3, 2, G_CTB32 | G_MINCB16 | G_TILES | G_TB16, 3, 0),
+    (256, 192, 8, 1, 1, 10, 113, 5, F_RA | F_WPP | F_TMVP | F_SDH, 1, 1, G_CTB32, 4, 0),
+    (256, 128, 8, 1, 1, 10, 114, 5, F_RA | F_LT | F_TMVP | F_SDH, 1, 1, G_CTB16 | G_PARMERGE | G_CONFWIN, 3, 0),
+    (320, 192, 8, 3, 2, 4, 119, 15, F_WP | F_QPDELTA | F_PCM, 1, 1, G_CTB16 | G_TILES | G_NOTILEFILTER, 4, 3),   # uneven tiles over three ranks
+]
+GEOM_GPU_CASES = [
+    (832, 480, 8, 1, 1, 5, 131, 10, 0, 1, 1, G_CTB32, 8, 0),
+    (832, 480, 10, 1, 1, 5, 132, 10, F_QPDELTA, 1, 2, G_CTB16, 8, 0),
+    (1280, 720, 8, 3, 2, 4, 133, 10, 0, 1, 1, G_TILES | G_NOTILEFILTER, 8, 0),
+    (1920, 1088, 8, 2, 2, 4, 134, 10, F_WP | F_QPDELTA, 1, 3, G_CTB32 | G_TILES | G_CONFWIN, 8, 0),              # 1080 lines shown out of 1088 coded
+    (832, 480, 8, 1, 1, 5, 135, 20, F_PCM | F_TSKIP | F_REXT, 3, 1, G_CTB16 | G_MINCB16 | G_TB16, 8, 0),
+    (1920, 1088, 8, 1, 1, 17, 136, 5, F_RA | F_LT | F_TMVP | F_SDH | F_WPP, 1, 1, G_CTB32 | G_PARMERGE | G_CONFWIN, 8, 0),
+    (1920, 1088, 8, 3, 2, 4, 137, 10, F_WP, 1, 1, G_CTB32 | G_TILES, 8, 3),
+]
+
+
+def check_geometry(ref, tmp_path, monkeypatch, case, backend):
+    w, h, bd, tc, tr, frames, seed, intra, feat, chroma, slices, geom, threads, ranks = case
+    if ranks:
+        monkeypatch.setenv("M355_GLUE_RANKS", str(ranks))
+    data = make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra, 1, 1, feat, chroma, slices, geom)
+    (check_random_access if feat & F_RA else check)(ref, data, frames, threads, backend)
+
+
+@pytest.mark.parametrize("case", GEOM_CPU_CASES, ids=lambda c: "%dx%d-seed%d-geom%d" % (c[0], c[1], c[6], c[11]))
+def test_geometry_streams_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, case):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    check_geometry(ref, tmp_path, monkeypatch, case, EMU_SO)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GEOM_GPU_CASES, ids=lambda c: "%dx%d-seed%d-geom%d" % (c[0], c[1], c[6], c[11]))
+def test_geometry_streams_gpu(ref, tmp_path, monkeypatch, case):
+    monkeypatch.delenv("M355_LIB", raising=False)
+    check_geometry(ref, tmp_path, monkeypatch, case, capi.DEFAULT_LIB)
 
 
 # One bitstream across several backend contexts of ONE process (M355_GLUE_RANKS: the glue splits every picture's lists by tile
