@@ -108,7 +108,7 @@ enum { hipStreamNonBlocking = 1 };
 
 /* ---- the interpreter ---- */
 namespace simt {
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, const char* kernel_name = nullptr);
 void sync_threads();
 void wave_rendezvous();                 /* all live lanes of the calling lane's wave */
 unsigned long long* wave_slots();       /* 64 exchange slots of the calling lane's wave */
@@ -117,11 +117,13 @@ unsigned long long live_mask();         /* live (not yet returned) lanes of the 
 }
 
 template <class... KArgs, class... Args>
-static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t stream, Args... args)
+static inline void simt_launch_named(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t stream, Args... args)
 {
   (void)shmem; (void)stream;
-  simt::launch(grid, block, [=]() { kernel(args...); });
+  simt::launch(grid, block, [=]() { kernel(args...); }, name);
 }
+/* (a macro, as in HIP: the kernel's spelling reaches the interpreter, which orders blocks per kernel — simt_emu.cpp) */
+#define hipLaunchKernelGGL(kernel, ...) simt_launch_named(#kernel, kernel, __VA_ARGS__)
 
 static inline void __syncthreads() { simt::sync_threads(); }
 static inline void __builtin_amdgcn_wave_barrier() { simt::wave_rendezvous(); }

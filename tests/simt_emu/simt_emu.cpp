@@ -99,10 +99,22 @@ void run_block(Block& b)
 {
   g_blk = &b;
   const int n = (int)b.fibers.size();
+  /* Wave order.  Between two barriers the waves of a workgroup run in no particular order on the hardware; here they run one after
+   * the other, in an order that changes with every scheduling round (start wave and direction), so that a missing barrier between
+   * a wave's LDS / global write and another wave's read is not hidden by "wave 0 always runs first".  Lanes of one wave stay in
+   * lane order.  SIMT_EMU_WAVE_ORDER=linear switches it off. */
+  static const bool wave_shuffle = [] { const char* e = getenv("SIMT_EMU_WAVE_ORDER"); return !(e && !strcmp(e, "linear")); }();
+  static thread_local unsigned round_no = 0;
+  const int nwaves = (n + 63) / 64;
   for (;;) {
     bool progressed = false;
     int done = 0;
-    for (int i = 0; i < n; i++) {
+    const unsigned rn = wave_shuffle ? ++round_no * 2654435761u >> 8 : 0;
+    const int w0 = (int)(rn % (unsigned)nwaves), dir = (rn >> 12) & 1;
+    for (int k = 0; k < nwaves * 64; k++) {
+      const int wk = k / 64, w = dir ? (w0 + nwaves - wk) % nwaves : (w0 + wk) % nwaves;
+      const int i = w * 64 + k % 64;
+      if (i >= n) continue;
       Fiber& f = b.fibers[i];
       if (f.state == DONE) { done++; continue; }
       if (f.state != RUNNABLE) continue;
@@ -155,7 +167,7 @@ void run_block(Block& b)
 
 namespace simt {
 
-void launch(dim3 grid, dim3 block, const std::function<void()>& body)
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, const char* kernel_name)
 {
   gridDim = grid; blockDim = block;
   const int n = (int)(block.x * block.y * block.z);
@@ -165,19 +177,43 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body)
   b.slots.assign(((n + 63) / 64) * 64, 0);
   while ((int)g_stacks.v.size() < n) g_stacks.v.push_back((char*)malloc(kStack));
   for (int i = 0; i < n; i++) b.fibers[i].stack = g_stacks.v[i];
-  for (unsigned bz = 0; bz < grid.z; bz++)
-    for (unsigned by = 0; by < grid.y; by++)
-      for (unsigned bx = 0; bx < grid.x; bx++) {
-        blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
-        for (int i = 0; i < n; i++) {
-          Fiber& f = b.fibers[i];
-          f.state = RUNNABLE;
-          f.tid.x = i % block.x; f.tid.y = (i / block.x) % block.y; f.tid.z = i / (block.x * block.y);
-          f.wave = i / 64; f.lane = i % 64;
-          ctx_make(f.ctx, f.stack, kStack, fiber_entry);
-        }
-        run_block(b);
-      }
+  /* Block order.  The hardware promises none; the default here is a different pseudo-random permutation for every launch, so a
+   * kernel whose blocks lean on each other's results without saying so fails in the CPU tier.  SIMT_EMU_ORDER=linear | reverse |
+   * shuffle (default).  One kernel is exempt and always runs in index order: k_intra, whose workgroups WAIT for each other by
+   * design (k_intra.hip: on inter pictures the CTBs without a dependency go by workgroup index, the dependent ones by an atomic
+   * ticket; it counts on the dispatcher starting lower indices first, and has a spin bound for the day it does not) — blocks run
+   * one after the other here, so a waiting block must come after the one it waits for.  SIMT_EMU_INORDER=<substring> names
+   * another such kernel. */
+  static const int order_env = [] { const char* e = getenv("SIMT_EMU_ORDER"); return !e || !*e || !strcmp(e, "shuffle") ? 2 : (!strcmp(e, "reverse") ? 1 : 0); }();
+  static const char* inorder_env = getenv("SIMT_EMU_INORDER");
+  const bool in_order = kernel_name && (strstr(kernel_name, "k_intra<") || (inorder_env && *inorder_env && strstr(kernel_name, inorder_env)));
+  const int order_mode = in_order ? 0 : order_env;
+  static thread_local uint64_t launch_no = 0;
+  const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
+  /* an affine permutation i -> (a * i + c) mod total with gcd(a, total) = 1 */
+  uint64_t a = 1, c = 0;
+  if (order_mode == 2 && total > 1) {
+    uint64_t h = (++launch_no) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    a = (h % total) | 1;
+    auto gcd = [](uint64_t x, uint64_t y) { while (y) { const uint64_t t = x % y; x = y; y = t; } return x; };
+    while (gcd(a, total) != 1) a += 2;
+    a %= total; if (a == 0) a = 1;
+    c = (h >> 17) % total;
+  }
+  for (uint64_t k = 0; k < total; k++) {
+    const uint64_t lin = order_mode == 1 ? total - 1 - k : (order_mode == 2 ? (uint64_t)(((unsigned __int128)a * k + c) % total) : k);
+    const unsigned bx = (unsigned)(lin % grid.x), by = (unsigned)((lin / grid.x) % grid.y), bz = (unsigned)(lin / ((uint64_t)grid.x * grid.y));
+    blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
+    for (int i = 0; i < n; i++) {
+      Fiber& f = b.fibers[i];
+      f.state = RUNNABLE;
+      f.tid.x = i % block.x; f.tid.y = (i / block.x) % block.y; f.tid.z = i / (block.x * block.y);
+      f.wave = i / 64; f.lane = i % 64;
+      ctx_make(f.ctx, f.stack, kStack, fiber_entry);
+    }
+    run_block(b);
+  }
 }
 
 void sync_threads()
