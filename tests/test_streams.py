@@ -186,6 +186,91 @@ def test_geometry_streams_gpu(ref, tmp_path, monkeypatch, case):
     check_geometry(ref, tmp_path, monkeypatch, case, capi.DEFAULT_LIB)
 
 
+# Damaged streams.  A picture that never arrives: the decoder makes up the reference pictures the later ones name (decctx.cc
+# generate_unavailable_reference_picture: mid-grey planes in HOST memory — the glue has to carry them to the device as reference
+# frames, glue/m355_glue.cc upload_host_planes) and carries on; flipped bits inside slice data: the parser stops somewhere in the
+# picture (DE265_WARNING_CTB_OUTSIDE_IMAGE_AREA and friends), the CTBs it never reached keep what the picture buffer held.  The backend
+# must show what the reference decoder shows, sample for sample, and raise the same warnings.
+def split_nals(data):
+    """[(nal_unit_type, bytes incl. start code)]"""
+    import re
+    pos = [m.start() for m in re.finditer(b"\x00\x00\x01", data)]
+    out = []
+    for i, p in enumerate(pos):
+        s = p - 1 if p > 0 and data[p - 1] == 0 else p
+        e = len(data) if i + 1 == len(pos) else (pos[i + 1] - 1 if data[pos[i + 1] - 1] == 0 else pos[i + 1])
+        out.append(((data[p + 3] >> 1) & 0x3F, data[s:e]))
+    return out
+
+
+def drop_pictures(data, pics):
+    """the stream without the slice NAL units of the pictures whose coding index is in `pics`"""
+    out, pic = [], -1
+    for t, b in split_nals(data):
+        if t < 32:
+            if b[b.index(b"\x00\x00\x01") + 5] & 0x80:      # first_slice_segment_in_pic_flag
+                pic += 1
+            if pic in pics:
+                continue
+        out.append(b)
+    return b"".join(out)
+
+
+def flip_bits(data, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for t, b in split_nals(data):
+        if t < 32 and len(b) > 40 and rnd.random() < 0.5:
+            b = bytearray(b)
+            for _ in range(rnd.randint(1, 4)):
+                b[rnd.randint(12, len(b) - 1)] ^= 1 << rnd.randint(0, 7)
+            b = bytes(b)
+        out.append(b)
+    return b"".join(out)
+
+
+def check_damaged(ref, data, threads, backend):
+    want = de265_py.decode_stream(ref, data, threads=0, scalar=True)
+    lib = glue_lib()
+    got = de265_py.decode_stream(lib, data, threads=threads)
+    assert got[:2] == want[:2], "damaged stream: the backend shows something else than the reference decoder"
+    assert set(got[2]) - {1000} == set(want[2]) - {1000}, (got[2], want[2])
+    assert lib.m355_glue_cpu_pixel_calls() == 0
+    assert os.path.realpath(lib.m355_glue_backend_path().decode()) == os.path.realpath(backend)
+    return want
+
+
+# (stream arguments of make_stream, pictures to drop (coding order))
+DROP_CPU_CASES = [((256, 128, 8, 1, 1, 8, 201, 10), [2]), ((256, 128, 8, 1, 1, 8, 201, 10), [0]), ((256, 128, 8, 1, 1, 8, 201, 10), [3, 4]),
+                  ((256, 128, 8, 1, 1, 18, 202, 5, 1, 1, F_RA | F_TMVP), [1]), ((256, 128, 8, 1, 1, 18, 202, 5, 1, 1, F_RA | F_TMVP), [1, 2, 3, 9])]
+DROP_GPU_CASES = [((832, 480, 8, 2, 1, 8, 211, 10), [2]), ((1280, 720, 10, 1, 1, 18, 212, 5, 1, 1, F_RA | F_TMVP | F_LT), [1, 2, 9]), ((832, 480, 8, 1, 1, 6, 213, 10), [0])]
+
+
+@pytest.mark.parametrize("args,pics", DROP_CPU_CASES)
+def test_lost_pictures_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, args, pics):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    data = make_stream(tmp_path, *args)
+    want = check_damaged(ref, drop_pictures(data, set(pics)), 2, EMU_SO)
+    assert want[1] == args[5] - len(pics)                # every picture that arrived is shown
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_flipped_bits_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, seed):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    data = make_stream(tmp_path, 256, 128, 8, 1, 1, 8, 201, 10)
+    check_damaged(ref, flip_bits(data, seed), 0, EMU_SO)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,pics", DROP_GPU_CASES)
+def test_lost_pictures_gpu(ref, tmp_path, monkeypatch, args, pics):
+    monkeypatch.delenv("M355_LIB", raising=False)
+    data = make_stream(tmp_path, *args)
+    want = check_damaged(ref, drop_pictures(data, set(pics)), 8, capi.DEFAULT_LIB)
+    assert want[1] == args[5] - len(pics)
+
+
 # One bitstream across several backend contexts of ONE process (M355_GLUE_RANKS: the glue splits every picture's lists by tile
 # owner, the library's m355_group_* carries the halos and the finished tiles between the contexts; glue/m355_glue.cc submit_sharded):
 # (w, h, bit depth, tile cols, tile rows, frames, seed, features, ranks)
