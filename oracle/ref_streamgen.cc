@@ -51,6 +51,12 @@
  *   F_WPP       entropy_coding_sync_enabled_flag: one substream per CTB row with the context models of the row above's second
  *               CTB (decode_substream, slice.cc:4732-4900; what decode_slice_unit_WPP threads parse, decctx.cc:840-1061)
  *
+ *   F_MIXSLICE  every slice of a picture its own slice type (I / P slices inside P / B pictures), number of active references,
+ *               MaxNumMergeCand and cabac_init_flag (slice.cc:639-702, 1280-1282): the per-slice tables of the decoder and of
+ *               whoever records its decisions
+ *   F_LISTMOD   ref_pic_lists_modification (slice.cc:668-690, list construction decctx.cc:1580-1640): lists that name the same
+ *               picture twice, or in another order than the default one
+ *   F_NOOUTPUT  pic_output_flag = 0 on some pictures (slice.cc:469-475): decoded, referenced, never shown (decctx.cc:1851, 1974)
  *   geom        picture / block geometry other than the default (CTB 64, CBs 8..64, TBs 4..32, uniform tiles): bits 0-1 CTB 32 (1) or
  *               16 (2); G_MINCB16 coding blocks of at least 16x16 (no 8x8 CUs, so no intra NxN below 8x8 PUs and no 8x4 / 4x8 PBs);
  *               G_TILES uniform_spacing_flag = 0 with explicit column widths / row heights (pps.cc:392-421); G_NOTILEFILTER
@@ -93,7 +99,7 @@ void encode_mvd(encoder_context* ectx, CABAC_encoder* cabac, const int16_t mvd[2
 namespace {
 
 enum { F_WP = 1, F_TSKIP = 2, F_BYPASS = 4, F_QPDELTA = 8, F_PCM = 16, F_SCALING = 32, F_SCALING_PPS = 64, F_REXT = 256, F_CIP = 512, F_DEPSLICE = 1024,
-       F_RA = 2048, F_WPP = 4096, F_TMVP = 8192, F_SDH = 16384, F_LT = 32768 };
+       F_RA = 2048, F_WPP = 4096, F_TMVP = 8192, F_SDH = 16384, F_LT = 32768, F_MIXSLICE = 65536, F_LISTMOD = 131072, F_NOOUTPUT = 262144 };
 enum { G_CTB = 3, G_MINCB16 = 4, G_TILES = 8, G_NOTILEFILTER = 16, G_PARMERGE = 32, G_TB16 = 64, G_CONFWIN = 128 };
 struct Cfg { int W, H, bd, tc, tr, frames; uint32_t seed; int intra_pct, b_frames, sao, features, chroma, slices, geom; };
 
@@ -117,6 +123,7 @@ struct Gen {
   std::vector<int> rps_neg, rps_neg_used, rps_pos, rps_pos_used;   /* POC distances (> 0), nearest first */
   std::vector<int> lt_lsb, lt_used;
   int col_from_l0 = 1, col_ref_idx = 0;
+  int list_total = 0, list_bits_total = 0;    /* NumPocTotalCurr: the pictures a modified list may name, and what sizes list_entry_lX (slice.cc:665-668) */
 
   uint32_t rnd() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
   int below(int n) { return (int)(rnd() % (uint32_t)n); }
@@ -625,6 +632,7 @@ struct Gen {
     }
     if (!sh->dependent_slice_segment_flag) {
       out.write_uvlc(sh->slice_type);
+      if (P.output_flag_present_flag) out.write_bit(sh->pic_output_flag);
       if (nal_type != NAL_UNIT_IDR_W_RADL && nal_type != NAL_UNIT_IDR_N_LP) {
         out.write_bits(sh->slice_pic_order_cnt_lsb, S.log2_max_pic_order_cnt_lsb);
         if (has(F_RA)) {
@@ -652,7 +660,17 @@ struct Gen {
       if (sh->slice_type != SLICE_TYPE_I) {
         out.write_bit(1);                                                       /* num_ref_idx_active_override_flag */
         out.write_uvlc(nref[0] - 1);
-        if (sh->slice_type == SLICE_TYPE_B) { out.write_uvlc(nref[1] - 1); out.write_bit(0); }   /* mvd_l1_zero_flag */
+        if (sh->slice_type == SLICE_TYPE_B) out.write_uvlc(nref[1] - 1);
+        if (P.lists_modification_present_flag && list_bits_total > 1) {         /* ref_pic_lists_modification (slice.cc:668-690) */
+          const int nb = ceil_log2(list_bits_total);
+          for (int l = 0; l <= (sh->slice_type == SLICE_TYPE_B ? 1 : 0); l++) {
+            const int mod = pct(75);
+            out.write_bit(mod);
+            if (mod) for (int i = 0; i < nref[l]; i++) out.write_bits(below(list_total), nb);   /* list_entry_lX: any picture, also twice */
+          }
+        }
+        if (sh->slice_type == SLICE_TYPE_B) out.write_bit(0);                   /* mvd_l1_zero_flag */
+        if (P.cabac_init_present_flag) out.write_bit(sh->cabac_init_flag);
         if (sh->slice_temporal_mvp_enabled_flag) {                              /* slice.cc:705-728 */
           if (sh->slice_type == SLICE_TYPE_B) out.write_bit(col_from_l0);
           if (nref[col_from_l0 ? 0 : 1] > 1) out.write_uvlc(col_ref_idx);
@@ -709,10 +727,10 @@ struct Gen {
     const pic_parameter_set& P = *pps;
     out.write_uvlc(0); out.write_uvlc(0);                                       /* pps / sps id */
     out.write_bit(P.dependent_slice_segments_enabled_flag);
-    out.write_bit(0);                                                           /* output_flag_present_flag */
+    out.write_bit(P.output_flag_present_flag);
     out.write_bits(0, 3);                                                       /* num_extra_slice_header_bits */
     out.write_bit(P.sign_data_hiding_flag);
-    out.write_bit(0);                                                           /* cabac_init_present_flag */
+    out.write_bit(P.cabac_init_present_flag);
     out.write_uvlc(P.num_ref_idx_l0_default_active - 1); out.write_uvlc(P.num_ref_idx_l1_default_active - 1);
     out.write_svlc(P.pic_init_qp - 26);
     out.write_bit(P.constrained_intra_pred_flag);
@@ -743,7 +761,7 @@ struct Gen {
     }
     out.write_bit(P.pic_scaling_list_data_present_flag);
     if (P.pic_scaling_list_data_present_flag) write_scaling_list_data(out);
-    out.write_bit(0);                                                           /* lists_modification_present_flag */
+    out.write_bit(P.lists_modification_present_flag);
     out.write_uvlc(P.log2_parallel_merge_level - 2);
     out.write_bit(0);                                                           /* slice_segment_header_extension_present_flag */
     out.write_bit(P.pps_range_extension_flag);                                  /* pps_extension_present_flag */
@@ -861,6 +879,9 @@ int run(const Cfg& cfg, const char* out_name)
     P.pps_slice_chroma_qp_offsets_present_flag = g.has(F_QPDELTA) && cfg.chroma != 0;
     P.weighted_pred_flag = P.weighted_bipred_flag = g.has(F_WP);
     P.dependent_slice_segments_enabled_flag = g.has(F_DEPSLICE);
+    P.cabac_init_present_flag = g.has(F_MIXSLICE);
+    P.lists_modification_present_flag = g.has(F_LISTMOD);
+    P.output_flag_present_flag = g.has(F_NOOUTPUT);
     if (cfg.slices > 1) { P.deblocking_filter_control_present_flag = 1; P.deblocking_filter_override_enabled_flag = 1; P.pic_disable_deblocking_filter_flag = 0; P.beta_offset = 2; P.tc_offset = -2; }
     P.pic_scaling_list_data_present_flag = g.has(F_SCALING_PPS);
     if (rext) {
@@ -977,6 +998,14 @@ int run(const Cfg& cfg, const char* out_name)
     for (slice_segment_header* h : g.img.slices) delete h;
     g.img.slices.clear();
     context_model_table end_ctx;                                               /* context models at the end of the previous segment */
+    int stype = type, snref = nrefs;                                           /* of the slice the current segment belongs to */
+    {
+      /* pictures a list may name = NumPocTotalCurr: the short-term pictures "used by curr" and the used long-term ones (slice.cc:574-577, 665) */
+      int st = 0, lt_used = 0;
+      if (g.has(F_RA)) { for (int u : plan.neg_used) st += u; for (int u : plan.pos_used) st += u; for (int u : plan.lt_used) lt_used += u; }
+      else st = nrefs >= 2 ? 2 : nrefs;
+      g.list_total = g.list_bits_total = st + lt_used;
+    }
     uint32_t indep_addr = 0;
     slice_segment_header* indep = nullptr;
     for (size_t k = 0; k + 1 < cut.size(); k++) {
@@ -995,18 +1024,27 @@ int run(const Cfg& cfg, const char* out_name)
       sh->pps = g.pps;
       if (!dependent) {
         indep_addr = sh->slice_segment_address;
-        sh->slice_type = type;
-        sh->pic_output_flag = 1;
+        /* this slice's own type and number of active references (F_MIXSLICE): I / P slices inside P / B pictures */
+        stype = type; snref = nrefs;
+        if (g.has(F_MIXSLICE) && type != SLICE_TYPE_I) {
+          const uint32_t q = r() % 10;
+          if (q < 2) stype = SLICE_TYPE_I; else if (q < 5 && type == SLICE_TYPE_B) stype = SLICE_TYPE_P;
+          snref = 1 + (int)(r() % (uint32_t)nrefs);
+        }
+        g.slice_type = stype; g.nref[0] = g.nref[1] = stype == SLICE_TYPE_I ? 0 : snref;
+        sh->slice_type = stype;
+        sh->pic_output_flag = (g.has(F_NOOUTPUT) && fr > 0 && (plan.poc % 3) == 1) ? 0 : 1;   /* (the same in every slice of the picture) */
+        sh->cabac_init_flag = (g.has(F_MIXSLICE) && stype != SLICE_TYPE_I) ? (int)(r() % 2) : 0;
         sh->slice_pic_order_cnt_lsb = plan.poc & 0xFF;
         sh->short_term_ref_pic_set_sps_flag = g.has(F_RA) ? 0 : 1;
         sh->short_term_ref_pic_set_idx = nrefs >= 2 ? 1 : 0;
-        sh->slice_temporal_mvp_enabled_flag = (g.has(F_TMVP) && type != SLICE_TYPE_I) ? (r() % 8 != 0) : 0;
-        g.col_from_l0 = type == SLICE_TYPE_B ? (int)(r() % 2) : 1;
-        g.col_ref_idx = nrefs > 1 ? (int)(r() % (uint32_t)nrefs) : 0;
+        sh->slice_temporal_mvp_enabled_flag = (g.has(F_TMVP) && stype != SLICE_TYPE_I) ? (r() % 8 != 0) : 0;
+        g.col_from_l0 = stype == SLICE_TYPE_B ? (int)(r() % 2) : 1;
+        g.col_ref_idx = snref > 1 ? (int)(r() % (uint32_t)snref) : 0;
         sh->slice_sao_luma_flag = sh->slice_sao_chroma_flag = cfg.sao ? 1 : 0;
-        sh->num_ref_idx_active_override_flag = type != SLICE_TYPE_I;
-        sh->num_ref_idx_l0_active = nrefs; sh->num_ref_idx_l1_active = nrefs;
-        sh->five_minus_max_num_merge_cand = 0;
+        sh->num_ref_idx_active_override_flag = stype != SLICE_TYPE_I;
+        sh->num_ref_idx_l0_active = snref; sh->num_ref_idx_l1_active = snref;
+        sh->five_minus_max_num_merge_cand = g.has(F_MIXSLICE) ? (int)(r() % 5) : 0;
         sh->slice_qp_delta = 0;
         sh->slice_loop_filter_across_slices_enabled_flag = 1;
         sh->slice_deblocking_filter_disabled_flag = P.pic_disable_deblocking_filter_flag;
@@ -1030,7 +1068,7 @@ int run(const Cfg& cfg, const char* out_name)
         sh->compute_derived_values(g.pps.get());
         sh->MaxNumMergeCand = 5 - sh->five_minus_max_num_merge_cand;
         sh->SliceQPY = P.pic_init_qp + sh->slice_qp_delta;
-        sh->initType = type == SLICE_TYPE_I ? 0 : (type == SLICE_TYPE_P ? 1 : 2);
+        sh->initType = stype == SLICE_TYPE_I ? 0 : (stype == SLICE_TYPE_P ? 1 + sh->cabac_init_flag : 2 - sh->cabac_init_flag);   /* slice.cc:1278-1283 */
         indep = sh;
       } else sh->SliceAddrRS = indep_addr;
       const uint32_t seed = cfg.seed * 2654435761u + 977u * (uint32_t)fr + 131071u * (uint32_t)k + 1u;
@@ -1049,15 +1087,15 @@ int run(const Cfg& cfg, const char* out_name)
       nal.set(nal_type); nal.write(enc);
       if (plain) {
         /* the header writer takes num_ref_idx_lX_active as the syntax element (minus 1) and leaves the count behind */
-        sh->num_ref_idx_l0_active = nrefs - 1; sh->num_ref_idx_l1_active = nrefs - 1;
+        sh->num_ref_idx_l0_active = snref - 1; sh->num_ref_idx_l1_active = snref - 1;
         if (sh->write(&g.dctx, enc, g.sps.get(), g.pps.get(), (uint8_t)nal_type) != DE265_OK) { fprintf(stderr, "streamgen: slice header not writable\n"); return 2; }
       } else {
         g.s = seed ^ 0x9E3779B9u;                                              /* (the weight table draws from the generator) */
         g.write_slice_header(enc, sh, nal_type);
       }
-      if (type == SLICE_TYPE_I) { sh->num_ref_idx_l0_active = sh->num_ref_idx_l1_active = 0; }
-      if (type == SLICE_TYPE_P) { sh->num_ref_idx_l0_active = nrefs; sh->num_ref_idx_l1_active = 0; }
-      if (type == SLICE_TYPE_B) { sh->num_ref_idx_l0_active = sh->num_ref_idx_l1_active = nrefs; }
+      if (stype == SLICE_TYPE_I) { sh->num_ref_idx_l0_active = sh->num_ref_idx_l1_active = 0; }
+      if (stype == SLICE_TYPE_P) { sh->num_ref_idx_l0_active = snref; sh->num_ref_idx_l1_active = 0; }
+      if (stype == SLICE_TYPE_B) { sh->num_ref_idx_l0_active = sh->num_ref_idx_l1_active = snref; }
       enc.add_trailing_bits();                                                   /* byte_alignment() of the slice header */
       enc.flush_VLC();
       std::vector<int> ends2;

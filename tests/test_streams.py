@@ -34,6 +34,9 @@ F_WP, F_TSKIP, F_BYPASS, F_QPDELTA, F_PCM, F_SCALING, F_SCALING_PPS, F_REXT, F_C
 # order, slice-header reference picture sets with up to 6 pictures and 4 active references per list, a long-term picture,
 # temporal motion vector prediction, sign data hiding, and WPP substreams (one per CTB row, parsed by the reference's WPP threads)
 F_RA, F_WPP, F_TMVP, F_SDH, F_LT = 2048, 4096, 8192, 16384, 32768
+# slice headers that differ inside a picture (slice type, active references, merge candidates, cabac_init_flag), reference picture list
+# modification (lists naming a picture twice / in another order), pictures that are decoded and referenced but never shown
+F_MIXSLICE, F_LISTMOD, F_NOOUTPUT = 65536, 131072, 262144
 # geometry bits of oracle/ref_streamgen.cc (`geom`): CTB 32 / 16 instead of 64, coding blocks of at least 16x16 (inter NxN), explicit
 # (non-uniform) tile column widths / row heights, no in-loop filtering across tile boundaries, log2_parallel_merge_level 4, TBs of at
 # most 16x16 + strong intra smoothing off, a conformance window (the application sees a cropped picture)
@@ -52,6 +55,22 @@ def make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra_pct=5, b_frames=
     subprocess.run([STREAMGEN, out, str(w), str(h), str(bd), str(tc), str(tr), str(frames), str(seed), str(intra_pct), str(b_frames), str(sao),
                     str(features), str(chroma), str(slices), str(geom)], check=True)
     return open(out, "rb").read()
+
+
+def shown_pictures(frames, feat):
+    """pictures the decoder hands out: all of them, minus (F_NOOUTPUT) those the writer gives pic_output_flag = 0 (POC % 3 == 1)"""
+    if not feat & F_NOOUTPUT:
+        return frames
+    if feat & F_RA:
+        pocs = [0]
+        base = 0
+        while len(pocs) < frames:
+            pocs += [base + g for g in (8, 4, 2, 1, 3, 6, 5, 7)]
+            base += 8
+        pocs = pocs[:frames]
+    else:
+        pocs = list(range(frames))
+    return sum(1 for i, p in enumerate(pocs) if i == 0 or p % 3 != 1)
 
 
 def feature_counts(lib):
@@ -165,18 +184,46 @@ GEOM_GPU_CASES = [
 ]
 
 
+# Slice headers: what one picture's slices may disagree on, reordered reference lists, pictures that are never shown (same case layout)
+HEADER_CPU_CASES = [
+    (256, 128, 8, 1, 1, 6, 301, 10, F_MIXSLICE, 1, 4, 0, 2, 0),
+    (256, 128, 8, 2, 2, 6, 302, 15, F_MIXSLICE | F_WP | F_QPDELTA | F_DEPSLICE, 1, 5, 0, 4, 0),
+    (256, 128, 8, 1, 1, 6, 304, 10, F_LISTMOD | F_MIXSLICE | F_WP, 1, 3, 0, 2, 0),
+    (256, 128, 8, 1, 1, 26, 308, 5, F_RA | F_TMVP | F_LT | F_SDH | F_LISTMOD | F_NOOUTPUT | F_MIXSLICE, 1, 1, G_CTB16, 3, 0),
+    (320, 192, 8, 2, 2, 7, 309, 15, F_MIXSLICE | F_LISTMOD | F_NOOUTPUT | F_WP | F_QPDELTA | F_PCM | F_CIP | F_DEPSLICE, 1, 5, G_CTB32 | G_TILES, 4, 2),
+]
+HEADER_GPU_CASES = [
+    (1280, 720, 8, 2, 2, 6, 321, 10, F_MIXSLICE | F_LISTMOD | F_WP | F_QPDELTA, 1, 6, 0, 8, 0),
+    (1920, 1080, 8, 1, 1, 25, 322, 5, F_RA | F_TMVP | F_LT | F_SDH | F_WPP | F_LISTMOD | F_NOOUTPUT | F_MIXSLICE, 1, 1, 0, 8, 0),
+    (832, 480, 10, 1, 1, 8, 323, 10, F_NOOUTPUT | F_LISTMOD, 1, 1, G_CTB32, 8, 0),
+]
+
+
 def check_geometry(ref, tmp_path, monkeypatch, case, backend):
     w, h, bd, tc, tr, frames, seed, intra, feat, chroma, slices, geom, threads, ranks = case
     if ranks:
         monkeypatch.setenv("M355_GLUE_RANKS", str(ranks))
     data = make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra, 1, 1, feat, chroma, slices, geom)
-    (check_random_access if feat & F_RA else check)(ref, data, frames, threads, backend)
+    (check_random_access if feat & F_RA else check)(ref, data, shown_pictures(frames, feat), threads, backend)
 
 
 @pytest.mark.parametrize("case", GEOM_CPU_CASES, ids=lambda c: "%dx%d-seed%d-geom%d" % (c[0], c[1], c[6], c[11]))
 def test_geometry_streams_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, case):  # noqa: F811
     monkeypatch.setenv("M355_LIB", EMU_SO)
     check_geometry(ref, tmp_path, monkeypatch, case, EMU_SO)
+
+
+@pytest.mark.parametrize("case", HEADER_CPU_CASES, ids=lambda c: "%dx%d-seed%d-feat%d" % (c[0], c[1], c[6], c[8]))
+def test_slice_header_streams_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, case):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    check_geometry(ref, tmp_path, monkeypatch, case, EMU_SO)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", HEADER_GPU_CASES, ids=lambda c: "%dx%d-seed%d-feat%d" % (c[0], c[1], c[6], c[8]))
+def test_slice_header_streams_gpu(ref, tmp_path, monkeypatch, case):
+    monkeypatch.delenv("M355_LIB", raising=False)
+    check_geometry(ref, tmp_path, monkeypatch, case, capi.DEFAULT_LIB)
 
 
 @pytest.mark.gpu
