@@ -105,3 +105,83 @@ def decode_stream(lib, data, threads=0, disable_deblocking=False, disable_sao=Fa
         return md5.hexdigest(), n, warnings + decode_errors
     finally:
         lib.de265_free_decoder(ctx)
+
+
+class App:
+    """One decoder driven the way applications drive it (dec265.cc:760-840, the reference's other front ends): data in pieces, NAL
+    units one by one, pictures taken as they come — with get_next_picture or peek / release —, a reset in mid-stream (a seek),
+    several decoders alive in one process.  result() = (md5 of everything shown, pictures shown, errors other than "waiting for
+    input data")."""
+
+    def __init__(self, lib, threads=0):
+        self.lib = bind(lib)
+        vp = ctypes.c_void_p
+        lib.de265_peek_next_picture.argtypes = [vp]
+        lib.de265_peek_next_picture.restype = vp
+        lib.de265_release_next_picture.argtypes = [vp]
+        lib.de265_reset.argtypes = [vp]
+        lib.de265_push_NAL.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int64, vp]
+        self.ctx = lib.de265_new_decoder()
+        if not self.ctx:
+            raise RuntimeError("de265_new_decoder failed")
+        if threads:
+            assert lib.de265_start_worker_threads(self.ctx, threads) == DE265_OK
+        self.md5, self.n, self.errs = hashlib.md5(), 0, []
+
+    def take(self, peek=False):
+        lib = self.lib
+        while True:
+            img = lib.de265_peek_next_picture(self.ctx) if peek else lib.de265_get_next_picture(self.ctx)
+            if not img:
+                return
+            for c in range(1 if lib.de265_get_chroma_format(img) == 0 else 3):
+                stride = ctypes.c_int()
+                p = lib.de265_get_image_plane(img, c, ctypes.byref(stride))
+                w, h = lib.de265_get_image_width(img, c), lib.de265_get_image_height(img, c)
+                row = ctypes.c_char * (w * ((lib.de265_get_bits_per_pixel(img, c) + 7) // 8))
+                for y in range(h):
+                    self.md5.update(row.from_address(p + y * stride.value))
+            self.n += 1
+            if peek:
+                lib.de265_release_next_picture(self.ctx)
+
+    def decode_some(self, peek=False):
+        more = ctypes.c_int(1)
+        while more.value:
+            more.value = 0
+            err = self.lib.de265_decode(self.ctx, ctypes.byref(more))
+            if err != DE265_OK:
+                if err != 13:                        # DE265_ERROR_WAITING_FOR_INPUT_DATA: push more
+                    self.errs.append(err)
+                break
+            self.take(peek)
+
+    def drain(self, peek=False):
+        while True:
+            before = self.n
+            self.decode_some(peek)
+            if self.n == before:
+                return
+
+    def push(self, b):
+        buf = ctypes.create_string_buffer(b, len(b))
+        assert self.lib.de265_push_data(self.ctx, buf, len(b), 0, None) == DE265_OK
+
+    def push_nal(self, nal_with_start_code):
+        b = nal_with_start_code[nal_with_start_code.index(b"\x00\x00\x01") + 3:]
+        buf = ctypes.create_string_buffer(b, len(b))
+        assert self.lib.de265_push_NAL(self.ctx, buf, len(b), 0, None) == DE265_OK
+
+    def flush(self):
+        assert self.lib.de265_flush_data(self.ctx) == DE265_OK
+
+    def reset(self):
+        self.lib.de265_reset(self.ctx)
+
+    def close(self):
+        if self.ctx:
+            self.lib.de265_free_decoder(self.ctx)
+            self.ctx = None
+
+    def result(self):
+        return self.md5.hexdigest(), self.n, self.errs
