@@ -285,6 +285,11 @@ def check_damaged(ref, data, threads, backend):
     assert set(got[2]) - {1000} == set(want[2]) - {1000}, (got[2], want[2])
     assert lib.m355_glue_cpu_pixel_calls() == 0
     assert os.path.realpath(lib.m355_glue_backend_path().decode()) == os.path.realpath(backend)
+    # DE265_DECODER_PARAM_SUPPRESS_FAULTY_PICTURES (de265.h:404, decctx.cc:1854): only pictures whose integrity is "correct" are
+    # shown — the marks the replaced functions own (motion.cc:387-405 and friends) have to be where the decoder looks for them
+    shown = [de265_py.decode_stream(x, data, threads=t, scalar=x is ref, after_create=lambda ctx, x=x: x.de265_set_parameter_bool(ctx, 6, 1))
+             for x, t in ((ref, 0), (lib, threads))]
+    assert shown[1][:2] == shown[0][:2] and shown[0][1] <= want[1], "faulty pictures suppressed: %r, reference %r" % (shown[1][1:], shown[0][1:])
     return want
 
 
