@@ -1,4 +1,4 @@
-"""CPU-tier counterpart of test_gpu_random.py: the same randomised pictures (a subset, to keep the CPU suite short) through the
+"""CPU-tier counterpart of test_gpu_random.py: the same randomised pictures (every third seed; all 200 take 70 s and pass) through the
 product kernels under the SIMT interpreter, against the oracle."""
 import pytest
 
@@ -9,7 +9,7 @@ from test_gpu_random import random_case
 from libde265_amd import capi
 
 
-@pytest.mark.parametrize("seed", range(0, 48, 3))
+@pytest.mark.parametrize("seed", range(0, 200, 3))
 def test_random_pictures_emulated(emu_lib, oracle, seed):  # noqa: F811
     pic, refs = make_case(**random_case(seed))
     ctx = capi.Context(emu_lib, 0)
