@@ -281,6 +281,7 @@ void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pi
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st);   /* one direction (tile sharding) */
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st);
+void m355_launch_sao_dbh(const DevPic& p, bool hbd, hipStream_t st);   /* EXPERIMENTAL: k_deblock<H> + k_sao in one pass (M355_FUSE_DBH) */
 /* tile sharding: `which` bit 0 = column strips, bit 1 = row strips; meta = border-unit records (16 B each) */
 void m355_launch_halo_pack(const DevPic& p, const HaloLayout& h, bool hbd, int which, void* samples, uint32_t* meta, hipStream_t st);
 /* buf[i] += sum over the n received copies scratch[k * pitch_words + i] (halo exchange of m355_decode_sharded over RCCL) */

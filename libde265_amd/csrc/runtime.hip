@@ -1198,6 +1198,13 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+/* M355_FUSE_DBH: 1 = k_deblock<H> runs inside k_sao (k_sao_dbh, decode_post).  EXPERIMENTAL: verified under the SIMT interpreter
+   only (tests/test_fuse_dbh.py) — written when the round's GPU minutes were spent; tools/gpu_r5a.sh times it. */
+static int fuse_dbh_sao()
+{
+  static const int v = getenv("M355_FUSE_DBH") ? atoi(getenv("M355_FUSE_DBH")) : 0;
+  return v;
+}
 /* M355_DEVICE_WORKLIST: 1 = k_intra's work list (order, plan bases, neighbourhood facts) is made by two small kernels behind the list
    copy instead of on the submitting thread (0.08-0.12 ms per 8K picture); 2 = both, compared after a synchronisation (self-check);
    unset / 0 = on the host.  EXPERIMENTAL: verified under the SIMT interpreter only (tests/test_device_worklist.py) — the round's GPU
@@ -1941,9 +1948,13 @@ static int decode_post(m355_ctx* c, Resident& r, DecodeState& S, bool filters = 
   const bool piped = c->depth >= 2;
   Frame* dstf = get_frame(c, r.hdr.dst_frame);
   hipStream_t st = c->stream;
-  if (filters && (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED)) m355_launch_deblock(d, hbd, st);
+  const bool deblock = filters && (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED);
+  /* M355_FUSE_DBH (EXPERIMENTAL, off by default): the horizontal-edge pass runs inside the SAO kernel (k_sao.hip d_dbh_block) —
+     one pass over the picture and one launch less; unsharded pictures with both filters on */
+  const bool fuse_dbh = deblock && filters && want_sao && fuse_dbh_sao() && !d.ctb_owner;
+  if (deblock) { if (fuse_dbh) m355_launch_deblock_pass(d, hbd, true, st); else m355_launch_deblock(d, hbd, st); }
   if (ev) hipEventRecord(ev[5], st);
-  if (filters && want_sao) { dst_hazards(c, dstf, piped); m355_launch_sao(d, hbd, st); }
+  if (filters && want_sao) { dst_hazards(c, dstf, piped); if (fuse_dbh) m355_launch_sao_dbh(d, hbd, st); else m355_launch_sao(d, hbd, st); }
   if (ev) hipEventRecord(ev[6], st);
   /* ONE mark behind the decode's last kernel for everything that has to know when it is over: the lists' arenas, the destination
      frame's next reader / writer, the reference frames' next writer, the lane's next decode, the status slot */
