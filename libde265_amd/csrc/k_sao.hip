@@ -110,27 +110,36 @@ __device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint3
  * same function a second time on the neighbouring 4x4 blocks (A = their rows).  Saves one pass over the picture (read + write of
  * every filtered row) and one launch; not used for tile-sharded pictures (the exchange between the passes) or batches.
  * A[1..4] = the rows of the 4x4 block at (xb, .) of component c, in / out; yE = the edge row (component samples) between the pair;
- * isQ = this lane holds the Q side; act = the lane has a block at all.  All lanes of the wave call it together. */
-template <class PIX, int NW>
-__device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const bool act, const int xb, const int yE, const bool isQ, uint32_t (&A)[6][NW])
+ * isQ = this lane holds the Q side; act = the lane has a block at all.  All lanes of the wave call both functions together. */
+struct DbhIdx { uint32_t ciQ, ciP, ip, iq; int ef, efo, slice_idx; bool flagged; };
+/* round trip 1 of an edge segment (clamped addresses, no branch in front of a load): edge flags, CU / PB indices of both sides, the
+   CTB's slice — requested for the tile's own segments and the rim's together, beside the sample rows */
+__device__ __forceinline__ DbhIdx d_dbh_fetch(const DevPic& p, const int c, const bool act, const int xb, const int yE)
 {
   const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
   const bool cand = act && yE > 0 && yE < p.ph[c] && xb >= 0 && xb < p.pw[c];
+  const int xDi = cand ? (xb << csw) : 0, yDi = cand ? (yE << csh) : 4;
+  const int u = (yDi >> 2) * p.w4 + (xDi >> 2), uo = u - p.w4;
+  DbhIdx m;
+  m.ciQ = d_cu_index_at(p, xDi, yDi); m.ciP = d_cu_index_at(p, xDi, yDi - 1);
+  m.ef = p.edge_tu[u] | p.edge_pb[u]; m.efo = p.edge_tu[uo];
+  m.ip = p.pb_of[uo]; m.iq = p.pb_of[u];
+  m.slice_idx = p.ctbs[d_ctb_of(p, xDi, yDi)].slice_idx;
+  m.flagged = cand && (m.ef & (E_TU_H | E_PB_H));
+  return m;
+}
+template <class PIX, int NW>
+__device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const DbhIdx& m, const bool isQ, uint32_t (&A)[6][NW])
+{
   /* the other side's rows (lane ^ 16 holds the same columns) */
   uint32_t B[5][NW];
 #pragma unroll
   for (int r = 1; r <= 4; r++)
 #pragma unroll
     for (int k = 0; k < NW; k++) B[r][k] = (uint32_t)__shfl_xor((int)A[r][k], 16, 64);
-  /* round trip 1 (clamped addresses, no branch in front of a load): edge flags, CU / PB indices of both sides, the CTB's slice */
-  const int xDi = cand ? (xb << csw) : 0, yDi = cand ? (yE << csh) : 4;
-  const int u = (yDi >> 2) * p.w4 + (xDi >> 2), uo = u - p.w4;
-  const uint32_t ciQ = d_cu_index_at(p, xDi, yDi), ciP = d_cu_index_at(p, xDi, yDi - 1);
-  const int ef = p.edge_tu[u] | p.edge_pb[u], efo = p.edge_tu[uo];
-  const uint32_t ip = p.pb_of[uo], iq = p.pb_of[u];
-  const int slice_idx = p.ctbs[d_ctb_of(p, xDi, yDi)].slice_idx;
-  M355_COMPILER_FENCE();
-  const bool flagged = cand && (ef & (E_TU_H | E_PB_H));
+  const uint32_t ciQ = m.ciQ, ciP = m.ciP, ip = m.ip, iq = m.iq;
+  const int ef = m.ef, efo = m.efo, slice_idx = m.slice_idx;
+  const bool flagged = m.flagged;
   if (!__any((int)flagged)) return;                        /* wave-uniform */
   /* round trip 2: the records (an absent one reads the CTB table instead: always there, never used) */
   const bool pb_ok = ip && iq && ip <= (uint32_t)p.n_pb_records && iq <= (uint32_t)p.n_pb_records;
@@ -269,9 +278,13 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   const bool halo = DBH && valid && ((lx == 0 && x0 >= 4) || (lx == 15 && x0 + 4 < width));
   const int xh = DBH ? (lx == 0 ? x0 - 4 : x0 + 4) : 0;
   uint32_t hr[6][NW];
+  const int yE = DBH ? ((ly & 1) ? y0 : y0 + 4) : 0;              /* DBH: the edge row between this lane and lane ^ 16 */
+  DbhIdx dbh_own, dbh_rim;
   if (DBH) {
 #pragma unroll
     for (int r = 1; r <= 4; r++) d_sao_load4<PIX>(in + (size_t)max(min(y0 + r - 1, height - 1), 0) * is + (halo ? xh : xs), hr[r]);
+    dbh_own = d_dbh_fetch(p, c, valid, x0, yE);
+    dbh_rim = d_dbh_fetch(p, c, halo, xh, yE);
   }
   /* this component's parameters, selected without indexing the record dynamically */
   const int band_pos = c == 0 ? ctb.sao_band_pos[0] : (c == 1 ? ctb.sao_band_pos[1] : ctb.sao_band_pos[2]);
@@ -300,9 +313,9 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   const bool any_edge = __any(type_raw == 2);
   if (DBH) {
     /* the horizontal edges of this tile, then (only if some CTB of the wave asks for an edge class) those of the rim blocks */
-    const int yE = (ly & 1) ? y0 : y0 + 4;
-    d_dbh_block<PIX, NW>(p, c, valid, x0, yE, (ly & 1) != 0, rw);
-    if (any_edge && __any((int)halo)) d_dbh_block<PIX, NW>(p, c, halo, xh, yE, (ly & 1) != 0, hr);
+    M355_COMPILER_FENCE();
+    d_dbh_block<PIX, NW>(p, c, dbh_own, (ly & 1) != 0, rw);
+    if (any_edge) d_dbh_block<PIX, NW>(p, c, dbh_rim, (ly & 1) != 0, hr);
   }
   const bool enabled = (nbmask_raw & 0x8000u) != 0;
   const int type = enabled ? type_raw : 0;
