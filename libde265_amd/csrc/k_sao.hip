@@ -104,8 +104,8 @@ __device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint3
  * horizontal edge at 16*by and the P / Q side of the edge at 16*by + 8 — both edges with their whole reach (3 modified + 1 read
  * sample on each side, deblock.cc:412-605) inside the tile, and the rows SAO looks at above and below the tile (16*by - 5 and
  * 16*by + 12) are the q3 / p3 rows of the neighbouring edges, which the pass never modifies.  The lanes 16 apart that hold the two
- * sides of an edge segment swap their rows, BOTH derive the decisions (same code as k_deblock_body<PIX, false>, k_deblock.hip) and
- * each keeps its own side; the working planes are only read (k_deblock<V> wrote them), the H-filtered samples exist in registers
+ * sides of an edge segment swap their rows, BOTH derive the decisions (as k_deblock_body<PIX, false>, k_deblock.hip) and each
+ * filters its own side (the filters are symmetric up to the sign of delta); the working planes are only read (k_deblock<V> wrote them), the H-filtered samples exist in registers
  * alone on their way to the SAO output.  Left and right of the tile SAO needs one filtered column each: the outer lanes run the
  * same function a second time on the neighbouring 4x4 blocks (A = their rows).  Saves one pass over the picture (read + write of
  * every filtered row) and one launch; not used for tile-sharded pictures (the exchange between the passes) or batches.
@@ -154,54 +154,50 @@ __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const 
   const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
   const bool filterP = !((plf && P.pcm) || P.bypass), filterQ = !((plf && Q.pcm) || Q.bypass);
   const int qP_L = (Q.qp + P.qp + 1) >> 1;
-  /* rp[i] / rq[i] = the row at distance i from the edge (its four samples are the segment's four lines) */
-  Raw4<PIX> rp[4], rq[4];
+  /* Both filters are symmetric in their two sides up to the sign of delta, so a lane computes ITS side only: mr[i] / orow[i] = the
+     row at distance i from the edge on this lane's side / on the other side (its four samples are the segment's four lines);
+     s = +1 on the Q side: q - p = s * (mine - other) */
+  const bool filterM = isQ ? filterQ : filterP;
+  if (!filterM) return;                                    /* pcm + pcm_loop_filter_disable / bypass: this side stays */
+  Raw4<PIX> mr[4], orow[4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int k = 0; k < NW; k++) { rp[i].w[k] = isQ ? B[4 - i][k] : A[4 - i][k]; rq[i].w[k] = isQ ? A[1 + i][k] : B[1 + i][k]; }
-#define PV(k, i) d_get<PIX>(rp[i], k)
-#define QV(k, i) d_get<PIX>(rq[i], k)
-#define SETP(k, i, v) d_set<PIX>(rp[i], k, v)
-#define SETQ(k, i, v) d_set<PIX>(rq[i], k, v)
+    for (int k = 0; k < NW; k++) { mr[i].w[k] = isQ ? A[1 + i][k] : A[4 - i][k]; orow[i].w[k] = isQ ? B[4 - i][k] : B[1 + i][k]; }
+#define MV(k, i) d_get<PIX>(mr[i], k)
+#define OV(k, i) d_get<PIX>(orow[i], k)
+#define SETM(k, i, v) d_set<PIX>(mr[i], k, v)
   if (c == 0) {
     /* ---- luma (deblock.cc:480-601, fallback-deblk.h:33-100) ---- */
     const int bd = p.pp.bit_depth_luma;
     const int beta = c_tab_beta[d_clip3(0, 51, qP_L + sh.beta_offset)] * (1 << (bd - 8));
     const int tc = c_tab_tc[d_clip3(0, 53, qP_L + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
-    const int dp0 = d_abs(PV(0, 2) - 2 * PV(0, 1) + PV(0, 0)), dp3 = d_abs(PV(3, 2) - 2 * PV(3, 1) + PV(3, 0));
-    const int dq0 = d_abs(QV(0, 2) - 2 * QV(0, 1) + QV(0, 0)), dq3 = d_abs(QV(3, 2) - 2 * QV(3, 1) + QV(3, 0));
-    const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
+    const int dm0 = d_abs(MV(0, 2) - 2 * MV(0, 1) + MV(0, 0)), dm3 = d_abs(MV(3, 2) - 2 * MV(3, 1) + MV(3, 0));
+    const int do0 = d_abs(OV(0, 2) - 2 * OV(0, 1) + OV(0, 0)), do3 = d_abs(OV(3, 2) - 2 * OV(3, 1) + OV(3, 0));
+    const int dpq0 = dm0 + do0, dpq3 = dm3 + do3, d = dpq0 + dpq3;
     if (d >= beta) return;
-    const bool dSam0 = 2 * dpq0 < (beta >> 2) && d_abs(PV(0, 3) - PV(0, 0)) + d_abs(QV(0, 0) - QV(0, 3)) < (beta >> 3) &&
-                       d_abs(PV(0, 0) - QV(0, 0)) < ((5 * tc + 1) >> 1);
-    const bool dSam3 = 2 * dpq3 < (beta >> 2) && d_abs(PV(3, 3) - PV(3, 0)) + d_abs(QV(3, 0) - QV(3, 3)) < (beta >> 3) &&
-                       d_abs(PV(3, 0) - QV(3, 0)) < ((5 * tc + 1) >> 1);
+    const bool dSam0 = 2 * dpq0 < (beta >> 2) && d_abs(MV(0, 3) - MV(0, 0)) + d_abs(OV(0, 0) - OV(0, 3)) < (beta >> 3) &&
+                       d_abs(MV(0, 0) - OV(0, 0)) < ((5 * tc + 1) >> 1);
+    const bool dSam3 = 2 * dpq3 < (beta >> 2) && d_abs(MV(3, 3) - MV(3, 0)) + d_abs(OV(3, 0) - OV(3, 3)) < (beta >> 3) &&
+                       d_abs(MV(3, 0) - OV(3, 0)) < ((5 * tc + 1) >> 1);
     const bool strong = dSam0 && dSam3;
-    const bool dEp = dp < ((beta + (beta >> 1)) >> 3), dEq = dq < ((beta + (beta >> 1)) >> 3);
+    const bool dEm = dm0 + dm3 < ((beta + (beta >> 1)) >> 3);          /* dEp on the P side, dEq on the Q side */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int p0 = PV(k, 0), p1 = PV(k, 1), p2 = PV(k, 2), p3 = PV(k, 3);
-      const int q0 = QV(k, 0), q1 = QV(k, 1), q2 = QV(k, 2), q3 = QV(k, 3);
+      const int m0 = MV(k, 0), m1 = MV(k, 1), m2 = MV(k, 2), m3 = MV(k, 3);
+      const int o0 = OV(k, 0), o1 = OV(k, 1);
       if (strong) {
-        if (filterP) {
-          SETP(k, 0, d_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3));
-          SETP(k, 1, d_clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2));
-          SETP(k, 2, d_clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3));
-        }
-        if (filterQ) {
-          SETQ(k, 0, d_clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3));
-          SETQ(k, 1, d_clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2));
-          SETQ(k, 2, d_clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
-        }
+        SETM(k, 0, d_clip3(m0 - 2 * tc, m0 + 2 * tc, (m2 + 2 * m1 + 2 * m0 + 2 * o0 + o1 + 4) >> 3));
+        SETM(k, 1, d_clip3(m1 - 2 * tc, m1 + 2 * tc, (m2 + m1 + m0 + o0 + 2) >> 2));
+        SETM(k, 2, d_clip3(m2 - 2 * tc, m2 + 2 * tc, (2 * m3 + 3 * m2 + m1 + m0 + o0 + 4) >> 3));
       } else {
-        int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+        const int t = 9 * (m0 - o0) - 3 * (m1 - o1);                    /* s * (9 (q0 - p0) - 3 (q1 - p1)) */
+        int delta = ((isQ ? t : -t) + 8) >> 4;
         if (d_abs(delta) < tc * 10) {
           delta = d_clip3(-tc, tc, delta);
-          if (filterP) SETP(k, 0, d_clip_bd(p0 + delta, bd));
-          if (filterQ) SETQ(k, 0, d_clip_bd(q0 - delta, bd));
-          if (dEp && filterP) SETP(k, 1, d_clip_bd(p1 + d_clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1), bd));
-          if (dEq && filterQ) SETQ(k, 1, d_clip_bd(q1 + d_clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1), bd));
+          const int ds = isQ ? -delta : delta;                          /* p0 + delta, q0 - delta */
+          SETM(k, 0, d_clip_bd(m0 + ds, bd));
+          if (dEm) SETM(k, 1, d_clip_bd(m1 + d_clip3(-(tc >> 1), tc >> 1, (((m2 + m0 + 1) >> 1) - m1 + ds) >> 1), bd));
         }
       }
     }
@@ -217,21 +213,20 @@ __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const 
     const int tc = c_tab_tc[d_clip3(0, 53, QP_C + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int p0 = PV(k, 0), p1 = PV(k, 1), q0 = QV(k, 0), q1 = QV(k, 1);
-      const int delta = d_clip3(-tc, tc, ((((q0 - p0) * 4) + p1 - q1 + 4) >> 3));
-      if (filterP) SETP(k, 0, d_clip_bd(p0 + delta, bd));
-      if (filterQ) SETQ(k, 0, d_clip_bd(q0 - delta, bd));
+      const int m0 = MV(k, 0), m1 = MV(k, 1), o0 = OV(k, 0), o1 = OV(k, 1);
+      const int t = (m0 - o0) * 4 - (m1 - o1);                          /* s * ((q0 - p0) * 4 + p1 - q1) */
+      const int delta = d_clip3(-tc, tc, ((isQ ? t : -t) + 4) >> 3);
+      SETM(k, 0, d_clip_bd(m0 + (isQ ? -delta : delta), bd));
     }
   }
-#undef PV
-#undef QV
-#undef SETP
-#undef SETQ
+#undef MV
+#undef OV
+#undef SETM
   /* this lane's side goes back into its rows */
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int k = 0; k < NW; k++) { if (isQ) A[1 + i][k] = rq[i].w[k]; else A[4 - i][k] = rp[i].w[k]; }
+    for (int k = 0; k < NW; k++) { if (isQ) A[1 + i][k] = mr[i].w[k]; else A[4 - i][k] = mr[i].w[k]; }
 }
 
 template <class PIX, bool PACKED, bool DBH = false>
