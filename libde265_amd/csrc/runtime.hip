@@ -1045,6 +1045,14 @@ static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, bo
 /* Which neighbour CTBs must the intra wavefront wait for?  (k_intra.hip reads this mask.)
  * touch bits per CTB: an intra block reaches its right column (1), bottom row (2), both (4);
  * need bits: an intra block reads across the left (L), top (T), top-left (TL), top-right (TR) border. */
+/* M355_INTRA_ONE_SIDED=1: dependency levels of the intra blocks from the side their mode reads (intra_schedule below) — fewer levels per
+   CTB, i.e. fewer barrier steps of k_intra's chain.  EXPERIMENTAL, off by default: verified under the SIMT interpreter only (shuffled
+   wave order, tests/test_intra_one_sided.py); M355_INTRA_LEVEL_STATS=1 prints the level count of every scheduled picture. */
+static int intra_one_sided()
+{
+  static const int v = getenv("M355_INTRA_ONE_SIDED") ? atoi(getenv("M355_INTRA_ONE_SIDED")) : 0;
+  return v;
+}
 static void intra_dependencies(int ctbW, int ctbH, const uint16_t* tile_id, const uint8_t* touch, const uint8_t* need, uint8_t* dep)
 {
   const int nCtb = ctbW * ctbH;
@@ -1085,13 +1093,14 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
 {
   const m355_pic_params& pp = pic->pp;
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
-  std::atomic<long long> n_blocks(0), n_intra_ctbs(0);
+  std::atomic<long long> n_blocks(0), n_intra_ctbs(0), n_levels(0);
   std::atomic<int> overlap(-1);
+  const bool one_sided = intra_one_sided() && !(pp.flags & M355_PF_CONSTRAINED_INTRA_PRED);
   /* (an intra picture has hundreds of blocks per CTB: smaller shares, so that a 1080p picture's 510 CTBs still use the whole pool) */
   parallel_ranges((size_t)pic->n_ctbs, (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs ? 16 : 256, [&](size_t cb, size_t ce) {
     std::vector<std::pair<uint32_t, uint32_t>> key, sorted;      /* (level << 2 | cidx, index) */
     uint32_t hist[4 * 128 + 1];                          /* stable counting sort of a CTB's keys (no allocation per CTB) */
-    long long my_blocks = 0, my_ctbs = 0;
+    long long my_blocks = 0, my_ctbs = 0, my_levels = 0;
     for (size_t c = cb; c < ce; c++) {
       const m355_ctb& ctb = pic->ctbs[c];
       log2_waves[c] = 0; plan_count[c] = 0; touch[c] = 0; need[c] = 0;
@@ -1127,9 +1136,52 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
         }
         if (ux < 0 || uy < 0 || ux >= 16 || uy >= 16) { key.push_back(std::make_pair((uint32_t)ib.cidx, k)); continue; }   /* rejected by validate() */
         if (!(ib.flags & M355_IBF_PCM)) {                /* raw blocks read nothing */
+          /* M355_INTRA_ONE_SIDED: wait only for the blocks whose samples the MODE can read, instead of the whole 2nT + 1 border on
+             both sides.  Per side, the border entries a mode uses (intrapred.h:261-433; entry 0 = corner, i > 0 the row above, i < 0
+             the column on the left; + 1 entry where the [1 2 1] smoothing of intrapred.h:185-258 applies):
+               planar +-(nT + 1) | DC +-nT | 11..25 (negative angle) +-nT | 10 / 26: nT on their own side, nT on the other one only
+               with the boundary filter | 27..34: the row above up to nT + ((nT * angle) >> 5) + 2, nothing on the left | 2..9: the
+               column on the left, nothing above.
+             What makes that sound is where SUBSTITUTED entries get their value from (intrapred.h:637-665: the scan runs from the
+             bottom-left entry up to the corner and on to the top-right one, an unavailable entry repeats the one before it):
+             * above, a block with neighbours of its own CTB there (uy > 0: earlier in z-order, hence available) has entries 1 .. nT
+               available, so an unavailable entry further right repeats one inside the used range; a block in the CTB's first row
+               has no block of this CTB above it anyway;
+             * on the left an unavailable entry repeats the one BELOW it, i.e. possibly one outside the used range: the range is
+               cut to nT only where entries -1 .. -nT are all that is used and no smoothing reaches below them (they are available
+               when ux > 0, and no block of this CTB is there when ux == 0) — else it stays 2nT;
+             * dropping a side altogether needs the used side's first nT entries available (uy > 0 resp. ux > 0), or the scan
+               would carry the other side's samples across the corner;
+             * not with constrained intra prediction (an inter neighbour is unavailable: none of the above holds), and 32x32 luma
+               blocks under strong smoothing read both ends of both sides for the bi-linear decision (intrapred.h:196-215).
+             The corner unit always stays.  The entries outside the used range are still fetched by k_intra — possibly while their
+             block is being written — and never used. */
+          const int nT = 1 << ib.log2_size;
+          int top_e = 2 * nT, left_e = 2 * nT;               /* used entries per side (0: the corner unit only) */
+          if (one_sided && !(ib.cidx == 0 && ib.log2_size == 5 && (pp.flags & M355_PF_STRONG_INTRA_SMOOTHING))) {
+            const int m = ib.mode;
+            bool filt = false;                                 /* as e0's M355_IBX_FILT below */
+            if (!(pp.flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (ib.cidx == 0 || pp.chroma_format_idc == 3) && m != 1 && ib.log2_size != 2) {
+              const int minDist = std::min(abs(m - 26), abs(m - 10));
+              filt = ib.log2_size == 3 ? minDist > 7 : (ib.log2_size == 4 ? minDist > 1 : (ib.log2_size == 5 ? minDist > 0 : false));
+            }
+            const bool bf = ib.cidx == 0 && ib.log2_size < 5 && (m == 1 || !(ib.flags & M355_IBF_DISABLE_BOUNDARY_FILTER));
+            static const int8_t mag[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+            int te = 2 * nT, le = 2 * nT;
+            if (m == 0) { te = nT + 1; le = 2 * nT; }
+            else if (m == 1) { te = nT; le = nT; }
+            else if (m > 10 && m < 26) { te = nT; le = nT; }
+            else if (m == 26) { te = nT; le = (bf || uy == 0) ? nT : 0; }
+            else if (m == 10) { le = nT; te = (bf || ux == 0) ? nT : 0; }
+            else if (m > 26) { te = std::min(2 * nT, nT + ((nT * mag[m - 26]) >> 5) + 2); le = uy > 0 ? 0 : 2 * nT; }
+            else /* 2..9 */ { le = 2 * nT; te = ux > 0 ? 0 : 2 * nT; }
+            if (filt) { if (te) te = std::min(2 * nT, te + 1); if (le) le = 2 * nT; }
+            top_e = te; left_e = le;
+          }
+          const int top_u = (top_e + 3) >> 2, left_u = (left_e + 3) >> 2;   /* units beside the corner */
           for (int t = -1; t < 2 * n4; t++) {
-            if (ux - 1 >= 0 && uy + t >= 0 && uy + t < 16) level = std::max(level, grid[ib.cidx][uy + t][ux - 1] + 1);
-            if (uy - 1 >= 0 && ux + t >= 0 && ux + t < 16) level = std::max(level, grid[ib.cidx][uy - 1][ux + t] + 1);
+            if (t < left_u && ux - 1 >= 0 && uy + t >= 0 && uy + t < 16) level = std::max(level, grid[ib.cidx][uy + t][ux - 1] + 1);
+            if (t < top_u && uy - 1 >= 0 && ux + t >= 0 && ux + t < 16) level = std::max(level, grid[ib.cidx][uy - 1][ux + t] + 1);
           }
         }
         level = std::min(level, 126);                    /* (only overlapping blocks — rejected below — could get there) */
@@ -1190,9 +1242,14 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
       }
       plan_count[c] = rel;
       log2_waves[c] = widest >= 5 ? 3 : (widest >= 3 ? 2 : (widest == 2 ? 1 : 0));
+      if (ctb.ib_count) my_levels += (key[ctb.ib_count - 1].first >> 2) + 1;
     }
-    n_blocks += my_blocks; n_intra_ctbs += my_ctbs;
+    n_blocks += my_blocks; n_intra_ctbs += my_ctbs; n_levels += my_levels;
   });
+  {
+    static const bool stats = getenv("M355_INTRA_LEVEL_STATS") != nullptr;
+    if (stats) fprintf(stderr, "intra_schedule: %lld blocks in %lld CTBs, %lld levels (one-sided %d)\n", n_blocks.load(), n_intra_ctbs.load(), n_levels.load(), (int)one_sided);
+  }
   *dense = (n_intra_ctbs.load() && n_blocks.load() >= 8 * (long)ctbW * ctbH) ? 1 : 0;
   return overlap.load();
 }
