@@ -1256,7 +1256,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 /* M355_FUSE_DBH: 1 = k_deblock<H> runs inside k_sao (k_sao_dbh, decode_post).  EXPERIMENTAL: verified under the SIMT interpreter
-   only (tests/test_fuse_dbh.py) — written when the round's GPU minutes were spent; tools/gpu_r5a.sh times it. */
+   only (tests/test_fuse_dbh.py) — written when the round's GPU minutes were spent; tools/gpu_r5b.sh times it. */
 static int fuse_dbh_sao()
 {
   static const int v = getenv("M355_FUSE_DBH") ? atoi(getenv("M355_FUSE_DBH")) : 0;

@@ -1,7 +1,7 @@
 """k_intra's dependency levels from what each intra mode can read (runtime.hip intra_schedule, M355_INTRA_ONE_SIDED=1) — an EXPERIMENTAL
 switch, off by default, written after the round's GPU minutes were spent: 42 % fewer levels (barrier steps of the chain) on the all-intra
 1080p picture of BASELINE config 2.  Bit-exact against the oracle under the SIMT interpreter (shuffled wave order, non-zero memory);
-the GPU case is opt-in until tools/gpu_r5a.sh has taken it to hardware.  The switch is read once per process."""
+the GPU case is opt-in until tools/gpu_r5c.sh has taken it to hardware.  The switch is read once per process."""
 import os
 import subprocess
 import sys
@@ -23,7 +23,7 @@ def test_mode_aware_intra_levels_emulated(emu_lib, oracle):  # noqa: F811
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("M355_TEST_INTRA_ONE_SIDED"), reason="opt-in (M355_TEST_INTRA_ONE_SIDED=1): the switch has not seen hardware yet — tools/gpu_r5a.sh is its first visit")
+@pytest.mark.skipif(not os.environ.get("M355_TEST_INTRA_ONE_SIDED"), reason="opt-in (M355_TEST_INTRA_ONE_SIDED=1): the switch has not seen hardware yet — tools/gpu_r5c.sh is its first visit")
 def test_mode_aware_intra_levels_gpu(oracle):
     r = subprocess.run([sys.executable, os.path.join(HERE, "one_sided_worker.py"), "default", oracle._name], env=dict(os.environ, M355_INTRA_ONE_SIDED="1"),
                        capture_output=True, text=True, timeout=600)
