@@ -131,16 +131,16 @@ __device__ __forceinline__ DbhIdx d_dbh_fetch(const DevPic& p, const int c, cons
 template <class PIX, int NW>
 __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const DbhIdx& m, const bool isQ, uint32_t (&A)[6][NW])
 {
+  const uint32_t ciQ = m.ciQ, ciP = m.ciP, ip = m.ip, iq = m.iq;
+  const int ef = m.ef, efo = m.efo, slice_idx = m.slice_idx;
+  const bool flagged = m.flagged;
+  if (!__any((int)flagged)) return;                        /* wave-uniform */
   /* the other side's rows (lane ^ 16 holds the same columns) */
   uint32_t B[5][NW];
 #pragma unroll
   for (int r = 1; r <= 4; r++)
 #pragma unroll
     for (int k = 0; k < NW; k++) B[r][k] = (uint32_t)__shfl_xor((int)A[r][k], 16, 64);
-  const uint32_t ciQ = m.ciQ, ciP = m.ciP, ip = m.ip, iq = m.iq;
-  const int ef = m.ef, efo = m.efo, slice_idx = m.slice_idx;
-  const bool flagged = m.flagged;
-  if (!__any((int)flagged)) return;                        /* wave-uniform */
   /* round trip 2: the records (an absent one reads the CTB table instead: always there, never used) */
   const bool pb_ok = ip && iq && ip <= (uint32_t)p.n_pb_records && iq <= (uint32_t)p.n_pb_records;
   const m355_cu cuQ = *(ciQ ? p.cus + (ciQ - 1) : (const m355_cu*)p.ctbs), cuP = *(ciP ? p.cus + (ciP - 1) : (const m355_cu*)p.ctbs);
@@ -277,7 +277,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   DbhIdx dbh_own, dbh_rim;
   if (DBH) {
 #pragma unroll
-    for (int r = 1; r <= 4; r++) d_sao_load4<PIX>(in + (size_t)max(min(y0 + r - 1, height - 1), 0) * is + (halo ? xh : xs), hr[r]);
+    for (int r = 1; r <= 4; r++) d_sao_load4<PIX>(in + (size_t)max(min(y0 + r - 1, height - 1), 0) * is + (halo ? xh : min(xt, width - 4)), hr[r]);   /* (the other lanes: one address per row) */
     dbh_own = d_dbh_fetch(p, c, valid, x0, yE);
     dbh_rim = d_dbh_fetch(p, c, halo, xh, yE);
   }
