@@ -170,7 +170,9 @@ __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const 
   if (c == 0) {
     /* ---- luma (deblock.cc:480-601, fallback-deblk.h:33-100) ---- */
     const int bd = p.pp.bit_depth_luma;
-    const int beta = c_tab_beta[d_clip3(0, 51, qP_L + sh.beta_offset)] * (1 << (bd - 8));
+    /* (the beta table of deblock.cc:385-392 is piecewise linear: 0 below 16, Q - 10 up to 28, 2Q - 38 above — one dependent load less) */
+    const int bq = d_clip3(0, 51, qP_L + sh.beta_offset);
+    const int beta = (bq < 16 ? 0 : (bq <= 28 ? bq - 10 : 2 * bq - 38)) * (1 << (bd - 8));
     const int tc = c_tab_tc[d_clip3(0, 53, qP_L + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
     const int dm0 = d_abs(MV(0, 2) - 2 * MV(0, 1) + MV(0, 0)), dm3 = d_abs(MV(3, 2) - 2 * MV(3, 1) + MV(3, 0));
     const int do0 = d_abs(OV(0, 2) - 2 * OV(0, 1) + OV(0, 0)), do3 = d_abs(OV(3, 2) - 2 * OV(3, 1) + OV(3, 0));
