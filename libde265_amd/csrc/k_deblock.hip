@@ -14,6 +14,7 @@
  */
 #include <algorithm>
 #include "k_common.h"
+#define K_DEBLOCK_DEV_OWNER
 #include "k_deblock_dev.h"
 
 template <class PIX, bool VERTICAL>

@@ -7,7 +7,11 @@
 #define K_DEBLOCK_DEV_H
 #include "k_common.h"
 
-namespace {   /* (one copy per translation unit: the library is linked without relocatable device code) */
+/* k_deblock.hip (K_DEBLOCK_DEV_OWNER) defines the tables with external linkage, as it always has; any other translation unit gets a
+   copy of its own (the library is linked without relocatable device code) */
+#ifndef K_DEBLOCK_DEV_OWNER
+namespace {
+#endif
 __constant__ uint8_t c_tab_beta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,
                                        8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28, 30, 32,
                                        34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
@@ -16,7 +20,9 @@ __constant__ uint8_t c_tab_tc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  
                                      4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
 __constant__ int8_t c_qpc_420[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37}; /* transform.h:29-34 */
 
+#ifndef K_DEBLOCK_DEV_OWNER
 }  /* namespace */
+#endif
 
 struct CuInfo { int pred_mode, qp, pcm, bypass; };
 __device__ __forceinline__ CuInfo d_cu_info(const DevPic& p, int xl, int yl)
