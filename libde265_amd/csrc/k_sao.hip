@@ -128,8 +128,10 @@ __device__ __forceinline__ DbhIdx d_dbh_fetch(const DevPic& p, const int c, cons
   m.flagged = cand && (m.ef & (E_TU_H | E_PB_H));
   return m;
 }
-template <class PIX, int NW>
-__device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const DbhIdx& m, const bool isQ, uint32_t (&A)[6][NW])
+/* RIM: the block is a rim block, of which SAO reads ONE column (line `rim_line`: 3 of the block on the left, 0 of the one on the right) —
+   the decisions still come from lines 0 and 3, but only that line is filtered (the run issues for an eighth of the lanes) */
+template <class PIX, int NW, bool RIM = false>
+__device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const DbhIdx& m, const bool isQ, uint32_t (&A)[6][NW], const int rim_line = 0)
 {
   const uint32_t ciQ = m.ciQ, ciP = m.ciP, ip = m.ip, iq = m.iq;
   const int ef = m.ef, efo = m.efo, slice_idx = m.slice_idx;
@@ -166,7 +168,10 @@ __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const 
     for (int k = 0; k < NW; k++) { mr[i].w[k] = isQ ? A[1 + i][k] : A[4 - i][k]; orow[i].w[k] = isQ ? B[4 - i][k] : B[1 + i][k]; }
 #define MV(k, i) d_get<PIX>(mr[i], k)
 #define OV(k, i) d_get<PIX>(orow[i], k)
-#define SETM(k, i, v) d_set<PIX>(mr[i], k, v)
+/* (RIM: the one line is line 3 or line 0, per lane) */
+#define RMV(k, i) (RIM ? (rim_line ? MV(3, i) : MV(0, i)) : MV(k, i))
+#define ROV(k, i) (RIM ? (rim_line ? OV(3, i) : OV(0, i)) : OV(k, i))
+#define SETM(k, i, v) do { if (RIM) { const int v_ = (v); Raw4<PIX> a_ = mr[i], b_ = mr[i]; d_set<PIX>(a_, 3, v_); d_set<PIX>(b_, 0, v_); mr[i] = rim_line ? a_ : b_; } else d_set<PIX>(mr[i], k, v); } while (0)
   if (c == 0) {
     /* ---- luma (deblock.cc:480-601, fallback-deblk.h:33-100) ---- */
     const int bd = p.pp.bit_depth_luma;
@@ -185,9 +190,9 @@ __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const 
     const bool strong = dSam0 && dSam3;
     const bool dEm = dm0 + dm3 < ((beta + (beta >> 1)) >> 3);          /* dEp on the P side, dEq on the Q side */
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int m0 = MV(k, 0), m1 = MV(k, 1), m2 = MV(k, 2), m3 = MV(k, 3);
-      const int o0 = OV(k, 0), o1 = OV(k, 1);
+    for (int k = 0; k < (RIM ? 1 : 4); k++) {
+      const int m0 = RMV(k, 0), m1 = RMV(k, 1), m2 = RMV(k, 2), m3 = RMV(k, 3);
+      const int o0 = ROV(k, 0), o1 = ROV(k, 1);
       if (strong) {
         SETM(k, 0, d_clip3(m0 - 2 * tc, m0 + 2 * tc, (m2 + 2 * m1 + 2 * m0 + 2 * o0 + o1 + 4) >> 3));
         SETM(k, 1, d_clip3(m1 - 2 * tc, m1 + 2 * tc, (m2 + m1 + m0 + o0 + 2) >> 2));
@@ -214,8 +219,8 @@ __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const 
     else QP_C = min(qP_i, 51);
     const int tc = c_tab_tc[d_clip3(0, 53, QP_C + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int m0 = MV(k, 0), m1 = MV(k, 1), o0 = OV(k, 0), o1 = OV(k, 1);
+    for (int k = 0; k < (RIM ? 1 : 4); k++) {
+      const int m0 = RMV(k, 0), m1 = RMV(k, 1), o0 = ROV(k, 0), o1 = ROV(k, 1);
       const int t = (m0 - o0) * 4 - (m1 - o1);                          /* s * ((q0 - p0) * 4 + p1 - q1) */
       const int delta = d_clip3(-tc, tc, ((isQ ? t : -t) + 4) >> 3);
       SETM(k, 0, d_clip_bd(m0 + (isQ ? -delta : delta), bd));
@@ -223,6 +228,8 @@ __device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const 
   }
 #undef MV
 #undef OV
+#undef RMV
+#undef ROV
 #undef SETM
   /* this lane's side goes back into its rows */
 #pragma unroll
@@ -312,7 +319,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
     /* the horizontal edges of this tile, then (only if some CTB of the wave asks for an edge class) those of the rim blocks */
     M355_COMPILER_FENCE();
     d_dbh_block<PIX, NW>(p, c, dbh_own, (ly & 1) != 0, rw);
-    if (any_edge) d_dbh_block<PIX, NW>(p, c, dbh_rim, (ly & 1) != 0, hr);
+    if (any_edge) d_dbh_block<PIX, NW, true>(p, c, dbh_rim, (ly & 1) != 0, hr, lx == 0 ? 3 : 0);
   }
   const bool enabled = (nbmask_raw & 0x8000u) != 0;
   const int type = enabled ? type_raw : 0;
