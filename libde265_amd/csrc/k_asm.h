@@ -94,4 +94,16 @@ __device__ __forceinline__ int d_dot2(unsigned a, unsigned b, int c)
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(m355_short2, a), __builtin_bit_cast(m355_short2, b), c, false);
 }
 
+/* v_dot4_i32_i8: c + sum of four signed-byte products — four filter taps per VALU issue (8-bit planes: samples XOR 0x80 are the
+ * signed operand, the +128 * sum(taps) correction sits in the accumulator's start value) */
+__device__ __forceinline__ int d_dot4(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+/* v_perm_b32: bytes 1..2 of two registers -> one packed pair = ((lo >> 8) & 0xFFFF) | ((hi >> 8) << 16): a filter sum whose taps were
+ * scaled so that its final right shift is 8 is shifted, truncated to int16 and packed with its neighbour in ONE issue */
+__device__ __forceinline__ unsigned d_pack_mid16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x06050201u); }
+/* bytes 0 and 2 of two registers (the low bytes of four packed 16-bit values) -> four bytes */
+__device__ __forceinline__ unsigned d_pack_bytes(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
+/* packed signed 16-bit: saturating add (v_pk_add_i16 clamp), arithmetic shift right (v_pk_ashrrev_i16) */
+__device__ __forceinline__ unsigned d_pk_addsat_i16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(m355_short2v, a), __builtin_bit_cast(m355_short2v, b))); }
+__device__ __forceinline__ unsigned d_pk_ashr16(unsigned v, int s) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(m355_short2v, v) >> (m355_short2v)(short)s); }
+
 #endif

@@ -161,12 +161,11 @@ struct DevPic {
   uint32_t res_fused_base[4];
   uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable; bit 15 = the CTB's slice has SAO on for the component (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
-  uint32_t* job_base;               /* [256-PB chunk][3]: the chunk's jobs per range (uni, bi, edge): k_job_count leaves the counts here, every
+  uint32_t* job_base;               /* [256-PB chunk][4]: the chunk's jobs per range (uni, bi, weighted, edge): k_job_count leaves the counts here, every
                                        workgroup of k_meta_pb sums the ones in front of its chunk (lane scratch) */
-  uint32_t* job_tot;                /* [0] one-list jobs, [1] + bi-predicted = where the EDGE range starts, [2] all jobs (k_meta_pb's workgroup 0; clamped to jobs_cap) */
+  uint32_t* job_tot;                /* range ENDS: [0] one-list jobs, [1] + bi-predicted, [2] + explicitly weighted = where the EDGE range starts, [3] all jobs (k_meta_pb's workgroup 0; clamped to jobs_cap) */
   uint32_t jobs_cap;                /* entries of jobs[]: >= what any list of disjoint prediction blocks produces (runtime.hip prepare) */
   int fill_pb_of_in_meta;           /* 1: k_meta_pb fills pb_of (inter stage off); 0: k_inter_jobs does, two units per job */
-  /* (jobs [0, job_tot[0]): one list; [job_tot[0], job_tot[1]): bi-predicted; [job_tot[1], job_tot[2]): EDGE = clamped loads) */
   /* intra wavefront state */
   unsigned long long* edge;         /* k_intra's halo exchange: 8-byte granules (epoch << 32 | two samples), per component the right
                                        columns of all CTB columns [ctbX][row >> 1], then the bottom rows of all CTB rows [ctbY][col >> 1] */
@@ -206,19 +205,22 @@ struct HaloLayout {
   int n_units;                      /* border 4x4 units: 2*n_vb*h4 + 2*n_hb*w4 */
 };
 
-/* Does any reference window of this PB cross the left/right picture border (so its jobs need the
- * per-sample clamped loads of motion.cc:141-159)?  Shared by the host (job counts at upload) and
- * k_meta_pb (job sorting): both must agree.  Luma span of a 4-column job: [x-3, x+7] (+1 pad sample),
- * chroma span of its 2 columns: [xc-1, xc+3].  Vertical clamping is done per row everywhere. */
-__host__ __device__ inline bool m355_pb_is_edge(const m355_pb& pb, int width, int chroma_format_idc)
+/* Does any reference window of this PB leave the picture (so its jobs need the coordinate-clamped loads of motion.cc:141-159)?
+ * Luma span of a 4-column job: [x-3, x+7] (+1 pad sample), chroma span of its 2 columns: [xc-1, xc+3]; a job is 8 rows high whatever
+ * the PB's height, so the vertical span is that of the height rounded up to 8: rows [y-3, y+h8+3] / [yc-1, yc+h8/2+1].  The jobs of
+ * every other PB are filtered without a clamp (k_inter.hip, lean filters). */
+__host__ __device__ inline bool m355_pb_is_edge(const m355_pb& pb, int width, int height, int chroma_format_idc)
 {
+  const int h8 = (pb.h + 7) & ~7;
   for (int l = 0; l < 2; l++) {
     if (!(pb.flags & (M355_PBF_MC_L0 << l)) || (pb.flags & (M355_PBF_FILL_L0 << l))) continue;
-    const int xl = pb.x + (pb.mv[l][0] >> 2);
+    const int xl = pb.x + (pb.mv[l][0] >> 2), yl = pb.y + (pb.mv[l][1] >> 2);
     if (xl - 3 < 0 || xl + pb.w + 3 > width - 1) return true;
+    if (yl - 3 < 0 || yl + h8 + 3 > height - 1) return true;
     if (chroma_format_idc == 1) {
-      const int xc = (pb.x >> 1) + (pb.mv[l][0] >> 3);
+      const int xc = (pb.x >> 1) + (pb.mv[l][0] >> 3), yc = (pb.y >> 1) + (pb.mv[l][1] >> 3);
       if (xc - 1 < 0 || xc + (pb.w >> 1) + 1 > (width >> 1) - 1) return true;
+      if (yc - 1 < 0 || yc + (h8 >> 1) + 1 > (height >> 1) - 1) return true;
     }
   }
   return false;

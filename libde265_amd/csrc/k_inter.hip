@@ -196,6 +196,12 @@ __global__ void __launch_bounds__(256) k_inter_generic(DevPic p)
 /* packed tap tables, built once per workgroup in LDS.
  *   qpel[f] : E0..E3 = (t0,t1)(t2,t3)(t4,t5)(t6,t7) ; O0..O4 = (0,t0)(t1,t2)(t3,t4)(t5,t6)(t7,0)
  *   epel[f] : E0..E1 = (c0,c1)(c2,c3)               ; O0..O2 = (0,c0)(c1,c2)(c3,0)            */
+#ifndef M355_INTER_WAVES
+#define M355_INTER_WAVES 3   /* waves per SIMD the register budget is sized for (tools/variants.sh sweeps it) */
+#endif
+#ifndef M355_INTER_BLOCK
+#define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
+#endif
 #define QT_STRIDE 9
 #define ET_STRIDE 5
 __device__ __forceinline__ unsigned d_pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
@@ -521,29 +527,289 @@ __device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
 }
 
 #undef CROW
+
+/* ================================================================================================
+ * lean filters (bit depths <= 12, i.e. every 8-bit plane and the 9..12-bit uint16 planes): the job classes whose windows lie
+ * INSIDE the reference picture (k_meta_pb sorts the others into the EDGE range).
+ *
+ *  * The reference's special cases fold into the general filter exactly (fallback-motion.cc:431-485 full-pel, :512-565 / :573-626 the
+ *    xFrac == 0 / yFrac == 0 copies): phase 0 is the tap row {0,0,0,64,0,0,0,0} ({0,64,0,0} chroma), so the H pass gives
+ *    (64 s) >> (bd - 8) = s << (14 - bd) (<= 16 380: an int16, nothing lost for bd <= 14), the V pass with shift 6 gives
+ *    (sum t (s << (14 - bd))) >> 6 = (sum t s) >> (bd - 8) for xFrac == 0, (64 h) >> 6 = h for yFrac == 0 and s << (14 - bd) =
+ *    s << shift3 (bd <= 12) for both: no selects, no second data path.
+ *  * The right shift of a pass is made 8 by scaling its taps (H: x 2^(16 - bd), <= 88 * 128; V: x 4; all products and sums stay far
+ *    inside int32), so that shift + truncation to int16 (the reference's int16 mcbuffer / predSamples stores) + packing two results
+ *    into a register pair is ONE v_perm_b32 (d_pack_mid16) instead of two shifts and a pack.
+ *  * Window rows are loaded from the dword-aligned address at or below their first sample (k_asm.h d_ldg*: a misaligned vector load
+ *    costs the texture addresser 4x) and NOT shifted into place: the lane picks the tap registers that match its window's phase
+ *    d = x & 1 instead (16-bit planes: T0 / T1 below; 20 dot2 per row instead of 18 + 6 funnel shifts).
+ *  * 8-bit planes: v_dot4_i32_i8 on the bytes as loaded (3 funnel shifts per 16-byte row, XOR 0x80 makes them signed operands,
+ *    + 128 * 64 in the accumulator): 11 dot4 per luma row instead of 12 unpacks + 18 dot2.
+ *  * No coordinate clamps: address = first row + r * pitch.
+ * ============================================================================================== */
+#define QL_STRIDE 12   /* 16-bit planes: [xf][d][12] = T0[5] T1[5] (2 spare);  8-bit planes: [xf][12] = W[j][3], j = output column */
+#define CL_STRIDE 8    /* 16-bit planes: [xf][d][8]  = U0[3] U1[3] (2 spare);  8-bit planes: [xf][4]  = C0 C1 C2 (1 spare) */
+__device__ __forceinline__ int d_qtap(int f, int i)   /* c_qpel_taps[f][i] from immediates (no constant-memory round trip in the prologue) */
+{
+  const unsigned long long t = f == 0 ? 0x0000000040000000ull : (f == 1 ? 0x0001FB113AF604FFull : (f == 2 ? 0xFF04F52828F504FFull : 0xFF04F63A11FB0100ull));
+  return (int)(int8_t)(t >> (8 * i));
+}
+__device__ __forceinline__ int d_etap(int f, int i)   /* c_epel_taps[f][i] */
+{
+  const unsigned lo = (f & 1) ? ((f & 2) ? 0xFC1C2EFAu : 0xFE0A3AFEu) : ((f & 2) ? 0xFE1036FCu : 0x00004000u);
+  const unsigned hi = (f & 1) ? ((f & 2) ? 0xFE3A0AFEu : 0xFA2E1CFCu) : ((f & 2) ? 0xFC3610FEu : 0xFC2424FCu);
+  return (int)(int8_t)(((f & 4) ? hi : lo) >> (8 * i));
+}
+/* entry e of the packed-pair tap sets of an N-tap filter (taps t(i), i = 0..N-1, times `scale`): E_k = (t 2k, t 2k+1), O_k = (t 2k-1, t 2k) */
+template <class F> __device__ __forceinline__ unsigned d_tap_pair(F t, int n, int first, int scale)
+{
+  const int a = first >= 0 && first < n ? t(first) * scale : 0, b = first + 1 >= 0 && first + 1 < n ? t(first + 1) * scale : 0;
+  return d_pack16(a, b);
+}
+template <class PIX>
+__device__ __forceinline__ void d_lean_tables(const DevPic& p, unsigned* s_ql, unsigned* s_qv, unsigned* s_cl, unsigned* s_cv)
+{
+  const int tid = threadIdx.x;
+  /* V taps x 4: qv[yf][9] = E0..E3 O0..O4, cv[yf][5] = E0 E1 O0 O1 O2 */
+  for (int i = tid; i < 4 * QT_STRIDE; i += M355_INTER_BLOCK) {
+    const int f = i / QT_STRIDE, k = i - f * QT_STRIDE;
+    s_qv[i] = d_tap_pair([&](int j) { return d_qtap(f, j); }, 8, k < 4 ? 2 * k : 2 * (k - 4) - 1, 4);
+  }
+  for (int i = tid; i < 8 * ET_STRIDE; i += M355_INTER_BLOCK) {
+    const int f = i / ET_STRIDE, k = i - f * ET_STRIDE;
+    s_cv[i] = d_tap_pair([&](int j) { return d_etap(f, j); }, 4, k < 2 ? 2 * k : 2 * (k - 2) - 1, 4);
+  }
+  if (sizeof(PIX) == 2) {
+    const int hs = 1 << (16 - p.pp.bit_depth_luma), hc = 1 << (16 - p.pp.bit_depth_chroma);
+    /* d = 0: T0 = (E0 E1 E2 E3 0), T1 = (O0 .. O4);  d = 1: T0 = (O0 .. O4), T1 = (0 E0 E1 E2 E3)   — pair k of T over window pairs k.. */
+    for (int i = tid; i < 4 * 2 * QL_STRIDE; i += M355_INTER_BLOCK) {
+      const int f = i / (2 * QL_STRIDE), r = i - f * 2 * QL_STRIDE, d = r / QL_STRIDE, e = r - d * QL_STRIDE;
+      const int set = e / 5, k = e - set * 5;          /* set 0: T0, 1: T1, 2: spare */
+      /* sample index (relative to the window's first loaded sample) of output column `set` = d + set; pair k starts at sample 2k */
+      s_ql[i] = set < 2 ? d_tap_pair([&](int j) { return d_qtap(f, j); }, 8, 2 * k - (d + set), hs) : 0u;
+    }
+    for (int i = tid; i < 8 * 2 * CL_STRIDE; i += M355_INTER_BLOCK) {
+      const int f = i / (2 * CL_STRIDE), r = i - f * 2 * CL_STRIDE, d = r / CL_STRIDE, e = r - d * CL_STRIDE;
+      const int set = e / 3, k = e - set * 3;
+      s_cl[i] = set < 2 ? d_tap_pair([&](int j) { return d_etap(f, j); }, 4, 2 * k - (d + set), hc) : 0u;
+    }
+  } else {
+    /* W[j][w]: the 8 taps as bytes at byte offset j of 12 */
+    for (int i = tid; i < 4 * QL_STRIDE; i += M355_INTER_BLOCK) {
+      const int f = i / QL_STRIDE, e = i - f * QL_STRIDE, j = e / 3, w = e - j * 3;
+      unsigned v = 0;
+      for (int b = 0; b < 4; b++) { const int idx = 4 * w + b - j; if (idx >= 0 && idx < 8) v |= ((unsigned)d_qtap(f, idx) & 0xFFu) << (8 * b); }
+      s_ql[i] = v;
+    }
+    for (int i = tid; i < 8 * 4; i += M355_INTER_BLOCK) {
+      const int f = i >> 2, e = i & 3;
+      unsigned c = 0;
+      for (int b = 0; b < 4; b++) c |= ((unsigned)d_etap(f, b) & 0xFFu) << (8 * b);
+      s_cl[i] = e == 0 ? c : (e == 1 ? c << 8 : (e == 2 ? c >> 24 : 0u));
+    }
+  }
+}
+
+/* luma 4x8 block of one list -> packed 14-bit predictions (fallback-motion.cc:492-636 with the folds above) */
+template <class PIX>
+__device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rstride, int xi, int yi, int xf, int yf,
+                                               const unsigned* s_ql, const unsigned* s_qv, unsigned pred[8][2])
+{
+  const int xa = xi - 3;
+  unsigned Q[8][4];
+  if (sizeof(PIX) == 2) {
+    const unsigned* tl = s_ql + (xf * 2 + (xa & 1)) * QL_STRIDE;
+    unsigned T0[5], T1[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { T0[k] = tl[k]; T1[k] = tl[5 + k]; }
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 3) * rstride + (xa & ~1);
+    unsigned S[2][2][6];
+    d_ldg16(q, S[0][0]); d_ldg8(q + 8, S[0][0] + 4); q += rstride;
+    d_ldg16(q, S[0][1]); d_ldg8(q + 8, S[0][1] + 4); q += rstride;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      /* rows are fetched one pair ahead of the pair being filtered (the scheduling barriers keep hipcc from hoisting all 15 rows) */
+      if (k < 7) {
+        d_ldg16(q, S[(k + 1) & 1][0]); d_ldg8(q + 8, S[(k + 1) & 1][0] + 4); q += rstride;
+        if (k < 6) { d_ldg16(q, S[(k + 1) & 1][1]); d_ldg8(q + 8, S[(k + 1) & 1][1] + 4); q += rstride; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      int h[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }   /* row 15 is never read with a non-zero tap */
+        const unsigned* E = S[k & 1][r];
+        h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2(E[0], T0[0], 0)))));
+        h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2(E[0], T1[0], 0)))));
+        h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2(E[1], T0[0], 0)))));
+        h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2(E[1], T1[0], 0)))));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) Q[k][j] = d_pack_mid16((unsigned)h[0][j], (unsigned)h[1][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    const unsigned* tl = s_ql + xf * QL_STRIDE;
+    unsigned W[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { W[j][0] = tl[3 * j]; W[j][1] = tl[3 * j + 1]; W[j][2] = tl[3 * j + 2]; }
+    const unsigned sh = (unsigned)xa & 3u;
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 3) * rstride + (xa & ~3);
+    unsigned S[2][2][4];
+    d_ldg16(q, S[0][0]); q += rstride;
+    d_ldg16(q, S[0][1]); q += rstride;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (k < 7) {
+        d_ldg16(q, S[(k + 1) & 1][0]); q += rstride;
+        if (k < 6) { d_ldg16(q, S[(k + 1) & 1][1]); q += rstride; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      int h[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }
+        const unsigned* E = S[k & 1][r];
+        unsigned A[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) A[i] = __builtin_amdgcn_alignbyte(E[i + 1], E[i], sh) ^ 0x80808080u;
+        h[r][0] = d_dot4(A[1], W[0][1], d_dot4(A[0], W[0][0], 8192));
+#pragma unroll
+        for (int j = 1; j < 4; j++) h[r][j] = d_dot4(A[2], W[j][2], d_dot4(A[1], W[j][1], d_dot4(A[0], W[j][0], 8192)));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) Q[k][j] = d_pack_lo16((unsigned)h[0][j], (unsigned)h[1][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const unsigned* ty = s_qv + yf * QT_STRIDE;
+  unsigned YE[4], YO[5];
+#pragma unroll
+  for (int k = 0; k < 4; k++) YE[k] = ty[k];
+#pragma unroll
+  for (int k = 0; k < 5; k++) YO[k] = ty[4 + k];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    int ve[4], vo[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      ve[j] = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0))));
+      vo[j] = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)))));
+    }
+#pragma unroll
+    for (int jp = 0; jp < 2; jp++) {
+      pred[2 * m][jp] = d_pack_mid16((unsigned)ve[2 * jp], (unsigned)ve[2 * jp + 1]);
+      pred[2 * m + 1][jp] = d_pack_mid16((unsigned)vo[2 * jp], (unsigned)vo[2 * jp + 1]);
+    }
+  }
+}
+
+/* chroma 2x4 block of one list and plane (fallback-motion.cc:305-415 / 262-302 with the folds above) */
+template <class PIX>
+__device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int rstride, int xi, int yi, int xf, int yf,
+                                                 const unsigned* s_cl, const unsigned* s_cv, unsigned pred[4])
+{
+  const int xa = xi - 1;
+  int h[8][2];
+  if (sizeof(PIX) == 2) {
+    const unsigned* tl = s_cl + (xf * 2 + (xa & 1)) * CL_STRIDE;
+    unsigned U0[3], U1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { U0[k] = tl[k]; U1[k] = tl[3 + k]; }
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 1) * rstride + (xa & ~1);
+    unsigned S[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; r++) { d_ldg12(q, S[r]); q += rstride; }
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      h[r][0] = d_dot2(S[r][2], U0[2], d_dot2(S[r][1], U0[1], d_dot2(S[r][0], U0[0], 0)));
+      h[r][1] = d_dot2(S[r][2], U1[2], d_dot2(S[r][1], U1[1], d_dot2(S[r][0], U1[0], 0)));
+    }
+  } else {
+    const unsigned* tl = s_cl + xf * 4;
+    const unsigned C0 = tl[0], C1 = tl[1], C2 = tl[2];
+    const unsigned sh = (unsigned)xa & 3u;
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 1) * rstride + (xa & ~3);
+    unsigned S[7][2];
+#pragma unroll
+    for (int r = 0; r < 7; r++) { d_ldg8(q, S[r]); q += rstride; }
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const unsigned A0 = __builtin_amdgcn_alignbyte(S[r][1], S[r][0], sh) ^ 0x80808080u, A1 = (S[r][1] >> (8 * sh)) ^ 0x80808080u;
+      h[r][0] = d_dot4(A0, C0, 8192);
+      h[r][1] = d_dot4(A1, C2, d_dot4(A0, C1, 8192));
+    }
+  }
+  h[7][0] = h[7][1] = 0;
+  unsigned Q[4][2];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) Q[k][j] = sizeof(PIX) == 2 ? d_pack_mid16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]) : d_pack_lo16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]);
+  const unsigned* ty = s_cv + yf * ET_STRIDE;
+  unsigned YE[2], YO[3];
+#pragma unroll
+  for (int k = 0; k < 2; k++) YE[k] = ty[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) YO[k] = ty[2 + k];
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    int ve[2], vo[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      ve[j] = d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0));
+      vo[j] = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)));
+    }
+    pred[2 * m] = d_pack_mid16((unsigned)ve[0], (unsigned)ve[1]);
+    pred[2 * m + 1] = d_pack_mid16((unsigned)vo[0], (unsigned)vo[1]);
+  }
+}
+
 /* One job.  FAST: the PB's reference windows lie inside the picture horizontally (k_meta_pb sorts the
  * others into the EDGE job range, handled with clamped per-sample loads). */
 template <class PIX, bool BIAS, bool FAST>
 __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et, const DevRef* s_refs);
+/* One job of the lean classes (windows inside the picture, bit depths <= 12).  WEIGHTED: explicit weights — one or two lists per lane,
+ * the 32-bit write-back; else the lists are the workgroup's (bi: wave-uniform) and the write-back is packed 16-bit arithmetic. */
+template <class PIX, bool WEIGHTED>
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, const DevRef* s_refs);
 
 /* one launch for the main and the edge job range: blocks [0, nblk_edge8) take edge jobs */
-#ifndef M355_INTER_WAVES
-#define M355_INTER_WAVES 3   /* waves per SIMD the register budget is sized for (tools/variants.sh sweeps it) */
-#endif
-#ifndef M355_INTER_BLOCK
-#define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
-#endif
-template <class PIX, bool BIAS>
+template <class PIX, bool BIAS, bool LEAN>
 __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jobs(DevPic p)
 {
   M355_GATE(p);
-  /* the job counts live on the device (k_job_scan); the grid is an upper bound: surplus workgroups leave here */
-  const int n_jobs_uni = (int)p.job_tot[0], n_jobs_main = (int)p.job_tot[1], n_jobs = (int)p.job_tot[2];
+  /* the job counts live on the device (k_job_count / k_meta_pb); the grid is an upper bound: surplus workgroups leave here.
+     Ranges: [0, tot0) one list, [tot0, tot1) two lists, [tot1, tot2) explicit weights, [tot2, tot3) EDGE (windows that leave the picture) */
+  const int t0 = (int)p.job_tot[0], t1 = (int)p.job_tot[1], t2 = (int)p.job_tot[2], t3 = (int)p.job_tot[3];
   auto blocks8 = [](int jobs) { return (((jobs + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK + 7) / 8) * 8; };
-  const int nblk_uni8 = blocks8(n_jobs_uni), nblk_bi8 = blocks8(n_jobs_main - n_jobs_uni), nblk_edge8 = blocks8(n_jobs - n_jobs_main);
-  if ((int)blockIdx.x >= nblk_edge8 + nblk_bi8 + nblk_uni8) return;
-  __shared__ unsigned s_qt[4 * QT_STRIDE];
-  __shared__ unsigned s_et[8 * ET_STRIDE];
+  const int nblk_uni8 = blocks8(t0), nblk_bi8 = blocks8(t1 - t0), nblk_w8 = blocks8(t2 - t1), nblk_edge8 = blocks8(t3 - t2);
+  if ((int)blockIdx.x >= nblk_edge8 + nblk_bi8 + nblk_uni8 + nblk_w8) return;
+  /* Dispatch order = expected cost, longest first: edge blocks (clamped loads make them latency-bound; started early they overlap with
+     everything else; spread round-robin over the XCDs), then the other classes in an XCD-aware order: block b runs on XCD b % 8, and
+     every XCD gets one contiguous eighth of each range (= compact regions of the picture) so reference-window overlap hits that XCD's
+     own L2.  Within an XCD the classes are interleaved in proportion (all lists are in PB order, so block i/per_a of one and block
+     i/per_b of another cover the same part of the picture): they then read the same reference region while it is still in that
+     XCD's L2 — run one class after the other and every region is fetched twice, far apart in time. */
+  const int b = blockIdx.x;
+  int cls, ji, jend;
+  if (b < nblk_edge8) { cls = 3; ji = t2 + b * M355_INTER_BLOCK; jend = t3; }
+  else {
+    const int bm = b - nblk_edge8, xcd = bm & 7, slot = bm >> 3;
+    const int per_bi = nblk_bi8 >> 3, per_uni = nblk_uni8 >> 3, per_w = nblk_w8 >> 3;
+    const int per = per_bi + per_uni + per_w;
+    const int bi_before = (int)(((long long)slot * per_bi) / per), bi_after = (int)(((long long)(slot + 1) * per_bi) / per);
+    if (bi_after != bi_before) { cls = 1; ji = t0 + (xcd * per_bi + bi_before) * M355_INTER_BLOCK; jend = t1; }
+    else {
+      const int s2 = slot - bi_before, per2 = per_uni + per_w;
+      const int w_before = (int)(((long long)s2 * per_w) / per2), w_after = (int)(((long long)(s2 + 1) * per_w) / per2);
+      if (w_after != w_before) { cls = 2; ji = t1 + (xcd * per_w + w_before) * M355_INTER_BLOCK; jend = t2; }
+      else { cls = 0; ji = (xcd * per_uni + s2 - w_before) * M355_INTER_BLOCK; jend = t0; }
+    }
+  }
+  if (ji >= jend) return;          /* (workgroup-uniform: the padding blocks of a range) */
+  ji += threadIdx.x;
+
   /* the reference-frame table (plane pointers / pitches per DPB slot) in LDS: a job looks its references up
      with ds_reads instead of a dependent global load per list and component (each one a full memory
      latency on the wave's critical path) */
@@ -553,6 +819,18 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     unsigned* dst = (unsigned*)s_refs;
     for (int i = threadIdx.x; i < (int)(sizeof(s_refs) / 4); i += M355_INTER_BLOCK) dst[i] = src[i];
   }
+  if (LEAN && cls != 3) {
+    __shared__ unsigned s_ql[4 * 2 * QL_STRIDE], s_qv[4 * QT_STRIDE], s_cl[8 * 2 * CL_STRIDE], s_cv[8 * ET_STRIDE];
+    d_lean_tables<PIX>(p, s_ql, s_qv, s_cl, s_cv);
+    __syncthreads();
+    if (ji >= jend) return;
+    const uint32_t job = p.jobs[ji];
+    if (cls == 2) d_inter_job_lean<PIX, true>(p, job, false, s_ql, s_qv, s_cl, s_cv, s_refs);
+    else d_inter_job_lean<PIX, false>(p, job, cls == 1, s_ql, s_qv, s_cl, s_cv, s_refs);
+    return;
+  }
+  __shared__ unsigned s_qt[4 * QT_STRIDE];
+  __shared__ unsigned s_et[8 * ET_STRIDE];
   if (threadIdx.x < 4) {
     const int8_t* t = c_qpel_taps[threadIdx.x];
     unsigned* o = s_qt + threadIdx.x * QT_STRIDE;
@@ -567,43 +845,9 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     o[2] = d_pack16(0, t[0]); o[3] = d_pack16(t[1], t[2]); o[4] = d_pack16(t[3], 0);
   }
   __syncthreads();
-
-  /* Dispatch order = expected cost, longest first: edge blocks (per-sample clamped loads make them
-     latency-bound; started early they overlap with everything else), then bi-predicted blocks (two
-     passes), then one-list blocks.  Edge blocks are spread round-robin over the XCDs.  The other two
-     ranges use an XCD-aware order: block b runs on XCD b % 8, and every XCD gets one contiguous eighth of
-     each range (= compact regions of the picture) so reference-window overlap hits that XCD's own L2. */
-  const int b = blockIdx.x;
-  if (b < nblk_edge8) {
-    const int ji = n_jobs_main + b * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < n_jobs) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et, s_refs);
-    return;
-  }
-  const int bm = b - nblk_edge8, xcd = bm & 7, slot = bm >> 3;
-  const int per_bi = nblk_bi8 >> 3, per_uni = nblk_uni8 >> 3;
-#ifndef M355_INTER_NO_INTERLEAVE
-  /* Within an XCD the bi-predicted and the one-list blocks are interleaved in proportion (both lists are in
-     PB order, so block i/per_bi of one and block i/per_uni of the other cover the same part of the picture):
-     the two classes then read the same reference region while it is still in that XCD's L2 — run one class
-     after the other and every region is fetched twice, far apart in time. */
-  const int per = per_bi + per_uni;
-  const int bi_before = (int)(((long long)slot * per_bi) / per), bi_after = (int)(((long long)(slot + 1) * per_bi) / per);
-  if (bi_after != bi_before) {
-    const int ji = n_jobs_uni + (xcd * per_bi + bi_before) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
-  } else {
-    const int ji = (xcd * per_uni + slot - bi_before) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
-  }
-#else
-  if (slot < per_bi) {
-    const int ji = n_jobs_uni + (xcd * per_bi + slot) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < n_jobs_main) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
-  } else {
-    const int ji = (xcd * per_uni + slot - per_bi) * M355_INTER_BLOCK + threadIdx.x;
-    if (ji < n_jobs_uni) d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
-  }
-#endif
+  if (ji >= jend) return;
+  if (cls == 3) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et, s_refs);
+  else d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
 }
 
 template <class PIX, bool BIAS, bool FAST>
@@ -830,25 +1074,249 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
   }
 }
 
-template <class PIX, bool BIAS>
+template <class PIX, bool WEIGHTED>
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, const DevRef* s_refs)
+{
+  const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
+  const int strip = (job >> 25) & 15, rblk = job >> 29;
+  const int x0 = pb.x + 4 * strip, y0 = pb.y + 8 * rblk;
+  const int rows = min(8, pb.h - 8 * rblk);          /* 4 or 8 */
+  {
+    uint32_t* po = p.pb_of + (size_t)(y0 >> 2) * p.w4 + (x0 >> 2);
+    po[0] = (job & 0x1FFFFFFu) + 1;
+    if (rows > 4) po[p.w4] = (job & 0x1FFFFFFu) + 1;
+  }
+  const bool mc0 = pb.flags & M355_PBF_MC_L0;
+  const bool bi = WEIGHTED ? (mc0 && (pb.flags & M355_PBF_MC_L1)) : bi_u;
+  const int npass = bi ? 2 : 1;
+  const bool a1 = !mc0;
+  const int refA = a1 ? pb.ref_slot[1] : pb.ref_slot[0], mvxA = a1 ? pb.mv[1][0] : pb.mv[0][0], mvyA = a1 ? pb.mv[1][1] : pb.mv[0][1];
+  const bool fillA = pb.flags & (a1 ? M355_PBF_FILL_L1 : M355_PBF_FILL_L0), fillB = pb.flags & M355_PBF_FILL_L1;
+  const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
+  const int nc = p.pp.chroma_format_idc ? 3 : 1;
+  const bool fused = p.res_map != nullptr;           /* (kernel argument: a scalar branch) */
+
+  /* weights of component c as the one formula of d_wpred (WEIGHTED jobs only; see d_inter_job) */
+  auto make_ws = [&](int c, int bd) {
+    WtSel ws;
+    const m355_wt wa = p.wts[wtA], wb = p.wts[wtB];
+    const int o0 = c == 0 ? wa.o[0] : (c == 1 ? wa.o[1] : wa.o[2]), o1 = c == 0 ? wb.o[0] : (c == 1 ? wb.o[1] : wb.o[2]);
+    const int log2WD = c ? wa.log2wd_chroma : wa.log2wd_luma;
+    ws.w0 = c == 0 ? wa.w[0] : (c == 1 ? wa.w[1] : wa.w[2]);
+    ws.w1 = bi ? (c == 0 ? wb.w[0] : (c == 1 ? wb.w[1] : wb.w[2])) : 0;
+    ws.rnd = bi ? (int)((unsigned)(o0 + o1 + 1) << log2WD) : (1 << (log2WD - 1));
+    ws.sh = bi ? log2WD + 1 : log2WD;
+    ws.o = bi ? 0 : o0;
+    return ws;
+  };
+  /* packed write-back of one register pair (two samples) — put_unweighted_pred / put_weighted_pred_avg (fallback-motion.cc:33-84):
+       one list : clip((a + rnd3) >> shift3),      shift3 = 14 - bd
+       two lists: clip((a + b + rnd2) >> shift2),  shift2 = 15 - bd
+     in SATURATING signed 16-bit arithmetic: a sum that leaves int16 is clipped by the reference as well (32767 >> shift2 is exactly the
+     largest sample value, 32767 >> shift3 lies above it; -32768 >> s is negative), so the saturated sum gives the same sample. */
+  auto pk_pred = [&](unsigned a, unsigned b, unsigned rnd, int sh, unsigned maxv) {
+    unsigned t = bi ? d_pk_addsat_i16(a, b) : b;
+    t = d_pk_ashr16(d_pk_addsat_i16(t, rnd), sh);
+    t = d_pk_max_i16(t, 0u);
+    return bi ? t : d_pk_min_i16(t, maxv);
+  };
+
+  /* ---- luma ---- */
+  {
+    const int bd = sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_luma;
+    unsigned pa[8][2];
+#pragma unroll
+    for (int y = 0; y < 8; y++) { pa[y][0] = 0; pa[y][1] = 0; }
+#pragma unroll 1
+    for (int pass = 0; pass < npass; pass++) {
+      unsigned cur[8][2];
+      if (pass ? fillB : fillA) {        /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
+#pragma unroll
+        for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
+      } else {
+        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+        d_mc_luma_lean<PIX>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, cur);
+      }
+      if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
+#pragma unroll
+        for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
+        continue;
+      }
+      M355_COMPILER_FENCE();          /* the residual / weight loads must not be hoisted into the filter loops */
+      PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
+      /* fused residual (k_common.h res_map): the residual rows of the job's two units (4 int16 each; tile pitch nT), added as
+         add_residual does (fallback-dct.h:65-73) */
+      unsigned rs[8][2];
+#pragma unroll
+      for (int y = 0; y < 8; y++) { rs[y][0] = 0; rs[y][1] = 0; }
+      if (fused) {
+        const uint32_t* m = p.res_map + (size_t)(y0 >> 2) * p.res_map_w[0] + (x0 >> 2);
+        const uint32_t e0 = m[0], e1 = rows > 4 ? m[p.res_map_w[0]] : 0u;
+        if (e0 >> 31) {
+          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e0 & 0x0FFFFFFFu) << 2);
+          const int nt = 4 << ((e0 >> 28) & 3);
+#pragma unroll
+          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[y]);
+        }
+        if (e1 >> 31) {
+          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e1 & 0x0FFFFFFFu) << 2);
+          const int nt = 4 << ((e1 >> 28) & 3);
+#pragma unroll
+          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[4 + y]);
+        }
+      }
+      if (WEIGHTED) {
+        const WtSel ws = make_ws(0, bd);
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          if (y >= rows) break;
+          unsigned o[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
+            o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
+            o[x] = (unsigned)d_clip_bd((int)o[x] + ((x & 1) ? d_hi16s(rs[y][x >> 1]) : d_lo16s(rs[y][x >> 1])), bd);
+          }
+          if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+          else d_st_nt4(d + (size_t)y * p.stride[0], o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24));
+        }
+      } else {
+        const int sh = (bi ? 15 : 14) - bd;
+        const unsigned rnd = (1u << (sh - 1)) * 0x10001u, maxv = ((1u << bd) - 1u) * 0x10001u;
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          if (y >= rows) break;
+          unsigned o0 = pk_pred(pa[y][0], cur[y][0], rnd, sh, maxv), o1 = pk_pred(pa[y][1], cur[y][1], rnd, sh, maxv);
+          if (fused) {
+            o0 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o0, rs[y][0]), 0u), maxv);
+            o1 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o1, rs[y][1]), 0u), maxv);
+          }
+          /* streaming stores (k_asm.h): -4 % kernel time, -10 % fabric fetch (profiles/r02_b_inter_variants.txt) */
+          if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o0, o1);
+          else d_st_nt4(d + (size_t)y * p.stride[0], d_pack_bytes(o0, o1));
+        }
+      }
+    }
+  }
+  if (nc == 1) return;
+
+  /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are in flight together;
+     chroma mv = luma mv in 1/8 pel (motion.cc:196-203) ---- */
+  {
+    const int bd = sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_chroma;
+    const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
+    unsigned pa1[4], pa2[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) { pa1[y] = 0; pa2[y] = 0; }
+#pragma unroll 1
+    for (int pass = 0; pass < npass; pass++) {
+      unsigned cur1[4], cur2[4];
+      if (pass ? fillB : fillA) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) { cur1[y] = 0x20002000u; cur2[y] = 0x20002000u; }
+      } else {
+        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+        d_mc_chroma_lean<PIX>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, cur1);
+        d_mc_chroma_lean<PIX>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, cur2);
+      }
+      if (pass + 1 < npass) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
+        continue;
+      }
+      M355_COMPILER_FENCE();
+      PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
+      PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
+      /* residual: the job's 2 x crows piece of each plane, unit-local position (xc & 3, yc & 3); a job that starts on an odd multiple
+         of 4 (PBs of asymmetric partitions) reaches two rows into the unit below */
+      unsigned rc1[4], rc2[4];
+#pragma unroll
+      for (int y = 0; y < 4; y++) { rc1[y] = 0; rc2[y] = 0; }
+      if (fused) {
+        const size_t cu = (size_t)(y0 >> 3) * p.res_map_w[1] + (x0 >> 3);
+        uint32_t ec1 = p.res_map[p.res_map_ofs[1] + cu], ec2 = p.res_map[p.res_map_ofs[2] + cu], ec1b = 0, ec2b = 0;
+        if (((y0 >> 1) & 3) + (rows >> 1) > 4) {
+          ec1b = p.res_map[p.res_map_ofs[1] + cu + p.res_map_w[1]];
+          ec2b = p.res_map[p.res_map_ofs[2] + cu + p.res_map_w[1]];
+        }
+        if ((ec1 | ec2 | ec1b | ec2b) >> 31) {
+          const int ly = yc & 3;
+          auto piece = [&](uint32_t ea, uint32_t eb, unsigned* rc) {
+            const int nta = 4 << ((ea >> 28) & 3), ntb = 4 << ((eb >> 28) & 3);
+            const M355_GLOBAL int16_t* ra = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(ea & 0x0FFFFFFFu) << 2) + (xc & 3);
+            const M355_GLOBAL int16_t* rb = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(eb & 0x0FFFFFFFu) << 2) + (xc & 3);
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+              if (y >= crows) break;
+              const int l = ly + y;
+              if (l < 4) { if (ea >> 31) rc[y] = d_ldg4(ra + l * nta); }
+              else if (eb >> 31) rc[y] = d_ldg4(rb + (l - 4) * ntb);
+            }
+          };
+          piece(ec1, ec1b, rc1);
+          piece(ec2, ec2b, rc2);
+        }
+      }
+      if (WEIGHTED) {
+        const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          if (y >= crows) break;
+          {
+            const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
+            const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc1[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc1[y]), bd);
+            if (sizeof(PIX) == 2) d_st_nt4(d1 + (size_t)y * p.stride[1], o0 | (o1 << 16));
+            else *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)(o0 | (o1 << 8));
+          }
+          {
+            const unsigned a = bi ? pa2[y] : cur2[y], b = cur2[y];
+            const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc2[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc2[y]), bd);
+            if (sizeof(PIX) == 2) d_st_nt4(d2 + (size_t)y * p.stride[2], o0 | (o1 << 16));
+            else *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)(o0 | (o1 << 8));
+          }
+        }
+      } else {
+        const int sh = (bi ? 15 : 14) - bd;
+        const unsigned rnd = (1u << (sh - 1)) * 0x10001u, maxv = ((1u << bd) - 1u) * 0x10001u;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          if (y >= crows) break;
+          unsigned o1 = pk_pred(pa1[y], cur1[y], rnd, sh, maxv), o2 = pk_pred(pa2[y], cur2[y], rnd, sh, maxv);
+          if (fused) {
+            o1 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o1, rc1[y]), 0u), maxv);
+            o2 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o2, rc2[y]), 0u), maxv);
+          }
+          if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
+          else {
+            *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
+            *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <class PIX, bool BIAS, bool LEAN>
 static void launch_jobs(const DevPic& p, hipStream_t st)
 {
   /* each range's blocks are padded to a multiple of 8 for the XCD-contiguous block order; the counts are on the device, so the
      grid covers the most jobs the list can hold */
-  const unsigned grid = (unsigned)((p.jobs_cap + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK) + 3 * 8;
-  /* M355_INTER_LDS_PAD=<bytes> (experiment): dynamic LDS nobody uses, to cap the workgroups per CU — k_inter_jobs fills the register
-     file of every SIMD it runs on (3 waves x 168 VGPRs), so kernels of the other pictures in flight only get what it leaves */
-  static const unsigned pad = getenv("M355_INTER_LDS_PAD") ? (unsigned)atoi(getenv("M355_INTER_LDS_PAD")) : 0u;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS>), dim3(grid), dim3(M355_INTER_BLOCK), pad, st, p);
+  const unsigned grid = (unsigned)((p.jobs_cap + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK) + 4 * 8;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS, LEAN>), dim3(grid), dim3(M355_INTER_BLOCK), 0, st, p);
 }
 
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
 {
   if (!p.n_pbs) return;
   if (p.pp.chroma_format_idc <= 1) {
-    if (!hbd) launch_jobs<uint8_t, false>(p, st);
-    else if (p.pp.bit_depth_luma == 16 || p.pp.bit_depth_chroma == 16) launch_jobs<uint16_t, true>(p, st);
-    else launch_jobs<uint16_t, false>(p, st);
+    const int bdmax = max(p.pp.bit_depth_luma, p.pp.bit_depth_chroma);
+    if (!hbd) launch_jobs<uint8_t, false, true>(p, st);
+    else if (bdmax <= 12) launch_jobs<uint16_t, false, true>(p, st);            /* the lean filters (folds exact for bit depths <= 12) */
+    else if (bdmax == 16) launch_jobs<uint16_t, true, false>(p, st);
+    else launch_jobs<uint16_t, false, false>(p, st);
     return;
   }
   const dim3 grid((p.n_pbs + 3) / 4), block(256);

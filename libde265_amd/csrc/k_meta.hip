@@ -82,6 +82,14 @@ __device__ __forceinline__ int d_pb_jobs(const m355_pb& pb)
   if (pb.w < 4 || pb.h < 4 || pb.w > 64 || pb.h > 64 || (pb.w & 3) || (pb.h & 3)) return 0;
   return (pb.w >> 2) * ((pb.h + 7) >> 3);
 }
+/* job class of a PB (= the range of the job list its jobs go to, k_inter_jobs): 0 one list, 1 two lists, 2 explicit weights,
+   3 EDGE = a reference window leaves the picture (coordinate-clamped loads) */
+__device__ __forceinline__ int d_pb_class(const DevPic& p, const m355_pb& pb)
+{
+  if (m355_pb_is_edge(pb, p.pp.width, p.pp.height, p.pp.chroma_format_idc)) return 3;
+  if (pb.flags & M355_PBF_WEIGHTED) return 2;
+  return ((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0;
+}
 /* 16-byte units of edge_tu | edge_pb | cb_cu (prepare() in runtime.hip: cb_cu starts at the next multiple of 64, 64 spare bytes behind) */
 __host__ __device__ static inline size_t d_meta_fill16(const DevPic& p) { return ((((size_t)2 * p.w4 * p.h4 + 63) & ~(size_t)63) + (size_t)p.wcb * p.hcb * 4 + 15) / 16; }
 /* clear_planes: the launch also zero-fills the metadata planes (edge_tu | edge_pb | cb_cu) that k_meta_planes scatters into — it is the
@@ -97,22 +105,26 @@ __global__ void __launch_bounds__(256) k_job_count(DevPic p, int clear_planes)
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) q[k] = make_uint4(0, 0, 0, 0);
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
-  int cnt[3] = {0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0};
   if (i < p.n_pbs) {
     const m355_pb pb = p.pbs[i];
-    const int cls = m355_pb_is_edge(pb, p.pp.width, p.pp.chroma_format_idc) ? 2 : (((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0);
+    const int cls = d_pb_class(p, pb);
     const int n = d_pb_jobs(pb);
-    cnt[0] = cls == 0 ? n : 0; cnt[1] = cls == 1 ? n : 0; cnt[2] = cls == 2 ? n : 0;
-  }
-  __shared__ int s_w[4][3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) cnt[k] = cls == k ? n : 0;
+  }
+  __shared__ int s_w[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cnt[k] += __shfl_xor(cnt[k], d, 64);
   }
-  if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6][0] = cnt[0]; s_w[threadIdx.x >> 6][1] = cnt[1]; s_w[threadIdx.x >> 6][2] = cnt[2]; }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_w[threadIdx.x >> 6][k] = cnt[k];
+  }
   __syncthreads();
-  if (threadIdx.x < 3) p.job_base[blockIdx.x * 3 + threadIdx.x] = (uint32_t)(s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x]);
+  if (threadIdx.x < 4) p.job_base[blockIdx.x * 4 + threadIdx.x] = (uint32_t)(s_w[0][threadIdx.x] + s_w[1][threadIdx.x] + s_w[2][threadIdx.x] + s_w[3][threadIdx.x]);
 }
 /* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) and the job list of
  * k_inter_jobs: (w/4) x ceil(h/8) jobs per PB, row block major so consecutive jobs are horizontally
@@ -127,60 +139,65 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   if (active) pb = p.pbs[i]; else { pb.x = pb.y = 0; pb.w = pb.h = 0; pb.flags = 0; }
   const int ns = pb.w >> 2;
   const int njobs = active ? d_pb_jobs(pb) : 0;              /* (as k_job_count counted it) */
-  /* three ranges: one-list jobs, bi-predicted jobs (so a wave never idles through a second pass it does
-     not need), edge jobs; wave-level exclusive scans, one atomic per wave and range */
-  const bool edge = active && m355_pb_is_edge(pb, p.pp.width, p.pp.chroma_format_idc);
-  const bool bi = (pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1);
-  const int cls = !active ? 3 : (edge ? 2 : (bi ? 1 : 0));
-  int incl[3] = {cls == 0 ? njobs : 0, cls == 1 ? njobs : 0, cls == 2 ? njobs : 0};
+  /* four ranges: one-list jobs, bi-predicted jobs (so a wave never idles through a second pass it does not need), explicitly weighted
+     jobs, edge jobs; wave-level exclusive scans */
+  const int cls = !active ? 4 : d_pb_class(p, pb);
+  int incl[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) incl[k] = cls == k ? njobs : 0;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) { const int t = __shfl_up(incl[k], (unsigned)d, 64); if (lane >= d) incl[k] += t; }
+    for (int k = 0; k < 4; k++) { const int t = __shfl_up(incl[k], (unsigned)d, 64); if (lane >= d) incl[k] += t; }
   }
-  /* first job of this wave per range = the chunk's base (prefix sums computed by the host while it
-     validates the PB list — no atomics, and the job list is in PB order: deterministic and spatially
-     coherent) + the totals of the workgroup's earlier waves */
-  __shared__ int s_wtot[4][3];
+  /* first job of this wave per range = the chunk's base + the totals of the workgroup's earlier waves (no atomics: the job list is
+     in PB order, deterministic and spatially coherent) */
+  __shared__ int s_wtot[4][4];
   const int wave = threadIdx.x >> 6;
-  if (lane == 63) { s_wtot[wave][0] = incl[0]; s_wtot[wave][1] = incl[1]; s_wtot[wave][2] = incl[2]; }
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_wtot[wave][k] = incl[k];
+  }
   __syncthreads();
   /* the chunk's first job per range: sum of the counts (k_job_count) of the chunks before it + where the range starts */
-  __shared__ uint32_t s_red[4][6];
+  __shared__ uint32_t s_red[4][8];
   {
-    uint32_t acc[6] = {0, 0, 0, 0, 0, 0};                    /* [0..2] all chunks, [3..5] the chunks in front of this one */
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};              /* [0..3] all chunks, [4..7] the chunks in front of this one */
     for (int ch = (int)threadIdx.x; ch < (int)gridDim.x; ch += 256) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const uint32_t n = p.job_base[ch * 3 + k];
+      for (int k = 0; k < 4; k++) {
+        const uint32_t n = p.job_base[ch * 4 + k];
         acc[k] += n;
-        acc[3 + k] += ch < (int)blockIdx.x ? n : 0u;
+        acc[4 + k] += ch < (int)blockIdx.x ? n : 0u;
       }
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < 8; k++) {
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) acc[k] += (uint32_t)__shfl_xor((int)acc[k], d, 64);
     }
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) s_red[wave][k] = acc[k];
+      for (int k = 0; k < 8; k++) s_red[wave][k] = acc[k];
     }
   }
   __syncthreads();
-  uint32_t base[3];
+  uint32_t base[4];
   {
-    uint32_t tot[6];
+    uint32_t tot[8];
 #pragma unroll
-    for (int k = 0; k < 6; k++) tot[k] = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
-    const uint32_t nu = tot[0], nb = tot[1], ne = tot[2];
-    base[0] = tot[3]; base[1] = nu + tot[4]; base[2] = nu + nb + tot[5];
+    for (int k = 0; k < 8; k++) tot[k] = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
+    uint32_t start = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { base[k] = start + tot[4 + k]; start += tot[k]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       const uint32_t cap = p.jobs_cap;
-      p.job_tot[0] = min(nu, cap); p.job_tot[1] = min(nu + nb, cap); p.job_tot[2] = min(nu + nb + ne, cap);
+      uint32_t end = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { end += tot[k]; p.job_tot[k] = min(end, cap); }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
       for (int w = 0; w < wave; w++) base[k] += (uint32_t)s_wtot[w][k];
   }
   /* emit the wave's jobs cooperatively: slot t of the wave's total belongs to the PB found by a binary
@@ -191,8 +208,9 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl_all, (unsigned)d, 64); if (lane >= d) incl_all += t; }
   const int total = __shfl(incl_all, 63, 64);
   const int excl_all = incl_all - njobs;
-  const uint32_t dst0 = cls == 0 ? base[0] + (uint32_t)(incl[0] - njobs)
-                      : (cls == 1 ? base[1] + (uint32_t)(incl[1] - njobs) : base[2] + (uint32_t)(incl[2] - njobs));
+  uint32_t dst0 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) dst0 = cls == k ? base[k] + (uint32_t)(incl[k] - njobs) : dst0;
   for (int t0 = 0; t0 < total; t0 += 64) {
     const int t = t0 + lane;
     int k = 0;

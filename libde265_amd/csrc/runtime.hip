@@ -1764,8 +1764,8 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
     const size_t cap = pic.n_pbs > 0 ? std::min(area / 16, area / 32 + 8 * (size_t)pic.n_pbs) + 256 : 1;
     const size_t n_chunks = ((size_t)(pic.n_pbs > 0 ? pic.n_pbs : 0) + 255) / 256;
     if ((rc = grow(&c->jobs, &c->cap_jobs, cap, c->stream, false))) return rc;
-    if ((rc = grow(&c->job_base, &c->cap_jobbase, n_chunks * 3 + 8, c->stream, true))) return rc;
-    d.jobs_cap = (uint32_t)cap; d.job_base = c->job_base; d.job_tot = c->job_base + n_chunks * 3;
+    if ((rc = grow(&c->job_base, &c->cap_jobbase, n_chunks * 4 + 8, c->stream, true))) return rc;
+    d.jobs_cap = (uint32_t)cap; d.job_base = c->job_base; d.job_tot = c->job_base + n_chunks * 4;
   }
   if ((rc = grow(&c->iplan, &c->cap_iplan, (size_t)r.n_iplan + 8, c->stream, false))) return rc;
 
