@@ -25,6 +25,10 @@ __device__ __forceinline__ void d_st_nt8(void* p, unsigned v0, unsigned v1) { __
  * between them — hipcc otherwise selects the ADDRESS and loads one of them later, behind whatever is in flight */
 #define M355_PIN_V(x) asm volatile("" : "+v"(x))
 
+/* four results pinned where they stand + a compiler memory barrier: the arithmetic that makes them cannot sink below this point and no
+ * load behind it can be hoisted above it (k_inter_jobs' software pipeline) */
+#define M355_PIN_V4_MEM(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
+
 /* spin bound of k_intra's granule polls: ~2^22 polls x (one L2 round trip + s_sleep) is seconds — far beyond any real wait */
 #define M355_SPIN_LIMIT (1u << 22)
 

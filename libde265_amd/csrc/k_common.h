@@ -265,7 +265,7 @@ void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for
 void m355_launch_job_count(const DevPic& p, bool clear_planes, hipStream_t st);   /* ... its first launch, optionally with the zero fill of the metadata planes */
 void m355_launch_job_list(const DevPic& p, hipStream_t st);      /* ... the rest */
 void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared, bool with_tu = true);   /* planes for intra / deblock / SAO (cleared: k_job_count filled them; !with_tu: the transform edges come with m355_launch_tu_plan) */
-void m355_launch_tu_plan(const DevPic& p, hipStream_t st);         /* transform edges + border plans in ONE launch (M355_MERGE_TU_PLAN) */
+void m355_launch_tu_plan(const DevPic& p, hipStream_t st);         /* transform edges + border plans in ONE launch */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
@@ -283,7 +283,6 @@ void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pi
 void m355_launch_deblock(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_deblock_pass(const DevPic& p, bool hbd, bool vertical, hipStream_t st);   /* one direction (tile sharding) */
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st);
-void m355_launch_sao_dbh(const DevPic& p, bool hbd, hipStream_t st);   /* EXPERIMENTAL: k_deblock<H> + k_sao in one pass (M355_FUSE_DBH) */
 /* tile sharding: `which` bit 0 = column strips, bit 1 = row strips; meta = border-unit records (16 B each) */
 void m355_launch_halo_pack(const DevPic& p, const HaloLayout& h, bool hbd, int which, void* samples, uint32_t* meta, hipStream_t st);
 /* buf[i] += sum over the n received copies scratch[k * pitch_words + i] (halo exchange of m355_decode_sharded over RCCL) */

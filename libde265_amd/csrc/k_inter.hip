@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) k_inter_generic(DevPic p)
  *   qpel[f] : E0..E3 = (t0,t1)(t2,t3)(t4,t5)(t6,t7) ; O0..O4 = (0,t0)(t1,t2)(t3,t4)(t5,t6)(t7,0)
  *   epel[f] : E0..E1 = (c0,c1)(c2,c3)               ; O0..O2 = (0,c0)(c1,c2)(c3,0)            */
 #ifndef M355_INTER_WAVES
-#define M355_INTER_WAVES 3   /* waves per SIMD the register budget is sized for (tools/variants.sh sweeps it) */
+#define M355_INTER_WAVES 4   /* waves per SIMD the register budget is sized for (tools/variants.sh sweeps it) */
 #endif
 #ifndef M355_INTER_BLOCK
 #define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
@@ -547,6 +547,9 @@ __device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
  *    + 128 * 64 in the accumulator): 11 dot4 per luma row instead of 12 unpacks + 18 dot2.
  *  * No coordinate clamps: address = first row + r * pitch.
  * ============================================================================================== */
+#ifndef M355_INTER_PIPE
+#define M355_INTER_PIPE 1   /* luma window rows: 0 = all 15 requested at once (hipcc's own order), D = D row pairs ahead of the arithmetic */
+#endif
 #define QL_STRIDE 12   /* 16-bit planes: [xf][d][12] = T0[5] T1[5] (2 spare);  8-bit planes: [xf][12] = W[j][3], j = output column */
 #define CL_STRIDE 8    /* 16-bit planes: [xf][d][8]  = U0[3] U1[3] (2 spare);  8-bit planes: [xf][4]  = C0 C1 C2 (1 spare) */
 __device__ __forceinline__ int d_qtap(int f, int i)   /* c_qpel_taps[f][i] from immediates (no constant-memory round trip in the prologue) */
@@ -617,28 +620,34 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
 {
   const int xa = xi - 3;
   unsigned Q[8][4];
+  constexpr int DEPTH = M355_INTER_PIPE ? M355_INTER_PIPE : 1, NB = DEPTH + 1;   /* row pairs requested ahead of the one being filtered */
   if (sizeof(PIX) == 2) {
     const unsigned* tl = s_ql + (xf * 2 + (xa & 1)) * QL_STRIDE;
     unsigned T0[5], T1[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { T0[k] = tl[k]; T1[k] = tl[5 + k]; }
     const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 3) * rstride + (xa & ~1);
-    unsigned S[2][2][6];
-    d_ldg16(q, S[0][0]); d_ldg8(q + 8, S[0][0] + 4); q += rstride;
-    d_ldg16(q, S[0][1]); d_ldg8(q + 8, S[0][1] + 4); q += rstride;
+    unsigned S[NB][2][6];
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) {
+      d_ldg16(q, S[k][0]); d_ldg8(q + 8, S[k][0] + 4); q += rstride;
+      d_ldg16(q, S[k][1]); d_ldg8(q + 8, S[k][1] + 4); q += rstride;
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      /* rows are fetched one pair ahead of the pair being filtered (the scheduling barriers keep hipcc from hoisting all 15 rows) */
-      if (k < 7) {
-        d_ldg16(q, S[(k + 1) & 1][0]); d_ldg8(q + 8, S[(k + 1) & 1][0] + 4); q += rstride;
-        if (k < 6) { d_ldg16(q, S[(k + 1) & 1][1]); d_ldg8(q + 8, S[(k + 1) & 1][1] + 4); q += rstride; }
+      /* the rows of pair k + DEPTH are requested before pair k is filtered; the pin behind a pair's arithmetic (a register
+         constraint on its results + a compiler memory barrier) is what holds the order: without it hipcc hoists all 15 rows of
+         loads to the top and filters behind one wait for everything — 90 registers of rows in flight and no overlap of a wave's
+         own loads with its own arithmetic */
+      if (k + DEPTH < 8) {
+        d_ldg16(q, S[(k + DEPTH) % NB][0]); d_ldg8(q + 8, S[(k + DEPTH) % NB][0] + 4); q += rstride;
+        if (k + DEPTH < 7) { d_ldg16(q, S[(k + DEPTH) % NB][1]); d_ldg8(q + 8, S[(k + DEPTH) % NB][1] + 4); q += rstride; }
       }
-      __builtin_amdgcn_sched_barrier(0);
       int h[2][4];
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }   /* row 15 is never read with a non-zero tap */
-        const unsigned* E = S[k & 1][r];
+        const unsigned* E = S[k % NB][r];
         h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2(E[0], T0[0], 0)))));
         h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2(E[0], T1[0], 0)))));
         h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2(E[1], T0[0], 0)))));
@@ -646,7 +655,7 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) Q[k][j] = d_pack_mid16((unsigned)h[0][j], (unsigned)h[1][j]);
-      __builtin_amdgcn_sched_barrier(0);
+      if (M355_INTER_PIPE) M355_PIN_V4_MEM(Q[k][0], Q[k][1], Q[k][2], Q[k][3]);
     }
   } else {
     const unsigned* tl = s_ql + xf * QL_STRIDE;
@@ -655,21 +664,23 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
     for (int j = 0; j < 4; j++) { W[j][0] = tl[3 * j]; W[j][1] = tl[3 * j + 1]; W[j][2] = tl[3 * j + 2]; }
     const unsigned sh = (unsigned)xa & 3u;
     const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 3) * rstride + (xa & ~3);
-    unsigned S[2][2][4];
-    d_ldg16(q, S[0][0]); q += rstride;
-    d_ldg16(q, S[0][1]); q += rstride;
+    unsigned S[NB][2][4];
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) {
+      d_ldg16(q, S[k][0]); q += rstride;
+      d_ldg16(q, S[k][1]); q += rstride;
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      if (k < 7) {
-        d_ldg16(q, S[(k + 1) & 1][0]); q += rstride;
-        if (k < 6) { d_ldg16(q, S[(k + 1) & 1][1]); q += rstride; }
+      if (k + DEPTH < 8) {
+        d_ldg16(q, S[(k + DEPTH) % NB][0]); q += rstride;
+        if (k + DEPTH < 7) { d_ldg16(q, S[(k + DEPTH) % NB][1]); q += rstride; }
       }
-      __builtin_amdgcn_sched_barrier(0);
       int h[2][4];
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }
-        const unsigned* E = S[k & 1][r];
+        const unsigned* E = S[k % NB][r];
         unsigned A[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) A[i] = __builtin_amdgcn_alignbyte(E[i + 1], E[i], sh) ^ 0x80808080u;
@@ -679,7 +690,7 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) Q[k][j] = d_pack_lo16((unsigned)h[0][j], (unsigned)h[1][j]);
-      __builtin_amdgcn_sched_barrier(0);
+      if (M355_INTER_PIPE) M355_PIN_V4_MEM(Q[k][0], Q[k][1], Q[k][2], Q[k][3]);
     }
   }
   const unsigned* ty = s_qv + yf * QT_STRIDE;
@@ -1313,8 +1324,13 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
   if (!p.n_pbs) return;
   if (p.pp.chroma_format_idc <= 1) {
     const int bdmax = max(p.pp.bit_depth_luma, p.pp.bit_depth_chroma);
+#ifdef M355_INTER_NO_LEAN                     /* A/B builds (tools/variants.sh): every class through the general filters */
+    if (!hbd) launch_jobs<uint8_t, false, false>(p, st);
+    else if (bdmax < 16) launch_jobs<uint16_t, false, false>(p, st);
+#else
     if (!hbd) launch_jobs<uint8_t, false, true>(p, st);
     else if (bdmax <= 12) launch_jobs<uint16_t, false, true>(p, st);            /* the lean filters (folds exact for bit depths <= 12) */
+#endif
     else if (bdmax == 16) launch_jobs<uint16_t, true, false>(p, st);
     else launch_jobs<uint16_t, false, false>(p, st);
     return;

@@ -15,7 +15,6 @@
  */
 #include <algorithm>
 #include "k_common.h"
-#include "k_deblock_dev.h"
 
 template <class PIX> struct Vec4;
 template <> struct Vec4<uint8_t> { typedef uint32_t T; };
@@ -98,147 +97,7 @@ __device__ __forceinline__ uint32_t d_sao_edge_idx(uint32_t c, uint32_t a, uint3
   return d_pk_add16(d_pk_add16(s1, s2), 0x00020002u);
 }
 
-
-/* ---- EXPERIMENTAL, off by default (M355_FUSE_DBH=1): the HORIZONTAL-edge deblocking pass inside this kernel ----
- * The wave tile is shifted up by four rows (rows 16*by - 4 .. 16*by + 11): its four lane rows are then the P side / Q side of the
- * horizontal edge at 16*by and the P / Q side of the edge at 16*by + 8 — both edges with their whole reach (3 modified + 1 read
- * sample on each side, deblock.cc:412-605) inside the tile, and the rows SAO looks at above and below the tile (16*by - 5 and
- * 16*by + 12) are the q3 / p3 rows of the neighbouring edges, which the pass never modifies.  The lanes 16 apart that hold the two
- * sides of an edge segment swap their rows, BOTH derive the decisions (as k_deblock_body<PIX, false>, k_deblock.hip) and each
- * filters its own side (the filters are symmetric up to the sign of delta); the working planes are only read (k_deblock<V> wrote them), the H-filtered samples exist in registers
- * alone on their way to the SAO output.  Left and right of the tile SAO needs one filtered column each: the outer lanes run the
- * same function a second time on the neighbouring 4x4 blocks (A = their rows).  Saves one pass over the picture (read + write of
- * every filtered row) and one launch; not used for tile-sharded pictures (the exchange between the passes) or batches.
- * A[1..4] = the rows of the 4x4 block at (xb, .) of component c, in / out; yE = the edge row (component samples) between the pair;
- * isQ = this lane holds the Q side; act = the lane has a block at all.  All lanes of the wave call both functions together. */
-struct DbhIdx { uint32_t ciQ, ciP, ip, iq; int ef, efo, slice_idx; bool flagged; };
-/* round trip 1 of an edge segment (clamped addresses, no branch in front of a load): edge flags, CU / PB indices of both sides, the
-   CTB's slice — requested for the tile's own segments and the rim's together, beside the sample rows */
-__device__ __forceinline__ DbhIdx d_dbh_fetch(const DevPic& p, const int c, const bool act, const int xb, const int yE)
-{
-  const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
-  const bool cand = act && yE > 0 && yE < p.ph[c] && xb >= 0 && xb < p.pw[c];
-  const int xDi = cand ? (xb << csw) : 0, yDi = cand ? (yE << csh) : 4;
-  const int u = (yDi >> 2) * p.w4 + (xDi >> 2), uo = u - p.w4;
-  DbhIdx m;
-  m.ciQ = d_cu_index_at(p, xDi, yDi); m.ciP = d_cu_index_at(p, xDi, yDi - 1);
-  m.ef = p.edge_tu[u] | p.edge_pb[u]; m.efo = p.edge_tu[uo];
-  m.ip = p.pb_of[uo]; m.iq = p.pb_of[u];
-  m.slice_idx = p.ctbs[d_ctb_of(p, xDi, yDi)].slice_idx;
-  m.flagged = cand && (m.ef & (E_TU_H | E_PB_H));
-  return m;
-}
-/* RIM: the block is a rim block, of which SAO reads ONE column (line `rim_line`: 3 of the block on the left, 0 of the one on the right) —
-   the decisions still come from lines 0 and 3, but only that line is filtered (the run issues for an eighth of the lanes) */
-template <class PIX, int NW, bool RIM = false>
-__device__ __forceinline__ void d_dbh_block(const DevPic& p, const int c, const DbhIdx& m, const bool isQ, uint32_t (&A)[6][NW], const int rim_line = 0)
-{
-  const uint32_t ciQ = m.ciQ, ciP = m.ciP, ip = m.ip, iq = m.iq;
-  const int ef = m.ef, efo = m.efo, slice_idx = m.slice_idx;
-  const bool flagged = m.flagged;
-  if (!__any((int)flagged)) return;                        /* wave-uniform */
-  /* the other side's rows (lane ^ 16 holds the same columns) */
-  uint32_t B[5][NW];
-#pragma unroll
-  for (int r = 1; r <= 4; r++)
-#pragma unroll
-    for (int k = 0; k < NW; k++) B[r][k] = (uint32_t)__shfl_xor((int)A[r][k], 16, 64);
-  /* round trip 2: the records (an absent one reads the CTB table instead: always there, never used) */
-  const bool pb_ok = ip && iq && ip <= (uint32_t)p.n_pb_records && iq <= (uint32_t)p.n_pb_records;
-  const m355_cu cuQ = *(ciQ ? p.cus + (ciQ - 1) : (const m355_cu*)p.ctbs), cuP = *(ciP ? p.cus + (ciP - 1) : (const m355_cu*)p.ctbs);
-  const m355_pb PA = *(pb_ok ? p.pbs + (ip - 1) : (const m355_pb*)p.ctbs), PB = *(pb_ok ? p.pbs + (iq - 1) : (const m355_pb*)p.ctbs);
-  const m355_slice sh = p.slices[slice_idx];
-  CuInfo Q = {0, 0, 0, 0}, P = {0, 0, 0, 0};
-  if (ciQ) { Q.pred_mode = cuQ.pred_mode; Q.qp = cuQ.qp_y; Q.pcm = (cuQ.flags & M355_CUF_PCM) != 0; Q.bypass = (cuQ.flags & M355_CUF_TRANSQUANT_BYPASS) != 0; }
-  if (ciP) { P.pred_mode = cuP.pred_mode; P.qp = cuP.qp_y; P.pcm = (cuP.flags & M355_CUF_PCM) != 0; P.bypass = (cuP.flags & M355_CUF_TRANSQUANT_BYPASS) != 0; }
-  const int bS = flagged ? d_boundary_strength(ef, efo, false, P, Q, pb_ok, PA, PB) : 0;
-  if (bS == 0) return;                                     /* (no cross-lane operation below) */
-  const bool plf = (p.pp.flags & M355_PF_PCM_LOOP_FILTER_DISABLE) != 0;
-  const bool filterP = !((plf && P.pcm) || P.bypass), filterQ = !((plf && Q.pcm) || Q.bypass);
-  const int qP_L = (Q.qp + P.qp + 1) >> 1;
-  /* Both filters are symmetric in their two sides up to the sign of delta, so a lane computes ITS side only: mr[i] / orow[i] = the
-     row at distance i from the edge on this lane's side / on the other side (its four samples are the segment's four lines);
-     s = +1 on the Q side: q - p = s * (mine - other) */
-  const bool filterM = isQ ? filterQ : filterP;
-  if (!filterM) return;                                    /* pcm + pcm_loop_filter_disable / bypass: this side stays */
-  Raw4<PIX> mr[4], orow[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int k = 0; k < NW; k++) { mr[i].w[k] = isQ ? A[1 + i][k] : A[4 - i][k]; orow[i].w[k] = isQ ? B[4 - i][k] : B[1 + i][k]; }
-#define MV(k, i) d_get<PIX>(mr[i], k)
-#define OV(k, i) d_get<PIX>(orow[i], k)
-/* (RIM: the one line is line 3 or line 0, per lane) */
-#define RMV(k, i) (RIM ? (rim_line ? MV(3, i) : MV(0, i)) : MV(k, i))
-#define ROV(k, i) (RIM ? (rim_line ? OV(3, i) : OV(0, i)) : OV(k, i))
-#define SETM(k, i, v) do { if (RIM) { const int v_ = (v); Raw4<PIX> a_ = mr[i], b_ = mr[i]; d_set<PIX>(a_, 3, v_); d_set<PIX>(b_, 0, v_); mr[i] = rim_line ? a_ : b_; } else d_set<PIX>(mr[i], k, v); } while (0)
-  if (c == 0) {
-    /* ---- luma (deblock.cc:480-601, fallback-deblk.h:33-100) ---- */
-    const int bd = p.pp.bit_depth_luma;
-    /* (the beta table of deblock.cc:385-392 is piecewise linear: 0 below 16, Q - 10 up to 28, 2Q - 38 above — one dependent load less) */
-    const int bq = d_clip3(0, 51, qP_L + sh.beta_offset);
-    const int beta = (bq < 16 ? 0 : (bq <= 28 ? bq - 10 : 2 * bq - 38)) * (1 << (bd - 8));
-    const int tc = c_tab_tc[d_clip3(0, 53, qP_L + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
-    const int dm0 = d_abs(MV(0, 2) - 2 * MV(0, 1) + MV(0, 0)), dm3 = d_abs(MV(3, 2) - 2 * MV(3, 1) + MV(3, 0));
-    const int do0 = d_abs(OV(0, 2) - 2 * OV(0, 1) + OV(0, 0)), do3 = d_abs(OV(3, 2) - 2 * OV(3, 1) + OV(3, 0));
-    const int dpq0 = dm0 + do0, dpq3 = dm3 + do3, d = dpq0 + dpq3;
-    if (d >= beta) return;
-    const bool dSam0 = 2 * dpq0 < (beta >> 2) && d_abs(MV(0, 3) - MV(0, 0)) + d_abs(OV(0, 0) - OV(0, 3)) < (beta >> 3) &&
-                       d_abs(MV(0, 0) - OV(0, 0)) < ((5 * tc + 1) >> 1);
-    const bool dSam3 = 2 * dpq3 < (beta >> 2) && d_abs(MV(3, 3) - MV(3, 0)) + d_abs(OV(3, 0) - OV(3, 3)) < (beta >> 3) &&
-                       d_abs(MV(3, 0) - OV(3, 0)) < ((5 * tc + 1) >> 1);
-    const bool strong = dSam0 && dSam3;
-    const bool dEm = dm0 + dm3 < ((beta + (beta >> 1)) >> 3);          /* dEp on the P side, dEq on the Q side */
-#pragma unroll
-    for (int k = 0; k < (RIM ? 1 : 4); k++) {
-      const int m0 = RMV(k, 0), m1 = RMV(k, 1), m2 = RMV(k, 2), m3 = RMV(k, 3);
-      const int o0 = ROV(k, 0), o1 = ROV(k, 1);
-      if (strong) {
-        SETM(k, 0, d_clip3(m0 - 2 * tc, m0 + 2 * tc, (m2 + 2 * m1 + 2 * m0 + 2 * o0 + o1 + 4) >> 3));
-        SETM(k, 1, d_clip3(m1 - 2 * tc, m1 + 2 * tc, (m2 + m1 + m0 + o0 + 2) >> 2));
-        SETM(k, 2, d_clip3(m2 - 2 * tc, m2 + 2 * tc, (2 * m3 + 3 * m2 + m1 + m0 + o0 + 4) >> 3));
-      } else {
-        const int t = 9 * (m0 - o0) - 3 * (m1 - o1);                    /* s * (9 (q0 - p0) - 3 (q1 - p1)) */
-        int delta = ((isQ ? t : -t) + 8) >> 4;
-        if (d_abs(delta) < tc * 10) {
-          delta = d_clip3(-tc, tc, delta);
-          const int ds = isQ ? -delta : delta;                          /* p0 + delta, q0 - delta */
-          SETM(k, 0, d_clip_bd(m0 + ds, bd));
-          if (dEm) SETM(k, 1, d_clip_bd(m1 + d_clip3(-(tc >> 1), tc >> 1, (((m2 + m0 + 1) >> 1) - m1 + ds) >> 1), bd));
-        }
-      }
-    }
-  } else {
-    /* ---- chroma (deblock.cc:635-761): bS == 2 only; a chroma lane's block always lies on the 8-sample chroma grid's unit
-       (x4 a multiple of SubWidthC, y4 of 2 * SubHeightC: the tile rows are multiples of 4 and the edge rows multiples of 8) ---- */
-    if (bS < 2) return;
-    const int bd = p.pp.bit_depth_chroma;
-    const int qP_i = qP_L + (c == 1 ? p.pp.pic_cb_qp_offset : p.pp.pic_cr_qp_offset);
-    int QP_C;
-    if (p.pp.chroma_format_idc == 1) QP_C = qP_i < 30 ? qP_i : (qP_i >= 43 ? qP_i - 6 : c_qpc_420[qP_i - 30]);
-    else QP_C = min(qP_i, 51);
-    const int tc = c_tab_tc[d_clip3(0, 53, QP_C + 2 * (bS - 1) + sh.tc_offset)] * (1 << (bd - 8));
-#pragma unroll
-    for (int k = 0; k < (RIM ? 1 : 4); k++) {
-      const int m0 = RMV(k, 0), m1 = RMV(k, 1), o0 = ROV(k, 0), o1 = ROV(k, 1);
-      const int t = (m0 - o0) * 4 - (m1 - o1);                          /* s * ((q0 - p0) * 4 + p1 - q1) */
-      const int delta = d_clip3(-tc, tc, ((isQ ? t : -t) + 4) >> 3);
-      SETM(k, 0, d_clip_bd(m0 + (isQ ? -delta : delta), bd));
-    }
-  }
-#undef MV
-#undef OV
-#undef RMV
-#undef ROV
-#undef SETM
-  /* this lane's side goes back into its rows */
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int k = 0; k < NW; k++) { if (isQ) A[1 + i][k] = mr[i].w[k]; else A[4 - i][k] = mr[i].w[k]; }
-}
-
-template <class PIX, bool PACKED, bool DBH = false>
+template <class PIX, bool PACKED>
 __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const int bx, const int by)
 {
   M355_GATE(p);
@@ -251,10 +110,10 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   typedef typename Vec4<PIX>::T V4;
   const int lane = threadIdx.x & 63, lx = lane & 15, ly = lane >> 4;
   const int width = p.pw[c], height = p.ph[c];
-  const int xt = (bx * 4 + (int)(threadIdx.x >> 6)) * 64, yt = DBH ? by * 16 - 4 : by * 16;   /* (DBH: see d_dbh_block) */
+  const int xt = (bx * 4 + (int)(threadIdx.x >> 6)) * 64, yt = by * 16;
   if (yt >= height || xt >= width) return;        /* wave-uniform (chroma planes are smaller than the grid) */
   const int x0 = xt + lx * 4, y0 = yt + ly * 4;
-  const bool valid = x0 < width && y0 < height && (!DBH || y0 >= 0);
+  const bool valid = x0 < width && y0 < height;
   const int rows = valid ? min(4, height - y0) : 0;
   const PIX* in = (const PIX*)p.plane[c];
   PIX* out = (PIX*)p.out_plane[c];
@@ -262,7 +121,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
 
   const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
   const int l2w = p.pp.log2_ctb_size - csw, l2h = p.pp.log2_ctb_size - csh;
-  const int xCtb = (valid ? x0 : xt) >> l2w, yCtb = (valid ? y0 : (DBH ? max(yt, 0) : yt)) >> l2h;
+  const int xCtb = (valid ? x0 : xt) >> l2w, yCtb = (valid ? y0 : yt) >> l2h;
   /* tile sharding: only own CTBs are filtered / written; waves without any own sample leave at once */
   const bool owned = !p.ctb_owner || p.ctb_owner[yCtb * p.ctbW + xCtb] != 0;
   if (!__any(owned)) return;
@@ -277,19 +136,7 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   const uint32_t nbmask_raw = p.sao_nb[c * p.nCtb + yCtb * p.ctbW + xCtb];
   uint32_t rw[6][NW];
 #pragma unroll
-  for (int r = 1; r <= 4; r++) d_sao_load4<PIX>(in + (size_t)(DBH ? max(min(y0 + r - 1, height - 1), 0) : min(y0 + r - 1, height - 1)) * is + xs, rw[r]);
-  /* DBH: the outer lanes' neighbour blocks left / right of the wave tile (their H-filtered edge column is SAO's rim) */
-  const bool halo = DBH && valid && ((lx == 0 && x0 >= 4) || (lx == 15 && x0 + 4 < width));
-  const int xh = DBH ? (lx == 0 ? x0 - 4 : x0 + 4) : 0;
-  uint32_t hr[6][NW];
-  const int yE = DBH ? ((ly & 1) ? y0 : y0 + 4) : 0;              /* DBH: the edge row between this lane and lane ^ 16 */
-  DbhIdx dbh_own, dbh_rim;
-  if (DBH) {
-#pragma unroll
-    for (int r = 1; r <= 4; r++) d_sao_load4<PIX>(in + (size_t)max(min(y0 + r - 1, height - 1), 0) * is + (halo ? xh : min(xt, width - 4)), hr[r]);   /* (the other lanes: one address per row) */
-    dbh_own = d_dbh_fetch(p, c, valid, x0, yE);
-    dbh_rim = d_dbh_fetch(p, c, halo, xh, yE);
-  }
+  for (int r = 1; r <= 4; r++) d_sao_load4<PIX>(in + (size_t)min(y0 + r - 1, height - 1) * is + xs, rw[r]);
   /* this component's parameters, selected without indexing the record dynamically */
   const int band_pos = c == 0 ? ctb.sao_band_pos[0] : (c == 1 ? ctb.sao_band_pos[1] : ctb.sao_band_pos[2]);
   const int so0 = c == 0 ? ctb.sao_offset[0][0] : (c == 1 ? ctb.sao_offset[1][0] : ctb.sao_offset[2][0]);
@@ -306,8 +153,8 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   uint32_t rim_up[NW], rim_dn[NW];
   uint32_t rim_col = 0;
   {
-    d_sao_load4<PIX>(in + (size_t)(ly == 0 ? max(y0 - 1, 0) : (DBH ? max(min(y0, height - 1), 0) : min(y0, height - 1))) * is + xs, rim_up);
-    d_sao_load4<PIX>(in + (size_t)(ly == 3 ? min(y0 + 4, height - 1) : (DBH ? max(min(y0 + 3, height - 1), 0) : min(y0 + 3, height - 1))) * is + xs, rim_dn);
+    d_sao_load4<PIX>(in + (size_t)(ly == 0 ? max(y0 - 1, 0) : min(y0, height - 1)) * is + xs, rim_up);
+    d_sao_load4<PIX>(in + (size_t)(ly == 3 ? min(y0 + 4, height - 1) : min(y0 + 3, height - 1)) * is + xs, rim_dn);
     /* lane i < 48: group g = i / 12 (the lanes with ly == g), side = (i % 12) / 6 (0 left, 1 right), row r = i % 6 */
     const int g = lane / 12, k12 = lane - g * 12, side = k12 >= 6 ? 1 : 0, r = k12 - 6 * side;
     const int yy = min(max(yt + 4 * min(g, 3) - 1 + r, 0), height - 1);
@@ -315,12 +162,6 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
     rim_col = in[(size_t)yy * is + xx];
   }
   const bool any_edge = __any(type_raw == 2);
-  if (DBH) {
-    /* the horizontal edges of this tile, then (only if some CTB of the wave asks for an edge class) those of the rim blocks */
-    M355_COMPILER_FENCE();
-    d_dbh_block<PIX, NW>(p, c, dbh_own, (ly & 1) != 0, rw);
-    if (any_edge) d_dbh_block<PIX, NW, true>(p, c, dbh_rim, (ly & 1) != 0, hr, lx == 0 ? 3 : 0);
-  }
   const bool enabled = (nbmask_raw & 0x8000u) != 0;
   const int type = enabled ? type_raw : 0;
   const bool edge = type == 2;
@@ -354,25 +195,13 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
     Ls[r] = Rs[r] = 0;
   }
   if (any_edge) {
-    int rim_h_up = 0, rim_h_dn = 0;
-    if (DBH) {
-      rim_h_up = __shfl_up(lx == 0 ? d_sao_sample<PIX>(hr[4], 3) : d_sao_sample<PIX>(hr[4], 0), 16, 64);
-      rim_h_dn = __shfl_down(lx == 0 ? d_sao_sample<PIX>(hr[1], 3) : d_sao_sample<PIX>(hr[1], 0), 16, 64);
-    }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       const int yy = y0 - 1 + r;
       const bool yok = valid && yy >= 0 && yy < height;
       /* the wave tile's left / right rim sample of this lane's row group: fetched by lane ly * 12 + r (left) / + 6 + r (right);
          the tile lies at x = xt .. xt + 63, so x0 > 0 for an outer-left lane means xt > 0 */
-      int rimv = __shfl((int)rim_col, ly * 12 + (lx == 15 ? 6 : 0) + r, 64);
-      if (DBH) {
-        /* rows 1..4 of the rim come H-filtered from the neighbour block, rows 0 / 5 from the lanes 16 up / down (the tile's
-           outermost rows y0 - 1 / y0 + 4 are never modified by the pass: memory) */
-        if (r >= 1 && r <= 4) rimv = lx == 0 ? d_sao_sample<PIX>(hr[r >= 1 && r <= 4 ? r : 1], 3) : d_sao_sample<PIX>(hr[r >= 1 && r <= 4 ? r : 1], 0);
-        else if (r == 0 && ly > 0) rimv = rim_h_up;
-        else if (r == 5 && ly < 3) rimv = rim_h_dn;
-      }
+      const int rimv = __shfl((int)rim_col, ly * 12 + (lx == 15 ? 6 : 0) + r, 64);
       int l = __shfl_up((int)(P[r][1] >> 16), 1, 64), rg = __shfl_down((int)(P[r][0] & 0xFFFFu), 1, 64);
       if (lx == 0) l = (edge && yok && x0 > 0) ? rimv : 0;
       if (lx == 15) rg = (edge && yok && x0 + 4 < width) ? rimv : 0;
@@ -529,8 +358,6 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
 }
 
 template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p) { k_sao_body<PIX, PACKED>(p, (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y); }
-/* EXPERIMENTAL (M355_FUSE_DBH): horizontal-edge deblocking + SAO in one pass, see d_dbh_block */
-template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao_dbh(DevPic p) { k_sao_body<PIX, PACKED, true>(p, (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y); }
 /* batch form: grid.z = 3 * picture + component */
 template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao_batch(DevBatch b)
 {
@@ -564,15 +391,4 @@ void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st)
   if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p);
   else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p);
-}
-
-/* EXPERIMENTAL (M355_FUSE_DBH=1, runtime.hip): replaces k_deblock<H> + k_sao for an unsharded picture with both filters on.
-   The tiles are shifted up by four rows, hence one more tile row when the height is not 12 (mod 16) or less. */
-void m355_launch_sao_dbh(const DevPic& p, bool hbd, hipStream_t st)
-{
-  const int nc = p.pp.chroma_format_idc ? 3 : 1;
-  const dim3 grid((p.pw[0] + 255) / 256, (p.ph[0] + 4 + 15) / 16, nc), block(256);
-  if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao_dbh<uint8_t, true>), grid, block, 0, st, p);
-  else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao_dbh<uint16_t, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao_dbh<uint16_t, false>), grid, block, 0, st, p);
 }

@@ -1045,14 +1045,9 @@ static int validate(const m355_picture* pic, const m355_rb* const* rb_bin_in, bo
 /* Which neighbour CTBs must the intra wavefront wait for?  (k_intra.hip reads this mask.)
  * touch bits per CTB: an intra block reaches its right column (1), bottom row (2), both (4);
  * need bits: an intra block reads across the left (L), top (T), top-left (TL), top-right (TR) border. */
-/* M355_INTRA_ONE_SIDED=1: dependency levels of the intra blocks from the side their mode reads (intra_schedule below) — fewer levels per
-   CTB, i.e. fewer barrier steps of k_intra's chain.  EXPERIMENTAL, off by default: verified under the SIMT interpreter only (shuffled
-   wave order, tests/test_intra_one_sided.py); M355_INTRA_LEVEL_STATS=1 prints the level count of every scheduled picture. */
-static int intra_one_sided()
-{
-  static const int v = getenv("M355_INTRA_ONE_SIDED") ? atoi(getenv("M355_INTRA_ONE_SIDED")) : 0;
-  return v;
-}
+/* The dependency levels of the intra blocks come from the side their MODE reads (intra_schedule below) — fewer levels per CTB, i.e.
+   fewer barrier steps of k_intra's chain (C2: 33.5 -> 19.3 levels per CTB, 1.638 -> 1.416 ms per picture on hardware,
+   profiles/r05_a_switches_one_sided.txt).  M355_INTRA_LEVEL_STATS=1 prints the level count of every scheduled picture. */
 static void intra_dependencies(int ctbW, int ctbH, const uint16_t* tile_id, const uint8_t* touch, const uint8_t* need, uint8_t* dep)
 {
   const int nCtb = ctbW * ctbH;
@@ -1095,7 +1090,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
   const int sw = (pp.chroma_format_idc == 1 || pp.chroma_format_idc == 2) ? 2 : 1, sh = pp.chroma_format_idc == 1 ? 2 : 1;
   std::atomic<long long> n_blocks(0), n_intra_ctbs(0), n_levels(0);
   std::atomic<int> overlap(-1);
-  const bool one_sided = intra_one_sided() && !(pp.flags & M355_PF_CONSTRAINED_INTRA_PRED);
+  const bool one_sided = !(pp.flags & M355_PF_CONSTRAINED_INTRA_PRED);
   /* (an intra picture has hundreds of blocks per CTB: smaller shares, so that a 1080p picture's 510 CTBs still use the whole pool) */
   parallel_ranges((size_t)pic->n_ctbs, (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs ? 16 : 256, [&](size_t cb, size_t ce) {
     std::vector<std::pair<uint32_t, uint32_t>> key, sorted;      /* (level << 2 | cidx, index) */
@@ -1255,13 +1250,6 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
-/* M355_FUSE_DBH: 1 = k_deblock<H> runs inside k_sao (k_sao_dbh, decode_post).  EXPERIMENTAL: verified under the SIMT interpreter
-   only (tests/test_fuse_dbh.py) — written when the round's GPU minutes were spent; tools/gpu_r5b.sh times it. */
-static int fuse_dbh_sao()
-{
-  static const int v = getenv("M355_FUSE_DBH") ? atoi(getenv("M355_FUSE_DBH")) : 0;
-  return v;
-}
 /* M355_DEVICE_WORKLIST: 1 = k_intra's work list (order, plan bases, neighbourhood facts) is made by two small kernels behind the list
    copy instead of on the submitting thread (0.08-0.12 ms per 8K picture); 2 = both, compared after a synchronisation (self-check);
    unset / 0 = on the host.  EXPERIMENTAL: verified under the SIMT interpreter only (tests/test_device_worklist.py) — the round's GPU
@@ -1875,15 +1863,11 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
     m355_launch_residual(d, hbd, true, st);
     if (ev) hipEventRecord(ev[1], st);
   }
-  /* M355_MERGE_TU_PLAN=1 (EXPERIMENT, emulator-verified only): transform edges and border plans in one launch */
-  static const bool merge_tu_plan = getenv("M355_MERGE_TU_PLAN") && atoi(getenv("M355_MERGE_TU_PLAN"));
-  if (merge_tu_plan && (c->stages & M355_STAGE_INTRA)) {
+  /* transform edges and border plans in ONE launch (a packet less per picture: C3 0.098 -> 0.093 ms, profiles/r05_a_switches_merge.txt) */
+  if (c->stages & M355_STAGE_INTRA) {
     m355_launch_meta_planes(d, s2, clear_in_count, false);
     m355_launch_tu_plan(d, s2);
-  } else {
-    m355_launch_meta_planes(d, s2, clear_in_count);
-    if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan(d, s2);   /* reads the CU plane (constrained intra prediction) */
-  }
+  } else m355_launch_meta_planes(d, s2, clear_in_count);
   if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
   if (ev) hipEventRecord(ev[fused ? 2 : 1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
@@ -2006,12 +1990,11 @@ static int decode_post(m355_ctx* c, Resident& r, DecodeState& S, bool filters = 
   Frame* dstf = get_frame(c, r.hdr.dst_frame);
   hipStream_t st = c->stream;
   const bool deblock = filters && (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED);
-  /* M355_FUSE_DBH (EXPERIMENTAL, off by default): the horizontal-edge pass runs inside the SAO kernel (k_sao.hip d_dbh_block) —
-     one pass over the picture and one launch less; unsharded pictures with both filters on */
-  const bool fuse_dbh = deblock && filters && want_sao && fuse_dbh_sao() && !d.ctb_owner;
-  if (deblock) { if (fuse_dbh) m355_launch_deblock_pass(d, hbd, true, st); else m355_launch_deblock(d, hbd, st); }
+  /* (the horizontal-edge pass inside the SAO kernel was built, is bit-exact on hardware and loses: C5 0.357 -> 0.392 ms per picture,
+     SAO 50 -> 104 us for 24 us less deblocking — profiles/r05_a_switches_fuse_dbh.txt, tools/experiments/sao_fused_deblock_h.patch) */
+  if (deblock) m355_launch_deblock(d, hbd, st);
   if (ev) hipEventRecord(ev[5], st);
-  if (filters && want_sao) { dst_hazards(c, dstf, piped); if (fuse_dbh) m355_launch_sao_dbh(d, hbd, st); else m355_launch_sao(d, hbd, st); }
+  if (filters && want_sao) { dst_hazards(c, dstf, piped); m355_launch_sao(d, hbd, st); }
   if (ev) hipEventRecord(ev[6], st);
   /* ONE mark behind the decode's last kernel for everything that has to know when it is over: the lists' arenas, the destination
      frame's next reader / writer, the reference frames' next writer, the lane's next decode, the status slot */

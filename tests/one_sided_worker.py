@@ -1,5 +1,4 @@
-"""Parity cases with k_intra's dependency levels derived from what each intra MODE can read (M355_INTRA_ONE_SIDED=1, read once per
-process; runtime.hip intra_schedule): python one_sided_worker.py <library .so or "default"> <oracle .so>.  Exit code 0 = every picture
+"""Parity cases with k_intra's dependency levels derived from what each intra MODE can read (runtime.hip intra_schedule): python one_sided_worker.py <library .so or "default"> <oracle .so>.  Exit code 0 = every picture
 equals the oracle's.  A dependency dropped wrongly lets a block run before (or beside) a block it reads from: the interpreter's
 shuffled wave order and non-zero memory turn that into different samples."""
 import ctypes
@@ -43,4 +42,4 @@ if __name__ == "__main__":
             assert_planes_equal(device_decode(ctx, pic, refs, resident=True, repeat=2), want, "seed %d resident" % case["seed"])
         finally:
             ctx.close()
-    print("one-sided worker ok (M355_INTRA_ONE_SIDED=%s)" % os.environ.get("M355_INTRA_ONE_SIDED", "unset"))
+    print("one-sided worker ok")

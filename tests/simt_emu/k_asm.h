@@ -10,6 +10,7 @@ static inline void d_st_nt8(void* p, unsigned v0, unsigned v1) { ((unsigned*)p)[
 #define M355_PIN_S(x) ((void)0)
 #define M355_PIN_V(x) ((void)0)
 #define M355_COMPILER_FENCE() ((void)0)
+#define M355_PIN_V4_MEM(a, b, c, d) ((void)0)
 
 #define M355_SPIN_LIMIT 4u
 static inline void d_drain_vmem() {}
