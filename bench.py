@@ -53,6 +53,20 @@ def main():
     ap.add_argument("--group-ranks", type=int, default=0, help="N=1 only, diagnostic: additionally decode the picture tile-sharded over this many contexts of THIS process (m355_group_*), all on the one GPU")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
     args = ap.parse_args()
+    # --gpus N without a launcher around us: become the launcher (one rank per GPU under torch.distributed.run, as the contract's
+    # own command line does) instead of silently measuring one GPU and printing n_gpus 1
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)"
+                         % (args.gpus, os.environ.get("WORLD_SIZE", "1"), args.gpus, args.gpus))
     # stdout carries exactly ONE line (rank 0's JSON): the libraries underneath are chatty on fd 1 (RCCL's version banner at
     # NCCL_DEBUG=VERSION, gloo's "[Gloo] Rank ... is connected" line), so fd 1 is pointed at stderr for the run and the
     # result is written to the saved descriptor at the end.
@@ -77,7 +91,12 @@ def main():
         import torch.distributed as dist
         if os.environ.get("M355_BENCH_SHARE_GPU"):   # plumbing check of the N>1 path on a box with fewer GPUs than ranks
             local_rank %= max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        else:
+            # no GPU: the CPU tier's plumbing check of this very script (tests/test_bench_launch.py: M355_LIB = the SIMT-interpreter build,
+            # every rank on "device" 0, exchanges over gloo) — never a measurement
+            local_rank = 0
         # The replica data path has no collective; torch.distributed only provides the barrier and the max-over-ranks
         # clock.  Those run over gloo: merely INITIALISING an RCCL communicator in the process slows every kernel of the
         # library by ~13 % on this stack (measured: 0.535 vs 0.460 ms per picture with / without an idle RCCL group), which
@@ -149,13 +168,13 @@ def main():
     for _ in range(repeats):                  # R timed regions of exactly K steps each: the run carries its own noise bar
         if dist:
             import torch
-            dist.barrier(); torch.cuda.synchronize()
+            dist.barrier(); dev_sync(torch)
         t0 = time.perf_counter()
         run_steps(args.steps)
         enq.append(time.perf_counter() - t0)  # host time to enqueue the K steps (launches are asynchronous)
         ctx.wait()
         if dist:
-            torch.cuda.synchronize()
+            dev_sync(torch)
         dt_r = time.perf_counter() - t0
         if dist:
             t = torch.tensor([dt_r], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
@@ -227,6 +246,36 @@ def main():
             ctx.submit_in_place(pic, state=st, refill=False)
         ctx.wait()
         dts = time.perf_counter() - t0
+        # (4b) "with transfers" (SURVEY.md 8d): the H2D of the lists as above AND the D2H of every output frame — each decode goes
+        # into one of `depth` frames, its download into pinned planes starts behind it (m355_frame_download_async: a copy engine
+        # beside the kernels), and a frame is decoded into again only after its previous download has landed
+        depth_t = max(1, args.pipeline_depth)
+        tframes = [ctx.frame_create_for(pp) for _ in range(depth_t)]
+        tplanes = [ctx.pinned_planes(f) for f in tframes]
+        saved_dst = pic.dst_frame
+        frame_bytes = sum(a.nbytes for a in tplanes[0][2])
+
+        def transfer_steps(n):
+            for k in range(n):
+                f = tframes[k % depth_t]
+                if k >= depth_t:
+                    ctx.frame_download_wait(f)
+                pic.dst_frame = f
+                ctx.submit_in_place(pic, state=st, refill=False)
+                ctx.frame_download_start(f, tplanes[k % depth_t])
+            for f in tframes[:min(n, depth_t)]:
+                ctx.frame_download_wait(f)
+        transfer_steps(2 * depth_t)
+        ctx.wait()
+        t0 = time.perf_counter()
+        transfer_steps(up_steps)
+        ctx.wait()
+        dtt = time.perf_counter() - t0
+        pic.dst_frame = saved_dst
+        for tp in tplanes:
+            ctx.pinned_free(tp)
+        for f in tframes:
+            ctx.frame_destroy(f)
         for _ in range(3):
             ctx.submit(pic)
         ctx.wait()
@@ -243,6 +292,9 @@ def main():
                        "list_bytes_per_picture": int(nbytes),
                        "submit_only": {"value": up_steps * n_ctbs / dts, "ms_per_step": 1e3 * dts / up_steps},
                        "copying_submit": {"value": n_copy * n_ctbs / dtcopy, "ms_per_step": 1e3 * dtcopy / n_copy},
+                       "with_transfers": {"value": up_steps * n_ctbs / dtt, "ms_per_step": 1e3 * dtt / up_steps, "frame_bytes": int(frame_bytes),
+                                          "d2h_GBps": frame_bytes * up_steps / dtt / 1e9,
+                                          "note": "submit_only + the D2H of EVERY output frame into pinned planes (what a player that reads each picture gets)"},
                        "note": "per step: lists written into the pinned arena (16 host threads) + validation + schedules + H2D + decode, %d pictures in flight; submit_only = without the writing; copying_submit = m355_submit_picture on lists elsewhere in host memory (incl. the Python marshalling of this harness)" % args.pipeline_depth}
     emitted = []
 
@@ -319,6 +371,11 @@ def main():
         dist.destroy_process_group()
 
 
+def dev_sync(torch):
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def pmc_traffic_total(workload):
     """HBM bytes per PICTURE over all kernels of the pipeline: the sum of profiles/pmc_traffic.json (per-launch figures x launches
     per picture as recorded there); null when no PMC passes of this workload are committed."""
@@ -364,7 +421,10 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         from libde265_amd import capi, shard
         rank, world = dist.get_rank(), dist.get_world_size()
         grp = None
-        if os.environ.get("M355_SHARD_TRANSPORT", "rccl") != "rccl":
+        on_gpu = torch.cuda.is_available()
+        if not on_gpu:
+            os.environ.setdefault("M355_SHARD_TRANSPORT", "torch")     # CPU tier: the exchanges over the job's gloo group
+        elif os.environ.get("M355_SHARD_TRANSPORT", "rccl") != "rccl":
             grp = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None     # torch's RCCL group for the exchanges
         cfg = dict(synth.CONFIGS[args.workload])
         pic = synth.picture(**cfg)                                 # the SAME picture on every rank
@@ -381,7 +441,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
                 idt = torch.frombuffer(bytearray(lib.rccl_unique_id()), dtype=torch.uint8).clone()
             dist.broadcast(idt, 0)
             rccl_id = bytes(idt.tolist())
-        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(grp) if transport != "rccl" else None, device="cuda:%d" % local_rank,
+        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(grp) if transport != "rccl" else None, device="cuda:%d" % local_rank if on_gpu else "cpu",
                                    halo=os.environ.get("M355_SHARD_HALO", "p2p"), native=transport != "python", rccl_id=rccl_id)
         refs = []
         for i in range(cfg["n_refs"]):
@@ -408,7 +468,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         # one picture through the point-to-point halo path first: if the stack refuses it, every rank falls back to the all-reduce
         ok = 1
         try:
-            dec.decode(h); ctx.wait(); torch.cuda.synchronize()
+            dec.decode(h); ctx.wait(); dev_sync(torch)
         except Exception:  # noqa: BLE001
             ok = 0
         okt = torch.tensor([ok], dtype=torch.int32)
@@ -420,13 +480,13 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
             for i in range(args.warmup):
                 dec.decode(hs[i % depth], gather=gather)
             ctx.wait()
-            dist.barrier(); torch.cuda.synchronize()
+            dist.barrier(); dev_sync(torch)
             t0 = time.perf_counter()
             for i in range(args.steps):
                 dec.decode(hs[i % depth], gather=gather)
             t_host = time.perf_counter() - t0
             ctx.wait()
-            torch.cuda.synchronize()
+            dev_sync(torch)
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item()), t_host
@@ -434,7 +494,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         dt_ng, _ = timed(False)             # the same without the finished-tile all-gather (a non-reference picture)
         # one picture at a time (latency of a single sharded picture)
         ctx.wait()
-        dist.barrier(); torch.cuda.synchronize()
+        dist.barrier(); dev_sync(torch)
         t0 = time.perf_counter()
         n1 = max(1, min(args.steps, 100))
         for _ in range(n1):
@@ -447,7 +507,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         ex_ms = None
         if world > 1 and dec.native:
             ex_ms = [ctx.shard_time_exchange(h, k, 20) for k in range(4)]
-        elif world > 1:
+        elif world > 1 and on_gpu:
             ex_ms = []
             for k in range(4):
                 buf = dec.xbufs[h][k]

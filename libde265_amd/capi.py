@@ -200,6 +200,35 @@ class Context:
         self.L.check(self.L.lib.m355_frame_download_async(self.h, f, dst, strides))
         return (f, arrays, bufs)
 
+    def pinned_planes(self, f):
+        """pinned host planes for frame f (m355_host_alloc), for repeated frame_download_start calls -> (dst[3], strides[3], arrays, pointers)"""
+        w, h, cf, bdl, bdc = self._geom[f]
+        dst = (ctypes.c_void_p * 3)(); strides = (ctypes.c_ssize_t * 3)()
+        arrays, bufs = [], []
+        for c, (pw, ph) in enumerate(worklist.plane_dims(w, h, cf)):
+            if pw == 0:
+                continue
+            dt = np.uint8 if (bdl if c == 0 else bdc) <= 8 else np.uint16
+            nbytes = pw * ph * np.dtype(dt).itemsize
+            p = self.L.lib.m355_host_alloc(nbytes)
+            if not p:
+                raise M355Error(5, self.L.error())
+            bufs.append(p)
+            arrays.append(np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), (nbytes,)).view(dt).reshape(ph, pw))
+            dst[c] = p; strides[c] = pw
+        return dst, strides, arrays, bufs
+
+    def frame_download_start(self, f, planes):
+        """m355_frame_download_async into planes from pinned_planes(); frame_download_wait(f) completes it"""
+        self.L.check(self.L.lib.m355_frame_download_async(self.h, f, planes[0], planes[1]))
+
+    def frame_download_wait(self, f):
+        self.L.check(self.L.lib.m355_frame_download_wait(self.h, f))
+
+    def pinned_free(self, planes):
+        for p in planes[3]:
+            self.L.lib.m355_host_free(p)
+
     def frame_download_finish(self, token):
         f, arrays, bufs = token
         self.L.check(self.L.lib.m355_frame_download_wait(self.h, f))

@@ -2551,6 +2551,14 @@ int m355_group_decode(m355_group* g, const int* handles, int gather)
 {
   if (!g || !handles) return fail(M355_ERR_INVALID, "bad arguments");
   const int N = (int)g->ctx.size();
+  /* every rank's handle and layout is checked BEFORE any rank starts: a rank thread that left early would never publish its steps, and
+     its neighbours would wait for them forever (the rank threads only tolerate failures behind this point: they keep publishing) */
+  for (int r = 0; r < N; r++) {
+    m355_ctx* c = g->ctx[(size_t)r];
+    const int h = handles[r];
+    if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used || !c->resident[h].sharded) return fail(M355_ERR_INVALID, "rank %d: not a sharded picture handle", r);
+    if (c->resident[h].shard_n != N || c->resident[h].shard_rank != r) return fail(M355_ERR_INVALID, "rank %d: the picture was uploaded for another group layout", r);
+  }
   if (g->th.empty()) return group_decode_lockstep(g, handles, gather);
   std::unique_lock<std::mutex> lk(g->mu);
   g->handles = handles; g->gather = gather; g->pending = N; g->job++;

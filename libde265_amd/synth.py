@@ -53,6 +53,8 @@ CONFIGS = {
                          deblock=1, sao=1, seed=0xC4C4C4C4),
     "c5_8k10_8tiles": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2,
                            deblock=1, sao=1, seed=0xC5C5C5C5),
+    # plumbing checks of bench.py itself on the CPU tier (SIMT-interpreter library; tests/test_bench_launch.py): never a benchmark
+    "tiny_4tiles": dict(width=256, height=192, bit_depth=8, tile_cols=2, tile_rows=2, intra_pct=5, n_refs=2, deblock=1, sao=1, seed=0x71117111),
     # diagnostics (not BASELINE configs): C5 with one CU size only / without out-of-picture motion vectors — what the block mix costs
     "c5x_cu64": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
                      seed=0xC5C5C5C5, fixed_cu_log2=6, oob_mv_pct=0),

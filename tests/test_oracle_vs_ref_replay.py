@@ -79,7 +79,7 @@ def test_oracle_equals_reference_replay(oracle, ref, case):
     assert_planes_equal(ref_replay(ref, pic, refs, W.STAGE_ALL, accel=1), ref_replay(ref, pic, refs, W.STAGE_ALL, accel=0), "SSE vs scalar reference")
 
 
-@pytest.mark.parametrize("name", ["c2_1080p_intra", "c4_4k_4tiles"])
+@pytest.mark.parametrize("name", ["c2_1080p_intra", "c3_4k_inter", "c4_4k_4tiles", "c5_8k10_8tiles"])   # every BASELINE config at full size, the headline list included
 def test_oracle_equals_reference_replay_baseline_configs(oracle, ref, name):
     o = Oracle(oracle)
     pic, refs = make_case(**synth.CONFIGS[name])

@@ -67,3 +67,28 @@ def test_group_lists_recorded_in_place(emu_lib, oracle, case, nranks, depth):  #
     want = oracle_decode(o, pic, refs)
     for r, got in enumerate(group_sharded_decode(emu_lib, pic, refs, nranks, depth=depth, repeat=2, in_place=True)):
         assert_planes_equal(got, want, "in-place group rank %d of %d" % (r, nranks))
+
+
+def test_group_decode_rejects_a_bad_handle_without_hanging(emu_lib):  # noqa: F811
+    """one invalid handle used to leave its rank's thread before it published a step, and the neighbours' threads spun
+    forever.  Every handle is validated before any rank starts: the call returns an error, and the group still decodes afterwards."""
+    from shard_util import _setup_rank
+    from libde265_amd import capi
+    pic, refs = make_case(width=256, height=192, bit_depth=8, seed=51, tile_cols=2, tile_rows=2)
+    ctxs = [capi.Context(emu_lib, 0) for _ in range(2)]
+    grp = capi.Group(emu_lib, ctxs)
+    try:
+        hs = []
+        for r, ctx in enumerate(ctxs):
+            sp, _dst = _setup_rank(ctx, pic, refs, r, 2, "cpu")
+            hs.append(ctx.upload(sp))
+        with pytest.raises(capi.M355Error):
+            grp.decode([hs[0], 12345], True)
+        with pytest.raises(capi.M355Error):
+            grp.decode([hs[0], -1], True)
+        grp.decode(hs, True)          # still alive
+        grp.wait()
+    finally:
+        grp.close()
+        for ctx in ctxs:
+            ctx.close()
