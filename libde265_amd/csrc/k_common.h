@@ -270,10 +270,6 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st, bool ticket_zero = false);
-/* k_intra's work list made on the device from the CTB table, the dependency bytes and the CTBs' plan counts (upload(), M355_DEVICE_WORKLIST);
-   word = scratch of 2 x nCtb words */
-void m355_launch_work_list(const m355_pic_params& pp, int ctbW, int ctbH, const m355_ctb* ctbs, const m355_slice* slices, const uint32_t* ctb_ts, const uint32_t* ts2rs,
-                           const uint16_t* tile_id, const uint8_t* dep, const uint32_t* plan_count, uint32_t* word, DevIntraWork* out, hipStream_t st);   /* ticket_zero: k_job_count(clear_planes) reset the lane's ticket word */
 void m355_launch_meta_planes_batch(const HostBatch& b, hipStream_t st);              /* the batch forms: pictures of one sample type and chroma format */
 void m355_launch_residual_batch(const HostBatch& b, bool hbd, bool big, hipStream_t st);
 void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st);

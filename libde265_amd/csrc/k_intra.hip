@@ -1010,90 +1010,6 @@ void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pi
   }
 }
 
-/* ---- the intra work list on the DEVICE (runtime.hip upload(), M355_DEVICE_WORKLIST) ------------------------------------------------
- * The order of k_intra's work items — first the CTBs that wait for no neighbour, LONGEST first, then the dependent ones in wavefront
- * order of their tile (x + 2y), decode order inside equal keys — is a rank: item i sits behind every item with a smaller sort word, or
- * the same word and an earlier decode position.  k_work_keys makes the word of every decode position (one thread each), k_work_items
- * gives every position with intra blocks a WAVE: its lanes sweep all positions, count the ones in front of it and add up their border
- * plans (the item's plan_base), nine lanes look at the 3x3 neighbourhood, lane 0 writes the 32-byte item at its rank.  No sort, no
- * scan, no atomics; O(n^2 / 64) per wave with n = CTBs of the picture (8K: 128 steps). */
-struct DevWorkArgs {
-  const m355_ctb* ctbs; const m355_slice* slices;
-  const uint32_t* ctb_ts; const uint32_t* ts2rs; const uint16_t* tile_id; const uint8_t* dep; const uint32_t* plan_count;
-  uint32_t* word;                    /* [decode position] sort word (0xFFFFFFFF: no intra blocks) | [nCtb + position] its plans, padded to 8 */
-  DevIntraWork* out;
-  int ctbW, ctbH, nCtb, ntc, ntr;
-  uint16_t col_bd[M355_MAX_TILE_COLS + 1], row_bd[M355_MAX_TILE_ROWS + 1];
-};
-__global__ void __launch_bounds__(256) k_work_keys(DevWorkArgs a)
-{
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.nCtb) return;
-  const uint32_t rs = a.ts2rs[t];
-  const uint32_t cnt = a.ctbs[rs].ib_count;
-  uint32_t w = 0xFFFFFFFFu;
-  if (cnt) {
-    if (!(a.dep[rs] & 15)) w = (0x7FFFu - min(cnt, 0x7FFFu)) << 16;                    /* free: longest first */
-    else {
-      const int cx = (int)rs % a.ctbW, cy = (int)rs / a.ctbW, ti = a.tile_id[rs];
-      const int tx = ti % a.ntc, ty = ti / a.ntc;
-      w = 0x80000000u | ((uint32_t)min((cx - a.col_bd[tx]) + 2 * (cy - a.row_bd[ty]), 0x7FFF) << 16);
-    }
-  }
-  a.word[t] = w;
-  a.word[a.nCtb + t] = cnt ? ((a.plan_count[rs] + 7u) & ~7u) : 0u;
-}
-__global__ void __launch_bounds__(256) k_work_items(DevWorkArgs a)
-{
-  const int t = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;     /* one wave per decode position */
-  if (t >= a.nCtb) return;
-  const uint32_t wi = a.word[t];
-  if (wi == 0xFFFFFFFFu) return;
-  uint32_t rank = 0, pbase = 0;
-  for (int j = lane; j < a.nCtb; j += 64) {
-    const uint32_t wj = a.word[j];
-    const bool before = wj < wi || (wj == wi && j < t);
-    rank += before ? 1u : 0u;
-    pbase += before ? a.word[a.nCtb + j] : 0u;
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { rank += (uint32_t)__shfl_xor((int)rank, d, 64); pbase += (uint32_t)__shfl_xor((int)pbase, d, 64); }
-  /* the 3x3 neighbourhood facts every availability test of intrapred.h:486-508 / :534-633 needs: lane q < 9 looks at neighbour q */
-  const uint32_t rs = a.ts2rs[t];
-  const int cx = (int)rs % a.ctbW, cy = (int)rs / a.ctbW;
-  const m355_ctb me = a.ctbs[rs];
-  const uint32_t my_sa = (uint32_t)a.slices[me.slice_idx].slice_addr_rs;
-  bool same = false, earlier = false;
-  if (lane < 9) {
-    const int nx = cx + lane % 3 - 1, ny = cy + lane / 3 - 1;
-    if (nx >= 0 && ny >= 0 && nx < a.ctbW && ny < a.ctbH) {
-      const int n = ny * a.ctbW + nx;
-      same = (uint32_t)a.slices[a.ctbs[n].slice_idx].slice_addr_rs == my_sa && a.tile_id[n] == a.tile_id[rs];
-      earlier = a.ctb_ts[n] < a.ctb_ts[rs];
-    }
-  }
-  const unsigned long long bs = __ballot(same), be = __ballot(earlier);
-  if (lane == 0) {
-    DevIntraWork w;
-    w.ctb = rs; w.ib_start = me.ib_start; w.ib_count = me.ib_count;
-    w.nb_same = (uint16_t)(bs & 0x1FFu); w.nb_earlier = (uint16_t)(be & 0x1FFu);
-    w.waves_code = (uint8_t)((a.dep[rs] >> 5) & 3); w.pad[0] = w.pad[1] = w.pad[2] = 0;
-    w.plan_base = pbase; w.plan_count = a.plan_count[rs]; w.reserved = 0;
-    a.out[rank] = w;
-  }
-}
-void m355_launch_work_list(const m355_pic_params& pp, int ctbW, int ctbH, const m355_ctb* ctbs, const m355_slice* slices, const uint32_t* ctb_ts, const uint32_t* ts2rs,
-                           const uint16_t* tile_id, const uint8_t* dep, const uint32_t* plan_count, uint32_t* word, DevIntraWork* out, hipStream_t st)
-{
-  DevWorkArgs a;
-  a.ctbs = ctbs; a.slices = slices; a.ctb_ts = ctb_ts; a.ts2rs = ts2rs; a.tile_id = tile_id; a.dep = dep; a.plan_count = plan_count; a.word = word; a.out = out;
-  a.ctbW = ctbW; a.ctbH = ctbH; a.nCtb = ctbW * ctbH; a.ntc = pp.num_tile_cols; a.ntr = pp.num_tile_rows;
-  for (int i = 0; i <= M355_MAX_TILE_COLS; i++) a.col_bd[i] = pp.col_bd[i];
-  for (int i = 0; i <= M355_MAX_TILE_ROWS; i++) a.row_bd[i] = pp.row_bd[i];
-  hipLaunchKernelGGL(k_work_keys, dim3((a.nCtb + 255) / 256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_work_items, dim3((a.nCtb + 3) / 4), dim3(256), 0, st, a);
-}
-
 void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
 {
   int work = 0, cf = 1;

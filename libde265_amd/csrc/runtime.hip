@@ -1250,16 +1250,6 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
 }
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
-/* M355_DEVICE_WORKLIST: 1 = k_intra's work list (order, plan bases, neighbourhood facts) is made by two small kernels behind the list
-   copy instead of on the submitting thread (0.08-0.12 ms per 8K picture); 2 = both, compared after a synchronisation (self-check);
-   unset / 0 = on the host.  EXPERIMENTAL: verified under the SIMT interpreter only (tests/test_device_worklist.py) — the round's GPU
-   minutes were spent when it was written; tools/gpu_r5a.sh is its first hardware visit. */
-static int device_work_list()
-{
-  static const int v = getenv("M355_DEVICE_WORKLIST") ? atoi(getenv("M355_DEVICE_WORKLIST")) : 0;
-  return v;
-}
-
 /* canonical exchange-buffer layout of a picture (k_common.h HaloLayout); depends on the picture parameters only */
 static void halo_layout(const m355_pic_params& pp, HaloLayout& h)
 {
@@ -1289,7 +1279,7 @@ struct Lay {
   Seg seg[32];
   int ns;
   size_t total;
-  int i_sl, i_ct, i_cu, i_tu, i_pb, i_wt, i_rb[4], i_ibin, i_ib, i_il, i_co, i_pc, i_sc, i_ts, i_rs, i_ti, i_iw, i_dp, i_jb, i_ow;
+  int i_sl, i_ct, i_cu, i_tu, i_pb, i_wt, i_rb[4], i_ibin, i_ib, i_il, i_co, i_pc, i_sc, i_ts, i_rs, i_ti, i_iw, i_dp, i_ow;
 };
 static void caps_of(const m355_picture* pic, m355_arena_caps& k)
 {
@@ -1321,7 +1311,6 @@ static void make_layout(const m355_arena_caps& k, int nCtb, int halo_units, bool
   L.i_ti = add(2 * (size_t)nCtb);   /* tile_id  */
   L.i_iw = add(sizeof(DevIntraWork) * (size_t)nCtb);   /* intra_work */
   L.i_dp = add((size_t)nCtb);       /* ctb_dep */
-  L.i_jb = add(device_work_list() ? 12 * (size_t)nCtb : 0);   /* plan counts per CTB + 2 scratch words per decode position: the work list made on the device */
   L.i_ow = add(sharded ? (size_t)nCtb : 0);                          /* ctb_owner */
 }
 
@@ -1363,7 +1352,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const int ns = L.ns;
   const size_t total = L.total;
   const int i_sl = L.i_sl, i_ct = L.i_ct, i_cu = L.i_cu, i_tu = L.i_tu, i_pb = L.i_pb, i_wt = L.i_wt, i_ib = L.i_ib, i_il = L.i_il, i_co = L.i_co, i_pc = L.i_pc,
-            i_sc = L.i_sc, i_ts = L.i_ts, i_rs = L.i_rs, i_ti = L.i_ti, i_iw = L.i_iw, i_dp = L.i_dp, i_jb = L.i_jb, i_ow = L.i_ow;
+            i_sc = L.i_sc, i_ts = L.i_ts, i_rs = L.i_rs, i_ti = L.i_ti, i_iw = L.i_iw, i_dp = L.i_dp, i_ow = L.i_ow;
   /* used bytes (what travels to the device) and, when copying, where they come from */
   {
     size_t rb_o = 0;
@@ -1381,7 +1370,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
     srcs[i_pc] = pic->pcm; used[i_pc] = 2 * (size_t)pic->n_pcm;
     srcs[i_sc] = pic->scaling_factors; used[i_sc] = pic->scaling_factors ? 6 * (16 + 64 + 256 + 1024) : 0;
     used[i_ts] = used[i_rs] = 4 * (size_t)nCtb; used[i_iw] = sizeof(DevIntraWork) * (size_t)nCtb;   /* (cut down to the items in use below) */ used[i_ti] = 2 * (size_t)nCtb; used[i_dp] = (size_t)nCtb;
-    used[i_jb] = 0; used[i_ow] = sharded ? (size_t)nCtb : 0;
+    used[i_ow] = sharded ? (size_t)nCtb : 0;
     for (int i = 0; i < ns; i++) { seg[i].src = srcs[i]; seg[i].bytes = used[i]; }
     if (in_place) {
       /* every list must sit where the arena put it (the four size bins of rbs[] in their own regions: m355_arena_begin
@@ -1463,22 +1452,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const auto t_deps = now();
   int nw = 0, n_free = 0;
   uint32_t n_iplan = 0;                                     /* border-plan entries of the picture (k_intra_plan) */
-  const int dev_wl = device_work_list();
-  if (dev_wl) {
-    /* the device orders the items (m355_launch_work_list below); the host only counts: items, free CTBs, plan entries */
-    const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
-    uint32_t* pc = (uint32_t*)(r.host + seg[i_jb].ofs);
-    for (int i = 0; i < nCtb; i++) {
-      pc[i] = plan_count[(size_t)i];
-      if (!pic->ctbs[i].ib_count) continue;
-      nw++;
-      if (!(dep[i] & 15)) n_free++;
-      n_iplan += (plan_count[(size_t)i] + 7u) & ~7u;
-    }
-    seg[i_jb].bytes = 4 * (size_t)nCtb;
-  }
-  if (dev_wl != 1) {
-    nw = 0; n_free = 0; n_iplan = 0;
+  {
     const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
     /* the order first — two stable COUNTING sorts over the CTBs in decode order (keys are small: blocks per CTB, x + 2y inside a
        tile), a comparison sort of the 8K picture's 2800 intra CTBs cost more than everything else here —, then the items, in parallel */
@@ -1547,7 +1521,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
       }
     });
   }
-  seg[i_iw].bytes = dev_wl == 1 ? 0 : sizeof(DevIntraWork) * (size_t)(nw ? nw : 1);   /* (made on the device: nothing to copy) */
+  seg[i_iw].bytes = sizeof(DevIntraWork) * (size_t)(nw ? nw : 1);
   r.n_intra_work = nw; r.n_iplan = n_iplan;
   if (sharded) {
     uint8_t* ow = (uint8_t*)(r.host + seg[i_ow].ofs);
@@ -1574,27 +1548,6 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
       if (used && run_e > run_b && b - run_e <= 4096) { run_e = e; continue; }      /* small gap: one copy */
       if (run_e > run_b) HIPCHK(hipMemcpyAsync(r.dev + run_b, r.host + run_b, run_e - run_b, hipMemcpyHostToDevice, c->stream));
       run_b = b; run_e = e;
-    }
-  }
-  if (dev_wl) {
-    char* dv = r.dev;
-    DevIntraWork* out = (DevIntraWork*)(dv + seg[i_iw].ofs);
-    std::vector<DevIntraWork> host_items;
-    if (dev_wl == 2) {            /* self-check: keep the host's items, let the device overwrite its copy, compare */
-      host_items.assign((const DevIntraWork*)(r.host + seg[i_iw].ofs), (const DevIntraWork*)(r.host + seg[i_iw].ofs) + nw);
-    }
-    m355_launch_work_list(pp, ctbW, ctbH, (const m355_ctb*)(dv + seg[i_ct].ofs), (const m355_slice*)(dv + seg[i_sl].ofs), (const uint32_t*)(dv + seg[i_ts].ofs),
-                          (const uint32_t*)(dv + seg[i_rs].ofs), (const uint16_t*)(dv + seg[i_ti].ofs), (const uint8_t*)(dv + seg[i_dp].ofs),
-                          (const uint32_t*)(dv + seg[i_jb].ofs), (uint32_t*)(dv + seg[i_jb].ofs) + nCtb, out, c->stream);
-    if (dev_wl == 2 && nw) {
-      std::vector<DevIntraWork> got((size_t)nw);
-      HIPCHK(hipStreamSynchronize(c->stream));
-      HIPCHK(hipMemcpy(got.data(), out, sizeof(DevIntraWork) * (size_t)nw, hipMemcpyDeviceToHost));
-      if (memcmp(got.data(), host_items.data(), sizeof(DevIntraWork) * (size_t)nw) != 0) {
-        int k = 0;
-        while (k < nw && !memcmp(&got[(size_t)k], &host_items[(size_t)k], sizeof(DevIntraWork))) k++;
-        return fail(M355_ERR_HIP, "M355_DEVICE_WORKLIST=2: item %d of %d differs (device ctb %u base %u, host ctb %u base %u)", k, nw, got[(size_t)k].ctb, got[(size_t)k].plan_base, host_items[(size_t)k].ctb, host_items[(size_t)k].plan_base);
-      }
     }
   }
   {

@@ -98,23 +98,13 @@ __global__ void __launch_bounds__(64) k_dot2(const uint32_t* __restrict__ pairs,
 
 // ---- the matrix pipe ----
 // constant operands, per lane (built once per wave): B1[s] = M[16 g + s][i], B2[s] = M[col(s, g)][i] with col(s, g) = (s & 3) + 8 (s >> 2) + 4 g, i = lane & 31, g = lane >> 5
-__global__ void __launch_bounds__(256) k_mfma(const int16_t* __restrict__ ct, uint16_t* __restrict__ plane, int nblk, int bd, int per_wave)
+__global__ void __launch_bounds__(256) k_mfma(const int16_t* __restrict__ ct, uint16_t* __restrict__ plane, int nblk, int bd, int per_wave, const int* __restrict__ lane_tab)
 {
   const int lane = threadIdx.x & 63, i = lane & 31, g = lane >> 5;
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  int4_ B1, B2;
-  int cs = 0;
-  {
-    int b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
-    for (int s = 0; s < 16; s++) {
-      b1[s >> 2] |= (M32(0, 0) * 0 + (int)((unsigned)(qw((16 * g + s) * (2 * i + 1)) & 0xFF) << (8 * (s & 3))));
-      const int col = (s & 3) + 8 * (s >> 2) + 4 * g;
-      b2[s >> 2] |= (int)((unsigned)(qw(col * (2 * i + 1)) & 0xFF) << (8 * (s & 3)));
-    }
-    for (int j = 0; j < 32; j++) cs += qw(j * (2 * i + 1));
-    B1 = int4_{b1[0], b1[1], b1[2], b1[3]};
-    B2 = int4_{b2[0], b2[1], b2[2], b2[3]};
-  }
+  /* the lane's constant operands from a 64 x 12-word table (the host built it: a kernel of the product would keep it in constant memory) */
+  const int4_ B1 = *(const int4_*)(lane_tab + lane * 12), B2 = *(const int4_*)(lane_tab + lane * 12 + 4);
+  const int cs = lane_tab[lane * 12 + 8];
   const int post = 20 - bd;
   const unsigned maxv = ((1u << bd) - 1u) * 0x10001u;
   const unsigned sel = (lane & 1) ? 0x07060302u : 0x05040100u;    // odd lanes: (nbr.hi, own.hi); even lanes: (own.lo, nbr.lo)  [perm(hi = second, lo = first)]
@@ -219,6 +209,21 @@ int main(int argc, char** argv)
   int16_t *d_ct; uint32_t* d_pairs; uint16_t* d_plane;
   CHK(hipMalloc(&d_ct, (size_t)nblk * 2048)); CHK(hipMalloc(&d_pairs, (size_t)nblk * 2048)); CHK(hipMalloc(&d_plane, plane0.size() * 2));
   hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  int* d_tab;
+  {
+    std::vector<int> tab(64 * 12, 0);
+    for (int lane = 0; lane < 64; lane++) {
+      const int i = lane & 31, g = lane >> 5;
+      for (int s2 = 0; s2 < 16; s2++) {
+        tab[lane * 12 + (s2 >> 2)] |= (int)((unsigned)(M32(16 * g + s2, i) & 0xFF) << (8 * (s2 & 3)));
+        const int col = (s2 & 3) + 8 * (s2 >> 2) + 4 * g;
+        tab[lane * 12 + 4 + (s2 >> 2)] |= (int)((unsigned)(M32(col, i) & 0xFF) << (8 * (s2 & 3)));
+      }
+      for (int j = 0; j < 32; j++) tab[lane * 12 + 8] += M32(j, i);
+    }
+    CHK(hipMalloc(&d_tab, tab.size() * 4));
+    CHK(hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  }
   printf("# %d blocks of 32x32, %d-bit plane; ns per block = kernel time / blocks (mean of %d launches)\n", nblk, bd, reps);
   for (int occ : {4, 8, 16, 32}) {
     // coefficients: the three scenarios of dev-tools/test-transform.cc (sparse small / dense +-2048 / full int16) inside the top-left occ x occ corner
@@ -245,15 +250,15 @@ int main(int argc, char** argv)
     for (int b = 0; b < ncheck; b++) ref_block(&coef[(size_t)b * 1024], &want[(size_t)(b / BLK_X) * 32 * PITCH + (b % BLK_X) * 32], PITCH, bd);
     CHK(hipMemcpy(d_ct, ct.data(), ct.size() * 2, hipMemcpyHostToDevice));
     CHK(hipMemcpy(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
-    for (int which = 0; which < 3; which++) {
-      const int per_wave = which == 2 ? 4 : 1;
+    for (int which = 0; which < 4; which++) {
+      const int per_wave = which == 3 ? 16 : (which == 2 ? 4 : 1);
       float tot = 0;
       bool ok = true;
       for (int r = 0; r < reps + 1; r++) {
         CHK(hipMemcpy(d_plane, plane0.data(), plane0.size() * 2, hipMemcpyHostToDevice));
         CHK(hipEventRecord(e0));
         if (which == 0) hipLaunchKernelGGL(k_dot2, dim3((nblk + 1) / 2), dim3(64), 0, 0, d_pairs, d_plane, nblk, occ, bd);
-        else hipLaunchKernelGGL(k_mfma, dim3((nblk + 4 * per_wave - 1) / (4 * per_wave)), dim3(256), 0, 0, d_ct, d_plane, nblk, bd, per_wave);
+        else hipLaunchKernelGGL(k_mfma, dim3((nblk + 4 * per_wave - 1) / (4 * per_wave)), dim3(256), 0, 0, d_ct, d_plane, nblk, bd, per_wave, d_tab);
         CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
         float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
         if (r) tot += ms;
@@ -269,7 +274,7 @@ int main(int argc, char** argv)
           ok = bad == 0;
         }
       }
-      printf("occupied %2dx%-2d  %-22s %8.1f ns/block  (%.4f ms)  %s\n", occ, occ, which == 0 ? "k_dot2 (product scheme)" : (which == 1 ? "k_mfma 1 block/wave" : "k_mfma 4 blocks/wave"),
+      printf("occupied %2dx%-2d  %-22s %8.1f ns/block  (%.4f ms)  %s\n", occ, occ, which == 0 ? "k_dot2 (product scheme)" : (which == 1 ? "k_mfma 1 block/wave" : (which == 2 ? "k_mfma 4 blocks/wave" : "k_mfma 16 blocks/wave")),
              tot / reps * 1e6 / nblk, tot / reps, ok ? "bit-exact" : "MISMATCH");
     }
   }
