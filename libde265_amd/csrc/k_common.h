@@ -119,6 +119,7 @@ struct DevPic {
   void* out_plane[3];               /* SAO output (the DPB frame) */
   int out_stride[3];
   const DevRef* refs;               /* M355_MAX_REF_FRAMES entries in device memory */
+  const uint32_t* inter_tabs;       /* tap tables of k_inter_jobs' lean filters for this picture's plane type and bit depths (k_inter.hip m355_inter_tables) */
   /* work lists (device copies) */
   const m355_slice* slices;
   const m355_ctb* ctbs;
@@ -265,8 +266,11 @@ void m355_launch_meta_jobs(const DevPic& p, hipStream_t st);     /* job list for
 void m355_launch_job_count(const DevPic& p, bool clear_planes, hipStream_t st);   /* ... its first launch, optionally with the zero fill of the metadata planes */
 void m355_launch_job_list(const DevPic& p, hipStream_t st);      /* ... the rest */
 void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared, bool with_tu = true);   /* planes for intra / deblock / SAO (cleared: k_job_count filled them; !with_tu: the transform edges come with m355_launch_tu_plan) */
+void m355_launch_meta_planes_jobs(const DevPic& p, hipStream_t st);   /* CU plane + PB edges, SAO masks and the job list as roles of ONE launch (behind m355_launch_job_count(clear)) */
 void m355_launch_tu_plan(const DevPic& p, hipStream_t st);         /* transform edges + border plans in ONE launch */
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
+#define M355_INTER_TAB_WORDS 300
+void m355_inter_tables(bool bytes, int bd_luma, int bd_chroma, uint32_t* out);   /* host: the tables behind DevPic.inter_tabs (M355_INTER_TAB_WORDS words) */
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st, bool ticket_zero = false);

@@ -202,6 +202,11 @@ __global__ void __launch_bounds__(256) k_inter_generic(DevPic p)
 #ifndef M355_INTER_BLOCK
 #define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
 #endif
+#ifdef M355_X_PROF      /* experiment builds (tools/prof_inter_timeline.py): when a workgroup entered, had its class, its tables, its luma, was done */
+#define TLI(k) do { if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[16384 + 6 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define TLI(k) do { } while (0)
+#endif
 #define QT_STRIDE 9
 #define ET_STRIDE 5
 __device__ __forceinline__ unsigned d_pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
@@ -550,67 +555,60 @@ __device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
 #ifndef M355_INTER_PIPE
 #define M355_INTER_PIPE 1   /* luma window rows: 0 = all 15 requested at once (hipcc's own order), D = D row pairs ahead of the arithmetic */
 #endif
+#ifndef M355_INTER_EDGE_DEPTH
+#define M355_INTER_EDGE_DEPTH 4   /* EDGE jobs of 16-bit planes: row pairs requested ahead */
+#endif
 #define QL_STRIDE 12   /* 16-bit planes: [xf][d][12] = T0[5] T1[5] (2 spare);  8-bit planes: [xf][12] = W[j][3], j = output column */
 #define CL_STRIDE 8    /* 16-bit planes: [xf][d][8]  = U0[3] U1[3] (2 spare);  8-bit planes: [xf][4]  = C0 C1 C2 (1 spare) */
-__device__ __forceinline__ int d_qtap(int f, int i)   /* c_qpel_taps[f][i] from immediates (no constant-memory round trip in the prologue) */
+/* The tap tables of the lean filters are made ONCE per plane type and bit-depth pair, on the host (runtime.hip keeps them in device
+ * memory, DevPic.inter_tabs), and a workgroup copies them into LDS with one coalesced load beside its first record loads — built per
+ * workgroup from immediates they cost a wave ~300 vector instructions, a sixth of a job's arithmetic.
+ *   [QL_MAIN 96] H luma of the classes inside the picture   : 16-bit planes [xf][d][12] = T0[5] T1[5];  8-bit planes [xf][12] = W[j][3]
+ *   [QV 36]      V luma x 4                                  : [yf][9] = E0..E3 O0..O4
+ *   [CL_MAIN 128] H chroma                                   : 16-bit planes [xf][d][8] = U0[3] U1[3];   8-bit planes [xf][4] = C0 C1 C2
+ *   [CV 40]      V chroma x 4                                : [yf][5] = E0 E1 O0 O1 O2
+ */
+#define LT_QL 0
+#define LT_QV 96
+#define LT_CL 132
+#define LT_CV 260
+#define LT_WORDS 300
+static int h_qtap(int f, int i) { static const int8_t t[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}}; return i >= 0 && i < 8 ? t[f][i] : 0; }
+static int h_etap(int f, int i) { static const int8_t t[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}}; return i >= 0 && i < 4 ? t[f][i] : 0; }
+/* packed pair (t(first), t(first + 1)) x scale of an n-tap filter: E_k = first 2k, O_k = first 2k - 1 */
+static uint32_t h_pair(int (*t)(int, int), int f, int first, int scale) { return ((uint32_t)(t(f, first) * scale) & 0xFFFFu) | ((uint32_t)(t(f, first + 1) * scale) << 16); }
+void m355_inter_tables(bool bytes, int bd_luma, int bd_chroma, uint32_t* out)
 {
-  const unsigned long long t = f == 0 ? 0x0000000040000000ull : (f == 1 ? 0x0001FB113AF604FFull : (f == 2 ? 0xFF04F52828F504FFull : 0xFF04F63A11FB0100ull));
-  return (int)(int8_t)(t >> (8 * i));
-}
-__device__ __forceinline__ int d_etap(int f, int i)   /* c_epel_taps[f][i] */
-{
-  const unsigned lo = (f & 1) ? ((f & 2) ? 0xFC1C2EFAu : 0xFE0A3AFEu) : ((f & 2) ? 0xFE1036FCu : 0x00004000u);
-  const unsigned hi = (f & 1) ? ((f & 2) ? 0xFE3A0AFEu : 0xFA2E1CFCu) : ((f & 2) ? 0xFC3610FEu : 0xFC2424FCu);
-  return (int)(int8_t)(((f & 4) ? hi : lo) >> (8 * i));
-}
-/* entry e of the packed-pair tap sets of an N-tap filter (taps t(i), i = 0..N-1, times `scale`): E_k = (t 2k, t 2k+1), O_k = (t 2k-1, t 2k) */
-template <class F> __device__ __forceinline__ unsigned d_tap_pair(F t, int n, int first, int scale)
-{
-  const int a = first >= 0 && first < n ? t(first) * scale : 0, b = first + 1 >= 0 && first + 1 < n ? t(first + 1) * scale : 0;
-  return d_pack16(a, b);
-}
-/* pairs: the H tables in their packed-pair form (16-bit planes, and the EDGE blocks of every plane type: their clamped rows are
-   unpacked to 16-bit pairs) — else the byte form for v_dot4 (8-bit planes) */
-template <class PIX>
-__device__ __forceinline__ void d_lean_tables(const DevPic& p, bool pairs, unsigned* s_ql, unsigned* s_qv, unsigned* s_cl, unsigned* s_cv)
-{
-  const int tid = threadIdx.x;
-  /* V taps x 4: qv[yf][9] = E0..E3 O0..O4, cv[yf][5] = E0 E1 O0 O1 O2 */
-  for (int i = tid; i < 4 * QT_STRIDE; i += M355_INTER_BLOCK) {
-    const int f = i / QT_STRIDE, k = i - f * QT_STRIDE;
-    s_qv[i] = d_tap_pair([&](int j) { return d_qtap(f, j); }, 8, k < 4 ? 2 * k : 2 * (k - 4) - 1, 4);
-  }
-  for (int i = tid; i < 8 * ET_STRIDE; i += M355_INTER_BLOCK) {
-    const int f = i / ET_STRIDE, k = i - f * ET_STRIDE;
-    s_cv[i] = d_tap_pair([&](int j) { return d_etap(f, j); }, 4, k < 2 ? 2 * k : 2 * (k - 2) - 1, 4);
-  }
-  if (pairs) {
-    const int hs = 1 << (16 - (sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_luma)), hc = 1 << (16 - (sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_chroma));
-    /* d = 0: T0 = (E0 E1 E2 E3 0), T1 = (O0 .. O4);  d = 1: T0 = (O0 .. O4), T1 = (0 E0 E1 E2 E3)   — pair k of T over window pairs k.. */
-    for (int i = tid; i < 4 * 2 * QL_STRIDE; i += M355_INTER_BLOCK) {
-      const int f = i / (2 * QL_STRIDE), r = i - f * 2 * QL_STRIDE, d = r / QL_STRIDE, e = r - d * QL_STRIDE;
-      const int set = e / 5, k = e - set * 5;          /* set 0: T0, 1: T1, 2: spare */
-      /* sample index (relative to the window's first loaded sample) of output column `set` = d + set; pair k starts at sample 2k */
-      s_ql[i] = set < 2 ? d_tap_pair([&](int j) { return d_qtap(f, j); }, 8, 2 * k - (d + set), hs) : 0u;
-    }
-    for (int i = tid; i < 8 * 2 * CL_STRIDE; i += M355_INTER_BLOCK) {
-      const int f = i / (2 * CL_STRIDE), r = i - f * 2 * CL_STRIDE, d = r / CL_STRIDE, e = r - d * CL_STRIDE;
-      const int set = e / 3, k = e - set * 3;
-      s_cl[i] = set < 2 ? d_tap_pair([&](int j) { return d_etap(f, j); }, 4, 2 * k - (d + set), hc) : 0u;
-    }
-  } else {
-    /* W[j][w]: the 8 taps as bytes at byte offset j of 12 */
-    for (int i = tid; i < 4 * QL_STRIDE; i += M355_INTER_BLOCK) {
-      const int f = i / QL_STRIDE, e = i - f * QL_STRIDE, j = e / 3, w = e - j * 3;
-      unsigned v = 0;
-      for (int b = 0; b < 4; b++) { const int idx = 4 * w + b - j; if (idx >= 0 && idx < 8) v |= ((unsigned)d_qtap(f, idx) & 0xFFu) << (8 * b); }
-      s_ql[i] = v;
-    }
-    for (int i = tid; i < 8 * 4; i += M355_INTER_BLOCK) {
-      const int f = i >> 2, e = i & 3;
-      unsigned c = 0;
-      for (int b = 0; b < 4; b++) c |= ((unsigned)d_etap(f, b) & 0xFFu) << (8 * b);
-      s_cl[i] = e == 0 ? c : (e == 1 ? c << 8 : (e == 2 ? c >> 24 : 0u));
+  for (int i = 0; i < LT_WORDS; i++) out[i] = 0;
+  for (int f = 0; f < 4; f++)
+    for (int k = 0; k < QT_STRIDE; k++) out[LT_QV + f * QT_STRIDE + k] = h_pair(h_qtap, f, k < 4 ? 2 * k : 2 * (k - 4) - 1, 4);
+  for (int f = 0; f < 8; f++)
+    for (int k = 0; k < ET_STRIDE; k++) out[LT_CV + f * ET_STRIDE + k] = h_pair(h_etap, f, k < 2 ? 2 * k : 2 * (k - 2) - 1, 4);
+  /* pair form: d = 0: T0 = (E0 E1 E2 E3 0), T1 = (O0 .. O4);  d = 1: T0 = (O0 .. O4), T1 = (0 E0 E1 E2 E3) — pair k of set s holds the taps of the
+     window's samples 2k, 2k + 1 for output column d + s (= the sample index of that column's first tap) */
+  auto pairs = [&](uint32_t* ql, uint32_t* cl, int hs, int hc) {
+    for (int f = 0; f < 4; f++)
+      for (int d = 0; d < 2; d++)
+        for (int set = 0; set < 2; set++)
+          for (int k = 0; k < 5; k++) ql[(f * 2 + d) * QL_STRIDE + set * 5 + k] = h_pair(h_qtap, f, 2 * k - (d + set), hs);
+    for (int f = 0; f < 8; f++)
+      for (int d = 0; d < 2; d++)
+        for (int set = 0; set < 2; set++)
+          for (int k = 0; k < 3; k++) cl[(f * 2 + d) * CL_STRIDE + set * 3 + k] = h_pair(h_etap, f, 2 * k - (d + set), hc);
+  };
+  if (!bytes) pairs(out + LT_QL, out + LT_CL, 1 << (16 - bd_luma), 1 << (16 - bd_chroma));
+  else {
+    for (int f = 0; f < 4; f++)          /* W[j][w]: the 8 taps as bytes at byte offset j of 12 */
+      for (int j = 0; j < 4; j++)
+        for (int w = 0; w < 3; w++) {
+          uint32_t v = 0;
+          for (int b = 0; b < 4; b++) v |= ((uint32_t)h_qtap(f, 4 * w + b - j) & 0xFFu) << (8 * b);
+          out[LT_QL + f * QL_STRIDE + 3 * j + w] = v;
+        }
+    for (int f = 0; f < 8; f++) {
+      uint32_t c = 0;
+      for (int b = 0; b < 4; b++) c |= ((uint32_t)h_etap(f, b) & 0xFFu) << (8 * b);
+      out[LT_CL + f * 4] = c; out[LT_CL + f * 4 + 1] = c << 8; out[LT_CL + f * 4 + 2] = c >> 24;
     }
   }
 }
@@ -643,33 +641,87 @@ __device__ __forceinline__ void d_fake_ld(const M355_GLOBAL void* p, unsigned* o
    launch at 4K: profiles/r05_c_inter_attribution.txt) */
 template <class PIX, bool EDGE>
 __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rstride, int pw, int ph, int xi, int yi, int xf, int yf,
-                                               const unsigned* s_ql, const unsigned* s_qv, unsigned pred[8][2])
+                                               const unsigned* s_ql, const unsigned* s_qv, unsigned* ext, unsigned pred[8][2])
 {
   const int xa = xi - 3;
   unsigned Q[8][4];
   constexpr int DEPTH = M355_INTER_PIPE ? M355_INTER_PIPE : 1, NB = DEPTH + 1;   /* row pairs requested ahead of the one being filtered */
   if (EDGE) {
-    const unsigned* tl = s_ql + (xf * 2) * QL_STRIDE;          /* phase d = 0: the rows come out of d_load12 starting at xa */
-    unsigned T0[5], T1[5];
+    if (sizeof(PIX) == 2) {
+      const int xb = d_clip3(0, pw - 12, xa), s_ = d_clip3(0, 24, 12 + xa - xb);       /* sample offset of the span in the extended row */
+      const unsigned* tl = s_ql + (xf * 2 + (s_ & 1)) * QL_STRIDE;
+      unsigned T0[5], T1[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) { T0[k] = tl[k]; T1[k] = tl[5 + k]; }
-    unsigned S[15][6];
+      for (int k = 0; k < 5; k++) { T0[k] = tl[k]; T1[k] = tl[5 + k]; }
+      /* four row pairs requested ahead of the one being filtered (all 15 rows at once would spill) */
+      constexpr int DE = M355_INTER_EDGE_DEPTH, NE = DE + 1;
+      unsigned G[NE][2][6];
+      auto fetch = [&](int k) {
 #pragma unroll
-    for (int r = 0; r < 15; r++) d_load12<PIX, false>(rp + (ptrdiff_t)d_clip3(0, ph - 1, yi - 3 + r) * rstride, xa, pw, S[r]);
+        for (int r = 0; r < 2; r++) {
+          if (2 * k + r >= 15) break;
+          const M355_GLOBAL PIX* q = rp + (ptrdiff_t)d_clip3(0, ph - 1, yi - 3 + 2 * k + r) * rstride + xb;
+          d_ldg16(q, G[k % NE][r]); d_ldg8(q + 8, G[k % NE][r] + 4);
+        }
+      };
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      int h[2][4];
+      for (int k = 0; k < DE; k++) fetch(k);
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }
-        const unsigned* E = S[2 * k + r];
-        h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2(E[0], T0[0], 0)))));
-        h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2(E[0], T1[0], 0)))));
-        h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2(E[1], T0[0], 0)))));
-        h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2(E[1], T1[0], 0)))));
+      for (int k = 0; k < 8; k++) {
+        if (k + DE < 8) fetch(k + DE);
+        int h[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }
+          const unsigned* g = G[k % NE][r];
+          const unsigned L = (g[0] & 0xFFFFu) * 0x10001u, R = (g[5] >> 16) * 0x10001u;
+          uint4* e4 = (uint4*)ext;
+          e4[0] = make_uint4(L, L, L, L); e4[1] = make_uint4(L, L, g[0], g[1]); e4[2] = make_uint4(g[2], g[3], g[4], g[5]); e4[3] = make_uint4(R, R, R, R);
+          ext[16] = R; ext[17] = R;
+          unsigned E[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) E[i] = ext[(s_ >> 1) + i];
+          h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2(E[0], T0[0], 0)))));
+          h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2(E[0], T1[0], 0)))));
+          h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2(E[1], T0[0], 0)))));
+          h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2(E[1], T1[0], 0)))));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) Q[k][j] = d_pack_mid16((unsigned)h[0][j], (unsigned)h[1][j]);
+        M355_PIN_V4_MEM(Q[k][0], Q[k][1], Q[k][2], Q[k][3]);
       }
+    } else {
+      const int xb = d_clip3(0, pw - 16, xa), s_ = d_clip3(0, 36, 16 + xa - xb);       /* byte offset of the span in the extended row */
+      const unsigned* tl = s_ql + xf * QL_STRIDE;
+      unsigned W[4][3];
 #pragma unroll
-      for (int j = 0; j < 4; j++) Q[k][j] = d_pack_mid16((unsigned)h[0][j], (unsigned)h[1][j]);
+      for (int j = 0; j < 4; j++) { W[j][0] = tl[3 * j]; W[j][1] = tl[3 * j + 1]; W[j][2] = tl[3 * j + 2]; }
+      const unsigned sh = (unsigned)s_ & 3u;
+      unsigned G[15][4];
+#pragma unroll
+      for (int r = 0; r < 15; r++) d_ldg16(rp + (ptrdiff_t)d_clip3(0, ph - 1, yi - 3 + r) * rstride + xb, G[r]);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        int h[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }
+          const unsigned* g = G[2 * k + r];
+          const unsigned L = (g[0] & 0xFFu) * 0x01010101u, R = (g[3] >> 24) * 0x01010101u;
+          uint4* e4 = (uint4*)ext;
+          e4[0] = make_uint4(L, L, L, L); e4[1] = make_uint4(g[0], g[1], g[2], g[3]); e4[2] = make_uint4(R, R, R, R); e4[3] = make_uint4(R, R, R, R);
+          unsigned E[4], A[3];
+#pragma unroll
+          for (int i = 0; i < 4; i++) E[i] = ext[(s_ >> 2) + i];
+#pragma unroll
+          for (int i = 0; i < 3; i++) A[i] = __builtin_amdgcn_alignbyte(E[i + 1], E[i], sh) ^ 0x80808080u;
+          h[r][0] = d_dot4(A[1], W[0][1], d_dot4(A[0], W[0][0], 8192));
+#pragma unroll
+          for (int j = 1; j < 4; j++) h[r][j] = d_dot4(A[2], W[j][2], d_dot4(A[1], W[j][1], d_dot4(A[0], W[j][0], 8192)));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) Q[k][j] = d_pack_lo16((unsigned)h[0][j], (unsigned)h[1][j]);
+      }
     }
   } else if (sizeof(PIX) == 2) {
     const unsigned* tl = s_ql + (xf * 2 + (xa & 1)) * QL_STRIDE;
@@ -768,22 +820,49 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
 /* chroma 2x4 block of one list and plane (fallback-motion.cc:305-415 / 262-302 with the folds above) */
 template <class PIX, bool EDGE>
 __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int rstride, int pw, int ph, int xi, int yi, int xf, int yf,
-                                                 const unsigned* s_cl, const unsigned* s_cv, unsigned pred[4])
+                                                 const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, unsigned pred[4])
 {
   const int xa = xi - 1;
   int h[8][2];
   if (EDGE) {
-    const unsigned* tl = s_cl + (xf * 2) * CL_STRIDE;
-    unsigned U0[3], U1[3];
+    if (sizeof(PIX) == 2) {
+      const int xb = d_clip3(0, pw - 6, xa), s_ = d_clip3(0, 12, 6 + xa - xb);
+      const unsigned* tl = s_cl + (xf * 2 + (s_ & 1)) * CL_STRIDE;
+      unsigned U0[3], U1[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { U0[k] = tl[k]; U1[k] = tl[3 + k]; }
-    unsigned S[7][3];
+      for (int k = 0; k < 3; k++) { U0[k] = tl[k]; U1[k] = tl[3 + k]; }
+      unsigned G[7][3];
 #pragma unroll
-    for (int r = 0; r < 7; r++) d_load6<PIX, false>(rp + (ptrdiff_t)d_clip3(0, ph - 1, yi - 1 + r) * rstride, xa, pw, S[r]);
+      for (int r = 0; r < 7; r++) d_ldg12(rp + (ptrdiff_t)d_clip3(0, ph - 1, yi - 1 + r) * rstride + xb, G[r]);
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
-      h[r][0] = d_dot2(S[r][2], U0[2], d_dot2(S[r][1], U0[1], d_dot2(S[r][0], U0[0], 0)));
-      h[r][1] = d_dot2(S[r][2], U1[2], d_dot2(S[r][1], U1[1], d_dot2(S[r][0], U1[0], 0)));
+      for (int r = 0; r < 7; r++) {
+        const unsigned* g = G[r];
+        const unsigned L = (g[0] & 0xFFFFu) * 0x10001u, R = (g[2] >> 16) * 0x10001u;
+        uint4* e4 = (uint4*)ext;
+        e4[0] = make_uint4(L, L, L, g[0]); e4[1] = make_uint4(g[1], g[2], R, R); ext[8] = R;
+        const unsigned E0 = ext[(s_ >> 1)], E1 = ext[(s_ >> 1) + 1], E2 = ext[(s_ >> 1) + 2];
+        h[r][0] = d_dot2(E2, U0[2], d_dot2(E1, U0[1], d_dot2(E0, U0[0], 0)));
+        h[r][1] = d_dot2(E2, U1[2], d_dot2(E1, U1[1], d_dot2(E0, U1[0], 0)));
+      }
+    } else {
+      const int xb = d_clip3(0, pw - 8, xa), s_ = d_clip3(0, 16, 8 + xa - xb);
+      const unsigned* tl = s_cl + xf * 4;
+      const unsigned C0 = tl[0], C1 = tl[1], C2 = tl[2];
+      const unsigned sh = (unsigned)s_ & 3u;
+      unsigned G[7][2];
+#pragma unroll
+      for (int r = 0; r < 7; r++) d_ldg8(rp + (ptrdiff_t)d_clip3(0, ph - 1, yi - 1 + r) * rstride + xb, G[r]);
+#pragma unroll
+      for (int r = 0; r < 7; r++) {
+        const unsigned* g = G[r];
+        const unsigned L = (g[0] & 0xFFu) * 0x01010101u, R = (g[1] >> 24) * 0x01010101u;
+        uint4* e4 = (uint4*)ext;
+        e4[0] = make_uint4(L, L, g[0], g[1]); e4[1] = make_uint4(R, R, R, R);
+        const unsigned E0 = ext[(s_ >> 2)], E1 = ext[(s_ >> 2) + 1];
+        const unsigned A0 = __builtin_amdgcn_alignbyte(E1, E0, sh) ^ 0x80808080u, A1 = (E1 >> (8 * sh)) ^ 0x80808080u;
+        h[r][0] = d_dot4(A0, C0, 8192);
+        h[r][1] = d_dot4(A1, C2, d_dot4(A0, C1, 8192));
+      }
     }
   } else if (sizeof(PIX) == 2) {
     const unsigned* tl = s_cl + (xf * 2 + (xa & 1)) * CL_STRIDE;
@@ -819,7 +898,7 @@ __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int 
 #pragma unroll
   for (int k = 0; k < 4; k++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) Q[k][j] = (EDGE || sizeof(PIX) == 2) ? d_pack_mid16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]) : d_pack_lo16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]);
+    for (int j = 0; j < 2; j++) Q[k][j] = sizeof(PIX) == 2 ? d_pack_mid16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]) : d_pack_lo16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]);
   const unsigned* ty = s_cv + yf * ET_STRIDE;
   unsigned YE[2], YO[3];
 #pragma unroll
@@ -847,7 +926,7 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
  * (bi: wave-uniform) and the write-back is packed 16-bit arithmetic; 1: explicit weights — one or two lists per lane, the 32-bit
  * write-back; 2: EDGE — windows that leave the picture (clamped rows), weights per lane. */
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, const DevRef* s_refs);
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs);
 
 /* one launch for the main and the edge job range: blocks [0, nblk_edge8) take edge jobs */
 template <class PIX, bool BIAS, bool LEAN>
@@ -867,6 +946,7 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
      i/per_b of another cover the same part of the picture): they then read the same reference region while it is still in that
      XCD's L2 — run one class after the other and every region is fetched twice, far apart in time. */
   const int b = blockIdx.x;
+  TLI(0);
   int cls, ji, jend;
   if (b < nblk_edge8) { cls = 3; ji = t2 + b * M355_INTER_BLOCK; jend = t3; }
   else {
@@ -895,14 +975,23 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     for (int i = threadIdx.x; i < (int)(sizeof(s_refs) / 4); i += M355_INTER_BLOCK) dst[i] = src[i];
   }
   if (LEAN) {
-    __shared__ unsigned s_ql[4 * 2 * QL_STRIDE], s_qv[4 * QT_STRIDE], s_cl[8 * 2 * CL_STRIDE], s_cv[8 * ET_STRIDE];
-    d_lean_tables<PIX>(p, sizeof(PIX) == 2 || cls == 3, s_ql, s_qv, s_cl, s_cv);
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[LT_WORDS];
+    if (threadIdx.x < LT_WORDS / 4) ((uint4*)s_tab)[threadIdx.x] = ((const uint4*)p.inter_tabs)[threadIdx.x];
+    uint32_t job = 0;
+    if (ji < jend) job = p.jobs[ji];          /* (requested beside the tables) */
+    TLI(1);
     __syncthreads();
+    TLI(2);
+#ifdef M355_X_PROF
+    if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[16384 + 6 * blockIdx.x + 5] = (unsigned long long)cls + 1;
+#endif
     if (ji >= jend) return;
-    const uint32_t job = p.jobs[ji];
-    if (cls == 3) d_inter_job_lean<PIX, 2>(p, job, false, s_ql, s_qv, s_cl, s_cv, s_refs);
-    else if (cls == 2) d_inter_job_lean<PIX, 1>(p, job, false, s_ql, s_qv, s_cl, s_cv, s_refs);
-    else d_inter_job_lean<PIX, 0>(p, job, cls == 1, s_ql, s_qv, s_cl, s_cv, s_refs);
+    /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
+    __shared__ __attribute__((aligned(16))) unsigned s_ext[M355_INTER_BLOCK * 20];
+    unsigned* ext = s_ext + threadIdx.x * 20;
+    if (cls == 3) d_inter_job_lean<PIX, 2>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
+    else if (cls == 2) d_inter_job_lean<PIX, 1>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
+    else d_inter_job_lean<PIX, 0>(p, job, cls == 1, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
     return;
   }
   __shared__ unsigned s_qt[4 * QT_STRIDE];
@@ -1151,7 +1240,7 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
 }
 
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, const DevRef* s_refs)
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs)
 {
   constexpr bool WEIGHTED = MODE != 0, EDGE = MODE == 2;
   const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
@@ -1222,7 +1311,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       } else {
         const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
         const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-        d_mc_luma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], p.pw[0], p.ph[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, cur);
+        d_mc_luma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], p.pw[0], p.ph[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, ext, cur);
       }
       if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
 #pragma unroll
@@ -1288,6 +1377,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       }
     }
   }
+  TLI(3);
   if (nc == 1) return;
 
   /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are in flight together;
@@ -1307,8 +1397,8 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       } else {
         const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
         const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-        d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], p.pw[1], p.ph[1], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, cur1);
-        d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], p.pw[2], p.ph[2], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, cur2);
+        d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], p.pw[1], p.ph[1], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur1);
+        d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], p.pw[2], p.ph[2], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur2);
       }
       if (pass + 1 < npass) {
 #pragma unroll
@@ -1389,6 +1479,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       }
     }
   }
+  TLI(4);
 }
 
 template <class PIX, bool BIAS, bool LEAN>
@@ -1409,8 +1500,11 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
     if (!hbd) launch_jobs<uint8_t, false, false>(p, st);
     else if (bdmax < 16) launch_jobs<uint16_t, false, false>(p, st);
 #else
-    if (!hbd) launch_jobs<uint8_t, false, true>(p, st);
-    else if (bdmax <= 12) launch_jobs<uint16_t, false, true>(p, st);            /* the lean filters (folds exact for bit depths <= 12) */
+    /* (the lean EDGE path fetches 12 / 16 luma and 6 / 8 chroma samples of a row with one vector load: pictures narrower than that keep the general kernels) */
+    const bool wide = p.pw[0] >= 16 && (p.pp.chroma_format_idc == 0 || p.pw[1] >= 8);
+    if (!hbd && wide) launch_jobs<uint8_t, false, true>(p, st);
+    else if (hbd && bdmax <= 12 && wide) launch_jobs<uint16_t, false, true>(p, st);            /* the lean filters (folds exact for bit depths <= 12) */
+    else if (!hbd) launch_jobs<uint8_t, false, false>(p, st);
 #endif
     else if (bdmax == 16) launch_jobs<uint16_t, true, false>(p, st);
     else launch_jobs<uint16_t, false, false>(p, st);

@@ -129,10 +129,9 @@ __global__ void __launch_bounds__(256) k_job_count(DevPic p, int clear_planes)
 /* one thread per prediction block: PB index plane (pb_info, image.cc set_mv_info) and the job list of
  * k_inter_jobs: (w/4) x ceil(h/8) jobs per PB, row block major so consecutive jobs are horizontally
  * adjacent; three ranges (one-list, bi-predicted, picture-edge jobs), each in PB order. */
-__global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
+__device__ __forceinline__ void k_meta_pb_body(const DevPic& p, const int chunk, const int n_chunks)
 {
-  M355_GATE(p);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = chunk * 256 + (int)threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool active = i < p.n_pbs;
   m355_pb pb;
@@ -163,12 +162,12 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   __shared__ uint32_t s_red[4][8];
   {
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};              /* [0..3] all chunks, [4..7] the chunks in front of this one */
-    for (int ch = (int)threadIdx.x; ch < (int)gridDim.x; ch += 256) {
+    for (int ch = (int)threadIdx.x; ch < n_chunks; ch += 256) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint32_t n = p.job_base[ch * 4 + k];
         acc[k] += n;
-        acc[4 + k] += ch < (int)blockIdx.x ? n : 0u;
+        acc[4 + k] += ch < chunk ? n : 0u;
       }
     }
 #pragma unroll
@@ -190,7 +189,7 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
     uint32_t start = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { base[k] = start + tot[4 + k]; start += tot[k]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (chunk == 0 && threadIdx.x == 0) {
       const uint32_t cap = p.jobs_cap;
       uint32_t end = 0;
 #pragma unroll
@@ -232,6 +231,12 @@ __global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
   if (!active || !p.fill_pb_of_in_meta) return;
   for (int y = pb.y >> 2; y < ((pb.y + pb.h) >> 2) && y < p.h4; y++)
     for (int x = pb.x >> 2; x < ((pb.x + pb.w) >> 2) && x < p.w4; x++) p.pb_of[y * p.w4 + x] = (uint32_t)i + 1;
+}
+
+__global__ void __launch_bounds__(256) k_meta_pb(DevPic p)
+{
+  M355_GATE(p);
+  k_meta_pb_body(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 /* one thread per (CTB, component): which of the 3x3 neighbouring CTBs may NOT contribute SAO edge
@@ -297,6 +302,17 @@ __global__ void __launch_bounds__(256) k_meta_planes(DevPic p, int nb_cu)
   if (b < nb_cu) k_meta_cu_body(p, b);
   else k_meta_sao_body(p, b - nb_cu);
 }
+/* ... and, on a lane that runs a picture on ONE stream (up to 4K), the job list of k_inter_jobs as a third role of the same launch: the
+   three scatters are independent of each other, the job list only needs k_job_count's counts (the launch in front).  One packet less per
+   picture, and the two latency-bound scatters run beside each other instead of one after the other. */
+__global__ void __launch_bounds__(256) k_meta_planes_jobs(DevPic p, int nb_pb, int nb_cu)
+{
+  M355_GATE(p);
+  const int b = (int)blockIdx.x;
+  if (b < nb_pb) k_meta_pb_body(p, b, nb_pb);
+  else if (b < nb_pb + nb_cu) k_meta_cu_body(p, b - nb_pb);
+  else k_meta_sao_body(p, b - nb_pb - nb_cu);
+}
 __global__ void __launch_bounds__(256) k_meta_tu(DevPic p) { k_meta_tu_body(p, (int)blockIdx.x); }
 __global__ void __launch_bounds__(256) k_meta_cu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_cu_body(p, (int)blockIdx.x); }
 __global__ void __launch_bounds__(256) k_meta_tu_batch(DevBatch b) { M355_BATCH_PIC(b); k_meta_tu_body(p, (int)blockIdx.x); }
@@ -319,6 +335,14 @@ void m355_launch_meta_planes(const DevPic& p, hipStream_t st, bool cleared, bool
   const int nb_cu = (p.n_cus + 255) / 256, nb_sao = (p.pp.flags & M355_PF_SAO_ENABLED) ? (p.nCtb * 3 + 255) / 256 : 0;
   if (nb_cu + nb_sao) hipLaunchKernelGGL(k_meta_planes, dim3(nb_cu + nb_sao), dim3(256), 0, st, p, nb_cu);
   if (with_tu && p.n_tus) hipLaunchKernelGGL(k_meta_tu, dim3((p.n_tus + 255) / 256), dim3(256), 0, st, p);   /* (else: k_tu_plan, k_intra.hip) */
+}
+
+/* metadata planes (without the transform edges: m355_launch_tu_plan follows) + the job list in one launch; the planes were cleared and the
+   jobs counted by k_job_count in front */
+void m355_launch_meta_planes_jobs(const DevPic& p, hipStream_t st)
+{
+  const int nb_pb = (p.n_pbs + 255) / 256, nb_cu = (p.n_cus + 255) / 256, nb_sao = (p.pp.flags & M355_PF_SAO_ENABLED) ? (p.nCtb * 3 + 255) / 256 : 0;
+  if (nb_pb + nb_cu + nb_sao) hipLaunchKernelGGL(k_meta_planes_jobs, dim3(nb_pb + nb_cu + nb_sao), dim3(256), 0, st, p, nb_pb, nb_cu);
 }
 
 void m355_launch_meta_planes_batch(const HostBatch& b, hipStream_t st)

@@ -186,6 +186,7 @@ struct m355_ctx {
   int device = 0;
   Lane lanes[M355_MAX_LANES];  /* parked lanes; lanes[active] is stale: the active lane lives in the fields below */
   int depth = 1, active = 0;   /* pipeline depth, index of the active lane */
+  std::vector<std::pair<uint32_t, uint32_t*>> inter_tabs;   /* k_inter_jobs' tap tables per (plane type, bit depths): m355_inter_tables */
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;           /* side stream: metadata planes are rasterised while k_inter / k_residual run */
   hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
@@ -524,6 +525,7 @@ void m355_destroy(m355_ctx* c)
   for (auto& t : c->transient) resident_free(t);
   for (hipEvent_t e : c->evs) hipEventDestroy(e);
   if (c->hash_acc) hipFree(c->hash_acc);
+  for (auto& e : c->inter_tabs) hipFree(e.second);
   for (auto& b : c->batch) { if (b.host) hipHostFree(b.host); if (b.dev) hipFree(b.dev); if (b.ev) hipEventDestroy(b.ev); }
   for (hipEvent_t e : c->batch_ev_pre) if (e) hipEventDestroy(e);
   for (hipStream_t bs : c->batch_stream) if (bs) hipStreamDestroy(bs);
@@ -1647,6 +1649,22 @@ static int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out)
     r.refs_valid = true;
   }
   d.refs = r.refs_dev;
+  {
+    /* k_inter_jobs' tap tables: one small constant buffer per (plane type, bit depths) this context has decoded */
+    const uint32_t key = (uint32_t)(dst->bpp[0] == 1) | ((uint32_t)pp.bit_depth_luma << 8) | ((uint32_t)pp.bit_depth_chroma << 16);
+    const uint32_t* tab = nullptr;
+    for (auto& e : c->inter_tabs) if (e.first == key) tab = e.second;
+    if (!tab) {
+      uint32_t host[M355_INTER_TAB_WORDS];
+      m355_inter_tables(dst->bpp[0] == 1, std::min((int)pp.bit_depth_luma, 16), std::min((int)pp.bit_depth_chroma, 16), host);
+      uint32_t* dev = nullptr;
+      HIPCHK(hipMalloc(&dev, sizeof(host)));
+      HIPCHK(hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice));
+      c->inter_tabs.emplace_back(key, dev);
+      tab = dev;
+    }
+    d.inter_tabs = tab;
+  }
   /* scratch */
   int rc;
   {
@@ -1817,11 +1835,17 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
     if (ev) hipEventRecord(ev[1], st);
   }
   /* transform edges and border plans in ONE launch (a packet less per picture: C3 0.098 -> 0.093 ms, profiles/r05_a_switches_merge.txt) */
-  if (c->stages & M355_STAGE_INTRA) {
-    m355_launch_meta_planes(d, s2, clear_in_count, false);
-    m355_launch_tu_plan(d, s2);
-  } else m355_launch_meta_planes(d, s2, clear_in_count);
-  if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
+  if (single && clear_in_count && (c->stages & M355_STAGE_INTRA)) {
+    /* one stream: the planes' scatters and the job list are independent roles of ONE launch (k_meta_planes_jobs) */
+    m355_launch_meta_planes_jobs(d, st);
+    m355_launch_tu_plan(d, st);
+  } else {
+    if (c->stages & M355_STAGE_INTRA) {
+      m355_launch_meta_planes(d, s2, clear_in_count, false);
+      m355_launch_tu_plan(d, s2);
+    } else m355_launch_meta_planes(d, s2, clear_in_count);
+    if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
+  }
   if (ev) hipEventRecord(ev[fused ? 2 : 1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
      reference — the list copy, validation, metadata planes, job list (and fused residuals) of a picture run beside the tail
