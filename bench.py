@@ -232,7 +232,7 @@ def main():
     if not args.no_with_upload and rank == 0:
         ctx.set_pipeline_depth(args.pipeline_depth)
         st = {}
-        for _ in range(13):                  # the rotating arenas (three; M355_TRANSIENT_RING up to 12) are allocated on first use
+        for _ in range(13):                  # the rotating arenas (three) are allocated on first use
             ctx.submit_in_place(pic, state=st)
         ctx.wait()
         up_steps = max(side_steps, 100)      # (a host-side rate: 20 steps are 20 ms of wall clock, too few to be stable)

@@ -260,7 +260,7 @@ class Context:
         """The in-place path: m355_arena_begin (capacities = the picture's counts x slack) -> the lists are written into the
         pinned arena by libm355synth's m355_synth_fill_arena (standing in for recorder threads) -> m355_submit_picture on
         those pointers (no host copy inside the library).  refill=False re-submits what the arena still holds from an
-        earlier call with the same capacities (three arenas rotate; M355_TRANSIENT_RING up to 12): the library's own share of the work alone.
+        earlier call with the same capacities (three arenas rotate): the library's own share of the work alone.
         `state` caches the marshalled source picture between calls."""
         from . import synth
         state = state if state is not None else {}

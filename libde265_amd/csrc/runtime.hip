@@ -202,19 +202,13 @@ struct m355_ctx {
   std::vector<Frame> frames;
   std::vector<Resident> resident;
   /* m355_submit_picture: rotating staging arenas, so the host prepares picture k+1 while k decodes; a slot is free again when the
-     decode of the lists it held has finished.  THREE slots: a longer ring (M355_TRANSIENT_RING=<n>, 2..M355_TRANSIENT_MAX; slots
-     allocate on first use) was measured and buys nothing — the submitting thread's own work per picture (list checks, schedules,
+     decode of the lists it held has finished.  THREE slots: a longer ring was measured and buys nothing — the submitting thread's own work per picture (list checks, schedules,
      ~20 launches: 0.45 ms at 8K) is what bounds a submit-every-picture decoder, and with more slots it runs further ahead of the
      three lanes, which costs more than it hides (C5 submit_only 0.74-0.79 ms with 3 slots, 0.80-0.94 with 4, 0.81-0.92 with 6:
      profiles/r04_ai_submit_ring.txt). */
   Resident transient[M355_TRANSIENT_MAX];
   int next_transient = 0;
-  int transient_ring() const
-  {
-    static const int env = getenv("M355_TRANSIENT_RING") ? atoi(getenv("M355_TRANSIENT_RING")) : 0;
-    const int n = env > 0 ? env : 3;
-    return n < 2 ? 2 : (n > M355_TRANSIENT_MAX ? M355_TRANSIENT_MAX : n);
-  }
+  int transient_ring() const { return 3; }
   Frame work;                  /* pre-SAO working planes */
   /* scratch */
   uint32_t *pb_of = nullptr, *ticket = nullptr, *timeout = nullptr;
@@ -242,7 +236,6 @@ struct m355_ctx {
   m355_comm comm = {nullptr, nullptr, nullptr};   /* exchanges of m355_decode_sharded */
   void* rccl = nullptr;              /* built-in RCCL communicator (m355_shard_rccl_init) */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
-  std::vector<hipStream_t> pad_streams;   /* (M355_X_STREAM_PAD) */
   std::vector<uint8_t> ev_fused;   /* per timed decode: the residual stage ran first (launch_prediction) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
@@ -324,20 +317,10 @@ static int lane_class_priority(int index)
   const int cls = (index / 3) % 3;
   return cls == 0 ? 0 : (cls == 1 ? hi : lo);
 }
-static int lane_priorities_mode()                            /* 0 off, 1 every stream, 2 (default) intra pictures only */
-{
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("M355_LANE_PRIORITIES"); mode = !e ? 2 : (atoi(e) == 0 ? 0 : 1); }
-  return mode;
-}
+static int lane_priorities_mode() { return 2; }              /* 0 off, 1 every stream, 2 intra pictures only (what the measurements of round 3 left: profiles/r03_v_*) */
 static int lane_priority(int index) { return lane_priorities_mode() == 1 ? lane_class_priority(index) : 0; }
 static int lane_create(m355_ctx* c, Lane& l, int index)
 {
-  /* M355_X_STREAM_PAD=n (experiment): n idle streams in front of every second lane's streams — shifts which hardware queue the
-     runtime gives the lanes' main streams (created main, side, main, side ... they land on every other queue) */
-  static const int pad = getenv("M355_X_STREAM_PAD") ? atoi(getenv("M355_X_STREAM_PAD")) : 0;
-  if (pad > 0 && index >= 2 && (index & 1) == 0)
-    for (int k = 0; k < pad; k++) { hipStream_t dummy; if (hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking) == hipSuccess) c->pad_streams.push_back(dummy); }
   HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, lane_priority(index)));
   HIPCHK(hipStreamCreateWithPriority(&l.stream2, hipStreamNonBlocking, lane_priority(index)));
   HIPCHK(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
@@ -529,7 +512,6 @@ void m355_destroy(m355_ctx* c)
   for (auto& b : c->batch) { if (b.host) hipHostFree(b.host); if (b.dev) hipFree(b.dev); if (b.ev) hipEventDestroy(b.ev); }
   for (hipEvent_t e : c->batch_ev_pre) if (e) hipEventDestroy(e);
   for (hipStream_t bs : c->batch_stream) if (bs) hipStreamDestroy(bs);
-  for (hipStream_t ps : c->pad_streams) hipStreamDestroy(ps);
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& e_ : c->evring) if (e_.ev) hipEventDestroy(e_.ev);
   if (c->status_words) hipHostFree(c->status_words);
@@ -1325,8 +1307,7 @@ static int upload(m355_ctx* c, Resident& r, const m355_picture* pic)
   const m355_pic_params& pp = pic->pp;
   const bool in_place = r.arena && r.host && pic->n_ctbs > 0 && (const char*)pic->ctbs >= r.host && (const char*)pic->ctbs < r.host + r.cap;
   int ctbW, ctbH;
-  static const bool host_only = getenv("M355_HOST_VALIDATION") != nullptr;     /* diagnostics: all record checks on the host */
-  r.device_validate = in_place && !host_only && c->shard_n < 1;   /* (a sharded picture's phases have no status slot: its lists are checked here) */
+  r.device_validate = in_place && c->shard_n < 1;   /* (a sharded picture's phases have no status slot: its lists are checked here) */
   int rc = validate(pic, in_place ? (const m355_rb* const*)r.caps.rb_bin : nullptr, r.device_validate, &ctbW, &ctbH);
   if (rc) return rc;
   const auto t_valid = now();
@@ -1800,27 +1781,21 @@ static void clear_target(m355_ctx* c, const DevPic& d, Frame* tgt, bool gated, h
 static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra = true)
 {
   hipStream_t st = c->stream;
-  /* an intra picture keeps to its lane's main stream (M355_DENSE_SINGLE_STREAM=0: forks like the others): its side work (metadata
-     planes, border plans: 0.07 ms) is nothing beside k_intra, and half as many streams compete for the runtime's hardware queues when
-     many such pictures are in flight — with M355_LANE_PRIORITIES=1 nine lanes are nine queues: C2 0.340 ms per picture = 1.50 M
-     CTB64/s at depth 9 (profiles/r03_v_*; forked: 0.59 at depth 8) */
-  static const bool single_env = !(getenv("M355_DENSE_SINGLE_STREAM") && atoi(getenv("M355_DENSE_SINGLE_STREAM")) == 0);
-  /* M355_SINGLE_STREAM=1 (experiment): every picture on its lane's main stream only — a lane is then ONE stream for the runtime's
-     hardware queues */
-  static const int single_mode = getenv("M355_SINGLE_STREAM") ? atoi(getenv("M355_SINGLE_STREAM")) : -1;   /* 1 always, 0 never, unset: by picture size */
-  /* ... and so does a picture of up to 4K: the fork / join of the side stream is six packets (three event records, three waits) at
-     about 2 us of pipeline time each, and what they buy — the metadata scatters and the second residual launch beside the main
-     stream — is worth less than that once the kernels are short (three in flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms
-     on one stream, C5 0.347 -> 0.351) */
-  const bool single_small = single_mode < 0 && (long long)d.pp.width * d.pp.height <= 16ll << 20;
-  const bool single = (single_env && d.intra_dense) || single_mode > 0 || single_small;
+  /* an intra picture keeps to its lane's main stream: its side work (metadata planes, border plans: 0.07 ms) is nothing beside k_intra,
+     and half as many streams compete for the runtime's hardware queues when many such pictures are in flight (C2 0.340 ms per picture
+     = 1.50 M CTB64/s at depth 9, profiles/r03_v_*; forked: 0.59 at depth 8) — and so does a picture of up to 4K: the fork / join of the
+     side stream is six packets (three event records, three waits) at about 2 us of pipeline time each, and what they buy — the metadata
+     scatters and the second residual launch beside the main stream — is worth less than that once the kernels are short (three in
+     flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms on one stream, C5 0.347 -> 0.351) */
+  const bool single = d.intra_dense || (long long)d.pp.width * d.pp.height <= 16ll << 20;
   const bool fused = d.res_map != nullptr;   /* prepare(): the residuals of inter CUs are added in k_inter_jobs' write-back */
   hipStream_t s2 = single ? st : c->stream2;
   /* the zero fill of the metadata planes rides in the picture's first main-stream launch (k_job_count), in FRONT of the fork: the
      side stream's scatters then start behind it — one launch less per inter picture (not with fused residuals: there the side
      stream starts with the residual stage, and the job count comes later) */
   /* (the fill is shared out over the launch's workgroups, one per 256 PBs: with a handful of them a fill of its own is faster;
-     M355_CLEAR_IN_COUNT_MIN=<PBs> moves the threshold — the CPU tier's small pictures take the path with 1) */
+     M355_CLEAR_IN_COUNT_MIN=<PBs> moves the threshold: tests/test_meta_merged_emu.py sends the CPU tier's small pictures down this path —
+     and through the merged planes + job-list launch behind it — with 1) */
   static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
   const bool clear_in_count = !fused && d.n_pbs >= std::max(1, clear_min);
   if (clear_in_count) m355_launch_job_count(d, true, st);
@@ -1873,10 +1848,9 @@ static void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, b
   if (ev) hipEventRecord(ev[fused ? 3 : 2], st);
   if (!fused && (c->stages & M355_STAGE_RESIDUAL)) {
     /* inter residuals are added to the prediction samples: behind k_inter_jobs; the two launches side by side on the lane's two
-       streams (M355_RES_SIDE=0: one after the other on the main stream, no second fork — measured 1 % slower at C5 with three
+       streams (one after the other on the main stream, without the second fork, was measured 1 % slower at C5 with three
        pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
-    static const bool res_side = !(getenv("M355_RES_SIDE") && atoi(getenv("M355_RES_SIDE")) == 0);
-    hipStream_t sr = (res_side && !single) ? s2 : st;
+    hipStream_t sr = !single ? s2 : st;
     if (sr != st) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }
     m355_launch_residual(d, hbd, false, sr);
     m355_launch_residual(d, hbd, true, st);
@@ -1937,8 +1911,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
   }
   hipStream_t st = c->stream;
   hipEvent_t* ev = nullptr;
-  static const bool always_time = getenv("M355_ALWAYS_TIME") && atoi(getenv("M355_ALWAYS_TIME"));   /* (A/B: the stage events on every decode, as before round 4) */
-  if (with_intra && (c->timing_on || always_time)) {                        /* (a batch's decodes are not stage-timed: their intra stage is shared) */
+  if (with_intra && c->timing_on) {                        /* (a batch's decodes are not stage-timed: their intra stage is shared) */
     if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
     while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
     ev = &c->evs[c->ev_used * 7];
@@ -2443,7 +2416,7 @@ int m355_group_create(m355_ctx* const* ctxs, int n, m355_group** out)
         return fail(M355_ERR_HIP, "hipEventCreate failed");
       }
   }
-  bool threads = n > 1 && !(getenv("M355_GROUP_THREADS") && atoi(getenv("M355_GROUP_THREADS")) == 0);
+  bool threads = n > 1;
 #ifdef SIMT_EMU
   threads = false;
 #endif
