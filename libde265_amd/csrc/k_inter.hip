@@ -553,7 +553,7 @@ __device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
  *  * No coordinate clamps: address = first row + r * pitch.
  * ============================================================================================== */
 #ifndef M355_INTER_PIPE
-#define M355_INTER_PIPE 1   /* luma window rows: 0 = all 15 requested at once (hipcc's own order), D = D row pairs ahead of the arithmetic */
+#define M355_INTER_PIPE 2   /* luma window rows: 0 = all 15 requested at once (hipcc's own order), D = D row pairs ahead of the arithmetic */
 #endif
 #ifndef M355_INTER_EDGE_DEPTH
 #define M355_INTER_EDGE_DEPTH 4   /* EDGE jobs of 16-bit planes: row pairs requested ahead */
