@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-with-upload", action="store_true", help="skip the PCIe-inclusive legs (lists recorded into the pinned arena -> validation -> H2D -> decode, per step)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the bitstream-level leg (synthetic 8K stream through the reference CLI on the reference library and on the glue library)")
     ap.add_argument("--no-dependent-chain", action="store_true", help="skip the leg in which every picture references the two decoded before it")
+    ap.add_argument("--no-cold-refs", action="store_true", help="skip the leg whose reference frames rotate through four pairs (working set beyond the Infinity Cache)")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
     ap.add_argument("--group-ranks", type=int, default=0, help="N=1 only, diagnostic: additionally decode the picture tile-sharded over this many contexts of THIS process (m355_group_*), all on the one GPU")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
@@ -75,7 +76,7 @@ def main():
     os.dup2(2, 1)
 
     # The residual order of the library follows the pictures in flight (fused into k_inter_jobs' write-back at depth 1, read-modify-
-    # write behind it otherwise, runtime.hip prepare()).  The headline runs with pictures in flight; the legs that time the stages one
+    # write behind it otherwise, runtime_decode.hip prepare()).  The headline runs with pictures in flight; the legs that time the stages one
     # picture at a time (stage_ms, roofline, the rocprofv3 traces under profiles/) must see the SAME kernels, so this process pins the
     # order of the headline unless told otherwise.
     os.environ.setdefault("M355_RES_FUSED", "0")
@@ -189,6 +190,49 @@ def main():
     spread = {"repeats": repeats, "min": 1e3 * regions[order[0]] / args.steps, "median": 1e3 * dt / args.steps, "max": 1e3 * regions[order[-1]] / args.steps,
               "p10": 1e3 * regions[order[repeats // 10]] / args.steps, "p90": 1e3 * regions[order[min(repeats - 1, (9 * repeats) // 10)]] / args.steps}
     ctx.set_pipeline_depth(1)
+
+    # (2b) the same timed region with the reference frames ROTATING through four distinct pairs: the headline's pictures all read the same
+    # two frames (2 x 99.5 MB at C5: inside the 256 MiB Infinity Cache), a stream's pictures read different ones.  Four pairs = 796 MB at
+    # C5: every picture's windows come from HBM, not from the last-level cache.
+    cold = None
+    if not args.no_cold_refs and rank == 0 and cfg["n_refs"] >= 1:
+        nr, n_sets = cfg["n_refs"], 4
+        sets = []
+        for k in range(n_sets):
+            fr = []
+            for i in range(nr):
+                f = ctx.frame_create_for(pp)
+                ctx.frame_upload(f, synth.ref_planes(cfg["seed"] + 17 * i + 1009 * (k + 1), int(pp["width"]), int(pp["height"]),
+                                                     int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
+                fr.append(f)
+            sets.append(fr)
+        saved = (pic.dst_frame, pic.ref_frames)
+        ch, cd = [], []
+        for k in range(max(n_sets, args.pipeline_depth)):
+            pic.dst_frame = ctx.frame_create_for(pp)
+            cd.append(pic.dst_frame)
+            pic.ref_frames = [sets[k % n_sets][i] if i < nr else -1 for i in range(worklist.MAX_REF_FRAMES)]
+            ch.append(ctx.upload(pic))
+        pic.dst_frame, pic.ref_frames = saved
+        ctx.wait()
+        ctx.set_pipeline_depth(args.pipeline_depth)
+        for k in range(2 * len(ch)):
+            ctx.decode_resident(ch[k % len(ch)])
+        ctx.wait()
+        t0 = time.perf_counter()
+        for k in range(side_steps):
+            ctx.decode_resident(ch[k % len(ch)])
+        ctx.wait()
+        dtk = time.perf_counter() - t0
+        ctx.set_pipeline_depth(1)
+        for h2 in ch:
+            ctx.release(h2)
+        for f in cd + [f for fr in sets for f in fr]:
+            ctx.frame_destroy(f)
+        ref_bytes = n_sets * nr * sum(int(a) * int(b) for a, b in worklist.plane_dims(int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]))) * (1 if pp["bit_depth_luma"] <= 8 else 2)
+        cold = {"value": side_steps * n_ctbs / dtk, "unit": "CTB64/s", "ms_per_step": 1e3 * dtk / side_steps, "steps": side_steps, "reference_sets": n_sets,
+                "reference_bytes": int(ref_bytes),
+                "note": "the timed region's loop with the reference frames rotating through %d distinct pairs (%.0f MB: beyond the 256 MiB Infinity Cache), %d pictures in flight" % (n_sets, ref_bytes / 1e6, args.pipeline_depth)}
 
     # (3) a dependent chain: picture k is predicted from the pictures k-1 and k-2 (the same lists, uploaded once per frame
     # assignment; frames rotate), decoded with the same number of pictures in flight — every decode waits for the SAO of its
@@ -340,6 +384,8 @@ def main():
                 out["tile_sharded_in_process"] = grp_leg
         if chain is not None:
             out["dependent_chain"] = chain
+        if cold is not None:
+            out["rotating_references"] = cold
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, synth, worklist)
         if not args.no_end_to_end and world == 1:

@@ -55,16 +55,16 @@ struct DevIntraWork {
   uint16_t nb_same;                 /* bit k: 3x3 neighbour k (row-major, 4 = the CTB itself) lies in the picture, in the same slice
                                        (SliceAddrRS) and in the same tile */
   uint16_t nb_earlier;              /* bit k: neighbour k precedes the CTB in decode (tile-scan) order */
-  uint8_t waves_code;               /* widest dependency level of the CTB (runtime.hip intra_schedule): 0..3 */
+  uint8_t waves_code;               /* widest dependency level of the CTB (runtime_upload.hip intra_schedule): 0..3 */
   uint8_t pad[3];
   uint32_t plan_base;               /* first entry of the CTB's border plans in DevPic.iplan (a multiple of 8 entries) */
   uint32_t plan_count;              /* ... and how many entries they are (<= M355_INTRA_PLAN_CAP) */
   uint32_t reserved;
 };
 /* Border plans (k_intra_plan -> k_intra): per intra block 4nT + 1 16-bit entries (one LDS source per border entry).
- * The blocks of one component of a CTB are disjoint (runtime.hip intra_schedule rejects lists where they are not), which bounds a
+ * The blocks of one component of a CTB are disjoint (runtime_upload.hip intra_schedule rejects lists where they are not), which bounds a
  * CTB's plans by its 4x4-only case, 18 entries per 4x4 block, ... */
-/* DevPic.ib_aux: one EXEC RECORD of four words per intra block (runtime.hip intra_schedule), everything k_intra's block chain needs
+/* DevPic.ib_aux: one EXEC RECORD of four words per intra block (runtime_upload.hip intra_schedule), everything k_intra's block chain needs
  * that is not a sample value:
  *   word 0  bits 0-6 lx, 7-13 ly (position inside the CTB, component samples), 14-16 log2 size, 17-18 component, 19-24 mode, flags:
  *   word 1  residual buffer offset (int16 units) / pcm[] offset
@@ -128,7 +128,7 @@ struct DevPic {
   const m355_pb* pbs;
   const m355_wt* wts;
   const m355_rb* rb_bin[4];         /* residual blocks of 4x4, 8x8, 16x16, 32x32 (rb_count[] entries each) */
-  const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime.hip intra_schedule) */
+  const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime_upload.hip intra_schedule) */
   const uint32_t* ib_aux;           /* per ibs[i]: the block's exec record, 4 words (M355_IBX_*) */
 #ifdef M355_X_PROF
   unsigned long long* prof;         /* timing hooks of experiment builds (tools/variants.sh -DM355_X_PROF=<work item>) */

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_inter_generic(DevPic p)
 #define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
 #endif
 #ifdef M355_X_PROF      /* experiment builds (tools/prof_inter_timeline.py): when a workgroup entered, had its class, its tables, its luma, was done */
-#define TLI(k) do { if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[16384 + 6 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#define TLI(k) do { if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[65536 + 6 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
 #define TLI(k) do { } while (0)
 #endif
@@ -983,7 +983,7 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     __syncthreads();
     TLI(2);
 #ifdef M355_X_PROF
-    if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[16384 + 6 * blockIdx.x + 5] = (unsigned long long)cls + 1;
+    if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[65536 + 6 * blockIdx.x + 5] = (unsigned long long)cls + 1;
 #endif
     if (ji >= jend) return;
     /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
@@ -1289,6 +1289,15 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
        two lists: clip((a + b + rnd2) >> shift2),  shift2 = 15 - bd
      in SATURATING signed 16-bit arithmetic: a sum that leaves int16 is clipped by the reference as well (32767 >> shift2 is exactly the
      largest sample value, 32767 >> shift3 lies above it; -32768 >> s is negative), so the saturated sum gives the same sample. */
+  /* two samples with per-lane weights (put_weighted_pred / _bipred, and the unweighted forms as weights 1 / 0: d_wpred's one formula):
+     ((a w0 + b w1 + rnd) >> sh) + o = (a w0 + b w1 + rnd + (o << sh)) >> sh — one v_dot2 per sample on the pairs (a, b); then the residual
+     (fused order) as add_residual does.  a, b: two samples each, packed */
+  auto wt_pair = [&](unsigned a, unsigned b, unsigned wp, int rnd, int sh, unsigned res, int bd_) {
+    int lo = d_dot2(d_pack_lo16(a, b), wp, rnd) >> sh, hi = d_dot2(d_pack_hi16(a, b), wp, rnd) >> sh;
+    lo = d_clip_bd(lo, bd_); hi = d_clip_bd(hi, bd_);
+    if (fused) { lo = d_clip_bd(lo + d_lo16s(res), bd_); hi = d_clip_bd(hi + d_hi16s(res), bd_); }
+    return (unsigned)lo | ((unsigned)hi << 16);
+  };
   auto pk_pred = [&](unsigned a, unsigned b, unsigned rnd, int sh, unsigned maxv) {
     unsigned t = bi ? d_pk_addsat_i16(a, b) : b;
     t = d_pk_ashr16(d_pk_addsat_i16(t, rnd), sh);
@@ -1342,19 +1351,18 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
         }
       }
       if (WEIGHTED) {
+        /* all four reference formulas as ONE dot2 per sample (see wt_pair): (a, b) . (w0, w1) + rnd', >> sh, clip */
         const WtSel ws = make_ws(0, bd);
+        const unsigned wp = d_pack16(ws.w0, ws.w1);
+        const int rnd = ws.rnd + (int)((unsigned)ws.o << ws.sh);
 #pragma unroll
         for (int y = 0; y < 8; y++) {
           if (y >= rows) break;
-          unsigned o[4];
+          unsigned o[2];
 #pragma unroll
-          for (int x = 0; x < 4; x++) {
-            const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
-            o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
-            o[x] = (unsigned)d_clip_bd((int)o[x] + ((x & 1) ? d_hi16s(rs[y][x >> 1]) : d_lo16s(rs[y][x >> 1])), bd);
-          }
-          if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-          else d_st_nt4(d + (size_t)y * p.stride[0], o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24));
+          for (int jp = 0; jp < 2; jp++) o[jp] = wt_pair(bi ? pa[y][jp] : cur[y][jp], cur[y][jp], wp, rnd, ws.sh, rs[y][jp], bd);
+          if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0], o[1]);
+          else d_st_nt4(d + (size_t)y * p.stride[0], d_pack_bytes(o[0], o[1]));
         }
       } else {
         const int sh = (bi ? 15 : 14) - bd;
@@ -1440,20 +1448,17 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       }
       if (WEIGHTED) {
         const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
+        const unsigned wp1 = d_pack16(ws1.w0, ws1.w1), wp2 = d_pack16(ws2.w0, ws2.w1);
+        const int rnd1 = ws1.rnd + (int)((unsigned)ws1.o << ws1.sh), rnd2 = ws2.rnd + (int)((unsigned)ws2.o << ws2.sh);
 #pragma unroll
         for (int y = 0; y < 4; y++) {
           if (y >= crows) break;
-          {
-            const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
-            const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc1[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc1[y]), bd);
-            if (sizeof(PIX) == 2) d_st_nt4(d1 + (size_t)y * p.stride[1], o0 | (o1 << 16));
-            else *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)(o0 | (o1 << 8));
-          }
-          {
-            const unsigned a = bi ? pa2[y] : cur2[y], b = cur2[y];
-            const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc2[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc2[y]), bd);
-            if (sizeof(PIX) == 2) d_st_nt4(d2 + (size_t)y * p.stride[2], o0 | (o1 << 16));
-            else *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)(o0 | (o1 << 8));
+          const unsigned o1 = wt_pair(bi ? pa1[y] : cur1[y], cur1[y], wp1, rnd1, ws1.sh, rc1[y], bd);
+          const unsigned o2 = wt_pair(bi ? pa2[y] : cur2[y], cur2[y], wp2, rnd2, ws2.sh, rc2[y], bd);
+          if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
+          else {
+            *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
+            *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
           }
         }
       } else {

@@ -33,7 +33,7 @@
  *     16, form R2: no fences, no write-back of the L2).  A consumer stages its halo from the picture where the
  *     neighbouring samples come from the preceding kernels and from the granules where they come from an intra block
  *     of a neighbour CTB; a granule that is not there yet is polled only by the block whose border needs it;
- *   - inside the workgroup the blocks run LEVEL BY LEVEL (host-derived levels, runtime.hip intra_schedule: blocks of
+ *   - inside the workgroup the blocks run LEVEL BY LEVEL (host-derived levels, runtime_upload.hip intra_schedule: blocks of
  *     one level are independent); each colour component has 1, 2, 4 or 8 wavefronts that share a level's blocks, with
  *     a workgroup barrier between levels when there is more than one wave per component;
  *   - the inverse transforms were done up front, in parallel, by k_residual.
@@ -255,11 +255,11 @@ template <int CF> __global__ void __launch_bounds__(256) k_tu_plan(DevPic p, int
  * level, the CTB's residuals and its whole plan are fetched into LDS up front), 4 for inter pictures (a handful of intra
  * blocks per CTB: up to 1-2 + 1 + 1 waves, residual cache lines requested in the prologue and loaded per block behind its
  * border gather, the plan of 64 blocks at a time; the smaller footprint keeps more CTBs in flight).  The CTB's own wave
- * counts come from DevIntraWork.waves_code (runtime.hip intra_schedule). */
+ * counts come from DevIntraWork.waves_code (runtime_upload.hip intra_schedule). */
 /* BATCH (intra pictures only): SEVERAL pictures' CTBs in one launch — pics[0 .. n_pics) in device memory, one shared ticket; ticket t
  * is item t / n_pics of picture t % n_pics (the pictures' wavefronts interleaved: a workgroup still only waits on items claimed
  * before its own, now of its own picture).  Independent intra pictures then overlap CTB by CTB inside one kernel instead of through
- * the runtime's hardware queues (m355_decode_batch, runtime.hip). */
+ * the runtime's hardware queues (m355_decode_batch, runtime_decode.hip). */
 template <class PIX, int CF, int NW, bool DENSE, bool BATCH>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
 {
@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #ifdef M355_X_PROF
   if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item] = (unsigned long long)ctb + 1;
 #endif
-  /* The CTB's exec records (runtime.hip intra_schedule: sorted by level, then component; everything about a block that is not a
+  /* The CTB's exec records (runtime_upload.hip intra_schedule: sorted by level, then component; everything about a block that is not a
      sample value) are fetched 64 at a time (one per lane, 16 bytes, coalesced) by EVERY wave.  A wave's blocks of the batch —
      those of its component whose rank inside their (level, component) group falls to it — are one 64-bit mask; it walks them
      level by level, and all waves meet at the workgroup barrier after every level of the batch (the loop bounds come from the

@@ -90,7 +90,7 @@ __device__ __forceinline__ int d_pb_class(const DevPic& p, const m355_pb& pb)
   if (pb.flags & M355_PBF_WEIGHTED) return 2;
   return ((pb.flags & M355_PBF_MC_L0) && (pb.flags & M355_PBF_MC_L1)) ? 1 : 0;
 }
-/* 16-byte units of edge_tu | edge_pb | cb_cu (prepare() in runtime.hip: cb_cu starts at the next multiple of 64, 64 spare bytes behind) */
+/* 16-byte units of edge_tu | edge_pb | cb_cu (prepare() in runtime_decode.hip: cb_cu starts at the next multiple of 64, 64 spare bytes behind) */
 __host__ __device__ static inline size_t d_meta_fill16(const DevPic& p) { return ((((size_t)2 * p.w4 * p.h4 + 63) & ~(size_t)63) + (size_t)p.wcb * p.hcb * 4 + 15) / 16; }
 /* clear_planes: the launch also zero-fills the metadata planes (edge_tu | edge_pb | cb_cu) that k_meta_planes scatters into — it is the
    first kernel of an inter picture on its lane's main stream, in FRONT of the fork of the side stream: one launch less per picture
@@ -384,7 +384,7 @@ void m355_launch_meta(const DevPic& p, hipStream_t st)
 
 
 /* ---- device-side validation of work lists that were recorded in place (m355_arena_begin): the record checks of the host's
- * validate() (runtime.hip), one thread per record over the concatenation cus | tus | pbs | wts | rbs (4 bins) | ibs.  A rejected
+ * validate() (runtime_upload.hip), one thread per record over the concatenation cus | tus | pbs | wts | rbs (4 bins) | ibs.  A rejected
  * record writes the decode's epoch into the lane's gate word (every later kernel of THIS decode returns at once: bad lists are
  * never acted upon; nothing needs resetting for the next decode) and leaves (list << 28 | record), tagged with the epoch, for the
  * per-decode status the host reads back (m355_decode_status, m355_wait).  (The CTB table and each CTB's intra block geometry

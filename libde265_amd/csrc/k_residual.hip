@@ -376,7 +376,7 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
   d_res_finish<LOG2, PIX, FUSED, true>(p, rbs, rb, active, c, tbi, cfp, w, eb);
 }
 
-/* Two launches, issued side by side on the lane's two streams (runtime.hip, launch_prediction): 32x32 + 16x16 blocks (2 / 4 per
+/* Two launches, issued side by side on the lane's two streams (runtime_decode.hip, launch_prediction): 32x32 + 16x16 blocks (2 / 4 per
  * wave; 128 VGPRs, 8 KB of LDS tiles per wave) and 8x8 + 4x4 blocks (8 / 16 per wave; 66 VGPRs -> 7 waves per SIMD instead of the
  * 3 the 32-point transform's registers would impose on every size).  The stage is a chain of dependent round trips per wave —
  * record, coefficient pairs, destination rows — so resident waves are what hides it.  Larger size first within each launch. */

@@ -1,0 +1,583 @@
+/*
+ * runtime_decode.hip — host side of the picture layer, part 3 of 4: prepare() (scratch, DevPic), the per-picture launch sequence
+ * (launch_prediction, decode_pre / decode_post), the status ring, m355_decode_batch.
+ */
+#include "runtime_internal.h"
+
+extern "C" {
+/* ----------------------------------------------------------------------- decode --------------- */
+
+/* frames, scratch and the device descriptor of one decode of `r` */
+int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
+  hipSetDevice(c->device);
+  const m355_picture& pic = r.hdr;
+  const m355_pic_params& pp = pic.pp;
+  Frame* dst = get_frame(c, pic.dst_frame);
+  if (!dst) return fail(M355_ERR_INVALID, "dst_frame %d is not a live frame", pic.dst_frame);
+  if (dst->w != pp.width || dst->h != pp.height || dst->cf != pp.chroma_format_idc || dst->bdl != pp.bit_depth_luma || dst->bdc != pp.bit_depth_chroma)
+    return fail(M355_ERR_INVALID, "dst frame geometry does not match the picture parameters");
+  DevPic d = r.dp;
+  d.ref_valid = 0;
+  DevRef refs[M355_MAX_REF_FRAMES];
+  memset(refs, 0, sizeof(refs));
+  for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+    if (pic.ref_frames[i] < 0) continue;
+    Frame* f = get_frame(c, pic.ref_frames[i]);
+    if (!f) return fail(M355_ERR_INVALID, "ref_frames[%d]=%d is not a live frame", i, pic.ref_frames[i]);
+    if (f->w != dst->w || f->h != dst->h || f->cf != dst->cf || f->bdl != dst->bdl || f->bdc != dst->bdc)
+      return fail(M355_ERR_INVALID, "reference frame %d geometry differs (motion.cc:377-398 would conceal; record FILL instead)", i);
+    if (f == dst) return fail(M355_ERR_INVALID, "a picture cannot reference itself");
+    for (int cc = 0; cc < 3; cc++) { refs[i].plane[cc] = f->plane[cc]; refs[i].stride[cc] = f->stride[cc]; }
+#ifdef M355_X_TILED
+    for (int cc = 0; cc < 3; cc++) {
+      if (!f->pw[cc]) continue;
+      const int row_len = cc ? M355_TILE_ROW_C : M355_TILE_ROW_L;
+      if (!f->tiled[cc]) {
+        f->tiles_w[cc] = (f->pw[cc] + M355_TILE_W - 1) / M355_TILE_W;
+        const size_t bytes = (size_t)((f->ph[cc] + M355_TILE_H - 1) / M355_TILE_H) * f->tiles_w[cc] * M355_TILE_H * row_len * f->bpp[cc] + 256;
+        HIPCHK(hipMalloc(&f->tiled[cc], bytes));
+        f->tiled_valid = false;
+      }
+      refs[i].tiled[cc] = f->tiled[cc]; refs[i].trs[cc] = f->tiles_w[cc] * M355_TILE_H * row_len;
+    }
+#endif
+    refs[i].valid = 1;
+    d.ref_valid |= 1u << i;
+  }
+  if (!r.refs_dev) {
+    HIPCHK(hipMalloc(&r.refs_dev, sizeof(refs)));
+    HIPCHK(hipHostMalloc(&r.refs_host, sizeof(refs), hipHostMallocDefault));
+    r.refs_valid = false;
+  }
+  if (!r.refs_valid || memcmp(r.refs_host, refs, sizeof(refs)) != 0) {
+    if (!r.fresh) HIPCHK(sync_all(c));       /* a decode in flight may still read the table / the staging copy */
+    memcpy(r.refs_host, refs, sizeof(refs));
+    HIPCHK(hipMemcpyAsync(r.refs_dev, r.refs_host, sizeof(refs), hipMemcpyHostToDevice, c->stream));
+    r.refs_valid = true;
+  }
+  d.refs = r.refs_dev;
+  {
+    /* k_inter_jobs' tap tables: one small constant buffer per (plane type, bit depths) this context has decoded */
+    const uint32_t key = (uint32_t)(dst->bpp[0] == 1) | ((uint32_t)pp.bit_depth_luma << 8) | ((uint32_t)pp.bit_depth_chroma << 16);
+    const uint32_t* tab = nullptr;
+    for (auto& e : c->inter_tabs) if (e.first == key) tab = e.second;
+    if (!tab) {
+      uint32_t host[M355_INTER_TAB_WORDS];
+      m355_inter_tables(dst->bpp[0] == 1, std::min((int)pp.bit_depth_luma, 16), std::min((int)pp.bit_depth_chroma, 16), host);
+      uint32_t* dev = nullptr;
+      HIPCHK(hipMalloc(&dev, sizeof(host)));
+      HIPCHK(hipMemcpy(dev, host, sizeof(host), hipMemcpyHostToDevice));
+      c->inter_tabs.emplace_back(key, dev);
+      tab = dev;
+    }
+    d.inter_tabs = tab;
+  }
+  /* scratch */
+  int rc;
+  {
+    /* edge_tu | edge_pb | cb_cu in one allocation (one memset per picture, k_meta.hip); pb_of separate */
+    const size_t u4 = (size_t)d.w4 * d.h4, ncb = (size_t)d.wcb * d.hcb;
+    const size_t need = ((2 * u4 + 63) & ~(size_t)63) + ncb * 4 + 64;
+    if ((rc = grow(&c->edge_tu, &c->cap_u4, need, c->stream, false))) return rc;
+    if ((rc = grow(&c->pb_of, &c->cap_cb, u4, c->stream, true))) return rc;
+  }
+  {
+    /* k_intra's halo granules: per component ctbW right columns of ph / 2 granules and ctbH bottom rows of pw / 2; zero at
+       allocation, never cleared: a granule is valid when it carries the epoch of the decode that reads it */
+    size_t n = 0;
+    for (int cc = 0; cc < 3; cc++) {
+      d.edge_col_ofs[cc] = (uint32_t)n; n += (size_t)d.ctbW * (size_t)(dst->ph[cc] >> 1);
+      d.edge_row_ofs[cc] = (uint32_t)n; n += (size_t)d.ctbH * (size_t)(dst->pw[cc] >> 1);
+    }
+    if ((rc = grow(&c->edge, &c->cap_edge, n + 1, c->stream, true))) return rc;
+  }
+  if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + (size_t)r.halo.n_units + 1, c->stream, false))) return rc;
+  /* Fused inter residuals (k_common.h res_map): whenever k_inter_jobs runs, k_residual hands the blocks of inter CUs over as int16
+     tiles behind the deferred (intra) ones instead of read-modify-writing the picture.  Not for 16-bit samples (a residual of
+     transform_idct_add, fallback-dct.cc:550-691, needs 18 bits there), not for the generic kernel's chroma formats, not when a
+     stage is isolated. */
+  /* When: with ONE picture in flight (the residual stage then runs beside the job list instead of behind k_inter_jobs: 0.505 vs
+     0.52 ms per C5 picture).  With pictures in flight the read-modify-write order is the faster one although it moves 80 MB more
+     per picture: k_inter_jobs is the stage everything else queues behind, the 20 us the residual rows add to it cost more than the
+     35 us k_residual saves beside the other pictures' kernels (0.379 vs 0.395 ms, profiles/r04_g_*).  M355_RES_FUSED=0 / 1 forces it. */
+  static const int fused_env = getenv("M355_RES_FUSED") ? atoi(getenv("M355_RES_FUSED")) : -1;
+  const bool fused_on = fused_env >= 0 ? fused_env != 0 : c->depth == 1;
+  const bool fused = fused_on && pic.n_pbs > 0 && pp.chroma_format_idc <= 1 && pp.bit_depth_luma < 16 && pp.bit_depth_chroma < 16 &&
+                     (c->stages & M355_STAGE_INTER) && (c->stages & M355_STAGE_RESIDUAL) &&
+                     (pic.rb_count[0] | pic.rb_count[1] | pic.rb_count[2] | pic.rb_count[3]);
+  size_t res_need = (size_t)pic.res_len + 1;
+  d.res_map = nullptr;
+  if (fused) {
+    size_t base = ((size_t)pic.res_len + 15) & ~(size_t)15;
+    for (int s = 0; s < 4; s++) { d.res_fused_base[s] = (uint32_t)base; base += (size_t)pic.rb_count[s] << (2 * (s + 2)); }
+    if (base >= ((size_t)1 << 30)) return fail(M355_ERR_INVALID, "residual blocks exceed the fused residual buffer");
+    res_need = base + 1;
+    size_t n = 0;
+    for (int cc = 0; cc < (pp.chroma_format_idc ? 3 : 1); cc++) {
+      d.res_map_ofs[cc] = (uint32_t)n; d.res_map_w[cc] = (dst->pw[cc] + 3) >> 2;
+      n += (size_t)d.res_map_w[cc] * ((dst->ph[cc] + 3) >> 2);
+    }
+    if ((rc = grow(&c->res_map, &c->cap_resmap, n + 1, c->stream, false))) return rc;
+    d.res_map = c->res_map;
+    d.res_map_words = (uint32_t)n;
+  }
+  if ((rc = grow(&c->resbuf, &c->cap_res, res_need, c->stream, false))) return rc;
+  if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
+  {
+    /* inter jobs of 4 x 8 luma samples: a list of disjoint prediction blocks makes at most one per 16 luma samples (8x4 blocks),
+       and at most one per 32 plus eight per block; the counts themselves are made on the device (k_job_count / k_job_scan) */
+    const size_t area = (size_t)pp.width * pp.height;
+    const size_t cap = pic.n_pbs > 0 ? std::min(area / 16, area / 32 + 8 * (size_t)pic.n_pbs) + 256 : 1;
+    const size_t n_chunks = ((size_t)(pic.n_pbs > 0 ? pic.n_pbs : 0) + 255) / 256;
+    if ((rc = grow(&c->jobs, &c->cap_jobs, cap, c->stream, false))) return rc;
+    if ((rc = grow(&c->job_base, &c->cap_jobbase, n_chunks * 4 + 8, c->stream, true))) return rc;
+    d.jobs_cap = (uint32_t)cap; d.job_base = c->job_base; d.job_tot = c->job_base + n_chunks * 4;
+  }
+  if ((rc = grow(&c->iplan, &c->cap_iplan, (size_t)r.n_iplan + 8, c->stream, false))) return rc;
+
+  const bool want_sao = (c->stages & M355_STAGE_SAO) && (pp.flags & M355_PF_SAO_ENABLED);
+  Frame* target = dst;
+  if (want_sao) {
+    if (!c->work.used || c->work.w != dst->w || c->work.h != dst->h || c->work.cf != dst->cf || c->work.bdl != dst->bdl || c->work.bdc != dst->bdc) {
+      HIPCHK(sync_all(c));
+      if (c->work.used) frame_free(c->work);
+      frame_geometry(c->work, dst->w, dst->h, dst->cf, dst->bdl, dst->bdc);
+      if ((rc = frame_alloc(c->work, c->stream))) return rc;
+    }
+    target = &c->work;
+  }
+  for (int cc = 0; cc < 3; cc++) {
+    d.pw[cc] = dst->pw[cc]; d.ph[cc] = dst->ph[cc];
+    d.plane[cc] = target->plane[cc]; d.stride[cc] = target->stride[cc];
+    d.out_plane[cc] = dst->plane[cc]; d.out_stride[cc] = dst->stride[cc];
+  }
+  d.edge_tu = c->edge_tu; d.edge_pb = c->edge_tu + (size_t)d.w4 * d.h4;
+  d.cb_cu = (uint32_t*)(c->edge_tu + (((size_t)2 * d.w4 * d.h4 + 63) & ~(size_t)63));
+  d.cuf = c->cuf; d.pb_of = c->pb_of;
+  d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && pp.chroma_format_idc <= 1) ? 0 : 1;   /* else k_inter_jobs writes it */
+  d.jobs = c->jobs; d.sao_nb = c->sao_nb; d.iplan = c->iplan;
+#ifdef M355_X_PROF
+  {
+    static unsigned long long* prof = nullptr;
+    if (!prof) { hipMalloc(&prof, 8 * 131072); }
+    hipMemsetAsync(prof, 0, 8 * 131072, c->stream);
+    d.prof = prof;
+    g_prof = prof;
+  }
+#endif
+  d.resbuf = c->resbuf; d.edge = c->edge; d.ticket = c->ticket; d.timeout = c->timeout;
+  {
+    /* intra pictures: k_intra's workgroups are persistent (k_intra.hip); with several pictures in flight every picture gets a
+       share of the GPU's workgroup slots (2 per CU for this kernel) — enough for its active wavefront, not a slot per CTB */
+    static const int grid_env = getenv("M355_INTRA_GRID") ? atoi(getenv("M355_INTRA_GRID")) : 0;
+    static int slots = 0;
+    if (!slots) { hipDeviceProp_t prop; slots = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512; }
+    d.intra_grid = grid_env > 0 ? grid_env : std::max(64, slots / std::max(1, c->depth));
+  }
+  d.epoch = ++c->epoch;
+  if (d.epoch == 0) d.epoch = ++c->epoch;
+  d_out = d; want_sao_out = want_sao;
+  return M355_OK;
+}
+
+hipError_t frame_event(hipEvent_t* e) {
+  if (*e) return hipSuccess;
+  return hipEventCreateWithFlags(e, hipEventDisableTiming);
+}
+
+/* The prediction half of a decode on the active lane: the metadata planes (read first by k_intra) are rasterised on the side
+ * stream while the main stream runs job list -> inter prediction, which do not read them; the residual stage then runs in two
+ * launches side by side — 32x32 + 16x16 blocks on the main stream, 8x8 + 4x4 on the side stream — and k_intra follows the join.
+ * ev: the decode's timing events [1..4] (after meta jobs / inter / residual / intra) or nullptr. */
+/* M355_PF_CLEAR_DST: a new picture starts from zero in the reference (image.cc:164); the planes being reconstructed are this
+ * lane's working planes (SAO rewrites every sample of the destination) or the destination itself — then, for lists checked on
+ * the device, by a kernel behind the decode's gate: a rejected picture must leave its destination frame untouched
+ * (de265_mi355x.h, m355_decode_status). */
+void clear_target(m355_ctx* c, const DevPic& d, Frame* tgt, bool gated, hipStream_t st) {
+  for (int cc = 0; cc < 3; cc++) {
+    if (!tgt->pw[cc]) continue;
+    const size_t bytes = (size_t)tgt->stride[cc] * tgt->ph[cc] * tgt->bpp[cc];
+    if (gated) m355_launch_clear_gated(d, tgt->plane[cc], bytes, st);
+    else hipMemsetAsync(tgt->plane[cc], 0, bytes, st);
+  }
+}
+
+void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra) {
+  hipStream_t st = c->stream;
+  /* an intra picture keeps to its lane's main stream: its side work (metadata planes, border plans: 0.07 ms) is nothing beside k_intra,
+     and half as many streams compete for the runtime's hardware queues when many such pictures are in flight (C2 0.340 ms per picture
+     = 1.50 M CTB64/s at depth 9, profiles/r03_v_*; forked: 0.59 at depth 8) — and so does a picture of up to 4K: the fork / join of the
+     side stream is six packets (three event records, three waits) at about 2 us of pipeline time each, and what they buy — the metadata
+     scatters and the second residual launch beside the main stream — is worth less than that once the kernels are short (three in
+     flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms on one stream, C5 0.347 -> 0.351) */
+  const bool single = d.intra_dense || (long long)d.pp.width * d.pp.height <= 16ll << 20;
+  const bool fused = d.res_map != nullptr;   /* prepare(): the residuals of inter CUs are added in k_inter_jobs' write-back */
+  hipStream_t s2 = single ? st : c->stream2;
+  /* the zero fill of the metadata planes rides in the picture's first main-stream launch (k_job_count), in FRONT of the fork: the
+     side stream's scatters then start behind it — one launch less per inter picture (not with fused residuals: there the side
+     stream starts with the residual stage, and the job count comes later) */
+  /* (the fill is shared out over the launch's workgroups, one per 256 PBs: with a handful of them a fill of its own is faster;
+     M355_CLEAR_IN_COUNT_MIN=<PBs> moves the threshold: tests/test_meta_merged_emu.py sends the CPU tier's small pictures down this path —
+     and through the merged planes + job-list launch behind it — with 1) */
+  static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
+  const bool clear_in_count = !fused && d.n_pbs >= std::max(1, clear_min);
+  if (clear_in_count) m355_launch_job_count(d, true, st);
+  if (fused) hipMemsetAsync(d.res_map, 0, (size_t)d.res_map_words * 4, st);
+  if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
+  if (fused) {
+    /* the residual stage reads nothing but the lists: it runs FIRST, side by side on the lane's two streams, beside the tail of
+       the previous picture; its event order is [residual, meta, inter] (m355_timing_collect) */
+    m355_launch_residual(d, hbd, false, s2);
+    if (!single) hipEventRecord(c->ev_fork2, s2);
+    m355_launch_residual(d, hbd, true, st);
+    if (ev) hipEventRecord(ev[1], st);
+  }
+  /* transform edges and border plans in ONE launch (a packet less per picture: C3 0.098 -> 0.093 ms, profiles/r05_a_switches_merge.txt) */
+  if (single && clear_in_count && (c->stages & M355_STAGE_INTRA)) {
+    /* one stream: the planes' scatters and the job list are independent roles of ONE launch (k_meta_planes_jobs) */
+    m355_launch_meta_planes_jobs(d, st);
+    m355_launch_tu_plan(d, st);
+  } else {
+    if (c->stages & M355_STAGE_INTRA) {
+      m355_launch_meta_planes(d, s2, clear_in_count, false);
+      m355_launch_tu_plan(d, s2);
+    } else m355_launch_meta_planes(d, s2, clear_in_count);
+    if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
+  }
+  if (ev) hipEventRecord(ev[fused ? 2 : 1], st);
+  /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
+     reference — the list copy, validation, metadata planes, job list (and fused residuals) of a picture run beside the tail
+     (filters) of the picture it references */
+  if (c->depth >= 2)
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+      if (f) ev_wait(c, st, f->wr);
+    }
+  if (fused && !single) hipStreamWaitEvent(st, c->ev_fork2, 0);   /* the 8x8 + 4x4 tiles */
+#ifdef M355_X_TILED
+  if ((c->stages & M355_STAGE_INTER) && d.n_pbs)
+    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+      if (!f || !f->tiled[0]) continue;
+      if (!f->tiled_valid) {                 /* the conversion pass (its time is the experiment's cost side: k_tile_convert in the kernel trace) */
+        for (int cc = 0; cc < 3; cc++) if (f->pw[cc]) m355_launch_tile_convert(f->plane[cc], f->stride[cc], f->pw[cc], f->ph[cc], f->bpp[cc], cc != 0, f->tiled[cc], f->tiles_w[cc], st);
+        if (!f->ev_tiled) hipEventCreateWithFlags(&f->ev_tiled, hipEventDisableTiming);
+        hipEventRecord(f->ev_tiled, st);
+        f->tiled_valid = true;
+      } else if (f->ev_tiled) hipStreamWaitEvent(st, f->ev_tiled, 0);
+    }
+#endif
+  if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
+  if (ev) hipEventRecord(ev[fused ? 3 : 2], st);
+  if (!fused && (c->stages & M355_STAGE_RESIDUAL)) {
+    /* inter residuals are added to the prediction samples: behind k_inter_jobs; the two launches side by side on the lane's two
+       streams (one after the other on the main stream, without the second fork, was measured 1 % slower at C5 with three
+       pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
+    hipStream_t sr = !single ? s2 : st;
+    if (sr != st) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }
+    m355_launch_residual(d, hbd, false, sr);
+    m355_launch_residual(d, hbd, true, st);
+  }
+  if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
+  if (!fused && ev) hipEventRecord(ev[3], st);
+  if (with_intra && (c->stages & M355_STAGE_INTRA)) m355_launch_intra(d, hbd, st, clear_in_count);   /* (m355_decode_batch launches several pictures' intra stage as one kernel) */
+  if (ev) hipEventRecord(ev[4], st);
+}
+
+/* write-after-write / write-after-read on the destination: waited for right before the first kernel that writes it — the SAO
+   stage when SAO runs (everything before writes this lane's working planes), else the first stage */
+void dst_hazards(m355_ctx* c, Frame* dstf, bool piped) {
+  if (dstf->dl_pending) hipStreamWaitEvent(c->stream, dstf->ev_dl, 0);     /* (stays pending for the HOST until m355_frame_download_wait / m355_wait) */
+  if (!piped) return;
+  ev_wait(c, c->stream, dstf->wr);
+  for (int k = 0; k < M355_MAX_LANES; k++) ev_wait(c, c->stream, dstf->rd[k]);
+}
+
+/* One decode = decode_pre (lane, hazards, validation, every stage in front of the intra stage [and, with_intra, that stage]) +
+ * decode_post (in-loop filters, events, status slot).  m355_decode_batch runs the pre part of several intra pictures on their lanes,
+ * ONE k_intra launch for all of them, then their post parts. */
+struct DecodeState { DevPic d; bool want_sao = false; hipEvent_t* ev = nullptr; hipStream_t saved_stream = nullptr; bool swapped = false; };
+
+/* front: PRE_ALL = everything up to and including the intra stage; PRE_NO_INTRA = without k_intra; PRE_HAZARDS = lane, hazards, validation and
+   clearing only (m355_decode_batch launches the stages itself, one launch per stage for all its pictures) */
+enum { PRE_ALL = 0, PRE_NO_INTRA = 1, PRE_HAZARDS = 2 };
+static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int mode, hipStream_t on_stream = nullptr)
+{
+  const bool with_intra = mode == PRE_ALL;
+  if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
+  if (rotate && c->depth >= 2) select_lane(c, (c->active + 1) % c->depth);   /* consecutive pictures go round the lanes */
+  /* which stream: an intra picture on lane 3.. takes the lane's class stream (lane_class_priority); the whole decode addresses
+     c->stream, which is that stream until decode_post returns (a batch keeps to the lanes' ordinary streams: its pictures overlap
+     inside one kernel, not through hardware queues) */
+  {
+    hipStream_t run = on_stream ? on_stream : c->stream;   /* (a batch on a stream of its own: its lanes lend their scratch only) */
+    if (!on_stream && with_intra && r.dp.intra_dense && c->active >= 3 && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
+      if (!c->stream_hi) HIPCHK(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, lane_class_priority(c->active)));
+      run = c->stream_hi;
+    }
+    ev_wait(c, run, c->last);                              /* the lane's scratch and working planes (when its last decode ran on its other stream) */
+    S.saved_stream = c->stream; S.swapped = run != c->stream;
+    c->stream = run;
+  }
+  DevPic& d = S.d;
+  int rc = prepare(c, r, d, S.want_sao);
+  if (rc) return rc;
+  const bool want_sao = S.want_sao;
+  const m355_pic_params& pp = r.hdr.pp;
+  const bool hbd = pp.bit_depth_luma > 8;
+  const bool piped = c->depth >= 2;
+  Frame* dstf = get_frame(c, r.hdr.dst_frame);
+  if (piped) {
+    /* read-after-write: the lists (uploaded on whichever lane was active); the reference frames' last writers: launch_prediction */
+    ev_wait(c, c->stream, r.up);
+  }
+  hipStream_t st = c->stream;
+  hipEvent_t* ev = nullptr;
+  if (with_intra && c->timing_on) {                        /* (a batch's decodes are not stage-timed: their intra stage is shared) */
+    if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
+    while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
+    ev = &c->evs[c->ev_used * 7];
+    if ((int)c->ev_fused.size() <= c->ev_used) c->ev_fused.resize(c->ev_used + 1);
+    c->ev_fused[c->ev_used] = d.res_map != nullptr;
+    c->ev_used++;
+    hipEventRecord(ev[0], st);
+  }
+  S.ev = ev;
+  if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
+  if (!want_sao) dst_hazards(c, dstf, piped);
+  if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, want_sao ? &c->work : dstf, r.device_validate && !want_sao, st);
+  if (mode != PRE_HAZARDS) launch_prediction(c, r, d, hbd, ev, with_intra);
+  return M355_OK;
+}
+
+static int decode_post(m355_ctx* c, Resident& r, DecodeState& S, bool filters = true)
+{
+  struct StreamRestore { m355_ctx* c; DecodeState& S; ~StreamRestore() { if (S.swapped) c->stream = S.saved_stream; } } restore{c, S};
+  const DevPic& d = S.d;
+  const bool want_sao = S.want_sao;
+  hipEvent_t* ev = S.ev;
+  const m355_pic_params& pp = r.hdr.pp;
+  const bool hbd = pp.bit_depth_luma > 8;
+  const bool piped = c->depth >= 2;
+  Frame* dstf = get_frame(c, r.hdr.dst_frame);
+  hipStream_t st = c->stream;
+  const bool deblock = filters && (c->stages & M355_STAGE_DEBLOCK) && (pp.flags & M355_PF_DEBLOCK_ENABLED);
+  /* (the horizontal-edge pass inside the SAO kernel was built, is bit-exact on hardware and loses: C5 0.357 -> 0.392 ms per picture,
+     SAO 50 -> 104 us for 24 us less deblocking — profiles/r05_a_switches_fuse_dbh.txt, tools/experiments/sao_fused_deblock_h.patch) */
+  if (deblock) m355_launch_deblock(d, hbd, st);
+  if (ev) hipEventRecord(ev[5], st);
+  if (filters && want_sao) { dst_hazards(c, dstf, piped); m355_launch_sao(d, hbd, st); }
+  if (ev) hipEventRecord(ev[6], st);
+  /* ONE mark behind the decode's last kernel for everything that has to know when it is over: the lists' arenas, the destination
+     frame's next reader / writer, the reference frames' next writer, the lane's next decode, the status slot */
+  EvRef done;
+  {
+    const int rcm = ev_mark(c, st, &done);
+    if (rcm) return rcm;
+  }
+  r.done = done; r.fresh = false;
+#ifdef M355_X_TILED
+  dstf->tiled_valid = false;
+#endif
+  dstf->wr_stream = st;
+  dstf->wr = done;
+  for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
+    Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
+    if (f) f->rd[c->active] = done;
+  }
+  if (ev) c->timed = true;
+  {
+    /* this decode's status slot; a device-validated decode also brings its lane's gate words back — behind the mark the dependent
+       decodes wait on, with a mark of its own: nobody waits for this copy but m355_decode_status / m355_wait */
+    m355_ctx::Status& s = c->status[++c->serial % M355_STATUS_RING];
+    if (s.serial && s.validated && !s.reported) {
+      /* the slot's previous decode (M355_STATUS_RING submits ago) was never asked about: resolve it before its words are
+         overwritten — a rejection must not get lost (m355_wait promises to report it) */
+      ev_sync(c, s.done);
+      if (c->status_words[4 * (s.serial % M355_STATUS_RING) + 1] == s.epoch) { if (!c->lost_count++) c->lost_first = s.serial; }
+    }
+    s.serial = c->serial; s.epoch = d.epoch; s.validated = r.device_validate; s.reported = false;
+    s.done = done;
+    if (r.device_validate) {
+      if (!c->status_words) HIPCHK(hipHostMalloc(&c->status_words, 16 * M355_STATUS_RING, hipHostMallocDefault));
+      hipMemcpyAsync(c->status_words + 4 * (c->serial % M355_STATUS_RING), c->timeout, 16, hipMemcpyDeviceToHost, st);
+      const int rcm = ev_mark(c, st, &s.done);
+      if (rcm) return rcm;
+    }
+  }
+  c->last = done; c->last_stream = st;                       /* (the lane's next decode may run on the lane's other stream) */
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(M355_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  {
+    /* M355_DEBUG_TIMEOUT=1: name the decode whose intra stage gave up a wait (diagnostic: serialises the pipeline) */
+    static const bool dbg = getenv("M355_DEBUG_TIMEOUT") && atoi(getenv("M355_DEBUG_TIMEOUT"));
+    if (dbg) {
+      hipStreamSynchronize(st);
+      uint32_t t = 0;
+      hipMemcpy(&t, c->timeout, 4, hipMemcpyDeviceToHost);
+      if (t) fprintf(stderr, "m355: decode %llu (epoch %u, %d pbs, %d ibs, %d cus, lane %d): intra wait gave up\n", c->serial, d.epoch, d.n_pbs, d.n_ibs, d.n_cus, c->active);
+    }
+  }
+  return M355_OK;
+}
+
+int decode(m355_ctx* c, Resident& r, bool rotate) {
+  DecodeState S;
+  int rc = decode_pre(c, r, rotate, S, PRE_ALL);
+  if (rc) { if (S.swapped) c->stream = S.saved_stream; return rc; }
+  return decode_post(c, r, S);
+}
+
+/* status of one finished decode from its ring slot: M355_OK, or M355_ERR_INVALID with the rejected record in the message */
+int status_of(m355_ctx* c, m355_ctx::Status& s) {
+  if (!s.validated) return M355_OK;
+  const uint32_t* w = c->status_words + 4 * (s.serial % M355_STATUS_RING);
+  if (w[1] != s.epoch) return M355_OK;                       /* the lane's last rejected decode is another one */
+  const unsigned long long key = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+  uint32_t bad = (uint32_t)key;
+  if ((uint32_t)(key >> 32) != ~s.epoch) bad = 0;            /* (cannot happen: gate and key are written together) */
+  static const char* const names[8] = {"?", "cu", "tu", "pb", "weight", "rb", "ib", "?"};
+  s.reported = true;
+  return fail(M355_ERR_INVALID, "picture %llu: %s %u rejected by the device-side list validation (the picture was not decoded)", s.serial, names[(bad >> 28) & 7], bad & 0x0FFFFFFFu);
+}
+
+unsigned long long m355_last_serial(m355_ctx* c) { return c->serial; }
+
+int m355_decode_status(m355_ctx* c, unsigned long long serial)
+{
+  if (serial == 0 || serial > c->serial) return fail(M355_ERR_INVALID, "no decode with serial %llu", serial);
+  m355_ctx::Status& s = c->status[serial % M355_STATUS_RING];
+  if (s.serial != serial) return fail(M355_ERR_INVALID, "decode %llu is older than the last %d decodes: its status is no longer kept (m355_wait reports rejections)", serial, M355_STATUS_RING);
+  hipSetDevice(c->device);
+  const hipError_t q = ev_query(c, s.done);
+  if (q == hipErrorNotReady) return M355_ERR_BUSY;
+  if (q != hipSuccess) return fail(M355_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+  return status_of(c, s);
+}
+
+/* Several independent intra pictures as ONE intra stage: every picture's front part (validation, residuals, border plans) on its own
+ * lane, then one k_intra<BATCH> launch over all their CTB wavefronts, then every picture's filters on its lane again.  What more
+ * lanes buy an intra picture — other pictures' CTBs filling the GPU while its own wavefront is narrow — without one hardware queue per
+ * picture. */
+int m355_decode_batch(m355_ctx* c, const int* handles, int n)
+{
+  if (n < 1 || !handles) return fail(M355_ERR_INVALID, "m355_decode_batch: no pictures");
+  if (n > std::max(1, c->depth)) return fail(M355_ERR_INVALID, "m355_decode_batch: %d pictures on %d lanes (m355_set_pipeline_depth)", n, c->depth);
+  for (int k = 0; k < n; k++) {
+    const int h = handles[k];
+    if (h < 0 || h >= (int)c->resident.size() || !c->resident[h].used) return fail(M355_ERR_INVALID, "bad picture handle");
+    for (int j = 0; j < k; j++) if (handles[j] == h) return fail(M355_ERR_INVALID, "m355_decode_batch: picture %d twice in one batch", h);
+    const Resident& r = c->resident[h];
+    const m355_pic_params &a = r.hdr.pp, &b = c->resident[handles[0]].hdr.pp;
+    if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
+    /* (pictures of a batch must not reference one another: their frames' writer events are recorded behind the shared launch) */
+    if (!r.dp.intra_dense || r.dp.n_pbs > 0) return fail(M355_ERR_INVALID, "m355_decode_batch: picture %d is not an intra picture", h);
+    if (a.chroma_format_idc != b.chroma_format_idc || (a.bit_depth_luma > 8) != (b.bit_depth_luma > 8))
+      return fail(M355_ERR_INVALID, "m355_decode_batch: the pictures differ in chroma format or sample type");
+    for (int j = 0; j < k; j++)
+      if (c->resident[handles[j]].hdr.dst_frame == r.hdr.dst_frame) return fail(M355_ERR_INVALID, "m355_decode_batch: two pictures into frame %d", r.hdr.dst_frame);
+  }
+  hipSetDevice(c->device);
+  if (n == 1 || !(c->stages & M355_STAGE_INTRA)) {
+    for (int k = 0; k < n; k++) { int rc = decode(c, c->resident[handles[k]]); if (rc) return rc; }
+    return M355_OK;
+  }
+  DecodeState S[M355_MAX_LANES];
+  int lane[M355_MAX_LANES];
+  int rc_late = M355_OK, n_ok = 0;
+  /* Where the batch runs.  M355_BATCH_STREAMS=N (default 4): whole batches go round N streams of their own — front parts, the shared
+     launch and the filters of ONE batch are one stream's worth of work (they depend on one another anyway), consecutive batches on
+     different lanes overlap on different hardware queues; the lanes lend their scratch and working planes.  =0: every picture's front
+     part and filters on its own lane's stream, the shared launch on the first lane's (measured slower: 16 lanes' small kernels
+     serialise on the runtime's four hardware queues AND with the batch, profiles/r04_n_c2_batch.txt). */
+  static const int streams_env = getenv("M355_BATCH_STREAMS") ? std::min(4, std::max(0, atoi(getenv("M355_BATCH_STREAMS")))) : -1;
+  /* as many streams as batches of this size fit the lanes side by side (batches that share lanes run one after the other anyway) */
+  const int n_streams = streams_env >= 0 ? streams_env : std::min(4, std::max(1, c->depth / n));
+  hipStream_t bs = nullptr;
+  if (n_streams > 0) {
+    const int j = (int)(c->batch_count++ % (unsigned)n_streams);
+    if (!c->batch_stream[j]) HIPCHK(hipStreamCreateWithFlags(&c->batch_stream[j], hipStreamNonBlocking));
+    bs = c->batch_stream[j];
+  }
+  for (int k = 0; k < n; k++) {
+    Resident& r = c->resident[handles[k]];
+    const int rc = decode_pre(c, r, true, S[k], bs ? PRE_HAZARDS : PRE_NO_INTRA, bs);
+    if (S[k].swapped) { c->stream = S[k].saved_stream; S[k].swapped = false; }   /* (select_lane parks c->stream with the lane) */
+    if (rc) { rc_late = rc; break; }                 /* the pictures in front of it are finished as a shorter batch */
+    lane[k] = c->active;
+    if (!bs) {
+      if (!c->batch_ev_pre[k] && hipEventCreateWithFlags(&c->batch_ev_pre[k], hipEventDisableTiming) != hipSuccess) return fail(M355_ERR_HIP, "hipEventCreate failed");
+      hipEventRecord(c->batch_ev_pre[k], c->stream);
+    }
+    n_ok++;
+  }
+  if (!n_ok) return rc_late;
+  m355_ctx::BatchSlot& b = c->batch[c->batch_next];
+  c->batch_next = (c->batch_next + 1) % M355_BATCH_RING;
+  if (!b.dev) {
+    HIPCHK(hipHostMalloc((void**)&b.host, sizeof(DevPic) * M355_MAX_LANES, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&b.dev, sizeof(DevPic) * M355_MAX_LANES + 64));
+    b.ticket = (uint32_t*)((uint8_t*)b.dev + sizeof(DevPic) * M355_MAX_LANES);
+    HIPCHK(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+  }
+  if (b.pending) { hipEventSynchronize(b.ev); b.pending = false; }     /* (M355_BATCH_RING batches ago) */
+  select_lane(c, lane[0]);
+  hipStream_t st0 = bs ? bs : c->stream;
+  int max_work = 0; long total = 0;
+  for (int k = 0; k < n_ok; k++) {
+    b.host[k] = S[k].d;
+    max_work = std::max(max_work, S[k].d.n_intra_work); total += S[k].d.n_intra_work;
+    if (k && !bs) hipStreamWaitEvent(st0, c->batch_ev_pre[k], 0);
+  }
+  hipMemcpyAsync(b.dev, b.host, sizeof(DevPic) * n_ok, hipMemcpyHostToDevice, st0);
+  hipMemsetAsync(b.ticket, 0, 4, st0);
+  const bool hbd = c->resident[handles[0]].hdr.pp.bit_depth_luma > 8;
+  const HostBatch hb{b.host, b.dev, n_ok, n_ok >= 32 ? 0xFFFFFFFFu : (1u << n_ok) - 1u};
+  if (bs) {
+    /* the stages in front of the intra stage, each ONE launch over the batch's pictures (launch_prediction's order for an intra
+       picture: metadata planes, border plans, 8x8 + 4x4 residuals, 32x32 + 16x16 residuals) */
+    m355_launch_meta_planes_batch(hb, st0);
+    if (c->stages & M355_STAGE_INTRA) m355_launch_intra_plan_batch(hb, st0);
+    if (c->stages & M355_STAGE_RESIDUAL) { m355_launch_residual_batch(hb, hbd, false, st0); m355_launch_residual_batch(hb, hbd, true, st0); }
+  }
+  {
+    static const int grid_env = getenv("M355_INTRA_GRID") ? atoi(getenv("M355_INTRA_GRID")) : 0;
+    static int slots = 0;
+    if (!slots) { hipDeviceProp_t prop; slots = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512; }
+    /* persistent workgroups of the shared launch: a batch on its own takes every slot of the GPU (4 pictures, 64 -> 512 workgroups:
+       0.573 -> 0.484 ms per picture); batches side by side take what covers their pictures' widest wavefronts (CTB (x, y) runs at
+       step x + 2y: 16 for 1080p) or half their share of the slots — more only spin and crowd the other batches' kernels (32 pictures
+       as 4 x 8, 512 -> 128 workgroups each: 0.161 -> 0.126; 16 as 4 x 4, 128 -> 64: 0.181 -> 0.160; profiles/r04_n_c2_batch.txt) */
+    int widest = 0;
+    for (int k = 0; k < n_ok; k++) widest += std::min(S[k].d.ctbH, (S[k].d.ctbW + 1) / 2) + 1;
+    const int grid = (int)std::min<long>(std::max<long>(total, 1), grid_env > 0 ? grid_env : std::min(slots, n_streams <= 1 ? slots : std::max(widest, slots / (2 * n_streams))));
+    m355_launch_intra_batch(S[0].d, hbd, b.dev, n_ok, max_work, b.ticket, grid, st0);
+  }
+  hipEventRecord(b.ev, st0); b.pending = true;
+  if (bs) {
+    /* the in-loop filters of the whole batch: two deblocking launches, one SAO launch (its pictures' destination hazards in front) */
+    uint32_t dbk = 0, sao = 0;
+    for (int k = 0; k < n_ok; k++) {
+      if ((c->stages & M355_STAGE_DEBLOCK) && (c->resident[handles[k]].hdr.pp.flags & M355_PF_DEBLOCK_ENABLED)) dbk |= 1u << k;
+      if (S[k].want_sao) sao |= 1u << k;
+    }
+    if (dbk) m355_launch_deblock_batch(HostBatch{b.host, b.dev, n_ok, dbk}, hbd, st0);
+    if (sao) {
+      hipStream_t keep = c->stream;
+      c->stream = bs;
+      for (int k = 0; k < n_ok; k++) if ((sao >> k) & 1u) dst_hazards(c, get_frame(c, c->resident[handles[k]].hdr.dst_frame), c->depth >= 2);
+      c->stream = keep;
+      m355_launch_sao_batch(HostBatch{b.host, b.dev, n_ok, sao}, hbd, st0);
+    }
+    hipEventRecord(b.ev, st0);     /* the filter launches read the slot's records too: the slot is free behind THEM */
+  }
+  for (int k = 0; k < n_ok; k++) {
+    select_lane(c, lane[k]);
+    if (bs) { S[k].saved_stream = c->stream; c->stream = bs; S[k].swapped = true; }      /* (decode_post puts the lane's stream back) */
+    else if (k) hipStreamWaitEvent(c->stream, b.ev, 0);
+    const int rc = decode_post(c, c->resident[handles[k]], S[k], !bs);
+    if (rc && !rc_late) rc_late = rc;
+  }
+  return rc_late;
+}
+} /* extern "C" */

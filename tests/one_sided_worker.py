@@ -1,4 +1,4 @@
-"""Parity cases with k_intra's dependency levels derived from what each intra MODE can read (runtime.hip intra_schedule): python one_sided_worker.py <library .so or "default"> <oracle .so>.  Exit code 0 = every picture
+"""Parity cases with k_intra's dependency levels derived from what each intra MODE can read (runtime_upload.hip intra_schedule): python one_sided_worker.py <library .so or "default"> <oracle .so>.  Exit code 0 = every picture
 equals the oracle's.  A dependency dropped wrongly lets a block run before (or beside) a block it reads from: the interpreter's
 shuffled wave order and non-zero memory turn that into different samples."""
 import ctypes

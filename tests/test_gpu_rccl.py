@@ -1,4 +1,4 @@
-"""The built-in RCCL transport of the tile-sharded mode (csrc/runtime.hip: m355_shard_rccl_init, rccl_halo_sum = grouped
+"""The built-in RCCL transport of the tile-sharded mode (csrc/runtime_shard.hip: m355_shard_rccl_init, rccl_halo_sum = grouped
 ncclSend / ncclRecv per neighbour + k_halo_add, rccl_all_gather = ncclAllGather in place) on real hardware.  The pool's boxes
 have ONE GPU, so (a) a communicator of one rank moves real bytes through every call (a grouped self-send), and (b) TWO rank
 processes share the one GPU — if this RCCL build accepts two ranks on one device, the whole sharded decode (X0..X3 between two

@@ -1,4 +1,4 @@
-"""k_intra's dependency levels come from what each intra MODE can read (runtime.hip intra_schedule; the default since round 5: 42 % fewer
+"""k_intra's dependency levels come from what each intra MODE can read (runtime_upload.hip intra_schedule; the default since round 5: 42 % fewer
 levels = barrier steps of the chain on the all-intra 1080p picture of BASELINE config 2, bit-exact on hardware, profiles/r05_a_*).
 Bit-exact against the oracle under the SIMT interpreter (shuffled wave order, non-zero memory: a dependency dropped wrongly lets a block
 run before or beside a block it reads from) and on the GPU, in a process of its own with the level statistics on: the picture with

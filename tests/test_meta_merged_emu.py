@@ -1,5 +1,5 @@
 """Pictures of 16 384 prediction blocks and more clear their metadata planes inside k_job_count and, on a single-stream lane, run the
-CU plane, the SAO masks and k_inter_jobs' job list as roles of ONE launch (k_meta_planes_jobs, runtime.hip launch_prediction).  The CPU
+CU plane, the SAO masks and k_inter_jobs' job list as roles of ONE launch (k_meta_planes_jobs, runtime_decode.hip launch_prediction).  The CPU
 tier's pictures are smaller than that: M355_CLEAR_IN_COUNT_MIN=1 (read once per process) sends them down the same path under the SIMT
 interpreter — the synthetic and the random picture suites once more, in a process of their own."""
 import os

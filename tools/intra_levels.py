@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dependency-level counts of k_intra's chain for named workloads (runtime.hip intra_schedule; host side only, interpreter library):
+"""Dependency-level counts of k_intra's chain for named workloads (runtime_upload.hip intra_schedule; host side only, interpreter library):
 M355_INTRA_LEVEL_STATS=1 M355_INTRA_ONE_SIDED=0|1 python tools/intra_levels.py c2_1080p_intra c3_4k_inter c5_8k10_8tiles"""
 import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 from libde265_amd import capi, synth, worklist

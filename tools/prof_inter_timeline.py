@@ -19,10 +19,10 @@ pic.dst_frame = ctx.frame_create_for(pp); h = ctx.upload(pic); ctx.wait()
 for _ in range(3): ctx.decode_resident(h)
 ctx.wait()
 ctx.decode_resident(h); ctx.wait()
-buf = (ctypes.c_uint64 * 65536)()
+buf = (ctypes.c_uint64 * 131072)()
 lib.lib.m355_x_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
-lib.lib.m355_x_prof_read(buf, 65536)
-a = np.frombuffer(buf, np.uint64).astype(np.int64)[16384:16384 + 6 * 8100].reshape(-1, 6)
+lib.lib.m355_x_prof_read(buf, 131072)
+a = np.frombuffer(buf, np.uint64).astype(np.int64)[65536:65536 + 6 * 8100].reshape(-1, 6)
 ent = a[a[:, 0] > 0]
 T0 = ent[:, 0].min()
 work = a[a[:, 5] > 0]
