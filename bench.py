@@ -75,11 +75,6 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    # The residual order of the library follows the pictures in flight (fused into k_inter_jobs' write-back at depth 1, read-modify-
-    # write behind it otherwise, runtime_decode.hip prepare()).  The headline runs with pictures in flight; the legs that time the stages one
-    # picture at a time (stage_ms, roofline, the rocprofv3 traces under profiles/) must see the SAME kernels, so this process pins the
-    # order of the headline unless told otherwise.
-    os.environ.setdefault("M355_RES_FUSED", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -371,8 +366,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "k_" + dom),
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": ab[dom] / max(1, launches[dom]),
                          "pictures_in_flight": 1,     # launch_ms / stage_ms: one picture at a time; `value`: args.pipeline_depth in flight
-                         "traffic_total": pmc_traffic_total(args.workload),
-                         "residual_order": "fused" if os.environ.get("M355_RES_FUSED") == "1" else "read-modify-write"},
+                         "traffic_total": pmc_traffic_total(args.workload)},
         }
         if sharded is not None:
             out["tile_sharded"] = sharded

@@ -150,16 +150,6 @@ struct DevPic {
   uint8_t* edge_pb;                 /* per 4x4: bit2 PB edge V, bit3 PB edge H */
   uint32_t* pb_of;                  /* per 4x4: PB index + 1 */
   int16_t* resbuf;
-  /* Fused inter residuals (k_residual -> k_inter_jobs' write-back; transform.cc:361-642 + fallback-dct.h:65-73 add_residual):
-     block i of size bin s that is NOT deferred to k_intra stores its int16 tile at resbuf + res_fused_base[s] + i * nT * nT, and
-     marks every 4x4 unit of its component that it covers in res_map: bit 31 valid, bits 28-29 log2(nT) - 2, bits 0-27 = (offset of
-     the unit's top-left sample in resbuf) / 4; the row pitch of the tile is nT.  res_map == NULL: the legacy order (k_inter, then
-     k_residual read-modify-writes the picture) — 4:2:2 / 4:4:4, 16-bit samples, stage-isolated runs. */
-  uint32_t* res_map;                /* [component][unit row][unit col], cleared per decode */
-  uint32_t res_map_ofs[3];          /* first entry of each component */
-  int res_map_w[3];                 /* units per row */
-  uint32_t res_map_words;           /* all components */
-  uint32_t res_fused_base[4];
   uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable; bit 15 = the CTB's slice has SAO on for the component (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
   uint32_t* job_base;               /* [256-PB chunk][4]: the chunk's jobs per range (uni, bi, weighted, edge): k_job_count leaves the counts here, every

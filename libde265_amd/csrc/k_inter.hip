@@ -1040,34 +1040,6 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
   const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
 
-  /* fused residual (k_common.h res_map): where the map entries of the job's two luma units and of its chroma piece are requested
-     decides the register pressure of the filter loops (M355_RES_MAP_WHEN: 0 = at the start, beside the PB record's dependants;
-     1 = luma at the start, chroma between the luma and the chroma filter; 2 = each right before its residual rows) */
-#ifndef M355_RES_MAP_WHEN
-#define M355_RES_MAP_WHEN 2
-#endif
-  uint32_t e0 = 0, e1 = 0, ec1 = 0, ec2 = 0, ec1b = 0, ec2b = 0;
-  auto map_luma = [&]() {
-    if (!p.res_map) return;
-    const uint32_t* m = p.res_map + (size_t)(y0 >> 2) * p.res_map_w[0] + (x0 >> 2);
-    e0 = m[0];
-    if (rows > 4) e1 = m[p.res_map_w[0]];
-  };
-  auto map_chroma = [&]() {
-    if (!p.res_map || nc != 3) return;
-    /* 4:2:0: the 2 x (rows / 2) chroma piece lies in unit (x0 >> 3, y0 >> 3); a job that starts on an odd multiple of 4
-       (PBs of asymmetric partitions) reaches two rows into the unit below */
-    const size_t cu = (size_t)(y0 >> 3) * p.res_map_w[1] + (x0 >> 3);
-    ec1 = p.res_map[p.res_map_ofs[1] + cu];
-    ec2 = p.res_map[p.res_map_ofs[2] + cu];
-    if (((y0 >> 1) & 3) + (rows >> 1) > 4) {
-      ec1b = p.res_map[p.res_map_ofs[1] + cu + p.res_map_w[1]];
-      ec2b = p.res_map[p.res_map_ofs[2] + cu + p.res_map_w[1]];
-    }
-  };
-  if (M355_RES_MAP_WHEN <= 1) map_luma();
-  if (M355_RES_MAP_WHEN == 0) map_chroma();
-
   /* weights of the job's component c (WtSel above).  Called in the write-back, behind the filter loops: the two weight records
      (8 registers) and the selection (5) are not carried through them — registers are what the loops are short of, and a
      spilled one is scratch traffic on the same memory path the kernel is bound by */
@@ -1117,28 +1089,9 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
         continue;
       }
-      /* residual rows of the two units (4 int16 each; tile pitch nT), clip(pred + res) as add_residual (fallback-dct.h:65-73) */
-      M355_COMPILER_FENCE();          /* the residual / weight loads must not be hoisted into the filter loops */
+      M355_COMPILER_FENCE();          /* the weight loads must not be hoisted into the filter loops */
       const WtSel ws = make_ws(0, bd);
       PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
-      if (M355_RES_MAP_WHEN == 2) map_luma();
-      unsigned rs[8][2];
-#pragma unroll
-      for (int y = 0; y < 8; y++) { rs[y][0] = 0; rs[y][1] = 0; }
-      if ((e0 | e1) >> 31) {
-        if (e0 >> 31) {
-          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e0 & 0x0FFFFFFFu) << 2);
-          const int nt = 4 << ((e0 >> 28) & 3);
-#pragma unroll
-          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[y]);
-        }
-        if (e1 >> 31) {
-          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e1 & 0x0FFFFFFFu) << 2);
-          const int nt = 4 << ((e1 >> 28) & 3);
-#pragma unroll
-          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[4 + y]);
-        }
-      }
 #pragma unroll
       for (int y = 0; y < 8; y++) {
         if (y >= rows) break;
@@ -1147,7 +1100,6 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         for (int x = 0; x < 4; x++) {
           const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
           o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
-          o[x] = (unsigned)d_clip_bd((int)o[x] + ((x & 1) ? d_hi16s(rs[y][x >> 1]) : d_lo16s(rs[y][x >> 1])), bd);
         }
         /* streaming stores (k_asm.h): -4 % kernel time, -10 % fabric fetch (profiles/r02_b_inter_variants.txt) */
         if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0] | (o[1] << 16), o[2] | (o[3] << 16));
@@ -1156,7 +1108,6 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
     }
   }
   if (nc == 1) return;
-  if (M355_RES_MAP_WHEN == 1) map_chroma();
 
   /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are
      in flight together (one memory latency per list instead of two); chroma mv = luma mv in 1/8 pel
@@ -1193,44 +1144,22 @@ __device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const
         for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
         continue;
       }
-      /* residual: the job's 2 x crows piece of each plane (unit-local position (xc & 3, yc & 3), see the map lookup above) */
       M355_COMPILER_FENCE();
       const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
       PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
       PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
-      if (M355_RES_MAP_WHEN == 2) map_chroma();
-      unsigned rc1[4], rc2[4];
-#pragma unroll
-      for (int y = 0; y < 4; y++) { rc1[y] = 0; rc2[y] = 0; }
-      if ((ec1 | ec2 | ec1b | ec2b) >> 31) {
-        const int ly = yc & 3;
-        auto piece = [&](uint32_t ea, uint32_t eb, unsigned* rc) {
-          const int nta = 4 << ((ea >> 28) & 3), ntb = 4 << ((eb >> 28) & 3);
-          const M355_GLOBAL int16_t* ra = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(ea & 0x0FFFFFFFu) << 2) + (xc & 3);
-          const M355_GLOBAL int16_t* rb = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(eb & 0x0FFFFFFFu) << 2) + (xc & 3);
-#pragma unroll
-          for (int y = 0; y < 4; y++) {
-            if (y >= crows) break;
-            const int l = ly + y;
-            if (l < 4) { if (ea >> 31) rc[y] = d_ldg4(ra + l * nta); }
-            else if (eb >> 31) rc[y] = d_ldg4(rb + (l - 4) * ntb);
-          }
-        };
-        piece(ec1, ec1b, rc1);
-        piece(ec2, ec2b, rc2);
-      }
 #pragma unroll
       for (int y = 0; y < 4; y++) {
         if (y >= crows) break;
         {
           const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
-          const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc1[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc1[y]), bd);
+          const unsigned o0 = (unsigned)d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd);
           if (sizeof(PIX) == 2) d_st_nt4(d1 + (size_t)y * p.stride[1], o0 | (o1 << 16));
           else *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)(o0 | (o1 << 8));
         }
         {
           const unsigned a = bi ? pa2[y] : cur2[y], b = cur2[y];
-          const unsigned o0 = (unsigned)d_clip_bd(d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd) + d_lo16s(rc2[y]), bd), o1 = (unsigned)d_clip_bd(d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd) + d_hi16s(rc2[y]), bd);
+          const unsigned o0 = (unsigned)d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd);
           if (sizeof(PIX) == 2) d_st_nt4(d2 + (size_t)y * p.stride[2], o0 | (o1 << 16));
           else *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)(o0 | (o1 << 8));
         }
@@ -1262,7 +1191,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
   const bool fillA = pb.flags & (a1 ? M355_PBF_FILL_L1 : M355_PBF_FILL_L0), fillB = pb.flags & M355_PBF_FILL_L1;
   const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
-  const bool fused = p.res_map != nullptr;           /* (kernel argument: a scalar branch) */
 
   /* weights of component c as the one formula of d_wpred (WEIGHTED jobs only; see d_inter_job) */
   auto make_ws = [&](int c, int bd) {
@@ -1290,12 +1218,10 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
      in SATURATING signed 16-bit arithmetic: a sum that leaves int16 is clipped by the reference as well (32767 >> shift2 is exactly the
      largest sample value, 32767 >> shift3 lies above it; -32768 >> s is negative), so the saturated sum gives the same sample. */
   /* two samples with per-lane weights (put_weighted_pred / _bipred, and the unweighted forms as weights 1 / 0: d_wpred's one formula):
-     ((a w0 + b w1 + rnd) >> sh) + o = (a w0 + b w1 + rnd + (o << sh)) >> sh — one v_dot2 per sample on the pairs (a, b); then the residual
-     (fused order) as add_residual does.  a, b: two samples each, packed */
-  auto wt_pair = [&](unsigned a, unsigned b, unsigned wp, int rnd, int sh, unsigned res, int bd_) {
-    int lo = d_dot2(d_pack_lo16(a, b), wp, rnd) >> sh, hi = d_dot2(d_pack_hi16(a, b), wp, rnd) >> sh;
-    lo = d_clip_bd(lo, bd_); hi = d_clip_bd(hi, bd_);
-    if (fused) { lo = d_clip_bd(lo + d_lo16s(res), bd_); hi = d_clip_bd(hi + d_hi16s(res), bd_); }
+     ((a w0 + b w1 + rnd) >> sh) + o = (a w0 + b w1 + rnd + (o << sh)) >> sh — one v_dot2 per sample on the pairs (a, b).  a, b: two
+     samples each, packed */
+  auto wt_pair = [&](unsigned a, unsigned b, unsigned wp, int rnd, int sh, int bd_) {
+    const int lo = d_clip_bd(d_dot2(d_pack_lo16(a, b), wp, rnd) >> sh, bd_), hi = d_clip_bd(d_dot2(d_pack_hi16(a, b), wp, rnd) >> sh, bd_);
     return (unsigned)lo | ((unsigned)hi << 16);
   };
   auto pk_pred = [&](unsigned a, unsigned b, unsigned rnd, int sh, unsigned maxv) {
@@ -1327,29 +1253,8 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
         for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
         continue;
       }
-      M355_COMPILER_FENCE();          /* the residual / weight loads must not be hoisted into the filter loops */
+      M355_COMPILER_FENCE();          /* the weight loads must not be hoisted into the filter loops */
       PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
-      /* fused residual (k_common.h res_map): the residual rows of the job's two units (4 int16 each; tile pitch nT), added as
-         add_residual does (fallback-dct.h:65-73) */
-      unsigned rs[8][2];
-#pragma unroll
-      for (int y = 0; y < 8; y++) { rs[y][0] = 0; rs[y][1] = 0; }
-      if (fused) {
-        const uint32_t* m = p.res_map + (size_t)(y0 >> 2) * p.res_map_w[0] + (x0 >> 2);
-        const uint32_t e0 = m[0], e1 = rows > 4 ? m[p.res_map_w[0]] : 0u;
-        if (e0 >> 31) {
-          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e0 & 0x0FFFFFFFu) << 2);
-          const int nt = 4 << ((e0 >> 28) & 3);
-#pragma unroll
-          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[y]);
-        }
-        if (e1 >> 31) {
-          const M355_GLOBAL int16_t* r = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(e1 & 0x0FFFFFFFu) << 2);
-          const int nt = 4 << ((e1 >> 28) & 3);
-#pragma unroll
-          for (int y = 0; y < 4; y++) d_ldg8(r + y * nt, rs[4 + y]);
-        }
-      }
       if (WEIGHTED) {
         /* all four reference formulas as ONE dot2 per sample (see wt_pair): (a, b) . (w0, w1) + rnd', >> sh, clip */
         const WtSel ws = make_ws(0, bd);
@@ -1360,7 +1265,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
           if (y >= rows) break;
           unsigned o[2];
 #pragma unroll
-          for (int jp = 0; jp < 2; jp++) o[jp] = wt_pair(bi ? pa[y][jp] : cur[y][jp], cur[y][jp], wp, rnd, ws.sh, rs[y][jp], bd);
+          for (int jp = 0; jp < 2; jp++) o[jp] = wt_pair(bi ? pa[y][jp] : cur[y][jp], cur[y][jp], wp, rnd, ws.sh, bd);
           if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0], o[1]);
           else d_st_nt4(d + (size_t)y * p.stride[0], d_pack_bytes(o[0], o[1]));
         }
@@ -1371,10 +1276,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
         for (int y = 0; y < 8; y++) {
           if (y >= rows) break;
           unsigned o0 = pk_pred(pa[y][0], cur[y][0], rnd, sh, maxv), o1 = pk_pred(pa[y][1], cur[y][1], rnd, sh, maxv);
-          if (fused) {
-            o0 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o0, rs[y][0]), 0u), maxv);
-            o1 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o1, rs[y][1]), 0u), maxv);
-          }
           /* streaming stores (k_asm.h): -4 % kernel time, -10 % fabric fetch (profiles/r02_b_inter_variants.txt) */
 #ifdef M355_X_INTER_NOSTORE
           if ((o0 ^ o1) != 0x9E3779B9u) continue;
@@ -1416,36 +1317,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       M355_COMPILER_FENCE();
       PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
       PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
-      /* residual: the job's 2 x crows piece of each plane, unit-local position (xc & 3, yc & 3); a job that starts on an odd multiple
-         of 4 (PBs of asymmetric partitions) reaches two rows into the unit below */
-      unsigned rc1[4], rc2[4];
-#pragma unroll
-      for (int y = 0; y < 4; y++) { rc1[y] = 0; rc2[y] = 0; }
-      if (fused) {
-        const size_t cu = (size_t)(y0 >> 3) * p.res_map_w[1] + (x0 >> 3);
-        uint32_t ec1 = p.res_map[p.res_map_ofs[1] + cu], ec2 = p.res_map[p.res_map_ofs[2] + cu], ec1b = 0, ec2b = 0;
-        if (((y0 >> 1) & 3) + (rows >> 1) > 4) {
-          ec1b = p.res_map[p.res_map_ofs[1] + cu + p.res_map_w[1]];
-          ec2b = p.res_map[p.res_map_ofs[2] + cu + p.res_map_w[1]];
-        }
-        if ((ec1 | ec2 | ec1b | ec2b) >> 31) {
-          const int ly = yc & 3;
-          auto piece = [&](uint32_t ea, uint32_t eb, unsigned* rc) {
-            const int nta = 4 << ((ea >> 28) & 3), ntb = 4 << ((eb >> 28) & 3);
-            const M355_GLOBAL int16_t* ra = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(ea & 0x0FFFFFFFu) << 2) + (xc & 3);
-            const M355_GLOBAL int16_t* rb = (const M355_GLOBAL int16_t*)p.resbuf + ((size_t)(eb & 0x0FFFFFFFu) << 2) + (xc & 3);
-#pragma unroll
-            for (int y = 0; y < 4; y++) {
-              if (y >= crows) break;
-              const int l = ly + y;
-              if (l < 4) { if (ea >> 31) rc[y] = d_ldg4(ra + l * nta); }
-              else if (eb >> 31) rc[y] = d_ldg4(rb + (l - 4) * ntb);
-            }
-          };
-          piece(ec1, ec1b, rc1);
-          piece(ec2, ec2b, rc2);
-        }
-      }
       if (WEIGHTED) {
         const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
         const unsigned wp1 = d_pack16(ws1.w0, ws1.w1), wp2 = d_pack16(ws2.w0, ws2.w1);
@@ -1453,8 +1324,8 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
 #pragma unroll
         for (int y = 0; y < 4; y++) {
           if (y >= crows) break;
-          const unsigned o1 = wt_pair(bi ? pa1[y] : cur1[y], cur1[y], wp1, rnd1, ws1.sh, rc1[y], bd);
-          const unsigned o2 = wt_pair(bi ? pa2[y] : cur2[y], cur2[y], wp2, rnd2, ws2.sh, rc2[y], bd);
+          const unsigned o1 = wt_pair(bi ? pa1[y] : cur1[y], cur1[y], wp1, rnd1, ws1.sh, bd);
+          const unsigned o2 = wt_pair(bi ? pa2[y] : cur2[y], cur2[y], wp2, rnd2, ws2.sh, bd);
           if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
           else {
             *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
@@ -1468,10 +1339,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
         for (int y = 0; y < 4; y++) {
           if (y >= crows) break;
           unsigned o1 = pk_pred(pa1[y], cur1[y], rnd, sh, maxv), o2 = pk_pred(pa2[y], cur2[y], rnd, sh, maxv);
-          if (fused) {
-            o1 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o1, rc1[y]), 0u), maxv);
-            o2 = d_pk_min_i16(d_pk_max_i16(d_pk_addsat_i16(o2, rc2[y]), 0u), maxv);
-          }
 #ifdef M355_X_INTER_NOSTORE
           if ((o1 ^ o2) != 0x9E3779B9u) continue;
 #endif

@@ -241,7 +241,7 @@ __device__ __forceinline__ m355_rb d_res_record(const m355_rb* rbs, int rb_n, in
   return rb;
 }
 
-template <int LOG2, class PIX, bool FUSED, bool PRE>
+template <int LOG2, class PIX, bool PRE>
 __device__ __forceinline__ void d_res_issue(const DevPic& p, const m355_rb& rb, bool active, int c, int tbi, uint32_t* w, uint32_t* eb)
 {
   constexpr int NT = ResGeom<LOG2, PIX>::NT, NVP = ResGeom<LOG2, PIX>::NVP;
@@ -252,18 +252,10 @@ __device__ __forceinline__ void d_res_issue(const DevPic& p, const m355_rb& rb, 
   for (int i = 0; i < NVP; i++) w[i] = 0;
   /* (an idle lane — no block — reads row 0: row c of a picture lower than the transform size does not exist) */
   const M355_GLOBAL PIX* d = (const M355_GLOBAL PIX*)M355_SEL3(p.plane, rb.cidx) + (size_t)(active ? rb.y + c : 0) * M355_SEL3(p.stride, rb.cidx) + rb.x;
-  /* FUSED: a block of an inter CU is handed to k_inter_jobs' write-back as a compact int16 tile (k_common.h, res_map); the lane
-     of every fourth row marks the row of 4x4 units it starts — fire and forget, ahead of the coefficient fetch */
-  if (FUSED && active && !(rb.flags & M355_RBF_DEFERRED) && (c & 3) == 0) {
-    const uint32_t fused_ofs = p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT;
-    M355_GLOBAL uint32_t* m = (M355_GLOBAL uint32_t*)p.res_map + M355_SEL3(p.res_map_ofs, rb.cidx) + (size_t)((rb.y + c) >> 2) * M355_SEL3(p.res_map_w, rb.cidx) + (rb.x >> 2);
-#pragma unroll
-    for (int u = 0; u < NT / 4; u++) m[u] = 0x80000000u | ((uint32_t)(LOG2 - 2) << 28) | ((fused_ofs >> 2) + u);
-  }
   /* (requested by every lane, also where the row is not used — blocks of intra CUs, idle lanes; their address is a valid row of the
      plane all the same: a load under a per-lane condition leaves hipcc unsure of what is in flight behind it, and it then drains
      everything before the next load) */
-  if (!FUSED) {
+  {
     if (sizeof(PIX) == 2) {
       if (NT >= 8) {
 #pragma unroll
@@ -289,13 +281,12 @@ __device__ __forceinline__ void d_res_issue(const DevPic& p, const m355_rb& rb, 
   }
 }
 
-template <int LOG2, class PIX, bool FUSED, bool PRE>
+template <int LOG2, class PIX, bool PRE>
 __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs, const m355_rb& rb, bool active, int c, int tbi, uint32_t* cfp, uint32_t* w, const uint32_t* eb)
 {
   constexpr int NT = ResGeom<LOG2, PIX>::NT;
   const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
   M355_GLOBAL PIX* d = (M355_GLOBAL PIX*)M355_SEL3(p.plane, rb.cidx) + (size_t)(rb.y + c) * M355_SEL3(p.stride, rb.cidx) + rb.x;
-  const uint32_t fused_ofs = FUSED ? p.res_fused_base[LOG2 - 2] + (uint32_t)tbi * (NT * NT) + (uint32_t)c * NT : 0u;
 
   int res[NT];      /* one row (lane's `c` is the row index here), NT adjacent samples */
   d_rb_compute<LOG2, PRE>(p, rb, active, c, cfp, res, eb);
@@ -327,8 +318,8 @@ __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs
 
   if (!active) return;
   const int y = c;
-  if (FUSED || (rb.flags & M355_RBF_DEFERRED)) {
-    int16_t* out = p.resbuf + ((FUSED && !(rb.flags & M355_RBF_DEFERRED)) ? fused_ofs : rb.res_ofs + y * NT);
+  if (rb.flags & M355_RBF_DEFERRED) {
+    int16_t* out = p.resbuf + rb.res_ofs + y * NT;
 #pragma unroll
     for (int i = 0; i < NT; i += 2) *(uint32_t*)(out + i) = res_pack(d_clip3(-32768, 32767, res[i]), d_clip3(-32768, 32767, res[i + 1]));
   } else {
@@ -358,7 +349,7 @@ __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs
   }
 }
 
-template <int LOG2, class PIX, bool FUSED>
+template <int LOG2, class PIX>
 __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb* rbs, int rb_n, int group, uint32_t* smem)
 {
   typedef ResGeom<LOG2, PIX> G;
@@ -372,8 +363,8 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
      8 nT pairs has no other batch): requested inside the batch loop, the pairs waited for the row first — hipcc drains every load in
      flight at a loop header */
   uint32_t w[G::NVP], eb[RES_GB];
-  d_res_issue<LOG2, PIX, FUSED, true>(p, rb, active, c, tbi, w, eb);
-  d_res_finish<LOG2, PIX, FUSED, true>(p, rbs, rb, active, c, tbi, cfp, w, eb);
+  d_res_issue<LOG2, PIX, true>(p, rb, active, c, tbi, w, eb);
+  d_res_finish<LOG2, PIX, true>(p, rbs, rb, active, c, tbi, cfp, w, eb);
 }
 
 /* Two launches, issued side by side on the lane's two streams (runtime_decode.hip, launch_prediction): 32x32 + 16x16 blocks (2 / 4 per
@@ -383,33 +374,33 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
 #define RES_LDS_DWORDS_SMALL (8 * RES_WPG * (4 * 8 + 8 * 5))   /* 8x8: 8 blocks per wave (4x4: 16 x 20 dwords fit too) */
 /* blocks per workgroup: RES_WPG waves * 64/nT */
 __host__ __device__ static inline int res_groups(int n, int per_wave) { return (n + per_wave * RES_WPG - 1) / (per_wave * RES_WPG); }
-template <class PIX, bool BIG, bool FUSED>
+template <class PIX, bool BIG>
 __device__ __forceinline__ void k_residual_body(const DevPic& p, int ng_hi, uint32_t* s_buf)
 {
   M355_GATE(p);
   const int g = (int)blockIdx.x;
   if (BIG) {
-    if (g < ng_hi) d_residual_group<5, PIX, FUSED>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
-    else d_residual_group<4, PIX, FUSED>(p, p.rb_bin[2], p.rb_count[2], g - ng_hi, s_buf);
+    if (g < ng_hi) d_residual_group<5, PIX>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
+    else d_residual_group<4, PIX>(p, p.rb_bin[2], p.rb_count[2], g - ng_hi, s_buf);
   } else {
-    if (g < ng_hi) d_residual_group<3, PIX, FUSED>(p, p.rb_bin[1], p.rb_count[1], g, s_buf);
-    else d_residual_group<2, PIX, FUSED>(p, p.rb_bin[0], p.rb_count[0], g - ng_hi, s_buf);
+    if (g < ng_hi) d_residual_group<3, PIX>(p, p.rb_bin[1], p.rb_count[1], g, s_buf);
+    else d_residual_group<2, PIX>(p, p.rb_bin[0], p.rb_count[0], g - ng_hi, s_buf);
   }
 }
 
-template <class PIX, bool BIG, bool FUSED>
+template <class PIX, bool BIG>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual(DevPic p, int ng_hi)
 {
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
-  k_residual_body<PIX, BIG, FUSED>(p, ng_hi, s_buf);
+  k_residual_body<PIX, BIG>(p, ng_hi, s_buf);
 }
-/* batch form (intra pictures: never the fused order) */
+/* batch form (intra pictures) */
 template <class PIX, bool BIG>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_batch(DevBatch b)
 {
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
   M355_BATCH_PIC(b);
-  k_residual_body<PIX, BIG, false>(p, BIG ? res_groups(p.rb_count[3], 2) : res_groups(p.rb_count[1], 8), s_buf);
+  k_residual_body<PIX, BIG>(p, BIG ? res_groups(p.rb_count[3], 2) : res_groups(p.rb_count[1], 8), s_buf);
 }
 
 template <class PIX, bool BIG>
@@ -432,8 +423,7 @@ template <class PIX, bool BIG>
 static void launch_res(const DevPic& p, int n, int ng_hi, hipStream_t st)
 {
   const dim3 blk(64 * RES_WPG);
-  if (p.res_map) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, true>), dim3(n), blk, 0, st, p, ng_hi);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG, false>), dim3(n), blk, 0, st, p, ng_hi);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG>), dim3(n), blk, 0, st, p, ng_hi);
 }
 
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)

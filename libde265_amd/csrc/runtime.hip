@@ -100,7 +100,7 @@ static void lane_destroy(Lane& l)
   if (l.stream) hipStreamSynchronize(l.stream);
   if (l.stream2) hipStreamSynchronize(l.stream2);
   if (l.work.used) frame_free(l.work);
-  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb, l.iplan, l.res_map, l.job_base};
+  void* bufs[] = {l.pb_of, l.edge, l.ticket, l.timeout, l.edge_tu, l.cuf, l.resbuf, l.jobs, l.sao_nb, l.iplan, l.job_base};
   for (void* b : bufs) if (b) hipFree(b);
   if (l.ev_fork) hipEventDestroy(l.ev_fork);
   if (l.ev_fork2) hipEventDestroy(l.ev_fork2);
@@ -649,10 +649,8 @@ int m355_timing_collect(m355_ctx* c, int* n_decodes, float* total_ms, float stag
     hipEvent_t* ev = &c->evs[k * 7];
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[6])); tot += ms;
-    /* stage order of the events: [meta, inter, residual, intra, deblock, sao], or with fused residuals [residual, meta, inter, ...] */
-    static const int order[2][6] = {{0, 1, 2, 3, 4, 5}, {2, 0, 1, 3, 4, 5}};
-    const int* o = order[k < (int)c->ev_fused.size() && c->ev_fused[k] ? 1 : 0];
-    for (int i = 0; i < 6; i++) { HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); st[o[i]] += ms; }
+    /* stage order of the events: [meta, inter, residual, intra, deblock, sao] */
+    for (int i = 0; i < 6; i++) { HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); st[i] += ms; }
   }
   if (n_decodes) *n_decodes = c->ev_used;
   if (total_ms) *total_ms = (float)(tot / c->ev_used);

@@ -92,35 +92,11 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
     if ((rc = grow(&c->edge, &c->cap_edge, n + 1, c->stream, true))) return rc;
   }
   if ((rc = grow(&c->cuf, &c->cap_cuf, (size_t)pic.n_cus + (size_t)r.halo.n_units + 1, c->stream, false))) return rc;
-  /* Fused inter residuals (k_common.h res_map): whenever k_inter_jobs runs, k_residual hands the blocks of inter CUs over as int16
-     tiles behind the deferred (intra) ones instead of read-modify-writing the picture.  Not for 16-bit samples (a residual of
-     transform_idct_add, fallback-dct.cc:550-691, needs 18 bits there), not for the generic kernel's chroma formats, not when a
-     stage is isolated. */
-  /* When: with ONE picture in flight (the residual stage then runs beside the job list instead of behind k_inter_jobs: 0.505 vs
-     0.52 ms per C5 picture).  With pictures in flight the read-modify-write order is the faster one although it moves 80 MB more
-     per picture: k_inter_jobs is the stage everything else queues behind, the 20 us the residual rows add to it cost more than the
-     35 us k_residual saves beside the other pictures' kernels (0.379 vs 0.395 ms, profiles/r04_g_*).  M355_RES_FUSED=0 / 1 forces it. */
-  static const int fused_env = getenv("M355_RES_FUSED") ? atoi(getenv("M355_RES_FUSED")) : -1;
-  const bool fused_on = fused_env >= 0 ? fused_env != 0 : c->depth == 1;
-  const bool fused = fused_on && pic.n_pbs > 0 && pp.chroma_format_idc <= 1 && pp.bit_depth_luma < 16 && pp.bit_depth_chroma < 16 &&
-                     (c->stages & M355_STAGE_INTER) && (c->stages & M355_STAGE_RESIDUAL) &&
-                     (pic.rb_count[0] | pic.rb_count[1] | pic.rb_count[2] | pic.rb_count[3]);
-  size_t res_need = (size_t)pic.res_len + 1;
-  d.res_map = nullptr;
-  if (fused) {
-    size_t base = ((size_t)pic.res_len + 15) & ~(size_t)15;
-    for (int s = 0; s < 4; s++) { d.res_fused_base[s] = (uint32_t)base; base += (size_t)pic.rb_count[s] << (2 * (s + 2)); }
-    if (base >= ((size_t)1 << 30)) return fail(M355_ERR_INVALID, "residual blocks exceed the fused residual buffer");
-    res_need = base + 1;
-    size_t n = 0;
-    for (int cc = 0; cc < (pp.chroma_format_idc ? 3 : 1); cc++) {
-      d.res_map_ofs[cc] = (uint32_t)n; d.res_map_w[cc] = (dst->pw[cc] + 3) >> 2;
-      n += (size_t)d.res_map_w[cc] * ((dst->ph[cc] + 3) >> 2);
-    }
-    if ((rc = grow(&c->res_map, &c->cap_resmap, n + 1, c->stream, false))) return rc;
-    d.res_map = c->res_map;
-    d.res_map_words = (uint32_t)n;
-  }
+  /* (Inter residuals are added to the prediction samples in place, behind k_inter_jobs.  Handing them to k_inter_jobs' write-back as int16
+     tiles — round 4's "fused" order, the default with one picture in flight then — saves 80 MB per 8K picture and was measured again with
+     round 5's lean k_inter_jobs: it loses at every depth, C5 0.362-0.368 against 0.346-0.356 ms with three pictures in flight, 0.486-0.494
+     against 0.470-0.486 one at a time, C3 0.087 against 0.0805 — profiles/r05_h_fused_order_ab.txt — and left the product.) */
+  const size_t res_need = (size_t)pic.res_len + 1;
   if ((rc = grow(&c->resbuf, &c->cap_res, res_need, c->stream, false))) return rc;
   if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
   {
@@ -211,27 +187,16 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
      scatters and the second residual launch beside the main stream — is worth less than that once the kernels are short (three in
      flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms on one stream, C5 0.347 -> 0.351) */
   const bool single = d.intra_dense || (long long)d.pp.width * d.pp.height <= 16ll << 20;
-  const bool fused = d.res_map != nullptr;   /* prepare(): the residuals of inter CUs are added in k_inter_jobs' write-back */
   hipStream_t s2 = single ? st : c->stream2;
   /* the zero fill of the metadata planes rides in the picture's first main-stream launch (k_job_count), in FRONT of the fork: the
-     side stream's scatters then start behind it — one launch less per inter picture (not with fused residuals: there the side
-     stream starts with the residual stage, and the job count comes later) */
+     side stream's scatters then start behind it — one launch less per inter picture */
   /* (the fill is shared out over the launch's workgroups, one per 256 PBs: with a handful of them a fill of its own is faster;
      M355_CLEAR_IN_COUNT_MIN=<PBs> moves the threshold: tests/test_meta_merged_emu.py sends the CPU tier's small pictures down this path —
      and through the merged planes + job-list launch behind it — with 1) */
   static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
-  const bool clear_in_count = !fused && d.n_pbs >= std::max(1, clear_min);
+  const bool clear_in_count = d.n_pbs >= std::max(1, clear_min);
   if (clear_in_count) m355_launch_job_count(d, true, st);
-  if (fused) hipMemsetAsync(d.res_map, 0, (size_t)d.res_map_words * 4, st);
   if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
-  if (fused) {
-    /* the residual stage reads nothing but the lists: it runs FIRST, side by side on the lane's two streams, beside the tail of
-       the previous picture; its event order is [residual, meta, inter] (m355_timing_collect) */
-    m355_launch_residual(d, hbd, false, s2);
-    if (!single) hipEventRecord(c->ev_fork2, s2);
-    m355_launch_residual(d, hbd, true, st);
-    if (ev) hipEventRecord(ev[1], st);
-  }
   /* transform edges and border plans in ONE launch (a packet less per picture: C3 0.098 -> 0.093 ms, profiles/r05_a_switches_merge.txt) */
   if (single && clear_in_count && (c->stages & M355_STAGE_INTRA)) {
     /* one stream: the planes' scatters and the job list are independent roles of ONE launch (k_meta_planes_jobs) */
@@ -244,16 +209,15 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
     } else m355_launch_meta_planes(d, s2, clear_in_count);
     if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
   }
-  if (ev) hipEventRecord(ev[fused ? 2 : 1], st);
+  if (ev) hipEventRecord(ev[1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
-     reference — the list copy, validation, metadata planes, job list (and fused residuals) of a picture run beside the tail
+     reference — the list copy, validation, metadata planes and job list of a picture run beside the tail
      (filters) of the picture it references */
   if (c->depth >= 2)
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
       if (f) ev_wait(c, st, f->wr);
     }
-  if (fused && !single) hipStreamWaitEvent(st, c->ev_fork2, 0);   /* the 8x8 + 4x4 tiles */
 #ifdef M355_X_TILED
   if ((c->stages & M355_STAGE_INTER) && d.n_pbs)
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
@@ -268,8 +232,8 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
     }
 #endif
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
-  if (ev) hipEventRecord(ev[fused ? 3 : 2], st);
-  if (!fused && (c->stages & M355_STAGE_RESIDUAL)) {
+  if (ev) hipEventRecord(ev[2], st);
+  if (c->stages & M355_STAGE_RESIDUAL) {
     /* inter residuals are added to the prediction samples: behind k_inter_jobs; the two launches side by side on the lane's two
        streams (one after the other on the main stream, without the second fork, was measured 1 % slower at C5 with three
        pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
@@ -279,7 +243,7 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
     m355_launch_residual(d, hbd, true, st);
   }
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
-  if (!fused && ev) hipEventRecord(ev[3], st);
+  if (ev) hipEventRecord(ev[3], st);
   if (with_intra && (c->stages & M355_STAGE_INTRA)) m355_launch_intra(d, hbd, st, clear_in_count);   /* (m355_decode_batch launches several pictures' intra stage as one kernel) */
   if (ev) hipEventRecord(ev[4], st);
 }
@@ -337,8 +301,6 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
     if (c->ev_used >= 4096) c->ev_used = 0;                 /* bounded ring */
     while ((int)c->evs.size() < (c->ev_used + 1) * 7) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->evs.push_back(e); }
     ev = &c->evs[c->ev_used * 7];
-    if ((int)c->ev_fused.size() <= c->ev_used) c->ev_fused.resize(c->ev_used + 1);
-    c->ev_fused[c->ev_used] = d.res_map != nullptr;
     c->ev_used++;
     hipEventRecord(ev[0], st);
   }

@@ -170,9 +170,8 @@ struct Lane {
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;   /* border plans of the picture's intra blocks */
-  uint32_t* res_map = nullptr; /* fused inter residuals: per component 4x4 unit -> tile piece (k_common.h) */
   uint32_t* job_base = nullptr; /* per 256-PB chunk the first job of each range + the three range ends (k_job_count / k_job_scan) */
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0, cap_jobbase = 0;
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_jobbase = 0;
 };
 
 struct m355_ctx {
@@ -211,9 +210,8 @@ struct m355_ctx {
   uint32_t* jobs = nullptr;
   uint16_t* sao_nb = nullptr;
   uint16_t* iplan = nullptr;
-  uint32_t* res_map = nullptr;
   uint32_t* job_base = nullptr;
-  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_resmap = 0, cap_jobbase = 0;
+  size_t cap_cb = 0, cap_u4 = 0, cap_edge = 0, cap_cuf = 0, cap_res = 0, cap_jobs = 0, cap_sao = 0, cap_iplan = 0, cap_jobbase = 0;
   uint32_t epoch = 0;
   /* per-decode status (m355_decode_status): the last M355_STATUS_RING decodes; a device-validated decode copies its lane's gate
      words into `words` (pinned) behind its last kernel */
@@ -229,7 +227,6 @@ struct m355_ctx {
   m355_comm comm = {nullptr, nullptr, nullptr};   /* exchanges of m355_decode_sharded */
   void* rccl = nullptr;              /* built-in RCCL communicator (m355_shard_rccl_init) */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
-  std::vector<uint8_t> ev_fused;   /* per timed decode: the residual stage ran first (launch_prediction) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
   bool timing_on = false;      /* between m355_timing_reset and m355_timing_collect: decodes record their seven stage events */
@@ -250,7 +247,7 @@ struct m355_ctx {
 };
 
 #define LANE_FIELDS(X) X(stream) X(stream2) X(stream_hi) X(last_stream) X(last) X(ev_fork) X(ev_fork2) X(ev_join) X(work) X(pb_of) X(edge) X(ticket) X(timeout) X(edge_tu) X(cuf) \
-  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(res_map) X(cap_resmap) X(job_base) X(cap_jobbase) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
+  X(resbuf) X(jobs) X(sao_nb) X(iplan) X(job_base) X(cap_jobbase) X(cap_iplan) X(cap_cb) X(cap_u4) X(cap_edge) X(cap_cuf) X(cap_res) X(cap_jobs) X(cap_sao)
 
 /* ---- shared between the parts ---- */
 struct TileRect { int x0, y0, x1, y1; };   /* luma samples */

@@ -66,7 +66,7 @@ def test_extreme_references_emulated(emu_lib, oracle, ref, case, pattern):  # no
     assert_planes_equal(want, ref_replay(ref, pic, refs, st, accel=0), "oracle vs scalar reference (%s)" % pattern)
     ctx = capi.Context(emu_lib, 0)
     try:
-        for depth in (1, 3):       # 1 = the fused residual order (write-back adds the residual), 3 = read-modify-write
+        for depth in (1, 3):
             ctx.set_pipeline_depth(depth)
             assert_planes_equal(device_decode(ctx, pic, refs, st), want, "kernels vs oracle (%s, depth %d)" % (pattern, depth))
     finally:

@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 STAGES = {"k_inter": "k_inter", "k_residual": "k_residual", "k_intra": "k_intra<", "k_deblock": "k_deblock", "k_sao": "k_sao<",
-          "k_meta": "k_meta", "k_intra_plan": "k_intra_plan", "k_job": "k_job_", "fill": "fillBuffer"}
+          "k_meta": "k_meta", "k_intra_plan": "k_intra_plan", "k_tu_plan": "k_tu_plan", "k_job": "k_job_", "fill": "fillBuffer"}
 
 
 def main(workload, label, paths):
