@@ -986,6 +986,10 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[65536 + 6 * blockIdx.x + 5] = (unsigned long long)cls + 1;
 #endif
     if (ji >= jend) return;
+#ifdef M355_X_INTER_LDS_PAD      /* experiment (tools/variants.sh): unused LDS that caps the workgroups per CU (in-flight footprint against the L2) */
+    __shared__ unsigned s_pad[M355_X_INTER_LDS_PAD / 4];
+    if (p.n_pbs < 0) s_pad[threadIdx.x] = 1;
+#endif
     /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
     __shared__ __attribute__((aligned(16))) unsigned s_ext[M355_INTER_BLOCK * 20];
     unsigned* ext = s_ext + threadIdx.x * 20;
