@@ -435,7 +435,7 @@ void collect_status(Glue* g, int wait_for_slot, const Glue::Job* job = nullptr)
     int st = api()->m355_decode_status(g->mctx, g->pending_serial[s]);
     while (st == M355_ERR_BUSY && s == wait_for_slot) { std::this_thread::yield(); st = api()->m355_decode_status(g->mctx, g->pending_serial[s]); }
     if (st == M355_ERR_BUSY) continue;
-    if (st != M355_OK && strstr(api()->m355_last_error(), "no longer kept")) st = M355_OK;   /* (older than the backend's status ring: a rejection would surface in m355_wait) */
+    if (st == M355_ERR_STALE) st = M355_OK;   /* (older than the backend's status ring: a rejection would surface in m355_wait) */
     if (st != M355_OK) {
       g->error = api()->m355_last_error();
       fprintf(stderr, "libde265 (MI355X glue): %s\n", g->error.c_str());

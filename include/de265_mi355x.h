@@ -49,7 +49,8 @@ enum {
   M355_ERR_INVALID = 3,       /* malformed work list / bad argument                  */
   M355_ERR_NOMEM = 4,
   M355_ERR_TIMEOUT = 5,       /* intra wavefront spin bound exceeded (device flag)   */
-  M355_ERR_BUSY = 6           /* m355_decode_status: the decode has not finished yet */
+  M355_ERR_BUSY = 6,          /* m355_decode_status: the decode has not finished yet */
+  M355_ERR_STALE = 7          /* m355_decode_status: the serial is older than the status ring (its outcome is no longer kept) */
 };
 
 M355_API const char* m355_last_error(void);
@@ -461,7 +462,7 @@ M355_API int m355_wait(m355_ctx* ctx);
  * ahead of the picture's kernels: m355_submit_picture has returned M355_OK long before a rejection is known.  Every decode gets
  * a serial (1, 2, ...); m355_decode_status(serial) is non-blocking: M355_ERR_BUSY while the decode runs, M355_OK when it finished,
  * M355_ERR_INVALID when its lists were rejected — none of its kernels acted on them, the destination frame was NOT written
- * (m355_last_error names the record).  Kept for the last 64 decodes (an older serial: M355_ERR_INVALID "no longer kept"; a
+ * (m355_last_error names the record).  Kept for the last 64 decodes (an older serial: M355_ERR_STALE — distinct from a rejection, which M355_ERR_INVALID stays for; a
  * rejection that left the ring unreported is still reported by the next m355_wait).  The caller marks the picture and whatever references it
  * as damaged (the reference does the same bookkeeping with de265_image::integrity, image.h:347). */
 M355_API unsigned long long m355_last_serial(m355_ctx* ctx);      /* of the decode the last submit / decode call enqueued */

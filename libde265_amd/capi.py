@@ -11,7 +11,7 @@ from . import worklist
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libde265_mi355x.so")
 
-ERRORS = {1: "M355_ERR_NO_DEVICE", 2: "M355_ERR_HIP", 3: "M355_ERR_INVALID", 4: "M355_ERR_NOMEM", 5: "M355_ERR_TIMEOUT", 6: "M355_ERR_BUSY"}
+ERRORS = {1: "M355_ERR_NO_DEVICE", 2: "M355_ERR_HIP", 3: "M355_ERR_INVALID", 4: "M355_ERR_NOMEM", 5: "M355_ERR_TIMEOUT", 6: "M355_ERR_BUSY", 7: "M355_ERR_STALE"}
 
 
 HALO_SUM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)

@@ -409,7 +409,7 @@ int m355_decode_status(m355_ctx* c, unsigned long long serial)
 {
   if (serial == 0 || serial > c->serial) return fail(M355_ERR_INVALID, "no decode with serial %llu", serial);
   m355_ctx::Status& s = c->status[serial % M355_STATUS_RING];
-  if (s.serial != serial) return fail(M355_ERR_INVALID, "decode %llu is older than the last %d decodes: its status is no longer kept (m355_wait reports rejections)", serial, M355_STATUS_RING);
+  if (s.serial != serial) return fail(M355_ERR_STALE, "decode %llu is older than the last %d decodes: its status is no longer kept (m355_wait reports rejections)", serial, M355_STATUS_RING);
   hipSetDevice(c->device);
   const hipError_t q = ev_query(c, s.done);
   if (q == hipErrorNotReady) return M355_ERR_BUSY;

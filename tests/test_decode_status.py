@@ -95,7 +95,7 @@ def run(lib, oracle, depth, ring=True):
             small.dst_frame = ctx.frame_create_for(spp)
             for _ in range(70):
                 ctx.submit_in_place(small, fill_threads=1)
-            assert ctx.decode_status(lost) == 3 and "no longer kept" in lib.error()
+            assert ctx.decode_status(lost) == 7 and "no longer kept" in lib.error()      # M355_ERR_STALE, not a rejection
             with pytest.raises(capi.M355Error) as e:
                 ctx.wait()
             assert e.value.code == 3 and "picture %d" % lost in str(e.value) and "ring" in str(e.value)
