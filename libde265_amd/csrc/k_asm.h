@@ -9,6 +9,8 @@
  * an agent-scope release fence hipcc may drop a builtin s_waitcnt whose counter it believes to be
  * zero, letting the flag store overtake the L2 write-back (MI355X guide, "Compiler hazard"). */
 __device__ __forceinline__ void d_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+/* this wave's LDS operations have completed (and nothing else is waited for: vector loads stay in flight) */
+__device__ __forceinline__ void d_drain_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 /* streaming stores (the `nt` bit): written samples do not displace the reference windows other workgroups are reading through the
  * same L2 — k_inter_jobs' own output is next read a kernel later, when the 4 MB L2 of an XCD has long been turned over */

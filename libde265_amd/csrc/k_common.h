@@ -175,6 +175,8 @@ struct DevPic {
                                        neighbour (longest first), then the dependent ones in decode order (k_intra's ticket order) */
   int n_intra_work, n_intra_free;
   int intra_grid;                   /* intra pictures: workgroups of k_intra's launch (persistent: each takes CTB after CTB); 0 = one per CTB */
+  int test_halo_late;               /* test hook (M355_TEST_HALO_LATE=1, tests/test_intra_halo_late.py): k_intra's prologue takes no neighbour's
+                                       sample from its granule — every one is fetched behind the prologue, by the halo keeper or the block's own poll */
   const uint8_t* ctb_dep;           /* per CTB: bit n = reads intra output of neighbour n (0 L, 1 TL, 2 T, 3 TR; orders the work list);
                                        bit 4 = a neighbour reads ours; bits 5-6 = the CTB's widest level (0: 1 luma block, 1: 2, 2: 3-4, 3: more) -> waves in k_intra */
   /* tile sharding (k_shard.hip): NULL = this context owns the whole picture */
@@ -215,6 +217,40 @@ __host__ __device__ inline bool m355_pb_is_edge(const m355_pb& pb, int width, in
     }
   }
   return false;
+}
+
+/* Which border entries does an intra block's prediction READ?  (k_intra.hip: the planner points every other entry at the constant
+ * cell, so that no block waits for a neighbour CTB's sample it will not use; runtime_upload.hip intra_schedule: which blocks of other
+ * CTBs a block waits for.)  Entries i = 1 .. *top_e of the row above and -1 .. -*left_e of the column on the left (entry 0, the
+ * corner, is always kept), the +-1 reach of the [1 2 1] smoothing (intrapred.h:185-258) included:
+ *   planar (intrapred.h:261-285): nT + 1 on both sides | DC (:288-310, 378-392): nT | 11..25, negative angles (:330-376): the
+ *   projection (x * invAngle + 128) >> 8 stays inside nT on the other side | 10 / 26: nT on their own side, the other one only for
+ *   the boundary filter (:378-433) | 27..34: the row above up to nT + 1 + ((nT * intraPredAngle) >> 5) (index x + iIdx + 2 of the
+ *   last sample's second tap), nothing of the column | 2..9: the mirror image.
+ * 32x32 luma under strong smoothing reads both ends of both sides (:196-215): everything. */
+__host__ __device__ inline void m355_intra_used_entries(int mode, int log2, int cidx, int chroma_format_idc, uint32_t pic_flags, uint32_t ib_flags, int* top_e, int* left_e)
+{
+  const int nT = 1 << log2;
+  *top_e = 2 * nT; *left_e = 2 * nT;
+  if (cidx == 0 && log2 == 5 && (pic_flags & M355_PF_STRONG_INTRA_SMOOTHING)) return;
+  bool filt = false;
+  if (!(pic_flags & M355_PF_INTRA_SMOOTHING_DISABLED) && (cidx == 0 || chroma_format_idc == 3) && mode != 1 && log2 != 2) {
+    const int d26 = mode > 26 ? mode - 26 : 26 - mode, d10 = mode > 10 ? mode - 10 : 10 - mode, minDist = d26 < d10 ? d26 : d10;
+    filt = log2 == 3 ? minDist > 7 : (log2 == 4 ? minDist > 1 : (log2 == 5 ? minDist > 0 : false));
+  }
+  const bool bf = cidx == 0 && log2 < 5 && (mode == 1 || !(ib_flags & M355_IBF_DISABLE_BOUNDARY_FILTER));
+  const int mag[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+  int te, le;
+  if (mode == 0) { te = nT + 1; le = nT + 1; }
+  else if (mode == 1) { te = nT; le = nT; }
+  else if (mode > 10 && mode < 26) { te = nT; le = nT; }
+  else if (mode == 26) { te = nT; le = bf ? nT : 0; }
+  else if (mode == 10) { le = nT; te = bf ? nT : 0; }
+  else if (mode > 26 && mode <= 34) { te = nT + 1 + ((nT * mag[mode - 26]) >> 5); le = 0; }
+  else if (mode >= 2 && mode < 10) { le = nT + 1 + ((nT * mag[10 - mode]) >> 5); te = 0; }
+  else return;                                             /* (not a mode: rejected elsewhere) */
+  if (filt) { if (te) te++; if (le) le++; }
+  *top_e = te < 2 * nT ? te : 2 * nT; *left_e = le < 2 * nT ? le : 2 * nT;
 }
 
 /* rectangles of one k_tiles_copy launch (finished tiles <-> all-gather buffer); wb / xb in bytes, ofs = byte offset in the buffer */

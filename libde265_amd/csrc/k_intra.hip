@@ -223,13 +223,22 @@ __device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n, c
     }
     wave_sync();
     uint16_t* out = p.iplan + plan_base + (aux & 0xFFFFu);
+    /* entries the block's mode never reads (k_common.h m355_intra_used_entries) are pointed at the constant cell AFTER the
+       substitution (an entry inside the used range may well take its value from one outside): k_intra's blocks fetch all 4nT + 1
+       entries, and a HALO entry whose CTB has not published it yet would make the block wait for a sample it does not use */
+    int top_e, left_e;
+    m355_intra_used_entries((int)((w1 >> 16) & 0xFFu), log2, c, CF, p.pp.flags, (uint32_t)flags, &top_e, &left_e);
+#ifdef M355_X_INTRA_NO_PRUNE        /* experiment (tools/variants.sh): every available entry stays in the plan, as before round 5's last visits */
+    top_e = left_e = 2 * nT;
+#endif
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       if (64 * q >= nEnt) continue;
       const int e = lane + 64 * q;
       if (e < nEnt) {
+        const int i = e - 2 * nT;
         uint32_t v;
-        if (none) v = (uint32_t)(HALO_BASE + HALO_N);        /* the constant cell */
+        if (none || i > top_e || i < -left_e) v = (uint32_t)(HALO_BASE + HALO_N);        /* the constant cell */
         else if ((am[q] >> lane) & 1) v = code[q];
         else v = codes[d_subst_src(e, am[0], am[1], am[2])];
         out[e] = (uint16_t)v;
@@ -284,6 +293,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint32_t s_cover[3][MAXCTB / 4];    /* per component and row of 4x4 units, which units an intra block of this CTB writes */
   __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
   __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
+  /* the halo keeper's slots (below): granule address and halo element per lane and slot */
+  __shared__ const m355_granule* s_kp_ptr[(DENSE && NW == 13) ? 5 * 64 : 1];
+  __shared__ uint16_t s_kp_h1[(DENSE && NW == 13) ? 5 * 64 : 1];
 #ifdef M355_X_INTRA_LDS_PAD      /* experiment (tools/variants.sh): what does a workgroup less per CU cost the sparse kernel? */
   __shared__ uint32_t s_pad[DENSE ? 1 : M355_X_INTRA_LDS_PAD / 4];
   if (threadIdx.x == 0 && work_n < 0) s_pad[work_n & 1] = 1;
@@ -499,7 +511,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
           val[u] = 0;
           if (intra[u]) {
             const m355_granule gr = __hip_atomic_load(top_[u] ? d_edge_row(p, cs, ctbY - 1, hx[u]) : d_edge_col(p, cs, ctbX - 1, hy[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val[u] = (uint32_t)(gr >> 32) == epoch ? (uint32_t)((gr >> (16 * ((top_[u] ? hx[u] : hy[u]) & 1))) & 0xFFFFu) : HALO_NOT_READY;
+            val[u] = ((uint32_t)(gr >> 32) == epoch && !p.test_halo_late) ? (uint32_t)((gr >> (16 * ((top_[u] ? hx[u] : hy[u]) & 1))) & 0xFFFFu) : HALO_NOT_READY;
           } else if (in[u]) val[u] = plane[(size_t)hy[u] * stride + hx[u]];
         }
 #pragma unroll
@@ -538,6 +550,66 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     }
   }
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
+  /* ---- the HALO KEEPER (intra pictures, the workgroup's last wave): a CTB's halo is staged long before its neighbours have
+     finished (the prologue is off the chain), so nearly every sample a block reads from another CTB is still HALO_NOT_READY there,
+     and the block's own poll costs it one fabric round trip even when the granule arrived long ago — on half of the levels of an
+     intra picture (tools/intra_sim.py).  This wave holds the granules still missing (one per lane and slot), and once per level —
+     beside the blocks, in front of the same barrier — takes in the loads it issued a level earlier, stores the samples that have
+     arrived into the halo and asks again for the rest.  Its loads stay in flight across the barrier (raw s_barrier, no fence: gfx950
+     backs off a barrier with memory operations outstanding).  A block whose sample is still missing polls as before. ---- */
+  constexpr bool KEEPER = DENSE && NW == 13;
+  constexpr int KSLOTS = CF == 3 ? 5 : 4;                    /* granules per lane: (cw + 1) + ch / 2 per component */
+  const bool keeper = KEEPER && wv == NW - 1;
+  uint32_t kp_pend = 0, kp_fly = 0;                          /* bit k: slot k is missing / has a load in flight */
+  m355_granule kp_gr[KSLOTS];
+  if (keeper) {
+    const int cwl = 1 << l2c;
+#pragma unroll
+    for (int k = 0; k < KSLOTS; k++) kp_gr[k] = 0;
+#pragma unroll 1
+    for (int k = 0; k < KSLOTS; k++) {
+      int q = lane + 64 * k, cq = -1, cwq = 0;
+      for (int cc = 0; cc < nc; cc++) {
+        const int cw_ = cc ? cwl >> (p.sw == 2) : cwl, ch_ = cc ? cwl >> (p.sh == 2) : cwl, n_ = cw_ + 1 + (ch_ >> 1);
+        if (cq < 0) { if (q < n_) { cq = cc; cwq = cw_; } else q -= n_; }
+      }
+      if (cq < 0) continue;
+      const int cswq = cq ? (p.sw == 2) : 0, cshq = cq ? (p.sh == 2) : 0;
+      const int x0q = (ctbX << l2c) >> cswq, y0q = (ctbY << l2c) >> cshq;
+      const int hbase = (cq == 0 ? 0 : SAMP_L + (cq - 1) * SAMP_C) + (cq == 0 ? BODY_L : BODY_C);
+      const bool top = q <= cwq;
+      const int t = top ? q : q - (cwq + 1);
+      /* top granule t: picture columns x0 - 2 + 2t, + 1 = halo entries 2t - 1, 2t; left granule t: rows y0 + 2t, + 1 */
+      const int h1 = top ? 2 * t : HALO_TOP_N + 2 * t + 1;
+      const bool lo = !(top && t == 0);
+      const bool miss = s_body[hbase + h1] == HALO_NOT_READY || (lo && s_body[hbase + h1 - 1] == HALO_NOT_READY);
+      if (!miss) continue;                                   /* (a missing entry lies inside the picture and has a CTB above / left of it) */
+      const size_t eofs = top ? (cq == 0 ? p.edge_row_ofs[0] : (cq == 1 ? p.edge_row_ofs[1] : p.edge_row_ofs[2]))
+                              : (cq == 0 ? p.edge_col_ofs[0] : (cq == 1 ? p.edge_col_ofs[1] : p.edge_col_ofs[2]));
+      const int pwq = cq == 0 ? p.pw[0] : (cq == 1 ? p.pw[1] : p.pw[2]), phq = cq == 0 ? p.ph[0] : (cq == 1 ? p.ph[1] : p.ph[2]);
+      s_kp_ptr[k * 64 + lane] = top ? p.edge + eofs + (size_t)(ctbY - 1) * (size_t)(pwq >> 1) + (size_t)((x0q - 2 + 2 * t) >> 1)
+                                    : p.edge + eofs + (size_t)(ctbX - 1) * (size_t)(phq >> 1) + (size_t)((y0q + 2 * t) >> 1);
+      s_kp_h1[k * 64 + lane] = (uint16_t)((hbase + h1) | (lo ? 0x8000 : 0));      /* (a component's arrays end below element 32768) */
+      kp_pend |= 1u << k;
+    }
+  }
+  auto keeper_step = [&]() {
+    if (!__any((int)(kp_pend != 0u))) return;
+#pragma unroll
+    for (int k = 0; k < KSLOTS; k++) {
+      if (!((kp_fly >> k) & 1u)) continue;
+      const m355_granule gr = kp_gr[k];
+      if ((uint32_t)(gr >> 32) != epoch) continue;
+      const uint32_t h = s_kp_h1[k * 64 + lane];
+      s_body[h & 0x7FFFu] = (uint16_t)(gr >> 16);
+      if (h & 0x8000u) s_body[(h & 0x7FFFu) - 1] = (uint16_t)gr;
+      kp_pend &= ~(1u << k);
+    }
+    kp_fly = kp_pend;
+#pragma unroll
+    for (int k = 0; k < KSLOTS; k++)
+      if ((kp_pend >> k) & 1u) kp_gr[k] = __hip_atomic_load(s_kp_ptr[k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   TL(1);
 #ifdef M355_X_PROF
   if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item] = (unsigned long long)ctb + 1;
@@ -556,6 +628,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   const int lofs_b4 = (lane >> 2) * BODY_PITCH + (lane & 3), lofs_b8 = (lane >> 3) * BODY_PITCH + (lane & 7);
   const int lofs_r4 = (lane >> 2) * RES_PITCH + (lane & 3), lofs_r8 = (lane >> 3) * RES_PITCH + (lane & 7);
   int taken = 0;                                           /* blocks of this wave's component in earlier batches */
+  if (KEEPER && keeper) {
+    /* the halo keeper's walk through the same barriers (a path of its own: what it holds is live nowhere in the block code) */
+    for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
+      const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
+      const int lv = lane < nvalid ? (int)((p.ib_aux[4 * (size_t)(ctbinfo.ib_start + kbase + lane) + 3] >> 16) & 0x3FFFu) : -1;
+      const int lv_first = __builtin_amdgcn_readlane(lv, 0), lv_last = __builtin_amdgcn_readlane(lv, nvalid - 1);
+      for (int L = lv_first; L <= lv_last; L++) { keeper_step(); d_drain_lds(); __builtin_amdgcn_s_barrier(); }
+    }
+  } else
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
     uint4 ex = make_uint4(0, 0, 0, 0);
     int lv = -1;
@@ -969,7 +1050,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 }
 
 #ifndef M355_INTRA_DENSE_NW
-#define M355_INTRA_DENSE_NW 12
+#define M355_INTRA_DENSE_NW 13
 #endif
 template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, bool ticket_zero, hipStream_t st)

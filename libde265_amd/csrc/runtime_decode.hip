@@ -149,6 +149,10 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
     static int slots = 0;
     if (!slots) { hipDeviceProp_t prop; slots = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512; }
     d.intra_grid = grid_env > 0 ? grid_env : std::max(64, slots / std::max(1, c->depth));
+    /* (test hook: the interpreter runs k_intra's workgroups one after the other, so a neighbour's samples are always there when a
+       CTB is staged — this sends them down the paths a CTB takes on the hardware, where they arrive later) */
+    static const int halo_late = getenv("M355_TEST_HALO_LATE") ? atoi(getenv("M355_TEST_HALO_LATE")) : 0;
+    d.test_halo_late = halo_late;
   }
   d.epoch = ++c->epoch;
   if (d.epoch == 0) d.epoch = ++c->epoch;

@@ -340,11 +340,15 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
   std::atomic<long long> n_blocks(0), n_intra_ctbs(0), n_levels(0);
   std::atomic<int> overlap(-1);
   const bool one_sided = !(pp.flags & M355_PF_CONSTRAINED_INTRA_PRED);
+  static const bool level_stats = getenv("M355_INTRA_LEVEL_STATS") != nullptr;
+  double span[4] = {0, 0, 0, 0};
+  std::mutex span_mu;
   /* (an intra picture has hundreds of blocks per CTB: smaller shares, so that a 1080p picture's 510 CTBs still use the whole pool) */
   parallel_ranges((size_t)pic->n_ctbs, (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs ? 16 : 256, [&](size_t cb, size_t ce) {
     std::vector<std::pair<uint32_t, uint32_t>> key, sorted;      /* (level << 2 | cidx, index) */
     uint32_t hist[4 * 128 + 1];                          /* stable counting sort of a CTB's keys (no allocation per CTB) */
     long long my_blocks = 0, my_ctbs = 0, my_levels = 0;
+    double my_span[4] = {0, 0, 0, 0};
     for (size_t c = cb; c < ce; c++) {
       const m355_ctb& ctb = pic->ctbs[c];
       log2_waves[c] = 0; plan_count[c] = 0; touch[c] = 0; need[c] = 0;
@@ -486,12 +490,41 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
       }
       plan_count[c] = rel;
       log2_waves[c] = widest >= 5 ? 3 : (widest >= 3 ? 2 : (widest == 2 ? 1 : 0));
+      if (level_stats) {
+        /* makespan of the CTB's levels in block units (4x4 / 8x8 = 1, 16x16 = 2, 32x32 = 4.5: the per-block times of
+           profiles/r03_*_intra_level_profile_*) under k_intra's wave policies: blocks of a (level, component) go round the
+           component's waves (8 + 2 + 2, 8 + 4 + 4) or round all waves (12, 16) in record order */
+        static const int GW[4][3] = {{8, 2, 2}, {8, 4, 4}, {12, 0, 0}, {16, 16, 16}};
+        double ms[4] = {0, 0, 0, 0};
+        uint32_t k0 = 0;
+        while (k0 < ctb.ib_count) {
+          uint32_t k1 = k0;
+          while (k1 < ctb.ib_count && (key[k1].first >> 2) == (key[k0].first >> 2)) k1++;
+          for (int pol = 0; pol < 4; pol++) {
+            double load[3][16]; memset(load, 0, sizeof(load));
+            int cnt[3] = {0, 0, 0};
+            for (uint32_t k = k0; k < k1; k++) {
+              const m355_ib& ib = pic->ibs[ctb.ib_start + key[k].second];
+              const double cost = ib.log2_size >= 5 ? 4.5 : (ib.log2_size == 4 ? 2.0 : 1.0);
+              const int comp = GW[pol][1] ? ib.cidx : 0;
+              load[comp][cnt[comp]++ % GW[pol][comp]] += cost;
+            }
+            double m = 0;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 16; b++) m = std::max(m, load[a][b]);
+            ms[pol] += m;
+          }
+          k0 = k1;
+        }
+        for (int pol = 0; pol < 4; pol++) my_span[pol] += ms[pol];
+      }
       if (ctb.ib_count) my_levels += (key[ctb.ib_count - 1].first >> 2) + 1;
     }
     n_blocks += my_blocks; n_intra_ctbs += my_ctbs; n_levels += my_levels;
+    if (level_stats) { std::lock_guard<std::mutex> lk(span_mu); for (int q = 0; q < 4; q++) span[q] += my_span[q]; }
   });
   {
-    static const bool stats = getenv("M355_INTRA_LEVEL_STATS") != nullptr;
+    const bool stats = level_stats;
+    if (stats) fprintf(stderr, "intra_schedule: level makespans in block units, waves 8+2+2: %.0f, 8+4+4: %.0f, 12 shared: %.0f, 16 shared: %.0f\n", span[0], span[1], span[2], span[3]);
     if (stats) fprintf(stderr, "intra_schedule: %lld blocks in %lld CTBs, %lld levels (one-sided %d)\n", n_blocks.load(), n_intra_ctbs.load(), n_levels.load(), (int)one_sided);
   }
   *dense = (n_intra_ctbs.load() && n_blocks.load() >= 8 * (long)ctbW * ctbH) ? 1 : 0;

@@ -14,6 +14,7 @@ static inline void d_st_nt8(void* p, unsigned v0, unsigned v1) { ((unsigned*)p)[
 
 #define M355_SPIN_LIMIT 4u
 static inline void d_drain_vmem() {}
+static inline void d_drain_lds() {}
 static inline void d_ldg16(const void* p, unsigned* o) { memcpy(o, p, 16); }
 static inline void d_ldg12(const void* p, unsigned* o) { memcpy(o, p, 12); }
 static inline void d_ldg8(const void* p, unsigned* o) { memcpy(o, p, 8); }
