@@ -175,6 +175,7 @@ struct DevPic {
                                        neighbour (longest first), then the dependent ones in decode order (k_intra's ticket order) */
   int n_intra_work, n_intra_free;
   int intra_grid;                   /* intra pictures: workgroups of k_intra's launch (persistent: each takes CTB after CTB); 0 = one per CTB */
+  int intra_keeper;                 /* intra pictures: launch k_intra with its halo keeper wave (one picture at a time; k_intra.hip) */
   int test_halo_late;               /* test hook (M355_TEST_HALO_LATE=1, tests/test_intra_halo_late.py): k_intra's prologue takes no neighbour's
                                        sample from its granule — every one is fetched behind the prologue, by the halo keeper or the block's own poll */
   const uint8_t* ctb_dep;           /* per CTB: bit n = reads intra output of neighbour n (0 L, 1 TL, 2 T, 3 TR; orders the work list);

@@ -561,6 +561,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   constexpr int KSLOTS = CF == 3 ? 5 : 4;                    /* granules per lane: (cw + 1) + ch / 2 per component */
   const bool keeper = KEEPER && wv == NW - 1;
   uint32_t kp_pend = 0, kp_fly = 0;                          /* bit k: slot k is missing / has a load in flight */
+#ifndef M355_INTRA_KEEPER_TICKS
+#define M355_INTRA_KEEPER_TICKS 0
+#endif
+  unsigned long long kp_t0 = 0;
   m355_granule kp_gr[KSLOTS];
   if (keeper) {
     const int cwl = 1 << l2c;
@@ -634,7 +638,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
       const int lv = lane < nvalid ? (int)((p.ib_aux[4 * (size_t)(ctbinfo.ib_start + kbase + lane) + 3] >> 16) & 0x3FFFu) : -1;
       const int lv_first = __builtin_amdgcn_readlane(lv, 0), lv_last = __builtin_amdgcn_readlane(lv, nvalid - 1);
-      for (int L = lv_first; L <= lv_last; L++) { keeper_step(); d_drain_lds(); __builtin_amdgcn_s_barrier(); }
+      for (int L = lv_first; L <= lv_last; L++) {
+#if M355_INTRA_KEEPER_TICKS > 0     /* experiment: ask again only this many 10 ns ticks after the last request */
+        const unsigned long long now_ = wall_clock64();
+        if (now_ - kp_t0 >= (unsigned long long)M355_INTRA_KEEPER_TICKS) { keeper_step(); kp_t0 = now_; }
+#else
+        keeper_step();
+#endif
+        d_drain_lds(); __builtin_amdgcn_s_barrier();
+      }
     }
   } else
   for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
@@ -1050,15 +1062,21 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 }
 
 #ifndef M355_INTRA_DENSE_NW
-#define M355_INTRA_DENSE_NW 13
+#define M355_INTRA_DENSE_NW 12
 #endif
+#define M355_INTRA_KEEPER_NW 13   /* k_intra's KEEPER instantiation: the worker waves + the halo keeper */
 template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, bool ticket_zero, hipStream_t st)
 {
   if (!ticket_zero) hipMemsetAsync(p.ticket, 0, 4, st);      /* (an inter picture's k_job_count zeroes it: one packet less) */
   /* dense intra pictures: 12 waves (up to 8 luma + 2 + 2 chroma blocks of a level at once); sparse ones: 4 (3 and 6 measured
      slower) */
-  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, false>), dim3(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work), dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
+  const dim3 dense_grid(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work);
+#ifndef M355_X_INTRA_NO_KEEPER
+  if (p.intra_dense && p.intra_keeper) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_KEEPER_NW, true, false>), dense_grid, dim3(64 * M355_INTRA_KEEPER_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
+  else
+#endif
+  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, false>), dense_grid, dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
 }
 

@@ -149,6 +149,10 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
     static int slots = 0;
     if (!slots) { hipDeviceProp_t prop; slots = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512; }
     d.intra_grid = grid_env > 0 ? grid_env : std::max(64, slots / std::max(1, c->depth));
+    /* the halo keeper (a 13th wave per workgroup, k_intra.hip) pays when the picture's own chain is all there is: with more pictures
+       in flight their kernels fill the waits, and a 13-wave workgroup at 128 registers leaves no room on its CU for the 4-wave
+       workgroups of the other pictures' kernels (C2, three in flight: 0.468 -> 0.536 ms per picture, profiles/r05_v14_*) */
+    d.intra_keeper = c->depth == 1;
     /* (test hook: the interpreter runs k_intra's workgroups one after the other, so a neighbour's samples are always there when a
        CTB is staged — this sends them down the paths a CTB takes on the hardware, where they arrive later) */
     static const int halo_late = getenv("M355_TEST_HALO_LATE") ? atoi(getenv("M355_TEST_HALO_LATE")) : 0;

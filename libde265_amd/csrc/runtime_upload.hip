@@ -340,23 +340,56 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
   std::atomic<long long> n_blocks(0), n_intra_ctbs(0), n_levels(0);
   std::atomic<int> overlap(-1);
   const bool one_sided = !(pp.flags & M355_PF_CONSTRAINED_INTRA_PRED);
+  /* INTRA PICTURES (8 or more intra blocks per CTB, as *dense below) get their levels from a picture-wide CLOCK instead of the
+     dependency depth inside the CTB: t(block) = the latest of its producers' t + cost — producers in its own CTB AND the blocks of
+     neighbour CTBs whose samples its mode reads (those a hand-off later) —, in units of one small block (4x4 / 8x8: 1, 16x16: 2,
+     32x32: 5, CTB-to-CTB hand-off: 6 — the times of profiles/r03_*_intra_level_profile_* and r05_v14, rounded); a CTB's levels are the
+     distinct t of its blocks, in order.  Why: with depth-only levels a block at the CTB's left edge that reads nothing of its own
+     CTB sits in level 0 and polls there for a sample the left CTB produces in its LAST level — and the level's barrier holds the
+     whole workgroup for it, i.e. neighbouring CTBs run one after the other instead of half a CTB apart (tools/intra_sim.py models
+     k_intra's chain on the 1080p picture of config 2: 981 -> 758 us with the hand-offs as measured).  Blocks now come up when the
+     clock says their inputs have arrived — which is also what lets the halo keeper (k_intra.hip) have them in LDS by then.  The CTBs
+     are walked in wavefront order (x + 2y) by the pool's threads, each waiting for its left and top-right neighbour's clock. */
+#ifdef M355_X_INTRA_ASAP_LEVELS    /* experiment (tools/variants.sh): depth-only levels for intra pictures too */
+  const bool timed = false;
+#else
+  const bool timed = one_sided && (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs;
+#endif
   static const bool level_stats = getenv("M355_INTRA_LEVEL_STATS") != nullptr;
   double span[4] = {0, 0, 0, 0};
   std::mutex span_mu;
   /* (an intra picture has hundreds of blocks per CTB: smaller shares, so that a 1080p picture's 510 CTBs still use the whole pool) */
-  parallel_ranges((size_t)pic->n_ctbs, (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs ? 16 : 256, [&](size_t cb, size_t ce) {
+  /* (timed) per CTB and component: t + cost of the block behind each 4x4 unit of the CTB's right column [0..15] and bottom row
+     [16..31], -1 = no intra block there; tile column / row of every CTB column / row */
+  std::vector<int32_t> edge_t;
+  std::vector<uint16_t> tcol, trow;
+  if (timed) {
+    edge_t.assign((size_t)pic->n_ctbs * 96, -1);
+    tcol.resize((size_t)ctbW); trow.resize((size_t)ctbH);
+    for (int i = 0; i < pp.num_tile_cols; i++) for (int x = pp.col_bd[i]; x < pp.col_bd[i + 1] && x < ctbW; x++) tcol[(size_t)x] = (uint16_t)i;
+    for (int i = 0; i < pp.num_tile_rows; i++) for (int y = pp.row_bd[i]; y < pp.row_bd[i + 1] && y < ctbH; y++) trow[(size_t)y] = (uint16_t)i;
+  }
+  constexpr int T_HANDOFF = 6;
+  struct Scratch {
     std::vector<std::pair<uint32_t, uint32_t>> key, sorted;      /* (level << 2 | cidx, index) */
-    uint32_t hist[4 * 128 + 1];                          /* stable counting sort of a CTB's keys (no allocation per CTB) */
+    std::vector<int32_t> tstart, tvals;
+    std::vector<uint32_t> histv;                         /* stable counting sort of a CTB's keys (grows once) */
     long long my_blocks = 0, my_ctbs = 0, my_levels = 0;
     double my_span[4] = {0, 0, 0, 0};
-    for (size_t c = cb; c < ce; c++) {
+  };
+  auto schedule_ctb = [&](size_t c, Scratch& S) {
+    auto& key = S.key; auto& sorted = S.sorted;
+    long long& my_blocks = S.my_blocks; long long& my_ctbs = S.my_ctbs; long long& my_levels = S.my_levels; double* const my_span = S.my_span;
+    {
       const m355_ctb& ctb = pic->ctbs[c];
       log2_waves[c] = 0; plan_count[c] = 0; touch[c] = 0; need[c] = 0;
-      if (!ctb.ib_count) continue;
+      if (!ctb.ib_count) return;
       my_ctbs++; my_blocks += ctb.ib_count;
       const int cx = (int)c % ctbW, cy = (int)c / ctbW;
       int8_t grid[3][16][16];                            /* level of the block covering each 4x4 unit (a chain in a CTB is < 64 long) */
+      int32_t tgrid[3][16][16];                          /* (timed) t + cost of the block covering each unit */
       memset(grid, 0xFF, sizeof(grid));                  /* -1: no intra block of this CTB there (yet) */
+      if (timed) { memset(tgrid, 0xFF, sizeof(tgrid)); S.tstart.assign(ctb.ib_count, 0); }
       key.clear();
       bool clash = false;
       for (uint32_t k = 0; k < ctb.ib_count; k++) {
@@ -427,10 +460,42 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
             top_e = te; left_e = le;
           }
           const int top_u = (top_e + 3) >> 2, left_u = (left_e + 3) >> 2;   /* units beside the corner */
-          for (int t = -1; t < 2 * n4; t++) {
+          if (!timed) for (int t = -1; t < 2 * n4; t++) {
             if (t < left_u && ux - 1 >= 0 && uy + t >= 0 && uy + t < 16) level = std::max(level, grid[ib.cidx][uy + t][ux - 1] + 1);
             if (t < top_u && uy - 1 >= 0 && ux + t >= 0 && ux + t < 16) level = std::max(level, grid[ib.cidx][uy - 1][ux + t] + 1);
           }
+          if (timed) {
+            /* the clock: in-CTB producers over the same (conservative) ranges as the levels above, producers in neighbour CTBs over
+               the entries the mode READS (m355_intra_used_entries: what k_intra's plan keeps — the rest is never waited for) */
+            int ute, ule;
+            m355_intra_used_entries(ib.mode, ib.log2_size, ib.cidx, pp.chroma_format_idc, pp.flags, ib.flags, &ute, &ule);
+            const int utop = (ute + 3) >> 2, uleft = (ule + 3) >> 2;
+            const int cu = ((1 << pp.log2_ctb_size) >> csw) >> 2, cv = ((1 << pp.log2_ctb_size) >> csh) >> 2;   /* the CTB in units */
+            int32_t ts = 0;
+            auto nb_edge = [&](int dx, int dy, int slot) -> int32_t {       /* neighbour CTB (cx + dx, cy + dy), same tile, or -1 */
+              const int nx = cx + dx, ny = cy + dy;
+              if (nx < 0 || ny < 0 || nx >= ctbW || tcol[(size_t)nx] != tcol[(size_t)cx] || trow[(size_t)ny] != trow[(size_t)cy]) return -1;
+              return edge_t[((size_t)ny * ctbW + nx) * 96 + (size_t)ib.cidx * 32 + slot];
+            };
+            for (int t = -1; t < 2 * n4; t++) {
+              const int ly_ = uy + t, lx_ = ux + t;
+              if (ux - 1 >= 0) { if (t < left_u && ly_ >= 0 && ly_ < 16) ts = std::max(ts, tgrid[ib.cidx][ly_][ux - 1]); }
+              else if ((t < uleft || t == -1) && ly_ < cv) {
+                const int32_t e = ly_ >= 0 ? nb_edge(-1, 0, ly_) : nb_edge(-1, -1, 16 + cu - 1);
+                if (e >= 0) ts = std::max(ts, e + T_HANDOFF);
+              }
+              if (uy - 1 >= 0) { if (t < top_u && lx_ >= 0 && lx_ < 16) ts = std::max(ts, tgrid[ib.cidx][uy - 1][lx_]); }
+              else if (t < utop || t == -1) {
+                const int32_t e = lx_ < 0 ? nb_edge(-1, -1, 16 + cu - 1) : (lx_ < cu ? nb_edge(0, -1, 16 + lx_) : (lx_ - cu < cu ? nb_edge(1, -1, 16 + lx_ - cu) : -1));
+                if (e >= 0) ts = std::max(ts, e + T_HANDOFF);
+              }
+            }
+            S.tstart[k] = ts;
+          }
+        }
+        if (timed) {
+          const int32_t td = S.tstart[k] + (ib.log2_size >= 5 ? 5 : (ib.log2_size == 4 ? 2 : 1));
+          for (int y = uy; y < uy + n4 && y < 16; y++) for (int x = ux; x < ux + n4 && x < 16; x++) tgrid[ib.cidx][y][x] = td;
         }
         level = std::min(level, 126);                    /* (only overlapping blocks — rejected below — could get there) */
         for (int y = uy; y < uy + n4 && y < 16; y++)
@@ -438,9 +503,36 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
         key.push_back(std::make_pair(((uint32_t)level << 2) | ib.cidx, k));
       }
       if (clash) { int e = -1; overlap.compare_exchange_strong(e, (int)c); }
+      if (timed) {
+        /* levels = the distinct start times, in order (a CTB's times span a few hundred units: ranks by counting); the CTB's edges
+           for the neighbours that follow */
+        int32_t tmin = INT32_MAX, tmax = 0;
+        for (uint32_t k = 0; k < ctb.ib_count; k++) { tmin = std::min(tmin, S.tstart[k]); tmax = std::max(tmax, S.tstart[k]); }
+        const size_t span_t = (size_t)(tmax - tmin) + 1;
+        if (span_t <= 8192) {
+          S.tvals.assign(span_t + 1, 0);
+          for (uint32_t k = 0; k < ctb.ib_count; k++) S.tvals[(size_t)(S.tstart[k] - tmin)] = 1;
+          int32_t r = 0;
+          for (size_t i = 0; i < span_t; i++) { const int32_t u = S.tvals[i]; S.tvals[i] = r; r += u; }
+          for (auto& e : key) e.first = ((uint32_t)S.tvals[(size_t)(S.tstart[e.second] - tmin)] << 2) | (e.first & 3u);
+        } else {
+          S.tvals.assign(S.tstart.begin(), S.tstart.end());
+          std::sort(S.tvals.begin(), S.tvals.end());
+          S.tvals.erase(std::unique(S.tvals.begin(), S.tvals.end()), S.tvals.end());
+          for (auto& e : key) e.first = ((uint32_t)(std::lower_bound(S.tvals.begin(), S.tvals.end(), S.tstart[e.second]) - S.tvals.begin()) << 2) | (e.first & 3u);
+        }
+        int32_t* const et = &edge_t[c * 96];
+        for (int q = 0; q < 3; q++) {
+          const int csw = q ? (sw == 2) : 0, csh = q ? (sh == 2) : 0;
+          const int cu = ((1 << pp.log2_ctb_size) >> csw) >> 2, cv = ((1 << pp.log2_ctb_size) >> csh) >> 2;
+          for (int i = 0; i < 16; i++) { et[q * 32 + i] = i < cv ? tgrid[q][i][cu - 1] : -1; et[q * 32 + 16 + i] = i < cu ? tgrid[q][cv - 1][i] : -1; }
+        }
+      }
       {
         uint32_t kmax = 0;
         for (const auto& e : key) kmax = std::max(kmax, e.first);
+        if (S.histv.size() < (size_t)kmax + 2) S.histv.resize((size_t)kmax + 2);
+        uint32_t* const hist = S.histv.data();
         for (uint32_t i = 0; i <= kmax + 1; i++) hist[i] = 0;
         for (const auto& e : key) hist[e.first + 1]++;
         for (uint32_t i = 1; i <= kmax; i++) hist[i] += hist[i - 1];
@@ -519,9 +611,49 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
       }
       if (ctb.ib_count) my_levels += (key[ctb.ib_count - 1].first >> 2) + 1;
     }
-    n_blocks += my_blocks; n_intra_ctbs += my_ctbs; n_levels += my_levels;
-    if (level_stats) { std::lock_guard<std::mutex> lk(span_mu); for (int q = 0; q < 4; q++) span[q] += my_span[q]; }
-  });
+  };
+  auto fold_stats = [&](const Scratch& S) {
+    n_blocks += S.my_blocks; n_intra_ctbs += S.my_ctbs; n_levels += S.my_levels;
+    if (level_stats) { std::lock_guard<std::mutex> lk(span_mu); for (int q = 0; q < 4; q++) span[q] += S.my_span[q]; }
+  };
+  if (!timed) {
+    parallel_ranges((size_t)pic->n_ctbs, (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs ? 16 : 256, [&](size_t cb, size_t ce) {
+      Scratch S;
+      for (size_t c = cb; c < ce; c++) schedule_ctb(c, S);
+      fold_stats(S);
+    });
+  } else {
+    /* wavefront order: a CTB's clock needs those of its left and top-right neighbours (which bring top-left and top with them);
+       the pool's threads claim CTBs in that order and wait for the two flags — a thread only ever waits for a CTB claimed before
+       its own, i.e. one that another running thread is working on */
+    const size_t n = (size_t)pic->n_ctbs;
+    std::vector<uint32_t> order(n);
+    {
+      std::vector<uint32_t> cnt((size_t)ctbW + 2 * (size_t)ctbH + 2, 0);
+      for (size_t c = 0; c < n; c++) cnt[(c % ctbW) + 2 * (c / ctbW) + 1]++;
+      for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
+      for (size_t c = 0; c < n; c++) order[cnt[(c % ctbW) + 2 * (c / ctbW)]++] = (uint32_t)c;
+    }
+    std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[n]);
+    for (size_t c = 0; c < n; c++) done[c].store(0, std::memory_order_relaxed);
+    std::atomic<size_t> next(0);
+    const size_t parts = std::min<size_t>((size_t)std::max(1, host_threads()), std::max<size_t>(1, (size_t)std::min(ctbW, ctbH)));
+    parallel_ranges(parts, 1, [&](size_t, size_t) {
+      Scratch S;
+      for (;;) {
+        const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= n) break;
+        const size_t c = order[i];
+        const int cx = (int)(c % ctbW), cy = (int)(c / ctbW);
+        const size_t dep[2] = {cx > 0 ? c - 1 : n, cy > 0 ? (cx + 1 < ctbW ? c - ctbW + 1 : c - ctbW) : n};
+        for (int d = 0; d < 2; d++)
+          if (dep[d] < n) while (!done[dep[d]].load(std::memory_order_acquire)) std::this_thread::yield();
+        schedule_ctb(c, S);
+        done[c].store(1, std::memory_order_release);
+      }
+      fold_stats(S);
+    });
+  }
   {
     const bool stats = level_stats;
     if (stats) fprintf(stderr, "intra_schedule: level makespans in block units, waves 8+2+2: %.0f, 8+4+4: %.0f, 12 shared: %.0f, 16 shared: %.0f\n", span[0], span[1], span[2], span[3]);

@@ -274,3 +274,30 @@ lvg = levels_greedy(dep_x_used)
 for pl in (0.5, 1.0, 1.5):
     a = simulate(lv0, dep_x_all, pl=pl)[0]; b = simulate(lv0, dep_x_used, pl=pl)[0]; c_ = simulate(lvg, dep_x_used, pl=pl)[0]; d_ = simulate(lvg, dep_x_used, pl=0)[0]
     print("poll %.1f us: shipped %.0f us, pruned %.0f, greedy + pruned %.0f, greedy + pruned + halo kept fresh by a poller wave %.0f" % (pl, a, b, c_, d_))
+
+
+def levels_timed_int(depx, ho_u=6, c32=5, c16=2):
+    """integer clock: block costs 1 / c16 / c32 units, a hand-off ho_u; a CTB's levels = the distinct start times of its blocks"""
+    ci_ = np.where(bl >= 5, c32, np.where(bl == 4, c16, 1)).astype(np.int64)
+    t = np.zeros(NB, np.int64)
+    for k in range(NB):
+        a = max([t[d] + ci_[d] for d in dep_in[k]], default=0)
+        b = max([t[d] + ci_[d] + ho_u for d in depx[k]], default=0)
+        t[k] = max(a, b)
+    lv = np.zeros(NB, np.int64)
+    for c in range(ctbW * ctbH):
+        s, n = int(ctbs["ib_start"][c]), int(ctbs["ib_count"][c])
+        if not n: continue
+        ts = sorted(set(int(t[k]) for k in range(s, s + n)))
+        rank = {v: i for i, v in enumerate(ts)}
+        for k in range(s, s + n): lv[k] = rank[int(t[k])]
+    return lv
+
+
+print("--- integer-clock levels (what the host can compute in one pass over the CTBs in wavefront order)")
+for ho_u, c32, c16 in ((6, 5, 2), (6, 4, 2), (8, 5, 2), (4, 5, 2), (10, 5, 2)):
+    lv3 = levels_timed_int(dep_x_used, ho_u, c32, c16)
+    res = []
+    for kw in ({}, dict(pl=0.5), dict(u=U * 1.2), dict(ho=4.0), dict(ho=1.5)):
+        T, nl, st, bs = simulate(lv3, dep_x_used, **kw); res.append(T)
+    print("hand-off %2d units, 32x32 %d, 16x16 %d: %6d levels; model %.0f us | +0.5 us poll floor %.0f | blocks 20 %% slower %.0f | hand-off 4 us %.0f | 1.5 us %.0f" % (ho_u, c32, c16, nl, *res))
