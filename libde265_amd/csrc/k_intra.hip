@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
   __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
   /* the halo keeper's slots (below): granule address and halo element per lane and slot */
-  __shared__ const m355_granule* s_kp_ptr[(DENSE && NW == 13) ? 5 * 64 : 1];
+  __shared__ uint32_t s_kp_idx[(DENSE && NW == 13) ? 5 * 64 : 1];      /* (an index into DevPic.edge: the load stays a GLOBAL one — a pointer out of LDS makes it flat, and a flat load also counts as an LDS operation, which the wave waits for in front of every barrier) */
   __shared__ uint16_t s_kp_h1[(DENSE && NW == 13) ? 5 * 64 : 1];
 #ifdef M355_X_INTRA_LDS_PAD      /* experiment (tools/variants.sh): what does a workgroup less per CU cost the sparse kernel? */
   __shared__ uint32_t s_pad[DENSE ? 1 : M355_X_INTRA_LDS_PAD / 4];
@@ -591,28 +591,30 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const size_t eofs = top ? (cq == 0 ? p.edge_row_ofs[0] : (cq == 1 ? p.edge_row_ofs[1] : p.edge_row_ofs[2]))
                               : (cq == 0 ? p.edge_col_ofs[0] : (cq == 1 ? p.edge_col_ofs[1] : p.edge_col_ofs[2]));
       const int pwq = cq == 0 ? p.pw[0] : (cq == 1 ? p.pw[1] : p.pw[2]), phq = cq == 0 ? p.ph[0] : (cq == 1 ? p.ph[1] : p.ph[2]);
-      s_kp_ptr[k * 64 + lane] = top ? p.edge + eofs + (size_t)(ctbY - 1) * (size_t)(pwq >> 1) + (size_t)((x0q - 2 + 2 * t) >> 1)
-                                    : p.edge + eofs + (size_t)(ctbX - 1) * (size_t)(phq >> 1) + (size_t)((y0q + 2 * t) >> 1);
+      s_kp_idx[k * 64 + lane] = (uint32_t)(top ? eofs + (size_t)(ctbY - 1) * (size_t)(pwq >> 1) + (size_t)((x0q - 2 + 2 * t) >> 1)
+                                               : eofs + (size_t)(ctbX - 1) * (size_t)(phq >> 1) + (size_t)((y0q + 2 * t) >> 1));
       s_kp_h1[k * 64 + lane] = (uint16_t)((hbase + h1) | (lo ? 0x8000 : 0));      /* (a component's arrays end below element 32768) */
       kp_pend |= 1u << k;
     }
   }
   auto keeper_step = [&]() {
     if (!__any((int)(kp_pend != 0u))) return;
+    uint32_t gi[KSLOTS], hh[KSLOTS];
+#pragma unroll
+    for (int k = 0; k < KSLOTS; k++) { gi[k] = s_kp_idx[k * 64 + lane]; hh[k] = s_kp_h1[k * 64 + lane]; }   /* (one LDS round trip for all slots) */
 #pragma unroll
     for (int k = 0; k < KSLOTS; k++) {
       if (!((kp_fly >> k) & 1u)) continue;
       const m355_granule gr = kp_gr[k];
       if ((uint32_t)(gr >> 32) != epoch) continue;
-      const uint32_t h = s_kp_h1[k * 64 + lane];
-      s_body[h & 0x7FFFu] = (uint16_t)(gr >> 16);
-      if (h & 0x8000u) s_body[(h & 0x7FFFu) - 1] = (uint16_t)gr;
+      s_body[hh[k] & 0x7FFFu] = (uint16_t)(gr >> 16);
+      if (hh[k] & 0x8000u) s_body[(hh[k] & 0x7FFFu) - 1] = (uint16_t)gr;
       kp_pend &= ~(1u << k);
     }
     kp_fly = kp_pend;
 #pragma unroll
     for (int k = 0; k < KSLOTS; k++)
-      if ((kp_pend >> k) & 1u) kp_gr[k] = __hip_atomic_load(s_kp_ptr[k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((kp_pend >> k) & 1u) kp_gr[k] = __hip_atomic_load(p.edge + gi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   TL(1);
 #ifdef M355_X_PROF

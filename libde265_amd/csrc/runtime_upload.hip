@@ -369,7 +369,13 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
     for (int i = 0; i < pp.num_tile_cols; i++) for (int x = pp.col_bd[i]; x < pp.col_bd[i + 1] && x < ctbW; x++) tcol[(size_t)x] = (uint16_t)i;
     for (int i = 0; i < pp.num_tile_rows; i++) for (int y = pp.row_bd[i]; y < pp.row_bd[i + 1] && y < ctbH; y++) trow[(size_t)y] = (uint16_t)i;
   }
-  constexpr int T_HANDOFF = 6;
+#ifndef M355_INTRA_T_HANDOFF
+#define M355_INTRA_T_HANDOFF 6
+#endif
+#ifndef M355_INTRA_T_32
+#define M355_INTRA_T_32 5
+#endif
+  constexpr int T_HANDOFF = M355_INTRA_T_HANDOFF;
   struct Scratch {
     std::vector<std::pair<uint32_t, uint32_t>> key, sorted;      /* (level << 2 | cidx, index) */
     std::vector<int32_t> tstart, tvals;
@@ -494,7 +500,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
           }
         }
         if (timed) {
-          const int32_t td = S.tstart[k] + (ib.log2_size >= 5 ? 5 : (ib.log2_size == 4 ? 2 : 1));
+          const int32_t td = S.tstart[k] + (ib.log2_size >= 5 ? M355_INTRA_T_32 : (ib.log2_size == 4 ? 2 : 1));
           for (int y = uy; y < uy + n4 && y < 16; y++) for (int x = ux; x < ux + n4 && x < 16; x++) tgrid[ib.cidx][y][x] = td;
         }
         level = std::min(level, 126);                    /* (only overlapping blocks — rejected below — could get there) */
