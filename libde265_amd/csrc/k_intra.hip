@@ -557,6 +557,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      beside the blocks, in front of the same barrier — takes in the loads it issued a level earlier, stores the samples that have
      arrived into the halo and asks again for the rest.  Its loads stay in flight across the barrier (raw s_barrier, no fence: gfx950
      backs off a barrier with memory operations outstanding).  A block whose sample is still missing polls as before. ---- */
+#ifdef M355_X_INTRA_NO_SHARE      /* experiment (tools/variants.sh): a big block is one wave's, as before */
+  constexpr bool SHARE_BIG = false;
+#else
+  constexpr bool SHARE_BIG = DENSE;
+#endif
   constexpr bool KEEPER = DENSE && NW == 13;
   constexpr int KSLOTS = CF == 3 ? 5 : 4;                    /* granules per lane: (cw + 1) + ch / 2 per component */
   const bool keeper = KEEPER && wv == NW - 1;
@@ -681,9 +686,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
          L + 1 — that wave did so while the others worked (after the barrier of ITS last block), and what is left between two
          barriers of the chain is border read -> taps -> arithmetic -> sample write */
       const unsigned long long same = __ballot((int)(comp && lane < nvalid && ((ex.x >> 17) & 3u) == (uint32_t)c));
-      const int rank = taken + __popcll(same & ((1ull << lane) - 1ull));
-      mine = same & __ballot((int)((rank & (G - 1)) == g));
-      taken += __popcll(same);
+      /* intra pictures: a 16x16 / 32x32 block is EVERY wave's of its component — each gathers (and smooths) the whole border itself and
+         predicts its share of the rows (below): no barrier beyond the level's own, and the block costs the chain about one small
+         block's time instead of 2 / 4.5 (the round trip is the border's, the arithmetic is 1 / 4 .. 1 / 8 of the samples) */
+      const unsigned long long big = SHARE_BIG ? same & __ballot((int)(((ex.x >> 14) & 7u) >= 4u && !(ex.x & M355_IBX_PCM))) : 0ull;
+      const unsigned long long few = same & ~big;
+      const int rank = taken + __popcll(few & ((1ull << lane) - 1ull));
+      mine = (few & __ballot((int)((rank & (G - 1)) == g))) | big;
+      taken += __popcll(few);
     }
     /* the wave's NEXT block, decoded: record words, offsets of its first sample in the body / residual tiles, mode parameters,
        and (4x4 / 8x8) the plan entries of its border, entry e in lane e */
@@ -821,8 +831,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       if (__builtin_expect(d_small, 1)) {
         if (log2 == 2) small_block(std::integral_constant<int, 2>()); else small_block(std::integral_constant<int, 3>());
       } else {
+      /* this wave's share of a 16x16 / 32x32 block: passes (64 samples = 4 / 2 rows each) [it_lo, it_hi) of the block's 4 / 16 */
+      const int nPass = (nT * nT) >> 6;
+      const int it_lo = SHARE_BIG ? (nPass * g) / G : 0, it_hi = SHARE_BIG ? (nPass * (g + 1)) / G : nPass;
       if (!(e0 & M355_IBX_PCM)) {
         /* ---- 16x16 / 32x32: the border lives in LDS (65 / 129 entries) ---- */
+        if (it_lo < it_hi) {
         const int nEnt = 4 * nT + 1, Z = 2 * nT;
         const uint16_t* pl = s_plan + ((e3 & 0xFFFFu) - plan_lo);
         /* (all plan entries, then all samples: two LDS round trips for the whole border, not two per 64-entry chunk) */
@@ -935,11 +949,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             const int u_tr = CLS == 0 ? BRD(1 + nT) : 0, u_bl = CLS == 0 ? BRD(-1 - nT) : 0;
             const int u_c = CLS == 2 ? BRD(0) : 0, u_f = CLS == 2 ? (vert ? BRD(1) : BRD(-1)) : 0;
             const int u_e2 = CLS == 1 ? BRD(-1) + BRD(1) : 0;
-            for (int it0 = 0; it0 < nIt; it0 += 4) {
+            (void)nIt;
+            for (int it0 = it_lo; it0 < it_hi; it0 += 4) {
               int ta[4], tb[4], fa[4], rs[4];
 #pragma unroll
               for (int u = 0; u < 4; u++) {
-                const int y = yb + (it0 + u) * ystep;
+                const int y = yb + min(it0 + u, it_hi - 1) * ystep;      /* (a share of 1 or 2 passes: the rest repeats the last one) */
                 fa[u] = 0; tb[u] = 0;
                 if (CLS == 0 || CLS == 2) ta[u] = BRD(-1 - y);
                 else if (CLS == 1) ta[u] = BRD(y == 0 ? x + 1 : -y - 1);
@@ -961,7 +976,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
               }
 #pragma unroll
               for (int u = 0; u < 4; u++) {
-                const int y = yb + (it0 + u) * ystep;
+                const int y = yb + min(it0 + u, it_hi - 1) * ystep;
                 int v;
                 if (CLS == 0) v = (__mul24(nT - 1 - x, ta[u]) + __mul24(x + 1, u_tr) + __mul24(nT - 1 - y, t_x) + __mul24(y + 1, u_bl) + nT) >> (log2 + 1);
                 else if (CLS == 1) {
@@ -998,21 +1013,24 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
 #undef BRD
 #undef PREDICT_SAMPLE
+        }   /* a share of the block */
       } else { /* raw block (slice.cc:4211-4255) */
         for (int o = lane; o < nT * nT; o += 64) {
           const int y = o >> log2, x = o & (nT - 1);
           body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = p.pcm[e1 + o];
         }
       }
-      /* ---- publish: the block's share of the CTB's right column / bottom row, two samples per granule ---- */
-      if (pub_col || pub_row) {
+      /* ---- publish: the block's share of the CTB's right column / bottom row, two samples per granule (of a shared block: the rows
+         this wave predicted — a pass is 4 / 2 whole rows —, the bottom row by the wave that holds the last pass) ---- */
+      const int pr_lo = (e0 & M355_IBX_PCM) ? 0 : it_lo * (64 >> log2), pr_hi = (e0 & M355_IBX_PCM) ? nT : it_hi * (64 >> log2);
+      if (pub_col || (pub_row && pr_hi == nT)) {
         wave_sync();
-        if (pub_col && lane < (nT >> 1)) {
+        if (pub_col && lane < (nT >> 1) && 2 * lane >= pr_lo && 2 * lane < pr_hi) {
           const int y = ly + 2 * lane;
           const uint32_t s0 = body[y * BODY_PITCH + lx + nT - 1 + BODY_X0], s1 = body[(y + 1) * BODY_PITCH + lx + nT - 1 + BODY_X0];
           __hip_atomic_store(d_edge_col(p, cs, ctbX, y0c + y), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (pub_row && lane >= 32 && lane < 32 + (nT >> 1)) {
+        if (pub_row && pr_hi == nT && lane >= 32 && lane < 32 + (nT >> 1)) {
           const int x = lx + 2 * (lane - 32);
           const uint32_t s0 = body[(ly + nT - 1) * BODY_PITCH + x + BODY_X0], s1 = body[(ly + nT - 1) * BODY_PITCH + x + 1 + BODY_X0];
           __hip_atomic_store(d_edge_row(p, cs, ctbY, x0c + x), ((m355_granule)epoch << 32) | (s1 << 16) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

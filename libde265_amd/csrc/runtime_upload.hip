@@ -342,8 +342,8 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
   const bool one_sided = !(pp.flags & M355_PF_CONSTRAINED_INTRA_PRED);
   /* INTRA PICTURES (8 or more intra blocks per CTB, as *dense below) get their levels from a picture-wide CLOCK instead of the
      dependency depth inside the CTB: t(block) = the latest of its producers' t + cost — producers in its own CTB AND the blocks of
-     neighbour CTBs whose samples its mode reads (those a hand-off later) —, in units of one small block (4x4 / 8x8: 1, 16x16: 2,
-     32x32: 5, CTB-to-CTB hand-off: 6 — the times of profiles/r03_*_intra_level_profile_* and r05_v14, rounded); a CTB's levels are the
+     neighbour CTBs whose samples its mode reads (those a hand-off later) —, in units of one small block (4x4 / 8x8: 1, 16x16: 1,
+     32x32: 2 — k_intra shares those among a component's waves —, CTB-to-CTB hand-off: 6 — the times of profiles/r03_*_intra_level_profile_* and r05_v14, rounded); a CTB's levels are the
      distinct t of its blocks, in order.  Why: with depth-only levels a block at the CTB's left edge that reads nothing of its own
      CTB sits in level 0 and polls there for a sample the left CTB produces in its LAST level — and the level's barrier holds the
      whole workgroup for it, i.e. neighbouring CTBs run one after the other instead of half a CTB apart (tools/intra_sim.py models
@@ -373,7 +373,10 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
 #define M355_INTRA_T_HANDOFF 6
 #endif
 #ifndef M355_INTRA_T_32
-#define M355_INTRA_T_32 5
+#define M355_INTRA_T_32 2     /* (k_intra shares a 16x16 / 32x32 block among its component's waves) */
+#endif
+#ifndef M355_INTRA_T_16
+#define M355_INTRA_T_16 1
 #endif
   constexpr int T_HANDOFF = M355_INTRA_T_HANDOFF;
   struct Scratch {
@@ -500,7 +503,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
           }
         }
         if (timed) {
-          const int32_t td = S.tstart[k] + (ib.log2_size >= 5 ? M355_INTRA_T_32 : (ib.log2_size == 4 ? 2 : 1));
+          const int32_t td = S.tstart[k] + (ib.log2_size >= 5 ? M355_INTRA_T_32 : (ib.log2_size == 4 ? M355_INTRA_T_16 : 1));
           for (int y = uy; y < uy + n4 && y < 16; y++) for (int x = ux; x < ux + n4 && x < 16; x++) tgrid[ib.cidx][y][x] = td;
         }
         level = std::min(level, 126);                    /* (only overlapping blocks — rejected below — could get there) */
