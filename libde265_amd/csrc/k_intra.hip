@@ -557,6 +557,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      beside the blocks, in front of the same barrier — takes in the loads it issued a level earlier, stores the samples that have
      arrived into the halo and asks again for the rest.  Its loads stay in flight across the barrier (raw s_barrier, no fence: gfx950
      backs off a barrier with memory operations outstanding).  A block whose sample is still missing polls as before. ---- */
+#ifndef M355_INTRA_SHARE_MIN_LOG2
+#define M355_INTRA_SHARE_MIN_LOG2 5   /* 32x32 only (16x16 too: C2 0.82 -> 0.87 ms, profiles/r05_v17_*) */
+#endif
 #ifdef M355_X_INTRA_NO_SHARE      /* experiment (tools/variants.sh): a big block is one wave's, as before */
   constexpr bool SHARE_BIG = false;
 #else
@@ -689,7 +692,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       /* intra pictures: a 16x16 / 32x32 block is EVERY wave's of its component — each gathers (and smooths) the whole border itself and
          predicts its share of the rows (below): no barrier beyond the level's own, and the block costs the chain about one small
          block's time instead of 2 / 4.5 (the round trip is the border's, the arithmetic is 1 / 4 .. 1 / 8 of the samples) */
-      const unsigned long long big = SHARE_BIG ? same & __ballot((int)(((ex.x >> 14) & 7u) >= 4u && !(ex.x & M355_IBX_PCM))) : 0ull;
+      const unsigned long long big = SHARE_BIG ? same & __ballot((int)(((ex.x >> 14) & 7u) >= (uint32_t)M355_INTRA_SHARE_MIN_LOG2 && !(ex.x & M355_IBX_PCM))) : 0ull;
       const unsigned long long few = same & ~big;
       const int rank = taken + __popcll(few & ((1ull << lane) - 1ull));
       mine = (few & __ballot((int)((rank & (G - 1)) == g))) | big;
@@ -833,7 +836,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       } else {
       /* this wave's share of a 16x16 / 32x32 block: passes (64 samples = 4 / 2 rows each) [it_lo, it_hi) of the block's 4 / 16 */
       const int nPass = (nT * nT) >> 6;
-      const int it_lo = SHARE_BIG ? (nPass * g) / G : 0, it_hi = SHARE_BIG ? (nPass * (g + 1)) / G : nPass;
+      const bool shared = SHARE_BIG && log2 >= M355_INTRA_SHARE_MIN_LOG2;
+      const int it_lo = shared ? (nPass * g) / G : 0, it_hi = shared ? (nPass * (g + 1)) / G : nPass;
       if (!(e0 & M355_IBX_PCM)) {
         /* ---- 16x16 / 32x32: the border lives in LDS (65 / 129 entries) ---- */
         if (it_lo < it_hi) {

@@ -376,7 +376,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
 #define M355_INTRA_T_32 2     /* (k_intra shares a 16x16 / 32x32 block among its component's waves) */
 #endif
 #ifndef M355_INTRA_T_16
-#define M355_INTRA_T_16 1
+#define M355_INTRA_T_16 2
 #endif
   constexpr int T_HANDOFF = M355_INTRA_T_HANDOFF;
   struct Scratch {
