@@ -124,34 +124,22 @@ template <int CF> struct IntraGeo {
   static constexpr int SAMP_L = COMP_LDS(BODY_L), SAMP_C = COMP_LDS(BODY_C);   /* elements of a luma / chroma component's array */
 };
 
-/* ------------------------------------------------------------------------------------------------------------------
- * k_intra_plan: PLAN_SPLIT workgroups of 4 waves per CTB with intra blocks; a wave takes every (4 * PLAN_SPLIT)-th block, one
- * border entry per lane (up to three passes for the 129 entries of a 32x32 block).
- * ---------------------------------------------------------------------------------------------------------------- */
 #ifndef PLAN_SPLIT
 #define PLAN_SPLIT 8   /* (4 -> 8: C2 waits 15 us less for its plans, profiles/r03_u_*) */
 #endif
+/* the plan of ONE block (record k of the CTB's sorted list): `codes` = 4 * 32 + 8 elements of the calling wave's LDS scratch, `dst` = where
+   the CTB's plans start (global memory: k_intra_plan; LDS: k_intra plans an intra picture's CTB itself, in its prologue) */
 template <int CF>
-__device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n, const int item, const int part, const int n_parts)
+__device__ __forceinline__ void d_intra_plan_block(const DevPic& p, const uint32_t ib_index, const int ctbX, const int ctbY, const uint32_t nb_same, const uint32_t nb_earlier, uint16_t* codes, uint16_t* dst)
 {
-  M355_GATE(p);
-  __shared__ uint16_t s_code[4][4 * 32 + 8];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  if (item >= work_n) return;
-  const DevIntraWork* wp = p.intra_work + item;
-  const int ctb = __builtin_amdgcn_readfirstlane((int)wp->ctb);
-  const uint32_t ib_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->ib_start), ib_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->ib_count);
-  const uint32_t nb_same = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->nb_same), nb_earlier = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->nb_earlier);
-  const uint32_t plan_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->plan_base);
-  const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
+  const int lane = threadIdx.x & 63;
   const int l2c = p.pp.log2_ctb_size;
-  uint16_t* codes = s_code[wv];
-  for (uint32_t k = (uint32_t)(wv + 4 * part); k < ib_count; k += 4 * (uint32_t)n_parts) {
-    const uint32_t* r = (const uint32_t*)&p.ibs[ib_start + k];
+  {
+    const uint32_t* r = (const uint32_t*)&p.ibs[ib_index];
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[0]), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[1]);
-    const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[4 * (ib_start + k) + 3]);
+    const uint32_t aux = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ib_aux[4 * ib_index + 3]);
     const int c = (int)(w1 & 0xFFu), log2 = (int)((w1 >> 8) & 0xFFu), flags = (int)(w1 >> 24);
-    if (flags & M355_IBF_PCM) continue;                      /* raw blocks read no border: no plan entries */
+    if (flags & M355_IBF_PCM) return;                        /* raw blocks read no border: no plan entries */
     const int nT = 1 << log2;
     const int csw = c ? (p.sw == 2) : 0, csh = c ? (p.sh == 2) : 0;
     const int SubW = 1 << csw, SubH = 1 << csh;
@@ -222,7 +210,7 @@ __device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n, c
       if (e < nEnt) codes[e] = (uint16_t)code[q];
     }
     wave_sync();
-    uint16_t* out = p.iplan + plan_base + (aux & 0xFFFFu);
+    uint16_t* out = dst + (aux & 0xFFFFu);
     /* entries the block's mode never reads (k_common.h m355_intra_used_entries) are pointed at the constant cell AFTER the
        substitution (an entry inside the used range may well take its value from one outside): k_intra's blocks fetch all 4nT + 1
        entries, and a HALO entry whose CTB has not published it yet would make the block wait for a sample it does not use */
@@ -246,6 +234,28 @@ __device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n, c
     }
     wave_sync();                                             /* codes[] is reused by the wave's next block */
   }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * k_intra_plan: PLAN_SPLIT workgroups of 4 waves per CTB with intra blocks; a wave takes every (4 * PLAN_SPLIT)-th block, one
+ * border entry per lane (up to three passes for the 129 entries of a 32x32 block).  (Pictures with a handful of intra blocks per CTB;
+ * an intra picture's CTBs are planned by k_intra itself.)
+ * ---------------------------------------------------------------------------------------------------------------- */
+template <int CF>
+__device__ __forceinline__ void k_intra_plan_body(const DevPic& p, int work_n, const int item, const int part, const int n_parts)
+{
+  M355_GATE(p);
+  __shared__ uint16_t s_code[4][4 * 32 + 8];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (item >= work_n) return;
+  const DevIntraWork* wp = p.intra_work + item;
+  const int ctb = __builtin_amdgcn_readfirstlane((int)wp->ctb);
+  const uint32_t ib_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->ib_start), ib_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->ib_count);
+  const uint32_t nb_same = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->nb_same), nb_earlier = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->nb_earlier);
+  const uint32_t plan_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wp->plan_base);
+  const int ctbX = ctb % p.ctbW, ctbY = ctb / p.ctbW;
+  for (uint32_t k = (uint32_t)(wv + 4 * part); k < ib_count; k += 4 * (uint32_t)n_parts)
+    d_intra_plan_block<CF>(p, ib_start + k, ctbX, ctbY, nb_same, nb_earlier, s_code[wv], p.iplan + plan_base);
 }
 template <int CF> __global__ void __launch_bounds__(256) k_intra_plan(DevPic p, int work_n) { k_intra_plan_body<CF>(p, work_n, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y); }
 template <int CF> __global__ void __launch_bounds__(256) k_intra_plan_batch(DevBatch b) { M355_BATCH_PIC(b); k_intra_plan_body<CF>(p, p.n_intra_work, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y); }
@@ -284,6 +294,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   /* the plan (k_intra_plan): the whole CTB's (dense: M355_INTRA_PLAN_CAP entries, runtime.hip rejects CTBs beyond it) or 64
      blocks' at a time (M355_INTRA_PLAN_BATCH) */
   constexpr int PLAN_LDS = DENSE ? M355_INTRA_PLAN_CAP(CF) : M355_INTRA_PLAN_BATCH(CF);
+#ifdef M355_X_INTRA_PLAN_LAUNCH   /* experiment (tools/variants.sh): intra pictures' plans from k_tu_plan's launch, as before */
+  constexpr bool PLAN_HERE = false;
+#else
+  constexpr bool PLAN_HERE = DENSE;
+#endif
   __shared__ __attribute__((aligned(16))) uint16_t s_plan[PLAN_LDS];
   /* per WAVE (a wave works on one block at a time): */
   __shared__ uint16_t s_raw[NW][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
@@ -389,7 +404,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   /* ---- the plan: the whole CTB's (dense) or its first PLAN_LDS entries (a later batch of 64 blocks reloads), 16 bytes per
      lane and step, requested before anything else ---- */
   uint32_t plan_lo = 0;                                    /* first entry held in s_plan */
-  {
+  if (PLAN_HERE) {
+    /* an intra picture's CTB is planned HERE, straight into LDS, by all the workgroup's waves (a block each, round robin): the
+       prologue is off the chain — a CTB is claimed long before its neighbours let it run —, whereas the planner's launch stood in
+       front of k_intra with 45-78 us for the 66 000 blocks of the 1080p picture of config 2 (profiles/r05_z_c2_*) */
+    const uint32_t nbs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w & 0xFFFFu)), nbe = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w >> 16));
+    for (uint32_t k = (uint32_t)wv; k < ctbinfo.ib_count; k += (uint32_t)NW)
+      d_intra_plan_block<CF>(p, ctbinfo.ib_start + k, ctbX, ctbY, nbs, nbe, s_raw[wv], s_plan);
+  } else {
     const uint32_t n = min(plan_count, (uint32_t)PLAN_LDS);
     const uint4* src = (const uint4*)(p.iplan + plan_base);  /* plan_base is a multiple of 8 entries */
     for (uint32_t o = (uint32_t)(wv * 64 + lane) * 8u; o < n; o += (uint32_t)NWV * 512u) *(uint4*)(s_plan + o) = src[o >> 3];
@@ -1136,6 +1158,9 @@ void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pi
 void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
 {
   int work = 0, cf = 1;
+#ifndef M355_X_INTRA_PLAN_LAUNCH
+  return;                                                  /* (a batch is made of intra pictures: planned by k_intra itself) */
+#endif
   for (int k = 0; k < b.n; k++) if ((b.on >> k) & 1u) { work = std::max(work, b.host[k].n_intra_work); cf = b.host[k].pp.chroma_format_idc; }
   if (!work) return;
   const DevBatch d{b.dev, b.on};
@@ -1152,19 +1177,28 @@ void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
    the metadata planes on the side stream, beside k_inter / k_residual) */
 void m355_launch_tu_plan(const DevPic& p, hipStream_t st)
 {
-  const int nb_tu = (p.n_tus + 255) / 256, split = p.intra_dense ? PLAN_SPLIT : 1, nb = nb_tu + p.n_intra_work * split;
+  /* (an intra picture's CTBs are planned by k_intra itself: the launch carries the transform edges only) */
+#ifdef M355_X_INTRA_PLAN_LAUNCH
+  const int n_plan = p.n_intra_work, split = p.intra_dense ? PLAN_SPLIT : 1;
+#else
+  const int n_plan = p.intra_dense ? 0 : p.n_intra_work, split = 1;
+#endif
+  const int nb_tu = (p.n_tus + 255) / 256, nb = nb_tu + n_plan * split;
   if (!nb) return;
   switch (p.pp.chroma_format_idc) {
-    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<0>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
-    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<1>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<2>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<3>), dim3(nb), dim3(256), 0, st, p, nb_tu, p.n_intra_work, split); break;
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<0>), dim3(nb), dim3(256), 0, st, p, nb_tu, n_plan, split); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<1>), dim3(nb), dim3(256), 0, st, p, nb_tu, n_plan, split); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<2>), dim3(nb), dim3(256), 0, st, p, nb_tu, n_plan, split); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tu_plan<3>), dim3(nb), dim3(256), 0, st, p, nb_tu, n_plan, split); break;
   }
 }
 
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st)
 {
   if (!p.n_intra_work) return;
+#ifndef M355_X_INTRA_PLAN_LAUNCH
+  if (p.intra_dense) return;                               /* planned by k_intra itself */
+#endif
   /* workgroups per CTB: PLAN_SPLIT for an intra picture (hundreds of blocks per CTB); ONE for the handful of intra blocks a CTB of an
      inter picture holds (3.4 on average at C5: with eight workgroups 90 000 waves were launched for 28 000 blocks) */
   const int split = p.intra_dense ? PLAN_SPLIT : 1;
