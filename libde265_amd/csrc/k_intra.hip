@@ -44,6 +44,7 @@
 #include "k_meta_tu.h"
 
 #define MAXCTB 64
+#define M355_INTRA_KEEPER_NW 13   /* k_intra's instantiation for ONE intra picture at a time: the worker waves + the halo keeper; plans its CTBs itself */
 /* body rows of a component: CTB width + 8 samples — sample x lives at column x + 8 (16-byte aligned 8-sample vectors).
    Chroma bodies are sized for the chroma format (template parameter CF): the LDS footprint decides how many CTBs a CU
    works on at once, and this stage lives on concurrency. */
@@ -216,9 +217,6 @@ __device__ __forceinline__ void d_intra_plan_block(const DevPic& p, const uint32
        entries, and a HALO entry whose CTB has not published it yet would make the block wait for a sample it does not use */
     int top_e, left_e;
     m355_intra_used_entries((int)((w1 >> 16) & 0xFFu), log2, c, CF, p.pp.flags, (uint32_t)flags, &top_e, &left_e);
-#ifdef M355_X_INTRA_NO_PRUNE        /* experiment (tools/variants.sh): every available entry stays in the plan, as before round 5's last visits */
-    top_e = left_e = 2 * nT;
-#endif
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       if (64 * q >= nEnt) continue;
@@ -294,11 +292,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   /* the plan (k_intra_plan): the whole CTB's (dense: M355_INTRA_PLAN_CAP entries, runtime.hip rejects CTBs beyond it) or 64
      blocks' at a time (M355_INTRA_PLAN_BATCH) */
   constexpr int PLAN_LDS = DENSE ? M355_INTRA_PLAN_CAP(CF) : M355_INTRA_PLAN_BATCH(CF);
-#ifdef M355_X_INTRA_PLAN_LAUNCH   /* experiment (tools/variants.sh): intra pictures' plans from k_tu_plan's launch, as before */
-  constexpr bool PLAN_HERE = false;
-#else
-  constexpr bool PLAN_HERE = DENSE;
-#endif
+  /* ONE intra picture at a time (the instantiation with the halo keeper, DevPic.intra_keeper): its CTBs are planned by k_intra itself
+     (below).  With pictures in flight the planner's launch stays: it plans at the whole GPU's rate beside the other pictures' kernels,
+     whereas planning inside the persistent workgroups adds to what bounds them then (C2, planned here: one at a time 0.920 -> 0.881 ms,
+     three in flight 0.358 -> 0.378, batches of 8 0.131 -> 0.177: profiles/r05_v20_*) */
+  constexpr bool PLAN_HERE = DENSE && NW == M355_INTRA_KEEPER_NW;
   __shared__ __attribute__((aligned(16))) uint16_t s_plan[PLAN_LDS];
   /* per WAVE (a wave works on one block at a time): */
   __shared__ uint16_t s_raw[NW][4 * 32 + 8];      /* gathered border, entry e = i + 2nT */
@@ -309,8 +307,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
   __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
   /* the halo keeper's slots (below): granule address and halo element per lane and slot */
-  __shared__ uint32_t s_kp_idx[(DENSE && NW == 13) ? 5 * 64 : 1];      /* (an index into DevPic.edge: the load stays a GLOBAL one — a pointer out of LDS makes it flat, and a flat load also counts as an LDS operation, which the wave waits for in front of every barrier) */
-  __shared__ uint16_t s_kp_h1[(DENSE && NW == 13) ? 5 * 64 : 1];
+  __shared__ uint32_t s_kp_idx[(DENSE && NW == M355_INTRA_KEEPER_NW) ? 5 * 64 : 1];      /* (an index into DevPic.edge: the load stays a GLOBAL one — a pointer out of LDS makes it flat, and a flat load also counts as an LDS operation, which the wave waits for in front of every barrier) */
+  __shared__ uint16_t s_kp_h1[(DENSE && NW == M355_INTRA_KEEPER_NW) ? 5 * 64 : 1];
 #ifdef M355_X_INTRA_LDS_PAD      /* experiment (tools/variants.sh): what does a workgroup less per CU cost the sparse kernel? */
   __shared__ uint32_t s_pad[DENSE ? 1 : M355_X_INTRA_LDS_PAD / 4];
   if (threadIdx.x == 0 && work_n < 0) s_pad[work_n & 1] = 1;
@@ -405,9 +403,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      lane and step, requested before anything else ---- */
   uint32_t plan_lo = 0;                                    /* first entry held in s_plan */
   if (PLAN_HERE) {
-    /* an intra picture's CTB is planned HERE, straight into LDS, by all the workgroup's waves (a block each, round robin): the
-       prologue is off the chain — a CTB is claimed long before its neighbours let it run —, whereas the planner's launch stood in
-       front of k_intra with 45-78 us for the 66 000 blocks of the 1080p picture of config 2 (profiles/r05_z_c2_*) */
+    /* the CTB is planned HERE, straight into LDS, by all the workgroup's waves (a block each, round robin): the prologue is off the
+       chain — a CTB is claimed long before its neighbours let it run —, whereas the planner's launch stands in front of k_intra with
+       45-78 us for the 66 000 blocks of the 1080p picture of config 2 (profiles/r05_z_c2_*) */
     const uint32_t nbs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w & 0xFFFFu)), nbe = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wd0.w >> 16));
     for (uint32_t k = (uint32_t)wv; k < ctbinfo.ib_count; k += (uint32_t)NW)
       d_intra_plan_block<CF>(p, ctbinfo.ib_start + k, ctbX, ctbY, nbs, nbe, s_raw[wv], s_plan);
@@ -582,19 +580,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #ifndef M355_INTRA_SHARE_MIN_LOG2
 #define M355_INTRA_SHARE_MIN_LOG2 5   /* 32x32 only (16x16 too: C2 0.82 -> 0.87 ms, profiles/r05_v17_*) */
 #endif
-#ifdef M355_X_INTRA_NO_SHARE      /* experiment (tools/variants.sh): a big block is one wave's, as before */
-  constexpr bool SHARE_BIG = false;
-#else
   constexpr bool SHARE_BIG = DENSE;
-#endif
-  constexpr bool KEEPER = DENSE && NW == 13;
+  constexpr bool KEEPER = DENSE && NW == M355_INTRA_KEEPER_NW;
   constexpr int KSLOTS = CF == 3 ? 5 : 4;                    /* granules per lane: (cw + 1) + ch / 2 per component */
   const bool keeper = KEEPER && wv == NW - 1;
   uint32_t kp_pend = 0, kp_fly = 0;                          /* bit k: slot k is missing / has a load in flight */
-#ifndef M355_INTRA_KEEPER_TICKS
-#define M355_INTRA_KEEPER_TICKS 0
-#endif
-  unsigned long long kp_t0 = 0;
   m355_granule kp_gr[KSLOTS];
   if (keeper) {
     const int cwl = 1 << l2c;
@@ -671,12 +661,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       const int lv = lane < nvalid ? (int)((p.ib_aux[4 * (size_t)(ctbinfo.ib_start + kbase + lane) + 3] >> 16) & 0x3FFFu) : -1;
       const int lv_first = __builtin_amdgcn_readlane(lv, 0), lv_last = __builtin_amdgcn_readlane(lv, nvalid - 1);
       for (int L = lv_first; L <= lv_last; L++) {
-#if M355_INTRA_KEEPER_TICKS > 0     /* experiment: ask again only this many 10 ns ticks after the last request */
-        const unsigned long long now_ = wall_clock64();
-        if (now_ - kp_t0 >= (unsigned long long)M355_INTRA_KEEPER_TICKS) { keeper_step(); kp_t0 = now_; }
-#else
-        keeper_step();
-#endif
+        keeper_step();          /* (every level: asking again only every 1.5 us was 3 % slower, profiles/r05_v15_*) */
         d_drain_lds(); __builtin_amdgcn_s_barrier();
       }
     }
@@ -1110,7 +1095,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #ifndef M355_INTRA_DENSE_NW
 #define M355_INTRA_DENSE_NW 12
 #endif
-#define M355_INTRA_KEEPER_NW 13   /* k_intra's KEEPER instantiation: the worker waves + the halo keeper */
+
 template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, bool ticket_zero, hipStream_t st)
 {
@@ -1118,11 +1103,8 @@ static void launch_intra_cf(const DevPic& p, bool ticket_zero, hipStream_t st)
   /* dense intra pictures: 12 waves (up to 8 luma + 2 + 2 chroma blocks of a level at once); sparse ones: 4 (3 and 6 measured
      slower) */
   const dim3 dense_grid(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work);
-#ifndef M355_X_INTRA_NO_KEEPER
   if (p.intra_dense && p.intra_keeper) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_KEEPER_NW, true, false>), dense_grid, dim3(64 * M355_INTRA_KEEPER_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
-  else
-#endif
-  if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, false>), dense_grid, dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
+  else if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, false>), dense_grid, dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
 }
 
@@ -1158,9 +1140,6 @@ void m355_launch_intra_batch(const DevPic& first, bool hbd, const DevPic* dev_pi
 void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
 {
   int work = 0, cf = 1;
-#ifndef M355_X_INTRA_PLAN_LAUNCH
-  return;                                                  /* (a batch is made of intra pictures: planned by k_intra itself) */
-#endif
   for (int k = 0; k < b.n; k++) if ((b.on >> k) & 1u) { work = std::max(work, b.host[k].n_intra_work); cf = b.host[k].pp.chroma_format_idc; }
   if (!work) return;
   const DevBatch d{b.dev, b.on};
@@ -1177,12 +1156,8 @@ void m355_launch_intra_plan_batch(const HostBatch& b, hipStream_t st)
    the metadata planes on the side stream, beside k_inter / k_residual) */
 void m355_launch_tu_plan(const DevPic& p, hipStream_t st)
 {
-  /* (an intra picture's CTBs are planned by k_intra itself: the launch carries the transform edges only) */
-#ifdef M355_X_INTRA_PLAN_LAUNCH
-  const int n_plan = p.n_intra_work, split = p.intra_dense ? PLAN_SPLIT : 1;
-#else
-  const int n_plan = p.intra_dense ? 0 : p.n_intra_work, split = 1;
-#endif
+  /* (one intra picture at a time: its CTBs are planned by k_intra itself, the launch carries the transform edges only) */
+  const int n_plan = (p.intra_dense && p.intra_keeper) ? 0 : p.n_intra_work, split = p.intra_dense ? PLAN_SPLIT : 1;
   const int nb_tu = (p.n_tus + 255) / 256, nb = nb_tu + n_plan * split;
   if (!nb) return;
   switch (p.pp.chroma_format_idc) {
@@ -1196,9 +1171,7 @@ void m355_launch_tu_plan(const DevPic& p, hipStream_t st)
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st)
 {
   if (!p.n_intra_work) return;
-#ifndef M355_X_INTRA_PLAN_LAUNCH
-  if (p.intra_dense) return;                               /* planned by k_intra itself */
-#endif
+  if (p.intra_dense && p.intra_keeper) return;             /* planned by k_intra itself */
   /* workgroups per CTB: PLAN_SPLIT for an intra picture (hundreds of blocks per CTB); ONE for the handful of intra blocks a CTB of an
      inter picture holds (3.4 on average at C5: with eight workgroups 90 000 waves were launched for 28 000 blocks) */
   const int split = p.intra_dense ? PLAN_SPLIT : 1;

@@ -193,12 +193,9 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
      = 1.50 M CTB64/s at depth 9, profiles/r03_v_*; forked: 0.59 at depth 8) — and so does a picture of up to 4K: the fork / join of the
      side stream is six packets (three event records, three waits) at about 2 us of pipeline time each, and what they buy — the metadata
      scatters and the second residual launch beside the main stream — is worth less than that once the kernels are short (three in
-     flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms on one stream, C5 0.347 -> 0.351) */
-#ifdef M355_X_INTRA_FORK_DEPTH1    /* experiment (tools/variants.sh): one intra picture at a time forks its metadata planes beside the residuals */
-  const bool single = (d.intra_dense && c->depth > 1) || (!d.intra_dense && (long long)d.pp.width * d.pp.height <= 16ll << 20);
-#else
+     flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms on one stream, C5 0.347 -> 0.351); one intra picture at a time with its
+     planes forked beside the residuals: 0.881 -> 0.896 ms (profiles/r05_v20_*) */
   const bool single = d.intra_dense || (long long)d.pp.width * d.pp.height <= 16ll << 20;
-#endif
   hipStream_t s2 = single ? st : c->stream2;
   /* the zero fill of the metadata planes rides in the picture's first main-stream launch (k_job_count), in FRONT of the fork: the
      side stream's scatters then start behind it — one launch less per inter picture */

@@ -342,7 +342,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
   const bool one_sided = !(pp.flags & M355_PF_CONSTRAINED_INTRA_PRED);
   /* INTRA PICTURES (8 or more intra blocks per CTB, as *dense below) get their levels from a picture-wide CLOCK instead of the
      dependency depth inside the CTB: t(block) = the latest of its producers' t + cost — producers in its own CTB AND the blocks of
-     neighbour CTBs whose samples its mode reads (those a hand-off later) —, in units of one small block (4x4 / 8x8: 1, 16x16: 1,
+     neighbour CTBs whose samples its mode reads (those a hand-off later) —, in units of one small block (4x4 / 8x8: 1, 16x16: 2,
      32x32: 2 — k_intra shares those among a component's waves —, CTB-to-CTB hand-off: 6 — the times of profiles/r03_*_intra_level_profile_* and r05_v14, rounded); a CTB's levels are the
      distinct t of its blocks, in order.  Why: with depth-only levels a block at the CTB's left edge that reads nothing of its own
      CTB sits in level 0 and polls there for a sample the left CTB produces in its LAST level — and the level's barrier holds the
@@ -350,11 +350,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
      k_intra's chain on the 1080p picture of config 2: 981 -> 758 us with the hand-offs as measured).  Blocks now come up when the
      clock says their inputs have arrived — which is also what lets the halo keeper (k_intra.hip) have them in LDS by then.  The CTBs
      are walked in wavefront order (x + 2y) by the pool's threads, each waiting for its left and top-right neighbour's clock. */
-#ifdef M355_X_INTRA_ASAP_LEVELS    /* experiment (tools/variants.sh): depth-only levels for intra pictures too */
-  const bool timed = false;
-#else
   const bool timed = one_sided && (size_t)pic->n_ibs >= 8 * (size_t)pic->n_ctbs;
-#endif
   static const bool level_stats = getenv("M355_INTRA_LEVEL_STATS") != nullptr;
   double span[4] = {0, 0, 0, 0};
   std::mutex span_mu;
@@ -369,16 +365,8 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
     for (int i = 0; i < pp.num_tile_cols; i++) for (int x = pp.col_bd[i]; x < pp.col_bd[i + 1] && x < ctbW; x++) tcol[(size_t)x] = (uint16_t)i;
     for (int i = 0; i < pp.num_tile_rows; i++) for (int y = pp.row_bd[i]; y < pp.row_bd[i + 1] && y < ctbH; y++) trow[(size_t)y] = (uint16_t)i;
   }
-#ifndef M355_INTRA_T_HANDOFF
-#define M355_INTRA_T_HANDOFF 6
-#endif
-#ifndef M355_INTRA_T_32
-#define M355_INTRA_T_32 2     /* (k_intra shares a 16x16 / 32x32 block among its component's waves) */
-#endif
-#ifndef M355_INTRA_T_16
-#define M355_INTRA_T_16 2
-#endif
-  constexpr int T_HANDOFF = M355_INTRA_T_HANDOFF;
+  /* (hand-offs of 3 / 6 / 10 units and a 32x32 block of 4 / 5 measured the same within 0.5 %: profiles/r05_v16_*) */
+  constexpr int T_HANDOFF = 6, T_16 = 2, T_32 = 2;          /* (k_intra shares a 32x32 block among its component's waves) */
   struct Scratch {
     std::vector<std::pair<uint32_t, uint32_t>> key, sorted;      /* (level << 2 | cidx, index) */
     std::vector<int32_t> tstart, tvals;
@@ -503,7 +491,7 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
           }
         }
         if (timed) {
-          const int32_t td = S.tstart[k] + (ib.log2_size >= 5 ? M355_INTRA_T_32 : (ib.log2_size == 4 ? M355_INTRA_T_16 : 1));
+          const int32_t td = S.tstart[k] + (ib.log2_size >= 5 ? T_32 : (ib.log2_size == 4 ? T_16 : 1));
           for (int y = uy; y < uy + n4 && y < 16; y++) for (int x = ux; x < ux + n4 && x < 16; x++) tgrid[ib.cidx][y][x] = td;
         }
         level = std::min(level, 126);                    /* (only overlapping blocks — rejected below — could get there) */

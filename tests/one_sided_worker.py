@@ -38,8 +38,11 @@ if __name__ == "__main__":
         want = oracle_decode(o, pic, refs)
         ctx = capi.Context(lib, 0)
         try:
-            assert_planes_equal(device_decode(ctx, pic, refs), want, "seed %d" % case["seed"])
-            assert_planes_equal(device_decode(ctx, pic, refs, resident=True, repeat=2), want, "seed %d resident" % case["seed"])
+            # depth 1: k_intra with its halo keeper wave, planning an intra picture's CTBs itself; depth 3: the 12-wave kernel behind the planner's launch
+            for depth in (1, 3):
+                ctx.set_pipeline_depth(depth)
+                assert_planes_equal(device_decode(ctx, pic, refs), want, "seed %d depth %d" % (case["seed"], depth))
+                assert_planes_equal(device_decode(ctx, pic, refs, resident=True, repeat=2), want, "seed %d depth %d resident" % (case["seed"], depth))
         finally:
             ctx.close()
     print("one-sided worker ok")
