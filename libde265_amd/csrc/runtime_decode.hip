@@ -153,6 +153,16 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
        in flight their kernels fill the waits, and a 13-wave workgroup at 128 registers leaves no room on its CU for the 4-wave
        workgroups of the other pictures' kernels (C2, three in flight: 0.468 -> 0.536 ms per picture, profiles/r05_v14_*) */
     d.intra_keeper = c->depth == 1;
+    if (!d.intra_keeper && r.dp.intra_dense) {
+      /* ... or when nothing else is in flight right now, whatever the depth: the intra picture a stream's other pictures wait for */
+      bool idle = true;
+      for (int i = 0; i < c->depth && idle; i++) if (i != c->active && ev_query(c, c->lanes[i].last) != hipSuccess) idle = false;
+      d.intra_keeper = idle;
+    }
+    /* (test hook: the interpreter finishes every launch before the next call, so its pipeline is always idle — M355_TEST_NO_KEEPER=1
+       sends intra pictures through the 12-wave kernel behind the planner's launch all the same) */
+    static const bool no_keeper = getenv("M355_TEST_NO_KEEPER") != nullptr;
+    if (no_keeper) d.intra_keeper = 0;
     /* (test hook: the interpreter runs k_intra's workgroups one after the other, so a neighbour's samples are always there when a
        CTB is staged — this sends them down the paths a CTB takes on the hardware, where they arrive later) */
     static const int halo_late = getenv("M355_TEST_HALO_LATE") ? atoi(getenv("M355_TEST_HALO_LATE")) : 0;
@@ -317,6 +327,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
   if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
   if (!want_sao) dst_hazards(c, dstf, piped);
   if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, want_sao ? &c->work : dstf, r.device_validate && !want_sao, st);
+  if (!with_intra) d.intra_keeper = 0;                     /* (a batch's shared intra stage is the 12-wave kernel: it needs the planner's launch) */
   if (mode != PRE_HAZARDS) launch_prediction(c, r, d, hbd, ev, with_intra);
   return M355_OK;
 }

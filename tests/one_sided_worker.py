@@ -38,7 +38,8 @@ if __name__ == "__main__":
         want = oracle_decode(o, pic, refs)
         ctx = capi.Context(lib, 0)
         try:
-            # depth 1: k_intra with its halo keeper wave, planning an intra picture's CTBs itself; depth 3: the 12-wave kernel behind the planner's launch
+            # (an idle pipeline at any depth: k_intra with its halo keeper wave, planning an intra picture's CTBs itself; M355_TEST_NO_KEEPER=1 or pictures
+            # in flight: the 12-wave kernel behind the planner's launch)
             for depth in (1, 3):
                 ctx.set_pipeline_depth(depth)
                 assert_planes_equal(device_decode(ctx, pic, refs), want, "seed %d depth %d" % (case["seed"], depth))

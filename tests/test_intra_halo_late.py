@@ -17,14 +17,21 @@ from test_emu_picture import EMU_SO, emu_lib  # noqa: F401  (fixture)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_late_halo_samples_emulated(emu_lib, oracle):  # noqa: F811
-    r = subprocess.run([sys.executable, os.path.join(HERE, "one_sided_worker.py"), EMU_SO, oracle._name], env=dict(os.environ, M355_TEST_HALO_LATE="1"),
-                       capture_output=True, text=True, timeout=1200)
+@pytest.mark.parametrize("no_keeper", [False, True], ids=["keeper", "own_polls"])
+def test_late_halo_samples_emulated(emu_lib, oracle, no_keeper):  # noqa: F811
+    # own_polls: M355_TEST_NO_KEEPER=1 — the 12-wave kernel behind the planner's launch (what a picture gets when others are in flight: the
+    # interpreter's pipeline is never busy), where every late sample is fetched by the block that reads it
+    env = dict(os.environ, M355_TEST_HALO_LATE="1")
+    if no_keeper: env["M355_TEST_NO_KEEPER"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "one_sided_worker.py"), EMU_SO, oracle._name], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "one-sided worker ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.gpu
-def test_late_halo_samples_gpu(oracle):
-    r = subprocess.run([sys.executable, os.path.join(HERE, "one_sided_worker.py"), "default", oracle._name], env=dict(os.environ, M355_TEST_HALO_LATE="1"),
+@pytest.mark.parametrize("no_keeper", [False, True], ids=["keeper", "own_polls"])
+def test_late_halo_samples_gpu(oracle, no_keeper):
+    env = dict(os.environ, M355_TEST_HALO_LATE="1")
+    if no_keeper: env["M355_TEST_NO_KEEPER"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "one_sided_worker.py"), "default", oracle._name], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "one-sided worker ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
