@@ -71,6 +71,11 @@ struct DevIntraWork {
  *   word 2  bits 0-7 intraPredAngle (signed), 8-10 mode class (0 planar, 1 DC, 2 pure horizontal / vertical, 3 / 4 angular with a
  *           positive / negative angle), 16-31 invAngle (signed; 0 unless the angle is negative)   (intrapred.h:313-326)
  *   word 3  bits 0-15 offset of the block's border plan inside the CTB's plans, 16-29 dependency level inside the CTB */
+/* blocks of this size and larger are SHARED by their component's waves in k_intra (each gathers the border itself and predicts its rows);
+   intra_schedule gives a CTB that holds one all the waves there are: 32x32 only (16x16 too: C2 0.82 -> 0.87 ms, profiles/r05_v17_*) */
+#ifndef M355_INTRA_SHARE_MIN_LOG2
+#define M355_INTRA_SHARE_MIN_LOG2 5
+#endif
 #define M355_IBX_HAS_RES 0x02000000u
 #define M355_IBX_PCM     0x04000000u
 #define M355_IBX_FILT    0x08000000u   /* [1 2 1] border smoothing applies (intrapred.h:195-212: mode, size and component decide) */
@@ -171,9 +176,11 @@ struct DevPic {
   int n_wts;
   uint32_t n_coeffs, n_pcm, res_len, ref_valid;   /* list lengths the records index into; bit s of ref_valid = ref_frames[s] is a frame */
   uint32_t epoch;                   /* value meaning "done" for this submission */
-  const DevIntraWork* intra_work;   /* one descriptor per CTB that holds intra blocks: first the n_intra_free CTBs that wait for no
-                                       neighbour (longest first), then the dependent ones in decode order (k_intra's ticket order) */
-  int n_intra_work, n_intra_free;
+  const DevIntraWork* intra_work;   /* one descriptor per CTB that holds intra blocks (runtime_upload.hip).  Intra pictures: the CTBs that wait for no
+                                       neighbour (longest first), then the dependent ones in wavefront order, all claimed through k_intra's ticket.
+                                       Inter pictures: first the n_intra_ticket CTBs of dependency chains, longest remaining chain first (ticket
+                                       order: a producer precedes its readers), then the CTBs without dependencies (by workgroup index) */
+  int n_intra_work, n_intra_ticket;
   int intra_grid;                   /* intra pictures: workgroups of k_intra's launch (persistent: each takes CTB after CTB); 0 = one per CTB */
   int intra_keeper;                 /* intra pictures: launch k_intra with its halo keeper wave (one picture at a time; k_intra.hip) */
   int test_halo_late;               /* test hook (M355_TEST_HALO_LATE=1, tests/test_intra_halo_late.py): k_intra's prologue takes no neighbour's

@@ -285,10 +285,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   constexpr int BODY_L = IntraGeo<CF>::BODY_L, BODY_C = IntraGeo<CF>::BODY_C;
   constexpr int SAMP_L = IntraGeo<CF>::SAMP_L, SAMP_C = IntraGeo<CF>::SAMP_C;
   __shared__ __attribute__((aligned(16))) uint16_t s_body[SAMP_L + 2 * SAMP_C];   /* per component: body | halo | constant cell */
-  /* the CTB's deferred residuals in picture layout (pitch = component CTB width): fetched up front, all loads in flight
-     together, so that the per-block chain reads them from LDS instead of paying a global-memory latency per block */
-  constexpr int RES_L = DENSE ? MAXCTB * MAXCTB : 8, RES_C = (CF == 0 || !DENSE) ? 8 : CH_C * CW_C;
-  __shared__ __attribute__((aligned(16))) int16_t s_res[RES_L + 2 * RES_C];
   /* the plan (k_intra_plan): the whole CTB's (dense: M355_INTRA_PLAN_CAP entries, runtime.hip rejects CTBs beyond it) or 64
      blocks' at a time (M355_INTRA_PLAN_BATCH) */
   constexpr int PLAN_LDS = DENSE ? M355_INTRA_PLAN_CAP(CF) : M355_INTRA_PLAN_BATCH(CF);
@@ -304,7 +300,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   __shared__ uint32_t s_ticket;
   __shared__ uint32_t s_need[3][MAXCTB];         /* per component and CTB row, which 8-sample vectors some block's border reads */
   __shared__ uint32_t s_cover[3][MAXCTB / 4];    /* per component and row of 4x4 units, which units an intra block of this CTB writes */
-  __shared__ uint32_t s_touch[64];               /* d_touch scratch (never read) */
   __shared__ uint32_t s_hneed[3][8];             /* ... and which halo entries (bit h: top entries 0 .. 2cw, then the left column) */
   /* the halo keeper's slots (below): granule address and halo element per lane and slot */
   __shared__ uint32_t s_kp_idx[(DENSE && NW == M355_INTRA_KEEPER_NW) ? 5 * 64 : 1];      /* (an index into DevPic.edge: the load stays a GLOBAL one — a pointer out of LDS makes it flat, and a flat load also counts as an LDS operation, which the wave waits for in front of every barrier) */
@@ -324,8 +319,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      grid is therefore free to be smaller than the list (runtime.hip: with several pictures in flight each picture gets a share of
      the GPU's workgroup slots that covers its ACTIVE wavefront, instead of parking a workgroup on every CTB of the picture for
      the picture's whole duration); a workgroup only ever waits on items claimed before its own, whose workgroups are running.
-     Inter pictures: one workgroup per CTB with intra blocks — the first n_intra_free items (no neighbour to wait for) go by
-     workgroup index (no atomic, no barrier), the dependent ones through the ticket. */
+     Inter pictures: one workgroup per CTB with intra blocks — the first n_intra_ticket items (the CTBs of dependency chains, the
+     longest remaining chain first) through the ticket, taken by the workgroups of lowest index, i.e. the first to be dispatched; the
+     CTBs without dependencies by workgroup index (no atomic, no barrier). */
   for (;;) {
   int item = (int)blockIdx.x, pk = 0;
   if (BATCH) {
@@ -334,8 +330,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ticket);
     if (t >= (uint32_t)work_n * (uint32_t)n_pics) return;       /* work_n = the longest picture's list */
     pk = (int)(t % (uint32_t)n_pics); item = (int)(t / (uint32_t)n_pics);
-  } else if (DENSE || item >= p0.n_intra_free) {          /* (uniform per workgroup) */
-    if (threadIdx.x == 0) s_ticket = (DENSE ? 0u : (uint32_t)p0.n_intra_free) + atomicAdd(p0.ticket, 1u);
+  } else if (DENSE || item < p0.n_intra_ticket) {         /* (uniform per workgroup) */
+    if (threadIdx.x == 0) s_ticket = atomicAdd(p0.ticket, 1u);
     __syncthreads();
     item = __builtin_amdgcn_readfirstlane((int)s_ticket);
   }
@@ -396,8 +392,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   uint16_t* pf = s_f[wv];
   const uint32_t epoch = p.epoch;
 #define SYNC_CTB() do { if (multi) __syncthreads(); else wave_sync(); } while (0)
-  int16_t* resl = s_res + (cs == 0 ? 0 : RES_L + (cs - 1) * RES_C);
-  const int RES_PITCH = cs == 0 ? MAXCTB : CW_C;
 
   /* ---- the plan: the whole CTB's (dense) or its first PLAN_LDS entries (a later batch of 64 blocks reloads), 16 bytes per
      lane and step, requested before anything else ---- */
@@ -437,11 +431,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         for (int uy = ly >> 2; uy < (ly + nT) >> 2; uy++) atomicOr(&s_cover[cs][uy], um);
       }
       if ((w1 >> 24) & M355_IBF_PCM) continue;               /* raw blocks read no border */
-      if (!DENSE && ((w1 >> 24) & M355_IBF_HAS_RESIDUAL)) {
-        /* the block's residual is read when its dependency level comes up: ask for its cache lines now */
-        const char* rp_ = (const char*)(p.resbuf + r[2]);
-        for (int o = 0; o < nT * nT * 2; o += 128) d_touch(rp_ + o, s_touch);
-      }
       if (ly >= 1) {
         const int v0 = max(lx - 1, 0) >> 3, v1 = min((lx + 2 * nT - 1) >> 3, nvr - 1);
         if (v1 >= v0) atomicOr(&s_need[cs][ly - 1], ((2u << v1) - 1u) & ~((1u << v0) - 1u));
@@ -498,7 +487,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             o.x = (bx & 0xFFu) | ((bx & 0xFF00u) << 8); o.y = ((bx >> 16) & 0xFFu) | ((bx >> 8) & 0xFF0000u);
             o.z = (by & 0xFFu) | ((by & 0xFF00u) << 8); o.w = ((by >> 16) & 0xFFu) | ((by >> 8) & 0xFF0000u);
           }
-          *(uint4*)(body + y * BODY_PITCH + BODY_X0 + xv) = o;
+          /* (a half some intra block of this CTB covers holds that block's RESIDUAL — below —, not a sample of the picture) */
+          const uint32_t cov = (s_cover[cs][y >> 2] >> (xv >> 2)) & 3u;
+          uint16_t* dst = body + y * BODY_PITCH + BODY_X0 + xv;
+          if (cov == 0u) *(uint4*)dst = o;
+          else if (cov == 2u) *(uint2*)dst = make_uint2(o.x, o.y);
+          else *(uint2*)(dst + 4) = make_uint2(o.z, o.w);
         }
       }
     }
@@ -543,9 +537,13 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       }
     }
   }
-  /* ---- residual pre-pass (intra pictures): the CTB's deferred residuals go to LDS, each component's waves taking its
-     blocks in turn ---- */
-  if (DENSE) {
+  /* ---- residual pre-pass: the CTB's deferred residuals go to LDS, each component's waves taking its blocks in turn (inter
+     pictures too: a block of the chain then reads its residual from LDS, where it paid a global-memory round trip — and the
+     32x32 blocks that make the chains of such a picture are predicted by the same loops as an intra picture's).  They go INTO
+     THE BODY, at the block's own position: nothing reads those elements before the block is predicted — the CTB's blocks are
+     disjoint, the staging above leaves covered units alone, a border entry only ever points at a sample that has been
+     reconstructed — and the lane that predicts a sample reads its residual from the element it then overwrites. ---- */
+  {
     int taken = 0;                                           /* blocks of this component seen so far (wave-uniform) */
     for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
       uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
@@ -562,9 +560,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         const int flags = (int)(w1 >> 24), log2 = (int)((w1 >> 8) & 0xFFu), nT = 1 << log2;
         if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
         const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
-        for (int o = lane * 4; o < nT * nT; o += 256) {        /* 4 samples (one row segment) per lane and step */
-          const uint2 v = *(const uint2*)(p.resbuf + w2 + o);
-          *(uint2*)(resl + (ly + (o >> log2)) * RES_PITCH + lx + (o & (nT - 1))) = v;
+        /* 4 samples (one row segment) per lane and step; the (up to four) steps of a block are requested together */
+        uint2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int o = lane * 4 + 256 * u;
+          v[u] = make_uint2(0, 0);
+          if (o < nT * nT) v[u] = *(const uint2*)(p.resbuf + w2 + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int o = lane * 4 + 256 * u;
+          if (o < nT * nT) *(uint2*)(body + (ly + (o >> log2)) * BODY_PITCH + BODY_X0 + lx + (o & (nT - 1))) = v[u];
         }
       }
     }
@@ -577,10 +584,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
      beside the blocks, in front of the same barrier — takes in the loads it issued a level earlier, stores the samples that have
      arrived into the halo and asks again for the rest.  Its loads stay in flight across the barrier (raw s_barrier, no fence: gfx950
      backs off a barrier with memory operations outstanding).  A block whose sample is still missing polls as before. ---- */
-#ifndef M355_INTRA_SHARE_MIN_LOG2
-#define M355_INTRA_SHARE_MIN_LOG2 5   /* 32x32 only (16x16 too: C2 0.82 -> 0.87 ms, profiles/r05_v17_*) */
-#endif
-  constexpr bool SHARE_BIG = DENSE;
   constexpr bool KEEPER = DENSE && NW == M355_INTRA_KEEPER_NW;
   constexpr int KSLOTS = CF == 3 ? 5 : 4;                    /* granules per lane: (cw + 1) + ch / 2 per component */
   const bool keeper = KEEPER && wv == NW - 1;
@@ -651,8 +654,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   const int thr_strong = 1 << (p.pp.bit_depth_luma - 5);
   const int pix_max = (1 << bd) - 1;
   /* a lane's sample of a 4x4 / 8x8 block, relative to the block's first sample in the body / residual tile */
-  const int lofs_b4 = (lane >> 2) * BODY_PITCH + (lane & 3), lofs_b8 = (lane >> 3) * BODY_PITCH + (lane & 7);
-  const int lofs_r4 = (lane >> 2) * RES_PITCH + (lane & 3), lofs_r8 = (lane >> 3) * RES_PITCH + (lane & 7);
+  const int lofs_b4 = ((lane & 15) >> 2) * BODY_PITCH + (lane & 3), lofs_b8 = (lane >> 3) * BODY_PITCH + (lane & 7);   /* (4x4: the lanes beyond the block alias its samples — they read, never store) */
   int taken = 0;                                           /* blocks of this wave's component in earlier batches */
   if (KEEPER && keeper) {
     /* the halo keeper's walk through the same barriers (a path of its own: what it holds is live nowhere in the block code) */
@@ -699,7 +701,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       /* intra pictures: a 16x16 / 32x32 block is EVERY wave's of its component — each gathers (and smooths) the whole border itself and
          predicts its share of the rows (below): no barrier beyond the level's own, and the block costs the chain about one small
          block's time instead of 2 / 4.5 (the round trip is the border's, the arithmetic is 1 / 4 .. 1 / 8 of the samples) */
-      const unsigned long long big = SHARE_BIG ? same & __ballot((int)(((ex.x >> 14) & 7u) >= (uint32_t)M355_INTRA_SHARE_MIN_LOG2 && !(ex.x & M355_IBX_PCM))) : 0ull;
+      const unsigned long long big = same & __ballot((int)(((ex.x >> 14) & 7u) >= (uint32_t)M355_INTRA_SHARE_MIN_LOG2 && !(ex.x & M355_IBX_PCM)));
       const unsigned long long few = same & ~big;
       const int rank = taken + __popcll(few & ((1ull << lane) - 1ull));
       mine = (few & __ballot((int)((rank & (G - 1)) == g))) | big;
@@ -709,8 +711,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
        and (4x4 / 8x8) the plan entries of its border, entry e in lane e */
     int nsrc = -1, nlevel = -1;
     uint32_t e0 = 0, e1 = 0, e3 = 0, ncode = 0;
-    int d_bofs = 0, d_rofs = 0, d_angle = 0, d_inv = 0, d_cls = 0, d_log2 = 0, d_small = 0;
-    int d_baddr = 0, d_raddr = 0;                           /* (4x4 / 8x8) this lane's sample in the body / residual tiles */
+    int d_bofs = 0, d_angle = 0, d_inv = 0, d_cls = 0, d_log2 = 0, d_small = 0;
+    int d_baddr = 0;                                        /* (4x4 / 8x8) this lane's sample in the body */
     auto fetch_next = [&]() {
       nsrc = mine ? __ffsll(mine) - 1 : -1;
       mine &= mine - 1;
@@ -721,14 +723,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       nlevel = (int)((e3 >> 16) & 0x3FFFu);
       d_log2 = (int)((e0 >> 14) & 7u);
       const int lx = (int)(e0 & 127u), ly = (int)((e0 >> 7) & 127u);
-      d_bofs = ly * BODY_PITCH + lx + BODY_X0; d_rofs = ly * RES_PITCH + lx;
+      d_bofs = ly * BODY_PITCH + lx + BODY_X0;
       d_cls = (int)((e2 >> 8) & 7u); d_angle = (int)(int8_t)(e2 & 0xFFu); d_inv = (int)(int16_t)(e2 >> 16);
       d_small = (d_log2 <= 3 && !(e0 & M355_IBX_PCM)) ? 1 : 0;
       if (d_small) {
         ncode = s_plan[((e3 & 0xFFFFu) - plan_lo) + (uint32_t)min(lane, 4 << d_log2)];
-        d_baddr = d_bofs + (d_log2 == 2 ? lofs_b4 : lofs_b8); d_raddr = d_rofs + (d_log2 == 2 ? lofs_r4 : lofs_r8);
+        d_baddr = d_bofs + (d_log2 == 2 ? lofs_b4 : lofs_b8);
       }
-      M355_PIN_S(d_small); M355_PIN_S(d_bofs); M355_PIN_S(d_rofs); M355_PIN_S(d_cls); M355_PIN_S(d_angle); M355_PIN_S(d_inv); M355_PIN_S(d_log2); M355_PIN_S(nlevel);
+      M355_PIN_S(d_small); M355_PIN_S(d_bofs); M355_PIN_S(d_cls); M355_PIN_S(d_angle); M355_PIN_S(d_inv); M355_PIN_S(d_log2); M355_PIN_S(nlevel);
     };
     fetch_next();
     bool pend = false;                                       /* the next block is still to be fetched (done behind the barrier) */
@@ -752,7 +754,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
          k_intra_plan: one sample per plan entry) and its residual — everything else of the block is decoded beside these reads */
       uint32_t bv0 = 0;
       int rs0 = 0;
-      if (__builtin_expect(d_small, 1)) { bv0 = body[code0]; if (DENSE) rs0 = (int)resl[d_raddr]; }
+      if (__builtin_expect(d_small, 1)) { bv0 = body[code0]; rs0 = (int)(int16_t)body[d_baddr]; }
       const int log2 = d_log2, nT = 1 << log2, cls = d_cls, angle = d_angle, inv = d_inv;
       const int mode = (int)((e0 >> 19) & 63u);
       const bool vert = mode >= 18;
@@ -769,8 +771,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         uint32_t bv = bv0;
         int rs = 0;
         /* (branch-free where it is cheap: a taken branch costs a lone wave more than the few instructions it skips) */
-        if (DENSE) rs = rs0 & (has_res ? -1 : 0);
-        else if (has_res) rs = inb ? (int)p.resbuf[e1 + lane] : 0;
+        rs = rs0 & (has_res ? -1 : 0);
         if (__builtin_expect(__any((int)(bv == HALO_NOT_READY)), 0)) {
           /* a halo sample its CTB has not published yet: poll its granule */
           const bool pending = bv == HALO_NOT_READY && code0 >= (uint32_t)HALO_BASE && code0 < (uint32_t)(HALO_BASE + HALO_N);
@@ -821,7 +822,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
 #undef BRL
 #undef BRP
-        if (DENSE || has_res) v = d_clip3(0, pix_max, v + rs);   /* (a prediction is inside the sample range: no-op without a residual) */
+        v = d_clip3(0, pix_max, v + rs);   /* (a prediction is inside the sample range: no-op without a residual) */
         if (inb) body[d_baddr] = (uint16_t)v;
         /* ---- publish from the registers: a granule = two samples, the second one comes from the lane below / beside ---- */
         if (__builtin_expect((e0 & (M355_IBX_PUB_COL | M355_IBX_PUB_ROW)) != 0, 0)) {
@@ -843,7 +844,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       } else {
       /* this wave's share of a 16x16 / 32x32 block: passes (64 samples = 4 / 2 rows each) [it_lo, it_hi) of the block's 4 / 16 */
       const int nPass = (nT * nT) >> 6;
-      const bool shared = SHARE_BIG && log2 >= M355_INTRA_SHARE_MIN_LOG2;
+      const bool shared = log2 >= M355_INTRA_SHARE_MIN_LOG2;
       const int it_lo = shared ? (nPass * g) / G : 0, it_hi = shared ? (nPass * (g + 1)) / G : nPass;
       if (!(e0 & M355_IBX_PCM)) {
         /* ---- 16x16 / 32x32: the border lives in LDS (65 / 129 entries) ---- */
@@ -879,41 +880,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
         }
         wave_sync();
         PROF_T(1);
-        /* residual of this block (sparse pictures: written by k_residual, its cache lines were requested in the prologue): the loads
-           are issued here, BEHIND the border gather, and consumed after smoothing, up to 16 samples per lane (32x32) */
-        int16_t rv[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const int o = lane + 64 * q;
-          rv[q] = (!DENSE && has_res && o < nT * nT) ? p.resbuf[e1 + o] : (int16_t)0;
-        }
-        const int sgn = vert ? 1 : -1;
-        /* one sample (x, y) of the block from border taps BRD(i), i = -2nT .. 2nT (intrapred.h:261-433) */
-#define PREDICT_SAMPLE(v, x, y, dcVal)                                                                                              \
-        do {                                                                                                                        \
-          if (mode == 0) {                                                                                                          \
-            v = ((nT - 1 - (x)) * BRD(-1 - (y)) + ((x) + 1) * BRD(1 + nT) + (nT - 1 - (y)) * BRD(1 + (x)) + ((y) + 1) * BRD(-1 - nT) + nT) >> (log2 + 1); \
-          } else if (mode == 1) {                                                                                                   \
-            v = dcVal;                                                                                                              \
-            if (bfilt) {                                                                                                            \
-              const int e0_ = BRD(-1), e1_ = BRD(1), ex_ = BRD((x) + 1), ey_ = BRD(-(y) - 1);                                       \
-              if ((x) == 0 && (y) == 0) v = (e0_ + 2 * dcVal + e1_ + 2) >> 2;                                                       \
-              else if ((y) == 0) v = (ex_ + 3 * dcVal + 2) >> 2;                                                                    \
-              else if ((x) == 0) v = (ey_ + 3 * dcVal + 2) >> 2;                                                                    \
-            }                                                                                                                       \
-          } else {                                                                                                                  \
-            const int a_ = vert ? (y) : (x), b_ = vert ? (x) : (y);                                                                 \
-            const int iIdx_ = ((a_ + 1) * angle) >> 5, iFact_ = ((a_ + 1) * angle) & 31;                                            \
-            const int x1_ = b_ + iIdx_ + 1, x2_ = b_ + iIdx_ + 2;                                                                   \
-            const int r1_ = BRD(x1_ >= 0 ? sgn * x1_ : -sgn * ((x1_ * inv + 128) >> 8));                                            \
-            const int r2_ = BRD(x2_ >= 0 ? sgn * x2_ : -sgn * ((x2_ * inv + 128) >> 8));                                            \
-            v = iFact_ ? ((32 - iFact_) * r1_ + iFact_ * r2_ + 16) >> 5 : r1_;                                                      \
-            if (bfilt && cls == 2) {                                                                                                \
-              const int t0_ = BRD(0), t1_ = BRD(vert ? 1 : -1), t2_ = BRD(vert ? -1 - (y) : 1 + (x));                               \
-              if (vert ? (x) == 0 : (y) == 0) v = d_clip3(0, pix_max, t1_ + ((t2_ - t0_) >> 1));                                    \
-            }                                                                                                                       \
-          }                                                                                                                         \
-        } while (0)
         uint16_t* P = raw; /* border in use, entry index = i + 2nT */
         if (e0 & M355_IBX_FILT) {     /* intra_prediction_sample_filtering (intrapred.h:185-258) */
           const bool bi = (e0 & M355_IBX_STRONG) && d_abs((int)raw[Z] + raw[Z + 64] - 2 * raw[Z + 32]) < thr_strong && d_abs((int)raw[Z] + raw[Z - 64] - 2 * raw[Z - 32]) < thr_strong;
@@ -947,7 +913,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
           s_ += __builtin_amdgcn_update_dpp(0, s_, 0x140, 0xF, 0xF, false);
           dcVal = (__builtin_amdgcn_readlane(s_, 0) + __builtin_amdgcn_readlane(s_, 16) + nT) >> (log2 + 1);
         }
-        if (DENSE) {
+        {
           /* one loop per mode class, FOUR samples per lane in flight: their border taps and residuals are requested together (one
              LDS round trip per four samples, not two per sample), then the four are computed and stored */
           const int xb = lane & (nT - 1), yb = lane >> log2, ystep = 64 >> log2, nIt = (nT * nT) >> 6;
@@ -983,7 +949,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
                   }
                   ta[u] = BRD(i1); tb[u] = BRD(fa[u] ? i2 : i1);   /* (no read beyond the border when the second tap has weight 0) */
                 }
-                rs[u] = (int)resl[d_rofs + y * RES_PITCH + x] & res_on;
+                rs[u] = (int)(int16_t)body[d_bofs + y * BODY_PITCH + x] & res_on;
               }
 #pragma unroll
               for (int u = 0; u < 4; u++) {
@@ -1010,20 +976,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
           else if (cls == 2) big_loop(std::integral_constant<int, 2>());
           else if (cls == 3) big_loop(std::integral_constant<int, 3>());
           else big_loop(std::integral_constant<int, 4>());
-        } else {
-#pragma unroll
-          for (int q = 0; q < 16; q++) {
-            const int o = lane + 64 * q;
-            if (o >= nT * nT) break;
-            const int y = o >> log2, x = o & (nT - 1);
-            int v;
-            PREDICT_SAMPLE(v, x, y, dcVal);
-            if (has_res) v = d_clip3(0, pix_max, v + (int)rv[q]);
-            body[(ly + y) * BODY_PITCH + lx + x + BODY_X0] = (uint16_t)v;
-          }
         }
 #undef BRD
-#undef PREDICT_SAMPLE
         }   /* a share of the block */
       } else { /* raw block (slice.cc:4211-4255) */
         for (int o = lane; o < nT * nT; o += 64) {
@@ -1095,6 +1049,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
 #ifndef M355_INTRA_DENSE_NW
 #define M355_INTRA_DENSE_NW 12
 #endif
+#ifndef M355_INTRA_SPARSE_NW
+#define M355_INTRA_SPARSE_NW 4    /* inter pictures: up to 2 luma + 1 + 1 chroma waves per CTB */
+#endif
 
 template <class PIX, int CF>
 static void launch_intra_cf(const DevPic& p, bool ticket_zero, hipStream_t st)
@@ -1105,7 +1062,7 @@ static void launch_intra_cf(const DevPic& p, bool ticket_zero, hipStream_t st)
   const dim3 dense_grid(p.intra_grid > 0 && p.intra_grid < p.n_intra_work ? p.intra_grid : p.n_intra_work);
   if (p.intra_dense && p.intra_keeper) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_KEEPER_NW, true, false>), dense_grid, dim3(64 * M355_INTRA_KEEPER_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
   else if (p.intra_dense) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_DENSE_NW, true, false>), dense_grid, dim3(64 * M355_INTRA_DENSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, 4, false, false>), dim3(p.n_intra_work), dim3(64 * 4), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_intra<PIX, CF, M355_INTRA_SPARSE_NW, false, false>), dim3(p.n_intra_work), dim3(64 * M355_INTRA_SPARSE_NW), 0, st, p, p.n_intra_work, (const DevPic*)nullptr, 1, (uint32_t*)nullptr);
 }
 
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st, bool ticket_zero)

@@ -576,6 +576,8 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
         if (!(ib.flags & M355_IBF_PCM) && ib.log2_size >= 2 && ib.log2_size <= 5) rel += (4u << ib.log2_size) + 1u;
         run = (k && key[k].first == key[k - 1].first) ? run + 1 : 1;
         if ((key[k].first & 3) == 0) widest = std::max(widest, run);      /* luma blocks of one level */
+        /* a 32x32 block is SHARED by its component's waves (k_intra.hip: each predicts its rows): all the waves there are */
+        if (ib.log2_size >= M355_INTRA_SHARE_MIN_LOG2 && !(ib.flags & M355_IBF_PCM)) widest = std::max(widest, 8u);
       }
       plan_count[c] = rel;
       log2_waves[c] = widest >= 5 ? 3 : (widest >= 3 ? 2 : (widest == 2 ? 1 : 0));
@@ -850,7 +852,7 @@ int upload(m355_ctx* c, Resident& r, const m355_picture* pic) {
   intra_dependencies(ctbW, ctbH, tile_id, ctb_touch, ctb_need, (uint8_t*)(r.host + seg[i_dp].ofs));
   for (int i = 0; i < nCtb; i++) ((uint8_t*)(r.host + seg[i_dp].ofs))[i] |= (uint8_t)(log2_waves[i] << 5);
   const auto t_deps = now();
-  int nw = 0, n_free = 0;
+  int nw = 0, n_free = 0, n_ticket = 0;
   uint32_t n_iplan = 0;                                     /* border-plan entries of the picture (k_intra_plan) */
   {
     const uint8_t* dep = (const uint8_t*)(r.host + seg[i_dp].ofs);
@@ -869,9 +871,47 @@ int upload(m355_ctx* c, Resident& r, const m355_picture* pic) {
       if (free_ctb) max_cnt = std::max(max_cnt, cnt); else n_dep++;
     }
     const size_t n_cand = cand.size() / 2;
-    n_free = (int)(n_cand - n_dep);
     order.resize(n_cand);
     std::vector<uint32_t>& bucket = r.sched_bucket;
+    if (!intra_dense) {
+      /* INTER pictures (one workgroup per CTB with intra blocks, more of them than the GPU holds at once at 8K): the CTBs that take
+         part in a dependency CHAIN — they read a neighbour's intra samples, or a neighbour reads theirs — come FIRST, by the length of
+         the chain still hanging on them (rem = the CTB's own levels + a hand-off + the longest rem among its readers; readers follow
+         their producers in decode order, so one pass backwards computes it): the stage ends with its longest chain, which therefore
+         has to start with the launch, not when the CTBs without dependencies have drained (C5: the last chains were claimed 30 us
+         into a 65 us launch, profiles/r05_g_intra_sparse_timeline.txt).  These go through the ticket, in this order: a producer's rem
+         exceeds its readers', ties keep decode order, so a workgroup still only waits on lower tickets.  The CTBs without
+         dependencies follow, by workgroup index (no ticket), longest first. */
+      std::vector<uint32_t>& rem = r.sched_u32b;            /* (rebuilt as the plan bases below) */
+      rem.assign((size_t)nCtb, 0);
+      const uint32_t* const aux = (const uint32_t*)(r.host + seg[i_il].ofs);
+      constexpr uint32_t REM_CAP = 4095, T_HANDOFF_LEVELS = 6;
+      for (size_t i = n_cand; i-- > 0;) {
+        const uint32_t rs = cand[2 * i];
+        if (!(dep[rs] & 31)) continue;
+        const m355_ctb& cb = pic->ctbs[rs];
+        const uint32_t levels = ((aux[4 * (size_t)(cb.ib_start + cb.ib_count - 1) + 3] >> 16) & 0x3FFFu) + 1u;
+        const uint32_t mine = std::min(REM_CAP, rem[rs] + levels + T_HANDOFF_LEVELS);
+        rem[rs] = mine;
+        const int cx = (int)rs % ctbW, cy = (int)rs / ctbW;
+        const int dx[4] = {-1, -1, 0, 1}, dy[4] = {0, -1, -1, -1};
+        for (int n = 0; n < 4; n++)
+          if ((dep[rs] >> n) & 1) { uint32_t& pr = rem[(size_t)(cy + dy[n]) * ctbW + (cx + dx[n])]; pr = std::max(pr, mine); }
+      }
+      /* (a producer's entry held its readers' maximum until its own turn came: every entry of a chain member is final now) */
+      bucket.assign((size_t)REM_CAP + 2 + (size_t)max_cnt + 2, 0);
+      size_t n_chain = 0;
+      auto slot_of = [&](size_t i) -> size_t {               /* chain members by falling rem, then the others by falling block count */
+        const uint32_t rs = cand[2 * i];
+        return (dep[rs] & 31) ? (size_t)(REM_CAP - rem[rs]) : (size_t)REM_CAP + 1 + (size_t)(max_cnt - (cand[2 * i + 1] & 0x7FFFFFFFu));
+      };
+      for (size_t i = 0; i < n_cand; i++) { bucket[slot_of(i) + 1]++; if (dep[cand[2 * i]] & 31) n_chain++; }
+      for (size_t i = 1; i < bucket.size(); i++) bucket[i] += bucket[i - 1];
+      for (size_t i = 0; i < n_cand; i++) order[bucket[slot_of(i)]++] = cand[2 * i];
+      n_ticket = (int)n_chain;
+    } else {
+    n_free = (int)(n_cand - n_dep);
+    n_ticket = (int)n_cand;                                  /* (an intra picture's persistent workgroups claim every item through the ticket) */
     {
       /* free CTBs, LONGEST first (bucket = max - count), decode order inside a bucket */
       bucket.assign((size_t)max_cnt + 2, 0);
@@ -892,6 +932,7 @@ int upload(m355_ctx* c, Resident& r, const m355_picture* pic) {
       for (size_t i = 0; i < n_cand; i++) if (!(cand[2 * i + 1] >> 31)) bucket[(size_t)wkey(cand[2 * i]) + 1]++;
       for (size_t i = 1; i < bucket.size(); i++) bucket[i] += bucket[i - 1];
       for (size_t i = 0; i < n_cand; i++) if (!(cand[2 * i + 1] >> 31)) order[(size_t)n_free + bucket[wkey(cand[2 * i])]++] = cand[2 * i];
+    }
     }
     nw = (int)order.size();
     /* where each item's border plans start (a running sum in work order) */
@@ -984,7 +1025,7 @@ int upload(m355_ctx* c, Resident& r, const m355_picture* pic) {
   d.ts2rs = (const uint32_t*)(r.dev + seg[i_rs].ofs);
   d.tile_id = (const uint16_t*)(r.dev + seg[i_ti].ofs);
   d.intra_work = (const DevIntraWork*)(r.dev + seg[i_iw].ofs);
-  d.n_intra_work = nw; d.n_intra_free = n_free;
+  d.n_intra_work = nw; d.n_intra_ticket = n_ticket;
   d.ctb_dep = (const uint8_t*)(r.dev + seg[i_dp].ofs);
   d.ctb_owner = sharded ? (const uint8_t*)(r.dev + seg[i_ow].ofs) : nullptr;
   d.halo_cu_base = pic->n_cus; d.halo_pb_base = pic->n_pbs;

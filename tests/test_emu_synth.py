@@ -36,6 +36,12 @@ CASES = [
     dict(width=128, height=128, bit_depth=10, seed=55, intra_pct=100, n_refs=0, fixed_cu_log2=5, chroma_format=3),
     dict(width=136, height=72, bit_depth=8, seed=56, intra_pct=100, n_refs=0, fixed_cu_log2=4, n_slices=2),
     dict(width=128, height=128, bit_depth=8, seed=57, intra_pct=100, n_refs=0, fixed_cu_log2=3, cbf_pct=0),
+    # inter pictures whose intra blocks are 32x32 (the chains of such a picture): a CTB's luma waves share the block, its residual comes
+    # from LDS as in an intra picture's kernel — 4:2:0, 4:4:4 (32x32 chroma blocks, shared too), 4:2:2, with and without residuals
+    dict(width=256, height=128, bit_depth=8, seed=61, intra_pct=50, fixed_cu_log2=5, cbf_pct=100),
+    dict(width=192, height=128, bit_depth=10, seed=62, intra_pct=40, fixed_cu_log2=6, chroma_format=3, cbf_pct=80),
+    dict(width=192, height=128, bit_depth=8, seed=63, intra_pct=60, fixed_cu_log2=5, chroma_format=2, tile_cols=2),
+    dict(width=256, height=192, bit_depth=10, seed=64, intra_pct=30, fixed_cu_log2=5, cbf_pct=0, features=31),
 ]
 
 
