@@ -393,8 +393,51 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   const uint32_t epoch = p.epoch;
 #define SYNC_CTB() do { if (multi) __syncthreads(); else wave_sync(); } while (0)
 
+  /* ---- The prologue is a handful of DEPENDENT memory round trips (descriptor -> block records -> CU plane -> CU records -> samples), and on an
+     inter picture it is half of a CTB's time in the kernel (profiles/r05_g_intra_sparse_timeline.txt: 6 of 12 us).  EARLY = everything whose address
+     follows from the descriptor alone is requested at once, before the first wait: the first 64 block records and exec records (an inter picture's
+     CTB rarely has more) and the CU index behind every halo entry; the CU records follow beside the plan, the residuals beside the need scan, the
+     halo samples / granules beside the body.  (An intra picture's prologue is off the chain — a CTB is claimed long before its neighbours let it
+     run — and its kernels have no registers to spare across the in-kernel planning: there everything is loaded where it is used.) ---- */
+  constexpr bool EARLY = !DENSE;
+  constexpr int HU = 4;                                    /* halo entries per lane: 2cw + 1 + ch <= 193 entries on >= 64 lanes */
+  static_assert(3 * MAXCTB + 1 <= 64 * HU, "a component's halo is staged in one pass");
+  const int nhalo = (2 * cw + 1) + ch;
+  uint4 ex_first = make_uint4(0, 0, 0, 0);
+  uint32_t rf0 = 0, rf1 = 0xFFu, rf2 = 0;
+  if (EARLY && lane < (int)min(ctbinfo.ib_count, 64u)) {
+    ex_first = ((const uint4*)p.ib_aux)[ctbinfo.ib_start + lane];
+    const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + lane];
+    rf0 = r[0]; rf1 = r[1]; rf2 = r[2];
+  }
+  /* halo entry h of this lane's u-th slot: picture position, inside the picture?, CU index / produced by an intra block? */
+  int hx[HU], hy[HU];
+  bool hin[HU], htop[HU], hintra[HU];
+  uint32_t hci[HU], hpm[HU];
+  auto halo_where = [&]() {
+#pragma unroll
+    for (int u = 0; u < HU; u++) {
+      const int h = lane + 64 * g + u * 64 * G;
+      htop[u] = h < 2 * cw + 1;
+      hx[u] = htop[u] ? x0c - 1 + h : x0c - 1; hy[u] = htop[u] ? y0c - 1 : y0c + (h - (2 * cw + 1));
+      hin[u] = comp && h < nhalo && hx[u] >= 0 && hy[u] >= 0 && hx[u] < pw && hy[u] < ph;
+      /* (loads without a branch around them — an entry outside the picture reads element 0 —: the four are in flight together, where a
+         conditional load is waited for inside its branch) */
+      hci[u] = d_cu_index_at(p, hin[u] ? hx[u] << csw : 0, hin[u] ? hy[u] << csh : 0);
+    }
+  };
+  auto halo_who = [&]() {
+#pragma unroll
+    for (int u = 0; u < HU; u++) hpm[u] = p.cus[hci[u] ? hci[u] - 1 : 0u].pred_mode;
+  };
+  auto halo_is_intra = [&]() {
+#pragma unroll
+    for (int u = 0; u < HU; u++) hintra[u] = hin[u] && hci[u] != 0 && hpm[u] == 0;
+  };
+  if (EARLY) halo_where();
+
   /* ---- the plan: the whole CTB's (dense) or its first PLAN_LDS entries (a later batch of 64 blocks reloads), 16 bytes per
-     lane and step, requested before anything else ---- */
+     lane and step ---- */
   uint32_t plan_lo = 0;                                    /* first entry held in s_plan */
   if (PLAN_HERE) {
     /* the CTB is planned HERE, straight into LDS, by all the workgroup's waves (a block each, round robin): the prologue is off the
@@ -408,6 +451,70 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     const uint4* src = (const uint4*)(p.iplan + plan_base);  /* plan_base is a multiple of 8 entries */
     for (uint32_t o = (uint32_t)(wv * 64 + lane) * 8u; o < n; o += (uint32_t)NWV * 512u) *(uint4*)(s_plan + o) = src[o >> 3];
   }
+  if (EARLY) halo_who();                                   /* (the CU indices came in with the plan) */
+
+  /* ---- residual pre-pass: the CTB's deferred residuals go to LDS, each component's waves taking its blocks in turn (inter
+     pictures too: a block of the chain then reads its residual from LDS, where it paid a global-memory round trip — and the
+     32x32 blocks that make the chains of such a picture are predicted by the same loops as an intra picture's).  They go INTO
+     THE BODY, at the block's own position: nothing reads those elements before the block is predicted — the CTB's blocks are
+     disjoint, the staging below leaves covered units alone, a border entry only ever points at a sample that has been
+     reconstructed — and the lane that predicts a sample reads its residual from the element it then overwrites.  Two blocks at a
+     time (4 samples = one row segment per lane and step, up to four steps per block): their loads are in flight together. ---- */
+  {
+    int taken = 0;                                           /* blocks of this component seen so far (wave-uniform) */
+    for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
+      uint32_t rw0 = rf0, rw1 = rf1, rw2 = rf2;
+      if (!(EARLY && kbase == 0)) {
+        rw0 = 0; rw1 = 0xFFu; rw2 = 0;
+        if (kbase + lane < ctbinfo.ib_count) {
+          const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
+          rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
+        }
+      }
+      unsigned long long mine = __ballot((int)(comp && (rw1 & 0xFFu) == (uint32_t)c));
+      /* this wave's next block with a residual among the batch's records: first body element, size, residual offset (wave-uniform) */
+      auto next_block = [&](int& b_ofs, int& b_log2, uint32_t& b_res) -> bool {
+        while (mine) {
+          const int src = __ffsll(mine) - 1;
+          mine &= mine - 1;
+          if ((taken++ & (G - 1)) != g) continue;
+          const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src);
+          const int flags = (int)(w1 >> 24);
+          if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
+          b_log2 = (int)((w1 >> 8) & 0xFFu); b_res = __builtin_amdgcn_readlane(rw2, src);
+          b_ofs = ((int)(w0 >> 16) - y0c) * BODY_PITCH + BODY_X0 + (int)(w0 & 0xFFFFu) - x0c;
+          return true;
+        }
+        return false;
+      };
+      auto load_block = [&](uint2* v, int b_log2, uint32_t b_res) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int o = lane * 4 + 256 * u;
+          v[u] = make_uint2(0, 0);
+          if (o < (1 << (2 * b_log2))) v[u] = *(const uint2*)(p.resbuf + b_res + o);
+        }
+      };
+      auto store_block = [&](const uint2* v, int b_ofs, int b_log2) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int o = lane * 4 + 256 * u;
+          if (o < (1 << (2 * b_log2))) *(uint2*)(body + b_ofs + (o >> b_log2) * BODY_PITCH + (o & ((1 << b_log2) - 1))) = v[u];
+        }
+      };
+      for (;;) {
+        int ofs_a = 0, log2_a = 2, ofs_b = 0, log2_b = 2;
+        uint32_t res_a = 0, res_b = 0;
+        if (!next_block(ofs_a, log2_a, res_a)) break;
+        const bool two = next_block(ofs_b, log2_b, res_b);
+        uint2 va[4], vb[4];
+        load_block(va, log2_a, res_a);
+        if (two) load_block(vb, log2_b, res_b);
+        store_block(va, ofs_a, log2_a);
+        if (two) store_block(vb, ofs_b, log2_b);
+      }
+    }
+  }
   /* ---- which body vectors does some block's border read?  Only those are staged: the row above a block
      (x-1 .. x+2nT-1) and the column left of it (y .. y+2nT-1), intrapred.h:436-674 — a 64x64 CTB with two 8x8 intra
      blocks: ~6 of its 512 luma vectors — and of those only what no intra block of this CTB produces itself (s_cover:
@@ -420,10 +527,16 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     if (lane < MAXCTB / 4) s_cover[cs][lane] = 0;
     wave_sync();
     const int nvr = cw >> 3;                                /* vectors per row */
-    for (uint32_t k = lane; k < ctbinfo.ib_count; k += 64) {
-      const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + k];
-      const uint32_t w0 = r[0], w1 = r[1];
-      if ((w1 & 0xFFu) != (uint32_t)c) continue;
+    for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
+      uint32_t w0 = rf0, w1 = rf1;
+      if (!(EARLY && kbase == 0)) {
+        w1 = 0xFFu;
+        if (kbase + lane < ctbinfo.ib_count) {
+          const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
+          w0 = r[0]; w1 = r[1];
+        }
+      }
+      if ((w1 & 0xFFu) != (uint32_t)c) continue;             /* (another component's block, or no block: 0xFF) */
       const int nT = 1 << ((w1 >> 8) & 0xFFu);
       const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
       {
@@ -454,13 +567,38 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   }
   SYNC_CTB();
   if (comp) {
-    /* ---- stage those vectors: 8 samples each; four per lane are requested before the first is stored (a loop of
+    /* ---- halo: the row above the CTB (x = -1 .. 2cw-1) and the column left of it, only the entries some block's border reads
+       (s_hneed).  A sample that an INTRA block of a neighbour CTB produces comes from that CTB's granules — if it is there already;
+       otherwise the entry stays HALO_NOT_READY and the block that needs it polls for it.  Everything else was finished by the preceding
+       kernels (stream order) and is read from the picture.  Requested here, stored behind the body's first pass. ---- */
+    if (!EARLY) { halo_where(); halo_who(); }
+    halo_is_intra();
+    m355_granule hgr[HU];
+    uint32_t hpl[HU];
+    /* (scalars: the granule rows of the CTB row above / the CTB column on the left — a per-lane choice between DevPic's arrays would be a vector
+       load from the kernel arguments in front of every granule load) */
+    const size_t g_row = p.edge_row_ofs[cs] + (size_t)max(ctbY - 1, 0) * (size_t)(pw >> 1), g_col = p.edge_col_ofs[cs] + (size_t)max(ctbX - 1, 0) * (size_t)(ph >> 1);
+#pragma unroll
+    for (int u = 0; u < HU; u++) {
+      const int h = lane + 64 * g + u * 64 * G;
+      const bool want = hin[u] && ((s_hneed[cs][min(h, nhalo - 1) >> 5] >> (h & 31)) & 1u);
+      hintra[u] = hintra[u] && want;
+      /* (both loads of every slot, without a branch around them — a slot that wants neither reads element 0 —: eight loads in flight, where a
+         conditional load is waited for inside its branch) */
+      const size_t gi = htop[u] ? g_row + (size_t)(hx[u] >> 1) : g_col + (size_t)(hy[u] >> 1);     /* (d_edge_row / d_edge_col) */
+      hgr[u] = __hip_atomic_load(p.edge + (hintra[u] ? gi : (size_t)0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hpl[u] = plane[(want && !hintra[u]) ? (size_t)hy[u] * stride + hx[u] : (size_t)0];
+      if (!want || hintra[u]) hpl[u] = 0;
+    }
+    /* ---- stage the needed body vectors: 8 samples each; four per lane are requested before the first is stored (a loop of
        load -> store steps costs one memory round trip per step, and a CTB has up to eight steps per lane) ---- */
     {
       const int l2v = (l2c - csw) - 3;                       /* log2(vectors per row); cw >= 8 */
       const int nvec = ch << l2v;
       constexpr int U = 4;
-      for (int idx0 = lane + 64 * g; idx0 < nvec; idx0 += 64 * G * U) {
+      /* (the first pass stands outside the loop: at a loop header the compiler waits for every load in flight — the halo's —, and an inter
+         picture's chroma components have one pass) */
+      auto stage_pass = [&](const int idx0) {
         uint4 v[U];
         bool take[U];
 #pragma unroll
@@ -487,93 +625,24 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
             o.x = (bx & 0xFFu) | ((bx & 0xFF00u) << 8); o.y = ((bx >> 16) & 0xFFu) | ((bx >> 8) & 0xFF0000u);
             o.z = (by & 0xFFu) | ((by & 0xFF00u) << 8); o.w = ((by >> 16) & 0xFFu) | ((by >> 8) & 0xFF0000u);
           }
-          /* (a half some intra block of this CTB covers holds that block's RESIDUAL — below —, not a sample of the picture) */
+          /* (a half some intra block of this CTB covers holds that block's RESIDUAL — above —, not a sample of the picture) */
           const uint32_t cov = (s_cover[cs][y >> 2] >> (xv >> 2)) & 3u;
           uint16_t* dst = body + y * BODY_PITCH + BODY_X0 + xv;
           if (cov == 0u) *(uint4*)dst = o;
           else if (cov == 2u) *(uint2*)dst = make_uint2(o.x, o.y);
           else *(uint2*)(dst + 4) = make_uint2(o.z, o.w);
         }
-      }
+      };
+      stage_pass(lane + 64 * g);
+      for (int idx0 = lane + 64 * g + 64 * G * U; idx0 < nvec; idx0 += 64 * G * U) stage_pass(idx0);
     }
-    /* ---- halo: the row above the CTB (x = -1 .. 2cw-1) and the column left of it.  A sample that an INTRA block of a
-       neighbour CTB produces comes from that CTB's granules — if it is there already; otherwise the entry stays
-       HALO_NOT_READY and the block that needs it polls for it.  Everything else was finished by the preceding kernels
-       (stream order) and is read from the picture. ---- */
-    const int nhalo = (2 * cw + 1) + ch;
-    /* only the entries some block's border reads (s_hneed); per entry up to three dependent loads (CU plane -> CU record ->
-       sample or granule): the lane's (up to four) entries go through each step together */
-    {
-      constexpr int U = 4;
-      for (int h0 = lane + 64 * g; h0 < nhalo; h0 += 64 * G * U) {
-        int hx[U], hy[U];
-        bool in[U], top_[U];
-        uint32_t ci[U], val[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int h = h0 + u * 64 * G;
-          top_[u] = h < 2 * cw + 1;
-          hx[u] = top_[u] ? x0c - 1 + h : x0c - 1; hy[u] = top_[u] ? y0c - 1 : y0c + (h - (2 * cw + 1));
-          in[u] = h < nhalo && ((s_hneed[cs][min(h, nhalo - 1) >> 5] >> (h & 31)) & 1u) && hx[u] >= 0 && hy[u] >= 0 && hx[u] < pw && hy[u] < ph;
-          ci[u] = in[u] ? d_cu_index_at(p, hx[u] << csw, hy[u] << csh) : 0u;
-        }
-        bool intra[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) intra[u] = in[u] && ci[u] != 0 && p.cus[ci[u] - 1].pred_mode == 0;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          val[u] = 0;
-          if (intra[u]) {
-            const m355_granule gr = __hip_atomic_load(top_[u] ? d_edge_row(p, cs, ctbY - 1, hx[u]) : d_edge_col(p, cs, ctbX - 1, hy[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val[u] = ((uint32_t)(gr >> 32) == epoch && !p.test_halo_late) ? (uint32_t)((gr >> (16 * ((top_[u] ? hx[u] : hy[u]) & 1))) & 0xFFFFu) : HALO_NOT_READY;
-          } else if (in[u]) val[u] = plane[(size_t)hy[u] * stride + hx[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int h = h0 + u * 64 * G;
-          if (h >= nhalo) continue;
-          if (top_[u]) halo[h] = (uint16_t)val[u]; else halo[HALO_TOP_N + h - (2 * cw + 1)] = (uint16_t)val[u];
-        }
-      }
-    }
-  }
-  /* ---- residual pre-pass: the CTB's deferred residuals go to LDS, each component's waves taking its blocks in turn (inter
-     pictures too: a block of the chain then reads its residual from LDS, where it paid a global-memory round trip — and the
-     32x32 blocks that make the chains of such a picture are predicted by the same loops as an intra picture's).  They go INTO
-     THE BODY, at the block's own position: nothing reads those elements before the block is predicted — the CTB's blocks are
-     disjoint, the staging above leaves covered units alone, a border entry only ever points at a sample that has been
-     reconstructed — and the lane that predicts a sample reads its residual from the element it then overwrites. ---- */
-  {
-    int taken = 0;                                           /* blocks of this component seen so far (wave-uniform) */
-    for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
-      uint32_t rw0 = 0, rw1 = 0xFF, rw2 = 0;
-      if (kbase + lane < ctbinfo.ib_count) {
-        const uint32_t* r = (const uint32_t*)&p.ibs[ctbinfo.ib_start + kbase + lane];
-        rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
-      }
-      unsigned long long mine = __ballot((int)(comp && (rw1 & 0xFFu) == (uint32_t)c));
-      while (mine) {
-        const int src = __ffsll(mine) - 1;
-        mine &= mine - 1;
-        if ((taken++ & (G - 1)) != g) continue;
-        const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src), w2 = __builtin_amdgcn_readlane(rw2, src);
-        const int flags = (int)(w1 >> 24), log2 = (int)((w1 >> 8) & 0xFFu), nT = 1 << log2;
-        if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
-        const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
-        /* 4 samples (one row segment) per lane and step; the (up to four) steps of a block are requested together */
-        uint2 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int o = lane * 4 + 256 * u;
-          v[u] = make_uint2(0, 0);
-          if (o < nT * nT) v[u] = *(const uint2*)(p.resbuf + w2 + o);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int o = lane * 4 + 256 * u;
-          if (o < nT * nT) *(uint2*)(body + (ly + (o >> log2)) * BODY_PITCH + BODY_X0 + lx + (o & (nT - 1))) = v[u];
-        }
-      }
+    for (int u = 0; u < HU; u++) {
+      const int h = lane + 64 * g + u * 64 * G;
+      if (h >= nhalo) continue;
+      uint32_t val = hpl[u];
+      if (hintra[u]) val = ((uint32_t)(hgr[u] >> 32) == epoch && !p.test_halo_late) ? (uint32_t)((hgr[u] >> (16 * ((htop[u] ? hx[u] : hy[u]) & 1))) & 0xFFFFu) : HALO_NOT_READY;
+      if (htop[u]) halo[h] = (uint16_t)val; else halo[HALO_TOP_N + h - (2 * cw + 1)] = (uint16_t)val;
     }
   }
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
@@ -673,7 +742,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     int lv = -1;
     const int nvalid = min(64, (int)(ctbinfo.ib_count - kbase));
     if (lane < nvalid) {
-      ex = ((const uint4*)p.ib_aux)[ctbinfo.ib_start + kbase + lane];
+      ex = (EARLY && kbase == 0) ? ex_first : ((const uint4*)p.ib_aux)[ctbinfo.ib_start + kbase + lane];
       lv = (int)((ex.w >> 16) & 0x3FFFu);
     }
     if (!DENSE) {
