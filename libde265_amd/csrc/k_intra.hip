@@ -281,7 +281,7 @@ template <class PIX, int CF, int NW, bool DENSE, bool BATCH>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
 {
   if (!BATCH) M355_GATE(p0);
-  constexpr int CW_C = IntraGeo<CF>::CW_C, CH_C = IntraGeo<CF>::CH_C;
+  constexpr int CW_C = IntraGeo<CF>::CW_C;
   constexpr int BODY_L = IntraGeo<CF>::BODY_L, BODY_C = IntraGeo<CF>::BODY_C;
   constexpr int SAMP_L = IntraGeo<CF>::SAMP_L, SAMP_C = IntraGeo<CF>::SAMP_C;
   __shared__ __attribute__((aligned(16))) uint16_t s_body[SAMP_L + 2 * SAMP_C];   /* per component: body | halo | constant cell */
