@@ -277,8 +277,16 @@ template <int CF> __global__ void __launch_bounds__(256) k_tu_plan(DevPic p, int
  * is item t / n_pics of picture t % n_pics (the pictures' wavefronts interleaved: a workgroup still only waits on items claimed
  * before its own, now of its own picture).  Independent intra pictures then overlap CTB by CTB inside one kernel instead of through
  * the runtime's hardware queues (m355_decode_batch, runtime_decode.hip). */
+#ifdef __clang__
+#define M355_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#else
+#define M355_WAVES_PER_EU(n)      /* (the CPU tier's interpreter build) */
+#endif
+#ifndef M355_INTRA_SPARSE_WAVES_PER_EU
+#define M355_INTRA_SPARSE_WAVES_PER_EU 4   /* (the register budget of an inter picture's kernel: 4 -> 96 registers = 5 workgroups per CU) */
+#endif
 template <class PIX, int CF, int NW, bool DENSE, bool BATCH>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4))) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
+__global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU(DENSE ? 4 : M355_INTRA_SPARSE_WAVES_PER_EU) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
 {
   if (!BATCH) M355_GATE(p0);
   constexpr int CW_C = IntraGeo<CF>::CW_C;
@@ -335,6 +343,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     __syncthreads();
     item = __builtin_amdgcn_readfirstlane((int)s_ticket);
   }
+  item = __builtin_amdgcn_readfirstlane(item);              /* (uniform either way: say so — the descriptor's address is then a scalar one) */
   const DevPic& p = *(BATCH ? pics + pk : &p0);
   if (BATCH) {
     /* a shorter picture's list is exhausted, or its lists were rejected (k_validate): nothing to do for this ticket */
@@ -342,8 +351,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
   } else if (item >= work_n) return;
 #ifdef M355_X_PROF      /* experiment builds (tools/prof_timeline.py): when a CTB was claimed, started its block loop, ended it, was written out */
 #define TL(k) do { if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item + 1 + (k)] = wall_clock64(); } while (0)
+/* (M355_X_PROF_TLP = 1 .. 4: stamp 1 is taken inside the prologue instead of at the block loop's start — behind the plan, the residuals, the need scan's
+   barrier, the staging — to see which of its round trips the prologue's time is) */
+#ifndef M355_X_PROF_TLP
+#define M355_X_PROF_TLP 0
+#endif
+#define TLP(k) do { if (M355_X_PROF_TLP == (k)) TL(1); } while (0)
 #else
 #define TL(k) do { } while (0)
+#define TLP(k) do { } while (0)
 #endif
   TL(0);
   /* the CTB's descriptor (host-prepared, runtime.hip): one scalar 32-byte load */
@@ -452,6 +468,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     for (uint32_t o = (uint32_t)(wv * 64 + lane) * 8u; o < n; o += (uint32_t)NWV * 512u) *(uint4*)(s_plan + o) = src[o >> 3];
   }
   if (EARLY) halo_who();                                   /* (the CU indices came in with the plan) */
+  TLP(1);
 
   /* ---- residual pre-pass: the CTB's deferred residuals go to LDS, each component's waves taking its blocks in turn (inter
      pictures too: a block of the chain then reads its residual from LDS, where it paid a global-memory round trip — and the
@@ -515,6 +532,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       }
     }
   }
+  TLP(2);
   /* ---- which body vectors does some block's border read?  Only those are staged: the row above a block
      (x-1 .. x+2nT-1) and the column left of it (y .. y+2nT-1), intrapred.h:436-674 — a 64x64 CTB with two 8x8 intra
      blocks: ~6 of its 512 luma vectors — and of those only what no intra block of this CTB produces itself (s_cover:
@@ -566,6 +584,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     }
   }
   SYNC_CTB();
+  TLP(3);
   if (comp) {
     /* ---- halo: the row above the CTB (x = -1 .. 2cw-1) and the column left of it, only the entries some block's border reads
        (s_hneed).  A sample that an INTRA block of a neighbour CTB produces comes from that CTB's granules — if it is there already;
@@ -645,6 +664,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
       if (htop[u]) halo[h] = (uint16_t)val; else halo[HALO_TOP_N + h - (2 * cw + 1)] = (uint16_t)val;
     }
   }
+  TLP(4);
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
   /* ---- the HALO KEEPER (intra pictures, the workgroup's last wave): a CTB's halo is staged long before its neighbours have
      finished (the prologue is off the chain), so nearly every sample a block reads from another CTB is still HALO_NOT_READY there,
@@ -708,7 +728,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)
     for (int k = 0; k < KSLOTS; k++)
       if ((kp_pend >> k) & 1u) kp_gr[k] = __hip_atomic_load(p.edge + gi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  TL(1);
+  TLP(0);
 #ifdef M355_X_PROF
   if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item] = (unsigned long long)ctb + 1;
 #endif

@@ -216,8 +216,19 @@ int m355_create(int device, m355_ctx** out)
   return M355_OK;
 }
 
+/* the exchange buffers of a sharded picture are read by the OTHER ranks' devices (m355_group_*: peer copies on their streams), which a hipFree on this
+   device does not wait for: before they go, every device is drained (a rare path: teardown, or a handle re-used for another geometry) */
+static void drain_all_devices(int keep_current)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return;
+  for (int d = 0; d < n; d++) if (hipSetDevice(d) == hipSuccess) hipDeviceSynchronize();
+  hipSetDevice(keep_current);
+}
+
 static void resident_free(Resident& r)
 {
+  if (r.xb[0]) { int cur = 0; hipGetDevice(&cur); drain_all_devices(cur); }
   for (void* b : r.xb) if (b) hipFree(b);
   if (r.xscratch) hipFree(r.xscratch);
   if (r.dev) hipFree(r.dev);
@@ -610,6 +621,7 @@ int m355_picture_replace(m355_ctx* c, int h, const m355_picture* pic)
   if (r.done.ticket) { HIPCHK(ev_sync(c, r.done)); r.done = EvRef(); }
   if (r.xb[0] && (memcmp(&r.hdr.pp, &pic->pp, sizeof(pic->pp)) != 0 || r.shard_n != c->shard_n || r.shard_rank != c->shard_rank)) {
     /* the exchange buffers of a sharded picture are sized by its geometry and tile structure */
+    drain_all_devices(c->device);
     for (void*& b : r.xb) { if (b) hipFree(b); b = nullptr; }
     if (r.xscratch) { hipFree(r.xscratch); r.xscratch = nullptr; }
     r.peers.clear();

@@ -304,6 +304,10 @@ static int group_rank_decode(m355_group* g, int r, unsigned long long n, const i
   int rc = rc0;
   for (int k = 0; k <= last; k++) {
     /* (a rank that failed keeps publishing its steps: the others must not wait for it forever) */
+    if (k == 3 && gather && N > 1)
+      /* the gather buffer is repacked: every rank's X3 read of the PREVIOUS decode has to be over (the halo exchanges in between order it only three
+         hops along a rank row; those events were recorded before m355_group_decode returned — a never-recorded one is no wait) */
+      for (int q = 0; q < N; q++) if (q != r) hipStreamWaitEvent((hipStream_t)m355_stream(c), g->ev_copied[(size_t)q][3], 0);
     if (!rc) rc = m355_decode_phase(c, h, k, k < 4 ? me.xb[k] : nullptr);
     if (N <= 1 || k >= last) continue;
     hipStream_t st = (hipStream_t)m355_stream(c);
@@ -337,6 +341,7 @@ static int group_rank_decode(m355_group* g, int r, unsigned long long n, const i
         hipStreamWaitEvent(st, g->ev_pack[(size_t)q][3], 0);
         if (hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)other.xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st) != hipSuccess) rc = fail(M355_ERR_HIP, "hipMemcpyPeerAsync failed");
       }
+      if (!rc) hipEventRecord(g->ev_copied[(size_t)r][3], st);      /* this rank has read the others' gather buffers (see phase 3 above) */
     }
   }
   return rc;
@@ -434,6 +439,8 @@ static int group_decode_lockstep(m355_group* g, const int* handles, int gather)
     for (int r = 0; r < N; r++) {
       m355_ctx* c = g->ctx[(size_t)r];
       hipSetDevice(c->device);
+      if (k == 3 && gather && N > 1)
+        for (int q = 0; q < N; q++) if (q != r) hipStreamWaitEvent((hipStream_t)m355_stream(c), g->ev_copied[(size_t)q][3], 0);   /* (as group_rank_decode) */
       const int rc = m355_decode_phase(c, handles[r], k, k < 4 ? R[(size_t)r]->xb[k] : nullptr);
       if (rc) return rc;
       if (N > 1 && k < last) hipEventRecord(g->ev_pack[(size_t)r][(size_t)k], (hipStream_t)m355_stream(c));
@@ -463,6 +470,7 @@ static int group_decode_lockstep(m355_group* g, const int* handles, int gather)
             hipStreamWaitEvent(st, g->ev_pack[(size_t)q][3], 0);
             HIPCHK(hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)R[(size_t)q]->xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st));
           }
+          hipEventRecord(g->ev_copied[(size_t)r][3], st);
         }
       }
   }

@@ -74,6 +74,7 @@ const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetLastError(void);
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipMalloc(void** p, size_t n);
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }

@@ -248,6 +248,7 @@ const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSucce
 hipError_t hipGetLastError(void) { hipError_t e = g_last; g_last = hipSuccess; return e; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "simt_emu"); strcpy(p->gcnArchName, "simt_emu"); p->multiProcessorCount = 1; return hipSuccess; }
 /* Device (and pinned) memory is NOT zero on the GPU, so it is not zero here: every allocation is filled with 0xA5 — a kernel or a
  * host path that relies on fresh memory being zero fails in the CPU tier.  SIMT_EMU_POISON=<byte> picks another fill (0 = zeros). */
