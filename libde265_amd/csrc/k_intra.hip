@@ -282,11 +282,14 @@ template <int CF> __global__ void __launch_bounds__(256) k_tu_plan(DevPic p, int
 #else
 #define M355_WAVES_PER_EU(n)      /* (the CPU tier's interpreter build) */
 #endif
+#ifndef M355_INTRA_DENSE_WAVES_PER_EU
+#define M355_INTRA_DENSE_WAVES_PER_EU 4    /* (the 12-wave kernel of intra pictures in flight / in batches) */
+#endif
 #ifndef M355_INTRA_SPARSE_WAVES_PER_EU
-#define M355_INTRA_SPARSE_WAVES_PER_EU 6   /* (the register budget of an inter picture's kernel: 6 -> 80 registers and one spilled pair = 6 workgroups per CU; 5 -> 87 registers, 4 -> 97) */
+#define M355_INTRA_SPARSE_WAVES_PER_EU 6   /* (the register budget of an inter picture's kernel at 4:2:0 / 4:0:0: 6 -> 80 registers and one spilled pair = 6 workgroups per CU, C5's intra stage 0.0467 -> 0.0424 ms, C3 / C4 unchanged: profiles/r05_v22_intra_w6_ab.txt; 4 -> 96 registers = 5 workgroups; 4:2:2 / 4:4:4 are bounded by their LDS) */
 #endif
 template <class PIX, int CF, int NW, bool DENSE, bool BATCH>
-__global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) ? 4 : M355_INTRA_SPARSE_WAVES_PER_EU) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
+__global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU(CF >= 2 ? 4 : (DENSE ? (NW == M355_INTRA_KEEPER_NW ? 4 : M355_INTRA_DENSE_WAVES_PER_EU) : M355_INTRA_SPARSE_WAVES_PER_EU)) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
 {
   if (!BATCH) M355_GATE(p0);
   constexpr int CW_C = IntraGeo<CF>::CW_C;
@@ -477,64 +480,10 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
      disjoint, the staging below leaves covered units alone, a border entry only ever points at a sample that has been
      reconstructed — and the lane that predicts a sample reads its residual from the element it then overwrites.  Two blocks at a
      time (4 samples = one row segment per lane and step, up to four steps per block): their loads are in flight together. ---- */
-  int r_taken = 0;                                           /* blocks of this component seen so far (wave-uniform) */
-  unsigned long long rmine = 0;                            /* the current batch's records of this component still to be looked at */
-  uint32_t rw0 = rf0, rw1 = rf1, rw2 = rf2;                /* the current batch's records, one per lane */
-  /* this wave's next block with a residual among the batch's records: first body element, size, residual offset (wave-uniform) */
-  auto next_block = [&](int& b_ofs, int& b_log2, uint32_t& b_res) -> bool {
-    while (rmine) {
-      const int src = __ffsll(rmine) - 1;
-      rmine &= rmine - 1;
-      if ((r_taken++ & (G - 1)) != g) continue;
-      const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src);
-      const int flags = (int)(w1 >> 24);
-      if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
-      b_log2 = (int)((w1 >> 8) & 0xFFu); b_res = __builtin_amdgcn_readlane(rw2, src);
-      b_ofs = ((int)(w0 >> 16) - y0c) * BODY_PITCH + BODY_X0 + (int)(w0 & 0xFFFFu) - x0c;
-      return true;
-    }
-    return false;
-  };
-  auto load_block = [&](uint2* v, int b_log2, uint32_t b_res, bool have = true) {
-    /* (`have` folded into the lanes' predicate: a wave-level branch around the loads would make the compiler wait where its arms meet) */
-    const int n = have ? 1 << (2 * b_log2) : 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int o = lane * 4 + 256 * u;
-      v[u] = make_uint2(0, 0);
-      if (o < n) v[u] = *(const uint2*)(p.resbuf + b_res + o);
-    }
-  };
-  auto store_block = [&](const uint2* v, int b_ofs, int b_log2, bool have = true) {
-    const int n = have ? 1 << (2 * b_log2) : 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int o = lane * 4 + 256 * u;
-      if (o < n) *(uint2*)(body + b_ofs + (o >> b_log2) * BODY_PITCH + (o & ((1 << b_log2) - 1))) = v[u];
-    }
-  };
-  auto drain_batch = [&]() {                               /* the batch's remaining blocks, two at a time */
-    for (;;) {
-      int ofs_a = 0, log2_a = 2, ofs_b = 0, log2_b = 2;
-      uint32_t res_a = 0, res_b = 0;
-      if (!next_block(ofs_a, log2_a, res_a)) break;
-      const bool two = next_block(ofs_b, log2_b, res_b);
-      uint2 va[4], vb[4];
-      load_block(va, log2_a, res_a);
-      if (two) load_block(vb, log2_b, res_b);
-      store_block(va, ofs_a, log2_a);
-      if (two) store_block(vb, ofs_b, log2_b);
-    }
-  };
-  /* an inter picture's CTB with one batch of records (nearly all of them): the first two blocks' loads are requested behind the need scan (a loop: the
-     compiler drains the loads in flight in front of one) and stored behind its barrier — which waits for LDS only —, beside the halo's and the body's
-     loads: one round trip less in a row */
-  const bool one_batch = EARLY && ctbinfo.ib_count <= 64u;
-  uint2 fa[4], fb[4];
-  int f_ofs_a = 0, f_log2_a = 2, f_ofs_b = 0, f_log2_b = 2;
-  bool f_have_a = false, f_have_b = false;
-  if (!one_batch) {
+  {
+    int taken = 0;                                           /* blocks of this component seen so far (wave-uniform) */
     for (uint32_t kbase = 0; kbase < ctbinfo.ib_count; kbase += 64) {
+      uint32_t rw0 = rf0, rw1 = rf1, rw2 = rf2;
       if (!(EARLY && kbase == 0)) {
         rw0 = 0; rw1 = 0xFFu; rw2 = 0;
         if (kbase + lane < ctbinfo.ib_count) {
@@ -542,8 +491,48 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
           rw0 = r[0]; rw1 = r[1]; rw2 = r[2];
         }
       }
-      rmine = __ballot((int)(comp && (rw1 & 0xFFu) == (uint32_t)c));
-      drain_batch();
+      unsigned long long mine = __ballot((int)(comp && (rw1 & 0xFFu) == (uint32_t)c));
+      /* this wave's next block with a residual among the batch's records: first body element, size, residual offset (wave-uniform) */
+      auto next_block = [&](int& b_ofs, int& b_log2, uint32_t& b_res) -> bool {
+        while (mine) {
+          const int src = __ffsll(mine) - 1;
+          mine &= mine - 1;
+          if ((taken++ & (G - 1)) != g) continue;
+          const uint32_t w0 = __builtin_amdgcn_readlane(rw0, src), w1 = __builtin_amdgcn_readlane(rw1, src);
+          const int flags = (int)(w1 >> 24);
+          if (!(flags & M355_IBF_HAS_RESIDUAL) || (flags & M355_IBF_PCM)) continue;
+          b_log2 = (int)((w1 >> 8) & 0xFFu); b_res = __builtin_amdgcn_readlane(rw2, src);
+          b_ofs = ((int)(w0 >> 16) - y0c) * BODY_PITCH + BODY_X0 + (int)(w0 & 0xFFFFu) - x0c;
+          return true;
+        }
+        return false;
+      };
+      auto load_block = [&](uint2* v, int b_log2, uint32_t b_res) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int o = lane * 4 + 256 * u;
+          v[u] = make_uint2(0, 0);
+          if (o < (1 << (2 * b_log2))) v[u] = *(const uint2*)(p.resbuf + b_res + o);
+        }
+      };
+      auto store_block = [&](const uint2* v, int b_ofs, int b_log2) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int o = lane * 4 + 256 * u;
+          if (o < (1 << (2 * b_log2))) *(uint2*)(body + b_ofs + (o >> b_log2) * BODY_PITCH + (o & ((1 << b_log2) - 1))) = v[u];
+        }
+      };
+      for (;;) {
+        int ofs_a = 0, log2_a = 2, ofs_b = 0, log2_b = 2;
+        uint32_t res_a = 0, res_b = 0;
+        if (!next_block(ofs_a, log2_a, res_a)) break;
+        const bool two = next_block(ofs_b, log2_b, res_b);
+        uint2 va[4], vb[4];
+        load_block(va, log2_a, res_a);
+        if (two) load_block(vb, log2_b, res_b);
+        store_block(va, ofs_a, log2_a);
+        if (two) store_block(vb, ofs_b, log2_b);
+      }
     }
   }
   TLP(2);
@@ -552,39 +541,7 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
      blocks: ~6 of its 512 luma vectors — and of those only what no intra block of this CTB produces itself (s_cover:
      those samples reach the same LDS tile when their block is predicted; they are also what the CTB writes to the
      picture at the end). ---- */
-  if (one_batch && comp && g == 0) {
-    /* one batch of records (in registers): a wave-uniform walk over the component's blocks, lane = CTB row (s_need), row of 4x4 units (s_cover),
-       32-entry word of the halo (s_hneed) — plain register arithmetic, where a lane per block pays an LDS atomic per row its block reads
-       (a 32x32 block: 64 of them in a row, 1.3 us between the residuals and the staging: profiles/r05_v22_intra_prologue_stamps.txt) */
-    uint32_t need = 0, cover = 0, hneed = 0;
-    const int nvr = cw >> 3;                                /* vectors per row */
-    unsigned long long bl = __ballot((int)((rf1 & 0xFFu) == (uint32_t)c));
-    while (bl) {
-      const int src = __ffsll(bl) - 1;
-      bl &= bl - 1;
-      const uint32_t w0 = __builtin_amdgcn_readlane(rf0, src), w1 = __builtin_amdgcn_readlane(rf1, src);
-      const int nT = 1 << ((w1 >> 8) & 0xFFu);
-      const int lx = (int)(w0 & 0xFFFFu) - x0c, ly = (int)(w0 >> 16) - y0c;
-      if (lane >= (ly >> 2) && lane < ((ly + nT) >> 2)) cover |= ((1u << (nT >> 2)) - 1u) << (lx >> 2);
-      if ((w1 >> 24) & M355_IBF_PCM) continue;               /* raw blocks read no border */
-      if (ly >= 1 && lane == ly - 1) {
-        const int v0 = max(lx - 1, 0) >> 3, v1 = min((lx + 2 * nT - 1) >> 3, nvr - 1);
-        if (v1 >= v0) need |= ((2u << v1) - 1u) & ~((1u << v0) - 1u);
-      }
-      if (lx >= 1 && lane >= max(ly, 0) && lane < min(ly + 2 * nT, ch)) need |= 1u << ((lx - 1) >> 3);
-      auto need_range = [&](int h0, int h1) {              /* halo entries h0 .. h1 inclusive: this lane's word of them */
-        if (lane < (h0 >> 5) || lane > (h1 >> 5)) return;
-        const int a = max(h0 - 32 * lane, 0), b = min(h1 - 32 * lane, 31);
-        hneed |= (b >= 31 ? ~0u : ((2u << b) - 1u)) & ~((1u << a) - 1u);
-      };
-      if (ly == 0) need_range(lx, min(lx + 2 * nT, 2 * cw));
-      if (lx == 0) need_range(2 * cw + 1 + max(ly - 1, 0), 2 * cw + 1 + min(ly + 2 * nT - 1, ch - 1));
-    }
-    if (lane < ch) s_need[cs][lane] = need;
-    if (lane < 8) s_hneed[cs][lane] = hneed;
-    if (lane < MAXCTB / 4) s_cover[cs][lane] = cover;
-    if (lane == 0) halo[HALO_N] = (uint16_t)(1u << (bd - 1));   /* the constant cell */
-  } else if (comp && g == 0) {
+  if (comp && g == 0) {
     for (int y = lane; y < ch; y += 64) s_need[cs][y] = 0;
     if (lane < 8) s_hneed[cs][lane] = 0;
     if (lane == 0) halo[HALO_N] = (uint16_t)(1u << (bd - 1));   /* the constant cell */
@@ -629,16 +586,7 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
       if (lx == 0) need_range(2 * cw + 1 + max(ly - 1, 0), 2 * cw + 1 + min(ly + 2 * nT - 1, ch - 1));
     }
   }
-  if (one_batch) {
-    uint32_t res_a = 0, res_b = 0;
-    rmine = __ballot((int)(comp && (rw1 & 0xFFu) == (uint32_t)c));
-    f_have_a = next_block(f_ofs_a, f_log2_a, res_a);
-    f_have_b = f_have_a && next_block(f_ofs_b, f_log2_b, res_b);
-    load_block(fa, f_log2_a, res_a, f_have_a);
-    load_block(fb, f_log2_b, res_b, f_have_b);
-  }
-  /* (a barrier that waits for this wave's LDS writes only — __syncthreads would wait for the loads in flight as well) */
-  if (multi) { d_drain_lds(); __builtin_amdgcn_s_barrier(); } else wave_sync();
+  SYNC_CTB();
   TLP(3);
   if (comp) {
     /* ---- halo: the row above the CTB (x = -1 .. 2cw-1) and the column left of it, only the entries some block's border reads
@@ -646,6 +594,7 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
        otherwise the entry stays HALO_NOT_READY and the block that needs it polls for it.  Everything else was finished by the preceding
        kernels (stream order) and is read from the picture.  Requested here, stored behind the body's first pass. ---- */
     if (!EARLY) { halo_where(); halo_who(); }
+    halo_is_intra();
     m355_granule hgr[HU];
     uint32_t hpl[HU];
     /* (scalars: the granule rows of the CTB row above / the CTB column on the left — a per-lane choice between DevPic's arrays would be a vector
@@ -655,18 +604,13 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
     for (int u = 0; u < HU; u++) {
       const int h = lane + 64 * g + u * 64 * G;
       const bool want = hin[u] && ((s_hneed[cs][min(h, nhalo - 1) >> 5] >> (h & 31)) & 1u);
-      hin[u] = want;
-      /* (BOTH loads of every wanted slot — the neighbour's granule and the picture's sample —, without a branch around them (a slot that wants
-         neither reads element 0; a conditional load is waited for inside its branch) and without a look at the CU records, which are still on
-         their way: eight loads in flight; which of the two counts is decided when they are stored) */
+      hintra[u] = hintra[u] && want;
+      /* (both loads of every slot, without a branch around them — a slot that wants neither reads element 0 —: eight loads in flight, where a
+         conditional load is waited for inside its branch) */
       const size_t gi = htop[u] ? g_row + (size_t)(hx[u] >> 1) : g_col + (size_t)(hy[u] >> 1);     /* (d_edge_row / d_edge_col) */
-      hgr[u] = __hip_atomic_load(p.edge + (want ? gi : (size_t)0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      hpl[u] = plane[want ? (size_t)hy[u] * stride + hx[u] : (size_t)0];
-    }
-    if (one_batch) {                                         /* (the residuals requested in front of the need scan) */
-      store_block(fa, f_ofs_a, f_log2_a, f_have_a);
-      store_block(fb, f_ofs_b, f_log2_b, f_have_b);
-      drain_batch();
+      hgr[u] = __hip_atomic_load(p.edge + (hintra[u] ? gi : (size_t)0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hpl[u] = plane[(want && !hintra[u]) ? (size_t)hy[u] * stride + hx[u] : (size_t)0];
+      if (!want || hintra[u]) hpl[u] = 0;
     }
     /* ---- stage the needed body vectors: 8 samples each; four per lane are requested before the first is stored (a loop of
        load -> store steps costs one memory round trip per step, and a CTB has up to eight steps per lane) ---- */
@@ -714,12 +658,11 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
       stage_pass(lane + 64 * g);
       for (int idx0 = lane + 64 * g + 64 * G * U; idx0 < nvec; idx0 += 64 * G * U) stage_pass(idx0);
     }
-    halo_is_intra();                                         /* (hin = wanted, by now) */
 #pragma unroll
     for (int u = 0; u < HU; u++) {
       const int h = lane + 64 * g + u * 64 * G;
       if (h >= nhalo) continue;
-      uint32_t val = hin[u] ? hpl[u] : 0u;
+      uint32_t val = hpl[u];
       if (hintra[u]) val = ((uint32_t)(hgr[u] >> 32) == epoch && !p.test_halo_late) ? (uint32_t)((hgr[u] >> (16 * ((htop[u] ? hx[u] : hy[u]) & 1))) & 0xFFFFu) : HALO_NOT_READY;
       if (htop[u]) halo[h] = (uint16_t)val; else halo[HALO_TOP_N + h - (2 * cw + 1)] = (uint16_t)val;
     }

@@ -214,21 +214,13 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
      and through the merged planes + job-list launch behind it — with 1) */
   static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
   const bool clear_in_count = d.n_pbs >= std::max(1, clear_min);
-  bool tu_forked = false;
   if (clear_in_count) m355_launch_job_count(d, true, st);
   if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
   /* transform edges and border plans in ONE launch (a packet less per picture: C3 0.098 -> 0.093 ms, profiles/r05_a_switches_merge.txt) */
   if (single && clear_in_count && (c->stages & M355_STAGE_INTRA)) {
     /* one stream: the planes' scatters and the job list are independent roles of ONE launch (k_meta_planes_jobs) */
     m355_launch_meta_planes_jobs(d, st);
-#ifdef M355_X_TU_FORK   /* experiment: the transform edges + border plans (read by k_intra and the deblocking filter only) beside k_inter / k_residual on the side stream */
-    hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-    m355_launch_tu_plan(d, c->stream2);
-    hipEventRecord(c->ev_join, c->stream2);
-    tu_forked = true;
-#else
     m355_launch_tu_plan(d, st);
-#endif
   } else {
     if (c->stages & M355_STAGE_INTRA) {
       m355_launch_meta_planes(d, s2, clear_in_count, false);
@@ -270,7 +262,6 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
     m355_launch_residual(d, hbd, true, st);
   }
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
-  if (tu_forked) hipStreamWaitEvent(st, c->ev_join, 0);
   if (ev) hipEventRecord(ev[3], st);
   if (with_intra && (c->stages & M355_STAGE_INTRA)) m355_launch_intra(d, hbd, st, clear_in_count);   /* (m355_decode_batch launches several pictures' intra stage as one kernel) */
   if (ev) hipEventRecord(ev[4], st);
