@@ -282,14 +282,13 @@ template <int CF> __global__ void __launch_bounds__(256) k_tu_plan(DevPic p, int
 #else
 #define M355_WAVES_PER_EU(n)      /* (the CPU tier's interpreter build) */
 #endif
-#ifndef M355_INTRA_DENSE_WAVES_PER_EU
-#define M355_INTRA_DENSE_WAVES_PER_EU 4    /* (the 12-wave kernel of intra pictures in flight / in batches) */
-#endif
+/* (the 12-wave kernel of intra pictures in flight at 96 / 80 registers — 5 / 6 waves per SIMD, i.e. two workgroups per CU at 80 —: C2 with three in flight
+   0.353 -> 0.351 / 0.388 ms, nine in flight 0.226 -> 0.224 / 0.210, batches of 8: 0.133 -> 0.131 / 0.136 (profiles/r05_v24_*): it stays at 4) */
 #ifndef M355_INTRA_SPARSE_WAVES_PER_EU
 #define M355_INTRA_SPARSE_WAVES_PER_EU 6   /* (the register budget of an inter picture's kernel at 4:2:0 / 4:0:0: 6 -> 80 registers and one spilled pair = 6 workgroups per CU, C5's intra stage 0.0467 -> 0.0424 ms, C3 / C4 unchanged: profiles/r05_v22_intra_w6_ab.txt; 4 -> 96 registers = 5 workgroups; 4:2:2 / 4:4:4 are bounded by their LDS) */
 #endif
 template <class PIX, int CF, int NW, bool DENSE, bool BATCH>
-__global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU(CF >= 2 ? 4 : (DENSE ? (NW == M355_INTRA_KEEPER_NW ? 4 : M355_INTRA_DENSE_WAVES_PER_EU) : M355_INTRA_SPARSE_WAVES_PER_EU)) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
+__global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) ? 4 : M355_INTRA_SPARSE_WAVES_PER_EU) k_intra(DevPic p0, int work_n, const DevPic* __restrict__ pics, int n_pics, uint32_t* batch_ticket)
 {
   if (!BATCH) M355_GATE(p0);
   constexpr int CW_C = IntraGeo<CF>::CW_C;
