@@ -196,7 +196,7 @@ void clear_target(m355_ctx* c, const DevPic& d, Frame* tgt, bool gated, hipStrea
   }
 }
 
-void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra) {
+void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra, hipStream_t chain) {
   hipStream_t st = c->stream;
   /* an intra picture keeps to its lane's main stream: its side work (metadata planes, border plans: 0.07 ms) is nothing beside k_intra,
      and half as many streams compete for the runtime's hardware queues when many such pictures are in flight (C2 0.340 ms per picture
@@ -232,6 +232,15 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
      reference — the list copy, validation, metadata planes and job list of a picture run beside the tail
      (filters) of the picture it references */
+  if (chain && chain != st) {
+    /* a picture of a dependent CHAIN (decode_pre: its newest reference is still being written, on `chain`): everything up to here — validation,
+       metadata planes, job list, plans: what does not read a reference — ran on the lane's own stream, beside the reference's last stages; from
+       here on the decode continues ON THE REFERENCE'S STREAM, where stream order stands for the wait.  The one cross-queue wait left is for this
+       decode's own front part, which is long over when the reference's filters are (a wait on a mark that has passed costs a packet; a wait the
+       queue really sleeps on cost a dependent 4K picture 25-40 us: profiles/r05_v25_*) */
+    EvRef front;
+    if (ev_mark(c, st, &front) == M355_OK) { c->stream = st = chain; ev_wait(c, st, front); }
+  }
   if (c->depth >= 2)
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
@@ -279,7 +288,7 @@ void dst_hazards(m355_ctx* c, Frame* dstf, bool piped) {
 /* One decode = decode_pre (lane, hazards, validation, every stage in front of the intra stage [and, with_intra, that stage]) +
  * decode_post (in-loop filters, events, status slot).  m355_decode_batch runs the pre part of several intra pictures on their lanes,
  * ONE k_intra launch for all of them, then their post parts. */
-struct DecodeState { DevPic d; bool want_sao = false; hipEvent_t* ev = nullptr; hipStream_t saved_stream = nullptr; bool swapped = false; };
+struct DecodeState { DevPic d; bool want_sao = false; hipEvent_t* ev = nullptr; hipStream_t saved_stream = nullptr; bool swapped = false; hipStream_t chain = nullptr; };
 
 /* front: PRE_ALL = everything up to and including the intra stage; PRE_NO_INTRA = without k_intra; PRE_HAZARDS = lane, hazards, validation and
    clearing only (m355_decode_batch launches the stages itself, one launch per stage for all its pictures) */
@@ -288,19 +297,25 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
 {
   const bool with_intra = mode == PRE_ALL;
   if (r.sharded) return fail(M355_ERR_INVALID, "a sharded picture is decoded by phases (m355_decode_phase)");
+  hipStream_t chain = nullptr;
   if (rotate && c->depth >= 2) {
-    /* consecutive pictures go round the lanes — EXCEPT a picture whose reference is still being written: it follows its (newest) reference onto
-       that lane, where stream order stands for the event wait.  A dependent chain (low-delay P / B: every picture references the one before) on
-       rotating lanes pays a cross-queue wait per picture that costs more than overlapping its metadata kernels with the reference's filters
-       gains — C3 0.187-0.200 ms per picture on three lanes against 0.159 on one, C5 0.455-0.476 against 0.437 (profiles/r05_v23_*: "chain") */
-    int lane = (c->active + 1) % c->depth;
+    /* consecutive pictures go round the lanes.  A picture whose (newest) reference is still being written is the next link of a dependent CHAIN
+       (low-delay P / B: every picture references the one before): its front part goes to a lane whose stream is NOT the reference's — it runs
+       beside the reference's last stages —, everything from k_inter on to the reference's stream (launch_prediction).  On rotating lanes alone
+       such a picture sleeps on a cross-queue event per picture: C3 0.182-0.200 ms per picture of a chain against 0.159 on one stream
+       (profiles/r05_v25_*) */
     unsigned long long newest = 0;
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
       if (!f || f->wr.ticket <= newest || ev_query(c, f->wr) == hipSuccess) continue;
-      for (int l = 0; l < c->depth; l++)
-        if ((l == c->active ? c->stream : c->lanes[l].stream) == f->wr.stream) { lane = l; newest = f->wr.ticket; break; }
+      newest = f->wr.ticket; chain = f->wr.stream;
     }
+    int lane = (c->active + 1) % c->depth;
+    if (chain)
+      for (int k = 0; k < c->depth; k++) {
+        const int l = (c->active + 1 + k) % c->depth;
+        if ((l == c->active ? c->stream : c->lanes[l].stream) != chain) { lane = l; break; }
+      }
     select_lane(c, lane);
   }
   /* which stream: an intra picture on lane 3.. takes the lane's class stream (lane_class_priority); the whole decode addresses
@@ -315,6 +330,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
     ev_wait(c, run, c->last);                              /* the lane's scratch and working planes (when its last decode ran on its other stream) */
     S.saved_stream = c->stream; S.swapped = run != c->stream;
     c->stream = run;
+    if (chain && chain != run && mode == PRE_ALL) { S.chain = chain; S.swapped = true; }   /* (launch_prediction moves the decode onto `chain`; decode_post restores) */
   }
   DevPic& d = S.d;
   int rc = prepare(c, r, d, S.want_sao);
@@ -342,7 +358,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
   if (!want_sao) dst_hazards(c, dstf, piped);
   if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, want_sao ? &c->work : dstf, r.device_validate && !want_sao, st);
   if (!with_intra) d.intra_keeper = 0;                     /* (a batch's shared intra stage is the 12-wave kernel: it needs the planner's launch) */
-  if (mode != PRE_HAZARDS) launch_prediction(c, r, d, hbd, ev, with_intra);
+  if (mode != PRE_HAZARDS) launch_prediction(c, r, d, hbd, ev, with_intra, S.chain);
   return M355_OK;
 }
 
