@@ -196,7 +196,7 @@ void clear_target(m355_ctx* c, const DevPic& d, Frame* tgt, bool gated, hipStrea
   }
 }
 
-void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra, hipStream_t chain) {
+void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra, hipStream_t chain, Frame* hazard_dst) {
   hipStream_t st = c->stream;
   /* an intra picture keeps to its lane's main stream: its side work (metadata planes, border plans: 0.07 ms) is nothing beside k_intra,
      and half as many streams compete for the runtime's hardware queues when many such pictures are in flight (C2 0.340 ms per picture
@@ -241,6 +241,9 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
     EvRef front;
     if (ev_mark(c, st, &front) == M355_OK) { c->stream = st = chain; ev_wait(c, st, front); }
   }
+  /* (a picture without SAO writes its destination from here on: its readers / last writer are waited for HERE, not in front of the metadata kernels —
+     the destination of a chain's picture is often a frame the picture before it still reads) */
+  if (hazard_dst) dst_hazards(c, hazard_dst, true);
   if (c->depth >= 2)
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
@@ -355,10 +358,13 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
   }
   S.ev = ev;
   if (r.device_validate) m355_launch_validate(d, st);     /* a rejection gates THIS decode's kernels (epoch-tagged gate word) */
-  if (!want_sao) dst_hazards(c, dstf, piped);
+  /* write-after-read / -write on the destination of a picture without SAO: in front of its first writer — the clearing fill if there is one, else
+     k_inter (launch_prediction, behind a chain picture's change of stream) */
+  const bool hazards_late = !want_sao && piped && mode != PRE_HAZARDS && !(pp.flags & M355_PF_CLEAR_DST);
+  if (!want_sao && !hazards_late) dst_hazards(c, dstf, piped);
   if (pp.flags & M355_PF_CLEAR_DST) clear_target(c, d, want_sao ? &c->work : dstf, r.device_validate && !want_sao, st);
   if (!with_intra) d.intra_keeper = 0;                     /* (a batch's shared intra stage is the 12-wave kernel: it needs the planner's launch) */
-  if (mode != PRE_HAZARDS) launch_prediction(c, r, d, hbd, ev, with_intra, S.chain);
+  if (mode != PRE_HAZARDS) launch_prediction(c, r, d, hbd, ev, with_intra, S.chain, hazards_late ? dstf : nullptr);
   return M355_OK;
 }
 

@@ -298,7 +298,7 @@ Frame* get_frame(m355_ctx* c, int h);
 void halo_layout(const m355_pic_params& pp, HaloLayout& h);
 int lane_class_priority(int index);
 int lane_priorities_mode();
-void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra = true, hipStream_t chain = nullptr);
+void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra = true, hipStream_t chain = nullptr, Frame* hazard_dst = nullptr);
 void make_layout(const m355_arena_caps& k, int nCtb, int halo_units, bool sharded, bool with_ib_input, Lay& L);
 int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out);
 void select_lane(m355_ctx* c, int lane);
