@@ -305,8 +305,9 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
     /* consecutive pictures go round the lanes.  A picture whose (newest) reference is still being written is the next link of a dependent CHAIN
        (low-delay P / B: every picture references the one before): its front part goes to a lane whose stream is NOT the reference's — it runs
        beside the reference's last stages —, everything from k_inter on to the reference's stream (launch_prediction).  On rotating lanes alone
-       such a picture sleeps on a cross-queue event per picture: C3 0.182-0.200 ms per picture of a chain against 0.159 on one stream
-       (profiles/r05_v25_*) */
+       such a picture sleeps on a cross-queue event per picture: C3 0.182-0.200 ms per picture of a chain, 0.160 with the whole picture on its
+       reference's lane, 0.139 with the front part beside the reference's tail; C4 0.184 / 0.180 / 0.155; C5 0.456-0.466 / 0.438 / 0.439 — an 8K picture's
+       kernels fill the GPU, nothing runs beside them for free (profiles/r05_v25_*, r05_v27_*) */
     unsigned long long newest = 0;
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
@@ -314,11 +315,16 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
       newest = f->wr.ticket; chain = f->wr.stream;
     }
     int lane = (c->active + 1) % c->depth;
-    if (chain)
+    if (chain) {
+      /* three lanes and more: the front part alternates between the lanes that are not the chain's (two scratch sets: the one a picture's back part
+         still uses and the one the next front part fills); two lanes: the whole picture on the chain's own lane — with one lane to spare the front
+         part would wait for the scratch of the picture before it and bring the cross-queue waits back (C3 0.162 -> 0.178 ms, profiles/r05_v27_*) */
+      const bool split = c->depth >= 3;
       for (int k = 0; k < c->depth; k++) {
         const int l = (c->active + 1 + k) % c->depth;
-        if ((l == c->active ? c->stream : c->lanes[l].stream) != chain) { lane = l; break; }
+        if (((l == c->active ? c->stream : c->lanes[l].stream) != chain) == split) { lane = l; break; }
       }
+    }
     select_lane(c, lane);
   }
   /* which stream: an intra picture on lane 3.. takes the lane's class stream (lane_class_priority); the whole decode addresses
