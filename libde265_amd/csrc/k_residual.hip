@@ -375,10 +375,9 @@ __device__ __forceinline__ void d_residual_group(const DevPic& p, const m355_rb*
 /* blocks per workgroup: RES_WPG waves * 64/nT */
 __host__ __device__ static inline int res_groups(int n, int per_wave) { return (n + per_wave * RES_WPG - 1) / (per_wave * RES_WPG); }
 template <class PIX, bool BIG>
-__device__ __forceinline__ void k_residual_body(const DevPic& p, int ng_hi, uint32_t* s_buf)
+__device__ __forceinline__ void k_residual_body(const DevPic& p, int ng_hi, uint32_t* s_buf, const int g = (int)blockIdx.x)
 {
   M355_GATE(p);
-  const int g = (int)blockIdx.x;
   if (BIG) {
     if (g < ng_hi) d_residual_group<5, PIX>(p, p.rb_bin[3], p.rb_count[3], g, s_buf);
     else d_residual_group<4, PIX>(p, p.rb_bin[2], p.rb_count[2], g - ng_hi, s_buf);
@@ -393,6 +392,17 @@ __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_
 {
   __shared__ __attribute__((aligned(16))) uint32_t s_buf[BIG ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
   k_residual_body<PIX, BIG>(p, ng_hi, s_buf);
+}
+/* BOTH launches as roles of one: workgroups [0, n_big) take the 32x32 + 16x16 groups, the rest the 8x8 + 4x4 groups.  For pictures on a one-stream lane
+   (up to 4K: runtime_decode.hip launch_prediction), where the two launches stand one behind the other and neither fills the GPU — the occupancy the
+   separate small-block kernel buys (66 registers) is not what a 4K picture's 13 us launch waits for */
+template <class PIX>
+__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_both(DevPic p, int n_big, int ng_hi_big, int ng_hi_small)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[RES_LDS_DWORDS > RES_LDS_DWORDS_SMALL ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
+  const int g = (int)blockIdx.x;
+  if (g < n_big) k_residual_body<PIX, true>(p, ng_hi_big, s_buf, g);
+  else k_residual_body<PIX, false>(p, ng_hi_small, s_buf, g - n_big);
 }
 /* batch form (intra pictures) */
 template <class PIX, bool BIG>
@@ -424,6 +434,15 @@ static void launch_res(const DevPic& p, int n, int ng_hi, hipStream_t st)
 {
   const dim3 blk(64 * RES_WPG);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual<PIX, BIG>), dim3(n), blk, 0, st, p, ng_hi);
+}
+
+void m355_launch_residual_both(const DevPic& p, bool hbd, hipStream_t st)
+{
+  const int ng2 = res_groups(p.rb_count[0], 16), ng3 = res_groups(p.rb_count[1], 8), ng4 = res_groups(p.rb_count[2], 4), ng5 = res_groups(p.rb_count[3], 2);
+  const int n = ng5 + ng4 + ng3 + ng2;
+  if (!n) return;
+  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_both<uint16_t>), dim3(n), dim3(64 * RES_WPG), 0, st, p, ng5 + ng4, ng5, ng3);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_both<uint8_t>), dim3(n), dim3(64 * RES_WPG), 0, st, p, ng5 + ng4, ng5, ng3);
 }
 
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)

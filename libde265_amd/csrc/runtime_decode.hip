@@ -270,8 +270,11 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
        pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
     hipStream_t sr = !single ? s2 : st;
     if (sr != st) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }
-    m355_launch_residual(d, hbd, false, sr);
-    m355_launch_residual(d, hbd, true, st);
+    if (sr == st) m355_launch_residual_both(d, hbd, st);       /* (one stream: one launch, k_residual.hip) */
+    else {
+      m355_launch_residual(d, hbd, false, sr);
+      m355_launch_residual(d, hbd, true, st);
+    }
   }
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
   if (ev) hipEventRecord(ev[3], st);

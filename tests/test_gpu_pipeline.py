@@ -174,7 +174,7 @@ def test_intra_and_inter_pictures_alternate_on_deep_pipelines(oracle, depth):
         ctx.close()
 
 
-def long_chain(lib, oracle, cfg, depth, n_decodes):
+def long_chain(lib, oracle, cfg, depth, n_decodes, n_pool=4):
     """More decodes than the context's ring of completion marks holds (runtime.hip EvRef: 256), none of them waited for by the host:
     every picture references the output of the one before it (read-after-write across lanes), four destination frames go round
     (write-after-read / write-after-write against marks that have long been taken over), six lists go round their handles."""
@@ -182,24 +182,24 @@ def long_chain(lib, oracle, cfg, depth, n_decodes):
     pics, ref0 = chain_case(6, **cfg)
     pp = pics[0].pp[0]
     of0 = o.frame_new(pp); o.frame_set_planes(of0, ref0)
-    opool = [o.frame_new(pp) for _ in range(4)]
+    opool = [o.frame_new(pp) for _ in range(n_pool)]
     oprev = of0
     for k in range(n_decodes):
         pic = pics[k % 6]
         pic.ref_frames = [0, 1] + [-1] * (worklist.MAX_REF_FRAMES - 2)
-        assert o.decode(pic, opool[k % 4], {0: of0, 1: oprev}) == 0
-        oprev = opool[k % 4]
+        assert o.decode(pic, opool[k % n_pool], {0: of0, 1: oprev}) == 0
+        oprev = opool[k % n_pool]
     want = [o.frame_planes(f) for f in opool]
     ctx = capi.Context(lib, 0)
     try:
         ctx.set_pipeline_depth(depth)
         g0 = ctx.frame_create_for(pp); ctx.frame_upload(g0, ref0)
-        pool = [ctx.frame_create_for(pp) for _ in range(4)]
+        pool = [ctx.frame_create_for(pp) for _ in range(n_pool)]
         handles = [None] * 6
         prev = g0
         for k in range(n_decodes):
             pic = pics[k % 6]
-            pic.dst_frame = pool[k % 4]
+            pic.dst_frame = pool[k % n_pool]
             pic.ref_frames = [g0, prev] + [-1] * (worklist.MAX_REF_FRAMES - 2)
             # the lists go back into their handle with the new frames (m355_picture_replace waits for that handle's last decode only)
             if handles[k % 6] is None:
@@ -211,7 +211,7 @@ def long_chain(lib, oracle, cfg, depth, n_decodes):
             ctx.decode_resident(handles[k % 6])
             prev = pic.dst_frame
         ctx.wait()
-        for k in range(4):
+        for k in range(n_pool):
             assert_planes_equal(ctx.frame_download(pool[k]), want[k], "frame %d after %d decodes" % (k, n_decodes))
     finally:
         ctx.close()
@@ -220,3 +220,13 @@ def long_chain(lib, oracle, cfg, depth, n_decodes):
 @pytest.mark.parametrize("depth", [3, 4])
 def test_long_unsynchronised_chain(oracle, depth):
     long_chain(capi.Library(), oracle, dict(width=416, height=240, bit_depth=8, seed=211, n_refs=2), depth, 700)
+
+
+@pytest.mark.parametrize("sao", [0, 1])
+@pytest.mark.parametrize("depth", [2, 3, 5])
+def test_chain_whose_destination_the_previous_picture_still_reads(oracle, depth, sao):
+    """Two destination frames go round: picture k writes the frame picture k - 1 reads as its reference (write-after-read at distance 1) and
+    reads the one picture k - 1 writes.  A chain picture's front part runs on a lane of its own beside its reference's last stages and its
+    back part on the reference's stream (runtime_decode.hip); without SAO the destination's hazards are waited for in front of k_inter, behind
+    that change of stream."""
+    long_chain(capi.Library(), oracle, dict(width=640, height=368, bit_depth=8, seed=213 + sao, n_refs=2, sao=sao), depth, 300, n_pool=2)
