@@ -307,6 +307,7 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_inter_tables(bool bytes, int bd_luma, int bd_chroma, uint32_t* out);   /* host: the tables behind DevPic.inter_tabs (M355_INTER_TAB_WORDS words) */
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_residual_both(const DevPic& p, bool hbd, hipStream_t st);      /* both size classes as roles of one launch (one-stream lanes) */
+void m355_launch_residual_tu_plan(const DevPic& p, bool hbd, hipStream_t st);   /* ... with the transform edges and the border plans (m355_launch_tu_plan's work) */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st, bool ticket_zero = false);
 void m355_launch_meta_planes_batch(const HostBatch& b, hipStream_t st);              /* the batch forms: pictures of one sample type and chroma format */

@@ -25,6 +25,8 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "k_common.h"
+#include "k_meta_tu.h"
+#include "k_intra_plan.h"
 
 
 /* ---- compile-time tables: M[k][n] = c(k(2n+1)), c = quarter wave of the HEVC core transform
@@ -404,6 +406,20 @@ __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_
   if (g < n_big) k_residual_body<PIX, true>(p, ng_hi_big, s_buf, g);
   else k_residual_body<PIX, false>(p, ng_hi_small, s_buf, g - n_big);
 }
+/* ... and with them the transform-edge scatter (k_meta_tu.h) and the border plans (k_intra_plan.h), which only k_intra and the deblocking filter read: workgroups
+   [n_res, n_res + nb_tu) walk the transform leaves (64 per workgroup), the rest plan work item r / n_parts, part r % n_parts (one wave each).  On a one-stream
+   lane they stood as a launch of their own (k_tu_plan) in front of k_inter: 14 us of a 4K picture's 176 */
+template <class PIX, int CF>
+__global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_tu_plan(DevPic p, int n_res, int n_big, int ng_hi_big, int ng_hi_small, int nb_tu, int work_n, int n_parts)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[RES_LDS_DWORDS > RES_LDS_DWORDS_SMALL ? RES_LDS_DWORDS : RES_LDS_DWORDS_SMALL];
+  const int g = (int)blockIdx.x;
+  if (g < n_big) { k_residual_body<PIX, true>(p, ng_hi_big, s_buf, g); return; }
+  if (g < n_res) { k_residual_body<PIX, false>(p, ng_hi_small, s_buf, g - n_big); return; }
+  const int q = g - n_res;
+  if (q < nb_tu) { k_meta_tu_body(p, q); return; }
+  k_intra_plan_body<CF>(p, work_n, (q - nb_tu) / n_parts, (q - nb_tu) % n_parts, n_parts);
+}
 /* batch form (intra pictures) */
 template <class PIX, bool BIG>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_batch(DevBatch b)
@@ -443,6 +459,30 @@ void m355_launch_residual_both(const DevPic& p, bool hbd, hipStream_t st)
   if (!n) return;
   if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_both<uint16_t>), dim3(n), dim3(64 * RES_WPG), 0, st, p, ng5 + ng4, ng5, ng3);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_both<uint8_t>), dim3(n), dim3(64 * RES_WPG), 0, st, p, ng5 + ng4, ng5, ng3);
+}
+
+template <class PIX>
+static void launch_res_tu_plan(const DevPic& p, int n_res, int n_big, int ng5, int ng3, int nb_tu, int n_plan, int n_parts, hipStream_t st)
+{
+  const dim3 grid(n_res + nb_tu + n_plan * n_parts), blk(64 * RES_WPG);
+  switch (p.pp.chroma_format_idc) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_tu_plan<PIX, 0>), grid, blk, 0, st, p, n_res, n_big, ng5, ng3, nb_tu, n_plan, n_parts); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_tu_plan<PIX, 1>), grid, blk, 0, st, p, n_res, n_big, ng5, ng3, nb_tu, n_plan, n_parts); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_tu_plan<PIX, 2>), grid, blk, 0, st, p, n_res, n_big, ng5, ng3, nb_tu, n_plan, n_parts); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_tu_plan<PIX, 3>), grid, blk, 0, st, p, n_res, n_big, ng5, ng3, nb_tu, n_plan, n_parts); break;
+  }
+}
+/* residuals (both size classes) + transform edges + border plans: the work m355_launch_residual_both and m355_launch_tu_plan (k_intra.hip) do, as one launch */
+void m355_launch_residual_tu_plan(const DevPic& p, bool hbd, hipStream_t st)
+{
+  const int ng2 = res_groups(p.rb_count[0], 16), ng3 = res_groups(p.rb_count[1], 8), ng4 = res_groups(p.rb_count[2], 4), ng5 = res_groups(p.rb_count[3], 2);
+  const int n_res = ng5 + ng4 + ng3 + ng2;
+  /* (one intra picture at a time: its CTBs are planned by k_intra itself; an intra picture's CTB is planned by PLAN_SPLIT x 4 waves, an inter picture's by 4) */
+  const int n_plan = (p.intra_dense && p.intra_keeper) ? 0 : p.n_intra_work, n_parts = 4 * (p.intra_dense ? PLAN_SPLIT : 1);
+  const int nb_tu = (p.n_tus + 64 * RES_WPG - 1) / (64 * RES_WPG);
+  if (!(n_res + nb_tu + n_plan)) return;
+  if (hbd) launch_res_tu_plan<uint16_t>(p, n_res, ng5 + ng4, ng5, ng3, nb_tu, n_plan, n_parts, st);
+  else launch_res_tu_plan<uint8_t>(p, n_res, ng5 + ng4, ng5, ng3, nb_tu, n_plan, n_parts, st);
 }
 
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st)

@@ -214,13 +214,15 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
      and through the merged planes + job-list launch behind it — with 1) */
   static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
   const bool clear_in_count = d.n_pbs >= std::max(1, clear_min);
+  bool tu_plan_with_residuals = false;
   if (clear_in_count) m355_launch_job_count(d, true, st);
   if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
   /* transform edges and border plans in ONE launch (a packet less per picture: C3 0.098 -> 0.093 ms, profiles/r05_a_switches_merge.txt) */
   if (single && clear_in_count && (c->stages & M355_STAGE_INTRA)) {
     /* one stream: the planes' scatters and the job list are independent roles of ONE launch (k_meta_planes_jobs) */
     m355_launch_meta_planes_jobs(d, st);
-    m355_launch_tu_plan(d, st);
+    /* (the transform edges + border plans — read by k_intra and the deblocking filter only — ride in the residual launch behind k_inter when there is one) */
+    if (c->stages & M355_STAGE_RESIDUAL) tu_plan_with_residuals = true; else m355_launch_tu_plan(d, st);
   } else {
     if (c->stages & M355_STAGE_INTRA) {
       m355_launch_meta_planes(d, s2, clear_in_count, false);
@@ -270,7 +272,8 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
        pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
     hipStream_t sr = !single ? s2 : st;
     if (sr != st) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }
-    if (sr == st) m355_launch_residual_both(d, hbd, st);       /* (one stream: one launch, k_residual.hip) */
+    if (tu_plan_with_residuals) m355_launch_residual_tu_plan(d, hbd, st);
+    else if (sr == st) m355_launch_residual_both(d, hbd, st);       /* (one stream: one launch, k_residual.hip) */
     else {
       m355_launch_residual(d, hbd, false, sr);
       m355_launch_residual(d, hbd, true, st);
