@@ -221,8 +221,11 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
   if (single && clear_in_count && (c->stages & M355_STAGE_INTRA)) {
     /* one stream: the planes' scatters and the job list are independent roles of ONE launch (k_meta_planes_jobs) */
     m355_launch_meta_planes_jobs(d, st);
-    /* (the transform edges + border plans — read by k_intra and the deblocking filter only — ride in the residual launch behind k_inter when there is one) */
-    if (c->stages & M355_STAGE_RESIDUAL) tu_plan_with_residuals = true; else m355_launch_tu_plan(d, st);
+    /* (the transform edges + border plans — read by k_intra and the deblocking filter only — ride in the residual launch behind k_inter when the context
+       decodes one picture at a time: C3 0.1494 -> 0.1427 ms, C4 0.1627 -> 0.1564.  With lanes they stay a launch of their own in FRONT of k_inter, where
+       other pictures' kernels — or, for a chain's picture, its reference's last stages — run beside them: merged, C3 0.0688 -> 0.0697 ms with three in
+       flight and a chain's picture 0.132 -> 0.136, C4 0.147 -> 0.156: profiles/r05_v30_*) */
+    if (c->depth == 1 && (c->stages & M355_STAGE_RESIDUAL)) tu_plan_with_residuals = true; else m355_launch_tu_plan(d, st);
   } else {
     if (c->stages & M355_STAGE_INTRA) {
       m355_launch_meta_planes(d, s2, clear_in_count, false);
