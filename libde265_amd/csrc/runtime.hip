@@ -653,7 +653,7 @@ int m355_timing_reset(m355_ctx* c) { c->ev_used = 0; c->timing_on = true; return
 int m355_timing_collect(m355_ctx* c, int* n_decodes, float* total_ms, float stage_ms[6])
 {
   c->timing_on = false;
-  if (c->ev_used == 0) return fail(M355_ERR_INVALID, "nothing decoded since the last timing reset");
+  if (c->ev_used == 0) return fail(M355_ERR_INVALID, "m355_timing_collect: no decode was timed — m355_timing_reset opens the timing window, this call (or an earlier one) closes it, and the pictures of m355_decode_batch are never stage-timed");
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
   double tot = 0, st[6] = {0, 0, 0, 0, 0, 0};
