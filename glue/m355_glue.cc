@@ -1485,7 +1485,10 @@ LIBDE265_API de265_decoder_context* de265_new_decoder()
       }
     }
   }
-  int depth = 2;
+  /* three lanes: the depth every measurement of the backend favours (independent 4K pictures 0.096 ms with two lanes, 0.070 with three, more do not help:
+     the runtime's streams share four hardware queues) and the one from which a dependent chain's picture can run its front part beside its reference's tail
+      */
+  int depth = 3;
   if (const char* e = getenv("M355_PIPELINE_DEPTH")) depth = atoi(e);
   if (depth >= 1 && depth <= 16) for (m355_ctx* x : g->rctx) A->m355_set_pipeline_depth(x, g->n_ranks > 1 ? std::min(depth, 3) : depth);
   g->sync_submit = getenv("M355_GLUE_SYNC") != nullptr;
