@@ -155,6 +155,11 @@ struct DevPic {
   uint8_t* edge_pb;                 /* per 4x4: bit2 PB edge V, bit3 PB edge H */
   uint32_t* pb_of;                  /* per 4x4: PB index + 1 */
   int16_t* resbuf;
+  /* a dependent chain's picture (runtime_decode.hip): k_residual runs in the picture's FRONT part, beside the reference's last stages, and leaves the residuals of
+     the blocks it would add to the prediction as int16 tiles — block i of size bin s at res_tiles + res_tile_base[s] + i * nT^2 —; k_residual_add adds them behind k_inter */
+  int16_t* res_tiles;
+  uint32_t res_tile_base[4];
+  int res_front;                    /* 1: this launch of k_residual stores tiles instead of adding */
   uint16_t* sao_nb;                 /* [component][CTB]: bit (dy+1)*3+(dx+1) set = SAO edge neighbours in that CTB are not usable; bit 15 = the CTB's slice has SAO on for the component (k_meta_sao) */
   uint32_t* jobs;                   /* inter jobs: pb index | strip << 25 | row block << 29 (k_meta_pb) */
   uint32_t* job_base;               /* [256-PB chunk][4]: the chunk's jobs per range (uni, bi, weighted, edge): k_job_count leaves the counts here, every
@@ -307,6 +312,7 @@ void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st);
 void m355_inter_tables(bool bytes, int bd_luma, int bd_chroma, uint32_t* out);   /* host: the tables behind DevPic.inter_tabs (M355_INTER_TAB_WORDS words) */
 void m355_launch_residual(const DevPic& p, bool hbd, bool big, hipStream_t st);   /* big: 32x32 + 16x16 blocks, else 8x8 + 4x4 */
 void m355_launch_residual_both(const DevPic& p, bool hbd, hipStream_t st);      /* both size classes as roles of one launch (one-stream lanes) */
+void m355_launch_residual_add(const DevPic& p, bool hbd, hipStream_t st);       /* the tiles a res_front launch left, added to the prediction */
 void m355_launch_residual_tu_plan(const DevPic& p, bool hbd, hipStream_t st);   /* ... with the transform edges and the border plans (m355_launch_tu_plan's work) */
 void m355_launch_intra_plan(const DevPic& p, hipStream_t st);   /* border plans of the intra blocks (k_intra.hip): before m355_launch_intra */
 void m355_launch_intra(const DevPic& p, bool hbd, hipStream_t st, bool ticket_zero = false);

@@ -283,6 +283,35 @@ __device__ __forceinline__ void d_res_issue(const DevPic& p, const m355_rb& rb, 
   }
 }
 
+/* a row of residuals added to the lane's destination row (w: read earlier) and written back: NT samples as 16-byte (NT >= 8) or 8-byte vectors — blocks are
+   aligned to their size, so the row segment is too */
+template <int LOG2, class PIX>
+__device__ __forceinline__ void d_res_add_row(M355_GLOBAL PIX* d, uint32_t* w, const int* res, const int bd)
+{
+  constexpr int NT = 1 << LOG2;
+  if (sizeof(PIX) == 2) {
+    constexpr int NV = NT / 2;                 /* dwords per row */
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+      w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFFFu) + res[2 * i], bd) | ((uint32_t)d_clip_bd((int)(w[i] >> 16) + res[2 * i + 1], bd) << 16);
+    if (NT >= 8) {
+#pragma unroll
+      for (int i = 0; i < NV; i += 4) d_stg16(d + 2 * i, w + i);
+    } else d_stg8(d, w);
+  } else {
+    constexpr int NV = NT / 4;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+      w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFu) + res[4 * i], bd) | ((uint32_t)d_clip_bd((int)((w[i] >> 8) & 0xFFu) + res[4 * i + 1], bd) << 8) |
+             ((uint32_t)d_clip_bd((int)((w[i] >> 16) & 0xFFu) + res[4 * i + 2], bd) << 16) | ((uint32_t)d_clip_bd((int)(w[i] >> 24) + res[4 * i + 3], bd) << 24);
+    if (NT >= 16) {
+#pragma unroll
+      for (int i = 0; i < NV; i += 4) d_stg16(d + 4 * i, w + i);
+    } else if (NT == 8) d_stg8(d, w);
+    else d_stg4(d, w[0]);
+  }
+}
+
 template <int LOG2, class PIX, bool PRE>
 __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs, const m355_rb& rb, bool active, int c, int tbi, uint32_t* cfp, uint32_t* w, const uint32_t* eb)
 {
@@ -320,35 +349,12 @@ __device__ __forceinline__ void d_res_finish(const DevPic& p, const m355_rb* rbs
 
   if (!active) return;
   const int y = c;
-  if (rb.flags & M355_RBF_DEFERRED) {
-    int16_t* out = p.resbuf + rb.res_ofs + y * NT;
+  if ((rb.flags & M355_RBF_DEFERRED) || p.res_front) {
+    /* (a chain picture's front launch: the block's tile — found by size bin and index, no offset table — instead of the add) */
+    int16_t* out = (rb.flags & M355_RBF_DEFERRED) ? p.resbuf + rb.res_ofs + y * NT : p.res_tiles + p.res_tile_base[LOG2 - 2] + (size_t)tbi * (NT * NT) + y * NT;
 #pragma unroll
     for (int i = 0; i < NT; i += 2) *(uint32_t*)(out + i) = res_pack(d_clip3(-32768, 32767, res[i]), d_clip3(-32768, 32767, res[i + 1]));
-  } else {
-    /* add to the lane's row (read above) and write it back: NT samples as 16-byte (NT >= 8) or 8-byte vectors — blocks are
-       aligned to their size, so the row segment is too */
-    if (sizeof(PIX) == 2) {
-      constexpr int NV = NT / 2;                 /* dwords per row */
-#pragma unroll
-      for (int i = 0; i < NV; i++)
-        w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFFFu) + res[2 * i], bd) | ((uint32_t)d_clip_bd((int)(w[i] >> 16) + res[2 * i + 1], bd) << 16);
-      if (NT >= 8) {
-#pragma unroll
-        for (int i = 0; i < NV; i += 4) d_stg16(d + 2 * i, w + i);
-      } else d_stg8(d, w);
-    } else {
-      constexpr int NV = NT / 4;
-#pragma unroll
-      for (int i = 0; i < NV; i++)
-        w[i] = (uint32_t)d_clip_bd((int)(w[i] & 0xFFu) + res[4 * i], bd) | ((uint32_t)d_clip_bd((int)((w[i] >> 8) & 0xFFu) + res[4 * i + 1], bd) << 8) |
-               ((uint32_t)d_clip_bd((int)((w[i] >> 16) & 0xFFu) + res[4 * i + 2], bd) << 16) | ((uint32_t)d_clip_bd((int)(w[i] >> 24) + res[4 * i + 3], bd) << 24);
-      if (NT >= 16) {
-#pragma unroll
-        for (int i = 0; i < NV; i += 4) d_stg16(d + 4 * i, w + i);
-      } else if (NT == 8) d_stg8(d, w);
-      else d_stg4(d, w[0]);
-    }
-  }
+  } else d_res_add_row<LOG2, PIX>(d, w, res, bd);
 }
 
 template <int LOG2, class PIX>
@@ -420,6 +426,60 @@ __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_
   if (q < nb_tu) { k_meta_tu_body(p, q); return; }
   k_intra_plan_body<CF>(p, work_n, (q - nb_tu) / n_parts, (q - nb_tu) % n_parts, n_parts);
 }
+/* k_residual_add: the tiles a res_front launch stored, added to the prediction samples (the add of d_res_finish, with the transform already done): one lane per
+   block row, 64 / nT blocks per wave, every size bin a range of the grid, largest first.  One round trip for the record, one for the tile row and the destination row. */
+template <int LOG2, class PIX>
+__device__ __forceinline__ void d_residual_add_group(const DevPic& p, const m355_rb* rbs, int rb_n, int group)
+{
+  constexpr int NT = 1 << LOG2, BPW = 64 / NT;
+  const int lane = threadIdx.x & 63, c = lane & (NT - 1), tbi = group * BPW + (lane >> LOG2);
+  if (tbi >= rb_n) return;
+  const m355_rb rb = rbs[tbi];
+  if (rb.flags & M355_RBF_DEFERRED) return;                  /* (a block of an intra CU: k_intra adds its residual) */
+  const int bd = rb.cidx ? p.pp.bit_depth_chroma : p.pp.bit_depth_luma;
+  M355_GLOBAL PIX* d = (M355_GLOBAL PIX*)M355_SEL3(p.plane, rb.cidx) + (size_t)(rb.y + c) * M355_SEL3(p.stride, rb.cidx) + rb.x;
+  const int16_t* t = p.res_tiles + p.res_tile_base[LOG2 - 2] + (size_t)tbi * (NT * NT) + c * NT;
+  uint32_t rr[NT / 2], w[ResGeom<LOG2, PIX>::NVP];
+  /* the tile row (2 NT bytes) and the destination row, both requested before either is used */
+  if (NT >= 8) {
+#pragma unroll
+    for (int i = 0; i < NT / 2; i += 4) d_ldg16((const M355_GLOBAL int16_t*)t + 2 * i, rr + i);
+  } else d_ldg8((const M355_GLOBAL int16_t*)t, rr);
+  if (sizeof(PIX) == 2) {
+    if (NT >= 8) {
+#pragma unroll
+      for (int i = 0; i < NT / 2; i += 4) d_ldg16(d + 2 * i, w + i);
+    } else d_ldg8(d, w);
+  } else {
+    if (NT >= 16) {
+#pragma unroll
+      for (int i = 0; i < NT / 4; i += 4) d_ldg16(d + 4 * i, w + i);
+    } else if (NT == 8) d_ldg8(d, w);
+    else w[0] = d_ldg4(d);
+  }
+  int res[NT];
+#pragma unroll
+  for (int i = 0; i < NT; i++) res[i] = (int)(int16_t)(rr[i >> 1] >> (16 * (i & 1)));
+  d_res_add_row<LOG2, PIX>(d, w, res, bd);
+}
+template <class PIX>
+__global__ void __launch_bounds__(64) k_residual_add(DevPic p, int n5, int n4, int n3)
+{
+  M355_GATE(p);
+  const int g = (int)blockIdx.x;
+  if (g < n5) d_residual_add_group<5, PIX>(p, p.rb_bin[3], p.rb_count[3], g);
+  else if (g < n5 + n4) d_residual_add_group<4, PIX>(p, p.rb_bin[2], p.rb_count[2], g - n5);
+  else if (g < n5 + n4 + n3) d_residual_add_group<3, PIX>(p, p.rb_bin[1], p.rb_count[1], g - n5 - n4);
+  else d_residual_add_group<2, PIX>(p, p.rb_bin[0], p.rb_count[0], g - n5 - n4 - n3);
+}
+void m355_launch_residual_add(const DevPic& p, bool hbd, hipStream_t st)
+{
+  const int n5 = (p.rb_count[3] + 1) / 2, n4 = (p.rb_count[2] + 3) / 4, n3 = (p.rb_count[1] + 7) / 8, n2 = (p.rb_count[0] + 15) / 16;
+  if (!(n5 + n4 + n3 + n2)) return;
+  if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_add<uint16_t>), dim3(n5 + n4 + n3 + n2), dim3(64), 0, st, p, n5, n4, n3);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_residual_add<uint8_t>), dim3(n5 + n4 + n3 + n2), dim3(64), 0, st, p, n5, n4, n3);
+}
+
 /* batch form (intra pictures) */
 template <class PIX, bool BIG>
 __global__ void __launch_bounds__(64 * RES_WPG) __attribute__((amdgpu_waves_per_eu(4))) k_residual_batch(DevBatch b)

@@ -8,6 +8,8 @@ extern "C" {
 /* ----------------------------------------------------------------------- decode --------------- */
 
 /* frames, scratch and the device descriptor of one decode of `r` */
+bool chain_residuals_forced();
+
 int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
   hipSetDevice(c->device);
   const m355_picture& pic = r.hdr;
@@ -96,8 +98,16 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
      tiles — round 4's "fused" order, the default with one picture in flight then — saves 80 MB per 8K picture and was measured again with
      round 5's lean k_inter_jobs: it loses at every depth, C5 0.362-0.368 against 0.346-0.356 ms with three pictures in flight, 0.486-0.494
      against 0.470-0.486 one at a time, C3 0.087 against 0.0805 — profiles/r05_h_fused_order_ab.txt — and left the product.) */
-  const size_t res_need = (size_t)pic.res_len + 1;
+  /* behind the intra residuals: room for the residual tiles of every other block, which a dependent chain's picture leaves there in its front part
+     (launch_prediction; with three lanes and more) — block i of size bin s at tile_base[s] + i * nT^2 */
+  const size_t res_intra = ((size_t)pic.res_len + 64) & ~(size_t)63;
+  size_t res_tiles = 0;
+  for (int s = 0; s < 4; s++) { d.res_tile_base[s] = (uint32_t)res_tiles; res_tiles += (size_t)pic.rb_count[s] << (2 * (s + 2)); }
+  const bool tiles = (c->depth >= 3 || chain_residuals_forced()) && res_tiles < ((size_t)1 << 31);
+  const size_t res_need = res_intra + (tiles ? res_tiles : 0) + 1;
   if ((rc = grow(&c->resbuf, &c->cap_res, res_need, c->stream, false))) return rc;
+  d.res_tiles = tiles ? c->resbuf + res_intra : nullptr;     /* (resbuf itself: below, with the lane's other scratch) */
+  d.res_front = 0;
   if ((rc = grow(&c->sao_nb, &c->cap_sao, (size_t)d.nCtb * 3, c->stream, false))) return rc;
   {
     /* inter jobs of 4 x 8 luma samples: a list of disjoint prediction blocks makes at most one per 16 luma samples (8x4 blocks),
@@ -196,6 +206,10 @@ void clear_target(m355_ctx* c, const DevPic& d, Frame* tgt, bool gated, hipStrea
   }
 }
 
+/* test hook (M355_TEST_CHAIN_RESIDUALS=1): every picture takes the residual order of a dependent chain's picture — k_residual in front of k_inter, storing tiles,
+   k_residual_add behind it —, chain or not: the CPU tier's interpreter finishes every launch before the next call, so no reference is ever "still being written" there */
+bool chain_residuals_forced() { static const bool on = getenv("M355_TEST_CHAIN_RESIDUALS") != nullptr; return on; }
+
 void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd, hipEvent_t* ev, bool with_intra, hipStream_t chain, Frame* hazard_dst) {
   hipStream_t st = c->stream;
   /* an intra picture keeps to its lane's main stream: its side work (metadata planes, border plans: 0.07 ms) is nothing beside k_intra,
@@ -215,6 +229,11 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
   static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
   const bool clear_in_count = d.n_pbs >= std::max(1, clear_min);
   bool tu_plan_with_residuals = false;
+  /* a dependent chain's picture (`chain`: decode_pre) transforms its residuals in its FRONT part — they do not depend on the reference —, as int16 tiles
+     (k_residual with res_front), and adds them behind k_inter (k_residual_add: two round trips instead of the transform's chain of them).  Not at 16 bits per
+     sample: a tile holds a residual clipped to int16, which is the same sum only while a sample needs no more than 15 bits. */
+  const bool res_front = (chain || chain_residuals_forced()) && d.res_tiles && (c->stages & M355_STAGE_RESIDUAL) && d.pp.bit_depth_luma <= 15 && d.pp.bit_depth_chroma <= 15 &&
+                         d.rb_count[0] + d.rb_count[1] + d.rb_count[2] + d.rb_count[3] > 0;
   if (clear_in_count) m355_launch_job_count(d, true, st);
   if (!single) { hipEventRecord(c->ev_fork, st); hipStreamWaitEvent(s2, c->ev_fork, 0); }
   /* transform edges and border plans in ONE launch (a packet less per picture: C3 0.098 -> 0.093 ms, profiles/r05_a_switches_merge.txt) */
@@ -225,7 +244,7 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
        decodes one picture at a time: C3 0.1494 -> 0.1427 ms, C4 0.1627 -> 0.1564.  With lanes they stay a launch of their own in FRONT of k_inter, where
        other pictures' kernels — or, for a chain's picture, its reference's last stages — run beside them: merged, C3 0.0688 -> 0.0697 ms with three in
        flight and a chain's picture 0.132 -> 0.136, C4 0.147 -> 0.156: profiles/r05_v30_*) */
-    if (c->depth == 1 && (c->stages & M355_STAGE_RESIDUAL)) tu_plan_with_residuals = true; else m355_launch_tu_plan(d, st);
+    if (c->depth == 1 && (c->stages & M355_STAGE_RESIDUAL) && !res_front) tu_plan_with_residuals = true; else m355_launch_tu_plan(d, st);
   } else {
     if (c->stages & M355_STAGE_INTRA) {
       m355_launch_meta_planes(d, s2, clear_in_count, false);
@@ -233,6 +252,20 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
     } else m355_launch_meta_planes(d, s2, clear_in_count);
     if (clear_in_count) m355_launch_job_list(d, st); else m355_launch_meta_jobs(d, st);
   }
+  auto launch_residuals = [&](const DevPic& dd) {
+    /* inter residuals are added to the prediction samples: behind k_inter_jobs; the two launches side by side on the lane's two
+       streams (one after the other on the main stream, without the second fork, was measured 1 % slower at C5 with three
+       pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
+    hipStream_t sr = !single ? s2 : st;
+    if (sr != st) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }
+    if (tu_plan_with_residuals) m355_launch_residual_tu_plan(dd, hbd, st);
+    else if (sr == st) m355_launch_residual_both(dd, hbd, st);       /* (one stream: one launch, k_residual.hip) */
+    else {
+      m355_launch_residual(dd, hbd, false, sr);
+      m355_launch_residual(dd, hbd, true, st);
+    }
+  };
+  if (res_front) { DevPic dq = d; dq.res_front = 1; launch_residuals(dq); }
   if (ev) hipEventRecord(ev[1], st);
   /* read-after-write on the reference frames: their last writers are waited for HERE, in front of the first kernel that reads a
      reference — the list copy, validation, metadata planes and job list of a picture run beside the tail
@@ -269,19 +302,8 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
 #endif
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   if (ev) hipEventRecord(ev[2], st);
-  if (c->stages & M355_STAGE_RESIDUAL) {
-    /* inter residuals are added to the prediction samples: behind k_inter_jobs; the two launches side by side on the lane's two
-       streams (one after the other on the main stream, without the second fork, was measured 1 % slower at C5 with three
-       pictures in flight: 0.3573-0.3605 against 0.3538-0.3580 ms, profiles/r04_am_residual_streams_ab.txt) */
-    hipStream_t sr = !single ? s2 : st;
-    if (sr != st) { hipEventRecord(c->ev_fork2, st); hipStreamWaitEvent(s2, c->ev_fork2, 0); }
-    if (tu_plan_with_residuals) m355_launch_residual_tu_plan(d, hbd, st);
-    else if (sr == st) m355_launch_residual_both(d, hbd, st);       /* (one stream: one launch, k_residual.hip) */
-    else {
-      m355_launch_residual(d, hbd, false, sr);
-      m355_launch_residual(d, hbd, true, st);
-    }
-  }
+  if ((c->stages & M355_STAGE_RESIDUAL) && !res_front) launch_residuals(d);
+  else if (res_front) m355_launch_residual_add(d, hbd, st);
   if (!single) { hipEventRecord(c->ev_join, s2); hipStreamWaitEvent(st, c->ev_join, 0); }     /* join */
   if (ev) hipEventRecord(ev[3], st);
   if (with_intra && (c->stages & M355_STAGE_INTRA)) m355_launch_intra(d, hbd, st, clear_in_count);   /* (m355_decode_batch launches several pictures' intra stage as one kernel) */
