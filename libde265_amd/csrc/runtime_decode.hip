@@ -344,7 +344,10 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
     unsigned long long newest = 0;
     for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
-      if (!f || f->wr.ticket <= newest || ev_query(c, f->wr) == hipSuccess) continue;
+      /* (test hook M355_TEST_CHAIN_LANES=1: every reference this context has decoded counts as still being written — the interpreter finishes every launch
+         before the next call, so the CPU tier would never walk the chain's bookkeeping: lane choice, change of stream, marks, late hazards) */
+      static const bool always = getenv("M355_TEST_CHAIN_LANES") != nullptr;
+      if (!f || f->wr.ticket <= newest || (!always && ev_query(c, f->wr) == hipSuccess)) continue;
       newest = f->wr.ticket; chain = f->wr.stream;
     }
     int lane = (c->active + 1) % c->depth;
