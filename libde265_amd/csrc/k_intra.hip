@@ -21,12 +21,15 @@
  *     live in the CTB's LDS tile, and the substitution of unavailable entries (intrapred.h:637-665) — is resolved into
  *     a PLAN: one 16-bit LDS source per border entry;
  *   k_intra  (the chain): one workgroup per CTB that contains intra blocks, described by one host-prepared 32-byte
- *     record (DevIntraWork).  The CTB's samples, its residuals and its plan are resident in LDS; a block is: gather the
+ *     record (DevIntraWork).  The CTB's samples, its residuals (inside the same tile, at each block's own position, until the block
+ *     is predicted) and its plan are resident in LDS; a block is: gather the
  *     border through the plan -> (smooth) -> predict -> add residual -> LDS.  No picture store, no metadata lookup and
  *     no availability arithmetic sits between two dependent blocks; the CTB's intra samples are written to the picture
  *     once, coalesced, when the CTB is finished.
- *   - CTBs that read no intra sample of a neighbour are taken by workgroup index; the dependent ones are claimed from
- *     an atomic ticket in DECODE (tile-scan) order, so a workgroup only ever waits on CTBs claimed before it;
+ *   - inter pictures: the CTBs of dependency chains (they read a neighbour's intra samples, or a neighbour reads theirs) are claimed
+ *     from an atomic ticket, longest remaining chain first — an order in which a producer precedes its readers, so a workgroup only ever
+ *     waits on CTBs claimed before it —, the others are taken by workgroup index; intra pictures: every CTB through the ticket, those
+ *     that wait for no neighbour first, then the dependent ones in wavefront order;
  *   - dependencies between CTBs are tracked at the granularity of the SAMPLES ACTUALLY READ: a block that finishes a
  *     piece of its CTB's right column or bottom row publishes those samples as 8-byte granules {tag = this decode's
  *     epoch, two samples} with agent-scope (write-through) stores — "the data is the flag" (MI355X guide, guideline
@@ -90,10 +93,12 @@ template <int CF> __global__ void __launch_bounds__(256) k_tu_plan(DevPic p, int
 }
 
 /* NW = waves per workgroup: 12 for intra pictures (CTBs with hundreds of blocks: up to 8 luma + 2 + 2 chroma waves share a
- * level, the CTB's residuals and its whole plan are fetched into LDS up front), 4 for inter pictures (a handful of intra
- * blocks per CTB: up to 1-2 + 1 + 1 waves, residual cache lines requested in the prologue and loaded per block behind its
- * border gather, the plan of 64 blocks at a time; the smaller footprint keeps more CTBs in flight).  The CTB's own wave
- * counts come from DevIntraWork.waves_code (runtime_upload.hip intra_schedule). */
+ * level, the CTB's whole plan is fetched into LDS up front; 13 with the halo keeper, one picture at a time), 4 for inter pictures
+ * (a handful of intra blocks per CTB: up to 2 + 1 + 1 waves, the plan of 64 blocks at a time, 80 registers: six workgroups per CU).
+ * Every instantiation runs the same block code — residuals in LDS inside the body tile, class-specialised 16x16 / 32x32 loops, a
+ * 32x32 block shared by its component's waves — and differs in how CTBs are claimed (persistent workgroups and a ticket / one
+ * workgroup per CTB, chain CTBs through the ticket) and in the prologue (an inter picture's: everything whose address follows from
+ * the descriptor requested at once).  The CTB's own wave counts come from DevIntraWork.waves_code (runtime_upload.hip intra_schedule). */
 /* BATCH (intra pictures only): SEVERAL pictures' CTBs in one launch — pics[0 .. n_pics) in device memory, one shared ticket; ticket t
  * is item t / n_pics of picture t % n_pics (the pictures' wavefronts interleaved: a workgroup still only waits on items claimed
  * before its own, now of its own picture).  Independent intra pictures then overlap CTB by CTB inside one kernel instead of through
