@@ -6,7 +6,8 @@ out-of-bounds access a validated-but-corrupt list provokes in a kernel is report
     LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 python tools/fuzz_asan.py
 (last runs, round 4's last tree: 480 corrupted pictures, 197 accepted by validation and decoded, 283 rejected, no ASan report — as built, and once
 more with the prepared switches on: M355_DEVICE_WORKLIST=1 M355_MERGE_TU_PLAN=1 M355_CLEAR_IN_COUNT_MIN=1; the round's last session: the same counts with
-M355_FUSE_DBH=1 M355_INTRA_ONE_SIDED=1)"""
+M355_FUSE_DBH=1 M355_INTRA_ONE_SIDED=1; round 5's last tree: the same counts as built and with M355_TEST_CHAIN_RESIDUALS=1 M355_CLEAR_IN_COUNT_MIN=1, plus — same build — the chain
+bookkeeping of tests/test_emu_chain.py under M355_TEST_CHAIN_LANES=1 and the 29 cases of tests/test_emu_synth.py: no report)"""
 import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np
 from libde265_amd import capi, worklist
