@@ -445,7 +445,7 @@ M355_API int m355_submit_picture(m355_ctx* ctx, const m355_picture* pic);
  * pointers (pic->rbs = the 4x4 bin's region; the four size bins live in their own regions caps->rb_bin[0..3], filled in by
  * the call) and its real counts (<= the capacities): the submit then validates, derives its schedules and starts the
  * host-to-device copy without copying a byte on the host.  It waits for the picture that used this arena last (three arenas
- * rotate; M355_TRANSIENT_RING=<n> makes the ring longer — measured: no gain, the submitting thread is the bound).  dst_frame / ref_frames / pp / counts are the caller's to fill in. */
+ * rotate — measured: a longer ring gains nothing, the submitting thread is the bound).  dst_frame / ref_frames / pp / counts are the caller's to fill in. */
 typedef struct m355_arena_caps {
   int32_t n_slices, n_ctbs, n_cus, n_tus, n_pbs, n_wts, n_ibs;
   int32_t n_rbs[4];

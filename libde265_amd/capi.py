@@ -193,7 +193,9 @@ class Context:
             nbytes = pw * ph * np.dtype(dt).itemsize
             p = self.L.lib.m355_host_alloc(nbytes)
             if not p:
-                raise M355Error(5, self.L.error())
+                for q in bufs:                       # (the planes of this call that were already allocated)
+                    self.L.lib.m355_host_free(q)
+                raise M355Error(4, self.L.error())   # M355_ERR_NOMEM
             bufs.append(p)
             arrays.append(np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), (nbytes,)).view(dt).reshape(ph, pw))
             dst[c] = p; strides[c] = pw
@@ -212,7 +214,9 @@ class Context:
             nbytes = pw * ph * np.dtype(dt).itemsize
             p = self.L.lib.m355_host_alloc(nbytes)
             if not p:
-                raise M355Error(5, self.L.error())
+                for q in bufs:                       # (the planes of this call that were already allocated)
+                    self.L.lib.m355_host_free(q)
+                raise M355Error(4, self.L.error())   # M355_ERR_NOMEM
             bufs.append(p)
             arrays.append(np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), (nbytes,)).view(dt).reshape(ph, pw))
             dst[c] = p; strides[c] = pw

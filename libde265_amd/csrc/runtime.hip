@@ -231,6 +231,7 @@ static void resident_free(Resident& r)
   if (r.xb[0]) { int cur = 0; hipGetDevice(&cur); drain_all_devices(cur); }
   for (void* b : r.xb) if (b) hipFree(b);
   if (r.xscratch) hipFree(r.xscratch);
+  for (hipEvent_t e : r.x3_read) if (e) hipEventDestroy(e);
   if (r.dev) hipFree(r.dev);
   if (r.host) hipHostFree(r.host);
   if (r.refs_dev) hipFree(r.refs_dev);
@@ -624,6 +625,8 @@ int m355_picture_replace(m355_ctx* c, int h, const m355_picture* pic)
     drain_all_devices(c->device);
     for (void*& b : r.xb) { if (b) hipFree(b); b = nullptr; }
     if (r.xscratch) { hipFree(r.xscratch); r.xscratch = nullptr; }
+    for (hipEvent_t e : r.x3_read) if (e) hipEventDestroy(e);
+    r.x3_read.clear();
     r.peers.clear();
   }
   const int rc = upload(c, r, pic);

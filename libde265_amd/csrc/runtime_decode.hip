@@ -279,7 +279,10 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
        decode's own front part, which is long over when the reference's filters are (a wait on a mark that has passed costs a packet; a wait the
        queue really sleeps on cost a dependent 4K picture 25-40 us: profiles/r05_v25_*) */
     EvRef front;
-    if (ev_mark(c, st, &front) == M355_OK) { c->stream = st = chain; ev_wait(c, st, front); }
+    if (ev_mark(c, st, &front) == M355_OK) {
+      c->stream = st = chain; ev_wait(c, st, front);
+      if (ev) hipEventRecord(ev[1], st);      /* (timed decode: the 'inter' interval starts behind the hand-over, the wait for the reference's stages is booked on 'meta') */
+    }
   }
   /* (a picture without SAO writes its destination from here on: its readers / last writer are waited for HERE, not in front of the metadata kernels —
      the destination of a chain's picture is often a frame the picture before it still reads) */

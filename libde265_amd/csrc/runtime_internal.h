@@ -135,6 +135,10 @@ struct Resident {
   void* xb[4] = {nullptr, nullptr, nullptr, nullptr};   /* m355_decode_sharded: the picture's exchange buffers X0..X3 + peer scratch (library-owned) */
   size_t xb_bytes[4] = {0, 0, 0, 0};
   void* xscratch = nullptr;
+  /* m355_group_decode: x3_read[q] = rank q has copied this handle's gather buffer xb[3] (recorded by q on its own stream, created on q's
+     device); the NEXT decode of this handle waits for them before it repacks the buffer — per buffer, not per rank: handles need not
+     rotate in step with the lane streams */
+  std::vector<hipEvent_t> x3_read;
   std::vector<int> peers;      /* ranks this rank exchanges halos with */
   EvRef up;                    /* lists copied to the device (decodes on another lane continue behind it) */
   EvRef done;                  /* last decode of these lists: behind it the arenas may be overwritten */

@@ -196,6 +196,7 @@ static int shard_buffers(m355_ctx* c, int h)
   const int np = m355_shard_peers(&r.hdr.pp, r.shard_rank, r.shard_n, peers, 256);
   if (np < 0) return M355_ERR_INVALID;
   r.peers.assign(peers, peers + np);
+  r.x3_read.assign((size_t)std::max(1, r.shard_n), nullptr);
   r.xscratch_pitch = (mx + 255) & ~(size_t)255;
   if (np) HIPCHK(hipMalloc(&r.xscratch, (r.xscratch_pitch + 256) * (size_t)np));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -284,6 +285,20 @@ struct m355_group {
   std::vector<std::string> err;
 };
 
+/* X3 read-complete handshake, per gather buffer: reader `q` has copied `owner`'s xb[3] (the event is created on the reader's device — the
+   current one — and recorded on the reader's stream); the owner's next repack of that buffer waits for every reader's event */
+static int x3_mark_read(Resident& owner, int q, int N, hipStream_t st)
+{
+  if ((int)owner.x3_read.size() < N) return fail(M355_ERR_INVALID, "no exchange buffers yet");
+  hipEvent_t& e = owner.x3_read[(size_t)q];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return fail(M355_ERR_HIP, "hipEventCreate failed"); }
+  return hipEventRecord(e, st) == hipSuccess ? M355_OK : fail(M355_ERR_HIP, "hipEventRecord failed");
+}
+static void x3_wait_readers(Resident& me, int r, hipStream_t st)
+{
+  for (size_t q = 0; q < me.x3_read.size(); q++) if ((int)q != r && me.x3_read[q]) hipStreamWaitEvent(st, me.x3_read[q], 0);
+}
+
 /* rank r's share of one picture: phases 0..last with the exchanges between them */
 static int group_rank_decode(m355_group* g, int r, unsigned long long n, const int* handles, int gather)
 {
@@ -305,9 +320,10 @@ static int group_rank_decode(m355_group* g, int r, unsigned long long n, const i
   for (int k = 0; k <= last; k++) {
     /* (a rank that failed keeps publishing its steps: the others must not wait for it forever) */
     if (k == 3 && gather && N > 1)
-      /* the gather buffer is repacked: every rank's X3 read of the PREVIOUS decode has to be over (the halo exchanges in between order it only three
-         hops along a rank row; those events were recorded before m355_group_decode returned — a never-recorded one is no wait) */
-      for (int q = 0; q < N; q++) if (q != r) hipStreamWaitEvent((hipStream_t)m355_stream(c), g->ev_copied[(size_t)q][3], 0);
+      /* the gather buffer of THIS handle is repacked: every rank's X3 read of the handle's previous decode has to be over (the halo exchanges in
+         between order it only three hops along a rank row).  The events belong to the buffer (Resident::x3_read[reader]); they were recorded
+         before that m355_group_decode returned — a never-recorded one is no wait */
+      x3_wait_readers(me, r, (hipStream_t)m355_stream(c));
     if (!rc) rc = m355_decode_phase(c, h, k, k < 4 ? me.xb[k] : nullptr);
     if (N <= 1 || k >= last) continue;
     hipStream_t st = (hipStream_t)m355_stream(c);
@@ -341,7 +357,8 @@ static int group_rank_decode(m355_group* g, int r, unsigned long long n, const i
         hipStreamWaitEvent(st, g->ev_pack[(size_t)q][3], 0);
         if (hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)other.xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st) != hipSuccess) rc = fail(M355_ERR_HIP, "hipMemcpyPeerAsync failed");
       }
-      if (!rc) hipEventRecord(g->ev_copied[(size_t)r][3], st);      /* this rank has read the others' gather buffers (see phase 3 above) */
+      /* this rank has read the others' gather buffers: said per buffer (see phase 3 above) */
+      for (int q = 0; q < N && !rc; q++) if (q != r) rc = x3_mark_read(g->ctx[(size_t)q]->resident[handles[q]], r, N, st);
     }
   }
   return rc;
@@ -439,8 +456,7 @@ static int group_decode_lockstep(m355_group* g, const int* handles, int gather)
     for (int r = 0; r < N; r++) {
       m355_ctx* c = g->ctx[(size_t)r];
       hipSetDevice(c->device);
-      if (k == 3 && gather && N > 1)
-        for (int q = 0; q < N; q++) if (q != r) hipStreamWaitEvent((hipStream_t)m355_stream(c), g->ev_copied[(size_t)q][3], 0);   /* (as group_rank_decode) */
+      if (k == 3 && gather && N > 1) x3_wait_readers(*R[(size_t)r], r, (hipStream_t)m355_stream(c));   /* (as group_rank_decode) */
       const int rc = m355_decode_phase(c, handles[r], k, k < 4 ? R[(size_t)r]->xb[k] : nullptr);
       if (rc) return rc;
       if (N > 1 && k < last) hipEventRecord(g->ev_pack[(size_t)r][(size_t)k], (hipStream_t)m355_stream(c));
@@ -470,7 +486,7 @@ static int group_decode_lockstep(m355_group* g, const int* handles, int gather)
             hipStreamWaitEvent(st, g->ev_pack[(size_t)q][3], 0);
             HIPCHK(hipMemcpyPeerAsync((char*)me.xb[3] + slot * (size_t)q, c->device, (const char*)R[(size_t)q]->xb[3] + slot * (size_t)q, g->ctx[(size_t)q]->device, slot, st));
           }
-          hipEventRecord(g->ev_copied[(size_t)r][3], st);
+          for (int q = 0; q < N; q++) if (q != r) { const int rcx = x3_mark_read(*R[(size_t)q], r, N, st); if (rcx) return rcx; }
         }
       }
   }

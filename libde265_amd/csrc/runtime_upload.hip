@@ -451,8 +451,9 @@ static int intra_schedule(const m355_picture* pic, int ctbW, int ctbH, m355_ib* 
             else if (m > 10 && m < 26) { te = nT; le = nT; }
             else if (m == 26) { te = nT; le = (bf || uy == 0) ? nT : 0; }
             else if (m == 10) { le = nT; te = (bf || ux == 0) ? nT : 0; }
-            else if (m > 26) { te = std::min(2 * nT, nT + ((nT * mag[m - 26]) >> 5) + 2); le = uy > 0 ? 0 : 2 * nT; }
-            else /* 2..9 */ { le = 2 * nT; te = ux > 0 ? 0 : 2 * nT; }
+            else if (m > 26 && m <= 34) { te = std::min(2 * nT, nT + ((nT * mag[m - 26]) >> 5) + 2); le = uy > 0 ? 0 : 2 * nT; }
+            else if (m >= 2 && m <= 9) { le = 2 * nT; te = ux > 0 ? 0 : 2 * nT; }
+            /* (a mode outside 0..34 — lists validated on the device only — keeps the full 2nT range, as m355_intra_used_entries does) */
             if (filt) { if (te) te = std::min(2 * nT, te + 1); if (le) le = 2 * nT; }
             top_e = te; left_e = le;
           }
