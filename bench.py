@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-cold-refs", action="store_true", help="skip the leg whose reference frames rotate through four pairs (working set beyond the Infinity Cache)")
     ap.add_argument("--force-tile-shard", action="store_true", help="run the tile-sharded measurement even at world size 1 (plumbing check)")
     ap.add_argument("--group-ranks", type=int, default=0, help="N=1 only, diagnostic: additionally decode the picture tile-sharded over this many contexts of THIS process (m355_group_*), all on the one GPU")
+    ap.add_argument("--no-verify", action="store_true", help="skip the frame checks of the legs against the CPU oracle (they run after the timed regions)")
     ap.add_argument("--no-tile-shard", action="store_true", help="N>1: skip the additional tile-sharded (one picture across all GPUs) measurement")
     args = ap.parse_args()
     # --gpus N without a launcher around us: become the launcher (one rank per GPU under torch.distributed.run, as the contract's
@@ -118,11 +119,17 @@ def main():
     pic.ref_frames = [refs[i] if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
     # one resident copy of the lists per picture in flight, each with its own destination frame (a decoder never reconstructs
     # consecutive pictures into the same frame; with one shared frame a picture without SAO could not overlap its predecessor at all)
-    handles = []
+    handles, dsts = [], []
     for _ in range(max(1, args.pipeline_depth)):
         pic.dst_frame = ctx.frame_create_for(pp)
+        dsts.append(pic.dst_frame)
         handles.append(ctx.upload(pic))
     handle = handles[0]
+    # frame checks of the legs (outside every timed region): the MD5 of the leg's LAST destination frame, made on the device (m355_frame_hash) or —
+    # with_transfers — over the planes that arrived on the host, is compared in emit() with the CPU oracle's decode of the same lists and references
+    # (oracle/ = the checker, never the thing measured): {leg: (md5 per plane, what the oracle has to decode)}
+    seen = {}
+    std_refs = ("independent", tuple(cfg["seed"] + 17 * i for i in range(cfg["n_refs"])))
     ctx.wait()
     if args.stages != 31:
         ctx.set_stages(args.stages)
@@ -184,6 +191,9 @@ def main():
     t_enq = enq[order[repeats // 2]]
     spread = {"repeats": repeats, "min": 1e3 * regions[order[0]] / args.steps, "median": 1e3 * dt / args.steps, "max": 1e3 * regions[order[-1]] / args.steps,
               "p10": 1e3 * regions[order[repeats // 10]] / args.steps, "p90": 1e3 * regions[order[min(repeats - 1, (9 * repeats) // 10)]] / args.steps}
+    if rank == 0 and args.stages == 31 and not args.no_verify:
+        last = (args.warmup + repeats * args.steps - 1) % len(handles)
+        seen["headline"] = (ctx.frame_hash(dsts[last], capi.HASH_MD5), std_refs)
     ctx.set_pipeline_depth(1)
 
     # (2b) the same timed region with the reference frames ROTATING through four distinct pairs: the headline's pictures all read the same
@@ -219,6 +229,9 @@ def main():
             ctx.decode_resident(ch[k % len(ch)])
         ctx.wait()
         dtk = time.perf_counter() - t0
+        if args.stages == 31 and not args.no_verify:
+            kl = (side_steps - 1) % len(ch)
+            seen["rotating_references"] = (ctx.frame_hash(cd[kl], capi.HASH_MD5), ("independent", tuple(cfg["seed"] + 17 * i + 1009 * (kl % n_sets + 1) for i in range(nr))))
         ctx.set_pipeline_depth(1)
         for h2 in ch:
             ctx.release(h2)
@@ -256,6 +269,18 @@ def main():
             ctx.decode_resident(hs[k % (nr + 1)])
         ctx.wait()
         dtc = time.perf_counter() - t0
+        if args.stages == 31 and not args.no_verify:
+            # the chain's frame check: the start frames again, then nr + 2 decodes of the chain with nothing waited for in between (every frame written
+            # at least once, the last picture predicted from two decoded ones) — the schedule of the timed loop, on a history short enough for the oracle
+            ctx.wait()
+            for i in range(nr):
+                ctx.frame_upload(frames[i + 1], synth.ref_planes(cfg["seed"] + 17 * i, int(pp["width"]), int(pp["height"]),
+                                                                 int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"])))
+            n_chk = nr + 2
+            for k in range(n_chk):
+                ctx.decode_resident(hs[k % (nr + 1)])
+            ctx.wait()
+            seen["dependent_chain"] = (ctx.frame_hash(frames[(n_chk - 1) % (nr + 1)], capi.HASH_MD5), ("chain", nr, n_chk))
         ctx.set_pipeline_depth(1)
         for h2 in hs:
             ctx.release(h2)
@@ -285,6 +310,8 @@ def main():
             ctx.submit_in_place(pic, state=st, refill=False)
         ctx.wait()
         dts = time.perf_counter() - t0
+        if args.stages == 31 and not args.no_verify:
+            seen["with_upload"] = (ctx.frame_hash(pic.dst_frame, capi.HASH_MD5), std_refs)
         # (4b) "with transfers" (SURVEY.md 8d): the H2D of the lists as above AND the D2H of every output frame — each decode goes
         # into one of `depth` frames, its download into pinned planes starts behind it (m355_frame_download_async: a copy engine
         # beside the kernels), and a frame is decoded into again only after its previous download has landed
@@ -310,6 +337,9 @@ def main():
         transfer_steps(up_steps)
         ctx.wait()
         dtt = time.perf_counter() - t0
+        if args.stages == 31 and not args.no_verify:
+            import hashlib
+            seen["with_transfers"] = ([hashlib.md5(a.tobytes()).digest() for a in tplanes[(up_steps - 1) % depth_t][2]], std_refs)     # (what landed in the pinned planes)
         pic.dst_frame = saved_dst
         for tp in tplanes:
             ctx.pinned_free(tp)
@@ -368,6 +398,20 @@ def main():
                          "pictures_in_flight": 1,     # launch_ms / stage_ms: one picture at a time; `value`: args.pipeline_depth in flight
                          "traffic_total": pmc_traffic_total(args.workload)},
         }
+        verdicts = verify_legs(seen, cfg, pic, synth, worklist) if seen else {}
+        if "headline" in verdicts:
+            out["verified"] = verdicts["headline"]
+        if with_upload is not None:
+            if "with_upload" in verdicts:
+                with_upload["verified"] = with_upload["submit_only"]["verified"] = verdicts["with_upload"]
+            if "with_transfers" in verdicts:
+                with_upload["with_transfers"]["verified"] = verdicts["with_transfers"]
+        if chain is not None and "dependent_chain" in verdicts:
+            chain["verified"] = verdicts["dependent_chain"]
+        if cold is not None and "rotating_references" in verdicts:
+            cold["verified"] = verdicts["rotating_references"]
+        if verdicts:
+            out["verified_against"] = "oracle/liboracle.so (CPU restatement; the checker, outside every timed region): MD5 per plane of each leg's last destination frame"
         if sharded is not None:
             out["tile_sharded"] = sharded
         if with_upload is not None:
@@ -409,6 +453,54 @@ def main():
     ctx.close()
     if dist:
         dist.destroy_process_group()
+
+
+def verify_legs(seen, cfg, pic, synth, worklist):
+    """{leg: True / False} — the CPU oracle decodes what each leg's last destination frame must hold (seen[leg] = (MD5 per plane, recipe)) and the
+    digests are compared.  Test infrastructure used as the CHECKER, after every timed region is over; {} when oracle/liboracle.so is not in the tree."""
+    import hashlib
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        return {}
+    try:
+        from oracle_py import Oracle
+        o = Oracle(ctypes.CDLL(so))
+        pp = pic.pp[0]
+        geo = (int(pp["width"]), int(pp["height"]), int(pp["chroma_format_idc"]), int(pp["bit_depth_luma"]))
+        saved = pic.ref_frames
+        cache, out = {}, {}
+
+        def digest(fr):
+            return [hashlib.md5(a.tobytes()).digest() for a in o.frame_planes(fr)]
+        for leg, (got, recipe) in seen.items():
+            if recipe not in cache:
+                if recipe[0] == "independent":          # one decode from reference planes of the given seeds
+                    refs = {}
+                    for i, sd in enumerate(recipe[1]):
+                        refs[i] = o.frame_new(pp); o.frame_set_planes(refs[i], synth.ref_planes(sd, *geo))
+                    dst = o.frame_new(pp)
+                    pic.ref_frames = [i if i < len(refs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
+                    assert o.decode(pic, dst, refs) == 0
+                    cache[recipe] = digest(dst)
+                    for f in list(refs.values()) + [dst]:
+                        o.frame_free(f)
+                else:                                   # ("chain", nr, n): bench.py's dependent chain from its start frames, n decodes
+                    nr, n = recipe[1], recipe[2]
+                    fr = [o.frame_new(pp) for _ in range(nr + 1)]
+                    for i in range(nr):
+                        o.frame_set_planes(fr[i + 1], synth.ref_planes(cfg["seed"] + 17 * i, *geo))
+                    pic.ref_frames = [k if k < nr else -1 for k in range(worklist.MAX_REF_FRAMES)]
+                    for k in range(n):
+                        i = k % (nr + 1)
+                        assert o.decode(pic, fr[i], {j: fr[(i + 1 + j) % (nr + 1)] for j in range(nr)}) == 0
+                    cache[recipe] = digest(fr[(n - 1) % (nr + 1)])
+                    for f in fr:
+                        o.frame_free(f)
+            out[leg] = bool(list(got) == cache[recipe])
+        pic.ref_frames = saved
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
 
 
 def dev_sync(torch):

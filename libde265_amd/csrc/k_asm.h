@@ -100,9 +100,34 @@ __device__ __forceinline__ int d_dot2(unsigned a, unsigned b, int c)
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(m355_short2, a), __builtin_bit_cast(m355_short2, b), c, false);
 }
 
+/* head of a dot2 chain: v_dot2_i32_i16 (VOP3P) with the inline constant 0 as its accumulator.  Through the builtin hipcc picks the two-operand
+ * v_dot2c (accumulates in place) and zeroes the destination with a v_mov in front of every chain — one extra issue per four or five dot2 */
+__device__ __forceinline__ int d_dot2z(unsigned a, unsigned b)
+{
+#ifdef M355_X_NO_DOT2Z
+  return d_dot2(a, b, 0);
+#else
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#endif
+}
+
 /* v_dot4_i32_i8: c + sum of four signed-byte products — four filter taps per VALU issue (8-bit planes: samples XOR 0x80 are the
  * signed operand, the +128 * sum(taps) correction sits in the accumulator's start value) */
 __device__ __forceinline__ int d_dot4(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+/* head of a dot4 chain that starts from a constant (the +128 * 64 of the XOR-0x80 operands): the three-operand v_dot4_i32_i8 with the constant in a
+ * scalar register instead of v_mov + v_dot4c */
+__device__ __forceinline__ int d_dot4k(unsigned a, unsigned b, int k)
+{
+#ifdef M355_X_NO_DOT2Z
+  return d_dot4(a, b, k);
+#else
+  int r;
+  asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+#endif
+}
 /* v_perm_b32: bytes 1..2 of two registers -> one packed pair = ((lo >> 8) & 0xFFFF) | ((hi >> 8) << 16): a filter sum whose taps were
  * scaled so that its final right shift is 8 is shifted, truncated to int16 and packed with its neighbour in ONE issue */
 __device__ __forceinline__ unsigned d_pack_mid16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x06050201u); }

@@ -24,28 +24,7 @@ struct DevRef {            /* one reference frame (indexed by m355_pb.ref_slot) 
   int stride[3];
   int valid;
   int pad;
-#ifdef M355_X_TILED
-  /* EXPERIMENT (tools/variants.sh -DM355_X_TILED): a second copy of the frame in tiles of 32 x 8 samples, every tile row followed by
-     an apron of the next columns (a window row never straddles a tile: the kernel's two vector loads per row stay two), read by
-     k_inter_jobs' FAST path only.  tile = 8 rows of M355_TILE_ROW(plane) samples; trs = samples per row of tiles. */
-  const void* tiled[3];
-  int trs[3];
-  int pad2;
-#endif
 };
-#ifdef M355_X_TILED
-#ifndef M355_TILE_LW
-#define M355_TILE_LW 5       /* log2 tile width (samples) */
-#endif
-#ifndef M355_TILE_LH
-#define M355_TILE_LH 3       /* log2 tile height (rows) */
-#endif
-#define M355_TILE_W (1 << M355_TILE_LW)
-#define M355_TILE_H (1 << M355_TILE_LH)
-#define M355_TILE_ROW_L (M355_TILE_W + 16)   /* luma: + 16 (8-bit rows are fetched as 16 bytes from the dword below the window, 16-bit as 12 samples) */
-#define M355_TILE_ROW_C (M355_TILE_W + 8)    /* chroma: + 8 */
-void m355_launch_tile_convert(const void* src, int stride, int pw, int ph, int bpp, bool chroma, void* dst, int tiles_w, hipStream_t st);
-#endif
 
 /* k_intra's work item: everything a workgroup needs to know about its CTB in ONE 32-byte record (one scalar load behind the
  * ticket instead of a chain of dependent lookups: work list -> CTB record -> neighbours' slices / tiles / scan positions) */
@@ -135,9 +114,6 @@ struct DevPic {
   const m355_rb* rb_bin[4];         /* residual blocks of 4x4, 8x8, 16x16, 32x32 (rb_count[] entries each) */
   const m355_ib* ibs;               /* device copy: each CTB's blocks sorted by dependency level (runtime_upload.hip intra_schedule) */
   const uint32_t* ib_aux;           /* per ibs[i]: the block's exec record, 4 words (M355_IBX_*) */
-#ifdef M355_X_PROF
-  unsigned long long* prof;         /* timing hooks of experiment builds (tools/variants.sh -DM355_X_PROF=<work item>) */
-#endif
   uint16_t* iplan;                  /* border plans of all intra blocks (k_intra_plan writes, k_intra reads), lane scratch */
   int intra_dense;                  /* k_intra variant: 1 = intra picture (12-wave workgroups, residuals in LDS), 0 = a handful of blocks per CTB */
   const uint32_t* coeffs;
@@ -268,6 +244,14 @@ __host__ __device__ inline void m355_intra_used_entries(int mode, int log2, int 
 
 /* rectangles of one k_tiles_copy launch (finished tiles <-> all-gather buffer); wb / xb in bytes, ofs = byte offset in the buffer */
 struct TileCopyRect { uint32_t plane, xb, y, wb, h, pad; uint64_t ofs; };
+/* which inter kernel a picture takes: the job kernels (k_inter_jobs: one lane per 4 x 8 block, lean filters exact for bit depths <= 12, rows fetched
+   with 12- / 16-sample vector loads) for 4:2:0 / monochrome pictures at least one such vector wide; else k_inter_generic (one wavefront per PB) */
+static inline bool m355_inter_uses_jobs(const DevPic& p)
+{
+  const int bdmax = p.pp.bit_depth_luma > p.pp.bit_depth_chroma ? p.pp.bit_depth_luma : p.pp.bit_depth_chroma;
+  return p.pp.chroma_format_idc <= 1 && bdmax <= 12 && p.pw[0] >= 16 && (p.pp.chroma_format_idc == 0 || p.pw[1] >= 8);
+}
+
 #define M355_TILE_COPY_RECTS 48
 struct TileCopyArgs { char* plane[3]; size_t pitch[3]; TileCopyRect r[M355_TILE_COPY_RECTS]; };
 void m355_launch_tiles_copy(const TileCopyArgs& a, int n, void* xbuf, bool to_slot, hipStream_t st);

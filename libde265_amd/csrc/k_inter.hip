@@ -193,345 +193,23 @@ __global__ void __launch_bounds__(256) k_inter_generic(DevPic p)
  * job kernel
  * ============================================================================================== */
 
-/* packed tap tables, built once per workgroup in LDS.
- *   qpel[f] : E0..E3 = (t0,t1)(t2,t3)(t4,t5)(t6,t7) ; O0..O4 = (0,t0)(t1,t2)(t3,t4)(t5,t6)(t7,0)
- *   epel[f] : E0..E1 = (c0,c1)(c2,c3)               ; O0..O2 = (0,c0)(c1,c2)(c3,0)            */
 #ifndef M355_INTER_WAVES
 #define M355_INTER_WAVES 3   /* waves per SIMD the register budget is sized for (tools/variants.sh sweeps it) */
 #endif
 #ifndef M355_INTER_BLOCK
 #define M355_INTER_BLOCK 256   /* lanes (jobs) per workgroup */
 #endif
-#ifdef M355_X_PROF      /* experiment builds (tools/prof_inter_timeline.py): when a workgroup entered, had its class, its tables, its luma, was done */
-#define TLI(k) do { if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[65536 + 6 * blockIdx.x + (k)] = wall_clock64(); } while (0)
-#else
-#define TLI(k) do { } while (0)
-#endif
 #define QT_STRIDE 9
 #define ET_STRIDE 5
 __device__ __forceinline__ unsigned d_pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
-__device__ __forceinline__ int d_lo16s(unsigned v) { return (int)(int16_t)(v & 0xFFFFu); }
-__device__ __forceinline__ int d_hi16s(unsigned v) { return (int)v >> 16; }
-/* branch-free select on a per-lane all-ones / all-zeros mask (v_bfi_b32): keeps the filter arithmetic
-   unconditional — hipcc otherwise sinks the dot2 chains under per-lane branches on the MV phase */
-__device__ __forceinline__ unsigned d_sel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
-
-/* Picture-edge rows (motion.cc:84-91,141-159: every sample coordinate clamped to the row): instead of one clamped load per
- * sample, the row segment nearest to the wanted span is fetched with the vector loads of the fast path and the clamp becomes a
- * SATURATING SHIFT of it.  P = NP packed pairs = loaded samples X[0 .. 2NP-1]; result pair m = (X[c(2m+d)], X[c(2m+1+d)]),
- * c = clamp to [0, 2NP-1].  The segment is chosen so that X[0] / X[2NP-1] are the row's first / last sample whenever the span
- * sticks out on that side. */
-template <int NP, int NOUT>
-__device__ __forceinline__ void d_shift_sat(const unsigned (&P)[NP], int d, unsigned* S)
-{
-  const unsigned L = (P[0] & 0xFFFFu) * 0x10001u, R = (P[NP - 1] >> 16) * 0x10001u;
-  const int q = d >> 1;
-  const unsigned sh = ((unsigned)d & 1u) << 4;
-  unsigned V[NOUT + 1];
-#pragma unroll
-  for (int m = 0; m <= NOUT; m++) {
-    const int i = m + q;
-    unsigned v = L;
-#pragma unroll
-    for (int j = 0; j < NP; j++) v = i == j ? P[j] : v;
-    V[m] = i >= NP ? R : v;
-  }
-#pragma unroll
-  for (int m = 0; m < NOUT; m++) S[m] = __builtin_amdgcn_alignbit(V[m + 1], V[m], sh);
-}
-
-/* 12 consecutive samples starting at column xa of one row -> 6 packed 16-bit pairs.  FAST: the span
- * lies inside the picture row (the 12th sample may be the first pad sample: never used with a
- * non-zero tap); otherwise every column is clamped (motion.cc:84-91,147-155). */
-/* Vector loads must start on a DWORD boundary: measured on MI355X (tools/ubench/ub_l1.hip), a global_load_dwordx4 whose
- * address is only 2-byte aligned is processed one dword per pass — 64 cycles per wave instruction instead of 16 (x2: 32
- * vs 16, x3: 48 vs 16) — and the texture addresser is what bounds this kernel.  So the window rows are fetched from the
- * dword-aligned address at or below the first sample and funnel-shifted into place (v_alignbit / v_alignbyte, per-lane
- * shift): a few VALU issues per row buy back up to 3/4 of the addresser time of a misaligned row. */
-template <class PIX, bool FAST>
-__device__ __forceinline__ void d_load12(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[6])
-{
-  if (FAST) {
-    if (sizeof(PIX) == 2) {
-      /* 11 samples xa..xa+10 are needed: the 12 loaded ones start at xa or xa-1 (the spare slot moves to the front) */
-      const unsigned sh = ((unsigned)xa & 1u) << 4;
-      unsigned E[6];
-      const M355_GLOBAL PIX* q = row + (xa & ~1);
-      d_ldg16(q, E);
-      d_ldg8(q + 8, E + 4);
-#pragma unroll
-      for (int k = 0; k < 5; k++) S[k] = __builtin_amdgcn_alignbit(E[k + 1], E[k], sh);
-      S[5] = E[5] >> sh;
-    } else {
-      /* 11 bytes xa..xa+10 out of the 16 at the dword-aligned address below */
-      const unsigned sh = (unsigned)xa & 3u;
-      unsigned E[4], a[3];
-      d_ldg16(row + (xa & ~3), E);
-#pragma unroll
-      for (int k = 0; k < 3; k++) a[k] = __builtin_amdgcn_alignbyte(E[k + 1], E[k], sh);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { S[2 * k] = (a[k] & 0xFFu) | ((a[k] & 0xFF00u) << 8); S[2 * k + 1] = ((a[k] >> 16) & 0xFFu) | ((a[k] >> 8) & 0xFF0000u); }
-    }
-  } else if (sizeof(PIX) == 2 && pw >= 12) {
-    const int xb = d_clip3(0, pw - 12, xa);
-    unsigned E[6];
-    d_ldg16(row + xb, E);
-    d_ldg8(row + xb + 8, E + 4);
-    d_shift_sat<6, 6>(E, xa - xb, S);
-  } else if (sizeof(PIX) == 1 && pw >= 16) {
-    const int xb = d_clip3(0, pw - 16, xa);
-    unsigned E[4], P[8];
-    d_ldg16(row + xb, E);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { P[2 * k] = (E[k] & 0xFFu) | ((E[k] & 0xFF00u) << 8); P[2 * k + 1] = ((E[k] >> 16) & 0xFFu) | ((E[k] >> 8) & 0xFF0000u); }
-    d_shift_sat<8, 6>(P, xa - xb, S);
-  } else {      /* rows shorter than one vector */
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const unsigned lo = row[d_clip3(0, pw - 1, xa + 2 * k)], hi = row[d_clip3(0, pw - 1, xa + 2 * k + 1)];
-      S[k] = lo | (hi << 16);
-    }
-  }
-}
-/* 6 consecutive samples -> 3 pairs (chroma window row; the last one is never used with a non-zero tap) */
-template <class PIX, bool FAST>
-__device__ __forceinline__ void d_load6(const M355_GLOBAL PIX* row, int xa, int pw, unsigned S[3])
-{
-  if (FAST) {
-    if (sizeof(PIX) == 2) {
-      const unsigned sh = ((unsigned)xa & 1u) << 4;
-      unsigned E[3];
-      d_ldg12(row + (xa & ~1), E);
-      S[0] = __builtin_amdgcn_alignbit(E[1], E[0], sh); S[1] = __builtin_amdgcn_alignbit(E[2], E[1], sh); S[2] = E[2] >> sh;
-    } else {
-      /* 5 bytes xa..xa+4 out of the 8 at the dword-aligned address below */
-      const unsigned sh = (unsigned)xa & 3u;
-      unsigned E[2];
-      d_ldg8(row + (xa & ~3), E);
-      const unsigned a = __builtin_amdgcn_alignbyte(E[1], E[0], sh), b = E[1] >> (8 * sh);
-      S[0] = (a & 0xFFu) | ((a & 0xFF00u) << 8); S[1] = ((a >> 16) & 0xFFu) | ((a >> 8) & 0xFF0000u);
-      S[2] = (b & 0xFFu) | ((b & 0xFF00u) << 8);
-    }
-  } else if (sizeof(PIX) == 2 && pw >= 6) {
-    const int xb = d_clip3(0, pw - 6, xa);
-    unsigned E[3];
-    d_ldg12(row + xb, E);
-    d_shift_sat<3, 3>(E, xa - xb, S);
-  } else if (sizeof(PIX) == 1 && pw >= 8) {
-    const int xb = d_clip3(0, pw - 8, xa);
-    unsigned E[2], P[4];
-    d_ldg8(row + xb, E);
-#pragma unroll
-    for (int k = 0; k < 2; k++) { P[2 * k] = (E[k] & 0xFFu) | ((E[k] & 0xFF00u) << 8); P[2 * k + 1] = ((E[k] >> 16) & 0xFFu) | ((E[k] >> 8) & 0xFF0000u); }
-    d_shift_sat<4, 3>(P, xa - xb, S);
-  } else {      /* rows shorter than one vector */
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const unsigned lo = row[d_clip3(0, pw - 1, xa + 2 * k)], hi = row[d_clip3(0, pw - 1, xa + 2 * k + 1)];
-      S[k] = lo | (hi << 16);
-    }
-  }
-}
-
-/* luma 4x8 block of one list -> packed 14-bit predictions (int16 pairs), fallback-motion.cc:492-636.
- * (xi,yi) = integer position of the block's top-left sample in the reference plane. */
-template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_mc_luma_4x8(const M355_GLOBAL PIX* rp, int rstride,
-#ifdef M355_X_TILED
-                                              const M355_GLOBAL PIX* tp, int trs,
-#endif
-                                              int pw, int ph, int xi, int yi, int xf, int yf, int bd,
-                                              const unsigned* qt, unsigned pred[8][2])
-{
-  const unsigned* tx = qt + xf * QT_STRIDE;
-  const unsigned* ty = qt + yf * QT_STRIDE;
-  const int shift1 = bd - 8, shift3 = max(2, 14 - bd);
-  const int xa = xi - 3;
-#ifdef M355_X_TILED
-  /* the tile column of the window's first loaded sample is the same for all 15 rows: fold it into the base */
-  const int txl = (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3)) >> M355_TILE_LW;
-  const M355_GLOBAL PIX* tpl = tp + txl * (M355_TILE_H * M355_TILE_ROW_L - M355_TILE_W);
-#define LROW(yc) (FAST ? tpl + __mul24((yc) >> M355_TILE_LH, trs) + ((yc) & (M355_TILE_H - 1)) * M355_TILE_ROW_L : rp + __mul24((yc), rstride))
-#else
-#define LROW(yc) (rp + __mul24((yc), rstride))
-#endif
-  const unsigned xmask = xf == 0 ? ~0u : 0u, ymask = yf == 0 ? ~0u : 0u, xymask = xmask & ymask;
-  unsigned Q[8][4];
-  {
-    unsigned XE[4], XO[5];
-#pragma unroll
-    for (int k = 0; k < 4; k++) XE[k] = tx[k];
-#pragma unroll
-    for (int k = 0; k < 5; k++) XO[k] = tx[4 + k];
-    const unsigned bias = BIAS ? 0x80008000u : 0u;
-    const int init = BIAS ? (1 << 21) : 0;
-    /* rows are fetched one pair ahead of the pair being filtered; the scheduling barriers keep hipcc
-       from hoisting all 15 rows of loads to the top (which spills) while still overlapping the next
-       pair's loads with this pair's arithmetic */
-    unsigned S[2][2][6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) S[1][1][i] = 0;
-    d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi - 3)), xa, pw, S[0][0]);
-    d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi - 2)), xa, pw, S[0][1]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (FAST) {
-        if (k < 7) {
-          d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k - 1)), xa, pw, S[(k + 1) & 1][0]);
-          if (k < 6) d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k)), xa, pw, S[(k + 1) & 1][1]);
-        }
-      } else if (k > 0) {   /* edge jobs: 24 clamped sample loads per pair, no prefetch (register pressure) */
-        d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k - 3)), xa, pw, S[k & 1][0]);
-        if (k < 7) d_load12<PIX, FAST>(LROW(d_clip3(0, ph - 1, yi + 2 * k - 2)), xa, pw, S[k & 1][1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      /* both rows of the pair, then one v_perm per column packs the (row 2k, row 2k+1) int16 pair —
-         the int16 mcbuffer store of fallback-motion.cc:512-565; xFrac == 0 copies the sample unshifted */
-      int h[2][4];
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const unsigned* R = S[k & 1][q];
-        unsigned B[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) B[i] = R[i] ^ bias;
-        h[q][0] = d_dot2(B[3], XE[3], d_dot2(B[2], XE[2], d_dot2(B[1], XE[1], d_dot2(B[0], XE[0], init)))) >> shift1;
-        h[q][1] = d_dot2(B[4], XO[4], d_dot2(B[3], XO[3], d_dot2(B[2], XO[2], d_dot2(B[1], XO[1], d_dot2(B[0], XO[0], init))))) >> shift1;
-        h[q][2] = d_dot2(B[4], XE[3], d_dot2(B[3], XE[2], d_dot2(B[2], XE[1], d_dot2(B[1], XE[0], init)))) >> shift1;
-        h[q][3] = d_dot2(B[5], XO[4], d_dot2(B[4], XO[3], d_dot2(B[3], XO[2], d_dot2(B[2], XO[1], d_dot2(B[1], XO[0], init))))) >> shift1;
-      }
-      const unsigned* Re = S[k & 1][0];
-      const unsigned* Ro = S[k & 1][1];
-      if (k < 7) {
-        Q[k][0] = d_sel(xmask, d_pack_hi16(Re[1], Ro[1]), d_pack_lo16((unsigned)h[0][0], (unsigned)h[1][0]));
-        Q[k][1] = d_sel(xmask, d_pack_lo16(Re[2], Ro[2]), d_pack_lo16((unsigned)h[0][1], (unsigned)h[1][1]));
-        Q[k][2] = d_sel(xmask, d_pack_hi16(Re[2], Ro[2]), d_pack_lo16((unsigned)h[0][2], (unsigned)h[1][2]));
-        Q[k][3] = d_sel(xmask, d_pack_lo16(Re[3], Ro[3]), d_pack_lo16((unsigned)h[0][3], (unsigned)h[1][3]));
-      } else {   /* row 14 only: the odd half (row 15) is never read with a non-zero tap */
-        Q[k][0] = d_sel(xmask, Re[1] >> 16, (unsigned)h[0][0] & 0xFFFFu);
-        Q[k][1] = d_sel(xmask, Re[2] & 0xFFFFu, (unsigned)h[0][1] & 0xFFFFu);
-        Q[k][2] = d_sel(xmask, Re[2] >> 16, (unsigned)h[0][2] & 0xFFFFu);
-        Q[k][3] = d_sel(xmask, Re[3] & 0xFFFFu, (unsigned)h[0][3] & 0xFFFFu);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const int vshift = xf == 0 ? shift1 : 6;
-  unsigned YE[4], YO[5];
-#pragma unroll
-  for (int k = 0; k < 4; k++) YE[k] = ty[k];
-#pragma unroll
-  for (int k = 0; k < 5; k++) YO[k] = ty[4 + k];
-#pragma unroll
-  for (int m = 0; m < 4; m++) {
-    int ve[4], vo[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      ve[j] = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0)))) >> vshift;
-      vo[j] = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0))))) >> vshift;
-    }
-    /* packed per column pair; the reference stores the prediction as int16 (predSamples, motion.cc:331).
-       yf == 0 copies row y+3 of the intermediates (y = 2m -> hi half of pair m+1, y = 2m+1 -> lo half of
-       pair m+2), and a full-pel block is the sample << shift3 */
-#pragma unroll
-    for (int jp = 0; jp < 2; jp++) {
-      const unsigned ce = d_pack_hi16(Q[m + 1][2 * jp], Q[m + 1][2 * jp + 1]), co = d_pack_lo16(Q[m + 2][2 * jp], Q[m + 2][2 * jp + 1]);
-      pred[2 * m][jp] = d_sel(ymask, d_sel(xymask, d_pk_shl16(ce, shift3), ce), d_pack_lo16((unsigned)ve[2 * jp], (unsigned)ve[2 * jp + 1]));
-      pred[2 * m + 1][jp] = d_sel(ymask, d_sel(xymask, d_pk_shl16(co, shift3), co), d_pack_lo16((unsigned)vo[2 * jp], (unsigned)vo[2 * jp + 1]));
-    }
-  }
-}
-
-#undef LROW
-/* chroma 2x4 block of one list and plane, fallback-motion.cc:305-415 / 262-302 */
-template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_mc_chroma_2x4(const M355_GLOBAL PIX* rp, int rstride,
-#ifdef M355_X_TILED
-                                                const M355_GLOBAL PIX* tp, int trs,
-#endif
-                                                int pw, int ph, int xi, int yi, int xf, int yf, int bd,
-                                                const unsigned* et, unsigned pred[4])
-{
-  const unsigned* tx = et + xf * ET_STRIDE;
-  const unsigned* ty = et + yf * ET_STRIDE;
-  const int shift1 = bd - 8, shift3 = max(2, 14 - bd);
-  const int xa = xi - 1;
-#ifdef M355_X_TILED
-  const int txc = (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3)) >> M355_TILE_LW;
-  const M355_GLOBAL PIX* tpc = tp + txc * (M355_TILE_H * M355_TILE_ROW_C - M355_TILE_W);
-#define CROW(yc) (FAST ? tpc + __mul24((yc) >> M355_TILE_LH, trs) + ((yc) & (M355_TILE_H - 1)) * M355_TILE_ROW_C : rp + __mul24((yc), rstride))
-#else
-#define CROW(yc) (rp + __mul24((yc), rstride))
-#endif
-  const unsigned xmask = xf == 0 ? ~0u : 0u, ymask = yf == 0 ? ~0u : 0u, xymask = xmask & ymask;
-  unsigned Q[4][2];
-  {
-    unsigned XE[2], XO[3];
-#pragma unroll
-    for (int k = 0; k < 2; k++) XE[k] = tx[k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) XO[k] = tx[2 + k];
-    const unsigned bias = BIAS ? 0x80008000u : 0u;
-    const int init = BIAS ? (1 << 21) : 0;
-    unsigned S[7][3];
-    if (FAST) {   /* all seven rows in flight at once; the edge path loads row by row (register pressure) */
-#pragma unroll
-      for (int r = 0; r < 7; r++) d_load6<PIX, FAST>(CROW(d_clip3(0, ph - 1, yi + r - 1)), xa, pw, S[r]);
-    }
-    int h[8][2];
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      if (!FAST) {
-        d_load6<PIX, FAST>(CROW(d_clip3(0, ph - 1, yi + r - 1)), xa, pw, S[r]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      const unsigned B0 = S[r][0] ^ bias, B1 = S[r][1] ^ bias, B2 = S[r][2] ^ bias;
-      h[r][0] = d_dot2(B1, XE[1], d_dot2(B0, XE[0], init)) >> shift1;
-      h[r][1] = d_dot2(B2, XO[2], d_dot2(B1, XO[1], d_dot2(B0, XO[0], init))) >> shift1;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      Q[k][0] = d_sel(xmask, d_pack_hi16(S[2 * k][0], S[2 * k + 1][0]), d_pack_lo16((unsigned)h[2 * k][0], (unsigned)h[2 * k + 1][0]));
-      Q[k][1] = d_sel(xmask, d_pack_lo16(S[2 * k][1], S[2 * k + 1][1]), d_pack_lo16((unsigned)h[2 * k][1], (unsigned)h[2 * k + 1][1]));
-    }
-    Q[3][0] = d_sel(xmask, S[6][0] >> 16, (unsigned)h[6][0] & 0xFFFFu);
-    Q[3][1] = d_sel(xmask, S[6][1] & 0xFFFFu, (unsigned)h[6][1] & 0xFFFFu);
-  }
-  unsigned YE[2], YO[3];
-#pragma unroll
-  for (int k = 0; k < 2; k++) YE[k] = ty[k];
-#pragma unroll
-  for (int k = 0; k < 3; k++) YO[k] = ty[2 + k];
-  const int vshift = xf == 0 ? shift1 : 6;
-#pragma unroll
-  for (int m = 0; m < 2; m++) {
-    int ve[2], vo[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      ve[j] = d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0)) >> vshift;
-      vo[j] = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0))) >> vshift;
-    }
-    /* yf == 0: row y+1: y = 2m -> hi half of pair m ; y = 2m+1 -> lo half of pair m+1 */
-    const unsigned ce = d_pack_hi16(Q[m][0], Q[m][1]), co = d_pack_lo16(Q[m + 1][0], Q[m + 1][1]);
-    pred[2 * m] = d_sel(ymask, d_sel(xymask, d_pk_shl16(ce, shift3), ce), d_pack_lo16((unsigned)ve[0], (unsigned)ve[1]));
-    pred[2 * m + 1] = d_sel(ymask, d_sel(xymask, d_pk_shl16(co, shift3), co), d_pack_lo16((unsigned)vo[0], (unsigned)vo[1]));
-  }
-}
-
-/* weighted write-back of one sample (fallback-motion.cc:33-256, selection motion.cc:493-688).  All four
- * reference formulas are instances of ((a*w0 + b*w1 + rnd) >> sh) + o with the same int32 arithmetic:
+/* the write-back weights of one component as ONE formula: all four reference forms (fallback-motion.cc:33-256, selection motion.cc:493-688) are
+ * instances of ((a*w0 + b*w1 + rnd) >> sh) + o with the same int32 arithmetic:
  *   unweighted uni : w0 1, w1 0, rnd 1<<(shift3-1),        sh shift3,   o 0      (put_unweighted_pred)
  *   average        : w0 1, w1 1, rnd 1<<(shift2-1),        sh shift2,   o 0      (put_weighted_pred_avg)
  *   weighted uni   : w0,   w1 0, rnd 1<<(log2WD-1),        sh log2WD,   o o0     (put_weighted_pred)
  *   weighted bi    : w0,   w1,   rnd (o0+o1+1)<<log2WD,    sh log2WD+1, o 0      (put_weighted_bipred)
  * so the per-lane mode costs no branch. */
 struct WtSel { int w0, w1, rnd, sh, o; };
-__device__ __forceinline__ int d_wpred(const WtSel& s, int a, int b, int bd)
-{
-  /* a, b are int16 and the weights int16: 24-bit multiplies are exact (v_mad_i32_i24, full rate) */
-  return d_clip_bd(((__mul24(a, s.w0) + __mul24(b, s.w1) + s.rnd) >> s.sh) + s.o, bd);
-}
-
-#undef CROW
 
 /* ================================================================================================
  * lean filters (bit depths <= 12, i.e. every 8-bit plane and the 9..12-bit uint16 planes): the job classes whose windows lie
@@ -613,26 +291,6 @@ void m355_inter_tables(bool bytes, int bd_luma, int bd_chroma, uint32_t* out)
   }
 }
 
-/* attribution builds (tools/variants.sh; never the product): -DM355_X_INTER_NOLOAD = the window rows are made of address bits (no
-   vector loads), -DM355_X_INTER_HOT = every window lies in the first rows / columns of the reference plane (all loads hit the caches),
-   -DM355_X_INTER_NOSTORE = the samples are computed and not stored */
-#if defined(M355_X_INTER_NOLOAD)
-__device__ __forceinline__ void d_fake_ld(const M355_GLOBAL void* p, unsigned* o, int n) { for (int i = 0; i < n; i++) o[i] = (unsigned)(unsigned long long)p * 2654435761u + (unsigned)i; }
-#define LEAN_LD16(p, o) d_fake_ld((p), (o), 4)
-#define LEAN_LD12(p, o) d_fake_ld((p), (o), 3)
-#define LEAN_LD8(p, o) d_fake_ld((p), (o), 2)
-#else
-#define LEAN_LD16(p, o) d_ldg16((p), (o))
-#define LEAN_LD12(p, o) d_ldg12((p), (o))
-#define LEAN_LD8(p, o) d_ldg8((p), (o))
-#endif
-#if defined(M355_X_INTER_HOT)
-#define LEAN_HOT_X(x) ((x) & 62)
-#define LEAN_HOT_Y(y) ((y) & 31)
-#else
-#define LEAN_HOT_X(x) (x)
-#define LEAN_HOT_Y(y) (y)
-#endif
 /* luma 4x8 block of one list -> packed 14-bit predictions (fallback-motion.cc:492-636 with the folds above) */
 /* EDGE: a window that leaves the picture (motion.cc:84-91, 141-159: every sample coordinate clamped): the rows are fetched from clamped
    row indices, the nearest in-range 12 / 16 samples of each with the vector loads of d_load12 and shifted into place with saturation
@@ -681,10 +339,10 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
           unsigned E[6];
 #pragma unroll
           for (int i = 0; i < 6; i++) E[i] = ext[(s_ >> 1) + i];
-          h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2(E[0], T0[0], 0)))));
-          h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2(E[0], T1[0], 0)))));
-          h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2(E[1], T0[0], 0)))));
-          h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2(E[1], T1[0], 0)))));
+          h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2z(E[0], T0[0])))));
+          h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2z(E[0], T1[0])))));
+          h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2z(E[1], T0[0])))));
+          h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2z(E[1], T1[0])))));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) Q[k][j] = d_pack_mid16((unsigned)h[0][j], (unsigned)h[1][j]);
@@ -715,9 +373,9 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
           for (int i = 0; i < 4; i++) E[i] = ext[(s_ >> 2) + i];
 #pragma unroll
           for (int i = 0; i < 3; i++) A[i] = __builtin_amdgcn_alignbyte(E[i + 1], E[i], sh) ^ 0x80808080u;
-          h[r][0] = d_dot4(A[1], W[0][1], d_dot4(A[0], W[0][0], 8192));
+          h[r][0] = d_dot4(A[1], W[0][1], d_dot4k(A[0], W[0][0], 8192));
 #pragma unroll
-          for (int j = 1; j < 4; j++) h[r][j] = d_dot4(A[2], W[j][2], d_dot4(A[1], W[j][1], d_dot4(A[0], W[j][0], 8192)));
+          for (int j = 1; j < 4; j++) h[r][j] = d_dot4(A[2], W[j][2], d_dot4(A[1], W[j][1], d_dot4k(A[0], W[j][0], 8192)));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) Q[k][j] = d_pack_lo16((unsigned)h[0][j], (unsigned)h[1][j]);
@@ -728,12 +386,12 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
     unsigned T0[5], T1[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { T0[k] = tl[k]; T1[k] = tl[5 + k]; }
-    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)LEAN_HOT_Y(yi - 3) * rstride + LEAN_HOT_X(xa & ~1);
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 3) * rstride + (xa & ~1);
     unsigned S[NB][2][6];
 #pragma unroll
     for (int k = 0; k < DEPTH; k++) {
-      LEAN_LD16(q, S[k][0]); LEAN_LD8(q + 8, S[k][0] + 4); q += rstride;
-      LEAN_LD16(q, S[k][1]); LEAN_LD8(q + 8, S[k][1] + 4); q += rstride;
+      d_ldg16(q, S[k][0]); d_ldg8(q + 8, S[k][0] + 4); q += rstride;
+      d_ldg16(q, S[k][1]); d_ldg8(q + 8, S[k][1] + 4); q += rstride;
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -742,18 +400,18 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
          loads to the top and filters behind one wait for everything — 90 registers of rows in flight and no overlap of a wave's
          own loads with its own arithmetic */
       if (k + DEPTH < 8) {
-        LEAN_LD16(q, S[(k + DEPTH) % NB][0]); LEAN_LD8(q + 8, S[(k + DEPTH) % NB][0] + 4); q += rstride;
-        if (k + DEPTH < 7) { LEAN_LD16(q, S[(k + DEPTH) % NB][1]); LEAN_LD8(q + 8, S[(k + DEPTH) % NB][1] + 4); q += rstride; }
+        d_ldg16(q, S[(k + DEPTH) % NB][0]); d_ldg8(q + 8, S[(k + DEPTH) % NB][0] + 4); q += rstride;
+        if (k + DEPTH < 7) { d_ldg16(q, S[(k + DEPTH) % NB][1]); d_ldg8(q + 8, S[(k + DEPTH) % NB][1] + 4); q += rstride; }
       }
       int h[2][4];
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }   /* row 15 is never read with a non-zero tap */
         const unsigned* E = S[k % NB][r];
-        h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2(E[0], T0[0], 0)))));
-        h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2(E[0], T1[0], 0)))));
-        h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2(E[1], T0[0], 0)))));
-        h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2(E[1], T1[0], 0)))));
+        h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2z(E[0], T0[0])))));
+        h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2z(E[0], T1[0])))));
+        h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2z(E[1], T0[0])))));
+        h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2z(E[1], T1[0])))));
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) Q[k][j] = d_pack_mid16((unsigned)h[0][j], (unsigned)h[1][j]);
@@ -765,18 +423,18 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
 #pragma unroll
     for (int j = 0; j < 4; j++) { W[j][0] = tl[3 * j]; W[j][1] = tl[3 * j + 1]; W[j][2] = tl[3 * j + 2]; }
     const unsigned sh = (unsigned)xa & 3u;
-    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)LEAN_HOT_Y(yi - 3) * rstride + LEAN_HOT_X(xa & ~3);
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 3) * rstride + (xa & ~3);
     unsigned S[NB][2][4];
 #pragma unroll
     for (int k = 0; k < DEPTH; k++) {
-      LEAN_LD16(q, S[k][0]); q += rstride;
-      LEAN_LD16(q, S[k][1]); q += rstride;
+      d_ldg16(q, S[k][0]); q += rstride;
+      d_ldg16(q, S[k][1]); q += rstride;
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       if (k + DEPTH < 8) {
-        LEAN_LD16(q, S[(k + DEPTH) % NB][0]); q += rstride;
-        if (k + DEPTH < 7) { LEAN_LD16(q, S[(k + DEPTH) % NB][1]); q += rstride; }
+        d_ldg16(q, S[(k + DEPTH) % NB][0]); q += rstride;
+        if (k + DEPTH < 7) { d_ldg16(q, S[(k + DEPTH) % NB][1]); q += rstride; }
       }
       int h[2][4];
 #pragma unroll
@@ -786,9 +444,9 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
         unsigned A[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) A[i] = __builtin_amdgcn_alignbyte(E[i + 1], E[i], sh) ^ 0x80808080u;
-        h[r][0] = d_dot4(A[1], W[0][1], d_dot4(A[0], W[0][0], 8192));
+        h[r][0] = d_dot4(A[1], W[0][1], d_dot4k(A[0], W[0][0], 8192));
 #pragma unroll
-        for (int j = 1; j < 4; j++) h[r][j] = d_dot4(A[2], W[j][2], d_dot4(A[1], W[j][1], d_dot4(A[0], W[j][0], 8192)));
+        for (int j = 1; j < 4; j++) h[r][j] = d_dot4(A[2], W[j][2], d_dot4(A[1], W[j][1], d_dot4k(A[0], W[j][0], 8192)));
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) Q[k][j] = d_pack_lo16((unsigned)h[0][j], (unsigned)h[1][j]);
@@ -806,8 +464,8 @@ __device__ __forceinline__ void d_mc_luma_lean(const M355_GLOBAL PIX* rp, int rs
     int ve[4], vo[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      ve[j] = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0))));
-      vo[j] = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)))));
+      ve[j] = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2z(Q[m][j], YE[0]))));
+      vo[j] = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2z(Q[m][j], YO[0])))));
     }
 #pragma unroll
     for (int jp = 0; jp < 2; jp++) {
@@ -841,8 +499,8 @@ __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int 
         uint4* e4 = (uint4*)ext;
         e4[0] = make_uint4(L, L, L, g[0]); e4[1] = make_uint4(g[1], g[2], R, R); ext[8] = R;
         const unsigned E0 = ext[(s_ >> 1)], E1 = ext[(s_ >> 1) + 1], E2 = ext[(s_ >> 1) + 2];
-        h[r][0] = d_dot2(E2, U0[2], d_dot2(E1, U0[1], d_dot2(E0, U0[0], 0)));
-        h[r][1] = d_dot2(E2, U1[2], d_dot2(E1, U1[1], d_dot2(E0, U1[0], 0)));
+        h[r][0] = d_dot2(E2, U0[2], d_dot2(E1, U0[1], d_dot2z(E0, U0[0])));
+        h[r][1] = d_dot2(E2, U1[2], d_dot2(E1, U1[1], d_dot2z(E0, U1[0])));
       }
     } else {
       const int xb = d_clip3(0, pw - 8, xa), s_ = d_clip3(0, 16, 8 + xa - xb);
@@ -860,8 +518,8 @@ __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int 
         e4[0] = make_uint4(L, L, g[0], g[1]); e4[1] = make_uint4(R, R, R, R);
         const unsigned E0 = ext[(s_ >> 2)], E1 = ext[(s_ >> 2) + 1];
         const unsigned A0 = __builtin_amdgcn_alignbyte(E1, E0, sh) ^ 0x80808080u, A1 = (E1 >> (8 * sh)) ^ 0x80808080u;
-        h[r][0] = d_dot4(A0, C0, 8192);
-        h[r][1] = d_dot4(A1, C2, d_dot4(A0, C1, 8192));
+        h[r][0] = d_dot4k(A0, C0, 8192);
+        h[r][1] = d_dot4(A1, C2, d_dot4k(A0, C1, 8192));
       }
     }
   } else if (sizeof(PIX) == 2) {
@@ -869,28 +527,28 @@ __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int 
     unsigned U0[3], U1[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { U0[k] = tl[k]; U1[k] = tl[3 + k]; }
-    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)LEAN_HOT_Y(yi - 1) * rstride + LEAN_HOT_X(xa & ~1);
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 1) * rstride + (xa & ~1);
     unsigned S[7][3];
 #pragma unroll
-    for (int r = 0; r < 7; r++) { LEAN_LD12(q, S[r]); q += rstride; }
+    for (int r = 0; r < 7; r++) { d_ldg12(q, S[r]); q += rstride; }
 #pragma unroll
     for (int r = 0; r < 7; r++) {
-      h[r][0] = d_dot2(S[r][2], U0[2], d_dot2(S[r][1], U0[1], d_dot2(S[r][0], U0[0], 0)));
-      h[r][1] = d_dot2(S[r][2], U1[2], d_dot2(S[r][1], U1[1], d_dot2(S[r][0], U1[0], 0)));
+      h[r][0] = d_dot2(S[r][2], U0[2], d_dot2(S[r][1], U0[1], d_dot2z(S[r][0], U0[0])));
+      h[r][1] = d_dot2(S[r][2], U1[2], d_dot2(S[r][1], U1[1], d_dot2z(S[r][0], U1[0])));
     }
   } else {
     const unsigned* tl = s_cl + xf * 4;
     const unsigned C0 = tl[0], C1 = tl[1], C2 = tl[2];
     const unsigned sh = (unsigned)xa & 3u;
-    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)LEAN_HOT_Y(yi - 1) * rstride + LEAN_HOT_X(xa & ~3);
+    const M355_GLOBAL PIX* q = rp + (ptrdiff_t)(yi - 1) * rstride + (xa & ~3);
     unsigned S[7][2];
 #pragma unroll
-    for (int r = 0; r < 7; r++) { LEAN_LD8(q, S[r]); q += rstride; }
+    for (int r = 0; r < 7; r++) { d_ldg8(q, S[r]); q += rstride; }
 #pragma unroll
     for (int r = 0; r < 7; r++) {
       const unsigned A0 = __builtin_amdgcn_alignbyte(S[r][1], S[r][0], sh) ^ 0x80808080u, A1 = (S[r][1] >> (8 * sh)) ^ 0x80808080u;
-      h[r][0] = d_dot4(A0, C0, 8192);
-      h[r][1] = d_dot4(A1, C2, d_dot4(A0, C1, 8192));
+      h[r][0] = d_dot4k(A0, C0, 8192);
+      h[r][1] = d_dot4(A1, C2, d_dot4k(A0, C1, 8192));
     }
   }
   h[7][0] = h[7][1] = 0;
@@ -910,26 +568,22 @@ __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int 
     int ve[2], vo[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      ve[j] = d_dot2(Q[m + 1][j], YE[1], d_dot2(Q[m][j], YE[0], 0));
-      vo[j] = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2(Q[m][j], YO[0], 0)));
+      ve[j] = d_dot2(Q[m + 1][j], YE[1], d_dot2z(Q[m][j], YE[0]));
+      vo[j] = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2z(Q[m][j], YO[0])));
     }
     pred[2 * m] = d_pack_mid16((unsigned)ve[0], (unsigned)ve[1]);
     pred[2 * m + 1] = d_pack_mid16((unsigned)vo[0], (unsigned)vo[1]);
   }
 }
 
-/* One job.  FAST: the PB's reference windows lie inside the picture horizontally (k_meta_pb sorts the
- * others into the EDGE job range, handled with clamped per-sample loads). */
-template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et, const DevRef* s_refs);
 /* One job of the lean kernels (bit depths <= 12).  MODE 0: windows inside the picture, no explicit weights: the lists are the workgroup's
  * (bi: wave-uniform) and the write-back is packed 16-bit arithmetic; 1: explicit weights — one or two lists per lane, the 32-bit
  * write-back; 2: EDGE — windows that leave the picture (clamped rows), weights per lane. */
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs);
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs, unsigned* s_touch);
 
 /* one launch for the main and the edge job range: blocks [0, nblk_edge8) take edge jobs */
-template <class PIX, bool BIAS, bool LEAN>
+template <class PIX>
 __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jobs(DevPic p)
 {
   M355_GATE(p);
@@ -946,7 +600,6 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
      i/per_b of another cover the same part of the picture): they then read the same reference region while it is still in that
      XCD's L2 — run one class after the other and every region is fetched twice, far apart in time. */
   const int b = blockIdx.x;
-  TLI(0);
   int cls, ji, jend;
   if (b < nblk_edge8) { cls = 3; ji = t2 + b * M355_INTER_BLOCK; jend = t3; }
   else {
@@ -974,219 +627,34 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     unsigned* dst = (unsigned*)s_refs;
     for (int i = threadIdx.x; i < (int)(sizeof(s_refs) / 4); i += M355_INTER_BLOCK) dst[i] = src[i];
   }
-  if (LEAN) {
-    __shared__ __attribute__((aligned(16))) unsigned s_tab[LT_WORDS];
-    if (threadIdx.x < LT_WORDS / 4) ((uint4*)s_tab)[threadIdx.x] = ((const uint4*)p.inter_tabs)[threadIdx.x];
-    uint32_t job = 0;
-    if (ji < jend) job = p.jobs[ji];          /* (requested beside the tables) */
-    TLI(1);
-    __syncthreads();
-    TLI(2);
-#ifdef M355_X_PROF
-    if (p.prof && threadIdx.x == 0 && blockIdx.x < 8100) p.prof[65536 + 6 * blockIdx.x + 5] = (unsigned long long)cls + 1;
-#endif
-    if (ji >= jend) return;
-#ifdef M355_X_INTER_LDS_PAD      /* experiment (tools/variants.sh): unused LDS that caps the workgroups per CU (in-flight footprint against the L2) */
-    __shared__ unsigned s_pad[M355_X_INTER_LDS_PAD / 4];
-    if (p.n_pbs < 0) s_pad[threadIdx.x] = 1;
-#endif
-    /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
-    __shared__ __attribute__((aligned(16))) unsigned s_ext[M355_INTER_BLOCK * 20];
-    unsigned* ext = s_ext + threadIdx.x * 20;
-    if (cls == 3) d_inter_job_lean<PIX, 2>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
-    else if (cls == 2) d_inter_job_lean<PIX, 1>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
-    else d_inter_job_lean<PIX, 0>(p, job, cls == 1, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
-    return;
-  }
-  __shared__ unsigned s_qt[4 * QT_STRIDE];
-  __shared__ unsigned s_et[8 * ET_STRIDE];
-  if (threadIdx.x < 4) {
-    const int8_t* t = c_qpel_taps[threadIdx.x];
-    unsigned* o = s_qt + threadIdx.x * QT_STRIDE;
-    for (int k = 0; k < 4; k++) o[k] = d_pack16(t[2 * k], t[2 * k + 1]);
-    o[4] = d_pack16(0, t[0]);
-    for (int k = 1; k < 4; k++) o[4 + k] = d_pack16(t[2 * k - 1], t[2 * k]);
-    o[8] = d_pack16(t[7], 0);
-  } else if (threadIdx.x >= 8 && threadIdx.x < 16) {
-    const int8_t* t = c_epel_taps[threadIdx.x - 8];
-    unsigned* o = s_et + (threadIdx.x - 8) * ET_STRIDE;
-    o[0] = d_pack16(t[0], t[1]); o[1] = d_pack16(t[2], t[3]);
-    o[2] = d_pack16(0, t[0]); o[3] = d_pack16(t[1], t[2]); o[4] = d_pack16(t[3], 0);
-  }
+  __shared__ __attribute__((aligned(16))) unsigned s_tab[LT_WORDS];
+  if (threadIdx.x < LT_WORDS / 4) ((uint4*)s_tab)[threadIdx.x] = ((const uint4*)p.inter_tabs)[threadIdx.x];
+  uint32_t job = 0;
+  if (ji < jend) job = p.jobs[ji];          /* (requested beside the tables) */
   __syncthreads();
   if (ji >= jend) return;
-  if (cls == 3) d_inter_job<PIX, BIAS, false>(p, p.jobs[ji], s_qt, s_et, s_refs);
-  else d_inter_job<PIX, BIAS, true>(p, p.jobs[ji], s_qt, s_et, s_refs);
-}
-
-template <class PIX, bool BIAS, bool FAST>
-__device__ __forceinline__ void d_inter_job(const DevPic& p, uint32_t job, const unsigned* s_qt, const unsigned* s_et, const DevRef* s_refs)
-{
-  const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
-  const int strip = (job >> 25) & 15, rblk = job >> 29;
-  const int x0 = pb.x + 4 * strip, y0 = pb.y + 8 * rblk;
-  const int rows = min(8, pb.h - 8 * rblk);          /* 4 or 8 */
-  /* PB index plane for the deblocking filter's motion comparison (pb_info): this job's two 4x4 units */
-  {
-    uint32_t* po = p.pb_of + (size_t)(y0 >> 2) * p.w4 + (x0 >> 2);
-    po[0] = (job & 0x1FFFFFFu) + 1;
-    if (rows > 4) po[p.w4] = (job & 0x1FFFFFFu) + 1;
-  }
-  const bool mc0 = pb.flags & M355_PBF_MC_L0, mc1 = pb.flags & M355_PBF_MC_L1;
-  const bool bi = mc0 && mc1;
-  const int npass = bi ? 2 : 1;
-  /* pass 0 = the first (or only) list, pass 1 = L1 of a bi-predicted block; selected without indexing
-     the record dynamically (that would push it out of registers) */
-  const bool a1 = !mc0;
-  const int refA = a1 ? pb.ref_slot[1] : pb.ref_slot[0], mvxA = a1 ? pb.mv[1][0] : pb.mv[0][0], mvyA = a1 ? pb.mv[1][1] : pb.mv[0][1];
-  const bool fillA = pb.flags & (a1 ? M355_PBF_FILL_L1 : M355_PBF_FILL_L0), fillB = pb.flags & M355_PBF_FILL_L1;
-  const bool weighted = (pb.flags & M355_PBF_WEIGHTED) != 0;
-  const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
-  const int nc = p.pp.chroma_format_idc ? 3 : 1;
-
-  /* weights of the job's component c (WtSel above).  Called in the write-back, behind the filter loops: the two weight records
-     (8 registers) and the selection (5) are not carried through them — registers are what the loops are short of, and a
-     spilled one is scratch traffic on the same memory path the kernel is bound by */
-  auto make_ws = [&](int c, int bd) {
-    WtSel ws;
-    m355_wt wa, wb;
-    if (weighted) { wa = p.wts[wtA]; wb = p.wts[wtB]; }
-    const int shift3 = max(2, 14 - bd), shift2 = max(3, 15 - bd);
-    ws.w0 = 1; ws.w1 = bi ? 1 : 0; ws.o = 0;
-    ws.sh = bi ? shift2 : shift3; ws.rnd = 1 << (ws.sh - 1);
-    if (weighted) {
-      const int o0 = c == 0 ? wa.o[0] : (c == 1 ? wa.o[1] : wa.o[2]), o1 = c == 0 ? wb.o[0] : (c == 1 ? wb.o[1] : wb.o[2]);
-      const int log2WD = c ? wa.log2wd_chroma : wa.log2wd_luma;
-      ws.w0 = c == 0 ? wa.w[0] : (c == 1 ? wa.w[1] : wa.w[2]);
-      ws.w1 = bi ? (c == 0 ? wb.w[0] : (c == 1 ? wb.w[1] : wb.w[2])) : 0;
-      ws.rnd = bi ? (int)((unsigned)(o0 + o1 + 1) << log2WD) : (1 << (log2WD - 1));
-      ws.sh = bi ? log2WD + 1 : log2WD;
-      ws.o = bi ? 0 : o0;
-    }
-    return ws;
-  };
-
-  /* ---- luma ---- */
-  {
-    const int bd = p.pp.bit_depth_luma;
-    const int pw = p.pw[0], ph = p.ph[0];
-    unsigned pa[8][2];
-#pragma unroll
-    for (int y = 0; y < 8; y++) { pa[y][0] = 0; pa[y][1] = 0; }
-#pragma unroll 1
-    for (int pass = 0; pass < npass; pass++) {
-      unsigned cur[8][2];
-      if (pass ? fillB : fillA) {        /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
-#pragma unroll
-        for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
-      } else {
-        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
-        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-        d_mc_luma_4x8<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0],
-#ifdef M355_X_TILED
-                                       (const M355_GLOBAL PIX*)ref->tiled[0], ref->trs[0],
-#endif
-                                       pw, ph, x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, bd, s_qt, cur);
-      }
-      if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
-#pragma unroll
-        for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
-        continue;
-      }
-      M355_COMPILER_FENCE();          /* the weight loads must not be hoisted into the filter loops */
-      const WtSel ws = make_ws(0, bd);
-      PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
-#pragma unroll
-      for (int y = 0; y < 8; y++) {
-        if (y >= rows) break;
-        unsigned o[4];
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-          const unsigned a = bi ? pa[y][x >> 1] : cur[y][x >> 1], b = cur[y][x >> 1];
-          o[x] = (unsigned)d_wpred(ws, (x & 1) ? d_hi16s(a) : d_lo16s(a), (x & 1) ? d_hi16s(b) : d_lo16s(b), bd);
-        }
-        /* streaming stores (k_asm.h): -4 % kernel time, -10 % fabric fetch (profiles/r02_b_inter_variants.txt) */
-        if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-        else d_st_nt4(d + (size_t)y * p.stride[0], o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24));
-      }
-    }
-  }
-  if (nc == 1) return;
-
-  /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are
-     in flight together (one memory latency per list instead of two); chroma mv = luma mv in 1/8 pel
-     (motion.cc:196-203) ---- */
-  {
-    const int bd = p.pp.bit_depth_chroma;
-    const int pw = p.pw[1], ph = p.ph[1];
-    const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
-    unsigned pa1[4], pa2[4];
-#pragma unroll
-    for (int y = 0; y < 4; y++) { pa1[y] = 0; pa2[y] = 0; }
-#pragma unroll 1
-    for (int pass = 0; pass < npass; pass++) {
-      unsigned cur1[4], cur2[4];
-      if (pass ? fillB : fillA) {
-#pragma unroll
-        for (int y = 0; y < 4; y++) { cur1[y] = 0x20002000u; cur2[y] = 0x20002000u; }
-      } else {
-        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
-        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1],
-#ifdef M355_X_TILED
-                                         (const M355_GLOBAL PIX*)ref->tiled[1], ref->trs[1],
-#endif
-                                         pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur1);
-        d_mc_chroma_2x4<PIX, BIAS, FAST>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2],
-#ifdef M355_X_TILED
-                                         (const M355_GLOBAL PIX*)ref->tiled[2], ref->trs[2],
-#endif
-                                         pw, ph, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, bd, s_et, cur2);
-      }
-      if (pass + 1 < npass) {
-#pragma unroll
-        for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
-        continue;
-      }
-      M355_COMPILER_FENCE();
-      const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
-      PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
-      PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
-#pragma unroll
-      for (int y = 0; y < 4; y++) {
-        if (y >= crows) break;
-        {
-          const unsigned a = bi ? pa1[y] : cur1[y], b = cur1[y];
-          const unsigned o0 = (unsigned)d_wpred(ws1, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws1, d_hi16s(a), d_hi16s(b), bd);
-          if (sizeof(PIX) == 2) d_st_nt4(d1 + (size_t)y * p.stride[1], o0 | (o1 << 16));
-          else *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)(o0 | (o1 << 8));
-        }
-        {
-          const unsigned a = bi ? pa2[y] : cur2[y], b = cur2[y];
-          const unsigned o0 = (unsigned)d_wpred(ws2, d_lo16s(a), d_lo16s(b), bd), o1 = (unsigned)d_wpred(ws2, d_hi16s(a), d_hi16s(b), bd);
-          if (sizeof(PIX) == 2) d_st_nt4(d2 + (size_t)y * p.stride[2], o0 | (o1 << 16));
-          else *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)(o0 | (o1 << 8));
-        }
-      }
-    }
-  }
+  /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
+  __shared__ __attribute__((aligned(16))) unsigned s_ext[M355_INTER_BLOCK * 20];
+  unsigned* ext = s_ext + threadIdx.x * 20;
+  __shared__ unsigned s_touch[64];      /* landing area of the window-row touches (d_touch): never read */
+  if (cls == 3) d_inter_job_lean<PIX, 2>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs, s_touch);
+  else if (cls == 2) d_inter_job_lean<PIX, 1>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs, s_touch);
+  else d_inter_job_lean<PIX, 0>(p, job, cls == 1, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs, s_touch);
 }
 
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs)
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs, unsigned* s_touch)
 {
   constexpr bool WEIGHTED = MODE != 0, EDGE = MODE == 2;
   const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
   const int strip = (job >> 25) & 15, rblk = job >> 29;
   const int x0 = pb.x + 4 * strip, y0 = pb.y + 8 * rblk;
   const int rows = min(8, pb.h - 8 * rblk);          /* 4 or 8 */
-#ifndef M355_X_INTER_NOPBOF
   {
     uint32_t* po = p.pb_of + (size_t)(y0 >> 2) * p.w4 + (x0 >> 2);
     po[0] = (job & 0x1FFFFFFu) + 1;
     if (rows > 4) po[p.w4] = (job & 0x1FFFFFFu) + 1;
   }
-#endif
   const bool mc0 = pb.flags & M355_PBF_MC_L0;
   const bool bi = WEIGHTED ? (mc0 && (pb.flags & M355_PBF_MC_L1)) : bi_u;
   const int npass = bi ? 2 : 1;
@@ -1235,6 +703,32 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
     return bi ? t : d_pk_min_i16(t, maxv);
   };
 
+#ifdef M355_X_TOUCH
+  /* EXPERIMENT: request the window rows that the software pipeline asks for late — luma rows beyond its first pairs, (level 2) the chroma rows of the
+     same list, (level 3) the second list's as well — with loads that land in LDS scratch (no register, nothing waits): the lines are on their way
+     while the first rows are filtered */
+  auto touch_list = [&](int pass) {
+    if (EDGE || (pass ? fillB : fillA)) return;
+    const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+    const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+    {
+      const int xa = x0 + (mvx >> 2) - 3;
+      const M355_GLOBAL PIX* q = (const M355_GLOBAL PIX*)ref->plane[0] + (ptrdiff_t)(y0 + (mvy >> 2) - 3) * ref->stride[0] + (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3));
+#pragma unroll
+      for (int r = 2 * M355_INTER_PIPE; r < 15; r++) d_touch((const void*)(q + (ptrdiff_t)r * ref->stride[0]), s_touch);
+    }
+    if (M355_X_TOUCH >= 2 && nc == 3) {
+      const int xa = (x0 >> 1) + (mvx >> 3) - 1;
+#pragma unroll
+      for (int c = 1; c < 3; c++) {
+        const M355_GLOBAL PIX* q = (const M355_GLOBAL PIX*)ref->plane[c] + (ptrdiff_t)((y0 >> 1) + (mvy >> 3) - 1) * ref->stride[c] + (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3));
+#pragma unroll
+        for (int r = 0; r < 7; r++) d_touch((const void*)(q + (ptrdiff_t)r * ref->stride[c]), s_touch);
+      }
+    }
+  };
+  if (M355_X_TOUCH >= 3) { touch_list(0); if (bi) touch_list(1); }
+#endif
   /* ---- luma ---- */
   {
     const int bd = sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_luma;
@@ -1250,6 +744,9 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       } else {
         const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
         const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+#ifdef M355_X_TOUCH
+        if (M355_X_TOUCH < 3) touch_list(pass);
+#endif
         d_mc_luma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], p.pw[0], p.ph[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, ext, cur);
       }
       if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
@@ -1281,16 +778,12 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
           if (y >= rows) break;
           unsigned o0 = pk_pred(pa[y][0], cur[y][0], rnd, sh, maxv), o1 = pk_pred(pa[y][1], cur[y][1], rnd, sh, maxv);
           /* streaming stores (k_asm.h): -4 % kernel time, -10 % fabric fetch (profiles/r02_b_inter_variants.txt) */
-#ifdef M355_X_INTER_NOSTORE
-          if ((o0 ^ o1) != 0x9E3779B9u) continue;
-#endif
           if (sizeof(PIX) == 2) d_st_nt8(d + (size_t)y * p.stride[0], o0, o1);
           else d_st_nt4(d + (size_t)y * p.stride[0], d_pack_bytes(o0, o1));
         }
       }
     }
   }
-  TLI(3);
   if (nc == 1) return;
 
   /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are in flight together;
@@ -1343,9 +836,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
         for (int y = 0; y < 4; y++) {
           if (y >= crows) break;
           unsigned o1 = pk_pred(pa1[y], cur1[y], rnd, sh, maxv), o2 = pk_pred(pa2[y], cur2[y], rnd, sh, maxv);
-#ifdef M355_X_INTER_NOSTORE
-          if ((o1 ^ o2) != 0x9E3779B9u) continue;
-#endif
           if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
           else {
             *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
@@ -1355,62 +845,27 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       }
     }
   }
-  TLI(4);
 }
 
-template <class PIX, bool BIAS, bool LEAN>
+template <class PIX>
 static void launch_jobs(const DevPic& p, hipStream_t st)
 {
   /* each range's blocks are padded to a multiple of 8 for the XCD-contiguous block order; the counts are on the device, so the
      grid covers the most jobs the list can hold */
   const unsigned grid = (unsigned)((p.jobs_cap + M355_INTER_BLOCK - 1) / M355_INTER_BLOCK) + 4 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX, BIAS, LEAN>), dim3(grid), dim3(M355_INTER_BLOCK), 0, st, p);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_jobs<PIX>), dim3(grid), dim3(M355_INTER_BLOCK), 0, st, p);
 }
 
 void m355_launch_inter(const DevPic& p, bool hbd, hipStream_t st)
 {
   if (!p.n_pbs) return;
-  if (p.pp.chroma_format_idc <= 1) {
-    const int bdmax = max(p.pp.bit_depth_luma, p.pp.bit_depth_chroma);
-#ifdef M355_INTER_NO_LEAN                     /* A/B builds (tools/variants.sh): every class through the general filters */
-    if (!hbd) launch_jobs<uint8_t, false, false>(p, st);
-    else if (bdmax < 16) launch_jobs<uint16_t, false, false>(p, st);
-#else
-    /* (the lean EDGE path fetches 12 / 16 luma and 6 / 8 chroma samples of a row with one vector load: pictures narrower than that keep the general kernels) */
-    const bool wide = p.pw[0] >= 16 && (p.pp.chroma_format_idc == 0 || p.pw[1] >= 8);
-    if (!hbd && wide) launch_jobs<uint8_t, false, true>(p, st);
-    else if (hbd && bdmax <= 12 && wide) launch_jobs<uint16_t, false, true>(p, st);            /* the lean filters (folds exact for bit depths <= 12) */
-    else if (!hbd) launch_jobs<uint8_t, false, false>(p, st);
-#endif
-    else if (bdmax == 16) launch_jobs<uint16_t, true, false>(p, st);
-    else launch_jobs<uint16_t, false, false>(p, st);
+  /* the job kernels: 4:2:0 / monochrome at bit depths up to 12 (every BASELINE configuration); everything else — 4:2:2 / 4:4:4, deeper planes,
+     pictures narrower than one vector load — takes the one-wave-per-PB kernel, whose arithmetic is the reference's as written (m355_inter_uses_jobs, k_common.h) */
+  if (m355_inter_uses_jobs(p)) {
+    if (hbd) launch_jobs<uint16_t>(p, st); else launch_jobs<uint8_t>(p, st);
     return;
   }
   const dim3 grid((p.n_pbs + 3) / 4), block(256);
   if (hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_generic<uint16_t>), grid, block, 0, st, p);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_inter_generic<uint8_t>), grid, block, 0, st, p);
 }
-
-#ifdef M355_X_TILED
-/* EXPERIMENT: linear plane -> tiled copy with aprons (k_common.h DevRef).  One thread per sample pair of the tiled copy; columns
-   beyond the picture repeat its last sample (never used with a non-zero tap). */
-template <class PIX>
-__global__ void __launch_bounds__(256) k_tile_convert(const PIX* __restrict__ src, int stride, int pw, int ph, int row_len, PIX* __restrict__ dst, int tiles_w)
-{
-  const int per_row = tiles_w * row_len;                       /* samples of one picture row in the tiled copy */
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
-  if (i >= per_row || y >= ph) return;
-  const int tx = i / row_len, e = i - tx * row_len;
-  const PIX* r = src + (size_t)y * stride;
-  PIX* o = dst + ((size_t)((y >> M355_TILE_LH) * tiles_w + tx) * M355_TILE_H + (y & (M355_TILE_H - 1))) * row_len + e;
-  o[0] = r[min(tx * M355_TILE_W + e, pw - 1)];
-  o[1] = r[min(tx * M355_TILE_W + e + 1, pw - 1)];
-}
-void m355_launch_tile_convert(const void* src, int stride, int pw, int ph, int bpp, bool chroma, void* dst, int tiles_w, hipStream_t st)
-{
-  const int row_len = chroma ? M355_TILE_ROW_C : M355_TILE_ROW_L;
-  const dim3 grid((tiles_w * row_len / 2 + 255) / 256, ph);
-  if (bpp == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_convert<uint16_t>), grid, dim3(256), 0, st, (const uint16_t*)src, stride, pw, ph, row_len, (uint16_t*)dst, tiles_w);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_convert<uint8_t>), grid, dim3(256), 0, st, (const uint8_t*)src, stride, pw, ph, row_len, (uint8_t*)dst, tiles_w);
-}
-#endif

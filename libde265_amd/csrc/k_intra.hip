@@ -140,10 +140,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
   /* the halo keeper's slots (below): granule address and halo element per lane and slot */
   __shared__ uint32_t s_kp_idx[(DENSE && NW == M355_INTRA_KEEPER_NW) ? 5 * 64 : 1];      /* (an index into DevPic.edge: the load stays a GLOBAL one — a pointer out of LDS makes it flat, and a flat load also counts as an LDS operation, which the wave waits for in front of every barrier) */
   __shared__ uint16_t s_kp_h1[(DENSE && NW == M355_INTRA_KEEPER_NW) ? 5 * 64 : 1];
-#ifdef M355_X_INTRA_LDS_PAD      /* experiment (tools/variants.sh): what does a workgroup less per CU cost the sparse kernel? */
-  __shared__ uint32_t s_pad[DENSE ? 1 : M355_X_INTRA_LDS_PAD / 4];
-  if (threadIdx.x == 0 && work_n < 0) s_pad[work_n & 1] = 1;
-#endif
 
   /* everything derived from the wave index or from a block record is wave-uniform: say so (readfirstlane / readlane), so that
      the component's plane pointers, pitches and granule offsets are scalar loads from the kernel arguments instead of vector
@@ -177,19 +173,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
     /* a shorter picture's list is exhausted, or its lists were rejected (k_validate): nothing to do for this ticket */
     if (item >= p.n_intra_work || p.timeout[1] == p.epoch) { __syncthreads(); continue; }
   } else if (item >= work_n) return;
-#ifdef M355_X_PROF      /* experiment builds (tools/prof_timeline.py): when a CTB was claimed, started its block loop, ended it, was written out */
-#define TL(k) do { if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item + 1 + (k)] = wall_clock64(); } while (0)
-/* (M355_X_PROF_TLP = 1 .. 4: stamp 1 is taken inside the prologue instead of at the block loop's start — behind the plan, the residuals, the need scan's
-   barrier, the staging — to see which of its round trips the prologue's time is) */
-#ifndef M355_X_PROF_TLP
-#define M355_X_PROF_TLP 0
-#endif
-#define TLP(k) do { if (M355_X_PROF_TLP == (k)) TL(1); } while (0)
-#else
-#define TL(k) do { } while (0)
-#define TLP(k) do { } while (0)
-#endif
-  TL(0);
   /* the CTB's descriptor (host-prepared, runtime.hip): one scalar 32-byte load */
   const DevIntraWork* wp = p.intra_work + item;
   const uint4 wd0 = *(const uint4*)wp;
@@ -296,7 +279,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
     for (uint32_t o = (uint32_t)(wv * 64 + lane) * 8u; o < n; o += (uint32_t)NWV * 512u) *(uint4*)(s_plan + o) = src[o >> 3];
   }
   if (EARLY) halo_who();                                   /* (the CU indices came in with the plan) */
-  TLP(1);
 
   /* ---- residual pre-pass: the CTB's deferred residuals go to LDS, each component's waves taking its blocks in turn (inter
      pictures too: a block of the chain then reads its residual from LDS, where it paid a global-memory round trip — and the
@@ -360,7 +342,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
       }
     }
   }
-  TLP(2);
   /* ---- which body vectors does some block's border read?  Only those are staged: the row above a block
      (x-1 .. x+2nT-1) and the column left of it (y .. y+2nT-1), intrapred.h:436-674 — a 64x64 CTB with two 8x8 intra
      blocks: ~6 of its 512 luma vectors — and of those only what no intra block of this CTB produces itself (s_cover:
@@ -412,7 +393,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
     }
   }
   SYNC_CTB();
-  TLP(3);
   if (comp) {
     /* ---- halo: the row above the CTB (x = -1 .. 2cw-1) and the column left of it, only the entries some block's border reads
        (s_hneed).  A sample that an INTRA block of a neighbour CTB produces comes from that CTB's granules — if it is there already;
@@ -492,7 +472,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
       if (htop[u]) halo[h] = (uint16_t)val; else halo[HALO_TOP_N + h - (2 * cw + 1)] = (uint16_t)val;
     }
   }
-  TLP(4);
   __syncthreads();     /* bodies, halos, residuals and the plan staged */
   /* ---- the HALO KEEPER (intra pictures, the workgroup's last wave): a CTB's halo is staged long before its neighbours have
      finished (the prologue is off the chain), so nearly every sample a block reads from another CTB is still HALO_NOT_READY there,
@@ -556,10 +535,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
     for (int k = 0; k < KSLOTS; k++)
       if ((kp_pend >> k) & 1u) kp_gr[k] = __hip_atomic_load(p.edge + gi[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  TLP(0);
-#ifdef M355_X_PROF
-  if (p.prof && threadIdx.x == 0 && item < 9000) p.prof[8200 + 5 * item] = (unsigned long long)ctb + 1;
-#endif
   /* The CTB's exec records (runtime_upload.hip intra_schedule: sorted by level, then component; everything about a block that is not a
      sample value) are fetched 64 at a time (one per lane, 16 bytes, coalesced) by EVERY wave.  A wave's blocks of the batch —
      those of its component whose rank inside their (level, component) group falls to it — are one 64-bit mask; it walks them
@@ -651,17 +626,7 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
     };
     fetch_next();
     bool pend = false;                                       /* the next block is still to be fetched (done behind the barrier) */
-#ifdef M355_X_PROF
-#define PROF_T(k) do { if (prof_on) pt[k] = __builtin_readcyclecounter(); } while (0)
-#ifndef M355_X_PROF_WAVE
-#define M355_X_PROF_WAVE 0
-#endif
-    const bool prof_on = p.prof != nullptr && item == M355_X_PROF && wv == M355_X_PROF_WAVE;
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
-    if (prof_on && kbase == 0 && lane == 0) { p.prof[0] = __builtin_readcyclecounter(); p.prof[1] = wall_clock64(); }
-#else
 #define PROF_T(k) do { } while (0)
-#endif
     for (int L = lv_first; L <= lv_last; L++) {
     PROF_T(0);
     if (pend) { fetch_next(); pend = false; }
@@ -928,20 +893,10 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
     PROF_T(3);
     SYNC_CTB();
     PROF_T(4);
-#ifdef M355_X_PROF
-    if (prof_on && lane == 0) {
-      const int slot = 4 + 8 * (int)(p.prof[3]++ & 1023);
-      for (int k = 0; k < 5; k++) p.prof[slot + k] = pt[k];
-      p.prof[slot + 5] = (unsigned long long)L | ((unsigned long long)kbase << 32);
-      p.prof[2] = wall_clock64();
-    }
-    pt[1] = pt[2] = 0;
-#endif
     /* level done: its samples are in LDS for the next level's borders (one wave per component: its own blocks are ordered
        by the wave-level sync; components do not interact) */
     }   /* levels in the batch */
   }   /* 64-record batches */
-  TL(2);
   /* ---- the CTB's intra samples -> the picture: every 4x4 unit some intra block covered (s_cover), one 4-sample row piece per
      lane, neighbouring lanes on neighbouring pieces of a row (the last level's barrier / wave_sync made them all visible) ---- */
   if (comp) {
@@ -956,7 +911,6 @@ __global__ void __launch_bounds__(64 * NW) M355_WAVES_PER_EU((DENSE || CF >= 2) 
       else *(uint32_t*)dst = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y & 0xFF0000u) << 8);
     }
   }
-  TL(3);
   if (!DENSE) return;
   __syncthreads();     /* the LDS tiles (and the ticket word) are free for the workgroup's next CTB */
   }   /* persistent workgroup: next CTB */

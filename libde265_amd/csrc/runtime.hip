@@ -12,10 +12,6 @@
 #include "runtime_internal.h"
 
 thread_local std::string g_err;
-#ifdef M355_X_PROF
-unsigned long long* g_prof = nullptr;
-extern "C" __attribute__((visibility("default"))) int m355_x_prof_read(unsigned long long* out, int n) { return g_prof ? (int)hipMemcpy(out, g_prof, 8 * (size_t)n, hipMemcpyDeviceToHost) : -1; }
-#endif
 int fail(int code, const char* fmt, ...)
 {
   char buf[512];
@@ -330,9 +326,6 @@ int m355_frame_upload(m355_ctx* c, int h, int cidx, const void* src, ptrdiff_t s
   if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-#ifdef M355_X_TILED
-  f->tiled_valid = false;
-#endif
   HIPCHK(hipMemcpy2D(f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx], src, (size_t)stride * f->bpp[cidx],
                      (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyHostToDevice));
   return M355_OK;
@@ -401,9 +394,6 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
   if (!f) return fail(M355_ERR_INVALID, "bad frame handle %d", h);
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-#ifdef M355_X_TILED
-  f->tiled_valid = false;
-#endif
   for (int cc = 0; cc < 3; cc++) {
     if (!f->pw[cc]) continue;
     const size_t n = (size_t)f->stride[cc] * f->ph[cc];

@@ -30,19 +30,6 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
       return fail(M355_ERR_INVALID, "reference frame %d geometry differs (motion.cc:377-398 would conceal; record FILL instead)", i);
     if (f == dst) return fail(M355_ERR_INVALID, "a picture cannot reference itself");
     for (int cc = 0; cc < 3; cc++) { refs[i].plane[cc] = f->plane[cc]; refs[i].stride[cc] = f->stride[cc]; }
-#ifdef M355_X_TILED
-    for (int cc = 0; cc < 3; cc++) {
-      if (!f->pw[cc]) continue;
-      const int row_len = cc ? M355_TILE_ROW_C : M355_TILE_ROW_L;
-      if (!f->tiled[cc]) {
-        f->tiles_w[cc] = (f->pw[cc] + M355_TILE_W - 1) / M355_TILE_W;
-        const size_t bytes = (size_t)((f->ph[cc] + M355_TILE_H - 1) / M355_TILE_H) * f->tiles_w[cc] * M355_TILE_H * row_len * f->bpp[cc] + 256;
-        HIPCHK(hipMalloc(&f->tiled[cc], bytes));
-        f->tiled_valid = false;
-      }
-      refs[i].tiled[cc] = f->tiled[cc]; refs[i].trs[cc] = f->tiles_w[cc] * M355_TILE_H * row_len;
-    }
-#endif
     refs[i].valid = 1;
     d.ref_valid |= 1u << i;
   }
@@ -104,7 +91,7 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
   size_t res_tiles = 0;
   for (int s = 0; s < 4; s++) { d.res_tile_base[s] = (uint32_t)res_tiles; res_tiles += (size_t)pic.rb_count[s] << (2 * (s + 2)); }
   /* (pictures of a one-stream lane only — up to 4K, launch_prediction: an 8K picture's kernels fill the GPU, its transforms gain nothing in front) */
-  const bool tiles = (c->depth >= 3 || chain_residuals_forced()) && (long long)pic.pp.width * pic.pp.height <= 16ll << 20;
+  const bool tiles = (c->depth >= sched::chain_residual_tiles_min_depth || chain_residuals_forced()) && (long long)pic.pp.width * pic.pp.height <= sched::one_stream_max_samples;
   const size_t res_need = res_intra + (tiles ? res_tiles : 0) + 1;
   if ((rc = grow(&c->resbuf, &c->cap_res, res_need, c->stream, false))) return rc;
   d.res_tiles = tiles ? c->resbuf + res_intra : nullptr;     /* (resbuf itself: below, with the lane's other scratch) */
@@ -141,17 +128,8 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
   d.edge_tu = c->edge_tu; d.edge_pb = c->edge_tu + (size_t)d.w4 * d.h4;
   d.cb_cu = (uint32_t*)(c->edge_tu + (((size_t)2 * d.w4 * d.h4 + 63) & ~(size_t)63));
   d.cuf = c->cuf; d.pb_of = c->pb_of;
-  d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && pp.chroma_format_idc <= 1) ? 0 : 1;   /* else k_inter_jobs writes it */
+  d.fill_pb_of_in_meta = ((c->stages & M355_STAGE_INTER) && m355_inter_uses_jobs(d)) ? 0 : 1;   /* else k_inter_jobs writes it */
   d.jobs = c->jobs; d.sao_nb = c->sao_nb; d.iplan = c->iplan;
-#ifdef M355_X_PROF
-  {
-    static unsigned long long* prof = nullptr;
-    if (!prof) { hipMalloc(&prof, 8 * 131072); }
-    hipMemsetAsync(prof, 0, 8 * 131072, c->stream);
-    d.prof = prof;
-    g_prof = prof;
-  }
-#endif
   d.resbuf = c->resbuf; d.edge = c->edge; d.ticket = c->ticket; d.timeout = c->timeout;
   {
     /* intra pictures: k_intra's workgroups are persistent (k_intra.hip); with several pictures in flight every picture gets a
@@ -163,7 +141,7 @@ int prepare(m355_ctx* c, Resident& r, DevPic& d_out, bool& want_sao_out) {
     /* the halo keeper (a 13th wave per workgroup, k_intra.hip) pays when the picture's own chain is all there is: with more pictures
        in flight their kernels fill the waits, and a 13-wave workgroup at 128 registers leaves no room on its CU for the 4-wave
        workgroups of the other pictures' kernels (C2, three in flight: 0.468 -> 0.536 ms per picture, profiles/r05_v14_*) */
-    d.intra_keeper = c->depth == 1;
+    d.intra_keeper = c->depth <= sched::intra_keeper_max_depth;
     if (!d.intra_keeper && r.dp.intra_dense) {
       /* ... or when nothing else is in flight right now, whatever the depth: the intra picture a stream's other pictures wait for */
       bool idle = true;
@@ -220,14 +198,14 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
      scatters and the second residual launch beside the main stream — is worth less than that once the kernels are short (three in
      flight, profiles/r04_al_*: C3 / C4 0.110 -> 0.098 / 0.100 ms on one stream, C5 0.347 -> 0.351); one intra picture at a time with its
      planes forked beside the residuals: 0.881 -> 0.896 ms (profiles/r05_v20_*) */
-  const bool single = d.intra_dense || (long long)d.pp.width * d.pp.height <= 16ll << 20;
+  const bool single = d.intra_dense || (long long)d.pp.width * d.pp.height <= sched::one_stream_max_samples;
   hipStream_t s2 = single ? st : c->stream2;
   /* the zero fill of the metadata planes rides in the picture's first main-stream launch (k_job_count), in FRONT of the fork: the
      side stream's scatters then start behind it — one launch less per inter picture */
   /* (the fill is shared out over the launch's workgroups, one per 256 PBs: with a handful of them a fill of its own is faster;
      M355_CLEAR_IN_COUNT_MIN=<PBs> moves the threshold: tests/test_meta_merged_emu.py sends the CPU tier's small pictures down this path —
      and through the merged planes + job-list launch behind it — with 1) */
-  static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : 64 * 256;
+  static const int clear_min = getenv("M355_CLEAR_IN_COUNT_MIN") ? atoi(getenv("M355_CLEAR_IN_COUNT_MIN")) : sched::clear_in_count_min_pbs;
   const bool clear_in_count = d.n_pbs >= std::max(1, clear_min);
   bool tu_plan_with_residuals = false;
   /* a dependent chain's picture (`chain`: decode_pre) transforms its residuals in its FRONT part — they do not depend on the reference —, as int16 tiles
@@ -246,7 +224,7 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
        decodes one picture at a time: C3 0.1494 -> 0.1427 ms, C4 0.1627 -> 0.1564.  With lanes they stay a launch of their own in FRONT of k_inter, where
        other pictures' kernels — or, for a chain's picture, its reference's last stages — run beside them: merged, C3 0.0688 -> 0.0697 ms with three in
        flight and a chain's picture 0.132 -> 0.136, C4 0.147 -> 0.156: profiles/r05_v30_*) */
-    if (c->depth == 1 && (c->stages & M355_STAGE_RESIDUAL) && !res_front) tu_plan_with_residuals = true; else m355_launch_tu_plan(d, st);
+    if (c->depth <= sched::tu_plan_in_residuals_max_depth && (c->stages & M355_STAGE_RESIDUAL) && !res_front) tu_plan_with_residuals = true; else m355_launch_tu_plan(d, st);
   } else {
     if (c->stages & M355_STAGE_INTRA) {
       m355_launch_meta_planes(d, s2, clear_in_count, false);
@@ -292,19 +270,6 @@ void launch_prediction(m355_ctx* c, const Resident& r, const DevPic& d, bool hbd
       Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
       if (f) ev_wait(c, st, f->wr);
     }
-#ifdef M355_X_TILED
-  if ((c->stages & M355_STAGE_INTER) && d.n_pbs)
-    for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {
-      Frame* f = r.hdr.ref_frames[i] >= 0 ? get_frame(c, r.hdr.ref_frames[i]) : nullptr;
-      if (!f || !f->tiled[0]) continue;
-      if (!f->tiled_valid) {                 /* the conversion pass (its time is the experiment's cost side: k_tile_convert in the kernel trace) */
-        for (int cc = 0; cc < 3; cc++) if (f->pw[cc]) m355_launch_tile_convert(f->plane[cc], f->stride[cc], f->pw[cc], f->ph[cc], f->bpp[cc], cc != 0, f->tiled[cc], f->tiles_w[cc], st);
-        if (!f->ev_tiled) hipEventCreateWithFlags(&f->ev_tiled, hipEventDisableTiming);
-        hipEventRecord(f->ev_tiled, st);
-        f->tiled_valid = true;
-      } else if (f->ev_tiled) hipStreamWaitEvent(st, f->ev_tiled, 0);
-    }
-#endif
   if (c->stages & M355_STAGE_INTER) m355_launch_inter(d, hbd, st);
   if (ev) hipEventRecord(ev[2], st);
   if ((c->stages & M355_STAGE_RESIDUAL) && !res_front) launch_residuals(d);
@@ -358,7 +323,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
       /* three lanes and more: the front part alternates between the lanes that are not the chain's (two scratch sets: the one a picture's back part
          still uses and the one the next front part fills); two lanes: the whole picture on the chain's own lane — with one lane to spare the front
          part would wait for the scratch of the picture before it and bring the cross-queue waits back (C3 0.162 -> 0.178 ms, profiles/r05_v27_*) */
-      const bool split = c->depth >= 3;
+      const bool split = c->depth >= sched::chain_split_min_depth;
       for (int k = 0; k < c->depth; k++) {
         const int l = (c->active + 1 + k) % c->depth;
         if (((l == c->active ? c->stream : c->lanes[l].stream) != chain) == split) { lane = l; break; }
@@ -371,7 +336,7 @@ static int decode_pre(m355_ctx* c, Resident& r, bool rotate, DecodeState& S, int
      inside one kernel, not through hardware queues) */
   {
     hipStream_t run = on_stream ? on_stream : c->stream;   /* (a batch on a stream of its own: its lanes lend their scratch only) */
-    if (!on_stream && with_intra && r.dp.intra_dense && c->active >= 3 && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
+    if (!on_stream && with_intra && r.dp.intra_dense && c->active >= sched::intra_class_first_lane && lane_priorities_mode() == 2 && lane_class_priority(c->active) != 0) {
       if (!c->stream_hi) HIPCHK(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, lane_class_priority(c->active)));
       run = c->stream_hi;
     }
@@ -439,9 +404,6 @@ static int decode_post(m355_ctx* c, Resident& r, DecodeState& S, bool filters = 
     if (rcm) return rcm;
   }
   r.done = done; r.fresh = false;
-#ifdef M355_X_TILED
-  dstf->tiled_valid = false;
-#endif
   dstf->wr_stream = st;
   dstf->wr = done;
   for (int i = 0; i < M355_MAX_REF_FRAMES; i++) {

@@ -32,9 +32,6 @@
 
 
 extern thread_local std::string g_err;
-#ifdef M355_X_PROF
-extern unsigned long long* g_prof;
-#endif
 int fail(int code, const char* fmt, ...);     /* sets the thread's last error text, returns `code` */
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(M355_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
@@ -42,6 +39,33 @@ int fail(int code, const char* fmt, ...);     /* sets the thread's last error te
 #define M355_BATCH_RING 16 /* m355_decode_batch: picture-record arrays in flight (the host runs this many batches ahead) */
 #define M355_MAX_LANES 32  /* pictures in flight per context (m355_set_pipeline_depth) */
 #define M355_TRANSIENT_MAX 12 /* staging arenas of m355_submit_picture (m355_ctx::transient_ring) */
+
+/* ---- THE SCHEDULE TABLE: every size / depth at which the runtime picks another launch order, in one place, with the measurement that set it
+ * (all A/Bs of two settings in ONE gpurun call on one box; boxes of the pool differ by +-5 %).  Each row is a separate correctness surface: the
+ * forced-schedule tests (tests/test_gpu_chain_forced.py, tests/test_emu_chain.py, tests/test_chain_residuals_emu.py, tests/test_meta_merged_emu.py)
+ * walk every one of them deterministically. ---- */
+namespace sched {
+/* pictures of up to this many luma samples run ALL their launches on the lane's main stream (no fork / join packets: six packets at ~2 us each are
+   worth more than what the side stream buys once the kernels are short): C3 / C4 0.110 -> 0.098 / 0.100 ms three in flight, C5 0.347 -> 0.351
+   (profiles/r04_al_*).  Above it the metadata planes + border plans and the small-block residual launch run on the lane's side stream. */
+constexpr long long one_stream_max_samples = 16ll << 20;
+/* from this many prediction blocks on, the zero fill of the metadata planes rides in k_job_count's workgroups (one per 256 PBs) and the planes + job list
+   are roles of one launch; below it a fill of its own is faster (a handful of workgroups cannot spread it): profiles/r04_ak_*, r05_v29_* */
+constexpr int clear_in_count_min_pbs = 64 * 256;
+/* transform edges + border plans inside the residual launch: only when the context decodes ONE picture at a time (C3 0.1494 -> 0.1427 ms, C4 0.1627 ->
+   0.1564; with lanes the separate launch runs beside other pictures' kernels: C3 0.0688 -> 0.0697, a chain's picture 0.132 -> 0.136, profiles/r05_v30_*) */
+constexpr int tu_plan_in_residuals_max_depth = 1;
+/* k_intra's halo keeper (13th wave): with one picture in flight, or for an intra picture when no other lane is busy (C2 1.22 -> 0.90 ms one at a time;
+   with three in flight the 13-wave workgroup crowds the other pictures' kernels out: 0.468 -> 0.536 ms, profiles/r05_v14_*) */
+constexpr int intra_keeper_max_depth = 1;
+/* a dependent chain's picture: front part on a spare lane from three lanes on (two lanes: the whole picture follows its reference onto that lane: C3 0.162 ->
+   0.178 ms when split there, profiles/r05_v27_*); its residual transforms move into the front part (int16 tiles + k_residual_add) on one-stream lanes only
+   (C3 0.131 -> 0.124 ms, C4 0.148 -> 0.140; C5 0.42-0.44 -> 0.44-0.45: profiles/r05_v31_*) */
+constexpr int chain_split_min_depth = 3;
+constexpr int chain_residual_tiles_min_depth = 3;
+/* lanes 3.. decode INTRA pictures on a stream of the next priority class (own hardware queues): C2 0.340 ms per picture at depth 9 (profiles/r03_v_*) */
+constexpr int intra_class_first_lane = 3;
+}
 
 /* A MARK = "everything enqueued on `stream` up to here", one event of the context's ring (ev_mark / ev_wait / ev_sync below).  The
  * objects a decode touches — destination and reference frames, its lists, its lane, its status slot — all remember the SAME mark
@@ -61,12 +85,6 @@ struct Frame {
   hipEvent_t ev_dl = nullptr;
   bool dl_pending = false;
   hipStream_t wr_stream = nullptr;         /* the stream that last wrote the frame (its downloads are queued on that stream) */
-#ifdef M355_X_TILED
-  void* tiled[3] = {nullptr, nullptr, nullptr};   /* EXPERIMENT: tiled copy read by k_inter_jobs (k_common.h DevRef) */
-  int tiles_w[3] = {0, 0, 0};
-  bool tiled_valid = false;
-  hipEvent_t ev_tiled = nullptr;
-#endif
 };
 
 static void frame_geometry(Frame& f, int w, int h, int cf, int bdl, int bdc)
@@ -100,11 +118,6 @@ static int frame_alloc(Frame& f, hipStream_t st)
 static void frame_free(Frame& f)
 {
   for (int c = 0; c < 3; c++) { if (f.plane[c]) hipFree(f.plane[c]); f.plane[c] = nullptr; }
-#ifdef M355_X_TILED
-  for (int c = 0; c < 3; c++) { if (f.tiled[c]) hipFree(f.tiled[c]); f.tiled[c] = nullptr; }
-  if (f.ev_tiled) hipEventDestroy(f.ev_tiled);
-  f.ev_tiled = nullptr; f.tiled_valid = false;
-#endif
   f.wr = EvRef();
   for (int k = 0; k < M355_MAX_LANES; k++) f.rd[k] = EvRef();
   f.ev_dl = nullptr; f.dl_pending = false; f.wr_stream = nullptr;

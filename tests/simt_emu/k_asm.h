@@ -52,11 +52,13 @@ static inline int d_dot2(unsigned a, unsigned b, int c)
 {
   return c + (int)(int16_t)(a & 0xFFFF) * (int16_t)(b & 0xFFFF) + (int)(int16_t)(a >> 16) * (int16_t)(b >> 16);
 }
+static inline int d_dot2z(unsigned a, unsigned b) { return d_dot2(a, b, 0); }
 static inline int d_dot4(unsigned a, unsigned b, int c)
 {
   for (int i = 0; i < 4; i++) c += (int)(signed char)(a >> (8 * i)) * (int)(signed char)(b >> (8 * i));
   return c;
 }
+static inline int d_dot4k(unsigned a, unsigned b, int k) { return d_dot4(a, b, k); }
 static inline unsigned d_pack_mid16(unsigned lo, unsigned hi) { return ((lo >> 8) & 0xFFFFu) | ((hi >> 8) << 16); }
 static inline unsigned d_pack_bytes(unsigned lo, unsigned hi) { return (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi & 0xFF0000u) << 8); }
 static inline int m355_sat16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }

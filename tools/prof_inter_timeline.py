@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# NOTE: the M355_X_PROF hooks this tool reads left the product sources in round 6 — apply tools/experiments/product_experiment_hooks_r5.patch to a scratch copy first.
 """Per-workgroup timeline of k_inter_jobs (experiment build -DM355_X_PROF=100000):
 M355_LIB=libde265_amd/variants/prof.so python tools/prof_inter_timeline.py [workload]
 For every workgroup: when it entered, when it knew its class, when its tables were in LDS, when its luma was written, when it was done

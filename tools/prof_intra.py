@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# NOTE: the M355_X_PROF hooks this tool reads left the product sources in round 6 — apply tools/experiments/product_experiment_hooks_r5.patch to a scratch copy first.
 """Per-level timing of one CTB of k_intra (experiment build -DM355_X_PROF=<work item>): M355_LIB=libde265_amd/variants/prof.so python tools/prof_intra.py [cu_log2]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# NOTE: the M355_X_PROF hooks this tool reads left the product sources in round 6 — apply tools/experiments/product_experiment_hooks_r5.patch to a scratch copy first.
 """Per-CTB timeline of k_intra on an all-intra picture (experiment build -DM355_X_PROF=100000):
 M355_LIB=libde265_amd/variants/prof.so python tools/prof_timeline.py [cu_log2]
 For every CTB: when its workgroup claimed it, when its block loop started (prologue done), when its last level ended, when its

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# NOTE: the M355_X_PROF hooks this tool reads left the product sources in round 6 — apply tools/experiments/product_experiment_hooks_r5.patch to a scratch copy first.
 """Per-CTB timeline of k_intra on an inter picture (experiment build -DM355_X_PROF=100000):
 M355_LIB=libde265_amd/variants/prof.so python tools/prof_timeline_sparse.py [workload]
 When each CTB with intra blocks was claimed, started its block loop, ended it, was written out (100 MHz wall clock)."""
