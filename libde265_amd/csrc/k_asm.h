@@ -104,13 +104,9 @@ __device__ __forceinline__ int d_dot2(unsigned a, unsigned b, int c)
  * v_dot2c (accumulates in place) and zeroes the destination with a v_mov in front of every chain — one extra issue per four or five dot2 */
 __device__ __forceinline__ int d_dot2z(unsigned a, unsigned b)
 {
-#ifdef M355_X_NO_DOT2Z
-  return d_dot2(a, b, 0);
-#else
   int r;
   asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
   return r;
-#endif
 }
 
 /* v_dot4_i32_i8: c + sum of four signed-byte products — four filter taps per VALU issue (8-bit planes: samples XOR 0x80 are the
@@ -120,13 +116,9 @@ __device__ __forceinline__ int d_dot4(unsigned a, unsigned b, int c) { return __
  * scalar register instead of v_mov + v_dot4c */
 __device__ __forceinline__ int d_dot4k(unsigned a, unsigned b, int k)
 {
-#ifdef M355_X_NO_DOT2Z
-  return d_dot4(a, b, k);
-#else
   int r;
   asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
   return r;
-#endif
 }
 /* v_perm_b32: bytes 1..2 of two registers -> one packed pair = ((lo >> 8) & 0xFFFF) | ((hi >> 8) << 16): a filter sum whose taps were
  * scaled so that its final right shift is 8 is shifted, truncated to int16 and packed with its neighbour in ONE issue */

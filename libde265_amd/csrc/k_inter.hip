@@ -580,7 +580,7 @@ __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int 
  * (bi: wave-uniform) and the write-back is packed 16-bit arithmetic; 1: explicit weights — one or two lists per lane, the 32-bit
  * write-back; 2: EDGE — windows that leave the picture (clamped rows), weights per lane. */
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs, unsigned* s_touch);
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs);
 
 /* one launch for the main and the edge job range: blocks [0, nblk_edge8) take edge jobs */
 template <class PIX>
@@ -636,14 +636,13 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
   /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
   __shared__ __attribute__((aligned(16))) unsigned s_ext[M355_INTER_BLOCK * 20];
   unsigned* ext = s_ext + threadIdx.x * 20;
-  __shared__ unsigned s_touch[64];      /* landing area of the window-row touches (d_touch): never read */
-  if (cls == 3) d_inter_job_lean<PIX, 2>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs, s_touch);
-  else if (cls == 2) d_inter_job_lean<PIX, 1>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs, s_touch);
-  else d_inter_job_lean<PIX, 0>(p, job, cls == 1, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs, s_touch);
+  if (cls == 3) d_inter_job_lean<PIX, 2>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
+  else if (cls == 2) d_inter_job_lean<PIX, 1>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
+  else d_inter_job_lean<PIX, 0>(p, job, cls == 1, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
 }
 
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs, unsigned* s_touch)
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs)
 {
   constexpr bool WEIGHTED = MODE != 0, EDGE = MODE == 2;
   const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
@@ -703,32 +702,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
     return bi ? t : d_pk_min_i16(t, maxv);
   };
 
-#ifdef M355_X_TOUCH
-  /* EXPERIMENT: request the window rows that the software pipeline asks for late — luma rows beyond its first pairs, (level 2) the chroma rows of the
-     same list, (level 3) the second list's as well — with loads that land in LDS scratch (no register, nothing waits): the lines are on their way
-     while the first rows are filtered */
-  auto touch_list = [&](int pass) {
-    if (EDGE || (pass ? fillB : fillA)) return;
-    const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
-    const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-    {
-      const int xa = x0 + (mvx >> 2) - 3;
-      const M355_GLOBAL PIX* q = (const M355_GLOBAL PIX*)ref->plane[0] + (ptrdiff_t)(y0 + (mvy >> 2) - 3) * ref->stride[0] + (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3));
-#pragma unroll
-      for (int r = 2 * M355_INTER_PIPE; r < 15; r++) d_touch((const void*)(q + (ptrdiff_t)r * ref->stride[0]), s_touch);
-    }
-    if (M355_X_TOUCH >= 2 && nc == 3) {
-      const int xa = (x0 >> 1) + (mvx >> 3) - 1;
-#pragma unroll
-      for (int c = 1; c < 3; c++) {
-        const M355_GLOBAL PIX* q = (const M355_GLOBAL PIX*)ref->plane[c] + (ptrdiff_t)((y0 >> 1) + (mvy >> 3) - 1) * ref->stride[c] + (sizeof(PIX) == 2 ? (xa & ~1) : (xa & ~3));
-#pragma unroll
-        for (int r = 0; r < 7; r++) d_touch((const void*)(q + (ptrdiff_t)r * ref->stride[c]), s_touch);
-      }
-    }
-  };
-  if (M355_X_TOUCH >= 3) { touch_list(0); if (bi) touch_list(1); }
-#endif
   /* ---- luma ---- */
   {
     const int bd = sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_luma;
@@ -744,9 +717,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, 
       } else {
         const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
         const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-#ifdef M355_X_TOUCH
-        if (M355_X_TOUCH < 3) touch_list(pass);
-#endif
         d_mc_luma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], p.pw[0], p.ph[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, ext, cur);
       }
       if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
