@@ -377,6 +377,10 @@ def main():
         dom = max(("inter", "residual", "intra", "deblock", "sao"), key=lambda s: stage_ms[s])
         per_launch_ms = stage_ms[dom] / max(1, launches[dom])
         achieved = (ab[dom] / max(1, launches[dom])) / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        try:
+            copy_gbs = ctx.measure_copy_rate(1 << 30, 9)          # this box's device-to-device copy rate (read + written bytes): the achievable ceiling
+        except Exception:  # noqa: BLE001
+            copy_gbs = None
         out = {
             "metric": "decoded CTBs/s", "value": world * args.steps * n_ctbs / dt, "unit": "CTB64/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -396,7 +400,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, "k_" + dom),
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": ab[dom] / max(1, launches[dom]),
                          "pictures_in_flight": 1,     # launch_ms / stage_ms: one picture at a time; `value`: args.pipeline_depth in flight
-                         "traffic_total": pmc_traffic_total(args.workload)},
+                         "traffic_total": pmc_traffic_total(args.workload),
+                         # the ceiling a copy kernel reaches on THIS box (m355_measure_copy_rate: 1 GiB read + 1 GiB written per launch) and the fraction of it
+                         "copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None},
         }
         verdicts = verify_legs(seen, cfg, pic, synth, worklist) if seen else {}
         if "headline" in verdicts:
@@ -763,10 +769,10 @@ def end_to_end(cfg):
             size = os.path.getsize(path)
             threads = 8 if ra else max(1, min(32, cfg["tile_cols"] * cfg["tile_rows"]))   # the parser runs one thread per tile / per CTB row in flight
 
-            def run(exe, output=False):
+            def run(exe, output=False, nthreads=None, scalar=False):
                 env = dict(os.environ, M355_PIPELINE_DEPTH="3")
                 env.pop("M355_LIB", None)
-                cmd = [exe, "-q", "-t", str(threads)] + (["-o", "/dev/null"] if output else []) + [path]
+                cmd = [exe, "-q", "-t", str(threads if nthreads is None else nthreads)] + (["-0"] if scalar else []) + (["-o", "/dev/null"] if output else []) + [path]
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
                 m = re.search(r"nFrames decoded: (\d+) \(\d+x\d+ @\s*([0-9.]+) fps\)", r.stdout + r.stderr)
                 return (int(m.group(1)), float(m.group(2))) if m else (0, 0.0)
@@ -777,12 +783,19 @@ def end_to_end(cfg):
             # i.e. for the backend a device-to-host copy of every frame into the pinned planes)
             nro, fro = run(ref, True)
             ngo, fgo = run(glue, True)
+            # the reference with its SIMD tables switched off (dec265 -0) and both decoders without worker threads (-t 0)
+            _, frs = run(ref, scalar=True)
+            _, fr0 = run(ref, nthreads=0)
+            _, fr0s = run(ref, nthreads=0, scalar=True)
+            _, fg0 = run(glue, nthreads=0)
         ctbs = ((cfg["width"] + 63) // 64) * ((cfg["height"] + 63) // 64)
         return {"stream": "%dx%d %d-bit, %dx%d tiles, %d pictures (%s), %d bytes; dec265 -q -t %d" %
                           (cfg["width"], cfg["height"], cfg["bit_depth"], cfg["tile_cols"], cfg["tile_rows"], frames,
                            "random access: hierarchical-B groups of 8, 4 references per list, long-term picture, TMVP, SDH, WPP" if ra else "I + P/B, 2 references", size, threads),
                 "reference_fps": fr, "reference_ctb64_per_s": fr * ctbs, "mi355x_fps": fg, "mi355x_ctb64_per_s": fg * ctbs,
                 "pictures": [nr, ng], "speedup": (fg / fr) if fr > 0 else None,
+                "columns_fps": {"reference -t %d" % threads: fr, "reference -t %d -0 (scalar)" % threads: frs, "reference -t 0": fr0, "reference -t 0 -0 (scalar)": fr0s,
+                                "mi355x -t %d" % threads: fg, "mi355x -t 0": fg0, "host_cpus": os.cpu_count()},
                 "with_output": {"reference_fps": fro, "mi355x_fps": fgo, "pictures": [nro, ngo], "speedup": (fgo / fro) if fro > 0 else None,
                                 "note": "dec265 -o /dev/null: every picture is taken by the application (the backend downloads each frame)"},
                 "note": "both decoders spend most of each picture in the reference's CABAC / syntax parser (host, one thread per tile); the backend's own rate is `value` / `with_upload`"}
@@ -855,6 +868,27 @@ def cpu_baseline(cfg, synth, worklist):
             if rA > best[0]:
                 best = (rA, Ta)
     out["best"] = {"value": best[0], "cores": best[1]}    # the host's best figure over the thread counts tried
+    if (small["width"], small["height"]) != (cfg["width"], cfg["height"]):
+        # the workload's OWN picture (not the cropped sample) through the same reference functions: at least one whole replay per thread and count
+        try:
+            fpic, frefs = make_case(**cfg)
+            frp = (ctypes.c_void_p * (worklist.MAX_REF_FRAMES * 3))()
+            for s_, planes in enumerate(frefs):
+                for c_, a in enumerate(planes):
+                    a = np.ascontiguousarray(a, dtype=dt_); keep.append(a); frp[s_ * 3 + c_] = a.ctypes.data
+            fpic.ref_frames = [i if i < len(frefs) else -1 for i in range(worklist.MAX_REF_FRAMES)]
+            fcpic, fk2 = fpic.to_c()
+
+            def frun(threads, seconds):
+                el = ctypes.c_double(0)
+                n = lib.m355_ref_bench(ctypes.byref(fcpic), frp, worklist.STAGE_ALL, 1, threads, seconds, ctypes.byref(el))
+                if n < 0:
+                    raise RuntimeError("m355_ref_bench failed: %d" % n)
+                return {"value": n * len(fpic.ctbs) / el.value, "cores": threads, "pictures": int(n), "seconds": el.value}
+            out["full_size"] = {"picture": "%dx%d %d-bit, %d CTB64 (the bench workload itself)" % (cfg["width"], cfg["height"], cfg["bit_depth"], len(fpic.ctbs)),
+                                "unit": "CTB64/s", "by_threads": [frun(1, 0.5), frun(T, 3.0)] + ([frun(best[1], 3.0)] if best[1] != T else [])}
+        except Exception as e:  # noqa: BLE001
+            out["full_size"] = {"error": repr(e)[:200]}
     return out
 
 

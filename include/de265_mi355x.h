@@ -413,6 +413,11 @@ M355_API int m355_frame_download_async(m355_ctx* ctx, int frame, void* const dst
 M355_API int m355_frame_download_wait(m355_ctx* ctx, int frame);
 M355_API int m355_frame_fill(m355_ctx* ctx, int frame, int value_luma, int value_chroma);
 
+/* Diagnostic (bench.py's roofline): the device-to-device copy rate this box reaches — `bytes` read + `bytes` written per launch of a float4 copy
+ * kernel, the median of `iters` launches timed with events on the context's stream, in GB/s (read + written bytes / time).  The achievable
+ * ceiling next to the 8 TB/s specification ("measure the real ceiling with a device-to-device copy kernel on the box"). */
+M355_API int m355_measure_copy_rate(m355_ctx* ctx, size_t bytes, int iters, double* gbps);
+
 /* Pinned host memory for the planes an application reads decoded pictures from: what a get_buffer callback registered
  * with de265_set_image_allocation_functions (de265.h:350-368; default allocator image.cc:110-184) hands out, so that
  * m355_frame_download runs at full PCIe rate.  NULL on failure. */

@@ -67,6 +67,7 @@ class Library:
         L.m355_frame_upload.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_download.argtypes = [vp, i, i, vp, ctypes.c_ssize_t]
         L.m355_frame_fill.argtypes = [vp, i, i, i]
+        L.m355_measure_copy_rate.argtypes = [vp, ctypes.c_size_t, i, ctypes.POINTER(ctypes.c_double)]
         L.m355_arena_begin.argtypes = [vp, vp, vp]
         if hasattr(L, "m355_picture_arena_begin"):      # (absent from older builds loaded through M355_LIB for an A/B)
             L.m355_picture_arena_begin.argtypes = [vp, i, vp, vp, vp]
@@ -243,6 +244,12 @@ class Context:
 
     def frame_fill(self, f, luma, chroma):
         self.L.check(self.L.lib.m355_frame_fill(self.h, f, luma, chroma))
+
+    def measure_copy_rate(self, nbytes=1 << 30, iters=9):
+        """device-to-device copy rate of this box in GB/s (m355_measure_copy_rate: read + written bytes / time)"""
+        g = ctypes.c_double(0)
+        self.L.check(self.L.lib.m355_measure_copy_rate(self.h, nbytes, iters, ctypes.byref(g)))
+        return float(g.value)
 
     def frame_hash(self, f, hash_type):
         """SEI decoded picture hash (m355_frame_hash): list of per-plane values — bytes (MD5) or int (CRC, checksum)"""

@@ -611,29 +611,37 @@ __device__ __forceinline__ WinUnit d_win_unit(int tid, int nvalid, int strip, in
    planes, 16 / 8 bytes on 8-bit planes */
 template <class PIX> __device__ __forceinline__ int d_win_cpr_luma(int s) { return sizeof(PIX) == 2 ? (8 * s + 31) >> 4 : (4 * s + 27) >> 4; }
 template <class PIX> __device__ __forceinline__ int d_win_cpr_chroma(int s) { return sizeof(PIX) == 2 ? (4 * s + 23) >> 4 : (2 * s + 23) >> 4; }
-/* lane `idx` of the unit's `n` lanes fetches chunks idx, idx + n, ... of its nrows x cpr chunks: all (up to 15) requested before the first is
-   stored; branch-free requests — a lane with fewer chunks asks for its last one again, a lane that takes no part for one harmless chunk (hipcc
-   waits for a load inside a lane-conditional branch in that branch: one round trip per chunk) */
+/* The unit's `n` lanes fetch its nrows x cpr chunks: lane idx owns ONE chunk column (idx mod cpr) and walks down the rows from row idx / cpr in
+   steps of n / cpr rows — a chunk then costs an address multiply-add, the request, a compare and the LDS store, not a division (units narrower
+   than a row's chunks — a 4-wide PB, the fragment of a run at a workgroup boundary — give each lane several columns, row by row).
+   M355_WIN_BATCH requests are in flight per lane at a time (the registers they land in are free here: no filter state is live between the
+   phases); the requests are branch-free — a lane past its last row asks for that row again, a lane that takes no part for one harmless chunk
+   (hipcc waits for a load inside a lane-conditional branch in that branch: one round trip per chunk) */
+#define M355_WIN_BATCH 8
 template <class PIX>
 __device__ __forceinline__ void d_win_stage(bool act, const M355_GLOBAL PIX* g, int gstride, int nrows, int cpr, int idx, int n, unsigned char* win, const M355_GLOBAL PIX* safe)
 {
-  const int nchunks = act ? nrows * cpr : 0;
-  const float rc = 1.0f / (float)cpr;            /* row = id / cpr for id < 4096, cpr <= 9: (id + 0.5) * rc never comes near an integer */
+  const float rc = 1.0f / (float)cpr;            /* x / cpr for x < 4096, cpr <= 9: (x + 0.5) * rc never comes near an integer */
   const int pitch = cpr * 16;
-  if (!act) { g = safe; gstride = 0; }
-  for (int c0 = idx; __any(c0 < nchunks); c0 += 15 * n) {
-    unsigned R[15][4];
-    int at[15];
+  int rstep = (int)(((float)n + 0.5f) * rc), row0 = (int)(((float)idx + 0.5f) * rc), col0 = idx - row0 * cpr, cstep = cpr;
+  if (rstep == 0) { rstep = 1; row0 = 0; col0 = idx; cstep = n; }          /* fewer lanes than chunk columns */
+  const bool on = act && row0 < rstep;
+  const int last = on ? nrows - 1 : 0;
+  if (!act) { g = safe; gstride = 0; col0 = 0; }
+  for (int col = col0; __any(on && col < cpr); col += cstep) {
+    const int cc = min(col, cpr - 1);
+    const M355_GLOBAL PIX* gc = g + cc * (16 / (int)sizeof(PIX));
+    unsigned char* wc = win + cc * 16;
+    for (int rb = row0; __any(on && col < cpr && rb < nrows); rb += M355_WIN_BATCH * rstep) {
+      unsigned R[M355_WIN_BATCH][4];
 #pragma unroll
-    for (int i = 0; i < 15; i++) {
-      const int id = max(0, min(c0 + i * n, nchunks - 1));
-      const int row = (int)(((float)id + 0.5f) * rc), col = act ? id - row * cpr : 0;
-      at[i] = row * pitch + col * 16;
-      d_ldg16(g + (ptrdiff_t)row * gstride + col * (16 / (int)sizeof(PIX)), R[i]);
+      for (int i = 0; i < M355_WIN_BATCH; i++) d_ldg16(gc + (ptrdiff_t)min(rb + i * rstep, last) * gstride, R[i]);
+#pragma unroll
+      for (int i = 0; i < M355_WIN_BATCH; i++) {
+        const int r = rb + i * rstep;
+        if (on && col < cpr && r < nrows) *(uint4*)(wc + r * pitch) = make_uint4(R[i][0], R[i][1], R[i][2], R[i][3]);
+      }
     }
-#pragma unroll
-    for (int i = 0; i < 15; i++)
-      if (c0 + i * n < nchunks) *(uint4*)(win + at[i]) = make_uint4(R[i][0], R[i][1], R[i][2], R[i][3]);
   }
 }
 
@@ -670,9 +678,15 @@ __device__ __forceinline__ void d_mc_luma_win(const unsigned char* w, int pitch,
   constexpr int NW = sizeof(PIX) == 2 ? 6 : 4;
   unsigned S[2][2][NW];
   auto ldrow = [&](int r, unsigned* o) {
-    const unsigned* q = (const unsigned*)(w + r * pitch);
+    if (sizeof(PIX) == 2) {          /* (16-bit planes: a lane's column offset is a multiple of 8 bytes — ds_read_b64) */
+      const uint2* q = (const uint2*)(w + r * pitch);
 #pragma unroll
-    for (int i = 0; i < NW; i++) o[i] = q[i];
+      for (int i = 0; i < 3; i++) { const uint2 v = q[i]; o[2 * i] = v.x; o[2 * i + 1] = v.y; }
+    } else {
+      const unsigned* q = (const unsigned*)(w + r * pitch);
+#pragma unroll
+      for (int i = 0; i < NW; i++) o[i] = q[i];
+    }
   };
   ldrow(0, S[0][0]); ldrow(1, S[0][1]);
   if (sizeof(PIX) == 2) {
@@ -886,7 +900,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
 
   /* ---- the workgroup's windows (WIN): which unit a lane belongs to, where the unit's luma / chroma windows lie in the buffer, in which round ---- */
   WinUnit u = {tid, 1, 0, 0, 1, 0, 8, 0};
-  int cprl = 1, cprc = 1, wofs_l = 0, wofs_c = 0, round_l = 0, round_c = 0, nround_l = 1, nround_c = 1;
+  int cprl = 1, cprc = 1, wofs_l = 0, wofs_c = 0, round_l = 0, round_c = 0, nround_l = 1, nround_c = 1, tot_l = 0, tot_c = 0;
   if (WIN) {
     int size_l = 0, size_c = 0;
     if (valid) {
@@ -905,7 +919,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
     if (lane == 63) { s_red[wv] = (unsigned)il; s_red[4 + wv] = (unsigned)ic; }
     if (size_l) { atomicMax(&s_red[8], (unsigned)size_l); atomicMax(&s_red[9], (unsigned)size_c); }
     __syncthreads();
-    int base_l = 0, base_c = 0, tot_l = 0, tot_c = 0;
+    int base_l = 0, base_c = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int a = (int)s_red[k], c = (int)s_red[4 + k]; tot_l += a; tot_c += c; if (k < wv) { base_l += a; base_c += c; } }
     if (valid && u.idx == 0) { s_wofs[2 * tid] = (unsigned)(base_l + il - size_l); s_wofs[2 * tid + 1] = (unsigned)(base_c + ic - size_c); }
@@ -975,12 +989,12 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
 #pragma unroll 1
     for (int pass = 0; pass < (WIN ? npass_wg : npass); pass++) {
       unsigned cur[8][2];
-#pragma unroll
-      for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }      /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
       const bool act = valid && pass < npass && !(pass ? fillB : fillA);
       const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
       const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
       if (!WIN) {
+#pragma unroll
+        for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }      /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
         if (act) d_mc_luma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], p.pw[0], p.ph[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, ext, cur);
       } else {
         const int xa = x0 + (mvx >> 2) - 3, xu = pb.x + 4 * u.strip0 + (mvx >> 2) - 3;          /* first window column of the lane / of its unit */
@@ -992,6 +1006,10 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
           const bool mine = act && round_l == r;
           d_win_stage<PIX>(mine, g, ref->stride[0], u.rows + 7, cprl, u.idx, u.n, win, safe);
           __syncthreads();
+          if (r == 0) {
+#pragma unroll
+            for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
+          }
           if (mine) d_mc_luma_win<PIX>(win + u.my_row * pitch + ((xa & ~AL) - (xu & ~AL)) * (int)sizeof(PIX), pitch, xa & AL, mvx & 3, mvy & 3, s_ql, s_qv, cur);
         }
       }
@@ -1038,77 +1056,107 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
   {
     const int bd = sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_chroma;
     const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
-    unsigned pa1[4], pa2[4];
+    unsigned pa1[4], pa2[4], cur1[4], cur2[4];
 #pragma unroll
     for (int y = 0; y < 4; y++) { pa1[y] = 0; pa2[y] = 0; }
-#pragma unroll 1
-    for (int pass = 0; pass < (WIN ? npass_wg : npass); pass++) {
-      unsigned cur1[4], cur2[4];
+    /* list `pass` of this lane: takes part?, reference, vector */
+    auto list_of = [&](int pass, bool& act, const DevRef*& ref, int& mvx, int& mvy) {
+      act = valid && pass < npass && !(pass ? fillB : fillA);
+      ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+      mvx = pass ? pb.mv[1][0] : mvxA; mvy = pass ? pb.mv[1][1] : mvyA;
+    };
+    const int pitch = cprc * 16, wrows = (u.rows >> 1) + 3;
+    /* both planes' windows of one list into the buffer at `base` (the lanes of round r) */
+    auto stage_c = [&](int pass, int r, int base) {
+      bool act; const DevRef* ref; int mvx, mvy;
+      list_of(pass, act, ref, mvx, mvy);
+      const bool mine = act && round_c == r;
+      const int xu = ((pb.x + 4 * u.strip0) >> 1) + (mvx >> 3) - 1;
+      const ptrdiff_t row = (ptrdiff_t)(((pb.y + u.row0) >> 1) + (mvy >> 3) - 1);
+      unsigned char* win = s_win + base + wofs_c;
+      d_win_stage<PIX>(mine, (const M355_GLOBAL PIX*)ref->plane[1] + row * ref->stride[1] + (xu & ~AL), ref->stride[1], wrows, cprc, u.idx, u.n, win, safe);
+      d_win_stage<PIX>(mine, (const M355_GLOBAL PIX*)ref->plane[2] + row * ref->stride[2] + (xu & ~AL), ref->stride[2], wrows, cprc, u.idx, u.n, win + wrows * pitch, safe);
+    };
+    /* the lane's two 2x4 blocks of one list from the windows at `base` -> pa (a first list with a second one to come) or cur */
+    auto filter_c = [&](int pass, int r, int base) {
+      bool act; const DevRef* ref; int mvx, mvy;
+      list_of(pass, act, ref, mvx, mvy);
+      if (!(valid && pass < npass) || (act && round_c != r)) return;
+      unsigned t1[4], t2[4];
 #pragma unroll
-      for (int y = 0; y < 4; y++) { cur1[y] = 0x20002000u; cur2[y] = 0x20002000u; }
-      const bool act = valid && pass < npass && !(pass ? fillB : fillA);
-      const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
-      const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-      if (!WIN) {
-        if (act) {
+      for (int y = 0; y < 4; y++) { t1[y] = 0x20002000u; t2[y] = 0x20002000u; }      /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
+      if (act) {
+        const int xa = xc + (mvx >> 3) - 1, xu = ((pb.x + 4 * u.strip0) >> 1) + (mvx >> 3) - 1;
+        const unsigned char* w = s_win + base + wofs_c + (u.my_row >> 1) * pitch + ((xa & ~AL) - (xu & ~AL)) * (int)sizeof(PIX);
+        d_mc_chroma_win<PIX>(w, pitch, xa & AL, mvx & 7, mvy & 7, s_cl, s_cv, t1);
+        d_mc_chroma_win<PIX>(w + wrows * pitch, pitch, xa & AL, mvx & 7, mvy & 7, s_cl, s_cv, t2);
+      }
+      const bool first = pass + 1 < npass;
+#pragma unroll
+      for (int y = 0; y < 4; y++) { if (first) { pa1[y] = t1[y]; pa2[y] = t2[y]; } else { cur1[y] = t1[y]; cur2[y] = t2[y]; } }
+    };
+    if (!WIN) {
+#pragma unroll 1
+      for (int pass = 0; pass < npass; pass++) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) { cur1[y] = 0x20002000u; cur2[y] = 0x20002000u; }
+        if (!(pass ? fillB : fillA)) {
+          const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+          const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
           d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], p.pw[1], p.ph[1], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur1);
           d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], p.pw[2], p.ph[2], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur2);
         }
-      } else {
-        const int xa = xc + (mvx >> 3) - 1, xu = ((pb.x + 4 * u.strip0) >> 1) + (mvx >> 3) - 1;
-        const int pitch = cprc * 16, wrows = (u.rows >> 1) + 3;
-        const ptrdiff_t gofs1 = (ptrdiff_t)(((pb.y + u.row0) >> 1) + (mvy >> 3) - 1) * ref->stride[1] + (xu & ~AL);
-        const ptrdiff_t gofs2 = (ptrdiff_t)(((pb.y + u.row0) >> 1) + (mvy >> 3) - 1) * ref->stride[2] + (xu & ~AL);
-        unsigned char* win = s_win + wofs_c;
+        if (pass + 1 < npass) {
+#pragma unroll
+          for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
+        }
+      }
+    } else if (npass_wg == 2 && nround_c == 1 && 2 * tot_c <= M355_WIN_BYTES) {
+      /* both lists' chroma windows fit the buffer together: ONE phase (the second list's windows behind the first's) */
+      __syncthreads();
+      stage_c(0, 0, 0); stage_c(1, 0, tot_c);
+      __syncthreads();
+      filter_c(0, 0, 0); filter_c(1, 0, tot_c);
+    } else {
+#pragma unroll 1
+      for (int pass = 0; pass < npass_wg; pass++)
         for (int r = 0; r < nround_c; r++) {
           __syncthreads();
-          const bool mine = act && round_c == r;
-          d_win_stage<PIX>(mine, (const M355_GLOBAL PIX*)ref->plane[1] + gofs1, ref->stride[1], wrows, cprc, u.idx, u.n, win, safe);
-          d_win_stage<PIX>(mine, (const M355_GLOBAL PIX*)ref->plane[2] + gofs2, ref->stride[2], wrows, cprc, u.idx, u.n, win + wrows * pitch, safe);
+          stage_c(pass, r, 0);
           __syncthreads();
-          if (mine) {
-            const unsigned char* w = win + (u.my_row >> 1) * pitch + ((xa & ~AL) - (xu & ~AL)) * (int)sizeof(PIX);
-            d_mc_chroma_win<PIX>(w, pitch, xa & AL, mvx & 7, mvy & 7, s_cl, s_cv, cur1);
-            d_mc_chroma_win<PIX>(w + wrows * pitch, pitch, xa & AL, mvx & 7, mvy & 7, s_cl, s_cv, cur2);
-          }
+          filter_c(pass, r, 0);
+        }
+    }
+    if (!valid) return;
+    M355_COMPILER_FENCE();
+    PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
+    PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
+    if (WEIGHTED) {
+      const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
+      const unsigned wp1 = d_pack16(ws1.w0, ws1.w1), wp2 = d_pack16(ws2.w0, ws2.w1);
+      const int rnd1 = ws1.rnd + (int)((unsigned)ws1.o << ws1.sh), rnd2 = ws2.rnd + (int)((unsigned)ws2.o << ws2.sh);
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+        if (y >= crows) break;
+        const unsigned o1 = wt_pair(bi ? pa1[y] : cur1[y], cur1[y], wp1, rnd1, ws1.sh, bd);
+        const unsigned o2 = wt_pair(bi ? pa2[y] : cur2[y], cur2[y], wp2, rnd2, ws2.sh, bd);
+        if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
+        else {
+          *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
+          *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
         }
       }
-      if (pass + 1 < npass) {
+    } else {
+      const int sh = (bi ? 15 : 14) - bd;
+      const unsigned rnd = (1u << (sh - 1)) * 0x10001u, maxv = ((1u << bd) - 1u) * 0x10001u;
 #pragma unroll
-        for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
-        continue;
-      }
-      if (!valid || pass >= npass) continue;
-      M355_COMPILER_FENCE();
-      PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
-      PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
-      if (WEIGHTED) {
-        const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
-        const unsigned wp1 = d_pack16(ws1.w0, ws1.w1), wp2 = d_pack16(ws2.w0, ws2.w1);
-        const int rnd1 = ws1.rnd + (int)((unsigned)ws1.o << ws1.sh), rnd2 = ws2.rnd + (int)((unsigned)ws2.o << ws2.sh);
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-          if (y >= crows) break;
-          const unsigned o1 = wt_pair(bi ? pa1[y] : cur1[y], cur1[y], wp1, rnd1, ws1.sh, bd);
-          const unsigned o2 = wt_pair(bi ? pa2[y] : cur2[y], cur2[y], wp2, rnd2, ws2.sh, bd);
-          if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
-          else {
-            *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
-            *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
-          }
-        }
-      } else {
-        const int sh = (bi ? 15 : 14) - bd;
-        const unsigned rnd = (1u << (sh - 1)) * 0x10001u, maxv = ((1u << bd) - 1u) * 0x10001u;
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-          if (y >= crows) break;
-          unsigned o1 = pk_pred(pa1[y], cur1[y], rnd, sh, maxv), o2 = pk_pred(pa2[y], cur2[y], rnd, sh, maxv);
-          if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
-          else {
-            *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
-            *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
-          }
+      for (int y = 0; y < 4; y++) {
+        if (y >= crows) break;
+        unsigned o1 = pk_pred(pa1[y], cur1[y], rnd, sh, maxv), o2 = pk_pred(pa2[y], cur2[y], rnd, sh, maxv);
+        if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
+        else {
+          *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
+          *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
         }
       }
     }
