@@ -576,235 +576,11 @@ __device__ __forceinline__ void d_mc_chroma_lean(const M355_GLOBAL PIX* rp, int 
   }
 }
 
-/* ================================================================================================
- * reference windows through LDS (the job classes whose windows lie inside the picture)
- *
- * A lane that fetches its own 11 x 15 window asks the CU's texture addresser for 30 + 14 row segments per list, most of them the same bytes its
- * neighbours ask for — and that unit, not the HBM, is what the per-lane kernel waited for: every vector-memory instruction added to it cost ~43
- * cycles of its CU's time whatever it fetched (profiles/r06_v2_inter_dot2z_touch_ab.txt).  Here the lanes of a workgroup fetch each window ONCE,
- * as 16-byte chunks of whole rows (consecutive lanes = consecutive chunks of a row), into LDS, and filter from there:
- *   UNIT   = the jobs of one PB inside this workgroup (PB order = lane order; (h + 7) window rows x the PB's width + 7, fetched once for all its
- *            row blocks) — or, for a PB the workgroup boundary cuts, the run of jobs of one row block (15 rows);
- *   LAYOUT = unit after unit in lane order (one exclusive scan over the workgroup), rows at a pitch of whole chunks, the row's first chunk starting
- *            at the dword-aligned sample at or below the unit's first column — a lane's row is then the same dwords its own vector loads used to
- *            bring, at column offset (its aligned first sample - the unit's), and the phase-selected taps (lean filters) apply unchanged;
- *   PHASES = luma list 0, luma list 1, chroma (both planes) list 0, chroma list 1: stage -> barrier -> filter -> barrier; a workgroup whose windows
- *            exceed the buffer (8x8 PBs only: 61 KB of luma windows per 256 jobs at 10 bits) takes a phase in ROUNDS of consecutive units.
- * ============================================================================================== */
-#define M355_WIN_BYTES 49152   /* window buffer per workgroup: three workgroups per CU (160 KB LDS); EDGE workgroups use its first 20 KB as their row-extension slots */
-struct WinUnit { int head, n, idx, strip0, strips, row0, rows, my_row; };
-/* the unit of lane `tid` (job = strip / row block of a w x h PB; nvalid = valid lanes of the workgroup) */
-__device__ __forceinline__ WinUnit d_win_unit(int tid, int nvalid, int strip, int rblk, int w, int h)
-{
-  WinUnit u;
-  const int strips = w >> 2, nrb = (h + 7) >> 3;
-  const int j = rblk * strips + strip, J = strips * nrb, first = tid - j;
-  if (first >= 0 && first + J <= nvalid) { u.head = first; u.n = J; u.strip0 = 0; u.strips = strips; u.row0 = 0; u.rows = h; }
-  else {
-    const int back = min(strip, tid), fwd = min(strips - 1 - strip, nvalid - 1 - tid);
-    u.head = tid - back; u.n = back + fwd + 1; u.strip0 = strip - back; u.strips = u.n; u.row0 = 8 * rblk; u.rows = min(8, h - 8 * rblk);
-  }
-  u.idx = tid - u.head; u.my_row = 8 * rblk - u.row0;
-  return u;
-}
-/* 16-byte chunks per window row of a unit `s` strips wide: the last lane reads 24 (luma) / 12 (chroma) bytes from its column offset on 16-bit
-   planes, 16 / 8 bytes on 8-bit planes */
-template <class PIX> __device__ __forceinline__ int d_win_cpr_luma(int s) { return sizeof(PIX) == 2 ? (8 * s + 31) >> 4 : (4 * s + 27) >> 4; }
-template <class PIX> __device__ __forceinline__ int d_win_cpr_chroma(int s) { return sizeof(PIX) == 2 ? (4 * s + 23) >> 4 : (2 * s + 23) >> 4; }
-/* The unit's `n` lanes fetch its nrows x cpr chunks: lane idx owns ONE chunk column (idx mod cpr) and walks down the rows from row idx / cpr in
-   steps of n / cpr rows — a chunk then costs an address multiply-add, the request, a compare and the LDS store, not a division (units narrower
-   than a row's chunks — a 4-wide PB, the fragment of a run at a workgroup boundary — give each lane several columns, row by row).
-   M355_WIN_BATCH requests are in flight per lane at a time (the registers they land in are free here: no filter state is live between the
-   phases); the requests are branch-free — a lane past its last row asks for that row again, a lane that takes no part for one harmless chunk
-   (hipcc waits for a load inside a lane-conditional branch in that branch: one round trip per chunk) */
-#define M355_WIN_BATCH 8
-template <class PIX>
-__device__ __forceinline__ void d_win_stage(bool act, const M355_GLOBAL PIX* g, int gstride, int nrows, int cpr, int idx, int n, unsigned char* win, const M355_GLOBAL PIX* safe)
-{
-  const float rc = 1.0f / (float)cpr;            /* x / cpr for x < 4096, cpr <= 9: (x + 0.5) * rc never comes near an integer */
-  const int pitch = cpr * 16;
-  int rstep = (int)(((float)n + 0.5f) * rc), row0 = (int)(((float)idx + 0.5f) * rc), col0 = idx - row0 * cpr, cstep = cpr;
-  if (rstep == 0) { rstep = 1; row0 = 0; col0 = idx; cstep = n; }          /* fewer lanes than chunk columns */
-  const bool on = act && row0 < rstep;
-  const int last = on ? nrows - 1 : 0;
-  if (!act) { g = safe; gstride = 0; col0 = 0; }
-  for (int col = col0; __any(on && col < cpr); col += cstep) {
-    const int cc = min(col, cpr - 1);
-    const M355_GLOBAL PIX* gc = g + cc * (16 / (int)sizeof(PIX));
-    unsigned char* wc = win + cc * 16;
-    for (int rb = row0; __any(on && col < cpr && rb < nrows); rb += M355_WIN_BATCH * rstep) {
-      unsigned R[M355_WIN_BATCH][4];
-#pragma unroll
-      for (int i = 0; i < M355_WIN_BATCH; i++) d_ldg16(gc + (ptrdiff_t)min(rb + i * rstep, last) * gstride, R[i]);
-#pragma unroll
-      for (int i = 0; i < M355_WIN_BATCH; i++) {
-        const int r = rb + i * rstep;
-        if (on && col < cpr && r < nrows) *(uint4*)(wc + r * pitch) = make_uint4(R[i][0], R[i][1], R[i][2], R[i][3]);
-      }
-    }
-  }
-}
-
-/* the V pass of a luma job: Q[k][j] = (row 2k, row 2k + 1) intermediates of column j -> 8 rows x 4 columns of 14-bit predictions, packed */
-__device__ __forceinline__ void d_luma_vpass(const unsigned (&Q)[8][4], const unsigned* s_qv, int yf, unsigned pred[8][2])
-{
-  const unsigned* ty = s_qv + yf * QT_STRIDE;
-  unsigned YE[4], YO[5];
-#pragma unroll
-  for (int k = 0; k < 4; k++) YE[k] = ty[k];
-#pragma unroll
-  for (int k = 0; k < 5; k++) YO[k] = ty[4 + k];
-#pragma unroll
-  for (int m = 0; m < 4; m++) {
-    int ve[4], vo[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      ve[j] = d_dot2(Q[m + 3][j], YE[3], d_dot2(Q[m + 2][j], YE[2], d_dot2(Q[m + 1][j], YE[1], d_dot2z(Q[m][j], YE[0]))));
-      vo[j] = d_dot2(Q[m + 4][j], YO[4], d_dot2(Q[m + 3][j], YO[3], d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2z(Q[m][j], YO[0])))));
-    }
-#pragma unroll
-    for (int jp = 0; jp < 2; jp++) {
-      pred[2 * m][jp] = d_pack_mid16((unsigned)ve[2 * jp], (unsigned)ve[2 * jp + 1]);
-      pred[2 * m + 1][jp] = d_pack_mid16((unsigned)vo[2 * jp], (unsigned)vo[2 * jp + 1]);
-    }
-  }
-}
-/* luma 4x8 block of one list from its window in LDS: w = the lane's first window row at its column offset, phase = xa & 1 (16-bit planes: which tap
-   set) / xa & 3 (8-bit planes: the byte shift) — the filters of d_mc_luma_lean, the rows coming from LDS one pair ahead of the pair being filtered */
-template <class PIX>
-__device__ __forceinline__ void d_mc_luma_win(const unsigned char* w, int pitch, int phase, int xf, int yf, const unsigned* s_ql, const unsigned* s_qv, unsigned pred[8][2])
-{
-  unsigned Q[8][4];
-  constexpr int NW = sizeof(PIX) == 2 ? 6 : 4;
-  unsigned S[2][2][NW];
-  auto ldrow = [&](int r, unsigned* o) {
-    if (sizeof(PIX) == 2) {          /* (16-bit planes: a lane's column offset is a multiple of 8 bytes — ds_read_b64) */
-      const uint2* q = (const uint2*)(w + r * pitch);
-#pragma unroll
-      for (int i = 0; i < 3; i++) { const uint2 v = q[i]; o[2 * i] = v.x; o[2 * i + 1] = v.y; }
-    } else {
-      const unsigned* q = (const unsigned*)(w + r * pitch);
-#pragma unroll
-      for (int i = 0; i < NW; i++) o[i] = q[i];
-    }
-  };
-  ldrow(0, S[0][0]); ldrow(1, S[0][1]);
-  if (sizeof(PIX) == 2) {
-    const unsigned* tl = s_ql + (xf * 2 + phase) * QL_STRIDE;
-    unsigned T0[5], T1[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) { T0[k] = tl[k]; T1[k] = tl[5 + k]; }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (k < 7) { ldrow(2 * k + 2, S[(k + 1) & 1][0]); if (k < 6) ldrow(2 * k + 3, S[(k + 1) & 1][1]); }
-      int h[2][4];
-#pragma unroll
-      for (int r = 0; r < 2; r++) {
-        if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }   /* row 15 is never read with a non-zero tap */
-        const unsigned* E = S[k & 1][r];
-        h[r][0] = d_dot2(E[4], T0[4], d_dot2(E[3], T0[3], d_dot2(E[2], T0[2], d_dot2(E[1], T0[1], d_dot2z(E[0], T0[0])))));
-        h[r][1] = d_dot2(E[4], T1[4], d_dot2(E[3], T1[3], d_dot2(E[2], T1[2], d_dot2(E[1], T1[1], d_dot2z(E[0], T1[0])))));
-        h[r][2] = d_dot2(E[5], T0[4], d_dot2(E[4], T0[3], d_dot2(E[3], T0[2], d_dot2(E[2], T0[1], d_dot2z(E[1], T0[0])))));
-        h[r][3] = d_dot2(E[5], T1[4], d_dot2(E[4], T1[3], d_dot2(E[3], T1[2], d_dot2(E[2], T1[1], d_dot2z(E[1], T1[0])))));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) Q[k][j] = d_pack_mid16((unsigned)h[0][j], (unsigned)h[1][j]);
-      M355_PIN_V4_MEM(Q[k][0], Q[k][1], Q[k][2], Q[k][3]);
-    }
-  } else {
-    const unsigned* tl = s_ql + xf * QL_STRIDE;
-    unsigned W[4][3];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { W[j][0] = tl[3 * j]; W[j][1] = tl[3 * j + 1]; W[j][2] = tl[3 * j + 2]; }
-    const unsigned sh = (unsigned)phase;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      if (k < 7) { ldrow(2 * k + 2, S[(k + 1) & 1][0]); if (k < 6) ldrow(2 * k + 3, S[(k + 1) & 1][1]); }
-      int h[2][4];
-#pragma unroll
-      for (int r = 0; r < 2; r++) {
-        if (k == 7 && r == 1) { h[r][0] = h[r][1] = h[r][2] = h[r][3] = 0; break; }
-        const unsigned* E = S[k & 1][r];
-        unsigned A[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) A[i] = __builtin_amdgcn_alignbyte(E[i + 1], E[i], sh) ^ 0x80808080u;
-        h[r][0] = d_dot4(A[1], W[0][1], d_dot4k(A[0], W[0][0], 8192));
-#pragma unroll
-        for (int j = 1; j < 4; j++) h[r][j] = d_dot4(A[2], W[j][2], d_dot4(A[1], W[j][1], d_dot4k(A[0], W[j][0], 8192)));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) Q[k][j] = d_pack_lo16((unsigned)h[0][j], (unsigned)h[1][j]);
-      M355_PIN_V4_MEM(Q[k][0], Q[k][1], Q[k][2], Q[k][3]);
-    }
-  }
-  d_luma_vpass(Q, s_qv, yf, pred);
-}
-/* chroma 2x4 block of one list and plane from its window in LDS (the filters of d_mc_chroma_lean) */
-template <class PIX>
-__device__ __forceinline__ void d_mc_chroma_win(const unsigned char* w, int pitch, int phase, int xf, int yf, const unsigned* s_cl, const unsigned* s_cv, unsigned pred[4])
-{
-  int h[8][2];
-  constexpr int NW = sizeof(PIX) == 2 ? 3 : 2;
-  unsigned S[7][NW];
-#pragma unroll
-  for (int r = 0; r < 7; r++) {
-    const unsigned* q = (const unsigned*)(w + r * pitch);
-#pragma unroll
-    for (int i = 0; i < NW; i++) S[r][i] = q[i];
-  }
-  if (sizeof(PIX) == 2) {
-    const unsigned* tl = s_cl + (xf * 2 + phase) * CL_STRIDE;
-    unsigned U0[3], U1[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { U0[k] = tl[k]; U1[k] = tl[3 + k]; }
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      h[r][0] = d_dot2(S[r][2], U0[2], d_dot2(S[r][1], U0[1], d_dot2z(S[r][0], U0[0])));
-      h[r][1] = d_dot2(S[r][2], U1[2], d_dot2(S[r][1], U1[1], d_dot2z(S[r][0], U1[0])));
-    }
-  } else {
-    const unsigned* tl = s_cl + xf * 4;
-    const unsigned C0 = tl[0], C1 = tl[1], C2 = tl[2];
-    const unsigned sh = (unsigned)phase;
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      const unsigned A0 = __builtin_amdgcn_alignbyte(S[r][1], S[r][0], sh) ^ 0x80808080u, A1 = (S[r][1] >> (8 * sh)) ^ 0x80808080u;
-      h[r][0] = d_dot4k(A0, C0, 8192);
-      h[r][1] = d_dot4(A1, C2, d_dot4k(A0, C1, 8192));
-    }
-  }
-  h[7][0] = h[7][1] = 0;
-  unsigned Q[4][2];
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) Q[k][j] = sizeof(PIX) == 2 ? d_pack_mid16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]) : d_pack_lo16((unsigned)h[2 * k][j], (unsigned)h[2 * k + 1][j]);
-  const unsigned* ty = s_cv + yf * ET_STRIDE;
-  unsigned YE[2], YO[3];
-#pragma unroll
-  for (int k = 0; k < 2; k++) YE[k] = ty[k];
-#pragma unroll
-  for (int k = 0; k < 3; k++) YO[k] = ty[2 + k];
-#pragma unroll
-  for (int m = 0; m < 2; m++) {
-    int ve[2], vo[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      ve[j] = d_dot2(Q[m + 1][j], YE[1], d_dot2z(Q[m][j], YE[0]));
-      vo[j] = d_dot2(Q[m + 2][j], YO[2], d_dot2(Q[m + 1][j], YO[1], d_dot2z(Q[m][j], YO[0])));
-    }
-    pred[2 * m] = d_pack_mid16((unsigned)ve[0], (unsigned)ve[1]);
-    pred[2 * m + 1] = d_pack_mid16((unsigned)vo[0], (unsigned)vo[1]);
-  }
-}
-
-/* The jobs of one workgroup.  MODE 0: windows inside the picture, no explicit weights: the lists are the workgroup's (bi: workgroup-uniform) and the
- * write-back is packed 16-bit arithmetic; 1: explicit weights — one or two lists per lane, the 32-bit write-back; both fetch their windows through LDS
- * (every lane of the workgroup enters, `valid` or not: the phases have barriers).  2: EDGE — windows that leave the picture: per-lane clamped rows
- * (d_mc_luma_lean), weights per lane, valid lanes only. */
+/* One job of the lean kernels (bit depths <= 12).  MODE 0: windows inside the picture, no explicit weights: the lists are the workgroup's
+ * (bi: wave-uniform) and the write-back is packed 16-bit arithmetic; 1: explicit weights — one or two lists per lane, the 32-bit
+ * write-back; 2: EDGE — windows that leave the picture (clamped rows), weights per lane. */
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, int nvalid, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv,
-                                                 unsigned* ext, const DevRef* s_refs, unsigned char* s_win, unsigned* s_wofs, unsigned* s_red);
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs);
 
 /* one launch for the main and the edge job range: blocks [0, nblk_edge8) take edge jobs */
 template <class PIX>
@@ -840,7 +616,6 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     }
   }
   if (ji >= jend) return;          /* (workgroup-uniform: the padding blocks of a range) */
-  const int nvalid = min(M355_INTER_BLOCK, jend - ji);
   ji += threadIdx.x;
 
   /* the reference-frame table (plane pointers / pitches per DPB slot) in LDS: a job looks its references up
@@ -853,38 +628,28 @@ __global__ void __launch_bounds__(M355_INTER_BLOCK, M355_INTER_WAVES) k_inter_jo
     for (int i = threadIdx.x; i < (int)(sizeof(s_refs) / 4); i += M355_INTER_BLOCK) dst[i] = src[i];
   }
   __shared__ __attribute__((aligned(16))) unsigned s_tab[LT_WORDS];
-  __shared__ __attribute__((aligned(16))) unsigned char s_win[M355_WIN_BYTES];
-  __shared__ unsigned s_wofs[2 * M355_INTER_BLOCK];
-  __shared__ unsigned s_red[16];
   if (threadIdx.x < LT_WORDS / 4) ((uint4*)s_tab)[threadIdx.x] = ((const uint4*)p.inter_tabs)[threadIdx.x];
-  if (threadIdx.x < 16) s_red[threadIdx.x] = 0;
   uint32_t job = 0;
-  const bool valid = ji < jend;
-  if (valid) job = p.jobs[ji];          /* (requested beside the tables) */
+  if (ji < jend) job = p.jobs[ji];          /* (requested beside the tables) */
   __syncthreads();
-  if (cls == 3) {
-    if (!valid) return;
-    /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
-    unsigned* ext = (unsigned*)s_win + threadIdx.x * 20;
-    d_inter_job_lean<PIX, 2>(p, true, nvalid, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs, nullptr, nullptr, nullptr);
-  } else if (cls == 2) d_inter_job_lean<PIX, 1>(p, valid, nvalid, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, nullptr, s_refs, s_win, s_wofs, s_red);
-  else d_inter_job_lean<PIX, 0>(p, valid, nvalid, job, cls == 1, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, nullptr, s_refs, s_win, s_wofs, s_red);
+  if (ji >= jend) return;
+  /* EDGE jobs extend their window rows in LDS: 20 words per lane (d_mc_luma_lean) */
+  __shared__ __attribute__((aligned(16))) unsigned s_ext[M355_INTER_BLOCK * 20];
+  unsigned* ext = s_ext + threadIdx.x * 20;
+  if (cls == 3) d_inter_job_lean<PIX, 2>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
+  else if (cls == 2) d_inter_job_lean<PIX, 1>(p, job, false, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
+  else d_inter_job_lean<PIX, 0>(p, job, cls == 1, s_tab + LT_QL, s_tab + LT_QV, s_tab + LT_CL, s_tab + LT_CV, ext, s_refs);
 }
 
 template <class PIX, int MODE>
-__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, int nvalid, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv,
-                                                 unsigned* ext, const DevRef* s_refs, unsigned char* s_win, unsigned* s_wofs, unsigned* s_red)
+__device__ __forceinline__ void d_inter_job_lean(const DevPic& p, uint32_t job, bool bi_u, const unsigned* s_ql, const unsigned* s_qv, const unsigned* s_cl, const unsigned* s_cv, unsigned* ext, const DevRef* s_refs)
 {
-  constexpr bool WEIGHTED = MODE != 0, EDGE = MODE == 2, WIN = !EDGE;
-  constexpr int AL = sizeof(PIX) == 2 ? 1 : 3;          /* a window row starts at the dword-aligned sample at or below its first column */
-  const int tid = threadIdx.x;
-  m355_pb pb;
-  if (valid) pb = p.pbs[job & 0x1FFFFFFu];
-  else { pb.x = pb.y = 0; pb.w = pb.h = 8; pb.flags = 0; pb.ref_slot[0] = pb.ref_slot[1] = 0; pb.mv[0][0] = pb.mv[0][1] = pb.mv[1][0] = pb.mv[1][1] = 0; pb.wt_idx[0] = pb.wt_idx[1] = 0; }
-  const int strip = valid ? (job >> 25) & 15 : 0, rblk = valid ? job >> 29 : 0;
+  constexpr bool WEIGHTED = MODE != 0, EDGE = MODE == 2;
+  const m355_pb pb = p.pbs[job & 0x1FFFFFFu];
+  const int strip = (job >> 25) & 15, rblk = job >> 29;
   const int x0 = pb.x + 4 * strip, y0 = pb.y + 8 * rblk;
   const int rows = min(8, pb.h - 8 * rblk);          /* 4 or 8 */
-  if (valid) {
+  {
     uint32_t* po = p.pb_of + (size_t)(y0 >> 2) * p.w4 + (x0 >> 2);
     po[0] = (job & 0x1FFFFFFu) + 1;
     if (rows > 4) po[p.w4] = (job & 0x1FFFFFFu) + 1;
@@ -898,43 +663,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
   const int wtA = a1 ? pb.wt_idx[1] : pb.wt_idx[0], wtB = pb.wt_idx[1];
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
 
-  /* ---- the workgroup's windows (WIN): which unit a lane belongs to, where the unit's luma / chroma windows lie in the buffer, in which round ---- */
-  WinUnit u = {tid, 1, 0, 0, 1, 0, 8, 0};
-  int cprl = 1, cprc = 1, wofs_l = 0, wofs_c = 0, round_l = 0, round_c = 0, nround_l = 1, nround_c = 1, tot_l = 0, tot_c = 0;
-  if (WIN) {
-    int size_l = 0, size_c = 0;
-    if (valid) {
-      u = d_win_unit(tid, nvalid, strip, rblk, pb.w, pb.h);
-      cprl = d_win_cpr_luma<PIX>(u.strips); cprc = d_win_cpr_chroma<PIX>(u.strips);
-      if (u.idx == 0) { size_l = (u.rows + 7) * cprl * 16; size_c = nc == 3 ? 2 * ((u.rows >> 1) + 3) * cprc * 16 : 0; }
-    }
-    /* exclusive scan of the units' sizes in lane order (k_meta_pb's scheme: wave scans + the earlier waves' totals), the largest unit beside it */
-    const int lane = tid & 63, wv = tid >> 6;
-    int il = size_l, ic = size_c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int tl = __shfl_up(il, (unsigned)d, 64), tc = __shfl_up(ic, (unsigned)d, 64);
-      if (lane >= d) { il += tl; ic += tc; }
-    }
-    if (lane == 63) { s_red[wv] = (unsigned)il; s_red[4 + wv] = (unsigned)ic; }
-    if (size_l) { atomicMax(&s_red[8], (unsigned)size_l); atomicMax(&s_red[9], (unsigned)size_c); }
-    __syncthreads();
-    int base_l = 0, base_c = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int a = (int)s_red[k], c = (int)s_red[4 + k]; tot_l += a; tot_c += c; if (k < wv) { base_l += a; base_c += c; } }
-    if (valid && u.idx == 0) { s_wofs[2 * tid] = (unsigned)(base_l + il - size_l); s_wofs[2 * tid + 1] = (unsigned)(base_c + ic - size_c); }
-    __syncthreads();
-    /* a round = the units that start inside one buffer's worth of bytes (less the largest unit, so that the last one of a round still ends inside) */
-    const int room_l = M355_WIN_BYTES - (int)s_red[8], room_c = M355_WIN_BYTES - (int)s_red[9];
-    wofs_l = (int)s_wofs[2 * u.head]; wofs_c = (int)s_wofs[2 * u.head + 1];
-    if (!valid) wofs_l = wofs_c = 0;
-    while (wofs_l >= room_l) { wofs_l -= room_l; round_l++; }
-    while (wofs_c >= room_c) { wofs_c -= room_c; round_c++; }
-    nround_l = tot_l > 0 ? (tot_l - 1) / room_l + 1 : 1; nround_c = tot_c > 0 ? (tot_c - 1) / room_c + 1 : 1;
-  }
-  const M355_GLOBAL PIX* safe = (const M355_GLOBAL PIX*)p.plane[0];      /* a valid address for the requests of lanes that take no part in a phase */
-
-  /* weights of component c as the one formula of WtSel (WEIGHTED jobs only) */
+  /* weights of component c as the one formula of d_wpred (WEIGHTED jobs only; see d_inter_job) */
   auto make_ws = [&](int c, int bd) {
     WtSel ws;
     const bool weighted = !EDGE || (pb.flags & M355_PBF_WEIGHTED) != 0;      /* (an edge job carries explicit weights or not, per lane) */
@@ -959,7 +688,7 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
        two lists: clip((a + b + rnd2) >> shift2),  shift2 = 15 - bd
      in SATURATING signed 16-bit arithmetic: a sum that leaves int16 is clipped by the reference as well (32767 >> shift2 is exactly the
      largest sample value, 32767 >> shift3 lies above it; -32768 >> s is negative), so the saturated sum gives the same sample. */
-  /* two samples with per-lane weights (put_weighted_pred / _bipred, and the unweighted forms as weights 1 / 0: WtSel's one formula):
+  /* two samples with per-lane weights (put_weighted_pred / _bipred, and the unweighted forms as weights 1 / 0: d_wpred's one formula):
      ((a w0 + b w1 + rnd) >> sh) + o = (a w0 + b w1 + rnd + (o << sh)) >> sh — one v_dot2 per sample on the pairs (a, b).  a, b: two
      samples each, packed */
   auto wt_pair = [&](unsigned a, unsigned b, unsigned wp, int rnd, int sh, int bd_) {
@@ -972,13 +701,6 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
     t = d_pk_max_i16(t, 0u);
     return bi ? t : d_pk_min_i16(t, maxv);
   };
-  /* a WEIGHTED workgroup mixes lanes with one and two lists: its second phase runs when any lane has a second list (workgroup-uniform) */
-  int npass_wg = npass;
-  if (WIN && WEIGHTED) {
-    if (valid && bi) s_red[10] = 1;
-    __syncthreads();
-    npass_wg = s_red[10] ? 2 : 1;
-  }
 
   /* ---- luma ---- */
   {
@@ -987,38 +709,21 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
 #pragma unroll
     for (int y = 0; y < 8; y++) { pa[y][0] = 0; pa[y][1] = 0; }
 #pragma unroll 1
-    for (int pass = 0; pass < (WIN ? npass_wg : npass); pass++) {
+    for (int pass = 0; pass < npass; pass++) {
       unsigned cur[8][2];
-      const bool act = valid && pass < npass && !(pass ? fillB : fillA);
-      const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
-      const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-      if (!WIN) {
+      if (pass ? fillB : fillA) {        /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
 #pragma unroll
-        for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }      /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
-        if (act) d_mc_luma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], p.pw[0], p.ph[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, ext, cur);
+        for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
       } else {
-        const int xa = x0 + (mvx >> 2) - 3, xu = pb.x + 4 * u.strip0 + (mvx >> 2) - 3;          /* first window column of the lane / of its unit */
-        const int pitch = cprl * 16;
-        const M355_GLOBAL PIX* g = (const M355_GLOBAL PIX*)ref->plane[0] + (ptrdiff_t)(pb.y + u.row0 + (mvy >> 2) - 3) * ref->stride[0] + (xu & ~AL);
-        unsigned char* win = s_win + wofs_l;
-        for (int r = 0; r < nround_l; r++) {
-          __syncthreads();                                   /* whoever still read the buffer's last contents is done */
-          const bool mine = act && round_l == r;
-          d_win_stage<PIX>(mine, g, ref->stride[0], u.rows + 7, cprl, u.idx, u.n, win, safe);
-          __syncthreads();
-          if (r == 0) {
-#pragma unroll
-            for (int y = 0; y < 8; y++) { cur[y][0] = 0x20002000u; cur[y][1] = 0x20002000u; }
-          }
-          if (mine) d_mc_luma_win<PIX>(win + u.my_row * pitch + ((xa & ~AL) - (xu & ~AL)) * (int)sizeof(PIX), pitch, xa & AL, mvx & 3, mvy & 3, s_ql, s_qv, cur);
-        }
+        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+        d_mc_luma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[0], ref->stride[0], p.pw[0], p.ph[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, s_ql, s_qv, ext, cur);
       }
       if (pass + 1 < npass) {            /* first list of a bi-predicted block: keep it for the second pass */
 #pragma unroll
         for (int y = 0; y < 8; y++) { pa[y][0] = cur[y][0]; pa[y][1] = cur[y][1]; }
         continue;
       }
-      if (!valid || pass >= npass) continue;
       M355_COMPILER_FENCE();          /* the weight loads must not be hoisted into the filter loops */
       PIX* d = (PIX*)p.plane[0] + (size_t)y0 * p.stride[0] + x0;
       if (WEIGHTED) {
@@ -1051,112 +756,61 @@ __device__ __forceinline__ void d_inter_job_lean(const DevPic& p, bool valid, in
   }
   if (nc == 1) return;
 
-  /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass (one phase; EDGE: their 14 window rows in flight together);
+  /* ---- chroma (4:2:0): 2 columns x 4 rows per plane, BOTH planes per pass so that their 14 window rows are in flight together;
      chroma mv = luma mv in 1/8 pel (motion.cc:196-203) ---- */
   {
     const int bd = sizeof(PIX) == 1 ? 8 : p.pp.bit_depth_chroma;
     const int xc = x0 >> 1, yc = y0 >> 1, crows = rows >> 1;
-    unsigned pa1[4], pa2[4], cur1[4], cur2[4];
+    unsigned pa1[4], pa2[4];
 #pragma unroll
     for (int y = 0; y < 4; y++) { pa1[y] = 0; pa2[y] = 0; }
-    /* list `pass` of this lane: takes part?, reference, vector */
-    auto list_of = [&](int pass, bool& act, const DevRef*& ref, int& mvx, int& mvy) {
-      act = valid && pass < npass && !(pass ? fillB : fillA);
-      ref = &s_refs[pass ? pb.ref_slot[1] : refA];
-      mvx = pass ? pb.mv[1][0] : mvxA; mvy = pass ? pb.mv[1][1] : mvyA;
-    };
-    const int pitch = cprc * 16, wrows = (u.rows >> 1) + 3;
-    /* both planes' windows of one list into the buffer at `base` (the lanes of round r) */
-    auto stage_c = [&](int pass, int r, int base) {
-      bool act; const DevRef* ref; int mvx, mvy;
-      list_of(pass, act, ref, mvx, mvy);
-      const bool mine = act && round_c == r;
-      const int xu = ((pb.x + 4 * u.strip0) >> 1) + (mvx >> 3) - 1;
-      const ptrdiff_t row = (ptrdiff_t)(((pb.y + u.row0) >> 1) + (mvy >> 3) - 1);
-      unsigned char* win = s_win + base + wofs_c;
-      d_win_stage<PIX>(mine, (const M355_GLOBAL PIX*)ref->plane[1] + row * ref->stride[1] + (xu & ~AL), ref->stride[1], wrows, cprc, u.idx, u.n, win, safe);
-      d_win_stage<PIX>(mine, (const M355_GLOBAL PIX*)ref->plane[2] + row * ref->stride[2] + (xu & ~AL), ref->stride[2], wrows, cprc, u.idx, u.n, win + wrows * pitch, safe);
-    };
-    /* the lane's two 2x4 blocks of one list from the windows at `base` -> pa (a first list with a second one to come) or cur */
-    auto filter_c = [&](int pass, int r, int base) {
-      bool act; const DevRef* ref; int mvx, mvy;
-      list_of(pass, act, ref, mvx, mvy);
-      if (!(valid && pass < npass) || (act && round_c != r)) return;
-      unsigned t1[4], t2[4];
-#pragma unroll
-      for (int y = 0; y < 4; y++) { t1[y] = 0x20002000u; t2[y] = 0x20002000u; }      /* reference missing: predSamples = 1 << 13 (motion.cc:362-376) */
-      if (act) {
-        const int xa = xc + (mvx >> 3) - 1, xu = ((pb.x + 4 * u.strip0) >> 1) + (mvx >> 3) - 1;
-        const unsigned char* w = s_win + base + wofs_c + (u.my_row >> 1) * pitch + ((xa & ~AL) - (xu & ~AL)) * (int)sizeof(PIX);
-        d_mc_chroma_win<PIX>(w, pitch, xa & AL, mvx & 7, mvy & 7, s_cl, s_cv, t1);
-        d_mc_chroma_win<PIX>(w + wrows * pitch, pitch, xa & AL, mvx & 7, mvy & 7, s_cl, s_cv, t2);
-      }
-      const bool first = pass + 1 < npass;
-#pragma unroll
-      for (int y = 0; y < 4; y++) { if (first) { pa1[y] = t1[y]; pa2[y] = t2[y]; } else { cur1[y] = t1[y]; cur2[y] = t2[y]; } }
-    };
-    if (!WIN) {
 #pragma unroll 1
-      for (int pass = 0; pass < npass; pass++) {
+    for (int pass = 0; pass < npass; pass++) {
+      unsigned cur1[4], cur2[4];
+      if (pass ? fillB : fillA) {
 #pragma unroll
         for (int y = 0; y < 4; y++) { cur1[y] = 0x20002000u; cur2[y] = 0x20002000u; }
-        if (!(pass ? fillB : fillA)) {
-          const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
-          const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
-          d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], p.pw[1], p.ph[1], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur1);
-          d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], p.pw[2], p.ph[2], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur2);
-        }
-        if (pass + 1 < npass) {
-#pragma unroll
-          for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
-        }
+      } else {
+        const DevRef* ref = &s_refs[pass ? pb.ref_slot[1] : refA];
+        const int mvx = pass ? pb.mv[1][0] : mvxA, mvy = pass ? pb.mv[1][1] : mvyA;
+        d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[1], ref->stride[1], p.pw[1], p.ph[1], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur1);
+        d_mc_chroma_lean<PIX, EDGE>((const M355_GLOBAL PIX*)ref->plane[2], ref->stride[2], p.pw[2], p.ph[2], xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7, s_cl, s_cv, ext, cur2);
       }
-    } else if (npass_wg == 2 && nround_c == 1 && 2 * tot_c <= M355_WIN_BYTES) {
-      /* both lists' chroma windows fit the buffer together: ONE phase (the second list's windows behind the first's) */
-      __syncthreads();
-      stage_c(0, 0, 0); stage_c(1, 0, tot_c);
-      __syncthreads();
-      filter_c(0, 0, 0); filter_c(1, 0, tot_c);
-    } else {
-#pragma unroll 1
-      for (int pass = 0; pass < npass_wg; pass++)
-        for (int r = 0; r < nround_c; r++) {
-          __syncthreads();
-          stage_c(pass, r, 0);
-          __syncthreads();
-          filter_c(pass, r, 0);
-        }
-    }
-    if (!valid) return;
-    M355_COMPILER_FENCE();
-    PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
-    PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
-    if (WEIGHTED) {
-      const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
-      const unsigned wp1 = d_pack16(ws1.w0, ws1.w1), wp2 = d_pack16(ws2.w0, ws2.w1);
-      const int rnd1 = ws1.rnd + (int)((unsigned)ws1.o << ws1.sh), rnd2 = ws2.rnd + (int)((unsigned)ws2.o << ws2.sh);
+      if (pass + 1 < npass) {
 #pragma unroll
-      for (int y = 0; y < 4; y++) {
-        if (y >= crows) break;
-        const unsigned o1 = wt_pair(bi ? pa1[y] : cur1[y], cur1[y], wp1, rnd1, ws1.sh, bd);
-        const unsigned o2 = wt_pair(bi ? pa2[y] : cur2[y], cur2[y], wp2, rnd2, ws2.sh, bd);
-        if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
-        else {
-          *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
-          *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
-        }
+        for (int y = 0; y < 4; y++) { pa1[y] = cur1[y]; pa2[y] = cur2[y]; }
+        continue;
       }
-    } else {
-      const int sh = (bi ? 15 : 14) - bd;
-      const unsigned rnd = (1u << (sh - 1)) * 0x10001u, maxv = ((1u << bd) - 1u) * 0x10001u;
+      M355_COMPILER_FENCE();
+      PIX* d1 = (PIX*)p.plane[1] + (size_t)yc * p.stride[1] + xc;
+      PIX* d2 = (PIX*)p.plane[2] + (size_t)yc * p.stride[2] + xc;
+      if (WEIGHTED) {
+        const WtSel ws1 = make_ws(1, bd), ws2 = make_ws(2, bd);
+        const unsigned wp1 = d_pack16(ws1.w0, ws1.w1), wp2 = d_pack16(ws2.w0, ws2.w1);
+        const int rnd1 = ws1.rnd + (int)((unsigned)ws1.o << ws1.sh), rnd2 = ws2.rnd + (int)((unsigned)ws2.o << ws2.sh);
 #pragma unroll
-      for (int y = 0; y < 4; y++) {
-        if (y >= crows) break;
-        unsigned o1 = pk_pred(pa1[y], cur1[y], rnd, sh, maxv), o2 = pk_pred(pa2[y], cur2[y], rnd, sh, maxv);
-        if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
-        else {
-          *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
-          *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
+        for (int y = 0; y < 4; y++) {
+          if (y >= crows) break;
+          const unsigned o1 = wt_pair(bi ? pa1[y] : cur1[y], cur1[y], wp1, rnd1, ws1.sh, bd);
+          const unsigned o2 = wt_pair(bi ? pa2[y] : cur2[y], cur2[y], wp2, rnd2, ws2.sh, bd);
+          if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
+          else {
+            *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
+            *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
+          }
+        }
+      } else {
+        const int sh = (bi ? 15 : 14) - bd;
+        const unsigned rnd = (1u << (sh - 1)) * 0x10001u, maxv = ((1u << bd) - 1u) * 0x10001u;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          if (y >= crows) break;
+          unsigned o1 = pk_pred(pa1[y], cur1[y], rnd, sh, maxv), o2 = pk_pred(pa2[y], cur2[y], rnd, sh, maxv);
+          if (sizeof(PIX) == 2) { d_st_nt4(d1 + (size_t)y * p.stride[1], o1); d_st_nt4(d2 + (size_t)y * p.stride[2], o2); }
+          else {
+            *(unsigned short*)(d1 + (size_t)y * p.stride[1]) = (unsigned short)d_pack_bytes(o1, 0u);
+            *(unsigned short*)(d2 + (size_t)y * p.stride[2]) = (unsigned short)d_pack_bytes(o2, 0u);
+          }
         }
       }
     }

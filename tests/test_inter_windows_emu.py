@@ -1,9 +1,8 @@
-"""k_inter_jobs fetches the reference windows of a workgroup's jobs through LDS (k_inter.hip, "reference windows through LDS"): units = the jobs of one PB
-inside the workgroup (or, for a PB the workgroup boundary cuts, the run of one row block), laid out by an exclusive scan in lane order, phases in ROUNDS when
-the windows exceed the buffer.  The picture suites mostly see one-round workgroups of mixed PBs; these cases aim at the corners, on the SIMT interpreter
-against the oracle: only 8x8 PBs at 10 bits (61 KB of luma windows per 256 jobs: two rounds), only 64x64 PBs (128 jobs each: every second one is cut by a
-workgroup boundary once the one-list / two-list / weighted ranges interleave), 16x16 and 32x32, explicit weights on half of the blocks (lanes with one and
-two lists in one workgroup), 8-bit planes (byte windows, dword-aligned column offsets), pictures that end in partial CTBs."""
+"""Inter prediction corner cases on the SIMT interpreter against the oracle: pictures of ONE block size (only 8x8 PBs at 10 bits — the densest job lists —, only
+64x64 PBs — 128 jobs each, every second one cut by a workgroup boundary once the one-list / two-list / weighted job ranges interleave —, 16x16, 32x32), explicit
+weights on half of the blocks (lanes with one and two lists in one workgroup), 8-bit and 12-bit planes, missing references, pictures that end in partial CTBs.
+(Written for the LDS-window variant of k_inter_jobs, tools/experiments/inter_windows_through_lds.patch — where a mutant without its rounds fails five of them —
+and kept for the per-lane kernel: they are the job-list shapes the mixed synthetic pictures do not contain.)"""
 import pytest
 
 from oracle_py import Oracle
