@@ -88,8 +88,13 @@ def main():
         import torch.distributed as dist
         if os.environ.get("M355_BENCH_SHARE_GPU"):   # plumbing check of the N>1 path on a box with fewer GPUs than ranks
             local_rank %= max(1, torch.cuda.device_count())
+        # torch's own HIP runtime is brought up only where it carries data (an nccl bootstrap group, the torch / RCCL transports of the tile-sharded leg): a second
+        # runtime's queues in the process cost the library's kernels 6 % by existing and 14-18 % with streams in use (profiles/r06_v5_rccl_idle_ab.txt: what
+        # round 2 booked as "an idle RCCL communicator"); the default transport of the tile-sharded leg (ipc) needs neither torch's runtime nor RCCL
+        torch_gpu = os.environ.get("M355_BENCH_BACKEND", "gloo") == "nccl" or os.environ.get("M355_SHARD_TRANSPORT", "ipc") != "ipc"
         if torch.cuda.is_available():
-            torch.cuda.set_device(local_rank)
+            if torch_gpu:
+                torch.cuda.set_device(local_rank)
         else:
             # no GPU: the CPU tier's plumbing check of this very script (tests/test_bench_launch.py: M355_LIB = the SIMT-interpreter build,
             # every rank on "device" 0, exchanges over gloo) — never a measurement
@@ -510,7 +515,7 @@ def verify_legs(seen, cfg, pic, synth, worklist):
 
 
 def dev_sync(torch):
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() and torch.cuda.is_initialized():     # (only where torch's runtime carries work: ctx.wait() has drained the library's)
         torch.cuda.synchronize()
 
 
@@ -562,7 +567,7 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         on_gpu = torch.cuda.is_available()
         if not on_gpu:
             os.environ.setdefault("M355_SHARD_TRANSPORT", "torch")     # CPU tier: the exchanges over the job's gloo group
-        elif os.environ.get("M355_SHARD_TRANSPORT", "rccl") != "rccl":
+        elif os.environ.get("M355_SHARD_TRANSPORT", "ipc") not in ("rccl", "ipc"):
             grp = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None     # torch's RCCL group for the exchanges
         cfg = dict(synth.CONFIGS[args.workload])
         pic = synth.picture(**cfg)                                 # the SAME picture on every rank
@@ -571,7 +576,9 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
         # transport of the exchanges: "rccl" (default) = issued by the library itself (m355_decode_sharded: phase loop in C++, neighbour
         # ncclSend / ncclRecv + ncclAllGather on the picture's stream; the unique id travels over the bootstrap group);
         # "torch" = the same loop calling back into torch.distributed; "python" = the phase loop in Python (round-2 path)
-        transport = os.environ.get("M355_SHARD_TRANSPORT", "rccl")
+        # "ipc" (default): the library's interprocess transport — exported buffers, interprocess events, a shared-memory segment (csrc/runtime_ipc.hip): one node,
+        # no collective library, no second HIP runtime in the process
+        transport = os.environ.get("M355_SHARD_TRANSPORT", "ipc")
         rccl_id = None
         if transport == "rccl":
             idt = torch.zeros(128, dtype=torch.uint8)
@@ -579,8 +586,11 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
                 idt = torch.frombuffer(bytearray(lib.rccl_unique_id()), dtype=torch.uint8).clone()
             dist.broadcast(idt, 0)
             rccl_id = bytes(idt.tolist())
-        dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(grp) if transport != "rccl" else None, device="cuda:%d" % local_rank if on_gpu else "cpu",
-                                   halo=os.environ.get("M355_SHARD_HALO", "p2p"), native=transport != "python", rccl_id=rccl_id)
+        if transport == "ipc":
+            dec = shard.ShardedDecoder(ctx, rank, world, ipc_name="bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "0")))
+        else:
+            dec = shard.ShardedDecoder(ctx, rank, world, comm=shard.DistComm(grp) if transport != "rccl" else None, device="cuda:%d" % local_rank if on_gpu else "cpu",
+                                       halo=os.environ.get("M355_SHARD_HALO", "p2p"), native=transport != "python", rccl_id=rccl_id)
         refs = []
         for i in range(cfg["n_refs"]):
             f = ctx.frame_create_for(pp)

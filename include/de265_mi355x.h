@@ -570,6 +570,16 @@ M355_API int m355_shard_set_comm(m355_ctx* ctx, const m355_comm* comm);
 M355_API int m355_decode_sharded(m355_ctx* ctx, int handle, int gather);
 M355_API int m355_rccl_unique_id(void* out128);                                  /* rank 0: ncclGetUniqueId (128 bytes) */
 M355_API int m355_shard_rccl_init(m355_ctx* ctx, const void* id128, int rank, int nranks);   /* m355_shard_set + an RCCL communicator on the context's device */
+/* The same exchanges between the rank PROCESSES of one node without a collective library (csrc/runtime_ipc.hip): every rank's exchange buffers are
+ * exported with hipIpcGetMemHandle through a POSIX shared-memory segment named after `name` (a job-unique string, the same on every rank; rank 0
+ * creates the segment) and mapped by their readers — X0..X2: a rank fetches its neighbours' buffers and adds; X3: a rank copies every other rank's
+ * finished tiles straight out of that rank's gather buffer (N - 1 concurrent peer reads, one per xGMI link) — ordered by interprocess events
+ * (M355_IPC_HOST_SYNC=1: by draining the recording stream instead) and per-rank sequence words in the segment.  Every rank must decode the same
+ * pictures in the same order with the same handle numbers (at most 32 handles with exchange buffers, 16 ranks).  m355_shard_set + the callbacks
+ * of m355_decode_sharded; needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only has dmabuf IPC.  M355_IPC_TIMEOUT=<seconds> (default 30)
+ * bounds every wait for another rank. */
+M355_API int m355_shard_ipc_init(m355_ctx* ctx, const char* name, int rank, int nranks);
+M355_API int m355_shard_ipc_close(m355_ctx* ctx);
 /* collective self-test of that transport: `words` 32-bit words through the halo exchange (every other rank as peer; a lone rank
  * sends to itself) and the all-gather, verified on the host */
 M355_API int m355_shard_rccl_selftest(m355_ctx* ctx, size_t words);

@@ -103,6 +103,8 @@ class Library:
         L.m355_rccl_unique_id.argtypes = [vp]
         L.m355_shard_rccl_init.argtypes = [vp, vp, i, i]
         L.m355_shard_rccl_selftest.argtypes = [vp, ctypes.c_size_t]
+        L.m355_shard_ipc_init.argtypes = [vp, ctypes.c_char_p, i, i]
+        L.m355_shard_ipc_close.argtypes = [vp]
         L.m355_group_create.argtypes = [ctypes.POINTER(vp), i, ctypes.POINTER(vp)]
         L.m355_group_destroy.argtypes = [vp]
         L.m355_group_destroy.restype = None
@@ -327,6 +329,13 @@ class Context:
     def shard_rccl_init(self, unique_id, rank, nranks):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         self.L.check(self.L.lib.m355_shard_rccl_init(self.h, buf, rank, nranks))
+
+    def shard_ipc_init(self, name, rank, nranks):
+        """tile sharding across the rank processes of one node without a collective library (m355_shard_ipc_init): `name` = a job-unique string, the same on every rank"""
+        self.L.check(self.L.lib.m355_shard_ipc_init(self.h, name.encode(), rank, nranks))
+
+    def shard_ipc_close(self):
+        self.L.check(self.L.lib.m355_shard_ipc_close(self.h))
 
     def last_serial(self):
         """serial of the decode the last submit / decode call enqueued"""

@@ -249,6 +249,7 @@ void m355_destroy(m355_ctx* c)
   for (auto& b : c->batch) { if (b.host) hipHostFree(b.host); if (b.dev) hipFree(b.dev); if (b.ev) hipEventDestroy(b.ev); }
   for (hipEvent_t e : c->batch_ev_pre) if (e) hipEventDestroy(e);
   for (hipStream_t bs : c->batch_stream) if (bs) hipStreamDestroy(bs);
+  if (c->ipc) m355_shard_ipc_close(c);
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& e_ : c->evring) if (e_.ev) hipEventDestroy(e_.ev);
   if (c->status_words) hipHostFree(c->status_words);

@@ -152,6 +152,7 @@ struct Resident {
      device); the NEXT decode of this handle waits for them before it repacks the buffer — per buffer, not per rank: handles need not
      rotate in step with the lane streams */
   std::vector<hipEvent_t> x3_read;
+  unsigned long long xb_epoch = 0;   /* which allocation xb[] is (counted per process: the interprocess transport exports a new one again) */
   std::vector<int> peers;      /* ranks this rank exchanges halos with */
   EvRef up;                    /* lists copied to the device (decodes on another lane continue behind it) */
   EvRef done;                  /* last decode of these lists: behind it the arenas may be overwritten */
@@ -243,6 +244,8 @@ struct m355_ctx {
   int shard_rank = 0, shard_n = 0;   /* shard_n == 0: sharding off */
   m355_comm comm = {nullptr, nullptr, nullptr};   /* exchanges of m355_decode_sharded */
   void* rccl = nullptr;              /* built-in RCCL communicator (m355_shard_rccl_init) */
+  void* ipc = nullptr;               /* interprocess transport (m355_shard_ipc_init, runtime_ipc.hip) */
+  int xchg_h = -1, xchg_k = -1;      /* m355_decode_sharded: the picture handle / exchange the callbacks are being called for */
   std::vector<hipEvent_t> evs;  /* 7 events per timed decode (ring grows on demand) */
   int ev_used = 0;             /* decodes recorded since the last m355_timing_reset */
   bool timed = false;
@@ -289,6 +292,9 @@ struct Rccl {
   int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
 };
 extern Rccl g_rccl;            /* runtime_shard.hip */
+int ipc_before_repack(m355_ctx* c, int h, hipStream_t st);      /* runtime_ipc.hip: hooks of m355_decode_sharded */
+int ipc_end_picture(m355_ctx* c, int rc_own);
+extern "C" int m355_shard_ipc_close(m355_ctx* c);
 template <class T> static int grow(T** p, size_t* cap, size_t need, hipStream_t st, bool zero)
 {
   if (need <= *cap) return M355_OK;

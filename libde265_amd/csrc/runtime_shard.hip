@@ -197,6 +197,7 @@ static int shard_buffers(m355_ctx* c, int h)
   if (np < 0) return M355_ERR_INVALID;
   r.peers.assign(peers, peers + np);
   r.x3_read.assign((size_t)std::max(1, r.shard_n), nullptr);
+  { static std::atomic<unsigned long long> epochs{0}; r.xb_epoch = ++epochs; }
   r.xscratch_pitch = (mx + 255) & ~(size_t)255;
   if (np) HIPCHK(hipMalloc(&r.xscratch, (r.xscratch_pitch + 256) * (size_t)np));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -215,17 +216,25 @@ int m355_decode_sharded(m355_ctx* c, int h, int gather)
     if (rc0) return rc0;
   }
   const int last = gather ? 4 : 3;
-  for (int k = 0; k <= last; k++) {
-    int rc = m355_decode_phase(c, h, k, k < 4 ? r.xb[k] : nullptr);
-    if (rc) return rc;
-    if (N <= 1 || k >= last) continue;                       /* a single rank owns every tile: nothing to exchange */
-    if (k < 3) {
-      if (!r.peers.empty() && (rc = c->comm.halo_sum(c->comm.user, r.xb[k], r.xb_bytes[k], r.peers.data(), (int)r.peers.size(), r.xscratch, (void*)c->stream)))
-        return fail(M355_ERR_HIP, "halo exchange %d failed (%d)", k, rc);
-    } else if ((rc = c->comm.all_gather(c->comm.user, r.xb[3], r.xb_bytes[3] / (size_t)N, r.shard_rank, N, (void*)c->stream)))
-      return fail(M355_ERR_HIP, "tile all-gather failed (%d)", rc);
-  }
-  return M355_OK;
+  const bool ipc = c->ipc && N > 1;                          /* (runtime_ipc.hip: the transport needs to know which buffers it is moving, and two hooks) */
+  auto run = [&]() -> int {
+    for (int k = 0; k <= last; k++) {
+      int rc = 0;
+      if (ipc && k == 3 && gather && (rc = ipc_before_repack(c, h, (hipStream_t)m355_stream(c)))) return rc;
+      rc = m355_decode_phase(c, h, k, k < 4 ? r.xb[k] : nullptr);
+      if (rc) return rc;
+      if (N <= 1 || k >= last) continue;                       /* a single rank owns every tile: nothing to exchange */
+      c->xchg_h = h; c->xchg_k = k;
+      if (k < 3) {
+        if (!r.peers.empty() && (rc = c->comm.halo_sum(c->comm.user, r.xb[k], r.xb_bytes[k], r.peers.data(), (int)r.peers.size(), r.xscratch, (void*)c->stream)))
+          return rc < 0 ? rc : fail(M355_ERR_HIP, "halo exchange %d failed (%d)", k, rc);
+      } else if ((rc = c->comm.all_gather(c->comm.user, r.xb[3], r.xb_bytes[3] / (size_t)N, r.shard_rank, N, (void*)c->stream)))
+        return rc < 0 ? rc : fail(M355_ERR_HIP, "tile all-gather failed (%d)", rc);
+    }
+    return M355_OK;
+  };
+  const int rc = run();
+  return ipc ? ipc_end_picture(c, rc) : rc;
 }
 
 /* device time of one exchange of a sharded picture's buffers, on its own (bench.py --gpus N: what X0..X3 cost over this transport);
@@ -242,8 +251,11 @@ int m355_shard_time_exchange(m355_ctx* c, int h, int which, int iters, float* ms
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   auto once = [&]() -> int {
-    if (which < 3) return r.peers.empty() ? 0 : c->comm.halo_sum(c->comm.user, r.xb[which], r.xb_bytes[which], r.peers.data(), (int)r.peers.size(), r.xscratch, (void*)c->stream);
-    return c->comm.all_gather(c->comm.user, r.xb[3], r.xb_bytes[3] / (size_t)r.shard_n, r.shard_rank, r.shard_n, (void*)c->stream);
+    c->xchg_h = h; c->xchg_k = which;
+    int rc1 = 0;
+    if (which < 3) rc1 = r.peers.empty() ? 0 : c->comm.halo_sum(c->comm.user, r.xb[which], r.xb_bytes[which], r.peers.data(), (int)r.peers.size(), r.xscratch, (void*)c->stream);
+    else rc1 = c->comm.all_gather(c->comm.user, r.xb[3], r.xb_bytes[3] / (size_t)r.shard_n, r.shard_rank, r.shard_n, (void*)c->stream);
+    return c->ipc ? ipc_end_picture(c, rc1) : rc1;         /* (the interprocess transport counts every exchange round as a picture of its own) */
   };
   int rc = 0;
   for (int i = 0; i < 2 && !rc; i++) rc = once();

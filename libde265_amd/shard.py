@@ -212,14 +212,21 @@ class ShardedDecoder:
     (rccl_id = the unique id rank 0 made with rccl_unique_id and handed round), or `comm` (a DistComm) through CallbackComm.
     native=False: the phase loop in Python over m355_decode_phase (exchange buffers = torch tensors), kept as the cross-check."""
 
-    def __init__(self, ctx, rank, nranks, comm=None, device="cuda", halo="p2p", native=True, rccl_id=None):
-        import torch
-        self.torch = torch
+    def __init__(self, ctx, rank, nranks, comm=None, device="cuda", halo="p2p", native=True, rccl_id=None, ipc_name=None):
         self.ctx, self.rank, self.nranks, self.comm = ctx, rank, nranks, comm
-        self.device = torch.device(device)
-        self.ctx.shard_set(rank, nranks)
         self.native = native and halo == "p2p"
         self.cb = None
+        if ipc_name is not None:
+            # the interprocess transport (csrc/runtime_ipc.hip: exported buffers + interprocess events + a shared-memory segment): no torch, no RCCL in
+            # the data path — a second HIP runtime's streams in the process cost the library's kernels 6-18 % (profiles/r06_v5_rccl_idle_ab.txt)
+            self.torch, self.device, self.native = None, None, True
+            self.ctx.shard_ipc_init(ipc_name, rank, nranks)
+            self.xbufs, self.halo, self._ptrs, self.peers, self.scratch, self._streams = {}, "p2p", {}, {}, {}, {}
+            return
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self.ctx.shard_set(rank, nranks)
         if self.native:
             if rccl_id is not None:
                 self.ctx.shard_rccl_init(rccl_id, rank, nranks)       # ncclSend / ncclRecv / ncclAllGather issued by the library

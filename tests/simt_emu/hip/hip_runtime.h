@@ -99,6 +99,17 @@ hipError_t hipDeviceSynchronize(void);
 hipError_t hipEventCreate(hipEvent_t* e);
 enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+/* interprocess memory / events (runtime_ipc.hip): the CPU tier runs the ranks as THREADS of one process — a "handle" is the pointer itself, an
+   opened event a fresh (inert) one: every launch is synchronous here, what the tier checks is the transport's bookkeeping (segment, sequence words,
+   export table, per-picture meeting), not the ordering on a device */
+enum { hipEventInterprocess = 4, hipIpcMemLazyEnablePeerAccess = 1 };
+struct hipIpcMemHandle_t { char reserved[64]; };
+struct hipIpcEventHandle_t { char reserved[64]; };
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &p, sizeof(p)); return hipSuccess; }
+static inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, h.reserved, sizeof(*p)); return hipSuccess; }
+static inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+static inline hipError_t hipIpcGetEventHandle(hipIpcEventHandle_t* h, hipEvent_t e) { memset(h, 0, sizeof(*h)); memcpy(h->reserved, &e, sizeof(e)); return hipSuccess; }
+static inline hipError_t hipIpcOpenEventHandle(hipEvent_t* e, hipIpcEventHandle_t) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = 0);
 hipError_t hipEventSynchronize(hipEvent_t e);

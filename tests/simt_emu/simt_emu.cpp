@@ -1,6 +1,7 @@
 /* tests/simt_emu/simt_emu.cpp — fiber scheduler + trivial host runtime of the SIMT interpreter.
  * See hip/hip_runtime.h in this directory for what this is (and is not). */
 #include "hip/hip_runtime.h"
+#include <mutex>
 
 uint3 threadIdx, blockIdx;
 dim3 blockDim, gridDim;
@@ -169,6 +170,10 @@ namespace simt {
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body, const char* kernel_name)
 {
+  /* one launch at a time: __shared__ variables are statics and the thread built-ins globals here — host threads of different contexts (the ranks of
+     tests/test_shard_ipc_emu.py) take turns */
+  static std::mutex launch_mu;
+  std::lock_guard<std::mutex> launch_lock(launch_mu);
   gridDim = grid; blockDim = block;
   const int n = (int)(block.x * block.y * block.z);
   Block b;

@@ -1,0 +1,62 @@
+"""Tile sharding across rank PROCESSES, executed: the interprocess transport of csrc/runtime_ipc.hip (m355_shard_ipc_init) with 2, 4 and 8 ranks as separate
+processes that SHARE the one GPU of the box — real exported buffers (hipIpcGetMemHandle / hipIpcOpenMemHandle), real interprocess events, the sequence words in
+a POSIX shared-memory segment — each rank decoding its tiles of the same pictures, three handles in flight, reference and non-reference pictures, every frame
+of every rank compared with the oracle's whole-picture decode.  Also with M355_IPC_HOST_SYNC=1 (the recorder drains its stream, nobody waits on the device).
+RCCL refuses two ranks on one device (tests/test_gpu_rccl.py); this transport has no such restriction, so the N > 1 control flow of one-process-per-GPU runs on the
+hardware here, on one GPU — what it cannot show is xGMI."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+SMALL = [dict(width=416, height=240, bit_depth=8, seed=91, tile_cols=2, tile_rows=1), dict(width=1280, height=720, bit_depth=10, seed=92, tile_cols=2, tile_rows=2)]
+C4 = [dict(width=3840, height=2160, bit_depth=8, tile_cols=2, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1, seed=0xC4C4C4C4)]
+C5 = [dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1, seed=0xC5C5C5C5)]
+EIGHT = [dict(width=1024, height=512, bit_depth=8, seed=93, tile_cols=4, tile_rows=2)]
+
+
+def run_ranks(nranks, cases, depth=3, env_extra=None, timeout=600):
+    name = "t%d_%d" % (os.getpid(), abs(hash((nranks, json.dumps(cases), str(env_extra)))) % 100000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", M355_IPC_TIMEOUT="120", **(env_extra or {}))
+    with tempfile.TemporaryDirectory() as td:
+        procs = []
+        for r in range(nranks):
+            out = os.path.join(td, "r%d.json" % r)
+            procs.append((out, subprocess.Popen([sys.executable, os.path.join(HERE, "shard_ipc_worker.py"), str(r), str(nranks), name, out, json.dumps(cases), str(depth)],
+                                                env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        res = []
+        for out, p in procs:
+            try:
+                so, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                for _, q in procs:
+                    q.kill()
+                raise AssertionError("a rank process hangs")
+            res.append(json.load(open(out)) if os.path.exists(out) else {"ok": False, "error": "no result: " + (so or "")[-400:]})
+    assert all(r.get("ok") for r in res), res
+    assert all(r["frames"] == depth * len(cases) for r in res), res
+
+
+@pytest.mark.parametrize("nranks,cases", [(2, SMALL), (4, SMALL[1:]), (8, EIGHT), (3, EIGHT)], ids=["2ranks", "4ranks", "8ranks", "3ranks_8tiles"])
+def test_rank_processes_share_the_gpu(nranks, cases):
+    run_ranks(nranks, cases)
+
+
+def test_rank_processes_host_sync_fallback():
+    run_ranks(2, SMALL, env_extra=dict(M355_IPC_HOST_SYNC="1"))
+
+
+def test_c4_on_four_rank_processes_full_size():
+    run_ranks(4, C4, depth=3, timeout=900)
+
+
+def test_c5_on_eight_rank_processes_full_size():
+    run_ranks(8, C5, depth=2, timeout=1200)

@@ -58,7 +58,7 @@ print("RESULT %%s %%.4f %%.4f %%.4f" %% (arm, r[4], r[0], r[8]))
 '''
 workload = sys.argv[1] if len(sys.argv) > 1 else "c5_8k10_8tiles"
 steps = sys.argv[2] if len(sys.argv) > 2 else "100"
-for arm in ("base", "torch", "streams", "nccl", "nccl_1ch", "nccl_gone", "own_rccl", "base"):
+for arm in (os.environ.get("M355_AB_ARMS", "base,torch,streams,nccl,nccl_1ch,nccl_gone,base").split(",")):
     env = dict(os.environ)
     if arm == "nccl_1ch":
         env.update(NCCL_MIN_NCHANNELS="1", NCCL_MAX_NCHANNELS="1")
