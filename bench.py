@@ -688,6 +688,8 @@ def tile_sharded_leg(args, dist, torch, lib, local_rank, synth, worklist):
                 "tiles_per_rank": (cfg["tile_cols"] * cfg["tile_rows"]) / world, "frames_identical_on_all_ranks": bool(same),
                 "exchange": {"halo_allreduce_bytes": xb[:3], "tile_allgather_bytes": xb[3]}}
     except Exception as e:  # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
         return {"error": repr(e)[:300]}
 
 

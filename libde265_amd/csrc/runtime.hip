@@ -240,6 +240,7 @@ void m355_destroy(m355_ctx* c)
   if (!c) return;
   hipSetDevice(c->device);
   sync_all(c);
+  if (c->ipc) m355_shard_ipc_close(c);          /* (first: it waits for the other ranks' last reads of this rank's exchange buffers) */
   for (auto& f : c->frames) if (f.used) frame_free(f);
   for (auto& r : c->resident) if (r.used) resident_free(r);
   for (auto& t : c->transient) resident_free(t);
@@ -249,7 +250,6 @@ void m355_destroy(m355_ctx* c)
   for (auto& b : c->batch) { if (b.host) hipHostFree(b.host); if (b.dev) hipFree(b.dev); if (b.ev) hipEventDestroy(b.ev); }
   for (hipEvent_t e : c->batch_ev_pre) if (e) hipEventDestroy(e);
   for (hipStream_t bs : c->batch_stream) if (bs) hipStreamDestroy(bs);
-  if (c->ipc) m355_shard_ipc_close(c);
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& e_ : c->evring) if (e_.ev) hipEventDestroy(e_.ev);
   if (c->status_words) hipHostFree(c->status_words);
@@ -650,6 +650,7 @@ int m355_picture_replace(m355_ctx* c, int h, const m355_picture* pic)
   if (r.done.ticket) { HIPCHK(ev_sync(c, r.done)); r.done = EvRef(); }
   if (r.xb[0] && (memcmp(&r.hdr.pp, &pic->pp, sizeof(pic->pp)) != 0 || r.shard_n != c->shard_n || r.shard_rank != c->shard_rank)) {
     /* the exchange buffers of a sharded picture are sized by its geometry and tile structure */
+    if (c->ipc) ipc_before_free(c, h);
     drain_all_devices(c->device);
     for (void*& b : r.xb) { if (b) hipFree(b); b = nullptr; }
     if (r.xscratch) { hipFree(r.xscratch); r.xscratch = nullptr; }
@@ -668,6 +669,7 @@ int m355_picture_release(m355_ctx* c, int h)
   if (h < 0 || h >= (int)c->resident.size() || !(c->resident[h].used || c->resident[h].reserved)) return fail(M355_ERR_INVALID, "bad picture handle");
   hipSetDevice(c->device);
   sync_all(c);
+  if (c->ipc && c->resident[h].xb[0]) ipc_before_free(c, h);     /* (the other rank processes' last reads of this handle's gather buffer) */
   resident_free(c->resident[h]);
   return M355_OK;
 }

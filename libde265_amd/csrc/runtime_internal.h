@@ -294,6 +294,7 @@ struct Rccl {
 extern Rccl g_rccl;            /* runtime_shard.hip */
 int ipc_before_repack(m355_ctx* c, int h, hipStream_t st);      /* runtime_ipc.hip: hooks of m355_decode_sharded */
 int ipc_end_picture(m355_ctx* c, int rc_own);
+int ipc_before_free(m355_ctx* c, int h);
 extern "C" int m355_shard_ipc_close(m355_ctx* c);
 template <class T> static int grow(T** p, size_t* cap, size_t need, hipStream_t st, bool zero)
 {

@@ -220,16 +220,16 @@ int m355_decode_sharded(m355_ctx* c, int h, int gather)
   auto run = [&]() -> int {
     for (int k = 0; k <= last; k++) {
       int rc = 0;
-      if (ipc && k == 3 && gather && (rc = ipc_before_repack(c, h, (hipStream_t)m355_stream(c)))) return rc;
+      if (ipc && k == 3 && (rc = ipc_before_repack(c, h, (hipStream_t)m355_stream(c)))) return rc;      /* (phase 3 packs this rank's tiles whether or not they are gathered) */
       rc = m355_decode_phase(c, h, k, k < 4 ? r.xb[k] : nullptr);
       if (rc) return rc;
       if (N <= 1 || k >= last) continue;                       /* a single rank owns every tile: nothing to exchange */
       c->xchg_h = h; c->xchg_k = k;
       if (k < 3) {
         if (!r.peers.empty() && (rc = c->comm.halo_sum(c->comm.user, r.xb[k], r.xb_bytes[k], r.peers.data(), (int)r.peers.size(), r.xscratch, (void*)c->stream)))
-          return rc < 0 ? rc : fail(M355_ERR_HIP, "halo exchange %d failed (%d)", k, rc);
+          return ipc ? rc : fail(M355_ERR_HIP, "halo exchange %d failed (%d)", k, rc);      /* (the interprocess transport has said what failed) */
       } else if ((rc = c->comm.all_gather(c->comm.user, r.xb[3], r.xb_bytes[3] / (size_t)N, r.shard_rank, N, (void*)c->stream)))
-        return rc < 0 ? rc : fail(M355_ERR_HIP, "tile all-gather failed (%d)", rc);
+        return ipc ? rc : fail(M355_ERR_HIP, "tile all-gather failed (%d)", rc);
     }
     return M355_OK;
   };
@@ -331,8 +331,8 @@ static int group_rank_decode(m355_group* g, int r, unsigned long long n, const i
   int rc = rc0;
   for (int k = 0; k <= last; k++) {
     /* (a rank that failed keeps publishing its steps: the others must not wait for it forever) */
-    if (k == 3 && gather && N > 1)
-      /* the gather buffer of THIS handle is repacked: every rank's X3 read of the handle's previous decode has to be over (the halo exchanges in
+    if (k == 3 && N > 1)
+      /* the gather buffer of THIS handle is repacked (phase 3 packs this rank's tiles whether or not they are then gathered): every rank's X3 read of the handle's previous decode has to be over (the halo exchanges in
          between order it only three hops along a rank row).  The events belong to the buffer (Resident::x3_read[reader]); they were recorded
          before that m355_group_decode returned — a never-recorded one is no wait */
       x3_wait_readers(me, r, (hipStream_t)m355_stream(c));
@@ -468,7 +468,7 @@ static int group_decode_lockstep(m355_group* g, const int* handles, int gather)
     for (int r = 0; r < N; r++) {
       m355_ctx* c = g->ctx[(size_t)r];
       hipSetDevice(c->device);
-      if (k == 3 && gather && N > 1) x3_wait_readers(*R[(size_t)r], r, (hipStream_t)m355_stream(c));   /* (as group_rank_decode) */
+      if (k == 3 && N > 1) x3_wait_readers(*R[(size_t)r], r, (hipStream_t)m355_stream(c));   /* (as group_rank_decode) */
       const int rc = m355_decode_phase(c, handles[r], k, k < 4 ? R[(size_t)r]->xb[k] : nullptr);
       if (rc) return rc;
       if (N > 1 && k < last) hipEventRecord(g->ev_pack[(size_t)r][(size_t)k], (hipStream_t)m355_stream(c));

@@ -67,7 +67,7 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErr
 typedef struct simt_stream* hipStream_t;
 typedef struct simt_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipHostMallocDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2 };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; char gcnArchName[256]; size_t totalGlobalMem; };
 
 const char* hipGetErrorString(hipError_t e);
@@ -148,6 +148,8 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
 static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned s) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> ((s & 3) * 8)); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
+static inline unsigned long long wall_clock64() { return 0; }      /* (only the interprocess transport's wait kernel reads it, and the interpreter never launches that) */
 
 template <class T> static inline T simt_exchange(T v, int src)
 {
