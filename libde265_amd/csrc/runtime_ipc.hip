@@ -49,6 +49,7 @@ struct IpcRank {
   hipIpcMemHandle_t flags;                                   /* the rank's flag words */
   std::atomic<unsigned long long> host_flag[IPC_FLAGS];      /* the same numbers for host-side waits (M355_IPC_HOST_SYNC, the interpreter) */
   struct Buf { std::atomic<unsigned long long> gen; hipIpcMemHandle_t mem[4]; } buf[IPC_MAXH];   /* the exchange buffers of handle h (gen 0: none) */
+  std::atomic<unsigned long long> rel[IPC_MAXH];            /* how many generations of handle h's buffers this rank has let go of (ipc_before_free: a meeting of all ranks) */
 };
 struct IpcShm {
   std::atomic<unsigned> magic, abort_flag;
@@ -66,8 +67,10 @@ struct Ipc {
   /* what this rank opened of the others */
   struct Peer {
     unsigned long long* flags = nullptr;
-    struct Map { unsigned long long gen = 0; void* p[4] = {nullptr, nullptr, nullptr, nullptr}; } map[IPC_MAXH];
+    struct Map { unsigned long long gen = 0, closed = 0; void* p[4] = {nullptr, nullptr, nullptr, nullptr}; } map[IPC_MAXH];   /* closed: the last generation this rank has let go of */
   } peer[IPC_MAXR];
+  unsigned long long rel_count[IPC_MAXH] = {};
+  bool broken = false;                                       /* a wait for another rank has failed: no further meetings */
   unsigned long long my_gen[IPC_MAXH] = {};                  /* generation under which handle h's buffers were exported (0: not yet) */
   unsigned long long exported[IPC_MAXH] = {};                /* ... and which allocation that was (Resident::xb_epoch: a re-allocation is exported again) */
   unsigned long long x3_packed[IPC_MAXH] = {};               /* the number of this rank's last gather on handle h (0: none): what the readers' flags must reach before it is repacked */
@@ -136,8 +139,8 @@ static int ipc_peer_buf(Ipc& I, int q, int h, int k, void** out)
   IpcRank::Buf& B = I.shm->rank[q].buf[h];
   Ipc::Peer::Map& M = I.peer[q].map[h];
   unsigned long long gen = B.gen.load(std::memory_order_acquire);
-  if (!gen) {
-    int rc = ipc_await(I, B.gen, 1, "buffers exported", q);
+  if (gen <= M.closed) {          /* (not yet exported — or still the generation this rank let go of at the handle's release: the owner exports the new buffers at its first exchange) */
+    int rc = ipc_await(I, B.gen, M.closed + 1, "buffers exported", q);
     if (rc) return rc;
     gen = B.gen.load(std::memory_order_acquire);
   }
@@ -252,16 +255,34 @@ int ipc_before_repack(m355_ctx* c, int h, hipStream_t st)
   }
   return M355_OK;
 }
-/* the exchange buffers of handle h are about to be freed (or this rank leaves): the other ranks' last reads of its gather buffer have to be over — the
-   halo buffers' readers were waited for by the exchange itself (step 2), the gather buffer's are only waited for by its next repack */
+/* The exchange buffers of handle h are about to be freed (m355_picture_release, a re-allocation, the rank leaving) — a MEETING of all ranks, which release their
+   handles in the same order as they decode: (1) the other ranks' last reads of this rank's gather buffer are over (the halo buffers' readers were waited for by
+   the exchange itself, the gather buffer's only by its next repack); (2) this rank lets go of its mappings of the others' buffers of h; (3) every rank has done
+   the same — only then may anybody free: a reader that ran ahead into the handle's next life would otherwise copy out of the old mapping.  The next use maps the
+   generation the owner exports then (ipc_peer_buf waits for one newer than the one closed here). */
 int ipc_before_free(m355_ctx* c, int h)
 {
   Ipc& I = *(Ipc*)c->ipc;
-  if (h < 0 || h >= IPC_MAXH || !I.x3_packed[h] || I.shm->abort_flag.load()) return M355_OK;
-  hipStream_t st = (hipStream_t)m355_stream(c);
-  int rc = ipc_before_repack(c, h, st);
-  if (!rc && !I.host_sync && hipStreamSynchronize(st) != hipSuccess) rc = fail(M355_ERR_HIP, "hipStreamSynchronize failed");
+  if (h < 0 || h >= IPC_MAXH || !I.my_gen[h]) return M355_OK;
+  int rc = M355_OK;
+  if (!I.broken && !I.shm->abort_flag.load()) {
+    hipStream_t st = (hipStream_t)m355_stream(c);
+    if (I.x3_packed[h]) rc = ipc_before_repack(c, h, st);
+    if (!rc && !I.host_sync && hipStreamSynchronize(st) != hipSuccess) rc = fail(M355_ERR_HIP, "hipStreamSynchronize failed");
+  }
+  for (int q = 0; q < I.n; q++) {
+    Ipc::Peer::Map& M = I.peer[q].map[h];
+    for (int j = 0; j < 4; j++) if (M.p[j]) { hipIpcCloseMemHandle(M.p[j]); M.p[j] = nullptr; }
+    if (M.gen) M.closed = M.gen;
+    M.gen = 0;
+  }
+  I.shm->rank[I.rank].buf[h].gen.store(0, std::memory_order_release);      /* (unpublished before the meeting ends: nobody can pick the old export up afterwards) */
+  I.shm->rank[I.rank].rel[h].store(++I.rel_count[h], std::memory_order_release);
+  for (int q = 0; q < I.n && !rc && !I.broken; q++)
+    if (q != I.rank) rc = ipc_await(I, I.shm->rank[q].rel[h], I.rel_count[h], "handle released", q);
+  if (rc) I.broken = true;
   I.x3_packed[h] = 0;
+  I.my_gen[h] = 0;
   return rc;
 }
 /* behind the last call of a picture (or of one exchange timed on its own): the picture number moves on — on every rank alike */
