@@ -23,7 +23,7 @@ C5 = [dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intr
 EIGHT = [dict(width=1024, height=512, bit_depth=8, seed=93, tile_cols=4, tile_rows=2)]
 
 
-def run_ranks(nranks, cases, depth=3, env_extra=None, timeout=600):
+def run_ranks(nranks, cases, depth=3, env_extra=None, timeout=240):
     name = "t%d_%d" % (os.getpid(), abs(hash((nranks, json.dumps(cases), str(env_extra)))) % 100000)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", M355_IPC_TIMEOUT="120", **(env_extra or {}))
     with tempfile.TemporaryDirectory() as td:
