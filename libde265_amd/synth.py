@@ -60,6 +60,13 @@ CONFIGS = {
                      seed=0xC5C5C5C5, fixed_cu_log2=6, oob_mv_pct=0),
     "c5x_cu16": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
                      seed=0xC5C5C5C5, fixed_cu_log2=4, oob_mv_pct=0),
+    # ... without explicit weights and out-of-picture vectors (k_inter_jobs' two main classes only), all PBs predicted from one list / from two
+    "c5x_plain": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
+                      seed=0xC5C5C5C5, oob_mv_pct=0, weighted_pct=0),
+    "c5x_uni": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
+                    seed=0xC5C5C5C5, oob_mv_pct=0, weighted_pct=0, bipred_pct=0),
+    "c5x_bi": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
+                   seed=0xC5C5C5C5, oob_mv_pct=0, weighted_pct=0, bipred_pct=100),
     "c5x_noedge": dict(width=7680, height=4320, bit_depth=10, tile_cols=4, tile_rows=2, intra_pct=3, n_refs=2, deblock=1, sao=1,
                        seed=0xC5C5C5C5, oob_mv_pct=0),
 }
