@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--intra-batch", type=int, default=0, help="intra workloads: the timed region's steps go out in groups of this many pictures with ONE intra stage "
                     "(m355_decode_batch; needs --pipeline-depth >= the group); a step is still one whole picture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--group-sync", type=int, default=0, help="DIAGNOSTIC ONLY: wait for the device after every N steps of the timed region (pictures start in phase-aligned groups)")
     ap.add_argument("--stages", type=int, default=31, help="DIAGNOSTIC ONLY: M355_STAGE_* mask (anything but 31 is not a valid benchmark)")
     ap.add_argument("--no-with-upload", action="store_true", help="skip the PCIe-inclusive legs (lists recorded into the pinned arena -> validation -> H2D -> decode, per step)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the bitstream-level leg (synthetic 8K stream through the reference CLI on the reference library and on the glue library)")
@@ -163,6 +164,8 @@ def main():
         if not batch:
             for i in range(n):
                 ctx.decode_resident(handles[i % len(handles)])
+                if args.group_sync and (i + 1) % args.group_sync == 0:
+                    ctx.wait()
             return
         i = 0
         while i < n:                          # groups of `batch` pictures, one shared k_intra launch each
