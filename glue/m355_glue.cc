@@ -126,6 +126,7 @@ enum { FEAT_PCM_CU, FEAT_WEIGHTED_PB, FEAT_BYPASS_RB, FEAT_SKIP_RB, FEAT_RDPCM_R
        FEAT_MULTI_SLICE_PIC, FEAT_WEIGHTED_PB_LATER_SLICE, FEAT_NO_BOUNDARY_FILTER_IB, FEAT_FILL_PB, FEAT_CHROMA_422_RB, FEAT_CHROMA_444_RB,
        FEAT_MONO_PIC, FEAT_DEBLOCK_OFF_SLICE, M355_GLUE_N_FEATURES };
 std::atomic<long long> g_feat[M355_GLUE_N_FEATURES];
+enum { RBF_ROTATE_PENDING = 0x80 };   /* m355_rb.flags bit the recorder alone uses (scale_coefficients): never reaches the library */
 
 struct Run { uint32_t ctb, start, count; };
 
@@ -956,6 +957,10 @@ bool submit_picture(Glue* g, Glue::Job& job)
           const std::vector<m355_rb>& v = r->rbs[sb];
           for (size_t i = 0; i < v.size(); i++) {
             m355_rb rb = v[i];
+            if (rb.flags & RBF_ROTATE_PENDING) {                  /* (scale_coefficients: the chroma block's look-up, now that every tile is parsed) */
+              rb.flags &= (uint8_t)~RBF_ROTATE_PENDING;
+              if (img->get_pred_mode(rb.x, rb.y) == MODE_INTRA) { rb.flags |= M355_RBF_ROTATE; g_feat[FEAT_ROTATE_RB]++; }
+            }
             rb.coeff_ofs += co_base[t];
             if (rb.flags & M355_RBF_DEFERRED) rb.res_ofs += res_base[t];
             dst[i] = rb;
@@ -1248,14 +1253,22 @@ void scale_coefficients(thread_context* tctx, int xT, int yT, int x0, int y0, in
   rb.x = (uint16_t)xT; rb.y = (uint16_t)yT; rb.cidx = (uint8_t)cIdx; rb.log2_size = (uint8_t)log2;
   rb.qp = (uint8_t)(cIdx == 0 ? tctx->qPYPrime : (cIdx == 1 ? tctx->qPCbPrime : tctx->qPCrPrime));       /* transform.cc:371-377 */
   const bool cuIntra = img->get_pred_mode(xT, yT) == MODE_INTRA;      /* transform.cc:398: looked up at (xT,yT) as given — restated literally */
-  const bool rotate = sps.range_extension.transform_skip_rotation_enabled_flag && nT == 4 && cuIntra;   /* :400-402 */
+  /* ... which for a CHROMA block of a 4:2:0 / 4:2:2 picture is a position up / left of the block (its chroma coordinates in the luma-indexed array):
+     in single-threaded decoding order a unit parsed earlier — but with tile (or WPP) threads possibly a unit of ANOTHER tile that its thread has not
+     reached yet, and the reference's own output then depends on the race (tools/soak_streams.py found it: 4:2:2, tile columns, transform_skip_rotation,
+     profiles/r06_v29_*).  The recorder leaves that one decision open (RBF_ROTATE_PENDING, glue-internal) and build_lists takes it once the whole picture is
+     parsed: always what the reference decodes single-threaded. */
+  const bool rot_on = sps.range_extension.transform_skip_rotation_enabled_flag && nT == 4;
+  const bool rot_later = rot_on && cIdx != 0 && (sps.SubWidthC != 1 || sps.SubHeightC != 1);
+  const bool rotate = rot_on && !rot_later && cuIntra;                /* :400-402 */
+  const uint8_t rot_flag = rot_later ? RBF_ROTATE_PENDING : (rotate ? M355_RBF_ROTATE : 0);
   if (tctx->cu_transquant_bypass_flag) {
     rb.kind = M355_RK_BYPASS;
-    if (rotate) rb.flags |= M355_RBF_ROTATE;
+    rb.flags |= rot_flag;
     r->feat[FEAT_BYPASS_RB]++;
   } else if (transform_skip_flag) {
     rb.kind = M355_RK_SKIP;
-    if (rotate) rb.flags |= M355_RBF_ROTATE;
+    rb.flags |= rot_flag;
     r->feat[FEAT_SKIP_RB]++;
   } else rb.kind = (nT == 4 && cIdx == 0 && cuIntra) ? M355_RK_DST : M355_RK_DCT;                          /* :601-606 */
   if (rb.kind == M355_RK_BYPASS || rb.kind == M355_RK_SKIP) {

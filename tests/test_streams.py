@@ -420,3 +420,38 @@ def test_parameter_sets_change_mid_stream_gpu(ref, tmp_path, monkeypatch):
     # ... and with every picture taken without a look at its samples (frames of the old size are released while decodes of the new size run)
     got = de265_py.decode_stream(glue_lib(), data, threads=8, touch_planes=False)
     assert got[1] == n and set(got[2]) <= {1000}, got
+
+
+# transform_skip_rotation of a CHROMA block: the reference looks the prediction mode up at the block's chroma coordinates in the luma-indexed array
+# (transform.cc:398) — with 4:2:2 and tile columns a position in ANOTHER tile, which that tile's thread may or may not have parsed yet: the reference's own
+# output varies from run to run once tile threads are used (tools/soak_streams.py found it on the hardware, profiles/r06_v29_stream_soak_reference_race.txt; it is
+# deterministic single-threaded).  The glue leaves that one decision open until the picture is parsed (glue/m355_glue.cc RBF_ROTATE_PENDING), so with ANY number
+# of threads the backend shows what the reference decodes single-threaded.  (w, h, bd, tc, tr, frames, seed, intra, b, sao, features, slices, geom: three of the
+# soak's streams)
+ROTATE_LOOKUP_CASES = [(256, 128, 8, 3, 1, 2, 594, 3, 0, 0, 290, 2, 56), (768, 256, 8, 2, 1, 4, 307, 3, 0, 1, 276, 1, 0), (640, 256, 8, 2, 1, 6, 70, 3, 0, 0, 8532, 1, 97)]
+
+
+def check_rotate_lookup(ref, tmp_path, case, backend, runs):
+    w, h, bd, tc, tr, frames, seed, intra, b, sao, feat, slices, geom = case
+    data = make_stream(tmp_path, w, h, bd, tc, tr, frames, seed, intra, b, sao, feat, 2, slices, geom)
+    want = de265_py.decode_stream(ref, data, threads=0, scalar=True)
+    assert want[1] == frames and not want[2]
+    lib = glue_lib()
+    for threads in [8] * runs + [0, 3]:
+        got = de265_py.decode_stream(lib, data, threads=threads)
+        assert got[:2] == want[:2], "threads %d: the backend differs from the single-threaded reference" % threads
+    assert lib.m355_glue_cpu_pixel_calls() == 0
+    assert os.path.realpath(lib.m355_glue_backend_path().decode()) == os.path.realpath(backend)
+
+
+@pytest.mark.parametrize("case", ROTATE_LOOKUP_CASES[:1], ids=lambda c: "seed%d" % c[6])
+def test_chroma_rotation_lookup_is_thread_independent_emulated_backend(ref, emu_lib, tmp_path, monkeypatch, case):  # noqa: F811
+    monkeypatch.setenv("M355_LIB", EMU_SO)
+    check_rotate_lookup(ref, tmp_path, case, EMU_SO, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ROTATE_LOOKUP_CASES, ids=lambda c: "seed%d" % c[6])
+def test_chroma_rotation_lookup_is_thread_independent_gpu(ref, tmp_path, monkeypatch, case):
+    monkeypatch.delenv("M355_LIB", raising=False)
+    check_rotate_lookup(ref, tmp_path, case, capi.DEFAULT_LIB, 8)
