@@ -253,6 +253,7 @@ void m355_destroy(m355_ctx* c)
   if (c->rccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl);
   for (auto& e_ : c->evring) if (e_.ev) hipEventDestroy(e_.ev);
   if (c->status_words) hipHostFree(c->status_words);
+  if (c->stage) hipHostFree(c->stage);
   for (hipEvent_t e : c->dl_evs) if (e) hipEventDestroy(e);
   {
     /* the active lane lives in the context's own fields: collect it into a Lane and destroy both */
@@ -321,15 +322,51 @@ int m355_frame_destroy(m355_ctx* c, int h)
   frame_free(*f);
   return M355_OK;
 }
+/* The blocking transfers of a plane go through a pinned staging buffer of the context and a copy QUEUED ON A STREAM OF THE LIBRARY (the frame's last writer's for a
+ * download) — not a blocking hipMemcpy2D between the device and pageable memory on the null stream.  Round 6's soak with 32 processes sharing the GPU and pictures of
+ * 1-14 Mi samples (tools/soak_recheck.py, profiles/r06_v35_*): the blocking copies now and then delivered planes with stale / missing rows IN BOTH DIRECTIONS — 46 of
+ * 1600 pictures: a reference uploaded wrong (every decode from it then repeats the same wrong samples), or a correct frame downloaded wrong with a different set of
+ * samples on every call — while the copies of m355_frame_download_async (pinned planes, the writer's stream) were right every time; alone on the GPU neither fails. */
+static int stage_reserve(m355_ctx* c, size_t bytes)
+{
+  if (bytes <= c->stage_bytes) return M355_OK;
+  if (c->stage) { hipHostFree(c->stage); c->stage = nullptr; c->stage_bytes = 0; }
+  const size_t want = (bytes + ((size_t)4 << 20) - 1) & ~(((size_t)4 << 20) - 1);
+  if (hipHostMalloc(&c->stage, want, hipHostMallocDefault) != hipSuccess) { c->stage = nullptr; return fail(M355_ERR_NOMEM, "staging buffer of %zu bytes", want); }
+  c->stage_bytes = want;
+  return M355_OK;
+}
+/* rows of row_bytes bytes: device plane -> host (pitch dst_pitch bytes) */
+static int frame_stage_down(m355_ctx* c, Frame* f, int cidx, void* dst, size_t dst_pitch)
+{
+  const size_t rb = (size_t)f->pw[cidx] * f->bpp[cidx];
+  int rc = stage_reserve(c, rb * f->ph[cidx]);
+  if (rc) return rc;
+  hipStream_t st = f->wr_stream ? f->wr_stream : c->stream;
+  HIPCHK(hipMemcpy2DAsync(c->stage, rb, f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx], rb, f->ph[cidx], hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (dst_pitch == rb) memcpy(dst, c->stage, rb * f->ph[cidx]);
+  else for (int y = 0; y < f->ph[cidx]; y++) memcpy((uint8_t*)dst + (size_t)y * dst_pitch, (const uint8_t*)c->stage + (size_t)y * rb, rb);
+  return M355_OK;
+}
+static int frame_stage_up(m355_ctx* c, Frame* f, int cidx, const void* src, size_t src_pitch)
+{
+  const size_t rb = (size_t)f->pw[cidx] * f->bpp[cidx];
+  int rc = stage_reserve(c, rb * f->ph[cidx]);
+  if (rc) return rc;
+  if (src_pitch == rb) memcpy(c->stage, src, rb * f->ph[cidx]);
+  else for (int y = 0; y < f->ph[cidx]; y++) memcpy((uint8_t*)c->stage + (size_t)y * rb, (const uint8_t*)src + (size_t)y * src_pitch, rb);
+  HIPCHK(hipMemcpy2DAsync(f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx], c->stage, rb, rb, f->ph[cidx], hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return M355_OK;
+}
 int m355_frame_upload(m355_ctx* c, int h, int cidx, const void* src, ptrdiff_t stride)
 {
   Frame* f = get_frame(c, h);
   if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-  HIPCHK(hipMemcpy2D(f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx], src, (size_t)stride * f->bpp[cidx],
-                     (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyHostToDevice));
-  return M355_OK;
+  return frame_stage_up(c, f, cidx, src, (size_t)stride * f->bpp[cidx]);
 }
 int m355_frame_download(m355_ctx* c, int h, int cidx, void* dst, ptrdiff_t stride)
 {
@@ -337,9 +374,7 @@ int m355_frame_download(m355_ctx* c, int h, int cidx, void* dst, ptrdiff_t strid
   if (!f || cidx < 0 || cidx > 2 || !f->pw[cidx]) return fail(M355_ERR_INVALID, "bad frame/plane");
   hipSetDevice(c->device);
   HIPCHK(sync_all(c));
-  HIPCHK(hipMemcpy2D(dst, (size_t)stride * f->bpp[cidx], f->plane[cidx], (size_t)f->stride[cidx] * f->bpp[cidx],
-                     (size_t)f->pw[cidx] * f->bpp[cidx], f->ph[cidx], hipMemcpyDeviceToHost));
-  return M355_OK;
+  return frame_stage_down(c, f, cidx, dst, (size_t)stride * f->bpp[cidx]);
 }
 /* The download of a whole frame, asynchronous: the copies run on the context's own copy stream, behind the frame's last writer and
  * beside the decodes of later pictures; the next picture written into the frame waits for them.  dst planes should be pinned
@@ -401,8 +436,11 @@ int m355_frame_fill(m355_ctx* c, int h, int vl, int vc)
     const int v = cc ? vc : vl;
     if (f->bpp[cc] == 1) { HIPCHK(hipMemsetAsync(f->plane[cc], v, n, c->stream)); HIPCHK(sync_all(c)); }
     else {
-      std::vector<uint16_t> tmp(n, (uint16_t)v);
-      HIPCHK(hipMemcpy(f->plane[cc], tmp.data(), n * 2, hipMemcpyHostToDevice));
+      int rc = stage_reserve(c, n * 2);
+      if (rc) return rc;
+      std::fill((uint16_t*)c->stage, (uint16_t*)c->stage + n, (uint16_t)v);
+      HIPCHK(hipMemcpyAsync(f->plane[cc], c->stage, n * 2, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
     }
   }
   return M355_OK;
@@ -467,7 +505,7 @@ int m355_frame_hash(m355_ctx* c, int h, int type, m355_picture_hash* out)
     for (int cc = 0; cc < np; cc++) {
       const size_t rb = (size_t)f->pw[cc] * f->bpp[cc];
       host[cc].resize(rb * f->ph[cc]);
-      HIPCHK(hipMemcpy2D(host[cc].data(), rb, f->plane[cc], (size_t)f->stride[cc] * f->bpp[cc], rb, f->ph[cc], hipMemcpyDeviceToHost));
+      { int rc = frame_stage_down(c, f, cc, host[cc].data(), rb); if (rc) { for (auto& t : th) t.join(); return rc; } }
       th.emplace_back([&, cc, rb] { m355_md5_rows(host[cc].data(), rb, (int)rb, f->ph[cc], out->md5[cc]); });
     }
     for (auto& t : th) t.join();

@@ -251,6 +251,9 @@ struct m355_ctx {
   bool timed = false;
   bool timing_on = false;      /* between m355_timing_reset and m355_timing_collect: decodes record their seven stage events */
   uint32_t* hash_acc = nullptr; /* m355_frame_hash accumulators */
+  /* pinned staging buffer of the blocking frame transfers (m355_frame_upload / _download / _fill, MD5 of m355_frame_hash): the copy itself is queued on the
+     stream that last wrote the frame, between pinned memory and the frame (frame_stage_* in runtime.hip) */
+  void* stage = nullptr; size_t stage_bytes = 0;
   /* m355_decode_batch: ring of picture-record arrays (pinned staging + device copy + the batch's ticket word); a slot's event is
      recorded behind the batch's k_intra — what the pictures' filter stages wait for, and what guards the slot's reuse */
   struct BatchSlot { DevPic* host = nullptr; DevPic* dev = nullptr; uint32_t* ticket = nullptr; hipEvent_t ev = nullptr; bool pending = false; };

@@ -41,10 +41,15 @@ if __name__ == "__main__":
         out = "/tmp/diag_s%d.h265" % seed
         subprocess.run([S.STREAMGEN, out] + [str(c[x]) for x in ("w", "h", "bd", "tc", "tr", "frames", "seed", "intra_pct", "b_frames", "sao", "features", "chroma", "slices", "geom")], capture_output=True)
         data = open(out, "rb").read()
+        if os.environ.get("SOAK_DAMAGE"):                   # (the damage tools/soak_streams.py applies to this seed)
+            import random
+            import test_streams
+            rr = random.Random(123457 + seed)
+            data = test_streams.flip_bits(data, seed) if rr.random() < 0.6 else test_streams.drop_pictures(data, {rr.randrange(0, c["frames"]) for _ in range(rr.randrange(1, 3))})
         want = []
         de265_py.decode_stream(ref, data, threads=0, scalar=True, planes_out=want)
         print("seed %d %s" % (seed, c))
-        for th in [c["threads"]] * reps + [0]:
+        for th in ([c["threads"]] * reps if not os.environ.get("SOAK_DAMAGE") else []) + [0]:
             got = []
             try:
                 de265_py.decode_stream(glue, data, threads=th, planes_out=got)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak of the product library on the GPU against the CPU oracle (the checker) on random pictures BEYOND the test suite's 200 seeds: geometry, bit depth, chroma format,
 CTB size, tiling, slicing, block mix and the optional coding tools drawn at random (tests/test_gpu_random.py random_case), one picture at a time and four decodes of the
-resident lists with three in flight.  python tools/soak_gpu.py <first seed> <count> [processes]  ->  one line per process + a total; exit code 1 on any difference."""
+resident lists with three in flight.  python tools/soak_gpu.py <first seed> <count> [processes]  ->  one line per process + a total; exit code 1 on any difference.
+SOAK_SCALE=<n> multiplies every picture's width and height by n (random_case draws up to 640 x 360): the launch orders the runtime picks by SIZE — the zero fill inside
+k_job_count from 16 384 prediction blocks, the two-stream lanes above 16 Mi samples — are then drawn too (n = 8: up to 5120 x 2880; n = 12: up to 7680 x 4320)."""
 import ctypes
 import multiprocessing as mp
 import os
@@ -26,6 +28,9 @@ def work(args):
     bad = []
     for seed in range(first + k, first + count, n):
         case = random_case(seed)
+        scale = int(os.environ.get("SOAK_SCALE", "1"))
+        if scale > 1:
+            case["width"] *= scale; case["height"] *= scale
         try:
             pic, refs = make_case(**case)
         except RuntimeError:
@@ -39,6 +44,13 @@ def work(args):
             assert_planes_equal(device_decode(ctx, pic, refs, resident=True, repeat=4), want, "seed %d depth 3" % seed)
         except AssertionError as e:
             bad.append((seed, str(e)[:200]))
+        except Exception as e:                              # noqa: BLE001  (an error of the library: reported, the context is made anew)
+            bad.append((seed, "exception %s: %s %r" % (type(e).__name__, str(e)[:200], case)))
+            try:
+                ctx.close()
+            except Exception:                               # noqa: BLE001
+                pass
+            ctx = capi.Context(lib, 0)
         done += 1
     ctx.close()
     return done, skipped, bad

@@ -37,8 +37,9 @@ def draw(seed):
     for bit, pr in ((G_MINCB16, .2), (G_NOTILEFILTER, .3), (G_PARMERGE, .3), (G_TB16, .2), (G_CONFWIN, .2)):
         if r.random() < pr and not (bit == G_MINCB16 and ctb == 16):
             geom |= bit
-    w = r.randrange(3, 14) * 64
-    h = r.randrange(2, 9) * 64
+    big = int(os.environ.get("SOAK_BIG", "0"))            # SOAK_BIG=<n>: widths and heights n times as large (n = 4: up to 3328 x 2048)
+    w = r.randrange(3, 14) * 64 * max(1, big)
+    h = r.randrange(2, 9) * 64 * max(1, big)
     if geom & G_CONFWIN:
         h += 0
     bd = r.choice([8, 8, 10, 10, 9, 12])
@@ -62,6 +63,8 @@ def draw(seed):
     if chroma in (2, 3, 0) and bd != 8 or chroma in (2, 3):
         feat |= F_REXT
     frames = r.choice([9, 17]) if ra else r.randrange(2, 7)
+    if big:
+        frames = 9 if ra else min(frames, 3)
     slices = r.choice([1, 1, 2, 3])
     # the writer's own rules (oracle/ref_streamgen.cc main): the reference picture set and the collocated picture are per picture (one slice), WPP means one slice and
     # no tiles, the hidden sign is written outside the range extensions only
@@ -94,6 +97,22 @@ def work(args):
             continue
         data = open(out, "rb").read()
         os.unlink(out)
+        if os.environ.get("SOAK_DAMAGE"):
+            # SOAK_DAMAGE=1: the stream with bits flipped inside slice data / with pictures removed (tests/test_streams.py flip_bits, drop_pictures), decoded
+            # single-threaded by both: the backend must show what the reference shows — the same samples, the same number of pictures, the same warnings
+            import test_streams
+            rr = random.Random(123457 + seed)
+            data = test_streams.flip_bits(data, seed) if rr.random() < 0.6 else test_streams.drop_pictures(data, {rr.randrange(0, c["frames"]) for _ in range(rr.randrange(1, 3))})
+            try:
+                want = de265_py.decode_stream(ref, data, threads=0, scalar=True)
+                got = de265_py.decode_stream(glue, data, threads=0)
+                ok = got[:2] == want[:2] and set(got[2]) - {1000} == set(want[2]) - {1000} and glue.m355_glue_cpu_pixel_calls() == 0
+            except Exception as e:                         # noqa: BLE001
+                ok, want, got = False, ("exception",), ("exception", str(e)[:100])
+            if not ok:
+                bad.append((seed, c, want, got))
+            done += 1
+            continue
         try:
             want = de265_py.decode_stream(ref, data, threads=0, scalar=True)
         except Exception as e:                             # noqa: BLE001
