@@ -401,7 +401,9 @@ M355_API void m355_destroy(m355_ctx* ctx);
 M355_API int m355_frame_create(m355_ctx* ctx, int width, int height, int chroma_format_idc,
                                int bit_depth_luma, int bit_depth_chroma);
 M355_API int m355_frame_destroy(m355_ctx* ctx, int frame);
-/* stride in SAMPLES, as everywhere in the reference (acceleration.h: "Strides are in samples") */
+/* stride in SAMPLES, as everywhere in the reference (acceleration.h: "Strides are in samples").  Both calls block until the plane has arrived; src / dst may be
+ * any host memory: the library stages the plane in a pinned buffer of the context and queues the copy on one of its own streams (the frame's last writer's for a
+ * download) — a blocking hipMemcpy2D on pageable memory was measured to deliver stale rows when many processes share the GPU. */
 M355_API int m355_frame_upload(m355_ctx* ctx, int frame, int cidx, const void* src, ptrdiff_t stride);
 M355_API int m355_frame_download(m355_ctx* ctx, int frame, int cidx, void* dst, ptrdiff_t stride);
 /* The same for all planes of the frame, asynchronous (picture output, de265_get_next_picture / de265_get_image_plane: image.h's planes

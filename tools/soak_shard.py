@@ -29,6 +29,8 @@ def work(args):
     bad = []
     for seed in range(first + k, first + count, n):
         case = random_case(seed)
+        scale = int(os.environ.get("SOAK_SCALE", "1"))     # (as in tools/soak_gpu.py: every picture's width and height times n)
+        case["width"] *= scale; case["height"] *= scale
         rng = np.random.default_rng(31000 + seed)
         ctbs_x, ctbs_y = -(-case["width"] >> case["log2_ctb"]), -(-case["height"] >> case["log2_ctb"])
         tc, tr = int(rng.integers(1, min(4, ctbs_x) + 1)), int(rng.integers(1, min(3, ctbs_y) + 1))
