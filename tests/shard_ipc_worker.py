@@ -22,7 +22,11 @@ def run_rank(lib, oracle_cdll, rank, nranks, name, cases, depth=3, rounds=2, dev
         dec = shard.ShardedDecoder(ctx, rank, nranks, ipc_name=name)
         ctx.set_pipeline_depth(depth)
         n_checked = 0
-        for case in cases:
+        diag = os.environ.get("M355_IPC_DIAG_DIR")           # (tools/soak_ipc.py: a line per picture — open file descriptors, what is being decoded — in <dir>/<name>_r<rank>.log)
+        for ci, case in enumerate(cases):
+            if diag:
+                with open(os.path.join(diag, "%s_r%d.log" % (name, rank)), "a") as df:
+                    df.write("case %d of %d: %d fds open, %r\n" % (ci, len(cases), len(os.listdir("/proc/self/fd")), case))
             pic, refs = make_case(**case)
             want = oracle_decode(o, pic, refs)
             pp = pic.pp[0]
@@ -64,6 +68,9 @@ def main():
     cases = json.loads(sys.argv[5])
     depth = int(sys.argv[6]) if len(sys.argv) > 6 else 3
     res = {"rank": rank, "ok": False}
+    if os.environ.get("M355_IPC_DIAG_DIR"):
+        import faulthandler
+        faulthandler.dump_traceback_later(240, repeat=False, file=open(os.path.join(os.environ["M355_IPC_DIAG_DIR"], "%s_r%d.stack" % (name, rank)), "w"))
     try:
         from libde265_amd import capi
         lib = capi.Library()
