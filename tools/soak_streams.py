@@ -113,6 +113,29 @@ def work(args):
                 bad.append((seed, c, want, got))
             done += 1
             continue
+        if os.environ.get("SOAK_APP"):
+            # SOAK_APP=1: the stream driven the ways applications drive a decoder (tests/test_glue_app_patterns.py): pushed in pieces of 1 byte .. 20 KB between decode
+            # calls (pictures taken with get or with peek / release), NAL unit by NAL unit, or with a de265_reset somewhere in the middle followed by the stream from its
+            # start — the reference single-threaded, the backend with the drawn thread count, the same calls in the same order
+            import test_glue_app_patterns as ap
+            rr = random.Random(424243 + seed)
+            kind = rr.choice(["pieces", "pieces", "nal", "reset"])
+            try:
+                if kind == "pieces":
+                    sd, peek = rr.randrange(1 << 20), rr.random() < 0.5
+                    want, got = ap.chunked(ref, data, sd, peek, 0), ap.chunked(glue, data, sd, peek, c["threads"])
+                elif kind == "nal":
+                    want, got = ap.by_nal(ref, data, 0), ap.by_nal(glue, data, c["threads"])
+                else:
+                    cut = rr.randrange(1, len(data))
+                    want, got = ap.with_reset(ref, data, cut, 0), ap.with_reset(glue, data, cut, c["threads"])
+                ok = want[1] > 0 and got[:2] == want[:2] and glue.m355_glue_cpu_pixel_calls() == 0
+            except Exception as e:                         # noqa: BLE001
+                ok, want, got = False, ("exception",), (kind, str(e)[:100])
+            if not ok:
+                bad.append((seed, kind, c, want, got))
+            done += 1
+            continue
         try:
             want = de265_py.decode_stream(ref, data, threads=0, scalar=True)
         except Exception as e:                             # noqa: BLE001
