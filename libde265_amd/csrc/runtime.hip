@@ -76,6 +76,10 @@ int lane_class_priority(int index) {
 }
 int lane_priorities_mode() { return 2; }              /* 0 off, 1 every stream, 2 intra pictures only (what the measurements of round 3 left: profiles/r03_v_*) */
 static int lane_priority(int index) { return lane_priorities_mode() == 1 ? lane_class_priority(index) : 0; }
+/* (the ORDER in which the streams are created is load-bearing: the runtime deals its streams round its four hardware queues in creation order, kernels of streams
+   that share a queue run one after the other, and which lanes share decides how three pictures' stages interleave — main, side, main, side, main, side (lanes 0 and 2 on
+   one pair of queues, lane 1 on the other) is the second best of the 187 ways of dealing six streams to four queues, 1 % behind the best and up to 37 % ahead of the
+   others at C5: tools/qmap_search.py, profiles/r06_v49_lane_stream_queue_mapping.txt) */
 static int lane_create(m355_ctx* c, Lane& l, int index)
 {
   HIPCHK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, lane_priority(index)));
