@@ -357,7 +357,21 @@ __device__ __forceinline__ void k_sao_body(const DevPic& p, const int c, const i
   }
 }
 
-template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p) { k_sao_body<PIX, PACKED>(p, (int)blockIdx.z, (int)blockIdx.x, (int)blockIdx.y); }
+/* A 1-D grid whose blocks are dealt to the XCDs in runs of SAO_XCD_ROWS whole block ROWS (block b runs on XCD b % 8): the 256-sample blocks of a row — and the rows of a
+   run — share one L2, so a row's rim lines (the 128-byte line left and right of every block, the rows above and below a run) are fetched from the fabric once instead of once
+   per neighbour: a third less fabric fetch for this kernel, its time unchanged (profiles/r04_af_*, r06_v52_*).  Rows = luma rows, then the Cb rows, then the Cr rows (chroma
+   rows are narrower: their surplus blocks leave at once). */
+#define SAO_XCD_ROWS 2
+template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao(DevPic p, int gx, int gy0, int gy1)
+{
+  constexpr int RP = SAO_XCD_ROWS;
+  const int b = (int)blockIdx.x, xcd = b & 7, i = b >> 3;
+  const int x = i % gx, rr = i / gx;
+  const int R = (rr / RP) * (8 * RP) + xcd * RP + rr % RP;
+  if (R >= gy0 + 2 * gy1) return;
+  const int c = R < gy0 ? 0 : (R < gy0 + gy1 ? 1 : 2), y = R - (c == 0 ? 0 : (c == 1 ? gy0 : gy0 + gy1));
+  k_sao_body<PIX, PACKED>(p, c, x, y);
+}
 /* batch form: grid.z = 3 * picture + component */
 template <class PIX, bool PACKED> __global__ void __launch_bounds__(256) k_sao_batch(DevBatch b)
 {
@@ -385,10 +399,12 @@ void m355_launch_sao_batch(const HostBatch& b, bool hbd, hipStream_t st)
 
 void m355_launch_sao(const DevPic& p, bool hbd, hipStream_t st)
 {
-  /* one launch for all components: grid.z = component; chroma blocks beyond the chroma plane exit at once */
+  /* one launch for all components (k_sao: block rows dealt to the XCDs); chroma blocks beyond the chroma plane exit at once */
   const int nc = p.pp.chroma_format_idc ? 3 : 1;
-  const dim3 grid((p.pw[0] + 255) / 256, (p.ph[0] + 15) / 16, nc), block(256);   /* 4 waves side by side: 256 x 16 samples */
-  if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p);
-  else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p);
+  const int gx = (p.pw[0] + 255) / 256, gy0 = (p.ph[0] + 15) / 16, gy1 = nc == 3 ? (p.ph[1] + 15) / 16 : 0;     /* 4 waves side by side: 256 x 16 samples */
+  const int rows = gy0 + 2 * gy1, rows_pad = (rows + 8 * SAO_XCD_ROWS - 1) / (8 * SAO_XCD_ROWS) * (8 * SAO_XCD_ROWS);
+  const dim3 grid((unsigned)(gx * rows_pad)), block(256);
+  if (!hbd) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint8_t, true>), grid, block, 0, st, p, gx, gy0, gy1);
+  else if (p.pp.bit_depth_luma <= 15 && p.pp.bit_depth_chroma <= 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, true>), grid, block, 0, st, p, gx, gy0, gy1);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sao<uint16_t, false>), grid, block, 0, st, p, gx, gy0, gy1);
 }
